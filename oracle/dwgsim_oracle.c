@@ -1,0 +1,1074 @@
+/*
+ * oracle/dwgsim_oracle.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A from-scratch, single-threaded, plain-C CPU restatement of the hot path of
+ * nh13/DWGSIM (reference at /root/reference, v0.1.17-dev):
+ *     src/mut.c     mutation walk, left-justification, mutations.txt / .vcf
+ *     src/dwgsim.c  dwgsim_core(): contig scheduling + the per-read-pair loop
+ *     src/dwgsim_opt.c  option surface, seeding, error-ramp slope
+ * Every function below cites the reference file:line it restates.  Nothing here is
+ * linked, imported or executed by the product (dwgsim_amd/, the C-ABI library, the
+ * dwgsim-hip CLI).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may use it, and only as the checker.
+ *
+ * Two RNG providers behind one call-site interface rng_u(domain,index,attempt,retry,slot):
+ *   MODE A ("drand48"): the reference's sequential glibc drand48 stream
+ *       X <- (0x5DEECE66D * X + 0xB) mod 2^48, value X * 2^-48, X0 = (seed << 16) | 0x330E
+ *       (dwgsim_opt.c:385-394).  The keys are ignored; draws happen in exactly the
+ *       order the reference makes them; the Box-Muller cache is global (dwgsim.c:158-159).
+ *       PINNED: byte-identical to the unmodified reference (oracle/_ref/dwgsim) on the
+ *       reference's own goldens (testdata/ex1.test.*) and on golden sets G1..G5
+ *       (tests/golden/MANIFEST.json; tests/test_oracle_golden.py).
+ *   MODE B ("philox"): Philox4x32-10 keyed by (seed, contig) with counter
+ *       (index, retry, domain|attempt, block): every random decision has a fixed slot, so
+ *       any read-index range is reproducible in any order.  Same code path as mode A; only
+ *       the source of each uniform and the scope of the Box-Muller cache (per normal
+ *       stream instead of global) differ.  This is what the HIP kernels must match
+ *       bit-for-bit.
+ *
+ * The representation is this file's own: one byte per base per haplotype
+ * (bits 0-3 base code, bits 4-5 mutation type, as the low byte of the reference's mut_t,
+ * mut.h:25-30) plus a position-sorted insertion table per haplotype.  The reference's
+ * short (<=26) / long insertion encodings (mut.c:282-377) carry the same sequence
+ * P[0..n-1] (P[t] = draw[n-1-t]); see ins_* below.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <ctype.h>
+#include <time.h>
+#include <unistd.h>
+#include <limits.h>
+#include <stdarg.h>
+
+/* ------------------------------------------------------------------------------------------
+ * RNG providers
+ * ---------------------------------------------------------------------------------------- */
+enum { RNG_DRAND48 = 0, RNG_PHILOX = 1 };
+
+/* mode-B domains (c2 = domain << 24 | attempt) */
+enum {
+    D_WALK = 1,        /* index = position; slots 0..5 (see walk_contig) */
+    D_WALK_INSLEN = 2, /* index = position; slot k = k-th length-extension test */
+    D_WALK_INSBASE = 3,/* index = position; slot k = k-th inserted-base draw */
+    D_PAIR = 4,        /* index = ii; slot 0 rand-read test, 1 haplotype, 2 strand */
+    D_PLACE = 5,       /* index = ii; slot t = position uniform of placement try t */
+    D_PLACE_NORM = 6,  /* index = ii; block t = polar tries of placement try t */
+    D_BASE0 = 8,       /* +j; index = ii; block i: slot 2i error test / random base, 2i+1 substitution */
+    D_QUAL0 = 10,      /* +j; index = ii; block p = polar tries giving normals 2p (v2) and 2p+1 (v1) */
+    D_FLOW0 = 12,      /* +j; index = ii; slot = running draw count inside generate_errors_flows */
+    D_CALIB = 14       /* -B calibration (dwgsim_opt.c:415-457); index = read number */
+};
+
+typedef struct {
+    int mode;
+    uint64_t x;            /* drand48 state (48 bits) */
+    uint32_t k0, k1;       /* philox key: (uint32)seed, contig index */
+    int iset; double gset; /* mode A: the reference's static Box-Muller cache (dwgsim.c:158-159) */
+    int use_libm_log;      /* ran_normal uses libm log() instead of det_log() */
+    uint64_t n_draws;      /* number of uniforms consumed (both modes) */
+    uint64_t n_log_mismatch; /* mode diagnostics: det_log(x) != log(x) bitwise */
+} rng_t;
+
+/* Philox4x32-10, Salmon et al. SC'11 (Random123).  SURVEY.md App. E.2 known answers are
+ * checked in tests/test_oracle_units.py. */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* the mode-B uniform: 53 bits from two words, exact in fp64 */
+static inline double u53(uint32_t hi, uint32_t lo)
+{
+    return (double)(((uint64_t)hi << 21) | (uint64_t)(lo >> 11)) * 0x1p-53;
+}
+
+double oracle_philox_uniform(uint32_t seed, uint32_t contig, uint32_t domain, uint64_t index,
+                             uint32_t attempt, uint32_t retry, uint32_t slot)
+{
+    uint32_t ctr[4], key[2], w[4];
+    ctr[0] = (uint32_t)index;
+    ctr[1] = (uint32_t)((index >> 32) & 0xFFFFu) | (retry << 16);
+    ctr[2] = (domain << 24) | (attempt & 0xFFFFFFu);
+    ctr[3] = slot >> 1;
+    key[0] = seed; key[1] = contig;
+    oracle_philox4x32_10(ctr, key, w);
+    return (slot & 1) ? u53(w[2], w[3]) : u53(w[0], w[1]);
+}
+
+/* glibc drand48 */
+double oracle_drand48_next(uint64_t *x)
+{
+    *x = (0x5DEECE66DULL * (*x) + 0xBULL) & 0xFFFFFFFFFFFFULL;
+    return (double)(*x) * 0x1p-48;
+}
+
+static void rng_seed(rng_t *r, int mode, int32_t seed)
+{
+    memset(r, 0, sizeof(*r));
+    r->mode = mode;
+    /* dwgsim_opt.c:388-393: xseed = {0x330e, seed & 0xffff, (seed >> 16) & 0xffff} */
+    long sv = seed;
+    r->x = ((uint64_t)((sv >> 16) & 0xffff) << 32) | ((uint64_t)(sv & 0xffff) << 16) | 0x330eULL;
+    r->k0 = (uint32_t)seed;
+    r->k1 = 0;
+}
+
+static inline double rng_u(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t retry, uint32_t slot)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
+    return oracle_philox_uniform(r->k0, r->k1, dom, idx, att, retry, slot);
+}
+
+/* Deterministic natural log for x > 0 finite: the classic fdlibm/FreeBSD-msun e_log.c
+ * algorithm (argument reduction x = 2^k (1+f), s = f/(2+f), degree-14 even polynomial in s)
+ * restated with only IEEE + - * / in fp64, so gcc/x86-64 and hipcc/gfx950 (both compiled
+ * with -ffp-contract=off) give identical bits.  The algorithm and its coefficients are from
+ * "e_log.c (c) 1993 Sun Microsystems, Inc. -- Permission to use, copy, modify, and distribute
+ * this software is freely granted, provided that this notice is preserved."  < 1 ulp. */
+double oracle_det_log(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+    uint64_t b; int32_t hx, k = 0, i, j;
+    memcpy(&b, &x, 8);
+    hx = (int32_t)(b >> 32);
+    if (hx < 0x00100000) { /* subnormal: scale up */
+        x *= 0x1p54; k -= 54;
+        memcpy(&b, &x, 8); hx = (int32_t)(b >> 32);
+    }
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    i = (hx + 0x95f64) & 0x100000;
+    b = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (b & 0xFFFFFFFFu);
+    memcpy(&x, &b, 8);              /* x in [sqrt(2)/2, sqrt(2)) */
+    k += (i >> 20);
+    double f = x - 1.0, dk = (double)k;
+    double s = f / (2.0 + f);
+    double z = s * s, w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    i = hx - 0x6147a; j = 0x6b851 - hx; i |= j;
+    if (i > 0) {
+        double hfsq = 0.5 * f * f;
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+/* A stream of normals.  Mode A ignores it (global cache + sequential draws).  Mode B: polar
+ * tries r = 0,1,.. of block p; the accepted try gives normal 2p (= v2*fac) and, if `cache`,
+ * normal 2p+1 (= v1*fac); p advances after every accepted try. */
+typedef struct { uint32_t dom; uint64_t idx; uint32_t att; uint32_t p; int cache; int has; double g; } nstream_t;
+
+/* dwgsim.c:156-175 ran_normal(): Marsaglia polar method */
+static double ran_normal(rng_t *r, nstream_t *ns)
+{
+    int *iset = (r->mode == RNG_DRAND48) ? &r->iset : &ns->has;
+    double *gset = (r->mode == RNG_DRAND48) ? &r->gset : &ns->g;
+    if (*iset == 0) {
+        double v1, v2, rsq, fac, lg;
+        uint32_t retry = 0;
+        do {
+            v1 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p) - 1.0;
+            v2 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p + 1) - 1.0;
+            rsq = v1 * v1 + v2 * v2;
+            retry++;
+        } while (rsq >= 1.0 || rsq == 0.0);
+        lg = oracle_det_log(rsq);
+        { double l2 = log(rsq); if (memcmp(&l2, &lg, 8) != 0) r->n_log_mismatch++; if (r->use_libm_log) lg = l2; }
+        fac = sqrt(-2.0 * lg / rsq);
+        *gset = v1 * fac;
+        *iset = (r->mode == RNG_DRAND48) ? 1 : ns->cache;
+        ns->p++;
+        return v2 * fac;
+    }
+    *iset = 0;
+    return *gset;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Options (dwgsim_opt.h:21-60, dwgsim_opt.c)
+ * ---------------------------------------------------------------------------------------- */
+enum { ILLUMINA = 0, SOLID = 1, IONTORRENT = 2 };
+typedef struct { double start, by, end; } erate_t;
+typedef struct {
+    erate_t e[2];
+    int is_inner, dist; double std_dev;
+    int64_t N; double C;
+    int length[2];
+    double mut_rate, mut_freq, indel_frac, indel_extend; int indel_min;
+    double rand_read; int max_n, data_type, strandedness, read_one_strand;
+    int8_t *flow_order; int flow_order_len, use_base_error, is_hap;
+    int32_t seed;
+    char *fixed_quality; double quality_std;
+    char *read_prefix; int reads_output_type, output_type, amplicons;
+    /* oracle-only switches */
+    int rng_mode, use_libm_log, null_fastq, verbose;
+} opt_t;
+
+static void opt_defaults(opt_t *o) /* dwgsim_opt.c:40-80 */
+{
+    memset(o, 0, sizeof(*o));
+    o->e[0].start = o->e[0].end = o->e[1].start = o->e[1].end = 0.02;
+    o->dist = 500; o->std_dev = 50; o->N = -1; o->C = 100;
+    o->length[0] = o->length[1] = 70;
+    o->mut_rate = 0.001; o->mut_freq = 0.5; o->indel_frac = 0.1; o->indel_extend = 0.3; o->indel_min = 1;
+    o->rand_read = 0.05; o->seed = -1; o->quality_std = 2.0;
+}
+
+static uint8_t nt4(int ch) /* dwgsim.c:56-73 nst_nt4_table */
+{
+    switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    case '-': return 5;
+    default: return 4;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FASTA (mut.c:49-87 seq_read_fasta): name = first token after '>', sequence keeps
+ * isalpha / '-' / '.'.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int64_t l, m; uint8_t *s; } seq_t;
+
+static int64_t fasta_next(FILE *fp, seq_t *seq, char *name)
+{
+    int c = 0; char *p = name;
+    while (!feof(fp) && fgetc(fp) != '>');
+    if (feof(fp)) return -1;
+    while (!feof(fp) && (c = fgetc(fp)) != ' ' && c != '\t' && c != '\n')
+        if (c != '\r') *p++ = (char)c;
+    *p = 0;
+    if (c != '\n') while (!feof(fp) && fgetc(fp) != '\n');
+    int64_t l = 0;
+    while (!feof(fp) && (c = fgetc(fp)) != '>') {
+        if (isalpha(c) || c == '-' || c == '.') {
+            if (l + 1 >= seq->m) { seq->m = seq->m ? seq->m * 2 : 1 << 16; seq->s = realloc(seq->s, (size_t)seq->m); }
+            seq->s[l++] = (uint8_t)c;
+        }
+    }
+    if (c == '>') ungetc(c, fp);
+    if (!seq->s) { seq->m = 16; seq->s = malloc(16); }
+    seq->s[l] = 0; seq->l = l;
+    return l;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Mutated haplotypes
+ * ---------------------------------------------------------------------------------------- */
+#define T_NONE 0x00
+#define T_INS  0x10
+#define T_SUB  0x20
+#define T_DEL  0x30
+#define TMASK  0x30
+#define BT_MASK 0x3f   /* mut_and_type_mask, mut.c:103 */
+
+typedef struct { int64_t pos; uint32_t n; uint8_t *b; } ins_t;   /* b[t] = P[t], printed order */
+typedef struct { int64_t l; uint8_t *c; ins_t *ins; int n_ins, m_ins; } hap_t;
+
+static void hap_free(hap_t *h) { for (int i = 0; i < h->n_ins; ++i) free(h->ins[i].b); free(h->ins); free(h->c); memset(h, 0, sizeof(*h)); }
+
+static ins_t *ins_find(hap_t *h, int64_t pos)
+{
+    int lo = 0, hi = h->n_ins - 1;
+    while (lo <= hi) { int mid = (lo + hi) >> 1; if (h->ins[mid].pos == pos) return &h->ins[mid]; if (h->ins[mid].pos < pos) lo = mid + 1; else hi = mid - 1; }
+    fprintf(stderr, "oracle: insertion lookup failed at %lld\n", (long long)pos); exit(2);
+}
+
+static void ins_push(hap_t *h, int64_t pos, uint32_t n, const uint8_t *P)
+{
+    if (h->n_ins == h->m_ins) { h->m_ins = h->m_ins ? h->m_ins * 2 : 16; h->ins = realloc(h->ins, sizeof(ins_t) * (size_t)h->m_ins); }
+    ins_t *e = &h->ins[h->n_ins++];
+    e->pos = pos; e->n = n; e->b = malloc(n ? n : 1); memcpy(e->b, P, n);
+}
+
+/* mut.c:282-377 mut_add_ins(), random-bases branch (bases == NULL, num_ins == 0, hap < 0) */
+static void walk_add_ins(const opt_t *o, rng_t *r, hap_t *h0, hap_t *h1, int64_t i, uint8_t c)
+{
+    uint64_t num = 0; uint32_t k = 0; int hap;
+    do { num++; } while (num < UINT32_MAX && (num < (uint64_t)o->indel_min || rng_u(r, D_WALK_INSLEN, (uint64_t)i, 0, 0, k++) < o->indel_extend));
+    if (o->is_hap || rng_u(r, D_WALK, (uint64_t)i, 0, 0, 4) < 0.333333) hap = 3;
+    else if (rng_u(r, D_WALK, (uint64_t)i, 0, 0, 5) < 0.5) hap = 1;
+    else hap = 2;
+    uint8_t *P = malloc((size_t)num);
+    for (uint64_t j = 0; j < num; ++j) /* draw j lands at printed index num-1-j (mut.c:313-315 / :347-365 with :249-279) */
+        P[num - 1 - j] = (uint8_t)(uint64_t)(rng_u(r, D_WALK_INSBASE, (uint64_t)i, 0, 0, (uint32_t)j) * 4.0);
+    if (hap & 1) { h0->c[i] = T_INS | c; ins_push(h0, i, (uint32_t)num, P); }
+    if (hap & 2) { h1->c[i] = T_INS | c; ins_push(h1, i, (uint32_t)num, P); }
+    free(P);
+}
+
+/* mut.c:606-643 mut_diref(), random branch.  Mode-B slots at position i (domain D_WALK):
+ * 0 deletion-extend test, 1 mutate test, 2 substitution-vs-indel, 3 substituted base / deletion-vs-insertion,
+ * 4 hom test, 5 het haplotype. */
+static void walk_contig(const opt_t *o, rng_t *r, const seq_t *seq, hap_t *h0, hap_t *h1)
+{
+    int deleting = 0; int64_t dlen = 0;
+    hap_t *h[2] = { h0, h1 };
+    for (int x = 0; x < 2; ++x) { h[x]->l = seq->l; h[x]->c = calloc((size_t)seq->l + 1, 1); h[x]->ins = NULL; h[x]->n_ins = h[x]->m_ins = 0; }
+    for (int64_t i = 0; i < seq->l; ++i) {
+        uint8_t c = nt4(seq->s[i]);
+        h0->c[i] = h1->c[i] = c;
+        if (deleting) {
+            if (dlen < o->indel_min || rng_u(r, D_WALK, (uint64_t)i, 0, 0, 0) < o->indel_extend) {
+                if (deleting & 1) h0->c[i] |= T_DEL | c;
+                if (deleting & 2) h1->c[i] |= T_DEL | c;
+                dlen++;
+                continue;
+            }
+            deleting = 0; dlen = 0;
+        }
+        if (c < 4 && rng_u(r, D_WALK, (uint64_t)i, 0, 0, 1) < o->mut_rate) {
+            if (rng_u(r, D_WALK, (uint64_t)i, 0, 0, 2) >= o->indel_frac) { /* substitution */
+                double rr = rng_u(r, D_WALK, (uint64_t)i, 0, 0, 3);
+                uint8_t c2 = (uint8_t)((c + (uint64_t)(rr * 3.0 + 1)) & 3);
+                if (o->is_hap || rng_u(r, D_WALK, (uint64_t)i, 0, 0, 4) < 0.333333) h0->c[i] = h1->c[i] = T_SUB | c2;
+                else h[rng_u(r, D_WALK, (uint64_t)i, 0, 0, 5) < 0.5 ? 0 : 1]->c[i] = T_SUB | c2;
+            } else if (rng_u(r, D_WALK, (uint64_t)i, 0, 0, 3) < 0.5) { /* deletion */
+                if (o->is_hap || rng_u(r, D_WALK, (uint64_t)i, 0, 0, 4) < 0.3333333) { h0->c[i] = h1->c[i] = T_DEL | c; deleting = 3; }
+                else { deleting = rng_u(r, D_WALK, (uint64_t)i, 0, 0, 5) < 0.5 ? 1 : 2; h[deleting - 1]->c[i] = T_DEL | c; }
+                dlen = 1;
+            } else walk_add_ins(o, r, h0, h1, i, c);
+        }
+    }
+}
+
+/* mut.c:427-478 mut_left_justify_ins(): while the cell to the left is unmutated and its base
+ * (low 2 bits -- N aliases to A) equals the LAST inserted base, rotate the
+ * insertion one base to the left. */
+static void justify_ins(hap_t *h, int64_t i)
+{
+    ins_t *e = ins_find(h, i);
+    int64_t j = i;
+    while (j > 0 && (h->c[j - 1] & TMASK) == T_NONE && e->b[e->n - 1] == (h->c[j - 1] & 3)) {
+        memmove(e->b + 1, e->b, e->n - 1);
+        e->b[0] = h->c[j - 1] & 3;
+        h->c[j] = h->c[j] & 3;
+        j--;
+    }
+    h->c[j] = T_INS | (h->c[j] & 3);
+    e->pos = j;
+}
+
+/* one haplotype's part of a deletion shift, mut.c:515-516 / :547 / :569 */
+static inline void del_swap(hap_t *h, int64_t j, int64_t dl)
+{
+    uint8_t t = h->c[j]; h->c[j] = h->c[j + dl]; h->c[j + dl] = (uint8_t)((t | TMASK) ^ TMASK);
+}
+static inline int64_t del_run(const hap_t *h, int64_t i)
+{
+    int64_t j, dl = 1;
+    for (j = i + 1; j < h->l && (h->c[j] & TMASK) == T_DEL; ++j) dl++;
+    return dl;
+}
+
+/* mut.c:481-589 mut_left_justify() */
+static void left_justify(const seq_t *seq, hap_t *h0, hap_t *h1)
+{
+    int prev_del[2] = { 0, 0 };
+    hap_t *h[2] = { h0, h1 };
+    for (int64_t i = 0; i < seq->l; ++i) {
+        uint8_t r0 = nt4(seq->s[i]), c1 = h0->c[i], c2 = h1->c[i];
+        if (r0 >= 4) continue;
+        if ((c1 & TMASK) == T_NONE && (c2 & TMASK) == T_NONE) { prev_del[0] = prev_del[1] = 0; continue; }
+        if ((c1 & BT_MASK) == (c2 & BT_MASK)) { /* hom */
+            if ((c1 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
+            else if ((c1 & TMASK) == T_DEL) {
+                if (prev_del[0] == 1 || prev_del[1] == 1) continue;
+                prev_del[0] = prev_del[1] = 1;
+                int64_t dl = del_run(h0, i);
+                if (seq->l <= i + dl) continue;
+                if (i > 0) for (int64_t j = i - 1;; --j) {
+                    uint8_t a = h0->c[j], b = h1->c[j];
+                    if ((a & TMASK) != T_INS && (b & TMASK) != T_INS && (a & TMASK) != T_DEL && (b & TMASK) != T_DEL
+                        && (a & 3) == (h0->c[j + dl] & 3) && (b & 3) == (h1->c[j + dl] & 3)) {
+                        del_swap(h0, j, dl); del_swap(h1, j, dl);
+                    } else break;
+                    if (j == 0) break;
+                }
+            } else { /* insertion */
+                prev_del[0] = prev_del[1] = 0;
+                justify_ins(h0, i); justify_ins(h1, i);
+            }
+        } else { /* het */
+            if ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
+            else if ((c1 & TMASK) == T_DEL || (c2 & TMASK) == T_DEL) {
+                int x = ((c1 & TMASK) == T_DEL) ? 0 : 1;
+                if (prev_del[x] == 1) continue;
+                prev_del[x] = 1;
+                int64_t dl = del_run(h[x], i);
+                if (seq->l <= i + dl) continue;
+                if (i > 0) for (int64_t j = i - 1;; --j) {
+                    uint8_t a = h[x]->c[j];
+                    if ((a & TMASK) == T_NONE && (a & 3) == (h[x]->c[j + dl] & 3)) del_swap(h[x], j, dl);
+                    else break;
+                    if (j == 0) break;
+                }
+            } else if ((c1 & TMASK) == T_INS) { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); }
+            else { prev_del[0] = prev_del[1] = 0; justify_ins(h1, i); }
+        }
+    }
+}
+
+/* growable text sink */
+typedef struct { char *p; size_t n, m; FILE *fp; int discard; uint64_t total; } sink_t;
+static void sink_flush(sink_t *s) { if (s->fp && s->n) fwrite(s->p, 1, s->n, s->fp); s->n = 0; }
+static inline void sink_putc(sink_t *s, char c)
+{
+    s->total++;
+    if (s->discard) return;
+    if (s->n == s->m) { if (s->fp && s->m >= (1u << 20)) sink_flush(s); else { s->m = s->m ? s->m * 2 : 1 << 16; s->p = realloc(s->p, s->m); } }
+    s->p[s->n++] = c;
+}
+static void sink_puts(sink_t *s, const char *z) { while (*z) sink_putc(s, *z++); }
+static void sink_printf(sink_t *s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static void sink_printf(sink_t *s, const char *fmt, ...)
+{
+    char buf[4096]; va_list ap; va_start(ap, fmt); int n = vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (n >= (int)sizeof buf) { char *b = malloc((size_t)n + 1); va_start(ap, fmt); vsnprintf(b, (size_t)n + 1, fmt, ap); va_end(ap); sink_puts(s, b); free(b); }
+    else sink_puts(s, buf);
+}
+
+static void print_ins(sink_t *s, hap_t *h, int64_t i) /* mut.c:249-279 */
+{
+    ins_t *e = ins_find(h, i);
+    for (uint32_t t = 0; t < e->n; ++t) sink_putc(s, "ACGTN"[e->b[t] & 3]);
+}
+
+/* mut.c:781-893 mut_print() */
+static void print_mutations(const char *name, const seq_t *seq, hap_t *h0, hap_t *h1, sink_t *txt, sink_t *vcf)
+{
+    int prev[2] = { 0, 0 };
+    for (int64_t i = 0; i < seq->l; ++i) {
+        uint8_t r0 = nt4(seq->s[i]), c1 = h0->c[i], c2 = h1->c[i];
+        if (r0 < 4 && ((c1 & TMASK) != T_NONE || (c2 & TMASK) != T_NONE)) {
+            sink_printf(txt, "%s\t%lld\t", name, (long long)i + 1);
+            int hom = (c1 & BT_MASK) == (c2 & BT_MASK);
+            if ((hom && (c1 & TMASK) == T_SUB) || (!hom && ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB))) {
+                if (hom) {
+                    sink_printf(txt, "%c\t%c\t3\n", "ACGTN"[r0], "ACGTN"[c1 & 0xf]);
+                    sink_printf(vcf, "%s\t%lld\t.\t%c\t%c\t100\tPASS\tAF=1.0;pl=3;mt=SUBSTITUTE\n", name, (long long)i + 1, "ACGTN"[r0], "ACGTN"[c1 & 0xf]);
+                } else {
+                    int hap = ((c1 & TMASK) == T_SUB) ? 1 : 2;
+                    sink_printf(txt, "%c\t%c\t%d\n", "ACGTN"[r0], "XACMGRSVTWYHKDBN"[1 << (c1 & 3) | 1 << (c2 & 3)], hap);
+                    sink_printf(vcf, "%s\t%lld\t.\t%c\t%c\t100\tPASS\tAF=0.5;pl=%d;mt=SUBSTITUTE\n", name, (long long)i + 1, "ACGTN"[r0], "ACGTN"[(hap == 1 ? c1 : c2) & 0xf], hap);
+                }
+            } else if ((hom && (c1 & TMASK) == T_DEL) || (!hom && ((c1 & TMASK) == T_DEL || (c2 & TMASK) == T_DEL))) {
+                /* hom: pl 3; het: haplotype 1 takes precedence (mut.c:833 before :853) */
+                int pl = hom ? 3 : (((c1 & TMASK) == T_DEL) ? 1 : 2);
+                sink_printf(txt, "%c\t-\t%d\n", "ACGTN"[r0], pl);
+                int open = hom ? (prev[0] == 0 || prev[1] == 0) : (prev[pl - 1] == 0);
+                if (open) { /* one VCF record per run, anchored on the previous reference base (POS = i, 1-based i) */
+                    sink_printf(vcf, "%s\t%lld\t.\t", name, (long long)i);
+                    if (i > 0) sink_putc(vcf, "ACGTN"[nt4(seq->s[i - 1])]);
+                    uint8_t a0 = r0, a1 = c1, a2 = c2;
+                    for (int64_t j = i; j < seq->l; ++j) {
+                        int h2 = (a1 & BT_MASK) == (a2 & BT_MASK);
+                        uint8_t td = (pl == 2) ? a2 : a1;
+                        if (!(h2 == hom && (td & TMASK) == T_DEL)) break;
+                        sink_putc(vcf, "ACGTN"[a0]);
+                        if (j + 1 < seq->l) { a0 = nt4(seq->s[j + 1]); a1 = h0->c[j + 1]; a2 = h1->c[j + 1]; }
+                    }
+                    if (i > 0) sink_printf(vcf, "\t%c", "ACGTN"[nt4(seq->s[i - 1])]); else sink_puts(vcf, "\t.");
+                    sink_printf(vcf, "\t100\tPASS\tAF=%s;pl=%d;mt=DELETE\n", hom ? "1.0" : "0.5", pl);
+                }
+            } else { /* insertion */
+                int pl = hom ? 3 : (((c1 & TMASK) == T_INS) ? 1 : 2);
+                hap_t *hh = (pl == 2) ? h1 : h0;
+                if (!hom && (c1 & TMASK) != T_INS && (c2 & TMASK) != T_INS) { fprintf(stderr, "oracle: unreachable mutation state\n"); exit(2); }
+                sink_puts(txt, "-\t"); print_ins(txt, hh, i); sink_printf(txt, "\t%d\n", pl);
+                sink_printf(vcf, "%s\t%lld\t.\t%c\t%c", name, (long long)i + 1, "ACGTN"[r0], "ACGTN"[r0]);
+                print_ins(vcf, hh, i);
+                sink_printf(vcf, "\t100\tPASS\tAF=%s;pl=%d;mt=INSERT\n", hom ? "1.0" : "0.5", pl);
+            }
+        }
+        prev[0] = (c1 & TMASK) != T_NONE; prev[1] = (c2 & TMASK) != T_NONE;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Read extraction: dwgsim.c:75-153 __gen_read
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int ext_coor, n_sub, n_indel, n_sub_first, n_indel_first; } readinfo_t;
+
+static void gen_read(hap_t *h, int64_t seq_l, int64_t start, int step, int s, int strand, uint8_t *out, readinfo_t *ri)
+{
+    int k = 0; int64_t i;
+    ri->ext_coor = -10;
+    for (i = start; i >= 0 && i < seq_l && k < s; i += step) {
+        uint8_t c = h->c[i], mt = c & TMASK;
+        if (ri->ext_coor < 0) {
+            if (mt != T_NONE && mt != T_SUB) continue;
+            ri->ext_coor = (int)i;
+            if (strand == 1) ri->ext_coor -= s - 1;
+        }
+        if (mt == T_DEL) {
+            ++ri->n_indel;
+            if (strand == 1) ri->ext_coor--;
+            if (k == 0) ri->n_indel_first++;
+        } else if (mt == T_NONE || mt == T_SUB) {
+            out[k++] = c & 0xf;
+            if (mt == T_SUB) { ++ri->n_sub; if (k == 0) ri->n_sub_first++; }
+        } else {
+            ins_t *e = ins_find(h, i);
+            uint32_t n = e->n;
+            ++ri->n_indel; ri->n_indel_first++;
+            if (strand == 0) {
+                if (k < s) out[k++] = c & 0xf;
+                for (uint32_t t = 0; t < n && k < s; ++t) out[k++] = e->b[t] & 3;
+            } else {
+                while (n > 0 && k < s) { ri->ext_coor++; out[k++] = e->b[n - 1] & 3; --n; }
+                if (k < s) out[k++] = c & 0xf;
+            }
+        }
+    }
+    if (k != s) ri->ext_coor = -10;
+    if (strand == 1) for (k = 0; k < s; ++k) out[k] = out[k] < 4 ? 3 - out[k] : 4;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Ion Torrent flow-space errors: dwgsim.c:246-417 generate_errors_flows
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint8_t *seq, *mask; int mem; } flowbuf_t;
+static void flow_grow(flowbuf_t *b, int need) /* dwgsim.c:296-311: grow while mem <= need (allocation only, no effect on results) */
+{
+    int grew = 0;
+    while (b->mem <= need) { b->mem <<= 1; grew = 1; }
+    if (grew) { b->seq = realloc(b->seq, (size_t)b->mem); b->mask = realloc(b->mask, (size_t)b->mem); }
+}
+static void flow_alloc(flowbuf_t *b, int len, int F)
+{
+    b->mem = (len + 2 > F + 2) ? len + 2 : F + 2;
+    b->seq = calloc((size_t)b->mem, 1); b->mask = calloc((size_t)b->mem, 1);
+}
+#define FLOW_U() rng_u(r, dom, idx, att, 0, (*slot)++)
+static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t *slot,
+                       flowbuf_t *b, int len, int strand, double e, int *n_err_out)
+{
+    int i, j, k, hp_l, flow_i, n_err, F = o->flow_order_len;
+    uint8_t prev_c, c;
+    for (i = 0; i < len; ++i) if (b->seq[i] >= 4) b->seq[i] = 0;
+    if (strand == 1) for (i = 0; i < len >> 1; ++i) { c = b->seq[i]; b->seq[i] = b->seq[len - i - 1]; b->seq[len - i - 1] = c; }
+    for (i = 0; i < F; ++i) {
+        c = (4 <= b->seq[0]) ? 0 : b->seq[0]; /* NB: reads seq[0] even when len == 0 (dwgsim.c:268-274) */
+        if (c == o->flow_order[i]) break;
+        b->mask[i] = 0;
+    }
+    if (F == i) { fprintf(stderr, "Error: first base not found in flow order\n"); return -1; }
+    flow_i = i; prev_c = 4;
+    for (i = 0; i < len; ++i) {
+        c = (4 <= b->seq[i]) ? 0 : b->seq[i];
+        while (c != o->flow_order[flow_i]) { b->mask[flow_i] = 0; flow_i = (flow_i + 1) % F; }
+        if (prev_c != c) {
+            b->mask[flow_i] = 0;
+            n_err = 0;
+            while (FLOW_U() < e) n_err++;
+            if (0 < n_err) {
+                if (FLOW_U() < 0.5) { /* insert */
+                    flow_grow(b, len + n_err);
+                    for (j = len - 1; i <= j; --j) b->seq[j + n_err] = b->seq[j];
+                    for (j = i; j < i + n_err; ++j) b->seq[j] = c;
+                    len += n_err;
+                } else { /* delete */
+                    int next_c = 4;
+                    for (j = i, hp_l = 0; j < len; ++j, ++hp_l) { next_c = (4 <= b->seq[j]) ? 0 : b->seq[j]; if (c != next_c) break; }
+                    n_err = (hp_l < n_err) ? hp_l : n_err;
+                    for (j = i; j < len - n_err; ++j) b->seq[j] = b->seq[j + n_err];
+                    len -= n_err;
+                    b->mask[flow_i] = 1;
+                    if (n_err == hp_l && (0 == i || prev_c == next_c)) { /* dot-fill */
+                        j = 0;
+                        while (next_c != o->flow_order[(flow_i + j) % F]) j++;
+                        k = (int)(FLOW_U() * j);
+                        for (j = len - 1; i <= j; --j) b->seq[j + 1] = b->seq[j];
+                        b->seq[i] = (uint8_t)o->flow_order[(flow_i + k) % F];
+                        len++;
+                    }
+                }
+                *n_err_out += n_err;
+            }
+            prev_c = c;
+        }
+    }
+    for (i = 0; i < len; ++i) { /* second pass: empty flows (flow_i continues) */
+        c = (4 <= b->seq[i]) ? 0 : b->seq[i];
+        while (c != o->flow_order[flow_i]) {
+            n_err = 0;
+            while (FLOW_U() < e) n_err++;
+            if (0 == b->mask[flow_i] && 0 < n_err) {
+                flow_grow(b, len + n_err);
+                for (j = len - 1; i <= j; --j) b->seq[j + n_err] = b->seq[j];
+                for (j = i; j < i + n_err; ++j) b->seq[j] = (uint8_t)o->flow_order[flow_i];
+                len += n_err;
+                *n_err_out += n_err;
+            }
+            flow_i = (flow_i + 1) % F;
+        }
+    }
+    if (strand == 1) for (i = 0; i < len >> 1; ++i) { c = b->seq[i]; b->seq[i] = b->seq[len - i - 1]; b->seq[len - i - 1] = c; }
+    return len;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Option parsing: dwgsim_opt.c:204-472 (mutation-input / region options are accepted by the
+ * reference but are outside this oracle's scope: SURVEY 8(f))
+ * ---------------------------------------------------------------------------------------- */
+static void get_error_rate(const char *str, erate_t *e) /* dwgsim_opt.c:162-179 */
+{
+    size_t i, n = strlen(str);
+    e->start = atof(str);
+    for (i = 0; i < n; ++i) if (str[i] == ',' || str[i] == '-') break;
+    if (n > 0 && i < n - 1) e->end = atof(str + i + 1); else e->end = e->start;
+}
+static int is_int(const char *a, int neg_ok) /* dwgsim_opt.c:181-192 */
+{
+    size_t n = strlen(a);
+    if (n == 0) return 0;
+    if ('+' != a[0] && (neg_ok == 0 || '-' != a[0]) && !isdigit((unsigned char)a[0])) return 0;
+    for (size_t i = 1; i < n; ++i) if (!isdigit((unsigned char)a[i])) return 0;
+    return 1;
+}
+static int xatoi(const char *a, char flag, int neg_ok)
+{
+    if (!is_int(a, neg_ok)) { fprintf(stderr, "Error: command line option -%c is not a number [%s]\n", flag, a); exit(1); }
+    return atoi(a);
+}
+#define CHECK(v, lo, hi, nm) do { if ((v) < (lo) || (hi) < (v)) { fprintf(stderr, "Error: command line option %s was out of range\n", nm); return 0; } } while (0)
+
+static int calibrate_flow_error(opt_t *o, rng_t *r);
+
+static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
+{
+    int c;
+    optind = 1;
+    while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
+        switch (c) {
+        case 'i': o->is_inner = 1; break;
+        case 'd': o->dist = xatoi(optarg, 'd', 0); break;
+        case 's': o->std_dev = atof(optarg); break;
+        case 'N': o->N = xatoi(optarg, 'N', 1); o->C = -1; break;
+        case 'C': o->C = atof(optarg); o->N = -1; break;
+        case '1': o->length[0] = xatoi(optarg, '1', 0); break;
+        case '2': o->length[1] = xatoi(optarg, '2', 0); break;
+        case 'e': get_error_rate(optarg, &o->e[0]); break;
+        case 'E': get_error_rate(optarg, &o->e[1]); break;
+        case 'r': o->mut_rate = atof(optarg); break;
+        case 'F': o->mut_freq = atof(optarg); break;
+        case 'R': o->indel_frac = atof(optarg); break;
+        case 'X': o->indel_extend = atof(optarg); break;
+        case 'I': o->indel_min = xatoi(optarg, 'I', 0); break;
+        case 'c': o->data_type = xatoi(optarg, 'c', 0); break;
+        case 'S': o->strandedness = xatoi(optarg, 'S', 0); break;
+        case 'A': o->read_one_strand = xatoi(optarg, 'A', 0); break;
+        case 'n': o->max_n = xatoi(optarg, 'n', 0); break;
+        case 'y': o->rand_read = atof(optarg); break;
+        case 'f': free(o->flow_order); o->flow_order = (int8_t *)strdup(optarg); break;
+        case 'B': o->use_base_error = 1; break;
+        case 'H': o->is_hap = 1; break;
+        case 'h': return 0;
+        case 'z': o->seed = xatoi(optarg, 'z', 1); break;
+        case 'M': o->output_type = xatoi(optarg, 'M', 0); break;
+        case 'm': case 'b': case 'v': case 'x':
+            fprintf(stderr, "oracle: option -%c (mutation-input / regions) is outside the oracle's scope\n", c); exit(3);
+        case 'P': free(o->read_prefix); o->read_prefix = strdup(optarg); break;
+        case 'q': free(o->fixed_quality); o->fixed_quality = strdup(optarg); break;
+        case 'Q': o->quality_std = atof(optarg); break;
+        case 'o': o->reads_output_type = atoi(optarg); break;
+        case 'a': o->amplicons = 1; break;
+        default: fprintf(stderr, "Unrecognized option: -%c\n", c); return 0;
+        }
+    }
+    if (argc - optind < 2) return 0;
+    *first_arg = optind;
+    CHECK(o->dist, 0, INT32_MAX, "-d");
+    CHECK(o->std_dev, 0, INT32_MAX, "-s");
+    if (o->N < 0 && o->C < 0) { fprintf(stderr, "Must use one of -N or -C"); return 0; }
+    else if (0 < o->N && 0 < o->C) { fprintf(stderr, "Cannot use both -N or -C"); return 0; }
+    else if (0 < o->N) { CHECK(o->N, 1, INT32_MAX, "-N"); CHECK(o->C, INT32_MIN, -1, "-C"); }
+    else { CHECK(o->N, INT32_MIN, -1, "-N"); CHECK(o->C, 0, INT32_MAX, "-C"); }
+    CHECK(o->length[0], 1, INT32_MAX, "-1");
+    CHECK(o->length[1], 0, INT32_MAX, "-2");
+    for (int i = 0; i < 2; ++i) {
+        if (o->e[i].start < 0.0 || 1.0 < o->e[i].start) { fprintf(stderr, "End %s: the start error is out of range (-e)\n", i ? "two" : "one"); return 0; }
+        if (o->e[i].end < 0.0 || 1.0 < o->e[i].end) { fprintf(stderr, "End %s: the end error is out of range (-e)\n", i ? "two" : "one"); return 0; }
+        if (IONTORRENT == o->data_type && o->e[i].end != o->e[i].start) { fprintf(stderr, "End %s: a uniform error rate must be given for Ion Torrent data\n", i ? "two" : "one"); return 0; }
+    }
+    CHECK(o->mut_rate, 0, 1.0, "-r"); CHECK(o->indel_frac, 0, 1.0, "-R"); CHECK(o->indel_extend, 0, 1.0, "-X");
+    CHECK(o->indel_min, 1, INT32_MAX, "-I"); CHECK(o->data_type, 0, 2, "-c"); CHECK(o->strandedness, 0, 2, "-S");
+    CHECK(o->read_one_strand, 0, 2, "-A"); CHECK(o->max_n, 0, INT32_MAX, "-n"); CHECK(o->rand_read, 0, 1.0, "-y");
+    if (IONTORRENT == o->data_type && NULL == o->flow_order) { fprintf(stderr, "Error: command line option -f is required\n"); return 0; }
+    if (o->fixed_quality && strlen(o->fixed_quality) != 1) { fprintf(stderr, "Error: command line option -q requires one character\n"); return 0; }
+    CHECK(o->quality_std, 0, INT32_MAX, "-Q");
+    CHECK(o->reads_output_type, 0, 2, "-o");
+
+    rng_seed(r, o->rng_mode, (-1 == o->seed) ? (int32_t)time(0) : o->seed);
+    r->use_libm_log = o->use_libm_log;
+
+    if (IONTORRENT == o->data_type) { /* dwgsim_opt.c:396-413 */
+        o->flow_order_len = (int)strlen((char *)o->flow_order);
+        for (int i = 0; i < o->flow_order_len; ++i) o->flow_order[i] = (int8_t)nt4(o->flow_order[i]);
+    }
+    if (IONTORRENT == o->data_type && o->use_base_error) { if (!calibrate_flow_error(o, r)) return 0; }
+    else { /* dwgsim_opt.c:459-460 (NaN for -2 0: harmless) */
+        o->e[0].by = (o->e[0].end - o->e[0].start) / o->length[0];
+        o->e[1].by = (o->e[1].end - o->e[1].start) / o->length[1];
+    }
+    CHECK(o->output_type, 0, 2, "-M");
+    return 1;
+}
+
+/* dwgsim_opt.c:415-457: rescale the per-flow error so the per-base rate matches -e */
+static int calibrate_flow_error(opt_t *o, rng_t *r)
+{
+    double sf = 0.0;
+    for (int i = 0; i < 2; ++i) {
+        if (o->length[i] <= 0) continue;
+        if (0 < i && o->length[i] == o->length[1 - i]) { o->e[i] = o->e[1 - i]; continue; }
+        flowbuf_t b; flow_alloc(&b, o->length[i], o->flow_order_len);
+        int n_err = 0, counts = 0; /* int32 accumulators as in the reference */
+        for (int j = 0; j < 1000000; ++j) {
+            uint32_t slot = 0;
+            for (int k = 0; k < o->length[i]; ++k) b.seq[k] = (uint8_t)((int)(rng_u(r, D_CALIB + i, (uint64_t)j, 0, 0, slot++) * 4.0) & 3);
+            int cur = 0;
+            int s = flow_errors(o, r, D_CALIB + i, (uint64_t)j, 1, &slot, &b, o->length[i], 0, o->e[i].start, &cur);
+            n_err += cur; counts += s;
+        }
+        sf = o->e[i].start / (n_err / (1.0 * counts));
+        o->e[i].start = o->e[i].end *= sf;
+        o->e[i].by = (o->e[i].end - o->e[i].start) / o->length[i];
+        free(b.seq); free(b.mask);
+        fprintf(stderr, "[oracle] end %d flow-error scaling factor %.5lf\n", i + 1, sf);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dwgsim_core: dwgsim.c:419-1121
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { sink_t bfast, bwa1, bwa2, txt, vcf; int has_bfast, has_bwa, has_mut; } outs_t;
+
+/* quality string for read end j, dwgsim.c:899-918 (and :1002-1021) */
+static void make_quals(const opt_t *o, rng_t *r, int j, uint64_t ii, uint32_t att, int len, char *q)
+{
+    nstream_t ns = { D_QUAL0 + (uint32_t)j, ii, att, 0, 1, 0, 0.0 };
+    int i;
+    if (o->fixed_quality) { for (i = 0; i < len; ++i) q[i] = o->fixed_quality[0]; }
+    else for (i = 0; i < len; ++i) {
+        double ei = o->e[j].start + o->e[j].by * i;
+        if (ei > 0) q[i] = (char)((int)(-10.0 * log(ei) / log(10.0) + 0.499) + '!');
+        else q[i] = 40 + '!';
+        if (0 < o->quality_std) q[i] = (char)(q[i] + (int)((ran_normal(r, &ns) * o->quality_std) + 0.5));
+        if (q[i] < '!') q[i] = '!';
+        if (40 + '!' < q[i]) q[i] = 40 + '!';
+    }
+    q[i] = 0;
+}
+
+static void put_name(sink_t *s, const opt_t *o, const char *name, unsigned p0, unsigned p1, unsigned s0, unsigned s1,
+                     unsigned r0, unsigned r1, const int a[6], unsigned long long ii, int suffix)
+{
+    sink_printf(s, "@%s%s%s_%u_%u_%1u_%1u_%1u_%1u_%d:%d:%d_%d:%d:%d_%llx", o->read_prefix ? o->read_prefix : "", o->read_prefix ? "_" : "",
+                name, p0, p1, s0, s1, r0, r1, a[0], a[1], a[2], a[3], a[4], a[5], ii);
+    if (suffix) sink_printf(s, "/%d", suffix);
+    sink_putc(s, '\n');
+}
+
+/* dwgsim.c:919-981 / :1033-1094: emit read end j to the bwa file j and to bfast */
+static void emit_read(const opt_t *o, outs_t *out, int j, const char *name, unsigned p0, unsigned p1, unsigned s0, unsigned s1,
+                      unsigned r0, unsigned r1, const int cnt[6], const int cnt_solid_bwa[6], unsigned long long ii,
+                      const uint8_t *seq, int len, const char *q)
+{
+    int i;
+    if (out->has_bwa) {
+        sink_t *f = j ? &out->bwa2 : &out->bwa1;
+        if (o->data_type != SOLID) {
+            put_name(f, o, name, p0, p1, s0, s1, r0, r1, cnt, ii, j + 1);
+            for (i = 0; i < len; ++i) sink_putc(f, "ACGTN"[seq[i]]);
+            sink_puts(f, "\n+\n"); sink_puts(f, q); sink_putc(f, '\n');
+        } else {
+            put_name(f, o, name, p0, p1, s0, s1, r0, r1, cnt_solid_bwa, ii, 2 - j);
+            for (i = 1; i < len; ++i) sink_putc(f, "ACGTN"[seq[i]]);
+            sink_puts(f, "\n+\n");
+            for (i = 1; i < len; ++i) sink_putc(f, q[i]);
+            sink_putc(f, '\n');
+        }
+    }
+    if (out->has_bfast) {
+        sink_t *f = &out->bfast;
+        put_name(f, o, name, p0, p1, s0, s1, r0, r1, cnt, ii, 0);
+        if (o->data_type != SOLID) {
+            for (i = 0; i < len; ++i) sink_putc(f, "ACGTN"[seq[i]]);
+            sink_puts(f, "\n+\n"); sink_puts(f, q); sink_putc(f, '\n');
+        } else {
+            sink_putc(f, 'A');
+            for (i = 0; i < len; ++i) sink_putc(f, "01234"[seq[i]]);
+            sink_puts(f, "\n+\n");
+            for (i = 0; i < len; ++i) sink_putc(f, q[i]);
+            sink_putc(f, '\n');
+        }
+    }
+}
+
+static void to_colors(uint8_t *seq, int len) /* dwgsim.c:845-858, __gf_add dwgsim.h:6 */
+{
+    int c1 = 0;
+    for (int i = 0; i < len; ++i) { int c2 = seq[i]; seq[i] = (uint8_t)((c1 >= 4 || c2 >= 4) ? 4 : (c1 ^ c2)); c1 = c2; }
+}
+
+typedef struct { uint64_t n_pairs_total, n_rand_total, n_attempt_fail; } stats_t;
+
+static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
+{
+    FILE *fp = fopen(fn_fa, "r");
+    if (!fp) { fprintf(stderr, "[oracle] fail to open file '%s'. Abort!\n", fn_fa); return 1; }
+    char fn_fai[4096]; snprintf(fn_fai, sizeof fn_fai, "%s.fai", fn_fa);
+    FILE *fai = fopen(fn_fai, "r");
+    seq_t seq = { 0, 0, NULL };
+    char name[4096];
+    uint64_t tot_len = 0, ctr = 0, rand_ii = 0; int n_ref = 0; int64_t l, n_sim = 0;
+    int lmax = o->length[0] > o->length[1] ? o->length[0] : o->length[1];
+    flowbuf_t tb[2];
+    for (int j = 0; j < 2; ++j) flow_alloc(&tb[j], lmax, o->flow_order_len);
+    int qcap = lmax; char *qstr = calloc((size_t)qcap + 1, 1);
+    int size[2] = { o->length[0], o->length[1] };
+
+    /* pass 1: contig lengths and the VCF header, dwgsim.c:465-492 */
+    if (out->has_mut) sink_puts(&out->vcf, "##fileformat=VCFv4.1\n");
+    if (fai) {
+        int ll, d0, d1, d2;
+        while (0 < fscanf(fai, "%s\t%d\t%d\t%d\t%d", name, &ll, &d0, &d1, &d2)) {
+            tot_len += (uint64_t)ll; ++n_ref;
+            if (out->has_mut) sink_printf(&out->vcf, "##contig=<ID=%s,length=%d>\n", name, ll);
+        }
+        fclose(fai);
+    } else {
+        while ((l = fasta_next(fp, &seq, name)) >= 0) {
+            tot_len += (uint64_t)l; ++n_ref;
+            if (out->has_mut) sink_printf(&out->vcf, "##contig=<ID=%s,length=%d>\n", name, (int)l);
+        }
+    }
+    rewind(fp);
+    if (out->has_mut) sink_puts(&out->vcf,
+        "##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n"
+        "##INFO=<ID=pl,Number=1,Type=Integer,Description=\"Phasing: 1 - HET contig 1, #2 - HET contig #2, 3 - HOM both contigs\">\n"
+        "##INFO=<ID=mt,Number=1,Type=String,Description=\"Variant Type: SUBSTITUTE/INSERT/DELETE\">\n"
+        "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
+
+    uint32_t contig_i = 0;
+    while ((l = fasta_next(fp, &seq, name)) >= 0) {
+        int64_t n_pairs = 0;
+        n_ref--;
+        if (o->output_type != 2) {
+            if (0 == n_ref && o->C < 0) n_pairs = o->N - n_sim;               /* dwgsim.c:535-537 */
+            else if (0 < o->N) {                                                 /* :582-586 */
+                n_pairs = (int64_t)(uint64_t)((long double)l / tot_len * o->N + 0.5);
+                if (o->N - n_sim < n_pairs) n_pairs = o->N - n_sim;
+            } else                                                               /* :589 */
+                n_pairs = (int64_t)(uint64_t)(l * o->C / ((long double)(size[0] + size[1])) / (1.0 - o->rand_read) + 0.5);
+            /* skip rules #2-#5, :595-623 */
+            if (o->amplicons == 1) { if (l < lmax) { contig_i++; continue; } }
+            else if (0 < o->length[1] && l < o->dist + 3 * o->std_dev) { contig_i++; continue; }
+            else if (l < o->length[0] || (0 < o->length[1] && l < o->length[1])) { contig_i++; continue; }
+            else if (n_pairs < 0) continue;
+        }
+        hap_t hap[2]; memset(hap, 0, sizeof hap);
+        r->k1 = contig_i;
+        walk_contig(o, r, &seq, &hap[0], &hap[1]);           /* dwgsim.c:628-629 -> mut.c:591 */
+        left_justify(&seq, &hap[0], &hap[1]);                /* mut.c:756 */
+        if (out->has_mut) print_mutations(name, &seq, &hap[0], &hap[1], &out->txt, &out->vcf);
+
+        if (o->output_type != 2) {
+            int num_failed = 0; uint32_t att = 0;
+            for (uint64_t ii = 0; ii != (uint64_t)n_pairs; ++ii, ++ctr) {
+                int s[2] = { size[0], size[1] }, strand[2] = { 0, 0 }, d = 0, pos = 0;
+                readinfo_t ri[2]; memset(ri, 0, sizeof ri);
+                int n_err[2] = { 0, 0 }, n_err_first[2] = { 0, 0 };
+                if (o->rand_read < rng_u(r, D_PAIR, ii, att, 0, 0)) {
+                    if (o->amplicons == 1) { pos = 0; d = (int)seq.l; }
+                    else {
+                        uint32_t t = 0;
+                        do { /* dwgsim.c:655-675 */
+                            if (0 < s[1]) {
+                                nstream_t ns = { D_PLACE_NORM, ii, att, t, 0, 0, 0.0 };
+                                double ran = ran_normal(r, &ns);
+                                ran = ran * o->std_dev + o->dist;
+                                d = (int)(ran + 0.5);
+                                int min_dist = s[0] + s[1];
+                                if (d < min_dist) d = min_dist;
+                                if (d > l) d = (int)l;
+                            } else d = 0;
+                            int64_t range = (int64_t)l - d + 1;
+                            pos = (int)(range * rng_u(r, D_PLACE, ii, att, 0, t));
+                            t++;
+                        } while (pos < 0 || pos >= seq.l || pos + d - 1 >= seq.l
+                                 || (0 < s[1] && 0 == o->is_inner && ((0 < s[0] && d <= s[1]) || (d <= s[0] && 0 < s[1]))));
+                    }
+                    hap_t *cur = &hap[rng_u(r, D_PAIR, ii, att, 0, 1) < o->mut_freq ? 0 : 1];  /* :716 */
+                    switch (o->read_one_strand) {                                               /* :722-727 */
+                    case 0: strand[0] = (rng_u(r, D_PAIR, ii, att, 0, 2) < 0.5) ? 1 : 0; break;
+                    case 1: strand[0] = 0; break;
+                    default: strand[0] = 1; break;
+                    }
+                    switch (o->strandedness) {                                                  /* :730-742 */
+                    case 0: strand[1] = (o->data_type == ILLUMINA) ? 1 - strand[0] : strand[0]; break;
+                    case 1: strand[1] = strand[0]; break;
+                    default: strand[1] = 1 - strand[0]; break;
+                    }
+                    /* read geometry, dwgsim.c:745-821 */
+                    int64_t sl = seq.l, st0, st1 = 0; int step0, step1 = 1;
+                    if (0 < s[1]) {
+                        int64_t far_outer = pos + (int64_t)d - 1;
+                        if (strand[0] == strand[1]) {
+                            if (0 == strand[0]) { st0 = o->amplicons ? sl - 1 : (o->is_inner ? (int64_t)pos + s[1] + d - 1 : (int64_t)pos + d - s[0]); step0 = 1; st1 = pos; step1 = 1; }
+                            else { st0 = (int64_t)pos + s[0] - 1; step0 = -1; st1 = o->amplicons ? sl - 1 : (o->is_inner ? (int64_t)pos + s[0] + d + s[1] - 1 : far_outer); step1 = -1; }
+                        } else {
+                            if (0 == strand[0]) { st0 = pos; step0 = 1; st1 = o->amplicons ? sl - 1 : (o->is_inner ? (int64_t)pos + s[0] + d + s[1] - 1 : far_outer); step1 = -1; }
+                            else { st0 = o->amplicons ? sl - 1 : (o->is_inner ? (int64_t)pos + s[1] + d + s[0] - 1 : far_outer); step0 = -1; st1 = pos; step1 = 1; }
+                        }
+                        gen_read(cur, sl, st0, step0, s[0], strand[0], tb[0].seq, &ri[0]);
+                        gen_read(cur, sl, st1, step1, s[1], strand[1], tb[1].seq, &ri[1]);
+                    } else {
+                        if (0 == strand[0]) { st0 = pos; step0 = 1; }
+                        else if (o->amplicons == 1) { st0 = sl - 1; step0 = -1; }
+                        else { st0 = (int64_t)pos + s[0] - 1; step0 = -1; }
+                        gen_read(cur, sl, st0, step0, s[0], strand[0], tb[0].seq, &ri[0]);
+                        ri[1].ext_coor = 0; /* dwgsim.c:643 ext_coor[2]={0,0}: never touched for single-end */
+                    }
+                    int num_n[2] = { 0, 0 };
+                    for (int j = 0; j < 2; ++j) for (int i = 0; i < s[j]; ++i) if (tb[j].seq[i] == 4) num_n[j]++;
+                    if (ri[0].ext_coor < 0 || ri[1].ext_coor < 0 || o->max_n < num_n[0] || o->max_n < num_n[1]) { /* :833-842 */
+                        --ii; --ctr; num_failed++; att++; st->n_attempt_fail++;
+                        if (num_failed > 10000) { fprintf(stderr, "\r[dwgsim_core] failed to generate a read after %d trials\n", num_failed); return 1; }
+                        continue;
+                    }
+                    num_failed = 0;
+                    if (SOLID == o->data_type) for (int j = 0; j < 2; ++j) if (0 < s[j]) to_colors(tb[j].seq, s[j]);
+                    if (IONTORRENT == o->data_type) { /* :861-864 */
+                        for (int j = 0; j < 2; ++j) { uint32_t slot = 0; s[j] = flow_errors(o, r, D_FLOW0 + (uint32_t)j, ii, att, &slot, &tb[j], s[j], strand[j], o->e[j].start, &n_err[j]); }
+                    } else for (int j = 0; j < 2; ++j) if (0 < s[j]) { /* :233-244, :866-881 */
+                        int i = strand[j] ? s[j] - 1 : 0, step = strand[j] ? -1 : 1;
+                        for (; 0 <= i && i < s[j]; i += step) {
+                            uint8_t c = tb[j].seq[i];
+                            if (c >= 4) c = 4;
+                            else if (rng_u(r, D_BASE0 + (uint32_t)j, ii, att, 0, 2 * (uint32_t)i) < o->e[j].start + o->e[j].by * i) {
+                                c = (uint8_t)((c + (uint64_t)(rng_u(r, D_BASE0 + (uint32_t)j, ii, att, 0, 2 * (uint32_t)i + 1) * 3.0 + 1)) & 3);
+                                ++n_err[j];
+                                if (0 == i) ++n_err_first[j];
+                            }
+                            tb[j].seq[i] = c;
+                        }
+                    }
+                    int cnt[6] = { n_err[0], ri[0].n_sub, ri[0].n_indel, n_err[1], ri[1].n_sub, ri[1].n_indel };
+                    int cnt2[6] = { n_err[0] - n_err_first[0], ri[0].n_sub - ri[0].n_sub_first, ri[0].n_indel - ri[0].n_indel_first,
+                                    n_err[1] - n_err_first[1], ri[1].n_sub - ri[1].n_sub_first, ri[1].n_indel - ri[1].n_indel_first };
+                    for (int j = 0; j < 2; ++j) { /* :885-981 */
+                        if (s[j] <= 0) continue;
+                        if (qcap < s[j]) { qcap = s[j]; qstr = realloc(qstr, (size_t)qcap + 1); }
+                        make_quals(o, r, j, ii, att, s[j], qstr);
+                        emit_read(o, out, j, name, (unsigned)(ri[0].ext_coor + 1), (unsigned)(ri[1].ext_coor + 1), (unsigned)strand[0], (unsigned)strand[1],
+                                  0, 0, cnt, cnt2, ii, tb[j].seq, s[j], qstr);
+                    }
+                } else { /* random read, dwgsim.c:983-1097 */
+                    static const int zero6[6] = { 0, 0, 0, 0, 0, 0 };
+                    for (int j = 0; j < 2; ++j) {
+                        if (s[j] <= 0) continue;
+                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_u(r, D_BASE0 + (uint32_t)j, ii, att, 0, 2 * (uint32_t)i) * 4.0) & 3);
+                        make_quals(o, r, j, ii, att, s[j], qstr);
+                        if (SOLID == o->data_type) to_colors(tb[j].seq, s[j]);
+                        emit_read(o, out, j, "rand", 0, 0, 0, 0, 1, 1, zero6, zero6, rand_ii, tb[j].seq, s[j], qstr);
+                    }
+                    rand_ii++;
+                }
+                att = 0;
+                n_sim++;
+            }
+        }
+        hap_free(&hap[0]); hap_free(&hap[1]);
+        contig_i++;
+    }
+    st->n_pairs_total = ctr; st->n_rand_total = rand_ii;
+    fclose(fp);
+    free(seq.s); free(qstr);
+    for (int j = 0; j < 2; ++j) { free(tb[j].seq); free(tb[j].mask); }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Entry point: dwgsim_oracle [--rng drand48|philox] [--log det|libm] [--null-fastq] [--verbose]
+ *                            <dwgsim options> <in.ref.fa> <out.prefix>
+ * Writes <prefix>.mutations.{txt,vcf} and UNCOMPRESSED <prefix>.{bfast,bwa.read1,bwa.read2}.fastq
+ * (the reference's own test compares decompressed bytes, testdata/test.sh:21-26).
+ * ---------------------------------------------------------------------------------------- */
+static FILE *open_out(const char *prefix, const char *suffix)
+{
+    char fn[4096]; snprintf(fn, sizeof fn, "%s.%s", prefix, suffix);
+    FILE *f = fopen(fn, "w");
+    if (!f) { fprintf(stderr, "[oracle] fail to open file '%s'. Abort!\n", fn); exit(1); }
+    return f;
+}
+
+int oracle_main(int argc, char **argv)
+{
+    opt_t o; rng_t r; opt_defaults(&o);
+    /* strip the oracle's own long options */
+    char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
+    for (int i = 0; i < argc; ++i) {
+        if (!strcmp(argv[i], "--rng") && i + 1 < argc) { ++i; o.rng_mode = !strcmp(argv[i], "philox") ? RNG_PHILOX : RNG_DRAND48; }
+        else if (!strcmp(argv[i], "--log") && i + 1 < argc) { ++i; o.use_libm_log = !strcmp(argv[i], "libm"); }
+        else if (!strcmp(argv[i], "--null-fastq")) o.null_fastq = 1;
+        else if (!strcmp(argv[i], "--verbose")) o.verbose = 1;
+        else av[ac++] = argv[i];
+    }
+    av[ac] = NULL;
+    int first = 0;
+    if (!opt_parse(&o, &r, ac, av, &first)) { fprintf(stderr, "usage: dwgsim_oracle [--rng drand48|philox] [--log det|libm] [--null-fastq] [dwgsim options] <in.ref.fa> <out.prefix>\n"); free(av); return 1; }
+    const char *fa = av[first], *prefix = av[first + 1];
+    outs_t out; memset(&out, 0, sizeof out);
+    out.has_mut = o.output_type != 1;
+    if (o.output_type != 2) { out.has_bfast = o.reads_output_type != 1; out.has_bwa = o.reads_output_type != 2; }
+    if (out.has_mut) { out.txt.fp = open_out(prefix, "mutations.txt"); out.vcf.fp = open_out(prefix, "mutations.vcf"); }
+    /* NB: the reference with -M 1 dereferences a NULL fp_vcf; the oracle simply writes no mutation files */
+    if (o.null_fastq) { out.bfast.discard = out.bwa1.discard = out.bwa2.discard = 1; }
+    else {
+        if (out.has_bfast) out.bfast.fp = open_out(prefix, "bfast.fastq");
+        if (out.has_bwa) { out.bwa1.fp = open_out(prefix, "bwa.read1.fastq"); out.bwa2.fp = open_out(prefix, "bwa.read2.fastq"); }
+    }
+    stats_t st; memset(&st, 0, sizeof st);
+    int rc = core(&o, &r, fa, &out, &st);
+    sink_t *all[5] = { &out.bfast, &out.bwa1, &out.bwa2, &out.txt, &out.vcf };
+    for (int i = 0; i < 5; ++i) { sink_flush(all[i]); if (all[i]->fp) fclose(all[i]->fp); free(all[i]->p); }
+    if (o.verbose)
+        fprintf(stderr, "[oracle] rng=%s pairs=%llu random=%llu failed_attempts=%llu uniforms=%llu log_mismatch=%llu fastq_bytes=%llu\n",
+                o.rng_mode ? "philox" : "drand48", (unsigned long long)st.n_pairs_total, (unsigned long long)st.n_rand_total,
+                (unsigned long long)st.n_attempt_fail, (unsigned long long)r.n_draws, (unsigned long long)r.n_log_mismatch,
+                (unsigned long long)(out.bfast.total + out.bwa1.total + out.bwa2.total));
+    free(o.flow_order); free(o.read_prefix); free(o.fixed_quality); free(av);
+    return rc;
+}
+
+#ifdef ORACLE_MAIN
+int main(int argc, char **argv) { return oracle_main(argc, argv); }
+#endif
