@@ -1,0 +1,46 @@
+"""Known-answer tests for the oracle's primitives."""
+import ctypes, math, random, struct
+
+
+def test_philox_known_answers(oracle_lib):
+    f = oracle_lib.oracle_philox4x32_10
+    A4, A2 = ctypes.c_uint32 * 4, ctypes.c_uint32 * 2
+    for ctr, key, want in [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]:
+        out = A4()
+        f(A4(*ctr), A2(*key), out)
+        assert tuple(out) == want
+
+
+def test_drand48_known_answers(oracle_lib):
+    x = ctypes.c_uint64((13 << 16) | 0x330E)
+    got = [oracle_lib.oracle_drand48_next(ctypes.byref(x)) for _ in range(3)]
+    assert got == [0.49125804875894019, 0.9095780156526132, 0.69616396868708463]
+
+
+def test_philox_uniform_layout(oracle_lib):
+    # u = ((w_hi << 21) | (w_lo >> 11)) * 2^-53 of block slot>>1, half slot&1; counter layout of DESIGN.md
+    A4, A2 = ctypes.c_uint32 * 4, ctypes.c_uint32 * 2
+    seed, contig, dom, idx, att, retry, slot = 13, 2, 8, (5 << 32) | 77, 3, 2, 9
+    out = A4()
+    oracle_lib.oracle_philox4x32_10(A4(idx & 0xffffffff, ((idx >> 32) & 0xffff) | (retry << 16), (dom << 24) | att, slot >> 1), A2(seed, contig), out)
+    want = ((out[2] << 21) | (out[3] >> 11)) * 2.0 ** -53
+    assert oracle_lib.oracle_philox_uniform(seed, contig, dom, idx, att, retry, slot) == want
+    assert 0.0 <= want < 1.0
+
+
+def test_det_log_accuracy(oracle_lib):
+    rnd = random.Random(1)
+    worst = 0
+    for _ in range(200000):
+        x = rnd.random() if rnd.random() < 0.8 else math.ldexp(rnd.random() + 0.5, rnd.randint(-110, 3))
+        if x <= 0:
+            continue
+        a, b = oracle_lib.oracle_det_log(x), math.log(x)
+        ia, ib = struct.unpack("<q", struct.pack("<d", a))[0], struct.unpack("<q", struct.pack("<d", b))[0]
+        worst = max(worst, abs(ia - ib))
+    assert worst <= 1, worst   # within 1 ulp of glibc everywhere
+    assert oracle_lib.oracle_det_log(1.0) == 0.0
