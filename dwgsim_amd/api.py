@@ -1,0 +1,309 @@
+"""ctypes binding of the C-ABI in include/dwgsim_hip.h (libdwgsim_hip.so) plus a thin driver that
+follows dwgsim_core()'s contig loop (reference src/dwgsim.c:419-1121) over that ABI.
+
+This module is plumbing for tests and bench.py; the product is the shared library.  It never falls
+back to a CPU implementation: if the library or a HIP device is missing it raises.
+"""
+from __future__ import annotations
+import ctypes as C
+import os
+import shlex
+from dataclasses import dataclass, field
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdwgsim_hip.so")
+
+STREAM_BWA1, STREAM_BWA2, STREAM_BFAST = 0, 1, 2
+STREAM_NAMES = {0: "bwa.read1.fastq", 1: "bwa.read2.fastq", 2: "bfast.fastq"}
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("e_start", C.c_double * 2), ("e_end", C.c_double * 2),
+        ("is_inner", C.c_int32), ("dist", C.c_int32), ("std_dev", C.c_double),
+        ("N", C.c_int64), ("C", C.c_double), ("length", C.c_int32 * 2),
+        ("mut_rate", C.c_double), ("mut_freq", C.c_double), ("indel_frac", C.c_double), ("indel_extend", C.c_double),
+        ("indel_min", C.c_int32), ("rand_read", C.c_double), ("max_n", C.c_int32), ("data_type", C.c_int32),
+        ("strandedness", C.c_int32), ("read_one_strand", C.c_int32), ("is_hap", C.c_int32), ("seed", C.c_int32),
+        ("fixed_quality", C.c_int32), ("quality_std", C.c_double), ("reads_output_type", C.c_int32),
+        ("output_type", C.c_int32), ("amplicons", C.c_int32), ("read_prefix", C.c_char_p), ("flow_order", C.c_char_p),
+        ("use_base_error", C.c_int32),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_random", C.c_uint64), ("n_retries", C.c_uint64), ("bytes", C.c_uint64 * 3),
+                ("dev_ptr", C.c_void_p * 3), ("kernel_ms", C.c_float), ("sim_kernel_ms", C.c_float)]
+
+
+EXPORTS = [
+    "dwgsim_hip_params_default", "dwgsim_hip_params_check", "dwgsim_hip_pairs_for_contig", "dwgsim_hip_create",
+    "dwgsim_hip_destroy", "dwgsim_hip_last_error", "dwgsim_hip_add_contig", "dwgsim_hip_drop_contig",
+    "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
+    "dwgsim_hip_fetch", "dwgsim_hip_device_info",
+]
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load the shared library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    lib = C.CDLL(p)
+    P = C.POINTER
+    lib.dwgsim_hip_params_default.argtypes = [P(Params)]
+    lib.dwgsim_hip_params_check.argtypes = [P(Params), C.c_char_p, C.c_size_t]
+    lib.dwgsim_hip_pairs_for_contig.restype = C.c_int64
+    lib.dwgsim_hip_pairs_for_contig.argtypes = [P(Params), C.c_int64, C.c_uint64, C.c_int, C.c_int64]
+    lib.dwgsim_hip_create.restype = C.c_void_p
+    lib.dwgsim_hip_create.argtypes = [P(Params), C.c_int, P(C.c_int)]
+    lib.dwgsim_hip_destroy.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_last_error.restype = C.c_char_p
+    lib.dwgsim_hip_last_error.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_uint32]
+    lib.dwgsim_hip_drop_contig.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_mutate_contig.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_mutations_text.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_size_t), P(C.c_void_p), P(C.c_size_t)]
+    lib.dwgsim_hip_count_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, P(C.c_uint64)]
+    lib.dwgsim_hip_simulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, P(Batch)]
+    lib.dwgsim_hip_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.dwgsim_hip_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, P(C.c_int), P(C.c_size_t)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class DwgsimError(RuntimeError):
+    pass
+
+
+def default_params(lib=None) -> Params:
+    lib = lib or load()
+    p = Params()
+    lib.dwgsim_hip_params_default(C.byref(p))
+    return p
+
+
+def _error_rate(s: str):
+    """dwgsim_opt.c:162-179 get_error_rate: 'a', 'a-b' or 'a,b'."""
+    import re
+    m = re.match(r"^([^,\-]*)[,\-]?(.*)$", s)
+    start = float(m.group(1))
+    sep = None
+    for i, ch in enumerate(s):
+        if ch in ",-":
+            sep = i
+            break
+    if sep is not None and sep < len(s) - 1:
+        return start, float(s[sep + 1:])
+    return start, start
+
+
+def parse_flags(flags: str, lib=None) -> Params:
+    """The dwgsim getopt surface (dwgsim_opt.c:211) for the options on the accelerated path."""
+    p = default_params(lib)
+    toks = shlex.split(flags)
+    i = 0
+    keep = []
+    while i < len(toks):
+        t = toks[i]
+        def arg():
+            nonlocal i
+            i += 1
+            return toks[i]
+        if t == "-i": p.is_inner = 1
+        elif t == "-d": p.dist = int(arg())
+        elif t == "-s": p.std_dev = float(arg())
+        elif t == "-N": p.N = int(arg()); p.C = -1
+        elif t == "-C": p.C = float(arg()); p.N = -1
+        elif t == "-1": p.length[0] = int(arg())
+        elif t == "-2": p.length[1] = int(arg())
+        elif t == "-e": p.e_start[0], p.e_end[0] = _error_rate(arg())
+        elif t == "-E": p.e_start[1], p.e_end[1] = _error_rate(arg())
+        elif t == "-r": p.mut_rate = float(arg())
+        elif t == "-F": p.mut_freq = float(arg())
+        elif t == "-R": p.indel_frac = float(arg())
+        elif t == "-X": p.indel_extend = float(arg())
+        elif t == "-I": p.indel_min = int(arg())
+        elif t == "-c": p.data_type = int(arg())
+        elif t == "-S": p.strandedness = int(arg())
+        elif t == "-A": p.read_one_strand = int(arg())
+        elif t == "-n": p.max_n = int(arg())
+        elif t == "-y": p.rand_read = float(arg())
+        elif t == "-H": p.is_hap = 1
+        elif t == "-z": p.seed = int(arg())
+        elif t == "-M": p.output_type = int(arg())
+        elif t == "-P": keep.append(arg().encode()); p.read_prefix = keep[-1]
+        elif t == "-q": p.fixed_quality = ord(arg()[0])
+        elif t == "-Q": p.quality_std = float(arg())
+        elif t == "-o": p.reads_output_type = int(arg())
+        elif t == "-a": p.amplicons = 1
+        else:
+            raise DwgsimError(f"option {t} is not on the accelerated path")
+        i += 1
+    p._keep = keep
+    return p
+
+
+def read_fasta(path: str):
+    """seq_read_fasta (mut.c:49-87): name = first token of the header; keeps isalpha, '-' and '.'."""
+    import numpy as np
+    out = []
+    name, chunks = None, []
+    with open(path, "rb") as f:
+        data = f.read()
+    # split on '>' at any position, as the reference's fgetc loop does
+    for rec in data.split(b">")[1:]:
+        nl = rec.find(b"\n")
+        header, body = (rec, b"") if nl < 0 else (rec[:nl], rec[nl + 1:])
+        header = header.replace(b"\r", b"")
+        name = header.split(b" ")[0].split(b"\t")[0].decode()
+        arr = np.frombuffer(body, dtype=np.uint8)
+        keep = ((arr >= 65) & (arr <= 90)) | ((arr >= 97) & (arr <= 122)) | (arr == 45) | (arr == 46)
+        out.append((name, np.ascontiguousarray(arr[keep])))
+    return out
+
+
+@dataclass
+class JobResult:
+    streams: dict = field(default_factory=dict)      # stream id -> bytes
+    mutations_txt: bytes = b""
+    mutations_vcf: bytes = b""
+    n_pairs: int = 0
+    n_random: int = 0
+    n_retries: int = 0
+    kernel_ms: float = 0.0
+    sim_kernel_ms: float = 0.0
+    walk_ms: float = 0.0
+
+
+VCF_HEADER_POST = (
+    b"##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n"
+    b"##INFO=<ID=pl,Number=1,Type=Integer,Description=\"Phasing: 1 - HET contig 1, #2 - HET contig #2, 3 - HOM both contigs\">\n"
+    b"##INFO=<ID=mt,Number=1,Type=String,Description=\"Variant Type: SUBSTITUTE/INSERT/DELETE\">\n"
+    b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+
+
+class Context:
+    """One GPU context (one per device / per rank)."""
+
+    def __init__(self, params: Params, device: int = 0, lib=None):
+        self.lib = lib or load()
+        self.params = params
+        err = C.c_int(0)
+        self.h = self.lib.dwgsim_hip_create(C.byref(params), device, C.byref(err))
+        if not self.h:
+            raise DwgsimError(f"dwgsim_hip_create failed with code {err.value} (no HIP device? there is no CPU fallback)")
+
+    def close(self):
+        if self.h:
+            self.lib.dwgsim_hip_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise DwgsimError(f"error {rc}: {self.lib.dwgsim_hip_last_error(self.h).decode(errors='replace')}")
+        return rc
+
+    def add_contig(self, name: str, ascii_arr, contig_index: int) -> int:
+        import numpy as np
+        arr = np.ascontiguousarray(ascii_arr, dtype=np.uint8)
+        return self._chk(self.lib.dwgsim_hip_add_contig(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p), len(arr), contig_index))
+
+    def drop_contig(self, cid: int):
+        self._chk(self.lib.dwgsim_hip_drop_contig(self.h, cid))
+
+    def mutate(self, cid: int):
+        self._chk(self.lib.dwgsim_hip_mutate_contig(self.h, cid))
+
+    def mutations_text(self, cid: int):
+        t, v = C.c_void_p(), C.c_void_p()
+        tl, vl = C.c_size_t(), C.c_size_t()
+        self._chk(self.lib.dwgsim_hip_mutations_text(self.h, cid, C.byref(t), C.byref(tl), C.byref(v), C.byref(vl)))
+        return C.string_at(t, tl.value) if tl.value else b"", C.string_at(v, vl.value) if vl.value else b""
+
+    def count_random(self, cid: int, first_ii: int, n_pairs: int) -> int:
+        n = C.c_uint64(0)
+        self._chk(self.lib.dwgsim_hip_count_random(self.h, cid, first_ii, n_pairs, C.byref(n)))
+        return n.value
+
+    def simulate(self, cid: int, first_ii: int, n_pairs: int, rand_base: int, slot: int = 0) -> Batch:
+        b = Batch()
+        self._chk(self.lib.dwgsim_hip_simulate(self.h, cid, first_ii, n_pairs, rand_base, slot, C.byref(b)))
+        return b
+
+    def fetch(self, slot: int, stream: int, nbytes: int) -> bytes:
+        buf = C.create_string_buffer(int(nbytes) if nbytes else 1)
+        self._chk(self.lib.dwgsim_hip_fetch(self.h, slot, stream, buf, nbytes))
+        return buf.raw[:nbytes]
+
+
+def pairs_for_contig(params: Params, l: int, tot_len: int, is_last: bool, n_sim: int, lib=None) -> int:
+    lib = lib or load()
+    return lib.dwgsim_hip_pairs_for_contig(C.byref(params), l, tot_len, 1 if is_last else 0, n_sim)
+
+
+def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None) -> JobResult:
+    """dwgsim_core (dwgsim.c:419-1121) over the C-ABI: header pass, then per contig
+    schedule -> mutate -> mutations text -> simulate in read-index batches."""
+    lib = lib or load()
+    res = JobResult(streams={0: bytearray(), 1: bytearray(), 2: bytearray()})
+    tot_len = sum(len(a) for _, a in contigs)
+    want_mut = params.output_type != 1
+    want_reads = params.output_type != 2
+    vcf = bytearray()
+    txt = bytearray()
+    if want_mut:
+        vcf += b"##fileformat=VCFv4.1\n"
+        for name, arr in contigs:
+            vcf += f"##contig=<ID={name},length={len(arr)}>\n".encode()
+        vcf += VCF_HEADER_POST
+    n_sim = 0
+    rand_ii = 0
+    n_ref = len(contigs)
+    with Context(params, device, lib) as ctx:
+        for ci, (name, arr) in enumerate(contigs):
+            n_ref -= 1
+            n_pairs = 0
+            if want_reads:
+                n_pairs = pairs_for_contig(params, len(arr), tot_len, n_ref == 0, n_sim, lib)
+                if n_pairs < 0:
+                    continue                      # skip rules #2-#5: no mutations either (dwgsim.c:596-623)
+            cid = ctx.add_contig(name, arr, ci)
+            ctx.mutate(cid)
+            if want_mut:
+                t, v = ctx.mutations_text(cid)
+                txt += t
+                vcf += v
+            first = 0
+            while want_reads and first < n_pairs:
+                n = min(batch_pairs, n_pairs - first)
+                b = ctx.simulate(cid, first, n, rand_ii, 0)
+                res.kernel_ms += b.kernel_ms
+                res.sim_kernel_ms += b.sim_kernel_ms
+                res.n_retries += b.n_retries
+                if fetch:
+                    for s in range(3):
+                        if b.bytes[s]:
+                            res.streams[s] += ctx.fetch(0, s, b.bytes[s])
+                rand_ii += b.n_random
+                first += n
+                n_sim += n
+            ctx.drop_contig(cid)
+    res.n_pairs = n_sim
+    res.n_random = rand_ii
+    res.mutations_txt = bytes(txt)
+    res.mutations_vcf = bytes(vcf)
+    res.streams = {k: bytes(v) for k, v in res.streams.items()}
+    return res

@@ -1,0 +1,169 @@
+// dw_common.hpp -- device-side primitives of the MI355X dwgsim hot path:
+// Philox4x32-10 counter RNG, the 53-bit uniform, the pure-IEEE natural log, agent-scope
+// status words and wave64 helpers.  gfx950 only (wave = 64 lanes).
+//
+// RNG layout (DESIGN.md "RNG layout"; this is the product's own definition of the
+// "matched RNG" stream that replaces the reference's sequential drand48):
+//   key     = (uint32 seed, uint32 contig_index)
+//   counter = ( index[31:0],  index[47:32] | retry << 16,  domain << 24 | attempt,  block )
+//   block b yields two uniforms: slot 2b = u53(w0,w1), slot 2b+1 = u53(w2,w3),
+//   u53(hi,lo) = ((hi << 21) | (lo >> 11)) * 2^-53   (exact in fp64).
+#pragma once
+#include <stdint.h>
+
+#define DW_DEV __device__ __forceinline__
+// dynamic LDS of a kernel (the test-only CPU emulation in tests/emu substitutes a heap buffer)
+#ifndef DW_EMU
+#define DW_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#else
+#define DW_DYN_SHARED(type, name) type *name = (type *)hipemu::dyn_shared()
+#endif
+
+namespace dw {
+
+// domains
+enum : uint32_t {
+    D_WALK = 1,         // index = position.  slot 0 deletion-extend (mut.c:611), 1 mutate (mut.c:618),
+                        // 2 substitution-vs-indel (:619), 3 new base (:620) / deletion-vs-insertion (:628),
+                        // 4 hom test (:622,:629, mut.c:301), 5 het haplotype (:625,:633, mut.c:303)
+    D_WALK_INSLEN = 2,  // slot k = k-th insertion length-extension test (mut.c:292)
+    D_WALK_INSBASE = 3, // slot k = k-th inserted-base draw (mut.c:314 / :351)
+    D_PAIR = 4,         // index = ii.  slot 0 random-read test (dwgsim.c:649), 1 haplotype (:716), 2 strand (:723)
+    D_PLACE = 5,        // slot t = position uniform of placement try t (dwgsim.c:671)
+    D_PLACE_NORM = 6,   // block t, retry r = polar tries of the insert-size normal of try t (dwgsim.c:657)
+    D_BASE0 = 8,        // +read end.  block i: slot 2i error test (dwgsim.c:237) or random base (:1000), 2i+1 substituted base (:238)
+    D_QUAL0 = 10,       // +read end.  block p, retry r: polar tries; accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) (dwgsim.c:912)
+    D_FLOW0 = 12        // +read end.  sequential slots inside generate_errors_flows (dwgsim.c:246-417)
+};
+
+struct U4 { uint32_t x, y, z, w; };
+
+DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+struct RngKey { uint32_t seed, contig; };
+
+DW_DEV U4 rng_block(RngKey k, uint32_t dom, uint64_t idx, uint32_t att, uint32_t retry, uint32_t block)
+{
+    return philox4x32_10((uint32_t)idx, (uint32_t)((idx >> 32) & 0xFFFFu) | (retry << 16), (dom << 24) | (att & 0xFFFFFFu), block, k.seed, k.contig);
+}
+
+DW_DEV double u53(uint32_t hi, uint32_t lo)
+{
+    return (double)(((uint64_t)hi << 21) | (uint64_t)(lo >> 11)) * 0x1p-53;
+}
+DW_DEV double u_lo(const U4 &b) { return u53(b.x, b.y); }   // even slot of the block
+DW_DEV double u_hi(const U4 &b) { return u53(b.z, b.w); }   // odd slot of the block
+
+DW_DEV double rng_slot(RngKey k, uint32_t dom, uint64_t idx, uint32_t att, uint32_t slot)
+{
+    const U4 b = rng_block(k, dom, idx, att, 0, slot >> 1);
+    return (slot & 1) ? u_hi(b) : u_lo(b);
+}
+
+DW_DEV uint64_t dbl_bits(double x) { union { double d; uint64_t u; } c; c.d = x; return c.u; }
+DW_DEV double bits_dbl(uint64_t u) { union { double d; uint64_t u; } c; c.u = u; return c.d; }
+
+// Natural log for finite x > 0 with only IEEE-754 fp64 + - * / (compile with -ffp-contract=off):
+// argument reduction x = 2^k (1+f), s = f/(2+f), even polynomial in s -- the classic fdlibm
+// e_log algorithm ("(c) 1993 Sun Microsystems, Inc. Permission to use, copy, modify, and
+// distribute this software is freely granted, provided that this notice is preserved").
+// Bit-identical on gfx950 and x86-64; the libm/ocml logs are not.
+DW_DEV double det_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t b = dbl_bits(x);
+    int32_t hx = (int32_t)(b >> 32), k = 0;
+    if (hx < 0x00100000) { x *= 0x1p54; k = -54; b = dbl_bits(x); hx = (int32_t)(b >> 32); }
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = bits_dbl(((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (b & 0xFFFFFFFFull));
+    k += (i >> 20);
+    const double f = x - 1.0, dk = (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    i = (hx - 0x6147a) | (0x6b851 - hx);
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// ---- wave64 helpers (all 64 lanes must call) ----
+DW_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+
+DW_DEV uint32_t wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane_id() >= d) v += o; }
+    return v;
+}
+DW_DEV uint64_t shfl_down_u64(uint64_t v, int d)
+{
+    uint32_t lo = __shfl_down((uint32_t)v, d), hi = __shfl_down((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+DW_DEV uint64_t wave_sum_u64(uint64_t v)   // result valid in lane 0, broadcast to all
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
+    uint32_t lo = __shfl((uint32_t)v, 0), hi = __shfl((uint32_t)(v >> 32), 0);
+    return ((uint64_t)hi << 32) | lo;
+}
+DW_DEV uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+    return __shfl(v, 0);
+}
+
+// ---- decoupled look-back status words: one naturally aligned 8-byte {flag:2, value:62},
+// written and read with relaxed agent-scope atomics (no payload besides the word itself) ----
+constexpr uint64_t ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_VAL = (1ull << 62) - 1;
+
+DW_DEV void status_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DW_DEV uint64_t status_load(uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Exclusive prefix of `aggregate` over logical blocks 0..t-1 (+ base).  Called by one whole wave;
+// logical block ids come from an atomic ticket, so every predecessor has already started.
+DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, uint64_t base)
+{
+    const int lane = lane_id();
+    if (t == 0) { if (lane == 0) status_store(&status[0], ST_PREFIX | ((base + aggregate) & ST_VAL)); return base; }
+    if (lane == 0) status_store(&status[t], ST_AGG | (aggregate & ST_VAL));
+    uint64_t excl = 0;
+    int64_t k = (int64_t)t - 1;
+    for (;;) {
+        const int64_t idx = k - lane;
+        uint64_t v = ST_PREFIX;             // below block 0: an empty prefix
+        if (idx >= 0) { do { v = status_load(&status[idx]); if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2); } while ((v >> 62) == 0); }
+        const uint64_t pm = __ballot((v >> 62) == 2);
+        const int first = pm ? (__ffsll((unsigned long long)pm) - 1) : 64;
+        excl += wave_sum_u64(lane <= first ? (v & ST_VAL) : 0);
+        if (pm) break;
+        k -= 64;
+    }
+    if (lane == 0) status_store(&status[t], ST_PREFIX | ((excl + aggregate) & ST_VAL));
+    return excl;
+}
+
+} // namespace dw

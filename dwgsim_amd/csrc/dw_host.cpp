@@ -1,0 +1,590 @@
+// dw_host.cpp -- C-ABI (include/dwgsim_hip.h) over the HIP kernels of dw_kernels.hip.
+//
+// Host responsibilities, mirroring what dwgsim_core() does around its two hot loops:
+//   * option defaults / checks / error-ramp tables      (dwgsim_opt.c:40-80, :307-371, :459-460)
+//   * contig scheduling arithmetic                       (dwgsim.c:535-537, :582-590, :595-618)
+//   * device residency of contigs and mutated haplotypes (replaces seq_t / mutseq_t, mut.h:12-47)
+//   * mutations.txt / .vcf text from the sparse list of mutated cells (mut.c:781-893)
+// There is no CPU implementation of the hot path here: without a HIP device create() fails.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <stdarg.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/dwgsim_hip.h"
+#include "dw_kernels.hpp"
+#include "dw_launch.hpp"
+
+using namespace dw;
+
+namespace {
+
+struct Contig {
+    std::string name;
+    std::vector<uint8_t> ascii;        // host copy (reference bases for the txt/vcf writer)
+    int64_t l = 0;
+    uint32_t contig_index = 0;
+    bool alive = false, mutated = false;
+    uint8_t *d_ref = nullptr, *d_cells[2] = {nullptr, nullptr};
+    int32_t *d_ins_pos[2] = {nullptr, nullptr};
+    uint32_t *d_ins_len[2] = {nullptr, nullptr}, *d_ins_off[2] = {nullptr, nullptr};
+    uint8_t *d_ins_bases[2] = {nullptr, nullptr};
+    uint32_t n_ins[2] = {0, 0}, n_ins_bases[2] = {0, 0};
+    uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
+    uint32_t n_cand = 0, n_events_live = 0;
+};
+
+struct DevBuf {                     // grow-only device buffer
+    void *p = nullptr; size_t cap = 0;
+};
+
+} // namespace
+
+struct dwgsim_hip_ctx {
+    dwgsim_hip_params_t prm;
+    std::string read_prefix;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+    double e_by[2] = {0, 0};
+    double *d_thr[2] = {nullptr, nullptr};
+    int8_t *d_qbase[2] = {nullptr, nullptr};
+    uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
+    std::vector<Contig> contigs;
+    // simulate() working set
+    DevBuf meta, block_rand, status[2], out[2][3], scratch_mask, scratch_cnt;
+    uint64_t *d_counters = nullptr;          // 8 x u64
+    uint64_t *h_counters = nullptr;          // pinned mirror
+    uint64_t out_bytes[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
+    std::string txt, vcf;
+};
+
+namespace {
+
+#define HIPC(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { char b_[512]; snprintf(b_, sizeof b_, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); (ctx)->err = b_; return DWGSIM_HIP_ERR_DEVICE; } } while (0)
+
+int ensure(dwgsim_hip_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIPC(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    HIPC(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+uint8_t nt4(int ch)      // dwgsim.c:56-73
+{
+    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
+}
+
+WalkParams walk_params(const dwgsim_hip_ctx *c)
+{
+    WalkParams w; w.mut_rate = c->prm.mut_rate; w.indel_frac = c->prm.indel_frac; w.indel_extend = c->prm.indel_extend;
+    w.indel_min = c->prm.indel_min; w.is_hap = c->prm.is_hap; w.seed = (uint32_t)c->prm.seed;
+    return w;
+}
+
+ContigDev contig_dev(const Contig &k)
+{
+    ContigDev d;
+    for (int h = 0; h < 2; ++h) {
+        d.hap[h].cells = k.d_cells[h]; d.hap[h].ins_pos = k.d_ins_pos[h]; d.hap[h].ins_len = k.d_ins_len[h];
+        d.hap[h].ins_off = k.d_ins_off[h]; d.hap[h].ins_bases = k.d_ins_bases[h]; d.hap[h].n_ins = k.n_ins[h];
+    }
+    d.ref = k.d_ref; d.l = k.l; d.contig_index = k.contig_index;
+    return d;
+}
+
+void free_contig(Contig &k)
+{
+    hipFree(k.d_ref);
+    for (int h = 0; h < 2; ++h) { hipFree(k.d_cells[h]); hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]); }
+    hipFree(k.d_name_fixed);
+    k = Contig();
+}
+
+} // namespace
+
+extern "C" {
+
+void dwgsim_hip_params_default(dwgsim_hip_params_t *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->e_start[0] = p->e_end[0] = p->e_start[1] = p->e_end[1] = 0.02;
+    p->dist = 500; p->std_dev = 50; p->N = -1; p->C = 100;
+    p->length[0] = p->length[1] = 70;
+    p->mut_rate = 0.001; p->mut_freq = 0.5; p->indel_frac = 0.1; p->indel_extend = 0.3; p->indel_min = 1;
+    p->rand_read = 0.05; p->seed = -1; p->fixed_quality = -1; p->quality_std = 2.0;
+}
+
+#define CHK(v, lo, hi, nm) do { if ((v) < (lo) || (hi) < (v)) { if (msg) snprintf(msg, cap, "Error: command line option %s was out of range\n", nm); return DWGSIM_HIP_ERR_ARG; } } while (0)
+
+int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap)
+{
+    if (msg && cap) msg[0] = 0;
+    CHK(p->is_inner, 0, 1, "-i"); CHK(p->dist, 0, INT32_MAX, "-d"); CHK(p->std_dev, 0, INT32_MAX, "-s");
+    if (p->N < 0 && p->C < 0) { if (msg) snprintf(msg, cap, "Must use one of -N or -C"); return DWGSIM_HIP_ERR_ARG; }
+    else if (0 < p->N && 0 < p->C) { if (msg) snprintf(msg, cap, "Cannot use both -N or -C"); return DWGSIM_HIP_ERR_ARG; }
+    else if (0 < p->N) { CHK(p->N, 1, INT32_MAX, "-N"); CHK(p->C, INT32_MIN, -1, "-C"); }
+    else { CHK(p->N, INT32_MIN, -1, "-N"); CHK(p->C, 0, INT32_MAX, "-C"); }
+    CHK(p->length[0], 1, INT32_MAX, "-1"); CHK(p->length[1], 0, INT32_MAX, "-2");
+    for (int i = 0; i < 2; ++i) {
+        if (p->e_start[i] < 0.0 || 1.0 < p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: the start error is out of range (-e)\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
+        if (p->e_end[i] < 0.0 || 1.0 < p->e_end[i]) { if (msg) snprintf(msg, cap, "End %s: the end error is out of range (-e)\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
+    }
+    CHK(p->mut_rate, 0, 1.0, "-r"); CHK(p->indel_frac, 0, 1.0, "-R"); CHK(p->indel_extend, 0, 1.0, "-X");
+    CHK(p->indel_min, 1, INT32_MAX, "-I"); CHK(p->data_type, 0, 2, "-c"); CHK(p->strandedness, 0, 2, "-S");
+    CHK(p->read_one_strand, 0, 2, "-A"); CHK(p->max_n, 0, INT32_MAX, "-n"); CHK(p->rand_read, 0, 1.0, "-y");
+    CHK(p->use_base_error, 0, 1, "-B"); CHK(p->is_hap, 0, 1, "-H");
+    CHK(p->quality_std, 0, INT32_MAX, "-Q"); CHK(p->reads_output_type, 0, 2, "-o"); CHK(p->output_type, 0, 2, "-M"); CHK(p->amplicons, 0, 1, "-a");
+    if (p->data_type == 2 && !p->flow_order) { if (msg) snprintf(msg, cap, "Error: command line option -f is required\n"); return DWGSIM_HIP_ERR_ARG; }
+    if (p->data_type != 0) { if (msg) snprintf(msg, cap, "dwgsim-hip: -c %d (SOLiD / Ion Torrent) is not on the accelerated path yet\n", p->data_type); return DWGSIM_HIP_ERR_UNSUP; }
+    if (p->seed < 0) { if (msg) snprintf(msg, cap, "dwgsim-hip: the seed must be resolved (>= 0) before the context is created\n"); return DWGSIM_HIP_ERR_ARG; }
+    return DWGSIM_HIP_OK;
+}
+
+int64_t dwgsim_hip_pairs_for_contig(const dwgsim_hip_params_t *p, int64_t l, uint64_t tot_len, int is_last_contig, int64_t n_sim_so_far)
+{
+    int64_t n_pairs = 0;
+    const int size0 = p->length[0], size1 = p->length[1];
+    if (is_last_contig && p->C < 0) n_pairs = p->N - n_sim_so_far;                                  // dwgsim.c:535-537
+    else if (0 < p->N) {                                                                            // :582-586
+        n_pairs = (int64_t)(uint64_t)((long double)l / tot_len * p->N + 0.5);
+        if (p->N - n_sim_so_far < n_pairs) n_pairs = p->N - n_sim_so_far;
+    } else n_pairs = (int64_t)(uint64_t)(l * p->C / ((long double)(size0 + size1)) / (1.0 - p->rand_read) + 0.5);   // :589
+    const int max_len = size0 > size1 ? size0 : size1;
+    if (p->amplicons == 1) { if (l < max_len) return -2; }                                          // #2 :596-603
+    else if (0 < size1 && l < p->dist + 3 * p->std_dev) return -3;                                 // #3 :605-611
+    else if (l < size0 || (0 < size1 && l < size1)) return -4;                                     // #4 :612-618
+    return n_pairs < 0 ? -5 : n_pairs;
+}
+
+int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes)
+{
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess) return DWGSIM_HIP_ERR_DEVICE;
+    if (name && cap) snprintf(name, cap, "%s (%s)", pr.name, pr.gcnArchName);
+    if (n_cu) *n_cu = pr.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = pr.totalGlobalMem;
+    return DWGSIM_HIP_ABI_VERSION;
+}
+
+static int set_err(int *err, int v) { if (err) *err = v; return v; }
+
+dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, int *err)
+{
+    char msg[512];
+    int rc = dwgsim_hip_params_check(p, msg, sizeof msg);
+    if (rc != DWGSIM_HIP_OK) { fprintf(stderr, "%s", msg); set_err(err, rc); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+        fprintf(stderr, "dwgsim-hip: no usable HIP device (requested %d of %d); the hot path has no CPU fallback\n", device, ndev);
+        set_err(err, DWGSIM_HIP_ERR_DEVICE); return nullptr;
+    }
+    dwgsim_hip_ctx *c = new dwgsim_hip_ctx();
+    c->prm = *p;
+    if (p->read_prefix) c->read_prefix = p->read_prefix;
+    c->prm.read_prefix = nullptr; c->prm.flow_order = nullptr;
+    c->device = device;
+    auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, DWGSIM_HIP_ERR_DEVICE); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
+    auto init = [&]() -> int {
+        HIPC(c, hipSetDevice(device));
+        HIPC(c, hipStreamCreate(&c->stream));
+        for (int i = 0; i < 4; ++i) HIPC(c, hipEventCreate(&c->ev[i]));
+        HIPC(c, hipMalloc((void **)&c->d_counters, 8 * sizeof(uint64_t)));
+        HIPC(c, hipHostMalloc((void **)&c->h_counters, 8 * sizeof(uint64_t), hipHostMallocDefault));
+        // per-position error thresholds and base qualities (dwgsim_opt.c:459-460, dwgsim.c:237, :906-910)
+        for (int j = 0; j < 2; ++j) {
+            const int n = c->prm.length[j];
+            if (n <= 0) continue;
+            c->e_by[j] = (c->prm.e_end[j] - c->prm.e_start[j]) / n;
+            std::vector<double> thr((size_t)n); std::vector<int8_t> qb((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                const double ei = c->prm.e_start[j] + c->e_by[j] * i;
+                thr[(size_t)i] = ei;
+                char q;
+                if (ei > 0) q = (char)((int)(-10.0 * log(ei) / log(10.0) + 0.499) + '!'); else q = 40 + '!';
+                qb[(size_t)i] = (int8_t)q;
+            }
+            HIPC(c, hipMalloc((void **)&c->d_thr[j], sizeof(double) * (size_t)n));
+            HIPC(c, hipMalloc((void **)&c->d_qbase[j], (size_t)n));
+            HIPC(c, hipMemcpy(c->d_thr[j], thr.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+            HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
+        }
+        std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";
+        c->rand_fixed_len = (int32_t)rf.size();
+        HIPC(c, hipMalloc((void **)&c->d_rand_fixed, rf.size() + 16));
+        HIPC(c, hipMemcpy(c->d_rand_fixed, rf.data(), rf.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (init() != 0) return fail("context initialisation failed");
+    set_err(err, DWGSIM_HIP_OK);
+    return c;
+}
+
+void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &k : c->contigs) if (k.alive) free_contig(k);
+    for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_qbase[j]); hipFree(c->status[j].p); }
+    hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
+    for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
+    hipFree(c->d_counters);
+    if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *dwgsim_hip_last_error(const dwgsim_hip_ctx_t *c) { return c ? c->err.c_str() : "no context"; }
+
+int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *ascii, int64_t len, uint32_t contig_index)
+{
+    if (!c || !name || (!ascii && len > 0) || len < 0 || len > INT32_MAX) { if (c) c->err = "bad contig arguments"; return DWGSIM_HIP_ERR_ARG; }
+    HIPC(c, hipSetDevice(c->device));
+    int id = -1;
+    for (size_t i = 0; i < c->contigs.size(); ++i) if (!c->contigs[i].alive) { id = (int)i; break; }
+    if (id < 0) { c->contigs.emplace_back(); id = (int)c->contigs.size() - 1; }
+    Contig &k = c->contigs[(size_t)id];
+    k.name = name; k.l = len; k.contig_index = contig_index; k.ascii.assign(ascii, ascii + len); k.alive = true; k.mutated = false;
+    const size_t padded = (size_t)((len + 15) & ~(int64_t)15) + CELL_PAD;
+    uint8_t *d_ascii = nullptr;
+    HIPC(c, hipMalloc((void **)&d_ascii, padded));
+    HIPC(c, hipMalloc((void **)&k.d_ref, padded));
+    for (int h = 0; h < 2; ++h) HIPC(c, hipMalloc((void **)&k.d_cells[h], padded));
+    HIPC(c, hipMemcpyAsync(d_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemsetAsync(k.d_ref, 4, padded, c->stream));
+    for (int h = 0; h < 2; ++h) HIPC(c, hipMemsetAsync(k.d_cells[h], 4, padded, c->stream));
+    if (len > 0) launch_pack(c->stream, d_ascii, k.d_ref, k.d_cells[0], k.d_cells[1], len);
+    HIPC(c, hipGetLastError());
+    std::string nf = c->read_prefix.empty() ? k.name : c->read_prefix + "_" + k.name;
+    k.name_fixed_len = (int32_t)nf.size();
+    HIPC(c, hipMalloc((void **)&k.d_name_fixed, nf.size() + 16));
+    HIPC(c, hipMemcpyAsync(k.d_name_fixed, nf.data(), nf.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipFree(d_ascii));
+    return id;
+}
+
+int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *c, int contig)
+{
+    if (!c || contig < 0 || (size_t)contig >= c->contigs.size() || !c->contigs[(size_t)contig].alive) return DWGSIM_HIP_ERR_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_contig(c->contigs[(size_t)contig]);
+    return DWGSIM_HIP_OK;
+}
+
+static Contig *get_contig(dwgsim_hip_ctx_t *c, int contig)
+{
+    if (!c || contig < 0 || (size_t)contig >= c->contigs.size() || !c->contigs[(size_t)contig].alive) { if (c) c->err = "unknown contig handle"; return nullptr; }
+    return &c->contigs[(size_t)contig];
+}
+
+int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
+{
+    Contig *kp = get_contig(c, contig);
+    if (!kp) return DWGSIM_HIP_ERR_ARG;
+    Contig &k = *kp;
+    HIPC(c, hipSetDevice(c->device));
+    if (k.mutated) { c->err = "contig already mutated"; return DWGSIM_HIP_ERR_STATE; }
+    const WalkParams wp = walk_params(c);
+    const int64_t l = k.l;
+    k.mutated = true;
+    if (l == 0) return DWGSIM_HIP_OK;
+    const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
+    if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
+    uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
+    // K1: candidate sites -> ordered list
+    launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt);
+    launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
+    HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const uint32_t n_cand = (uint32_t)c->h_counters[7];
+    k.n_cand = n_cand;
+    if (n_cand == 0) return DWGSIM_HIP_OK;
+    int32_t *d_cand = nullptr; Event *d_ev = nullptr; uint4 *d_flags = nullptr; uint32_t *d_small = nullptr;   // d_small: [0] max_del, [1..4] tot4
+    HIPC(c, hipMalloc((void **)&d_cand, sizeof(int32_t) * (size_t)n_cand));
+    HIPC(c, hipMalloc((void **)&d_ev, sizeof(Event) * (size_t)n_cand));
+    HIPC(c, hipMalloc((void **)&d_flags, sizeof(uint4) * (size_t)n_cand));
+    HIPC(c, hipMalloc((void **)&d_small, 8 * sizeof(uint32_t)));
+    HIPC(c, hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), c->stream));
+    launch_compact(c->stream, d_mask, d_cnt, d_cand, l);
+    // K2: events, liveness, insertion-table allocation
+    launch_events(c->stream, d_cand, n_cand, k.d_ref, l, wp, k.contig_index, d_ev, &d_small[0]);
+    launch_resolve(c->stream, d_ev, n_cand, &d_small[0], d_flags, &d_small[1]);
+    uint32_t h_small[8];
+    HIPC(c, hipMemcpyAsync(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int h = 0; h < 2; ++h) {
+        k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h];
+        const size_t n = k.n_ins[h] ? k.n_ins[h] : 1, nb = k.n_ins_bases[h] ? k.n_ins_bases[h] : 1;
+        HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * n));
+        HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * n));
+        HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * n));
+        HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], nb + 16));
+    }
+    // K3 + K4
+    const ContigDev cd = contig_dev(k);
+    launch_apply(c->stream, d_ev, n_cand, d_flags, cd, wp);
+    launch_justify(c->stream, d_ev, n_cand, cd);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipFree(d_cand)); HIPC(c, hipFree(d_ev)); HIPC(c, hipFree(d_flags)); HIPC(c, hipFree(d_small));
+    return DWGSIM_HIP_OK;
+}
+
+// ---- mutations.txt / mutations.vcf from the sparse list of mutated cells (mut.c:781-893) ----
+namespace {
+struct HostIns { std::vector<int32_t> pos; std::vector<uint32_t> len, off; std::vector<uint8_t> bases; };
+const char *ins_text(const HostIns &t, int32_t pos, std::string &tmp)
+{
+    tmp.clear();
+    auto it = std::lower_bound(t.pos.begin(), t.pos.end(), pos);
+    if (it == t.pos.end() || *it != pos) return tmp.c_str();
+    const size_t k = (size_t)(it - t.pos.begin());
+    for (uint32_t q = 0; q < t.len[k]; ++q) tmp.push_back("ACGTN"[t.bases[t.off[k] + q] & 3]);
+    return tmp.c_str();
+}
+void appendf(std::string &s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void appendf(std::string &s, const char *fmt, ...)
+{
+    char buf[1024]; va_list ap; va_start(ap, fmt); int n = vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (n < (int)sizeof buf) { s.append(buf, (size_t)n); return; }
+    std::vector<char> big((size_t)n + 1); va_start(ap, fmt); vsnprintf(big.data(), big.size(), fmt, ap); va_end(ap); s.append(big.data(), (size_t)n);
+}
+} // namespace
+
+int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt, size_t *txt_len, const char **vcf, size_t *vcf_len)
+{
+    Contig *kp = get_contig(c, contig);
+    if (!kp) return DWGSIM_HIP_ERR_ARG;
+    Contig &k = *kp;
+    if (!k.mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    c->txt.clear(); c->vcf.clear();
+    const int64_t l = k.l;
+    std::vector<int32_t> pos; std::vector<uint16_t> cells;
+    HostIns ins[2];
+    if (l > 0 && k.n_cand > 0) {
+        const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
+        if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
+        if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
+        uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
+        launch_collect_mask(c->stream, k.d_cells[0], k.d_cells[1], l, d_mask, d_cnt);
+        launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
+        HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        const uint32_t n = (uint32_t)c->h_counters[7];
+        if (n) {
+            int32_t *d_pos = nullptr; uint16_t *d_cells = nullptr;
+            HIPC(c, hipMalloc((void **)&d_pos, sizeof(int32_t) * (size_t)n));
+            HIPC(c, hipMalloc((void **)&d_cells, sizeof(uint16_t) * (size_t)n));
+            launch_compact(c->stream, d_mask, d_cnt, d_pos, l);
+            launch_gather(c->stream, d_pos, n, k.d_cells[0], k.d_cells[1], d_cells);
+            pos.resize(n); cells.resize(n);
+            HIPC(c, hipMemcpyAsync(pos.data(), d_pos, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipMemcpyAsync(cells.data(), d_cells, sizeof(uint16_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, hipFree(d_pos)); HIPC(c, hipFree(d_cells));
+        }
+        for (int h = 0; h < 2; ++h) if (k.n_ins[h]) {
+            ins[h].pos.resize(k.n_ins[h]); ins[h].len.resize(k.n_ins[h]); ins[h].off.resize(k.n_ins[h]); ins[h].bases.resize(k.n_ins_bases[h]);
+            HIPC(c, hipMemcpy(ins[h].pos.data(), k.d_ins_pos[h], sizeof(int32_t) * k.n_ins[h], hipMemcpyDeviceToHost));
+            HIPC(c, hipMemcpy(ins[h].len.data(), k.d_ins_len[h], sizeof(uint32_t) * k.n_ins[h], hipMemcpyDeviceToHost));
+            HIPC(c, hipMemcpy(ins[h].off.data(), k.d_ins_off[h], sizeof(uint32_t) * k.n_ins[h], hipMemcpyDeviceToHost));
+            HIPC(c, hipMemcpy(ins[h].bases.data(), k.d_ins_bases[h], k.n_ins_bases[h], hipMemcpyDeviceToHost));
+        }
+    }
+    // sparse restatement of the per-position loop: only listed positions can print; "previous position
+    // mutated" (mut_prev, mut.c:890-891) is "position i-1 is listed with a mutated cell on that haplotype"
+    static const char B5[] = "ACGTN";       // B5[5] is the terminating NUL, as in the reference for code 5 ('-')
+    const char *nm = k.name.c_str();
+    std::string tmp;
+    auto cell = [&](size_t e, int h) -> uint8_t { return (uint8_t)(h ? cells[e] >> 8 : cells[e] & 0xff); };
+    for (size_t e = 0; e < pos.size(); ++e) {
+        const int64_t i = pos[e];
+        const uint8_t r0 = nt4(k.ascii[(size_t)i]), c1 = cell(e, 0), c2 = cell(e, 1);
+        if (r0 >= 4) continue;
+        const bool adj = e > 0 && pos[e - 1] == i - 1;
+        const bool prev0 = adj && (cell(e - 1, 0) & TMASK) != T_NONE, prev1 = adj && (cell(e - 1, 1) & TMASK) != T_NONE;
+        appendf(c->txt, "%s\t%lld\t", nm, (long long)i + 1);
+        const bool hom = (c1 & BTMASK) == (c2 & BTMASK);
+        const uint8_t t1 = c1 & TMASK, t2 = c2 & TMASK;
+        if (hom ? t1 == T_SUB : (t1 == T_SUB || t2 == T_SUB)) {
+            if (hom) {
+                appendf(c->txt, "%c\t%c\t3\n", B5[r0], B5[c1 & 0xf]);
+                appendf(c->vcf, "%s\t%lld\t.\t%c\t%c\t100\tPASS\tAF=1.0;pl=3;mt=SUBSTITUTE\n", nm, (long long)i + 1, B5[r0], B5[c1 & 0xf]);
+            } else {
+                const int hap = t1 == T_SUB ? 1 : 2;
+                appendf(c->txt, "%c\t%c\t%d\n", B5[r0], "XACMGRSVTWYHKDBN"[1 << (c1 & 3) | 1 << (c2 & 3)], hap);
+                appendf(c->vcf, "%s\t%lld\t.\t%c\t%c\t100\tPASS\tAF=0.5;pl=%d;mt=SUBSTITUTE\n", nm, (long long)i + 1, B5[r0], B5[(hap == 1 ? c1 : c2) & 0xf], hap);
+            }
+        } else if (hom ? t1 == T_DEL : (t1 == T_DEL || t2 == T_DEL)) {
+            const int pl = hom ? 3 : (t1 == T_DEL ? 1 : 2);
+            appendf(c->txt, "%c\t-\t%d\n", B5[r0], pl);
+            const bool open = hom ? (!prev0 || !prev1) : !(pl == 1 ? prev0 : prev1);
+            if (open) {      // one VCF record for the run, anchored at the previous reference base (mut.c:801-815)
+                appendf(c->vcf, "%s\t%lld\t.\t", nm, (long long)i);
+                if (i > 0) c->vcf.push_back(B5[nt4(k.ascii[(size_t)i - 1])]);
+                size_t ee = e; int64_t j = i;
+                for (;;) {
+                    c->vcf.push_back(B5[nt4(k.ascii[(size_t)j])]);
+                    if (j + 1 >= l) break;
+                    // cell at j+1: listed -> its cells, else unmutated
+                    if (ee + 1 < pos.size() && pos[ee + 1] == j + 1) {
+                        ++ee; ++j;
+                        const uint8_t a1 = cell(ee, 0), a2 = cell(ee, 1);
+                        const bool h2 = (a1 & BTMASK) == (a2 & BTMASK);
+                        if (!(h2 == hom && ((pl == 2 ? a2 : a1) & TMASK) == T_DEL)) break;
+                    } else break;
+                }
+                if (i > 0) appendf(c->vcf, "\t%c", B5[nt4(k.ascii[(size_t)i - 1])]); else c->vcf.append("\t.");
+                appendf(c->vcf, "\t100\tPASS\tAF=%s;pl=%d;mt=DELETE\n", hom ? "1.0" : "0.5", pl);
+            }
+        } else {
+            const int pl = hom ? 3 : (t1 == T_INS ? 1 : 2);
+            const char *seq = ins_text(ins[pl == 2 ? 1 : 0], (int32_t)i, tmp);
+            appendf(c->txt, "-\t%s\t%d\n", seq, pl);
+            appendf(c->vcf, "%s\t%lld\t.\t%c\t%c%s\t100\tPASS\tAF=%s;pl=%d;mt=INSERT\n", nm, (long long)i + 1, B5[r0], B5[r0], seq, hom ? "1.0" : "0.5", pl);
+        }
+    }
+    if (txt) *txt = c->txt.data();
+    if (txt_len) *txt_len = c->txt.size();
+    if (vcf) *vcf = c->vcf.data();
+    if (vcf_len) *vcf_len = c->vcf.size();
+    return DWGSIM_HIP_OK;
+}
+
+// ---- read simulation ----
+static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, SimArgs &a)
+{
+    const dwgsim_hip_params_t &p = c->prm;
+    memset(&a, 0, sizeof a);
+    a.p.std_dev = p.std_dev; a.p.mut_freq = p.mut_freq; a.p.rand_read = p.rand_read; a.p.quality_std = p.quality_std;
+    a.p.dist = p.dist; a.p.is_inner = p.is_inner; a.p.len[0] = p.length[0]; a.p.len[1] = p.length[1]; a.p.max_n = p.max_n;
+    a.p.strandedness = p.strandedness; a.p.read_one_strand = p.read_one_strand; a.p.amplicons = p.amplicons;
+    a.p.fixed_quality = p.fixed_quality; a.p.data_type = p.data_type;
+    a.p.has_bfast = p.reads_output_type != 1; a.p.has_bwa = p.reads_output_type != 2;
+    a.p.seed = (uint32_t)p.seed;
+    a.c = contig_dev(k);
+    a.first_ii = first_ii; a.n_pairs = n_pairs; a.rand_base = rand_base;
+    for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.qbase[j] = c->d_qbase[j]; }
+    a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
+    a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
+    const uint64_t nblk = (n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
+    if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    for (int j = 0; j < 2; ++j) if (ensure(c, c->status[j], sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
+    a.status[0] = (uint64_t *)c->status[0].p; a.status[1] = (uint64_t *)c->status[1].p;
+    const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
+    a.lds_words = (lmax + 7) / 8;
+    return 0;
+}
+
+int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t *n_random)
+{
+    Contig *kp = get_contig(c, contig);
+    if (!kp) return DWGSIM_HIP_ERR_ARG;
+    if (!kp->mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    if (n_random) *n_random = 0;
+    if (n_pairs == 0) return DWGSIM_HIP_OK;
+    SimArgs a;
+    if (build_sim_args(c, *kp, first_ii, n_pairs, 0, a)) return DWGSIM_HIP_ERR_DEVICE;
+    HIPC(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint64_t), c->stream));
+    launch_place(c->stream, a);
+    const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+    launch_scan_excl(c->stream, a.block_rand, nblk, &c->d_counters[3]);
+    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
+    if (n_random) *n_random = c->h_counters[3];
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, int slot, dwgsim_hip_batch_t *out)
+{
+    Contig *kp = get_contig(c, contig);
+    if (!kp || slot < 0 || slot > 1) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
+    if (!kp->mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    if (out) memset(out, 0, sizeof *out);
+    for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = 0;
+    if (n_pairs == 0) return DWGSIM_HIP_OK;
+    SimArgs a;
+    if (build_sim_args(c, *kp, first_ii, n_pairs, rand_base, a)) return DWGSIM_HIP_ERR_DEVICE;
+    // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
+    const dwgsim_hip_params_t &p = c->prm;
+    const int fixed_max = kp->name_fixed_len > c->rand_fixed_len ? kp->name_fixed_len : c->rand_fixed_len;
+    const size_t nreads = (size_t)n_pairs * (p.length[1] > 0 ? 2 : 1);
+    size_t cap[3] = {0, 0, 0};
+    for (int j = 0; j < 2; ++j) if (p.length[j] > 0) cap[j] = (size_t)n_pairs * (size_t)(1 + fixed_max + 120 + 3 + 2 * p.length[j] + 4);
+    cap[2] = cap[0] + cap[1];
+    if (!a.p.has_bwa) cap[0] = cap[1] = 0;
+    if (!a.p.has_bfast) cap[2] = 0;
+    (void)nreads;
+    for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
+    const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+    HIPC(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint64_t), c->stream));
+    for (int j = 0; j < 2; ++j) HIPC(c, hipMemsetAsync(a.status[j], 0, sizeof(uint64_t) * (size_t)nblk, c->stream));
+    HIPC(c, hipEventRecord(c->ev[0], c->stream));
+    launch_place(c->stream, a);
+    launch_scan_excl(c->stream, a.block_rand, nblk, &c->d_counters[3]);
+    HIPC(c, hipEventRecord(c->ev[1], c->stream));
+    launch_simulate(c->stream, a);
+    HIPC(c, hipEventRecord(c->ev[2], c->stream));
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
+    for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];
+    if (out) {
+        out->n_pairs = n_pairs; out->n_random = c->h_counters[3]; out->n_retries = c->h_counters[1];
+        for (int t = 0; t < 3; ++t) { out->bytes[t] = c->out_bytes[slot][t]; out->dev_ptr[t] = c->out[slot][t].p; }
+        HIPC(c, hipEventElapsedTime(&out->kernel_ms, c->ev[0], c->ev[2]));
+        HIPC(c, hipEventElapsedTime(&out->sim_kernel_ms, c->ev[1], c->ev[2]));
+    }
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)
+{
+    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) return DWGSIM_HIP_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->out_bytes[slot][stream];
+    if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
+    if (n == 0) return DWGSIM_HIP_OK;
+    // double-buffered pinned staging: D2H of chunk k+1 overlaps the host copy of chunk k
+    const size_t CH = (size_t)16 << 20;
+    if (!c->h_stage) { HIPC(c, hipHostMalloc(&c->h_stage, 2 * CH, hipHostMallocDefault)); c->h_stage_cap = 2 * CH; }
+    const uint8_t *src = (const uint8_t *)c->out[slot][stream].p;
+    uint8_t *stage[2] = {(uint8_t *)c->h_stage, (uint8_t *)c->h_stage + CH};
+    size_t done = 0; int b = 0;
+    size_t cur = n < CH ? n : CH;
+    HIPC(c, hipMemcpyAsync(stage[0], src, cur, hipMemcpyDeviceToHost, c->stream));
+    while (done < n) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        const size_t next_off = done + cur, next = next_off < n ? ((n - next_off) < CH ? (n - next_off) : CH) : 0;
+        if (next) HIPC(c, hipMemcpyAsync(stage[b ^ 1], src + next_off, next, hipMemcpyDeviceToHost, c->stream));
+        memcpy((uint8_t *)host_dst + done, stage[b], cur);
+        done += cur; cur = next; b ^= 1;
+    }
+    return DWGSIM_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,850 @@
+// dw_kernels.hip -- hand-written HIP kernels (gfx950 / MI355X) for the dwgsim hot path.
+//
+//   mutation walk (replaces src/mut.c:591-643 + :481-589 of the reference)
+//     k_pack          ASCII -> base codes, initialises both haplotypes            HBM: 1 B in, 3 B out / base
+//     k_site_scan     one Philox draw per position: candidate sites (bitmask)     HBM: 1 B in / base; ALU (Philox)
+//     k_scan_excl     single-block exclusive scan of per-block counts
+//     k_compact       ordered compaction of a bitmask into a position list
+//     k_events        one thread per candidate: speculative event (type, ploidy, lengths)
+//     k_resolve       liveness of candidates (deletion runs swallow later candidates)
+//     k_apply         writes live events into the haplotype cells + insertion tables
+//     k_justify       left-justification of indels (sequential semantics, sparse walk)
+//     k_collect_mask / k_gather   list of mutated cells for the host's txt/vcf writer
+//   read simulation (replaces the loop body src/dwgsim.c:636-1099)
+//     k_place         per pair: attempts until the N filter / geometry accept; random-read flag
+//     k_simulate      per read end: base extraction through indels, errors, qualities,
+//                     FASTQ formatting, decoupled look-back for record offsets, packed stores
+//
+// Everything is byte/integer work plus fp64 for the normals: no MFMA.  fp64 expressions mirror the
+// reference's evaluation order; compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include "dw_common.hpp"
+#include "dw_kernels.hpp"
+
+namespace dw {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+DW_DEV uint32_t code_of_ascii(uint32_t ch)          // dwgsim.c:56-73 nst_nt4_table
+{
+    const uint32_t u = ch | 0x20u;
+    return u == 'a' ? 0u : u == 'c' ? 1u : u == 'g' ? 2u : u == 't' ? 3u : (ch == '-' ? 5u : 4u);
+}
+
+// block-wide exclusive scan of one uint32 per thread (blockDim multiple of 64, <= 1024); returns the
+// exclusive prefix, *total gets the block sum.  `sm` = 17 words of LDS scratch.
+DW_DEV uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *total)
+{
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    const uint32_t inc = wave_incl_scan(v);
+    __syncthreads();                       // protect sm from a previous use
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int w = 0; w < nw; ++w) { uint32_t t = sm[w]; sm[w] = run; run += t; } sm[16] = run; }
+    __syncthreads();
+    *total = sm[16];
+    return inc - v + sm[wave];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: ASCII -> codes; both haplotypes start as the reference (mut.c:609)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t *__restrict__ ascii, uint8_t *__restrict__ ref, uint8_t *__restrict__ h0,
+                       uint8_t *__restrict__ h1, int64_t l)
+{
+    const int64_t nchunk = (l + 15) >> 4;
+    for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p0 = ch << 4;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (p0 + 16 <= l) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ascii + p0);
+            const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w[q] |= code_of_ascii((in[q] >> (8 * b)) & 0xff) << (8 * b);
+        } else {
+            for (int b = 0; b < 16; ++b) { const uint32_t c = (p0 + b < l) ? code_of_ascii(ascii[p0 + b]) : 4u; w[b >> 2] |= c << (8 * (b & 3)); }
+        }
+        const uint4 o = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(ref + p0) = o;
+        *reinterpret_cast<uint4 *>(h0 + p0) = o;
+        *reinterpret_cast<uint4 *>(h1 + p0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: candidate sites.  mut.c:618 `c < 4 && drand48() < opt->mut_rate` with the draw taken from
+// (D_WALK, position, slot 1).  16 positions per thread, 4096 per block; emits a bitmask (uint16 per
+// thread) and the per-block candidate count.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkParams wp, uint32_t contig_index,
+                            uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count)
+{
+    __shared__ uint32_t sm[17];
+    const RngKey key{wp.seed, contig_index};
+    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    uint32_t bits = 0;
+    if (p0 < l) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ref + p0);      // ref is padded: reading past l is safe
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint32_t c = (in[b >> 2] >> (8 * (b & 3))) & 0xff;
+            if (c < 4 && p0 + b < l) {
+                const U4 blk = rng_block(key, D_WALK, (uint64_t)(p0 + b), 0, 0, 0);
+                if (u_hi(blk) < wp.mut_rate) bits |= 1u << b;
+            }
+        }
+    }
+    mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x] = (uint16_t)bits;
+    uint32_t total;
+    (void)block_excl_scan((uint32_t)__popc(bits), sm, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+// single-block exclusive scan (in place) of n uint32; optional 64-bit total
+__global__ void k_scan_excl(uint32_t *data, uint32_t n, uint64_t *total_out)
+{
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    uint64_t grand = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? data[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, sm, &total);
+        const uint32_t carry = carry_s;
+        if (i < n) data[i] = ex + carry;
+        grand += total;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (total_out && threadIdx.x == 0) *total_out = grand;
+}
+
+// ordered compaction: positions of set bits of `mask` (one uint16 per thread of the producing kernel)
+__global__ void k_compact(const uint16_t *__restrict__ mask, const uint32_t *__restrict__ block_base, int32_t *__restrict__ out)
+{
+    __shared__ uint32_t sm[17];
+    uint32_t bits = mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x];
+    uint32_t total;
+    uint32_t off = block_base[blockIdx.x] + block_excl_scan((uint32_t)__popc(bits), sm, &total);
+    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; out[off++] = (int32_t)(p0 + b); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a: one thread per candidate site: the event it would be if it is live.  mut.c:619-640, 287-308.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_events(const int32_t *__restrict__ cand, uint32_t n_cand, const uint8_t *__restrict__ ref, int64_t l,
+                         WalkParams wp, uint32_t contig_index, Event *__restrict__ ev, uint32_t *__restrict__ max_del)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_cand) {
+        const RngKey key{wp.seed, contig_index};
+        const int64_t p = cand[k];
+        const uint32_t c = ref[p];
+        const U4 b1 = rng_block(key, D_WALK, (uint64_t)p, 0, 0, 1);   // slots 2,3
+        const U4 b2 = rng_block(key, D_WALK, (uint64_t)p, 0, 0, 2);   // slots 4,5
+        Event e; e.pos = (int32_t)p; e.live = 1; e.len = 1; e.base = (uint8_t)c;
+        if (u_lo(b1) >= wp.indel_frac) {                 // substitution (mut.c:619-626)
+            e.type = 1;
+            e.base = (uint8_t)((c + (uint32_t)(uint64_t)(u_hi(b1) * 3.0 + 1)) & 3);
+            e.hap = (wp.is_hap || u_lo(b2) < 0.333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
+        } else if (u_hi(b1) < 0.5) {                     // deletion (mut.c:628-636) + its run (mut.c:610-617)
+            e.type = 2;
+            e.hap = (wp.is_hap || u_lo(b2) < 0.3333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
+            uint32_t len = 1;
+            for (int64_t q = p + 1; q < l; ++q) {
+                if ((int64_t)len < wp.indel_min || rng_slot(key, D_WALK, (uint64_t)q, 0, 0) < wp.indel_extend) ++len; else break;
+            }
+            e.len = len;
+            atomicMax(max_del, len);
+        } else {                                         // insertion (mut.c:637-639 -> :287-308)
+            e.type = 3;
+            uint64_t num = 0; uint32_t kk = 0;
+            do { ++num; } while (num < 0xFFFFFFFFull && ((int64_t)num < wp.indel_min || rng_slot(key, D_WALK_INSLEN, (uint64_t)p, 0, kk++) < wp.indel_extend));
+            e.len = (uint32_t)num;
+            e.hap = (wp.is_hap || u_lo(b2) < 0.333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
+        }
+        ev[k] = e;
+    }
+}
+
+// K2b: liveness.  In the sequential walk a candidate inside an active deletion run is never tested
+// (mut.c:610-615 `continue`).  Candidate k is dead iff a LIVE earlier deletion covers it.  Exact
+// parallel evaluation: a candidate no earlier deletion reaches at all is live; otherwise replay the
+// (tiny) chain from the nearest such anchor.
+DW_DEV bool reached_by_any(const Event *ev, uint32_t k, uint32_t max_del)
+{
+    const int64_t pk = ev[k].pos;
+    for (int64_t j = (int64_t)k - 1; j >= 0; --j) {
+        const int64_t pj = ev[j].pos;
+        if (pk - pj >= (int64_t)max_del) break;
+        if (ev[j].type == 2 && pj + (int64_t)ev[j].len - 1 >= pk) return true;
+    }
+    return false;
+}
+__global__ void k_resolve(Event *ev, uint32_t n_cand, const uint32_t *max_del_p, uint4 *flags)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    const uint32_t max_del = *max_del_p;
+    bool live = true;
+    if (max_del > 1 && reached_by_any(ev, k, max_del)) {
+        int64_t a = (int64_t)k - 1;
+        while (a > 0 && reached_by_any(ev, (uint32_t)a, max_del)) --a;     // anchor: definitely live (or first candidate)
+        int64_t reach = -1;
+        for (int64_t m = a; m <= (int64_t)k; ++m) {
+            const bool lv = ev[m].pos > reach;
+            if (lv && ev[m].type == 2) reach = (int64_t)ev[m].pos + ev[m].len - 1;
+            live = lv;
+        }
+    }
+    // (the live flag is written to a side array so that neighbours still read the speculative events)
+    const Event e = ev[k];
+    uint4 f;
+    f.x = (live && e.type == 3 && (e.hap & 1)) ? 1u : 0u;       // insertion count hap 1
+    f.y = (live && e.type == 3 && (e.hap & 1)) ? e.len : 0u;    // inserted bases hap 1
+    f.z = (live && e.type == 3 && (e.hap & 2)) ? 1u : 0u;
+    f.w = (live && e.type == 3 && (e.hap & 2)) ? e.len : 0u;
+    if (!live) f.x |= 0x80000000u;                               // dead marker
+    flags[k] = f;
+}
+
+// exclusive scan of the four insertion-allocation columns (single block); totals -> tot[0..3]
+__global__ void k_scan4(uint4 *flags, uint32_t n, uint32_t *tot)
+{
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t carry_s[4];
+    if (threadIdx.x < 4) carry_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < n) v = flags[i];
+        const uint32_t dead = v.x & 0x80000000u;
+        uint32_t in[4] = {v.x & 0x7fffffffu, v.y, v.z, v.w}, ex[4], total[4];
+        for (int c = 0; c < 4; ++c) ex[c] = block_excl_scan(in[c], sm, &total[c]) + carry_s[c];
+        if (i < n) flags[i] = make_uint4(ex[0] | dead, ex[1], ex[2], ex[3]);
+        __syncthreads();
+        if (threadIdx.x < 4) carry_s[threadIdx.x] += total[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) tot[threadIdx.x] = carry_s[threadIdx.x];
+}
+
+// K3: write live events into the cells and the insertion tables.
+__global__ void k_apply(Event *ev, uint32_t n_cand, const uint4 *flags, ContigDev c, WalkParams wp)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    const uint4 f = flags[k];
+    Event e = ev[k];
+    if (f.x & 0x80000000u) { ev[k].live = 0; return; }
+    const int64_t p = e.pos;
+    if (e.type == 1) {
+        if (e.hap & 1) c.hap[0].cells[p] = T_SUB | e.base;
+        if (e.hap & 2) c.hap[1].cells[p] = T_SUB | e.base;
+    } else if (e.type == 2) {
+        for (uint32_t q = 0; q < e.len; ++q) {
+            const uint8_t v = T_DEL | c.ref[p + q];
+            if (e.hap & 1) c.hap[0].cells[p + q] = v;
+            if (e.hap & 2) c.hap[1].cells[p + q] = v;
+        }
+    } else {
+        const RngKey key{wp.seed, c.contig_index};
+        const uint32_t idx[2] = {f.x & 0x7fffffffu, f.z}, off[2] = {f.y, f.w};
+        for (int h = 0; h < 2; ++h) if (e.hap & (1 << h)) {
+            c.hap[h].cells[p] = T_INS | e.base;
+            c.hap[h].ins_pos[idx[h]] = (int32_t)p;
+            c.hap[h].ins_len[idx[h]] = e.len;
+            c.hap[h].ins_off[idx[h]] = off[h];
+        }
+        for (uint32_t j = 0; j < e.len; ++j) {      // draw j lands at printed index len-1-j (mut.c:313-315, :347-365 read by :249-279)
+            const uint8_t b = (uint8_t)(uint64_t)(rng_slot(key, D_WALK_INSBASE, (uint64_t)p, 0, j) * 4.0);
+            if (e.hap & 1) c.hap[0].ins_bases[off[0] + e.len - 1 - j] = b;
+            if (e.hap & 2) c.hap[1].ins_bases[off[1] + e.len - 1 - j] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: left-justification (mut.c:427-589).  The reference scans every position; only mutated cells act
+// and unmutated (non-N) positions merely reset prev_del, so the walk visits the live events'
+// original footprints in order and treats the gaps between them in O(1).
+// ------------------------------------------------------------------------------------------------
+DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
+{
+    uint32_t lo = 0, hi = h.n_ins;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)h.ins_pos[mid] < pos) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+DW_DEV void justify_ins(HapDev &h, int64_t i)          // mut.c:427-478
+{
+    const uint32_t idx = ins_find(h, i);
+    const uint32_t n = h.ins_len[idx];
+    uint8_t *P = h.ins_bases + h.ins_off[idx];
+    int64_t j = i;
+    while (j > 0 && (h.cells[j - 1] & TMASK) == T_NONE && P[n - 1] == (h.cells[j - 1] & 3)) {
+        for (uint32_t t = n - 1; t > 0; --t) P[t] = P[t - 1];
+        P[0] = h.cells[j - 1] & 3;
+        h.cells[j] = h.cells[j] & 3;
+        --j;
+    }
+    h.cells[j] = T_INS | (h.cells[j] & 3);
+    h.ins_pos[idx] = (int32_t)j;
+}
+DW_DEV void del_swap(HapDev &h, int64_t j, int64_t dl)   // mut.c:515-516
+{
+    const uint8_t t = h.cells[j]; h.cells[j] = h.cells[j + dl]; h.cells[j + dl] = (uint8_t)((t | TMASK) ^ TMASK);
+}
+DW_DEV int64_t del_run(const HapDev &h, int64_t i, int64_t l)
+{
+    int64_t dl = 1;
+    for (int64_t j = i + 1; j < l && (h.cells[j] & TMASK) == T_DEL; ++j) ++dl;
+    return dl;
+}
+DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
+{
+    if (c.ref[i] >= 4) return;
+    HapDev &h0 = c.hap[0], &h1 = c.hap[1];
+    const uint8_t c1 = h0.cells[i], c2 = h1.cells[i];
+    if ((c1 & TMASK) == T_NONE && (c2 & TMASK) == T_NONE) { prev_del[0] = prev_del[1] = 0; return; }
+    if ((c1 & BTMASK) == (c2 & BTMASK)) {
+        if ((c1 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
+        else if ((c1 & TMASK) == T_DEL) {
+            if (prev_del[0] == 1 || prev_del[1] == 1) return;
+            prev_del[0] = prev_del[1] = 1;
+            const int64_t dl = del_run(h0, i, c.l);
+            if (c.l <= i + dl) return;
+            if (i > 0) for (int64_t j = i - 1;; --j) {
+                const uint8_t a = h0.cells[j], b = h1.cells[j];
+                if ((a & TMASK) != T_INS && (b & TMASK) != T_INS && (a & TMASK) != T_DEL && (b & TMASK) != T_DEL
+                    && (a & 3) == (h0.cells[j + dl] & 3) && (b & 3) == (h1.cells[j + dl] & 3)) { del_swap(h0, j, dl); del_swap(h1, j, dl); }
+                else break;
+                if (j == 0) break;
+            }
+        } else { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); justify_ins(h1, i); }
+    } else {
+        if ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
+        else if ((c1 & TMASK) == T_DEL || (c2 & TMASK) == T_DEL) {
+            const int x = ((c1 & TMASK) == T_DEL) ? 0 : 1;
+            if (prev_del[x] == 1) return;
+            prev_del[x] = 1;
+            HapDev &h = c.hap[x];
+            const int64_t dl = del_run(h, i, c.l);
+            if (c.l <= i + dl) return;
+            if (i > 0) for (int64_t j = i - 1;; --j) {
+                const uint8_t a = h.cells[j];
+                if ((a & TMASK) == T_NONE && (a & 3) == (h.cells[j + dl] & 3)) del_swap(h, j, dl); else break;
+                if (j == 0) break;
+            }
+        } else if ((c1 & TMASK) == T_INS) { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); }
+        else { prev_del[0] = prev_del[1] = 0; justify_ins(h1, i); }
+    }
+}
+// one thread walks events [k0, k1) of the contig (v1: the whole contig from one thread)
+__global__ void k_justify(const Event *ev, uint32_t n_cand, ContigDev c)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int prev_del[2] = {0, 0};
+    int64_t last = -1;
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const Event e = ev[k];
+        if (!e.live) continue;
+        const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
+        if (prev_del[0] | prev_del[1])      // an unmutated non-N position in the gap resets prev_del (mut.c:585-587)
+            for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
+        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
+        last = right;
+    }
+}
+
+// mutated cells for the host's mutations.txt / .vcf writer
+__global__ void k_collect_mask(const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, int64_t l,
+                               uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count)
+{
+    __shared__ uint32_t sm[17];
+    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    uint32_t bits = 0;
+    if (p0 < l) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(h0 + p0), b = *reinterpret_cast<const uint4 *>(h1 + p0);
+        const uint32_t m[4] = {(a.x | b.x) & 0x30303030u, (a.y | b.y) & 0x30303030u, (a.z | b.z) & 0x30303030u, (a.w | b.w) & 0x30303030u};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (((m[q >> 2] >> (8 * (q & 3))) & 0xff) && p0 + q < l) bits |= 1u << q;
+    }
+    mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x] = (uint16_t)bits;
+    uint32_t total;
+    (void)block_excl_scan((uint32_t)__popc(bits), sm, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+__global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, uint16_t *__restrict__ cells)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) cells[k] = (uint16_t)(h0[pos[k]] | (h1[pos[k]] << 8));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Read simulation
+// ------------------------------------------------------------------------------------------------
+struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n; };
+
+// dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
+template <bool STORE>
+DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
+{
+    ReadRes r{-10, 0, 0, 0};
+    int k = 0; uint32_t acc = 0;
+    int64_t blk = -1; uint64_t clo = 0, chi = 0;          // current 16-byte chunk of the haplotype, decoded from registers
+    auto emit = [&](uint32_t v) {
+        if (strand) v = v < 4 ? 3 - v : 4;                 // dwgsim.c:150-152
+        r.num_n += (v == 4);                                // dwgsim.c:824-831
+        if (STORE) { acc |= v << ((k & 7) * 4); if ((k & 7) == 7) { lds[(k >> 3) * stride] = acc; acc = 0; } }
+        ++k;
+    };
+    for (int64_t i = start; i >= 0 && i < l && k < s; i += step) {
+        if ((i >> 4) != blk) {
+            blk = i >> 4;
+            const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (blk << 4));
+            clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        }
+        const uint32_t c = (uint32_t)(((i & 8) ? chi : clo) >> ((i & 7) * 8)) & 0xffu, mt = c & TMASK;
+        if (r.ext_coor < 0) {
+            if (mt != T_NONE && mt != T_SUB) continue;
+            r.ext_coor = (int32_t)i;
+            if (strand) r.ext_coor -= s - 1;
+        }
+        if (mt == T_DEL) { ++r.n_indel; if (strand) r.ext_coor--; }
+        else if (mt == T_NONE || mt == T_SUB) { emit(c & 0xf); if (mt == T_SUB) ++r.n_sub; }
+        else {
+            ++r.n_indel;
+            const uint32_t idx = ins_find(h, i);
+            uint32_t n = h.ins_len[idx];
+            const uint8_t *P = h.ins_bases + h.ins_off[idx];
+            if (!strand) {
+                if (k < s) emit(c & 0xf);
+                for (uint32_t t = 0; t < n && k < s; ++t) emit(P[t] & 3u);
+            } else {
+                while (n > 0 && k < s) { r.ext_coor++; emit(P[n - 1] & 3u); --n; }
+                if (k < s) emit(c & 0xf);
+            }
+        }
+    }
+    if (STORE && (k & 7)) lds[(k >> 3) * stride] = acc;
+    if (k != s) r.ext_coor = -10;
+    return r;
+}
+
+struct PairDraw { bool is_rand; int32_t pos, d; int hap, strand0, strand1; };
+
+// select-by-value accessors: dynamic indexing into the by-value kernel argument block would force a
+// private copy of the whole struct (promoted to LDS by the backend)
+DW_DEV HapDev sel_hap(const SimArgs &a, int h)
+{
+    HapDev r;
+    r.cells = h ? a.c.hap[1].cells : a.c.hap[0].cells;
+    r.ins_pos = h ? a.c.hap[1].ins_pos : a.c.hap[0].ins_pos;
+    r.ins_len = h ? a.c.hap[1].ins_len : a.c.hap[0].ins_len;
+    r.ins_off = h ? a.c.hap[1].ins_off : a.c.hap[0].ins_off;
+    r.ins_bases = h ? a.c.hap[1].ins_bases : a.c.hap[0].ins_bases;
+    r.n_ins = h ? a.c.hap[1].n_ins : a.c.hap[0].n_ins;
+    return r;
+}
+DW_DEV int sel_len(const SimArgs &a, int j) { return j ? a.p.len[1] : a.p.len[0]; }
+
+// dwgsim.c:649-742: random-read test, fragment size + position, haplotype, strands
+DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t att)
+{
+    PairDraw pd; pd.pos = 0; pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
+    const U4 b0 = rng_block(key, D_PAIR, ii, att, 0, 0);
+    pd.is_rand = !(a.p.rand_read < u_lo(b0));
+    if (pd.is_rand) return pd;
+    const int s0 = a.p.len[0], s1 = a.p.len[1];
+    const int64_t l = a.c.l;
+    if (a.p.amplicons) { pd.pos = 0; pd.d = (int32_t)l; }
+    else {
+        uint32_t t = 0; int32_t pos, d;
+        do {
+            if (s1 > 0) {
+                double v1, v2, rsq; uint32_t r = 0;
+                do {
+                    const U4 b = rng_block(key, D_PLACE_NORM, ii, att, r, t);
+                    v1 = 2.0 * u_lo(b) - 1.0; v2 = 2.0 * u_hi(b) - 1.0;
+                    rsq = v1 * v1 + v2 * v2; ++r;
+                } while (rsq >= 1.0 || rsq == 0.0);
+                const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+                double ran = v2 * fac;
+                ran = ran * a.p.std_dev + a.p.dist;
+                d = (int32_t)(ran + 0.5);
+                const int32_t min_dist = s0 + s1;
+                if (d < min_dist) d = min_dist;
+                if ((int64_t)d > l) d = (int32_t)l;
+            } else d = 0;
+            const int64_t range = l - d + 1;
+            pos = (int32_t)((double)range * rng_slot(key, D_PLACE, ii, att, t));
+            ++t;
+        } while (pos < 0 || pos >= l || (int64_t)pos + d - 1 >= l
+                 || (s1 > 0 && !a.p.is_inner && ((s0 > 0 && d <= s1) || (d <= s0 && s1 > 0))));
+        pd.pos = pos; pd.d = d;
+    }
+    pd.hap = u_hi(b0) < a.p.mut_freq ? 0 : 1;
+    switch (a.p.read_one_strand) {
+    case 0: pd.strand0 = rng_slot(key, D_PAIR, ii, att, 2) < 0.5 ? 1 : 0; break;
+    case 1: pd.strand0 = 0; break;
+    default: pd.strand0 = 1; break;
+    }
+    switch (a.p.strandedness) {
+    case 0: pd.strand1 = (a.p.data_type == 0) ? 1 - pd.strand0 : pd.strand0; break;
+    case 1: pd.strand1 = pd.strand0; break;
+    default: pd.strand1 = 1 - pd.strand0; break;
+    }
+    return pd;
+}
+
+// dwgsim.c:745-821: first cell and direction of read end j
+DW_DEV void read_geom(const SimArgs &a, const PairDraw &pd, int j, int64_t *start, int *step)
+{
+    const int64_t pos = pd.pos, d = pd.d, s0 = a.p.len[0], s1 = a.p.len[1], sl = a.c.l;
+    const bool amp = a.p.amplicons != 0, inner = a.p.is_inner != 0;
+    if (s1 > 0) {
+        const int64_t far_outer = pos + d - 1;
+        if (pd.strand0 == pd.strand1) {
+            if (pd.strand0 == 0) {
+                if (j == 0) { *start = amp ? sl - 1 : (inner ? pos + s1 + d - 1 : pos + d - s0); *step = 1; }
+                else { *start = pos; *step = 1; }
+            } else {
+                if (j == 0) { *start = pos + s0 - 1; *step = -1; }
+                else { *start = amp ? sl - 1 : (inner ? pos + s0 + d + s1 - 1 : far_outer); *step = -1; }
+            }
+        } else {
+            if (pd.strand0 == 0) {
+                if (j == 0) { *start = pos; *step = 1; }
+                else { *start = amp ? sl - 1 : (inner ? pos + s0 + d + s1 - 1 : far_outer); *step = -1; }
+            } else {
+                if (j == 0) { *start = amp ? sl - 1 : (inner ? pos + s1 + d + s0 - 1 : far_outer); *step = -1; }
+                else { *start = pos; *step = 1; }
+            }
+        }
+    } else {
+        if (pd.strand0 == 0) { *start = pos; *step = 1; }
+        else if (amp) { *start = sl - 1; *step = -1; }
+        else { *start = pos + s0 - 1; *step = -1; }
+    }
+}
+
+// K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.
+__global__ void k_place(SimArgs a)
+{
+    __shared__ uint32_t sm[17];
+    const uint64_t pair = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
+    const bool valid = pair < a.n_pairs;
+    const uint64_t ii = a.first_ii + pair;
+    const RngKey key{a.p.seed, a.c.contig_index};
+    uint32_t att = 0; bool is_rand = false, failed = false;
+    if (valid) {
+        for (;;) {
+            const PairDraw pd = draw_pair(a, key, ii, att);
+            if (pd.is_rand) { is_rand = true; break; }
+            bool ok = true;
+            const HapDev hp = sel_hap(a, pd.hap);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int sj = j ? a.p.len[1] : a.p.len[0];
+                if (sj <= 0 || !ok) continue;
+                int64_t start; int step;
+                read_geom(a, pd, j, &start, &step);
+                const ReadRes r = gen_read<false>(hp, a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
+            }
+            if (ok) break;
+            if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; break; }
+        }
+        a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);
+    }
+    uint32_t total;
+    (void)block_excl_scan(is_rand ? 1u : 0u, sm, &total);
+    if (threadIdx.x == 0) a.block_rand[blockIdx.x] = total;
+    const uint32_t retries = wave_sum_u32(valid ? att : 0u);
+    if (lane_id() == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries);
+    if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
+}
+
+// ---- FASTQ text assembly ----
+struct Writer {               // sequential byte stream -> aligned dword stores (byte stores for head / tail)
+    uint8_t *dst; uint32_t acc, nacc;
+    DW_DEV void init(uint8_t *p) { dst = p; acc = 0; nacc = 0; }
+    DW_DEV void put(uint32_t b)
+    {
+        if (nacc == 0 && ((uintptr_t)dst & 3)) { *dst++ = (uint8_t)b; return; }
+        acc |= b << (8 * nacc);
+        if (++nacc == 4) { *reinterpret_cast<uint32_t *>(dst) = acc; dst += 4; acc = 0; nacc = 0; }
+    }
+    DW_DEV void put4(uint32_t w)
+    {
+        if ((uintptr_t)dst & 3) { put(w & 0xff); put((w >> 8) & 0xff); put((w >> 16) & 0xff); put(w >> 24); return; }
+        if (nacc == 0) { *reinterpret_cast<uint32_t *>(dst) = w; dst += 4; }
+        else { const uint32_t sh = 8 * nacc; *reinterpret_cast<uint32_t *>(dst) = acc | (w << sh); dst += 4; acc = w >> (32 - sh); }
+    }
+    DW_DEV void flush() { for (uint32_t k = 0; k < nacc; ++k) dst[k] = (uint8_t)(acc >> (8 * k)); nacc = 0; }
+};
+struct Out2 {                 // the bwa stream of this read end and the interleaved bfast stream
+    Writer a, b; bool ea, eb;
+    DW_DEV void put(uint32_t c) { if (ea) a.put(c); if (eb) b.put(c); }
+    DW_DEV void put4(uint32_t w) { if (ea) a.put4(w); if (eb) b.put4(w); }
+    DW_DEV void flush() { if (ea) a.flush(); if (eb) b.flush(); }
+};
+DW_DEV uint32_t ndigits10(uint32_t v)
+{
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+DW_DEV uint32_t ndigits16(uint64_t v) { return v ? (uint32_t)(67 - __clzll((long long)v)) >> 2 : 1u; }
+DW_DEV void put_dec(Out2 &o, uint32_t v)
+{
+    bool started = false;
+#pragma unroll
+    for (uint32_t p = 1000000000u; p >= 10u; p /= 10u) {
+        const uint32_t dgt = v / p; v -= dgt * p;
+        if (dgt || started) { o.put('0' + dgt); started = true; }
+    }
+    o.put('0' + v);
+}
+DW_DEV void put_hex(Out2 &o, uint64_t v)
+{
+    for (int k = (int)ndigits16(v) - 1; k >= 0; --k) { const uint32_t h = (uint32_t)(v >> (4 * k)) & 15u; o.put(h < 10 ? '0' + h : 'a' + (h - 10)); }
+}
+DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull >> (8 * (v & 7))) & 0xff); }  // "ACGTNNNN"
+
+// K6: one lane per read end (LPP = 2: lanes 2q / 2q+1 are the two ends of pair q; LPP = 1: single end).
+template <int LPP>
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
+{
+    DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_base[2];
+    const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK * LPP;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
+    __syncthreads();
+    const uint32_t t = s_ticket;                                  // logical block: predecessors have started
+    const int j = (LPP == 2) ? (tid & 1) : 0;
+    const uint64_t pair = (uint64_t)t * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);
+    const bool valid = pair < a.n_pairs;
+    const uint64_t ii = a.first_ii + pair;
+    const RngKey key{a.p.seed, a.c.contig_index};
+    const int s = sel_len(a, j);
+    uint32_t *lds = dyn_lds + tid;
+
+    const uint32_t meta = valid ? a.meta[pair] : 0u;
+    const uint32_t att = meta & 0x7fffffffu;
+    const bool is_rand = (meta >> 31) != 0;
+
+    // running random-read index (dwgsim.c:1042,1096): block prefix from k_place/k_scan + rank inside the block
+    uint32_t rtot;
+    const uint32_t rrank = block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &rtot);
+    const uint64_t rand_ii = a.rand_base + a.block_rand[t] + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+
+    // ---- bases of this read end ----
+    PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
+    ReadRes rr{0, 0, 0, 0};
+    if (valid && !is_rand) {
+        pd = draw_pair(a, key, ii, att);
+        int64_t start; int step;
+        read_geom(a, pd, j, &start, &step);
+        rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
+    }
+    // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
+    int32_t n_err = 0;
+    if (valid) {
+        const double *thr = j ? a.e_thr[1] : a.e_thr[0];
+        for (int w = 0; w * 8 < s; ++w) {
+            uint32_t word = is_rand ? 0u : lds[w * nthr], out = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int i = w * 8 + b;
+                if (i < s) {
+                    const U4 blk = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i);
+                    uint32_t c;
+                    if (is_rand) c = (uint32_t)((int32_t)(u_lo(blk) * 4.0) & 3);
+                    else {
+                        c = (word >> (4 * b)) & 15u;
+                        if (c >= 4) c = 4;
+                        else if (u_lo(blk) < thr[i]) { c = (c + (uint32_t)(uint64_t)(u_hi(blk) * 3.0 + 1)) & 3u; ++n_err; }
+                    }
+                    out |= c << (4 * b);
+                }
+            }
+            lds[w * nthr] = out;
+        }
+    }
+    // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
+    int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
+    int32_t e1c = 0, u1 = 0, i1 = 0, x1 = 0;                                   // read end 2 (single-end: zeros, dwgsim.c:643)
+    if (LPP == 2) {
+        const int32_t o0 = __shfl_xor(n_err, 1), o1 = __shfl_xor(rr.n_sub, 1), o2 = __shfl_xor(rr.n_indel, 1), o3 = __shfl_xor(rr.ext_coor, 1);
+        if (j == 0) { e1c = o0; u1 = o1; i1 = o2; x1 = o3; }
+        else { e1c = n_err; u1 = rr.n_sub; i1 = rr.n_indel; x1 = rr.ext_coor; e0 = o0; u0 = o1; i0 = o2; x0 = o3; }
+    }
+    uint32_t tail_len, fixed_len;
+    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
+    else {
+        fixed_len = (uint32_t)a.name_fixed_len;
+        tail_len = 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
+                 + ndigits10((uint32_t)e0) + 1 + ndigits10((uint32_t)u0) + 1 + ndigits10((uint32_t)i0) + 1
+                 + ndigits10((uint32_t)e1c) + 1 + ndigits10((uint32_t)u1) + 1 + ndigits10((uint32_t)i1) + 1
+                 + ndigits16(ii);
+    }
+    const uint32_t Lbwa = (valid && s > 0) ? (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s + 3u + (uint32_t)s + 1u) : 0u;
+
+    // ---- record offsets: block scan + decoupled look-back over logical blocks ----
+    uint32_t T1, T2;
+    const uint32_t e1 = block_excl_scan(j == 0 ? Lbwa : 0u, sm, &T1);
+    const uint32_t e2 = block_excl_scan(j == 1 ? Lbwa : 0u, sm, &T2);
+    if (wave == 0) { const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g; }
+    else if (wave == 1) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
+    __syncthreads();
+    const uint64_t G1 = s_base[0], G2 = s_base[1];
+    const uint64_t reads_before_block = (uint64_t)t * PAIRS_PER_BLOCK * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
+    const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
+    const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
+    const uint64_t off_bf = G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
+    if (tid == nthr - 1) {
+        const uint64_t nblocks = (a.n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
+        if ((uint64_t)t + 1 == nblocks) {
+            const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
+            a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
+            a.counters[5] = a.p.has_bwa ? G2 + T2 : 0;
+            a.counters[6] = a.p.has_bfast ? G1 + T1 + G2 + T2 - 2 * nreads : 0;
+        }
+    }
+
+    // ---- write the record(s) ----
+    if (valid && s > 0) {
+        Out2 o;
+        o.ea = a.p.has_bwa != 0; o.eb = a.p.has_bfast != 0;
+        o.a.init((j ? a.out[1] : a.out[0]) + off_bwa); o.b.init(a.out[2] + off_bf);
+        o.put('@');
+        { const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed; for (uint32_t q = 0; q < fixed_len; ++q) o.put(fx[q]); }
+        if (is_rand) {
+            const char *lit = "_0_0_0_0_1_1_0:0:0_0:0:0_";
+            for (int q = 0; q < 25; ++q) o.put((uint32_t)lit[q]);
+            put_hex(o, rand_ii);
+        } else {
+            o.put('_'); put_dec(o, (uint32_t)(x0 + 1)); o.put('_'); put_dec(o, (uint32_t)(x1 + 1));
+            o.put('_'); o.put('0' + pd.strand0); o.put('_'); o.put('0' + pd.strand1); o.put('_'); o.put('0'); o.put('_'); o.put('0'); o.put('_');
+            put_dec(o, (uint32_t)e0); o.put(':'); put_dec(o, (uint32_t)u0); o.put(':'); put_dec(o, (uint32_t)i0); o.put('_');
+            put_dec(o, (uint32_t)e1c); o.put(':'); put_dec(o, (uint32_t)u1); o.put(':'); put_dec(o, (uint32_t)i1); o.put('_');
+            put_hex(o, ii);
+        }
+        if (o.ea) { o.a.put('/'); o.a.put('1' + j); }
+        o.put('\n');
+        // bases
+        for (int w = 0; w * 8 < s; ++w) {
+            const uint32_t word = lds[w * nthr];
+            const int rem = s - w * 8;
+            if (rem >= 8) {
+                o.put4(base_char(word & 15) | base_char((word >> 4) & 15) << 8 | base_char((word >> 8) & 15) << 16 | base_char((word >> 12) & 15) << 24);
+                o.put4(base_char((word >> 16) & 15) | base_char((word >> 20) & 15) << 8 | base_char((word >> 24) & 15) << 16 | base_char(word >> 28) << 24);
+            } else for (int b = 0; b < rem; ++b) o.put(base_char((word >> (4 * b)) & 15));
+        }
+        o.put('\n'); o.put('+'); o.put('\n');
+        // qualities (dwgsim.c:899-918)
+        const int8_t *qb = j ? a.qbase[1] : a.qbase[0];
+        if (a.p.fixed_quality >= 0) { for (int i = 0; i < s; ++i) o.put((uint32_t)a.p.fixed_quality); }
+        else if (!(0 < a.p.quality_std)) {
+            for (int i = 0; i < s; ++i) { int32_t q = qb[i]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
+        } else {
+            uint32_t qacc = 0, nq = 0, r = 0; int p = 0; const int np = (s + 1) >> 1;
+            while (p < np) {
+                const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, r, (uint32_t)p);
+                const double v1 = 2.0 * u_lo(blk) - 1.0, v2 = 2.0 * u_hi(blk) - 1.0;
+                const double rsq = v1 * v1 + v2 * v2;
+                if (rsq >= 1.0 || rsq == 0.0) { ++r; continue; }
+                const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * p + h;
+                    const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
+                    if (i < s) {
+                        int32_t q = (int8_t)(qb[i] + (int32_t)((nrm * a.p.quality_std) + 0.5));
+                        if (q < 33) q = 33;
+                        if (q > 73) q = 73;
+                        qacc |= (uint32_t)q << (8 * nq);
+                        if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
+                    }
+                }
+                ++p; r = 0;
+            }
+            for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
+        }
+        o.put('\n');
+        o.flush();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (declared in dw_launch.hpp)
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l)
+{
+    const uint64_t nchunk = (uint64_t)(l + 15) >> 4;
+    uint32_t nb = cdiv(nchunk, 256); if (nb > (1u << 16)) nb = 1u << 16; if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, ascii, ref, h0, h1, l);
+}
+void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count)
+{
+    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, l, wp, contig_index, mask, block_count);
+}
+void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out)
+{
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, data, n, total_out);
+}
+void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l)
+{
+    hipLaunchKernelGGL(k_compact, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, mask, block_base, out);
+}
+void launch_events(hipStream_t st, const int32_t *cand, uint32_t n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del)
+{
+    if (n) hipLaunchKernelGGL(k_events, dim3(cdiv(n, 256)), dim3(256), 0, st, cand, n, ref, l, wp, contig_index, ev, max_del);
+}
+void launch_resolve(hipStream_t st, Event *ev, uint32_t n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4)
+{
+    if (n) hipLaunchKernelGGL(k_resolve, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, max_del, flags);
+    hipLaunchKernelGGL(k_scan4, dim3(1), dim3(1024), 0, st, flags, n, tot4);
+}
+void launch_apply(hipStream_t st, Event *ev, uint32_t n, const uint4 *flags, ContigDev c, WalkParams wp)
+{
+    if (n) hipLaunchKernelGGL(k_apply, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, flags, c, wp);
+}
+void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c)
+{
+    if (n) hipLaunchKernelGGL(k_justify, dim3(1), dim3(64), 0, st, ev, n, c);
+}
+void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count)
+{
+    hipLaunchKernelGGL(k_collect_mask, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, h0, h1, l, mask, block_count);
+}
+void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells)
+{
+    if (n) hipLaunchKernelGGL(k_gather, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, n, h0, h1, cells);
+}
+void launch_place(hipStream_t st, const SimArgs &a)
+{
+    hipLaunchKernelGGL(k_place, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), 0, st, a);
+}
+void launch_simulate(hipStream_t st, const SimArgs &a)
+{
+    const uint32_t nb = cdiv(a.n_pairs, PAIRS_PER_BLOCK);
+    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_simulate<2>, dim3(nb), dim3(PAIRS_PER_BLOCK * 2), (size_t)a.lds_words * PAIRS_PER_BLOCK * 2 * 4, st, a);
+    else hipLaunchKernelGGL(k_simulate<1>, dim3(nb), dim3(PAIRS_PER_BLOCK), (size_t)a.lds_words * PAIRS_PER_BLOCK * 4, st, a);
+}
+
+} // namespace dw

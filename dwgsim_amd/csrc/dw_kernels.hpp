@@ -1,0 +1,74 @@
+// dw_kernels.hpp -- argument blocks shared by the HIP kernels (dw_kernels.hip) and the
+// C-ABI host code (dw_host.cpp).
+#pragma once
+#include <stdint.h>
+
+namespace dw {
+
+constexpr int PAIRS_PER_BLOCK = 128;     // k_place and k_simulate partition pairs identically
+constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_POS_PER_BLOCK = SCAN_POS_PER_THREAD * SCAN_THREADS;   // 4096
+constexpr int CELL_PAD = 32;             // cells are allocated with 32 readable pad bytes after the contig
+constexpr int MAX_ATTEMPTS = 10000;      // dwgsim.c:837
+
+// mutation type bits of a cell (low byte of the reference's mut_t, mut.h:25-30)
+constexpr uint8_t T_NONE = 0x00, T_INS = 0x10, T_SUB = 0x20, T_DEL = 0x30, TMASK = 0x30, BTMASK = 0x3f;
+
+// a candidate mutation site resolved speculatively (k_events) and then marked live/dead (k_resolve)
+struct Event {
+    int32_t  pos;
+    uint8_t  type;      // 0 dead, 1 substitution, 2 deletion, 3 insertion
+    uint8_t  hap;       // haplotype mask 1|2
+    uint8_t  base;      // substitution: new base; else reference code at pos
+    uint8_t  live;
+    uint32_t len;       // deletion run length / insertion length
+};
+
+// one haplotype of one contig, resident in HBM
+struct HapDev {
+    uint8_t *cells;         // [l + CELL_PAD]  bits 0-3 base code (0-3 ACGT, 4 N, 5 '-'), bits 4-5 type
+    int32_t *ins_pos;       // sorted positions of INSERT cells
+    uint32_t *ins_len;
+    uint32_t *ins_off;      // offset of the inserted bases P[0..n) (printed order) in ins_bases
+    uint8_t *ins_bases;
+    uint32_t n_ins;
+};
+
+struct ContigDev {
+    HapDev hap[2];
+    const uint8_t *ref;     // [l + CELL_PAD] reference base codes
+    int64_t l;
+    uint32_t contig_index;  // RNG key
+};
+
+struct WalkParams {
+    double mut_rate, indel_frac, indel_extend;
+    int32_t indel_min, is_hap;
+    uint32_t seed;
+};
+
+struct SimParams {
+    double std_dev, mut_freq, rand_read, quality_std;
+    int32_t dist, is_inner, len[2], max_n, strandedness, read_one_strand, amplicons, fixed_quality, data_type;
+    int32_t has_bwa, has_bfast;
+    uint32_t seed;
+};
+
+struct SimArgs {
+    SimParams p;
+    ContigDev c;
+    uint64_t first_ii, n_pairs, rand_base;
+    const double *e_thr[2];        // per-position error thresholds e.start + e.by*i (dwgsim.c:237)
+    const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics
+    const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"
+    const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"
+    uint32_t *meta;                // per pair: accepted attempt | is_random << 31
+    uint32_t *block_rand;          // per 128-pair block: random pairs (k_place), then exclusive prefix (k_scan)
+    uint64_t *counters;            // [0] ticket, [1] retries, [2] fail flag, [3] total random, [4..6] stream bytes
+    uint64_t *status[2];           // look-back words of stream BWA1 / BWA2 record bytes
+    uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
+    int32_t lds_words;             // uint32 words of packed bases per lane
+};
+
+} // namespace dw

@@ -1,0 +1,19 @@
+// dw_launch.hpp -- host-callable launchers of the kernels in dw_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dw_kernels.hpp"
+
+namespace dw {
+void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l);
+void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count);
+void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out);
+void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l);
+void launch_events(hipStream_t st, const int32_t *cand, uint32_t n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del);
+void launch_resolve(hipStream_t st, Event *ev, uint32_t n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4);
+void launch_apply(hipStream_t st, Event *ev, uint32_t n, const uint4 *flags, ContigDev c, WalkParams wp);
+void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c);
+void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count);
+void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells);
+void launch_place(hipStream_t st, const SimArgs &a);
+void launch_simulate(hipStream_t st, const SimArgs &a);
+}

@@ -1,0 +1,144 @@
+/*
+ * dwgsim_hip.h -- C-ABI of the MI355X-native dwgsim hot path (libdwgsim_hip.so).
+ *
+ * The reference (nh13/DWGSIM) has no plugin/FFI layer; its seam is the single call
+ * dwgsim_core(dwgsim_opt_t*) (src/dwgsim.c:419, called at :1163) and inside it
+ * mut_diref() (src/mut.c:591, called at dwgsim.c:629) followed by the inlined per-pair loop
+ * (dwgsim.c:636-1099).  The entry points below are what a host-side binding for that seam
+ * binds: plain pointers and sizes, no C++/torch types, error codes
+ * instead of exit(1) (the reference's messages are available through dwgsim_hip_last_error).
+ *
+ * Random numbers: Philox4x32-10 keyed by (seed, contig) and counter
+ * (index, retry, domain|attempt, block) -- see DESIGN.md "RNG layout".  Any read-index range
+ * of any contig can be generated independently and in any order.
+ *
+ * Threading: a context is single-owner; different contexts (one per GPU) may be used
+ * concurrently.  There is no global state.
+ */
+#ifndef DWGSIM_HIP_H
+#define DWGSIM_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWGSIM_HIP_ABI_VERSION 1
+
+/* error codes (negative) */
+#define DWGSIM_HIP_OK            0
+#define DWGSIM_HIP_ERR_ARG      -1   /* bad argument / option out of range (dwgsim_opt.c:307-371) */
+#define DWGSIM_HIP_ERR_DEVICE   -2   /* no usable HIP device / HIP runtime error */
+#define DWGSIM_HIP_ERR_NOMEM    -3
+#define DWGSIM_HIP_ERR_UNSUP    -4   /* option outside the accelerated path (see DESIGN.md "out of scope") */
+#define DWGSIM_HIP_ERR_FAILED   -5   /* "failed to generate a read after %d trials" (dwgsim.c:837-840) */
+#define DWGSIM_HIP_ERR_STATE    -6   /* call order violated (e.g. simulate before mutate) */
+
+/* POD mirror of the dwgsim_opt_t fields read on the path (src/dwgsim_opt.h:21-60);
+ * defaults are those of dwgsim_opt_init() (src/dwgsim_opt.c:40-80). */
+typedef struct dwgsim_hip_params {
+    double  e_start[2], e_end[2];   /* -e / -E  per-base error rate ramp (start..end) of read 1 / 2   */
+    int32_t is_inner;               /* -i */
+    int32_t dist;                   /* -d */
+    double  std_dev;                /* -s */
+    int64_t N;                      /* -N (-1: use C) */
+    double  C;                      /* -C (-1: use N) */
+    int32_t length[2];              /* -1 / -2 */
+    double  mut_rate;               /* -r */
+    double  mut_freq;               /* -F */
+    double  indel_frac;             /* -R */
+    double  indel_extend;           /* -X */
+    int32_t indel_min;              /* -I */
+    double  rand_read;              /* -y */
+    int32_t max_n;                  /* -n */
+    int32_t data_type;              /* -c 0 Illumina, 1 SOLiD, 2 Ion Torrent */
+    int32_t strandedness;           /* -S */
+    int32_t read_one_strand;        /* -A */
+    int32_t is_hap;                 /* -H */
+    int32_t seed;                   /* -z (must be >= 0 here: the CLI resolves -1 to time(0)) */
+    int32_t fixed_quality;          /* -q as a character code, or -1 */
+    double  quality_std;            /* -Q */
+    int32_t reads_output_type;      /* -o 0 all, 1 bwa only, 2 bfast only */
+    int32_t output_type;            /* -M 0 all, 1 reads only, 2 mutations only */
+    int32_t amplicons;              /* -a */
+    const char *read_prefix;        /* -P or NULL */
+    const char *flow_order;         /* -f or NULL */
+    int32_t use_base_error;         /* -B */
+} dwgsim_hip_params_t;
+
+typedef struct dwgsim_hip_ctx dwgsim_hip_ctx_t;
+
+/* output streams of one simulate() batch */
+enum { DWGSIM_HIP_STREAM_BWA1 = 0, DWGSIM_HIP_STREAM_BWA2 = 1, DWGSIM_HIP_STREAM_BFAST = 2 };
+
+typedef struct dwgsim_hip_batch {
+    uint64_t n_pairs;          /* pairs generated (== requested) */
+    uint64_t n_random;         /* how many of them are random reads ("rand_ii" increment, dwgsim.c:1096) */
+    uint64_t n_retries;        /* rejected attempts (N filter / walk off the contig, dwgsim.c:833-842) */
+    uint64_t bytes[3];         /* finished FASTQ text bytes per stream (0 if the stream is disabled) */
+    const void *dev_ptr[3];    /* device addresses of the packed text (valid until the slot is reused) */
+    float    kernel_ms;        /* HIP-event time of the batch's kernels on the context's stream */
+    float    sim_kernel_ms;    /* ... of the dominant kernel (simulate_pairs) alone */
+} dwgsim_hip_batch_t;
+
+/* dwgsim_opt_init() defaults (dwgsim_opt.c:40-80) */
+void dwgsim_hip_params_default(dwgsim_hip_params_t *p);
+
+/* Range/consistency checks of dwgsim_opt_parse() (dwgsim_opt.c:307-371, :396-413, :463-469).
+ * Returns DWGSIM_HIP_OK or DWGSIM_HIP_ERR_ARG / _UNSUP; msg (optional, cap bytes) receives the
+ * reference's message text. */
+int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap);
+
+/* Pairs to simulate on a contig of length l: dwgsim.c:535-537, :582-590 and the skip rules
+ * #2-#4 (:595-618).  Returns n_pairs (>= 0), or -2/-3/-4 for skip rule #2/#3/#4
+ * (skipped contigs get no mutations either, dwgsim.c:605-611). */
+int64_t dwgsim_hip_pairs_for_contig(const dwgsim_hip_params_t *p, int64_t l, uint64_t tot_len,
+                                    int is_last_contig, int64_t n_sim_so_far);
+
+/* Replaces the allocation/teardown half of dwgsim_core (dwgsim.c:442-453, :1103-1120).
+ * device = HIP device ordinal.  Fails (NULL, *err set) when no GPU is present. */
+dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, int *err);
+void dwgsim_hip_destroy(dwgsim_hip_ctx_t *ctx);
+const char *dwgsim_hip_last_error(const dwgsim_hip_ctx_t *ctx);
+
+/* Replaces seq_read_fasta()'s result + nst_nt4_table lookup (mut.c:49-87, dwgsim.c:56-73):
+ * ascii[0..len) are the contig's sequence characters (caller keeps ownership); the packed bases
+ * stay resident in HBM.  contig_index = 0-based ordinal of the contig in the FASTA (RNG key).
+ * Returns a handle >= 0 or an error code. */
+int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *ctx, const char *name, const uint8_t *ascii, int64_t len,
+                          uint32_t contig_index);
+int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *ctx, int contig);
+
+/* Replaces mut_diref() random branch + mut_left_justify() (mut.c:591-643, :481-589): builds the
+ * two mutated haplotypes of the contig in HBM. */
+int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *ctx, int contig);
+
+/* Replaces mut_print() (mut.c:781-893): the mutations.txt and mutations.vcf BODY lines of this
+ * contig.  Buffers are owned by the context and valid until the next call for any contig. */
+int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *ctx, int contig, const char **txt, size_t *txt_len,
+                              const char **vcf, size_t *vcf_len);
+
+/* Number of random reads among pairs [first_ii, first_ii + n_pairs) of the contig (for sharding:
+ * rand_ii is a running count over all earlier pairs, dwgsim.c:1042,1096). */
+int dwgsim_hip_count_random(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
+                            uint64_t *n_random);
+
+/* Replaces the loop body dwgsim.c:636-1099 for the read-index range [first_ii, first_ii+n_pairs)
+ * of one contig.  rand_base = number of random reads emitted before first_ii (over all contigs).
+ * slot in {0,1}: which of the context's double-buffered output sets to fill.  The call enqueues
+ * the kernels and returns after they completed; FASTQ text stays in HBM (out->dev_ptr) until
+ * dwgsim_hip_fetch copies it out. */
+int dwgsim_hip_simulate(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
+                        uint64_t rand_base, int slot, dwgsim_hip_batch_t *out);
+
+/* Copy one finished stream of a slot to host memory (pinned staging + hipMemcpyAsync inside). */
+int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
+
+/* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
+int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,8 @@
+#!/bin/bash
+# tests/emu/build.sh -- compile the product's kernel + host sources against the CPU SIMT emulation shim
+# (TEST INFRASTRUCTURE ONLY).  Output: tests/emu/libdwgsim_emu.so exporting the same C-ABI.
+set -e
+cd "$(dirname "$0")"
+SRC=../../dwgsim_amd/csrc
+g++ -O2 -g -std=c++17 -ffp-contract=off -fPIC -shared -pthread -I. -x c++ $SRC/dw_kernels.hip $SRC/dw_host.cpp hip_emu.cpp -o libdwgsim_emu.so
+echo built tests/emu/libdwgsim_emu.so

@@ -1,0 +1,71 @@
+"""Shared parity checker: product path (C-ABI library) vs the oracle in Philox mode, byte for byte.
+
+Used by tests/test_gpu_parity.py (-m gpu, real MI355X, libdwgsim_hip.so) and by
+tests/test_emu_parity.py (CPU-only SIMT emulation build of the same kernel sources, tests/emu)."""
+import os, subprocess, tempfile
+
+from dwgsim_amd import api
+
+STREAMS = {0: "bwa.read1.fastq", 1: "bwa.read2.fastq", 2: "bfast.fastq"}
+
+
+def run_oracle(oracle_bin, fasta, flags, workdir):
+    prefix = os.path.join(workdir, "ora")
+    subprocess.run([oracle_bin, "--rng", "philox"] + flags.split() + [fasta, prefix], check=True, stderr=subprocess.DEVNULL)
+    out = {}
+    for k, suf in list(STREAMS.items()) + [("txt", "mutations.txt"), ("vcf", "mutations.vcf")]:
+        p = prefix + "." + suf
+        out[k] = open(p, "rb").read() if os.path.exists(p) else b""
+    return out
+
+
+def first_diff(a: bytes, b: bytes):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            lo = max(0, i - 120)
+            return f"first difference at byte {i}: got …{a[lo:i + 60]!r} want …{b[lo:i + 60]!r}"
+    return f"length differs: got {len(a)} want {len(b)}"
+
+
+def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22):
+    """Returns the JobResult; raises AssertionError with a readable diff on any mismatch."""
+    with tempfile.TemporaryDirectory() as t:
+        want = run_oracle(oracle_bin, fasta, flags, t)
+    params = api.parse_flags(flags, lib)
+    contigs = api.read_fasta(fasta)
+    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib)
+    assert res.mutations_txt == want["txt"], "mutations.txt: " + first_diff(res.mutations_txt, want["txt"])
+    assert res.mutations_vcf == want["vcf"], "mutations.vcf: " + first_diff(res.mutations_vcf, want["vcf"])
+    for k in STREAMS:
+        assert res.streams[k] == want[k], f"{STREAMS[k]}: " + first_diff(res.streams[k], want[k])
+    return res
+
+
+# (fasta under tests/golden, flags): the option surface of the accelerated (Illumina) path
+CASES = [
+    ("ex1.fa", "-z 13 -N 10000"),                                  # the reference's bundled test configuration
+    ("ex1.fa", "-z 13 -N 10000 -1 100 -2 100"),                   # BASELINE configs[0]
+    ("tiny.fa", "-z 5 -C 20 -1 150 -2 150 -o 1"),
+    ("tiny.fa", "-z 3 -N 5000 -r 0.01 -R 0.3 -X 0.5"),
+    ("tiny.fa", "-z 4 -N 5000 -r 0.02 -R 0.5 -I 30 -X 0.6"),
+    ("odd.fa", "-z 3 -N 5000 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50"),
+    ("odd.fa", "-z 2 -N 5000 -1 50 -2 50 -d 200 -s 20 -r 0.05 -R 0.7 -X 0.5 -n 3"),
+    ("tiny.fa", "-z 9 -N 3000 -H"),
+    ("tiny.fa", "-z 9 -N 3000 -S 1"),
+    ("tiny.fa", "-z 9 -N 3000 -S 2 -A 1"),
+    ("tiny.fa", "-z 9 -N 3000 -A 2"),
+    ("tiny.fa", "-z 9 -N 3000 -i -d 100"),
+    ("tiny.fa", "-z 9 -N 3000 -y 0"),
+    ("tiny.fa", "-z 9 -N 3000 -n 2"),
+    ("tiny.fa", "-z 9 -N 3000 -e 0.001-0.05 -E 0.01"),
+    ("tiny.fa", "-z 9 -N 3000 -q I"),
+    ("tiny.fa", "-z 9 -N 3000 -Q 0"),
+    ("tiny.fa", "-z 9 -N 3000 -2 0"),
+    ("tiny.fa", "-z 9 -N 3000 -P pfx"),
+    ("tiny.fa", "-z 9 -N 3000 -o 2"),
+    ("tiny.fa", "-z 9 -N 3000 -M 2"),
+    ("tiny.fa", "-z 9 -N 300 -a"),
+    ("tiny.fa", "-z 21 -N 3000 -F 0.2 -y 0.3 -Q 10"),
+    ("tiny.fa", "-z 8 -N 2000 -1 33 -2 77 -d 300 -Q 40"),
+]
