@@ -299,10 +299,18 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     if (!kp) return DWGSIM_HIP_ERR_ARG;
     Contig &k = *kp;
     HIPC(c, hipSetDevice(c->device));
-    if (k.mutated) { c->err = "contig already mutated"; return DWGSIM_HIP_ERR_STATE; }
     const WalkParams wp = walk_params(c);
     const int64_t l = k.l;
-    k.mutated = true;
+    if (k.mutated) {       // re-run: start again from the resident packed reference
+        const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
+        for (int h = 0; h < 2; ++h) {
+            HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]);
+            k.d_ins_pos[h] = nullptr; k.d_ins_len[h] = k.d_ins_off[h] = nullptr; k.d_ins_bases[h] = nullptr; k.n_ins[h] = k.n_ins_bases[h] = 0;
+        }
+    }
+    k.mutated = true; k.n_cand = 0;
     if (l == 0) return DWGSIM_HIP_OK;
     const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
     if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;

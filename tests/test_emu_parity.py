@@ -1,0 +1,29 @@
+"""CPU-only check of the kernels' logic: the SAME kernel sources (dwgsim_amd/csrc) compiled against
+the SIMT emulation shim in tests/emu (one OS thread per GPU thread) must match the oracle in Philox
+mode byte for byte.  This is test infrastructure -- the product library has no CPU path -- and only
+a subset of the GPU parity cases is run (the emulation is slow)."""
+import os, subprocess
+import pytest
+
+from dwgsim_amd import api
+from parity_common import compare_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_CASES = [
+    ("ex1.fa", "-z 13 -N 1500"),
+    ("tiny.fa", "-z 4 -N 1200 -r 0.02 -R 0.5 -I 30 -X 0.6"),
+    ("odd.fa", "-z 3 -N 1200 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50"),
+    ("tiny.fa", "-z 9 -N 1000 -2 0 -n 2"),
+    ("tiny.fa", "-z 9 -N 700 -o 1 -y 0.3 -P pfx -A 2"),
+]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.run([os.path.join(HERE, "emu", "build.sh")], check=True, stdout=subprocess.DEVNULL)
+    return api.load(os.path.join(HERE, "emu", "libdwgsim_emu.so"))
+
+
+@pytest.mark.parametrize("fasta,flags", EMU_CASES, ids=[f"{f}:{fl}" for f, fl in EMU_CASES])
+def test_kernel_logic_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags):
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=700)
