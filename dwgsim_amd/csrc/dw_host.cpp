@@ -35,6 +35,7 @@ struct Contig {
     uint32_t *d_ins_len[2] = {nullptr, nullptr}, *d_ins_off[2] = {nullptr, nullptr};
     uint8_t *d_ins_bases[2] = {nullptr, nullptr};
     uint32_t n_ins[2] = {0, 0}, n_ins_bases[2] = {0, 0};
+    size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
     uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
     uint32_t n_cand = 0, n_events_live = 0;
 };
@@ -59,6 +60,8 @@ struct dwgsim_hip_ctx {
     std::vector<Contig> contigs;
     // simulate() working set
     DevBuf meta, block_rand, status[2], out[2][3], scratch_mask, scratch_cnt;
+    DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
+    bool seq_justify = false;
     uint64_t *d_counters = nullptr;          // 8 x u64
     uint64_t *h_counters = nullptr;          // pinned mirror
     uint64_t out_bytes[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -195,6 +198,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     if (p->read_prefix) c->read_prefix = p->read_prefix;
     c->prm.read_prefix = nullptr; c->prm.flow_order = nullptr;
     c->device = device;
+    { const char *e = getenv("DWGSIM_HIP_JUSTIFY"); c->seq_justify = e && !strcmp(e, "seq"); }   // cross-check mode
     auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, DWGSIM_HIP_ERR_DEVICE); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
     auto init = [&]() -> int {
         HIPC(c, hipSetDevice(device));
@@ -238,6 +242,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_qbase[j]); hipFree(c->status[j].p); }
+    hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters);
@@ -305,9 +310,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
         for (int h = 0; h < 2; ++h) {
             HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
-            HIPC(c, hipStreamSynchronize(c->stream));
-            hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]);
-            k.d_ins_pos[h] = nullptr; k.d_ins_len[h] = k.d_ins_off[h] = nullptr; k.d_ins_bases[h] = nullptr; k.n_ins[h] = k.n_ins_bases[h] = 0;
+            k.n_ins[h] = k.n_ins_bases[h] = 0;
         }
     }
     k.mutated = true; k.n_cand = 0;
@@ -324,11 +327,12 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     const uint32_t n_cand = (uint32_t)c->h_counters[7];
     k.n_cand = n_cand;
     if (n_cand == 0) return DWGSIM_HIP_OK;
-    int32_t *d_cand = nullptr; Event *d_ev = nullptr; uint4 *d_flags = nullptr; uint32_t *d_small = nullptr;   // d_small: [0] max_del, [1..4] tot4
-    HIPC(c, hipMalloc((void **)&d_cand, sizeof(int32_t) * (size_t)n_cand));
-    HIPC(c, hipMalloc((void **)&d_ev, sizeof(Event) * (size_t)n_cand));
-    HIPC(c, hipMalloc((void **)&d_flags, sizeof(uint4) * (size_t)n_cand));
-    HIPC(c, hipMalloc((void **)&d_small, 8 * sizeof(uint32_t)));
+    if (ensure(c, c->w_cand, sizeof(int32_t) * (size_t)n_cand) || ensure(c, c->w_ev, sizeof(Event) * (size_t)n_cand) ||
+        ensure(c, c->w_flags, sizeof(uint4) * (size_t)n_cand) || ensure(c, c->w_small, 8 * sizeof(uint32_t)) ||
+        ensure(c, c->w_lo, sizeof(int32_t) * (size_t)n_cand) || ensure(c, c->w_sufmin, sizeof(int32_t) * (size_t)n_cand) ||
+        ensure(c, c->w_bound, (size_t)n_cand)) return DWGSIM_HIP_ERR_DEVICE;
+    int32_t *d_cand = (int32_t *)c->w_cand.p; Event *d_ev = (Event *)c->w_ev.p; uint4 *d_flags = (uint4 *)c->w_flags.p;
+    uint32_t *d_small = (uint32_t *)c->w_small.p;   // [0] max_del, [1..4] tot4
     HIPC(c, hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), c->stream));
     launch_compact(c->stream, d_mask, d_cnt, d_cand, l);
     // K2: events, liveness, insertion-table allocation
@@ -340,18 +344,26 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     for (int h = 0; h < 2; ++h) {
         k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h];
         const size_t n = k.n_ins[h] ? k.n_ins[h] : 1, nb = k.n_ins_bases[h] ? k.n_ins_bases[h] : 1;
-        HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * n));
-        HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * n));
-        HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * n));
-        HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], nb + 16));
+        if (n > k.cap_ins[h]) {
+            hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]);
+            k.cap_ins[h] = n + n / 4 + 64;
+            HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * k.cap_ins[h]));
+            HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * k.cap_ins[h]));
+            HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * k.cap_ins[h]));
+        }
+        if (nb > k.cap_bases[h]) {
+            hipFree(k.d_ins_bases[h]);
+            k.cap_bases[h] = nb + nb / 4 + 256;
+            HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], k.cap_bases[h] + 16));
+        }
     }
     // K3 + K4
     const ContigDev cd = contig_dev(k);
     launch_apply(c->stream, d_ev, n_cand, d_flags, cd, wp);
-    launch_justify(c->stream, d_ev, n_cand, cd);
+    if (c->seq_justify) launch_justify_seq(c->stream, d_ev, n_cand, cd);
+    else launch_justify(c->stream, d_ev, n_cand, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
-    HIPC(c, hipFree(d_cand)); HIPC(c, hipFree(d_ev)); HIPC(c, hipFree(d_flags)); HIPC(c, hipFree(d_small));
     return DWGSIM_HIP_OK;
 }
 

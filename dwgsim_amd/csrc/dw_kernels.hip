@@ -8,7 +8,8 @@
 //     k_events        one thread per candidate: speculative event (type, ploidy, lengths)
 //     k_resolve       liveness of candidates (deletion runs swallow later candidates)
 //     k_apply         writes live events into the haplotype cells + insertion tables
-//     k_justify       left-justification of indels (sequential semantics, sparse walk)
+//     k_jreach / k_sufmin / k_jbound / k_jrun   left-justification of indels: exact sequential
+//                     semantics inside independent clusters, clusters in parallel
 //     k_collect_mask / k_gather   list of mutated cells for the host's txt/vcf writer
 //   read simulation (replaces the loop body src/dwgsim.c:636-1099)
 //     k_place         per pair: attempts until the N filter / geometry accept; random-read flag
@@ -349,8 +350,8 @@ DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
         else { prev_del[0] = prev_del[1] = 0; justify_ins(h1, i); }
     }
 }
-// one thread walks events [k0, k1) of the contig (v1: the whole contig from one thread)
-__global__ void k_justify(const Event *ev, uint32_t n_cand, ContigDev c)
+// sequential cross-check (DWGSIM_HIP_JUSTIFY=seq): one thread walks every live event of the contig
+__global__ void k_justify_seq(const Event *ev, uint32_t n_cand, ContigDev c)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int prev_del[2] = {0, 0};
@@ -359,7 +360,121 @@ __global__ void k_justify(const Event *ev, uint32_t n_cand, ContigDev c)
         const Event e = ev[k];
         if (!e.live) continue;
         const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
-        if (prev_del[0] | prev_del[1])      // an unmutated non-N position in the gap resets prev_del (mut.c:585-587)
+        if (prev_del[0] | prev_del[1])
+            for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
+        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
+        last = right;
+    }
+}
+
+// ---- parallel left-justification --------------------------------------------------------------
+// The reference's pass is sequential, but an indel only interacts with what its leftward scan can
+// touch.  (1) k_jreach: per live event, a conservative lower bound `lo` of every cell its scan can
+// read or write: continue while the cell is mutated on either haplotype (pre-justify state) or the
+// reference is periodic there (deletion: ref[j]&3 == ref[j+L]&3, insertion: the rotated copy keeps
+// matching).  Shifts preserve (cell & 3) at every position, so the true scan never goes further.
+// (2) k_sufmin: suffix minimum of lo.  (3) k_jbound: event b starts a new cluster iff no event >= b
+// can reach the previous live event's footprint and an unmutated non-N position separates them
+// (prev_del is then 0, mut.c:585-587).  (4) k_jrun: one thread per cluster replays the exact
+// sequential semantics (justify_visit) over its events; clusters touch disjoint cells.
+__global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, int32_t *__restrict__ lo)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    const Event e = ev[k];
+    int64_t reach = 0x7fffffff;
+    if (e.live) {
+        const int64_t p = e.pos;
+        reach = p;
+        if (e.type == 2) {
+            // period = the run of DELETE cells the sequential pass would measure at p (adjacent runs merge,
+            // mut.c:503 / :535 / :557): haplotype 1 for hom and hap-1 events, haplotype 2 for hap-2 events
+            const int64_t L = del_run(c.hap[(e.hap & 1) ? 0 : 1], p, c.l);
+            int64_t j = p - 1;
+            for (; j >= 0; --j) {
+                const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
+                if (!(mutated || (p + L < c.l && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
+            }
+            reach = j < 0 ? 0 : j;                     // last cell read
+        } else if (e.type == 3) {
+            // the copies on the two haplotypes carry the same bases before justification: follow one of them
+            const int h = (e.hap & 1) ? 0 : 1;
+            const uint32_t idx = ins_find(c.hap[h], p);
+            const uint32_t n = c.hap[h].ins_len[idx];
+            const uint8_t *P = c.hap[h].ins_bases + c.hap[h].ins_off[idx];
+            // rotating left by one makes the cell's base the new first base: after r rotations the last
+            // inserted base is P[n-1-r] while r < n, then ref[p-1-(r-n)] & 3 (bases rotated in earlier)
+            int64_t j = p - 1; int64_t r = 0;
+            for (; j >= 0; --j, ++r) {
+                const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
+                const uint32_t last = r < (int64_t)n ? (uint32_t)P[n - 1 - r] : (uint32_t)(c.ref[p - 1 - (r - n)] & 3);
+                if (!(mutated || last == (uint32_t)(c.ref[j] & 3))) break;
+            }
+            reach = j < 0 ? 0 : j;
+        } else if (p > 0) {
+            // substitution: no scan; it only matters as a neighbour (prev_del) of adjacent events
+            reach = p;
+        }
+    }
+    lo[k] = (int32_t)reach;
+}
+// single block: sufmin[k] = min(lo[k..n))
+__global__ void k_sufmin(const int32_t *__restrict__ lo, uint32_t n, int32_t *__restrict__ sufmin)
+{
+    __shared__ int32_t sm[16];
+    __shared__ int32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0x7fffffff;
+    __syncthreads();
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    const uint32_t nchunk = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t ch = 0; ch < nchunk; ++ch) {
+        // walk the array from its end: thread t handles element (n-1) - (ch*blockDim + t)
+        const int64_t i = (int64_t)n - 1 - ((int64_t)ch * blockDim.x + threadIdx.x);
+        int32_t v = i >= 0 ? lo[i] : 0x7fffffff;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d); if (lane >= d && o < v) v = o; }   // inclusive min-scan
+        if (lane == 63) sm[wave] = v;
+        __syncthreads();
+        int32_t pre = carry_s;
+        for (int w = 0; w < wave; ++w) if (sm[w] < pre) pre = sm[w];
+        if (pre < v) v = pre;
+        if (i >= 0) sufmin[i] = v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry_s = v;
+        (void)nw;
+        __syncthreads();
+    }
+}
+__global__ void k_jbound(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const int32_t *__restrict__ sufmin, uint8_t *__restrict__ bound)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    uint8_t b = 0;
+    if (ev[k].live) {
+        int64_t a = (int64_t)k - 1;
+        while (a >= 0 && !ev[a].live) --a;
+        if (a < 0) b = 1;
+        else {
+            const int64_t right_a = (int64_t)ev[a].pos + (ev[a].type == 2 ? (int64_t)ev[a].len - 1 : 0);
+            if ((int64_t)sufmin[k] > right_a) {
+                for (int64_t q = right_a + 1; q < (int64_t)ev[k].pos; ++q) if (c.ref[q] < 4) { b = 1; break; }
+            }
+        }
+    }
+    bound[k] = b;
+}
+__global__ void k_jrun(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const uint8_t *__restrict__ bound)
+{
+    const uint32_t k0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k0 >= n_cand || !bound[k0]) return;
+    int prev_del[2] = {0, 0};
+    int64_t last = -1;
+    for (uint32_t k = k0; k < n_cand; ++k) {
+        const Event e = ev[k];
+        if (!e.live) continue;
+        if (k > k0 && bound[k]) break;
+        const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
+        if (k > k0 && (prev_del[0] | prev_del[1]))      // an unmutated non-N position in the gap resets prev_del (mut.c:585-587)
             for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
         for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
         last = right;
@@ -824,9 +939,17 @@ void launch_apply(hipStream_t st, Event *ev, uint32_t n, const uint4 *flags, Con
 {
     if (n) hipLaunchKernelGGL(k_apply, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, flags, c, wp);
 }
-void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c)
+void launch_justify_seq(hipStream_t st, const Event *ev, uint32_t n, ContigDev c)
 {
-    if (n) hipLaunchKernelGGL(k_justify, dim3(1), dim3(64), 0, st, ev, n, c);
+    if (n) hipLaunchKernelGGL(k_justify_seq, dim3(1), dim3(64), 0, st, ev, n, c);
+}
+void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_jreach, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, lo);
+    hipLaunchKernelGGL(k_sufmin, dim3(1), dim3(1024), 0, st, lo, n, sufmin);
+    hipLaunchKernelGGL(k_jbound, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
+    hipLaunchKernelGGL(k_jrun, dim3(cdiv(n, 64)), dim3(64), 0, st, ev, n, c, bound);
 }
 void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count)
 {

@@ -48,10 +48,36 @@ def write_fasta(path: str, contigs, width: int = 60) -> None:
                 f.write(arr[full:].tobytes() + b"\n")
 
 
+def repeat_rich_contig(length: int, seed: int) -> np.ndarray:
+    """Random bases with homopolymers, short tandem repeats and N blocks sprinkled in: the worst case
+    for indel left-justification (long shifts, interacting neighbours)."""
+    out = random_contig(length, seed)
+    r = _splitmix64(4 * (length // 400 + 8), seed ^ 0xABCDEF)
+    k = 0
+    pos = 50
+    units = [b"A", b"T", b"C", b"G", b"AT", b"CA", b"CAG", b"TTAGGG", b"AAAT", b"GC"]
+    while pos < length - 400:
+        kind = int(r[k] % np.uint64(12)); reps = int(r[k + 1] % np.uint64(40)) + 3; gap = int(r[k + 2] % np.uint64(500)) + 20
+        k += 3
+        if kind < len(units):
+            u = np.frombuffer(units[kind], dtype=np.uint8)
+            seg = np.tile(u, reps)[: min(len(u) * reps, length - pos - 1)]
+            out[pos:pos + len(seg)] = seg
+            pos += len(seg)
+        elif kind == 10:
+            n = reps * 3
+            out[pos:pos + n] = ord("N")
+            pos += n
+        pos += gap
+    return out
+
+
 # named workloads (SURVEY.md 8d)
 def workload_contigs(name: str):
     if name == "tiny":            # a few kb with an N run, for unit tests
         return [("t1", random_contig(6000, 11, [(2500, 2530)])), ("t2", random_contig(4000, 12)), ("short", random_contig(300, 13))]
+    if name == "repeats":         # left-justification stress
+        return [("rep1", repeat_rich_contig(1_500_000, 21)), ("rep2", repeat_rich_contig(300_000, 22))]
     if name == "ecoli":           # S2: one contig, E. coli K-12 MG1655 length
         return [("ecoli_synth", random_contig(4_641_652, 1))]
     if name == "chr20":           # S3: chr20-length with telomere / internal N blocks

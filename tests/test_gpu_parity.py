@@ -23,3 +23,33 @@ def test_batches_and_shards_are_order_independent(lib, oracle_bin, golden_dir):
     """Read-index ranges are independent: tiny batches (many simulate() calls, rand_base chained by the
     host) give the same bytes as one call -- the property multi-GPU sharding relies on."""
     compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 3000 -y 0.2", batch_pairs=257)
+
+
+@pytest.fixture(scope="module")
+def repeats_fa(tmp_path_factory):
+    from dwgsim_amd import synth
+    p = str(tmp_path_factory.mktemp("rep") / "repeats.fa")
+    synth.write_fasta(p, synth.workload_contigs("repeats"))
+    return p
+
+
+@pytest.mark.parametrize("flags", [
+    "-z 31 -M 2 -r 0.02 -R 0.6 -X 0.5",
+    "-z 32 -M 2 -r 0.2 -R 0.9 -X 0.3 -I 2",
+    "-z 33 -M 2 -r 0.05 -R 1.0 -X 0.8 -H",
+    "-z 34 -N 20000 -1 100 -2 100 -r 0.03 -R 0.5 -X 0.4 -n 5",
+])
+def test_mutation_walk_on_repeat_rich_contigs(lib, oracle_bin, repeats_fa, flags):
+    """1.8 Mb of homopolymers / tandem repeats / N blocks at high indel rates: the cluster-parallel
+    left-justification must reproduce the oracle's sequential pass exactly."""
+    compare_case(lib, oracle_bin, repeats_fa, flags)
+
+
+def test_parallel_justify_equals_sequential_crosscheck(lib, repeats_fa, monkeypatch):
+    params = api.parse_flags("-z 35 -M 2 -r 0.1 -R 0.8 -X 0.6", lib)
+    contigs = api.read_fasta(repeats_fa)
+    par = api.run_job(params, contigs, lib=lib)
+    monkeypatch.setenv("DWGSIM_HIP_JUSTIFY", "seq")
+    seq = api.run_job(params, contigs, lib=lib)
+    assert par.mutations_txt == seq.mutations_txt and par.mutations_vcf == seq.mutations_vcf
+    assert len(par.mutations_txt) > 100000
