@@ -51,10 +51,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ecoli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     args = ap.parse_args()
 
     import torch
-    from dwgsim_amd import api, synth
+    from dwgsim_amd import api, synth, shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -68,7 +69,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = api.load()
-    params = api.parse_flags(FLAGS, lib)
+    flags = args.flags or FLAGS
+    params = api.parse_flags(flags, lib)
     contigs = synth.workload_contigs(args.workload)
     name, arr = contigs[0]
     tot_len = len(arr)
@@ -90,12 +92,8 @@ def main():
         t0 = time.perf_counter()
         ctx.mutate(cid)                                        # mutation walk on the GPU
         t1 = time.perf_counter()
-        rand_base = 0
-        if dist is not None:                                   # one integer per rank (no data-path collective)
-            mine = torch.tensor([ctx.count_random(cid, first_ii, n_pairs)], dtype=torch.int64, device="cuda")
-            allc = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allc, mine)
-            rand_base = int(sum(int(x.item()) for x in allc[:rank]))
+        # one integer per rank (no data-path collective): random reads in the ranges of lower ranks
+        rand_base = shard.exchange_rand_base(ctx, cid, first_ii, n_pairs, rank, world, dist, device="cuda")
         t2 = time.perf_counter()
         b = ctx.simulate(cid, first_ii, n_pairs, rand_base, 0)
         if record:
@@ -127,7 +125,7 @@ def main():
             "metric": "M read-pairs/sec (2x150 bp PE)", "value": round(value, 3), "unit": "M read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"S2 {name}: one {tot_len} bp uniform-random contig (BASELINE configs[1] stand-in), dwgsim {FLAGS}, "
+            "config": {"workload": f"S2 {name}: one {tot_len} bp uniform-random contig (BASELINE configs[1] stand-in), dwgsim {flags}, "
                                    f"{n_pairs} pairs per GPU per step; step = mutation walk + all pairs, FASTQ text left in HBM",
                        "pairs_per_gpu": n_pairs, "fastq_bytes_per_step_per_gpu": stats["bytes"], "random_pairs": stats["n_random"],
                        "parallelism": f"read-index shards x{world}"},

@@ -53,3 +53,19 @@ def test_parallel_justify_equals_sequential_crosscheck(lib, repeats_fa, monkeypa
     seq = api.run_job(params, contigs, lib=lib)
     assert par.mutations_txt == seq.mutations_txt and par.mutations_vcf == seq.mutations_vcf
     assert len(par.mutations_txt) > 100000
+
+
+def test_cli_is_a_drop_in_for_the_dwgsim_command(oracle_bin, golden_dir, tmp_path):
+    """dwgsim-hip <options> ref.fa prefix writes the reference's five files; after gunzip they equal the
+    oracle's (Philox mode) outputs, as the reference's own test compares them (testdata/test.sh:21-26)."""
+    import gzip, subprocess
+    from parity_common import run_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "dwgsim_amd", "dwgsim-hip")
+    fasta, flags = os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 3000 -P pfx -r 0.01 -R 0.3"
+    want = run_oracle(oracle_bin, fasta, flags, str(tmp_path))
+    subprocess.run([cli] + flags.split() + [fasta, str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL)
+    for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz"), (2, "bfast.fastq.gz")]:
+        assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k]
+    assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
+    assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
