@@ -31,9 +31,12 @@ enum : uint32_t {
     D_PAIR = 4,         // index = ii.  slot 0 random-read test (dwgsim.c:649), 1 haplotype (:716), 2 strand (:723)
     D_PLACE = 5,        // slot t = position uniform of placement try t (dwgsim.c:671)
     D_PLACE_NORM = 6,   // block t, retry r = polar tries of the insert-size normal of try t (dwgsim.c:657)
-    D_BASE0 = 8,        // +read end.  block i: slot 2i error test (dwgsim.c:237) or random base (:1000), 2i+1 substituted base (:238)
-    D_QUAL0 = 10,       // +read end.  block p, retry r: polar tries; accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) (dwgsim.c:912)
-    D_FLOW0 = 12        // +read end.  sequential slots inside generate_errors_flows (dwgsim.c:246-417)
+    // NARROW domains: a draw is one 32-bit word w of a block, u = w * 2^-32, four draws per Philox block
+    D_BASE0 = 8,        // +read end.  word i (block i>>2, word i&3): error test of base i (dwgsim.c:237) or random-read base i (:1000)
+    D_QUAL0 = 10,       // +read end.  block p, retry m: polar tries 2m = words (0,1), 2m+1 = words (2,3); the accepted try gives
+                        // quality normals 2p (v2*fac) and 2p+1 (v1*fac) (dwgsim.c:912, :156-175)
+    D_FLOW0 = 12,       // +read end.  sequential slots inside generate_errors_flows (dwgsim.c:246-417)
+    D_SUB0 = 16         // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
 };
 
 struct U4 { uint32_t x, y, z, w; };

@@ -54,7 +54,7 @@ struct dwgsim_hip_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     double e_by[2] = {0, 0};
-    double *d_thr[2] = {nullptr, nullptr};
+    uint64_t *d_thr[2] = {nullptr, nullptr};
     int8_t *d_qbase[2] = {nullptr, nullptr};
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
@@ -93,6 +93,7 @@ WalkParams walk_params(const dwgsim_hip_ctx *c)
 {
     WalkParams w; w.mut_rate = c->prm.mut_rate; w.indel_frac = c->prm.indel_frac; w.indel_extend = c->prm.indel_extend;
     w.indel_min = c->prm.indel_min; w.is_hap = c->prm.is_hap; w.seed = (uint32_t)c->prm.seed;
+    w.mut_thr53 = c->prm.mut_rate <= 0 ? 0 : (uint64_t)ceil(c->prm.mut_rate * 9007199254740992.0);   // exact scaling by 2^53
     return w;
 }
 
@@ -211,17 +212,17 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             const int n = c->prm.length[j];
             if (n <= 0) continue;
             c->e_by[j] = (c->prm.e_end[j] - c->prm.e_start[j]) / n;
-            std::vector<double> thr((size_t)n); std::vector<int8_t> qb((size_t)n);
+            std::vector<uint64_t> thr((size_t)n); std::vector<int8_t> qb((size_t)n);
             for (int i = 0; i < n; ++i) {
                 const double ei = c->prm.e_start[j] + c->e_by[j] * i;
-                thr[(size_t)i] = ei;
+                thr[(size_t)i] = ei <= 0 ? 0 : (uint64_t)ceil(ei * 4294967296.0);   // u = w * 2^-32 < ei  <=>  w < ceil(ei * 2^32) (exact: scaling by 2^32 is exact)
                 char q;
                 if (ei > 0) q = (char)((int)(-10.0 * log(ei) / log(10.0) + 0.499) + '!'); else q = 40 + '!';
                 qb[(size_t)i] = (int8_t)q;
             }
-            HIPC(c, hipMalloc((void **)&c->d_thr[j], sizeof(double) * (size_t)n));
+            HIPC(c, hipMalloc((void **)&c->d_thr[j], sizeof(uint64_t) * (size_t)n));
             HIPC(c, hipMalloc((void **)&c->d_qbase[j], (size_t)n));
-            HIPC(c, hipMemcpy(c->d_thr[j], thr.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+            HIPC(c, hipMemcpy(c->d_thr[j], thr.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
             HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
         }
         std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";

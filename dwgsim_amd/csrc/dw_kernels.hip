@@ -95,7 +95,7 @@ __global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkPara
             const uint32_t c = (in[b >> 2] >> (8 * (b & 3))) & 0xff;
             if (c < 4 && p0 + b < l) {
                 const U4 blk = rng_block(key, D_WALK, (uint64_t)(p0 + b), 0, 0, 0);
-                if (u_hi(blk) < wp.mut_rate) bits |= 1u << b;
+                if ((((uint64_t)blk.z << 21) | (uint64_t)(blk.w >> 11)) < wp.mut_thr53) bits |= 1u << b;   // u53(w2,w3) < mut_rate
             }
         }
     }
@@ -691,22 +691,46 @@ __global__ void k_place(SimArgs a)
 }
 
 // ---- FASTQ text assembly ----
-struct Writer {               // sequential byte stream -> aligned dword stores (byte stores for head / tail)
-    uint8_t *dst; uint32_t acc, nacc;
-    DW_DEV void init(uint8_t *p) { dst = p; acc = 0; nacc = 0; }
+struct Writer {               // sequential byte stream -> 16-byte aligned dwordx4 stores
+    // `blk` = 16-byte aligned block being filled, (lo,hi) its bytes, `n` = bytes filled (head: bytes
+    // [0,skip) of the first block belong to the previous record and are never stored)
+    uint8_t *blk; uint64_t lo, hi; uint32_t n, skip;
+    DW_DEV void init(uint8_t *p)
+    {
+        const uint32_t o = (uint32_t)((uintptr_t)p & 15);
+        blk = p - o; lo = hi = 0; n = o; skip = o;
+    }
+    DW_DEV void store_block(uint32_t upto)       // store bytes [skip, upto) of the current block
+    {
+        if (skip == 0 && upto == 16) { *reinterpret_cast<uint4 *>(blk) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); return; }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {       // whole dwords where possible, single bytes at the ragged edges
+            const uint32_t w = (uint32_t)((q < 2 ? lo : hi) >> (32 * (q & 1)));
+            const uint32_t b0 = 4 * q, b1 = b0 + 4;
+            if (skip <= b0 && upto >= b1) *reinterpret_cast<uint32_t *>(blk + b0) = w;
+            else for (uint32_t k = b0; k < b1; ++k) if (k >= skip && k < upto) blk[k] = (uint8_t)(w >> (8 * (k - b0)));
+        }
+    }
+    DW_DEV void advance() { store_block(16); blk += 16; lo = hi = 0; n = 0; skip = 0; }
     DW_DEV void put(uint32_t b)
     {
-        if (nacc == 0 && ((uintptr_t)dst & 3)) { *dst++ = (uint8_t)b; return; }
-        acc |= b << (8 * nacc);
-        if (++nacc == 4) { *reinterpret_cast<uint32_t *>(dst) = acc; dst += 4; acc = 0; nacc = 0; }
+        const uint64_t v = (uint64_t)b << (8 * (n & 7));
+        if (n < 8) lo |= v; else hi |= v;
+        if (++n == 16) advance();
     }
-    DW_DEV void put4(uint32_t w)
+    DW_DEV void put4(uint32_t w)                 // four bytes, little-endian
     {
-        if ((uintptr_t)dst & 3) { put(w & 0xff); put((w >> 8) & 0xff); put((w >> 16) & 0xff); put(w >> 24); return; }
-        if (nacc == 0) { *reinterpret_cast<uint32_t *>(dst) = w; dst += 4; }
-        else { const uint32_t sh = 8 * nacc; *reinterpret_cast<uint32_t *>(dst) = acc | (w << sh); dst += 4; acc = w >> (32 - sh); }
+        const uint32_t sh = 8 * (n & 7);
+        const uint64_t v = (uint64_t)w << sh;
+        if (n < 8) { lo |= v; if (sh > 32) hi |= (uint64_t)w >> (64 - sh); }
+        else hi |= v;
+        if (n + 4 >= 16) {
+            const uint32_t over = n + 4 - 16;    // bytes that belong to the next block (0..3)
+            advance();
+            if (over) { lo = (uint64_t)w >> (8 * (4 - over)); n = over; }
+        } else n += 4;
     }
-    DW_DEV void flush() { for (uint32_t k = 0; k < nacc; ++k) dst[k] = (uint8_t)(acc >> (8 * k)); nacc = 0; }
+    DW_DEV void flush() { if (n > skip) store_block(n); }
 };
 struct Out2 {                 // the bwa stream of this read end and the interleaved bfast stream
     Writer a, b; bool ea, eb;
@@ -775,27 +799,51 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
     }
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
+    // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
+    // substituted base is drawn afterwards, only for the (few) marked bases
     int32_t n_err = 0;
+    const int nw = (s + 7) >> 3;
     if (valid) {
-        const double *thr = j ? a.e_thr[1] : a.e_thr[0];
-        for (int w = 0; w * 8 < s; ++w) {
-            uint32_t word = is_rand ? 0u : lds[w * nthr], out = 0;
+        const uint64_t *thr = j ? a.e_thr[1] : a.e_thr[0];
+        for (int w = 0; w < nw; ++w) {
+            const uint32_t word = is_rand ? 0u : lds[w * nthr];
+            uint32_t out = 0;
+            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w));
+            const U4 q1 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w + 1));
+            const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int i = w * 8 + b;
                 if (i < s) {
-                    const U4 blk = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i);
                     uint32_t c;
-                    if (is_rand) c = (uint32_t)((int32_t)(u_lo(blk) * 4.0) & 3);
+                    if (is_rand) c = rw[b] >> 30;                       // (int)(u * 4.0) & 3
                     else {
                         c = (word >> (4 * b)) & 15u;
                         if (c >= 4) c = 4;
-                        else if (u_lo(blk) < thr[i]) { c = (c + (uint32_t)(uint64_t)(u_hi(blk) * 3.0 + 1)) & 3u; ++n_err; }
+                        else if ((uint64_t)rw[b] < thr[i]) { c |= 8u; ++n_err; }
                     }
                     out |= c << (4 * b);
                 }
             }
             lds[w * nthr] = out;
+        }
+        if (!is_rand) {
+            int w = 0; uint32_t pend = 0;
+            for (;;) {
+                while (pend == 0 && w < nw) { pend = lds[w * nthr] & 0x88888888u; if (!pend) ++w; }
+                if (!pend) break;
+                const int b = (__ffs((int)pend) - 1) >> 2;
+                pend &= pend - 1;
+                const int i = w * 8 + b;
+                const U4 q = rng_block(key, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)(i >> 2));
+                const uint32_t rwd = (i & 2) ? ((i & 1) ? q.w : q.z) : ((i & 1) ? q.y : q.x);
+                const uint32_t add = 1u + (uint32_t)(((uint64_t)rwd * 3u) >> 32);        // (int)(u * 3.0 + 1), exact
+                uint32_t word = lds[w * nthr];
+                const uint32_t c = (((word >> (4 * b)) & 7u) + add) & 3u;
+                word = (word & ~(0xFu << (4 * b))) | (c << (4 * b));
+                lds[w * nthr] = word;
+                if (!pend) ++w;
+            }
         }
     }
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
@@ -875,12 +923,16 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         else if (!(0 < a.p.quality_std)) {
             for (int i = 0; i < s; ++i) { int32_t q = qb[i]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
         } else {
-            uint32_t qacc = 0, nq = 0, r = 0; int p = 0; const int np = (s + 1) >> 1;
+            uint32_t qacc = 0, nq = 0, m = 0; int p = 0; const int np = (s + 1) >> 1;
             while (p < np) {
-                const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, r, (uint32_t)p);
-                const double v1 = 2.0 * u_lo(blk) - 1.0, v2 = 2.0 * u_hi(blk) - 1.0;
-                const double rsq = v1 * v1 + v2 * v2;
-                if (rsq >= 1.0 || rsq == 0.0) { ++r; continue; }
+                const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, m, (uint32_t)p);
+                // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
+                const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
+                const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
+                const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
+                const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
+                if (!oka && !okb) { ++m; continue; }
+                const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
                 const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -894,7 +946,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
                         if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
                     }
                 }
-                ++p; r = 0;
+                ++p; m = 0;
             }
             for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
         }

@@ -44,6 +44,7 @@ struct ContigDev {
 
 struct WalkParams {
     double mut_rate, indel_frac, indel_extend;
+    uint64_t mut_thr53;            // ceil(mut_rate * 2^53): u53 < mut_rate  <=>  k53 < mut_thr53
     int32_t indel_min, is_hap;
     uint32_t seed;
 };
@@ -59,7 +60,7 @@ struct SimArgs {
     SimParams p;
     ContigDev c;
     uint64_t first_ii, n_pairs, rand_base;
-    const double *e_thr[2];        // per-position error thresholds e.start + e.by*i (dwgsim.c:237)
+    const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
     const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics
     const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"
     const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"

@@ -57,10 +57,12 @@ enum {
     D_PAIR = 4,        /* index = ii; slot 0 rand-read test, 1 haplotype, 2 strand */
     D_PLACE = 5,       /* index = ii; slot t = position uniform of placement try t */
     D_PLACE_NORM = 6,  /* index = ii; block t = polar tries of placement try t */
-    D_BASE0 = 8,       /* +j; index = ii; block i: slot 2i error test / random base, 2i+1 substitution */
-    D_QUAL0 = 10,      /* +j; index = ii; block p = polar tries giving normals 2p (v2) and 2p+1 (v1) */
+    D_BASE0 = 8,       /* +j; index = ii; NARROW (32-bit) uniforms: word i = error test of base i / random-read base i */
+    D_QUAL0 = 10,      /* +j; index = ii; NARROW: block p holds two polar tries (words 0,1 and 2,3) per retry index;
+                          the accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) */
     D_FLOW0 = 12,      /* +j; index = ii; slot = running draw count inside generate_errors_flows */
-    D_CALIB = 14       /* -B calibration (dwgsim_opt.c:415-457); index = read number */
+    D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
+    D_SUB0 = 16        /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
 };
 
 typedef struct {
@@ -136,6 +138,27 @@ static inline double rng_u(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, u
     return oracle_philox_uniform(r->k0, r->k1, dom, idx, att, retry, slot);
 }
 
+/* NARROW uniform of the per-base domains: mode B takes one 32-bit word (word = slot & 3 of block
+ * slot >> 2) and returns w * 2^-32, so one Philox block serves four draws.  Mode A: next drand48. */
+double oracle_philox_uniform32(uint32_t seed, uint32_t contig, uint32_t domain, uint64_t index,
+                               uint32_t attempt, uint32_t retry, uint32_t slot)
+{
+    uint32_t ctr[4], key[2], w[4];
+    ctr[0] = (uint32_t)index;
+    ctr[1] = (uint32_t)((index >> 32) & 0xFFFFu) | (retry << 16);
+    ctr[2] = (domain << 24) | (attempt & 0xFFFFFFu);
+    ctr[3] = slot >> 2;
+    key[0] = seed; key[1] = contig;
+    oracle_philox4x32_10(ctr, key, w);
+    return (double)w[slot & 3] * 0x1p-32;
+}
+static inline double rng_u32(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t retry, uint32_t slot)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
+    return oracle_philox_uniform32(r->k0, r->k1, dom, idx, att, retry, slot);
+}
+
 /* Deterministic natural log for x > 0 finite: the classic fdlibm/FreeBSD-msun e_log.c
  * algorithm (argument reduction x = 2^k (1+f), s = f/(2+f), degree-14 even polynomial in s)
  * restated with only IEEE + - * / in fp64, so gcc/x86-64 and hipcc/gfx950 (both compiled
@@ -178,7 +201,7 @@ double oracle_det_log(double x)
 /* A stream of normals.  Mode A ignores it (global cache + sequential draws).  Mode B: polar
  * tries r = 0,1,.. of block p; the accepted try gives normal 2p (= v2*fac) and, if `cache`,
  * normal 2p+1 (= v1*fac); p advances after every accepted try. */
-typedef struct { uint32_t dom; uint64_t idx; uint32_t att; uint32_t p; int cache; int has; double g; } nstream_t;
+typedef struct { uint32_t dom; uint64_t idx; uint32_t att; uint32_t p; int cache; int has; double g; int narrow; } nstream_t;
 
 /* dwgsim.c:156-175 ran_normal(): Marsaglia polar method */
 static double ran_normal(rng_t *r, nstream_t *ns)
@@ -189,8 +212,13 @@ static double ran_normal(rng_t *r, nstream_t *ns)
         double v1, v2, rsq, fac, lg;
         uint32_t retry = 0;
         do {
-            v1 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p) - 1.0;
-            v2 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p + 1) - 1.0;
+            if (ns->narrow) { /* two tries per Philox block: try `retry` uses words 2*(retry&1), +1 of block p, retry index retry>>1 */
+                v1 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, retry >> 1, 4 * ns->p + 2 * (retry & 1)) - 1.0;
+                v2 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, retry >> 1, 4 * ns->p + 2 * (retry & 1) + 1) - 1.0;
+            } else {
+                v1 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p) - 1.0;
+                v2 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p + 1) - 1.0;
+            }
             rsq = v1 * v1 + v2 * v2;
             retry++;
         } while (rsq >= 1.0 || rsq == 0.0);
@@ -773,7 +801,7 @@ typedef struct { sink_t bfast, bwa1, bwa2, txt, vcf; int has_bfast, has_bwa, has
 /* quality string for read end j, dwgsim.c:899-918 (and :1002-1021) */
 static void make_quals(const opt_t *o, rng_t *r, int j, uint64_t ii, uint32_t att, int len, char *q)
 {
-    nstream_t ns = { D_QUAL0 + (uint32_t)j, ii, att, 0, 1, 0, 0.0 };
+    nstream_t ns = { D_QUAL0 + (uint32_t)j, ii, att, 0, 1, 0, 0.0, 1 };
     int i;
     if (o->fixed_quality) { for (i = 0; i < len; ++i) q[i] = o->fixed_quality[0]; }
     else for (i = 0; i < len; ++i) {
@@ -912,7 +940,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                         uint32_t t = 0;
                         do { /* dwgsim.c:655-675 */
                             if (0 < s[1]) {
-                                nstream_t ns = { D_PLACE_NORM, ii, att, t, 0, 0, 0.0 };
+                                nstream_t ns = { D_PLACE_NORM, ii, att, t, 0, 0, 0.0, 0 };
                                 double ran = ran_normal(r, &ns);
                                 ran = ran * o->std_dev + o->dist;
                                 d = (int)(ran + 0.5);
@@ -973,8 +1001,8 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                         for (; 0 <= i && i < s[j]; i += step) {
                             uint8_t c = tb[j].seq[i];
                             if (c >= 4) c = 4;
-                            else if (rng_u(r, D_BASE0 + (uint32_t)j, ii, att, 0, 2 * (uint32_t)i) < o->e[j].start + o->e[j].by * i) {
-                                c = (uint8_t)((c + (uint64_t)(rng_u(r, D_BASE0 + (uint32_t)j, ii, att, 0, 2 * (uint32_t)i + 1) * 3.0 + 1)) & 3);
+                            else if (rng_u32(r, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i) < o->e[j].start + o->e[j].by * i) {
+                                c = (uint8_t)((c + (uint64_t)(rng_u32(r, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 3.0 + 1)) & 3);
                                 ++n_err[j];
                                 if (0 == i) ++n_err_first[j];
                             }
@@ -995,7 +1023,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                     static const int zero6[6] = { 0, 0, 0, 0, 0, 0 };
                     for (int j = 0; j < 2; ++j) {
                         if (s[j] <= 0) continue;
-                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_u(r, D_BASE0 + (uint32_t)j, ii, att, 0, 2 * (uint32_t)i) * 4.0) & 3);
+                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_u32(r, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 4.0) & 3);
                         make_quals(o, r, j, ii, att, s[j], qstr);
                         if (SOLID == o->data_type) to_colors(tb[j].seq, s[j]);
                         emit_read(o, out, j, "rand", 0, 0, 0, 0, 1, 1, zero6, zero6, rand_ii, tb[j].seq, s[j], qstr);
