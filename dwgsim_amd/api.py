@@ -11,7 +11,7 @@ import shlex
 from dataclasses import dataclass, field
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdwgsim_hip.so")
+LIB_PATH = os.environ.get("DWGSIM_HIP_LIB") or os.path.join(_HERE, "libdwgsim_hip.so")   # env override: analysis builds only
 
 STREAM_BWA1, STREAM_BWA2, STREAM_BFAST = 0, 1, 2
 STREAM_NAMES = {0: "bwa.read1.fastq", 1: "bwa.read2.fastq", 2: "bfast.fastq"}

@@ -205,8 +205,8 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         HIPC(c, hipSetDevice(device));
         HIPC(c, hipStreamCreate(&c->stream));
         for (int i = 0; i < 4; ++i) HIPC(c, hipEventCreate(&c->ev[i]));
-        HIPC(c, hipMalloc((void **)&c->d_counters, 8 * sizeof(uint64_t)));
-        HIPC(c, hipHostMalloc((void **)&c->h_counters, 8 * sizeof(uint64_t), hipHostMallocDefault));
+        HIPC(c, hipMalloc((void **)&c->d_counters, 16 * sizeof(uint64_t)));
+        HIPC(c, hipHostMalloc((void **)&c->h_counters, 16 * sizeof(uint64_t), hipHostMallocDefault));
         // per-position error thresholds and base qualities (dwgsim_opt.c:459-460, dwgsim.c:237, :906-910)
         for (int j = 0; j < 2; ++j) {
             const int n = c->prm.length[j];
@@ -527,11 +527,11 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, 
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     SimArgs a;
     if (build_sim_args(c, *kp, first_ii, n_pairs, 0, a)) return DWGSIM_HIP_ERR_DEVICE;
-    HIPC(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint64_t), c->stream));
+    HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
     launch_place(c->stream, a);
     const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
     launch_scan_excl(c->stream, a.block_rand, nblk, &c->d_counters[3]);
-    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     if (n_random) *n_random = c->h_counters[3];
@@ -561,7 +561,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     (void)nreads;
     for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
     const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-    HIPC(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint64_t), c->stream));
+    HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
     for (int j = 0; j < 2; ++j) HIPC(c, hipMemsetAsync(a.status[j], 0, sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(c->ev[0], c->stream));
     launch_place(c->stream, a);
@@ -570,10 +570,16 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     launch_simulate(c->stream, a);
     HIPC(c, hipEventRecord(c->ev[2], c->stream));
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];
+    if (getenv("DWGSIM_HIP_PHASES")) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)
+        uint64_t tot = 0; for (int k = 0; k < 7; ++k) tot += c->h_counters[8 + k];
+        fprintf(stderr, "[phases]");
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " p%d=%.1f%%", k, tot ? 100.0 * c->h_counters[8 + k] / tot : 0.0);
+        fprintf(stderr, " (ticks %llu)\n", (unsigned long long)tot);
+    }
     if (out) {
         out->n_pairs = n_pairs; out->n_random = c->h_counters[3]; out->n_retries = c->h_counters[1];
         for (int t = 0; t < 3; ++t) { out->bytes[t] = c->out_bytes[slot][t]; out->dev_ptr[t] = c->out[slot][t].p; }

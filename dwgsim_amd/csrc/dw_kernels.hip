@@ -511,27 +511,75 @@ __global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint
 struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n; };
 
 // dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
+// The haplotype is read in 16-byte chunks with the next chunk prefetched; runs of up to 8 cells that
+// hold no INSERT/DELETE cell (bit 4 clear) are handled at once with byte-parallel arithmetic, any other
+// cell goes through the reference's per-cell logic.
 template <bool STORE>
 DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
 {
     ReadRes r{-10, 0, 0, 0};
-    int k = 0; uint32_t acc = 0;
-    int64_t blk = -1; uint64_t clo = 0, chi = 0;          // current 16-byte chunk of the haplotype, decoded from registers
+    int k = 0, kw = 0; uint64_t acc = 0; uint32_t nacc = 0;       // nacc nibbles pending in acc
+    auto push = [&](uint64_t nibs, uint32_t cnt) {                 // append cnt packed nibbles
+        if (STORE) {
+            acc |= nibs << (4 * nacc); nacc += cnt;
+            if (nacc >= 8) { lds[kw * stride] = (uint32_t)acc; acc >>= 32; nacc -= 8; ++kw; }
+        }
+        k += (int)cnt;
+    };
     auto emit = [&](uint32_t v) {
         if (strand) v = v < 4 ? 3 - v : 4;                 // dwgsim.c:150-152
         r.num_n += (v == 4);                                // dwgsim.c:824-831
-        if (STORE) { acc |= v << ((k & 7) * 4); if ((k & 7) == 7) { lds[(k >> 3) * stride] = acc; acc = 0; } }
-        ++k;
+        push(v, 1);
     };
-    for (int64_t i = start; i >= 0 && i < l && k < s; i += step) {
-        if ((i >> 4) != blk) {
-            blk = i >> 4;
-            const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (blk << 4));
-            clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    const int64_t last_chunk = (l - 1) >> 4;
+    const int dirc = step > 0 ? 1 : -1;
+    int64_t cb = -1, pb = -1; uint64_t clo = 0, chi = 0, plo = 0, phi = 0;
+    if (start >= 0 && start < l) {
+        cb = start >> 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (cb << 4));
+        clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        pb = cb + dirc;
+        if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
+    }
+    int64_t i = start;
+    while (i >= 0 && i < l && k < s) {
+        if ((i >> 4) != cb) {
+            cb = i >> 4;
+            if (cb == pb) { clo = plo; chi = phi; }
+            else { const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (cb << 4)); clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+            pb = cb + dirc;
+            if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
         }
-        const uint32_t c = (uint32_t)(((i & 8) ? chi : clo) >> ((i & 7) * 8)) & 0xffu, mt = c & TMASK;
+        const uint64_t half = (i & 8) ? chi : clo;
+        const uint32_t off = (uint32_t)(i & 7);
+        // cells of this 8-byte half in travel order, limited by the half, the read and the contig end
+        uint32_t want = step > 0 ? 8 - off : off + 1;
+        const uint32_t left = (uint32_t)(s - k);
+        if (want > left) want = left;
+        if (step > 0) { const int64_t room = l - i; if ((int64_t)want > room) want = (uint32_t)room; }
+        uint64_t cells = step > 0 ? half >> (8 * off) : __builtin_bswap64(half << (8 * (7 - off)));
+        if (want < 8) cells &= (1ull << (8 * want)) - 1;
+        if ((cells & 0x1010101010101010ull) == 0) {           // only NOCHANGE / SUBSTITUTE cells: one base each
+            if (r.ext_coor < 0) { r.ext_coor = (int32_t)i; if (strand) r.ext_coor -= s - 1; }
+            r.n_sub += __popcll(cells & 0x2020202020202020ull);
+            uint64_t codes = cells & 0x0f0f0f0f0f0f0f0full;
+            const uint64_t ge4 = (codes >> 2) & 0x0101010101010101ull;
+            if (strand) {
+                codes = ((codes ^ 0x0303030303030303ull) & ~(ge4 * 0x0f)) | (ge4 << 2);
+                if (want < 8) codes &= (1ull << (8 * want)) - 1;
+                r.num_n += __popcll(ge4);
+            } else r.num_n += __popcll(ge4 & ~codes);          // exactly code 4 (code 5, '-', is not counted on this strand)
+            uint64_t x = codes;
+            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+            push(x, want);
+            i += (int64_t)step * want;
+            continue;
+        }
+        const uint32_t c = (uint32_t)(half >> (8 * off)) & 0xffu, mt = c & TMASK;
         if (r.ext_coor < 0) {
-            if (mt != T_NONE && mt != T_SUB) continue;
+            if (mt != T_NONE && mt != T_SUB) { i += step; continue; }
             r.ext_coor = (int32_t)i;
             if (strand) r.ext_coor -= s - 1;
         }
@@ -550,8 +598,9 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
                 if (k < s) emit(c & 0xf);
             }
         }
+        i += step;
     }
-    if (STORE && (k & 7)) lds[(k >> 3) * stride] = acc;
+    if (STORE && nacc) lds[kw * stride] = (uint32_t)acc;
     if (k != s) r.ext_coor = -10;
     return r;
 }
@@ -760,6 +809,17 @@ DW_DEV void put_hex(Out2 &o, uint64_t v)
 DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull >> (8 * (v & 7))) & 0xff); }  // "ACGTNNNN"
 
 // K6: one lane per read end (LPP = 2: lanes 2q / 2q+1 are the two ends of pair q; LPP = 1: single end).
+// Opt-in phase timing (tools/phase_profile.sh builds a separate library with -DDW_PHASE_TIMING; the
+// product build compiles these macros to nothing): per wave, shader-clock ticks spent in each phase
+// are added to counters[8 + phase].
+#ifdef DW_PHASE_TIMING
+#define PH_INIT() uint64_t ph_t = __builtin_amdgcn_s_memtime()
+#define PH_MARK(k) do { const uint64_t ph_n = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&a.counters[8 + (k)], (unsigned long long)(ph_n - ph_t)); ph_t = ph_n; } while (0)
+#else
+#define PH_INIT() do { } while (0)
+#define PH_MARK(k) do { } while (0)
+#endif
+
 template <int LPP>
 __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
 {
@@ -769,6 +829,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     __shared__ uint64_t s_base[2];
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK * LPP;
     const int wave = tid >> 6, lane = tid & 63;
+    PH_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     __syncthreads();
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
@@ -789,6 +850,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     const uint32_t rrank = block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &rtot);
     const uint64_t rand_ii = a.rand_base + a.block_rand[t] + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
 
+    PH_MARK(0);     // ticket, meta, random-read rank
     // ---- bases of this read end ----
     PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
     ReadRes rr{0, 0, 0, 0};
@@ -798,6 +860,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         read_geom(a, pd, j, &start, &step);
         rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
     }
+    PH_MARK(1);     // placement + base extraction
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
     // substituted base is drawn afterwards, only for the (few) marked bases
@@ -846,6 +909,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
             }
         }
     }
+    PH_MARK(2);     // error tests + substitutions
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
     int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
     int32_t e1c = 0, u1 = 0, i1 = 0, x1 = 0;                                   // read end 2 (single-end: zeros, dwgsim.c:643)
@@ -887,6 +951,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         }
     }
 
+    PH_MARK(3);     // name lengths, block scan, look-back
     // ---- write the record(s) ----
     if (valid && s > 0) {
         Out2 o;
@@ -907,6 +972,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         }
         if (o.ea) { o.a.put('/'); o.a.put('1' + j); }
         o.put('\n');
+        PH_MARK(4); // header line
         // bases
         for (int w = 0; w * 8 < s; ++w) {
             const uint32_t word = lds[w * nthr];
@@ -917,6 +983,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
             } else for (int b = 0; b < rem; ++b) o.put(base_char((word >> (4 * b)) & 15));
         }
         o.put('\n'); o.put('+'); o.put('\n');
+        PH_MARK(5); // sequence line
         // qualities (dwgsim.c:899-918)
         const int8_t *qb = j ? a.qbase[1] : a.qbase[0];
         if (a.p.fixed_quality >= 0) { for (int i = 0; i < s; ++i) o.put((uint32_t)a.p.fixed_quality); }
@@ -953,6 +1020,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         o.put('\n');
         o.flush();
     }
+    PH_MARK(6);     // quality line
 }
 
 // ------------------------------------------------------------------------------------------------
