@@ -225,10 +225,12 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             HIPC(c, hipMemcpy(c->d_thr[j], thr.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
             HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
         }
+        // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 256 bytes in LDS)
         std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";
         c->rand_fixed_len = (int32_t)rf.size();
-        HIPC(c, hipMalloc((void **)&c->d_rand_fixed, rf.size() + 16));
-        HIPC(c, hipMemcpy(c->d_rand_fixed, rf.data(), rf.size(), hipMemcpyHostToDevice));
+        std::string rbuf = "@" + rf; rbuf.resize(rbuf.size() < 256 ? 272 : rbuf.size() + 16, '\0');
+        HIPC(c, hipMalloc((void **)&c->d_rand_fixed, rbuf.size()));
+        HIPC(c, hipMemcpy(c->d_rand_fixed, rbuf.data(), rbuf.size(), hipMemcpyHostToDevice));
         return 0;
     };
     if (init() != 0) return fail("context initialisation failed");
@@ -277,8 +279,9 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *
     HIPC(c, hipGetLastError());
     std::string nf = c->read_prefix.empty() ? k.name : c->read_prefix + "_" + k.name;
     k.name_fixed_len = (int32_t)nf.size();
-    HIPC(c, hipMalloc((void **)&k.d_name_fixed, nf.size() + 16));
-    HIPC(c, hipMemcpyAsync(k.d_name_fixed, nf.data(), nf.size(), hipMemcpyHostToDevice, c->stream));
+    std::string nbuf = "@" + nf; nbuf.resize(nbuf.size() < 256 ? 272 : nbuf.size() + 16, '\0');
+    HIPC(c, hipMalloc((void **)&k.d_name_fixed, nbuf.size()));
+    HIPC(c, hipMemcpyAsync(k.d_name_fixed, nbuf.data(), nbuf.size(), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipFree(d_ascii));
     return id;

@@ -767,6 +767,19 @@ struct Writer {               // sequential byte stream -> 16-byte aligned dword
         if (n < 8) lo |= v; else hi |= v;
         if (++n == 16) advance();
     }
+    DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes, little-endian in v, upper bytes zero
+    {
+        const uint32_t sh = 8 * (n & 7);
+        if (n < 8) { lo |= v << sh; if (sh) hi |= v >> (64 - sh); }
+        else hi |= v << sh;
+        const uint32_t total = n + cnt;
+        if (total >= 16) {
+            const uint32_t over = total - 16;       // bytes that belong to the next block (0..7)
+            const uint64_t carry = over ? v >> (8 * (cnt - over)) : 0;
+            advance();
+            lo = carry; n = over;
+        } else n = total;
+    }
     DW_DEV void put4(uint32_t w)                 // four bytes, little-endian
     {
         const uint32_t sh = 8 * (n & 7);
@@ -785,6 +798,7 @@ struct Out2 {                 // the bwa stream of this read end and the interle
     Writer a, b; bool ea, eb;
     DW_DEV void put(uint32_t c) { if (ea) a.put(c); if (eb) b.put(c); }
     DW_DEV void put4(uint32_t w) { if (ea) a.put4(w); if (eb) b.put4(w); }
+    DW_DEV void putn(uint64_t v, uint32_t cnt) { if (ea) a.putn(v, cnt); if (eb) b.putn(v, cnt); }
     DW_DEV void flush() { if (ea) a.flush(); if (eb) b.flush(); }
 };
 DW_DEV uint32_t ndigits10(uint32_t v)
@@ -792,19 +806,33 @@ DW_DEV uint32_t ndigits10(uint32_t v)
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
 }
 DW_DEV uint32_t ndigits16(uint64_t v) { return v ? (uint32_t)(67 - __clzll((long long)v)) >> 2 : 1u; }
-DW_DEV void put_dec(Out2 &o, uint32_t v)
+// decimal digits of v as packed ASCII, most significant digit in the lowest byte (stream order);
+// lead = one separator byte to emit in front (0 = none).  Numbers above 10^7 take the two-part path.
+DW_DEV void put_dec(Out2 &o, uint32_t v, uint32_t lead)
 {
-    bool started = false;
-#pragma unroll
-    for (uint32_t p = 1000000000u; p >= 10u; p /= 10u) {
-        const uint32_t dgt = v / p; v -= dgt * p;
-        if (dgt || started) { o.put('0' + dgt); started = true; }
+    uint32_t low7 = 0; bool big = false;
+    if (v >= 10000000u) { const uint32_t hi = v / 10000000u; low7 = v - hi * 10000000u; v = hi; big = true; }   // 8..10 digits
+    uint64_t w = 0; uint32_t nd = 0;
+    do { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; ++nd; } while (v);
+    if (lead) { w = (w << 8) | lead; ++nd; }
+    o.putn(w, nd);
+    if (big) {                                 // the low seven digits, zero padded
+        w = 0;
+        for (int d = 0; d < 7; ++d) { const uint32_t q = low7 / 10u; w = (w << 8) | ('0' + (low7 - q * 10u)); low7 = q; }
+        o.putn(w, 7);
     }
-    o.put('0' + v);
 }
 DW_DEV void put_hex(Out2 &o, uint64_t v)
 {
-    for (int k = (int)ndigits16(v) - 1; k >= 0; --k) { const uint32_t h = (uint32_t)(v >> (4 * k)) & 15u; o.put(h < 10 ? '0' + h : 'a' + (h - 10)); }
+    const uint32_t nd = ndigits16(v);
+    for (uint32_t part = 0; part < 2; ++part) {      // up to 16 digits: the high (nd-8) first, then the low 8
+        const uint32_t cnt = part == 0 ? (nd > 8 ? nd - 8 : 0) : (nd > 8 ? 8 : nd);
+        if (!cnt) continue;
+        const uint64_t x = part == 0 ? v >> 32 : (nd > 8 ? (v & 0xFFFFFFFFull) : v);
+        uint64_t w = 0;
+        for (uint32_t d = 0; d < cnt; ++d) { const uint32_t hx = (uint32_t)(x >> (4 * d)) & 15u; w = (w << 8) | (hx < 10 ? '0' + hx : 'a' + (hx - 10)); }
+        o.putn(w, cnt);
+    }
 }
 DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull >> (8 * (v & 7))) & 0xff); }  // "ACGTNNNN"
 
@@ -827,10 +855,13 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     __shared__ uint32_t sm[17];
     __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_base[2];
+    __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK * LPP;
     const int wave = tid >> 6, lane = tid & 63;
     PH_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
+    if (tid < 64) s_fixed[0][tid] = reinterpret_cast<const uint32_t *>(a.name_fixed)[tid];      // buffers are padded to 256 + 16 bytes
+    else if (tid < 128) s_fixed[1][tid - 64] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[tid - 64];
     __syncthreads();
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
     const int j = (LPP == 2) ? (tid & 1) : 0;
@@ -957,21 +988,32 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         Out2 o;
         o.ea = a.p.has_bwa != 0; o.eb = a.p.has_bfast != 0;
         o.a.init((j ? a.out[1] : a.out[0]) + off_bwa); o.b.init(a.out[2] + off_bf);
-        o.put('@');
-        { const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed; for (uint32_t q = 0; q < fixed_len; ++q) o.put(fx[q]); }
+        {   // '@' + fixed part: whole words from LDS (first 256 bytes), any rest from HBM
+            const uint32_t *fw = is_rand ? s_fixed[1] : s_fixed[0];
+            const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed;
+            const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
+            uint32_t q = 0;
+            for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
+            if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
+            for (q = inl; q < flen; ++q) o.put(fx[q]);
+        }
         if (is_rand) {
-            const char *lit = "_0_0_0_0_1_1_0:0:0_0:0:0_";
-            for (int q = 0; q < 25; ++q) o.put((uint32_t)lit[q]);
+            o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
+            o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
+            o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
+            o.putn(0x5F303Aull, 3);                    // ":0_"
             put_hex(o, rand_ii);
         } else {
-            o.put('_'); put_dec(o, (uint32_t)(x0 + 1)); o.put('_'); put_dec(o, (uint32_t)(x1 + 1));
-            o.put('_'); o.put('0' + pd.strand0); o.put('_'); o.put('0' + pd.strand1); o.put('_'); o.put('0'); o.put('_'); o.put('0'); o.put('_');
-            put_dec(o, (uint32_t)e0); o.put(':'); put_dec(o, (uint32_t)u0); o.put(':'); put_dec(o, (uint32_t)i0); o.put('_');
-            put_dec(o, (uint32_t)e1c); o.put(':'); put_dec(o, (uint32_t)u1); o.put(':'); put_dec(o, (uint32_t)i1); o.put('_');
+            put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
+            o.putn((uint64_t)'_' | ((uint64_t)('0' + pd.strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + pd.strand1) << 24)
+                       | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
+            put_dec(o, (uint32_t)e0, '_'); put_dec(o, (uint32_t)u0, ':'); put_dec(o, (uint32_t)i0, ':');
+            put_dec(o, (uint32_t)e1c, '_'); put_dec(o, (uint32_t)u1, ':'); put_dec(o, (uint32_t)i1, ':');
+            o.put('_');
             put_hex(o, ii);
         }
-        if (o.ea) { o.a.put('/'); o.a.put('1' + j); }
-        o.put('\n');
+        if (o.ea) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
+        if (o.eb) o.b.put('\n');
         PH_MARK(4); // header line
         // bases
         for (int w = 0; w * 8 < s; ++w) {
