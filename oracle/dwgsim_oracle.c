@@ -252,6 +252,7 @@ typedef struct {
     char *read_prefix; int reads_output_type, output_type, amplicons;
     /* oracle-only switches */
     int rng_mode, use_libm_log, null_fastq, verbose;
+    int64_t emit_first, emit_count;   /* --emit-range first:count (mode B only): emit only these read indices of every contig */
 } opt_t;
 
 static void opt_defaults(opt_t *o) /* dwgsim_opt.c:40-80 */
@@ -993,6 +994,10 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                         continue;
                     }
                     num_failed = 0;
+                    if (o->emit_count >= 0 && (r->mode != RNG_PHILOX || (int64_t)ii < o->emit_first || (int64_t)ii >= o->emit_first + o->emit_count)) {
+                        if (r->mode != RNG_PHILOX) { fprintf(stderr, "oracle: --emit-range needs --rng philox\n"); return 1; }
+                        att = 0; n_sim++; continue;     /* outside the window: nothing is emitted, no later state depends on it */
+                    }
                     if (SOLID == o->data_type) for (int j = 0; j < 2; ++j) if (0 < s[j]) to_colors(tb[j].seq, s[j]);
                     if (IONTORRENT == o->data_type) { /* :861-864 */
                         for (int j = 0; j < 2; ++j) { uint32_t slot = 0; s[j] = flow_errors(o, r, D_FLOW0 + (uint32_t)j, ii, att, &slot, &tb[j], s[j], strand[j], o->e[j].start, &n_err[j]); }
@@ -1021,7 +1026,8 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                     }
                 } else { /* random read, dwgsim.c:983-1097 */
                     static const int zero6[6] = { 0, 0, 0, 0, 0, 0 };
-                    for (int j = 0; j < 2; ++j) {
+                    const int in_win = o->emit_count < 0 || ((int64_t)ii >= o->emit_first && (int64_t)ii < o->emit_first + o->emit_count);
+                    for (int j = 0; j < 2 && in_win; ++j) {
                         if (s[j] <= 0) continue;
                         for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_u32(r, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 4.0) & 3);
                         make_quals(o, r, j, ii, att, s[j], qstr);
@@ -1060,7 +1066,7 @@ static FILE *open_out(const char *prefix, const char *suffix)
 
 int oracle_main(int argc, char **argv)
 {
-    opt_t o; rng_t r; opt_defaults(&o);
+    opt_t o; rng_t r; opt_defaults(&o); o.emit_first = 0; o.emit_count = -1;
     /* strip the oracle's own long options */
     char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
     for (int i = 0; i < argc; ++i) {
@@ -1068,6 +1074,7 @@ int oracle_main(int argc, char **argv)
         else if (!strcmp(argv[i], "--log") && i + 1 < argc) { ++i; o.use_libm_log = !strcmp(argv[i], "libm"); }
         else if (!strcmp(argv[i], "--null-fastq")) o.null_fastq = 1;
         else if (!strcmp(argv[i], "--verbose")) o.verbose = 1;
+        else if (!strcmp(argv[i], "--emit-range") && i + 1 < argc) { ++i; long long a = 0, b = 0; sscanf(argv[i], "%lld:%lld", &a, &b); o.emit_first = a; o.emit_count = b; }
         else av[ac++] = argv[i];
     }
     av[ac] = NULL;

@@ -1,0 +1,91 @@
+"""-m gpu: parity at BASELINE.json's full sizes.
+
+configs[1] (E. coli-sized S2, 2x150, 30x, 488 595 pairs): the whole job is compared bit-for-bit with the
+oracle (sha256 of both FASTQ streams and the mutation files).
+configs[2] (chr20-sized S3 with N blocks, 64 Mb, 6.78 M pairs): the oracle is too slow for the whole job,
+so (a) windows of read indices at the start, middle and end are compared bit-for-bit with the oracle's
+--emit-range output (the API call a shard would make: count_random for the prefix, simulate for the
+window), (b) one-call vs many-batch runs must give identical stream hashes, (c) structural invariants
+(record count, line structure, read lengths, N filter) hold over the full output."""
+import hashlib, os, subprocess
+import numpy as np
+import pytest
+
+from dwgsim_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return api.load()
+
+
+def _oracle(oracle_bin, flags, fasta, prefix, extra=()):
+    subprocess.run([oracle_bin, "--rng", "philox", *extra] + flags.split() + [fasta, prefix], check=True, stderr=subprocess.DEVNULL)
+
+
+def test_ecoli_full_job_bit_exact(lib, oracle_bin, tmp_path):
+    flags = "-z 13 -1 150 -2 150 -C 30 -o 1"
+    fa = str(tmp_path / "ecoli.fa")
+    contigs = synth.workload_contigs("ecoli")
+    synth.write_fasta(fa, contigs)
+    _oracle(oracle_bin, flags, fa, str(tmp_path / "o"))
+    res = api.run_job(api.parse_flags(flags, lib), contigs, lib=lib)
+    assert res.n_pairs == 488595
+    for k, suf in ((0, "bwa.read1.fastq"), (1, "bwa.read2.fastq")):
+        want = hashlib.sha256(open(str(tmp_path / ("o." + suf)), "rb").read()).hexdigest()
+        assert hashlib.sha256(res.streams[k]).hexdigest() == want, suf
+    assert res.mutations_txt == open(str(tmp_path / "o.mutations.txt"), "rb").read()
+    assert res.mutations_vcf == open(str(tmp_path / "o.mutations.vcf"), "rb").read()
+
+
+def test_chr20_sized_windows_and_invariants(lib, oracle_bin, tmp_path):
+    flags = "-z 20 -1 150 -2 150 -C 30 -o 1 -r 0.001 -R 0.1"
+    fa = str(tmp_path / "chr20.fa")
+    contigs = synth.workload_contigs("chr20")
+    synth.write_fasta(fa, contigs)
+    params = api.parse_flags(flags, lib)
+    name, arr = contigs[0]
+    n_pairs = api.pairs_for_contig(params, len(arr), len(arr), True, 0, lib)
+    assert n_pairs == 6783597
+    with api.Context(params, 0, lib) as ctx:
+        cid = ctx.add_contig(name, arr, 0)
+        ctx.mutate(cid)
+        txt, vcf = ctx.mutations_text(cid)
+        # (a) three windows against the oracle (the walk of 64 Mb + the attempt loop runs once per window on the CPU)
+        for first in (0, 3_400_000, n_pairs - 5000):
+            cnt = 5000
+            pre = str(tmp_path / f"w{first}")
+            _oracle(oracle_bin, flags, fa, pre, extra=("--emit-range", f"{first}:{cnt}"))
+            rand_base = ctx.count_random(cid, 0, first) if first else 0
+            b = ctx.simulate(cid, first, cnt, rand_base, 0)
+            for s, suf in ((0, "bwa.read1.fastq"), (1, "bwa.read2.fastq")):
+                assert ctx.fetch(0, s, b.bytes[s]) == open(pre + "." + suf, "rb").read(), (first, suf)
+            if first == 0:
+                assert txt == open(pre + ".mutations.txt", "rb").read() and vcf.endswith(open(pre + ".mutations.vcf", "rb").read().split(b"INFO\n", 1)[1])
+        # (b) one call vs batches of 1 000 003 pairs
+        one = ctx.simulate(cid, 0, n_pairs, 0, 0)
+        h_one = [hashlib.sha256(ctx.fetch(0, s, one.bytes[s])).hexdigest() for s in (0, 1)]
+        hs = [hashlib.sha256(), hashlib.sha256()]
+        first, rand_ii = 0, 0
+        last_stream = None
+        while first < n_pairs:
+            n = min(1_000_003, n_pairs - first)
+            b = ctx.simulate(cid, first, n, rand_ii, 1)
+            for s in (0, 1):
+                last_stream = ctx.fetch(1, s, b.bytes[s]); hs[s].update(last_stream)
+            rand_ii += b.n_random; first += n
+        assert [h.hexdigest() for h in hs] == h_one and rand_ii == one.n_random
+        # (c) structure of the full read-1 stream
+        data = np.frombuffer(ctx.fetch(0, 0, one.bytes[0]), dtype=np.uint8)
+        nl = np.flatnonzero(data == 10)
+        assert len(nl) == 4 * n_pairs
+        starts = np.concatenate(([0], nl[:-1] + 1))
+        assert (data[starts[0::4]] == ord("@")).all() and (data[starts[2::4]] == ord("+")).all()
+        assert ((nl[1::4] - starts[1::4]) == 150).all() and ((nl[3::4] - starts[3::4]) == 150).all()
+        seq_bytes = np.zeros(256, dtype=bool); seq_bytes[[65, 67, 71, 84]] = True      # -n 0: no N survives the filter
+        body = np.concatenate([data[a:a + 150] for a in starts[1::4][:: max(1, n_pairs // 20000)]])
+        assert seq_bytes[body].all()
+        q = np.concatenate([data[a:a + 150] for a in starts[3::4][:: max(1, n_pairs // 20000)]])
+        assert q.min() >= 33 and q.max() <= 73
