@@ -121,6 +121,13 @@ def main():
         value = total_pairs * K / elapsed / 1e6
         sim_ms = stats["sim_kernel_ms"] / K
         achieved = ALGO_BYTES_PER_PAIR * n_pairs / (sim_ms * 1e-3) / 1e9 if sim_ms > 0 else 0.0
+        traffic = None          # HBM bytes per launch from the PMC passes kept under profiles/ (same workload only)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj["pairs_per_launch"] == n_pairs and flags == FLAGS:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "M read-pairs/sec (2x150 bp PE)", "value": round(value, 3), "unit": "M read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -131,8 +138,9 @@ def main():
                        "parallelism": f"read-index shards x{world}"},
             "breakdown_ms": {"walk": round(stats["walk_ms"] / K, 4), "rand_count_exchange": round(stats["count_ms"] / K, 4),
                              "place+scan+simulate_kernels": round(stats["kernel_ms"] / K, 4), "simulate_kernel": round(sim_ms, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_simulate<2>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_simulate<2,1>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PAIR * n_pairs),
                          "note": "863 algorithmic B/pair x pairs per launch / HIP-event time of the launch; the kernel is Philox+fp64 ALU bound, not HBM bound (DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:

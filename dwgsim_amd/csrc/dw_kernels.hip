@@ -740,27 +740,60 @@ __global__ void k_place(SimArgs a)
 }
 
 // ---- FASTQ text assembly ----
-struct Writer {               // sequential byte stream -> 16-byte aligned dwordx4 stores
-    // `blk` = 16-byte aligned block being filled, (lo,hi) its bytes, `n` = bytes filled (head: bytes
-    // [0,skip) of the first block belong to the previous record and are never stored)
-    uint8_t *blk; uint64_t lo, hi; uint32_t n, skip;
+struct Writer {               // sequential byte stream -> bursts of 64-byte aligned chunks
+    // A lane's record is cut at 64-byte boundaries of the output buffer; a chunk is assembled in registers
+    // (three finished 16-byte sub-blocks in s0..s5, the one being filled in lo/hi) and leaves as four
+    // back-to-back dwordx4 stores, so L2 sees whole 64-byte request units instead of 16-byte crumbs
+    // (partially written lines were being evicted and written back 2.6x, profiles/r01_p3).
+    // Only the first / last chunk of a record is ragged: bytes [skip, upto) go out as dwords / bytes.
+    uint8_t *blk; uint64_t lo, hi, s0, s1, s2, s3, s4, s5; uint32_t n, sub, skip;
     DW_DEV void init(uint8_t *p)
     {
-        const uint32_t o = (uint32_t)((uintptr_t)p & 15);
-        blk = p - o; lo = hi = 0; n = o; skip = o;
+        const uint32_t o = (uint32_t)((uintptr_t)p & 63);
+        blk = p - o; sub = o >> 4; n = o & 15; skip = o;
+        lo = hi = s0 = s1 = s2 = s3 = s4 = s5 = 0;
     }
-    DW_DEV void store_block(uint32_t upto)       // store bytes [skip, upto) of the current block
+    static DW_DEV void store16(uint8_t *dst, uint64_t a, uint64_t b, uint32_t from, uint32_t upto)   // bytes [from, upto) of a 16-byte block
     {
-        if (skip == 0 && upto == 16) { *reinterpret_cast<uint4 *>(blk) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); return; }
+        if (from == 0 && upto == 16) { *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); return; }
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {       // whole dwords where possible, single bytes at the ragged edges
-            const uint32_t w = (uint32_t)((q < 2 ? lo : hi) >> (32 * (q & 1)));
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t w = (uint32_t)((q < 2 ? a : b) >> (32 * (q & 1)));
             const uint32_t b0 = 4 * q, b1 = b0 + 4;
-            if (skip <= b0 && upto >= b1) *reinterpret_cast<uint32_t *>(blk + b0) = w;
-            else for (uint32_t k = b0; k < b1; ++k) if (k >= skip && k < upto) blk[k] = (uint8_t)(w >> (8 * (k - b0)));
+            if (from <= b0 && upto >= b1) *reinterpret_cast<uint32_t *>(dst + b0) = w;
+            else for (uint32_t k = b0; k < b1; ++k) if (k >= from && k < upto) dst[k] = (uint8_t)(w >> (8 * (k - b0)));
         }
     }
-    DW_DEV void advance() { store_block(16); blk += 16; lo = hi = 0; n = 0; skip = 0; }
+    DW_DEV void store_chunk(uint32_t upto)       // bytes [skip, upto) of the current chunk
+    {
+        if (skip == 0 && upto == 64) {           // the common case: one 64-byte burst
+            uint4 *d = reinterpret_cast<uint4 *>(blk);
+            d[0] = make_uint4((uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32));
+            d[1] = make_uint4((uint32_t)s2, (uint32_t)(s2 >> 32), (uint32_t)s3, (uint32_t)(s3 >> 32));
+            d[2] = make_uint4((uint32_t)s4, (uint32_t)(s4 >> 32), (uint32_t)s5, (uint32_t)(s5 >> 32));
+            d[3] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            return;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t b0 = 16 * q;
+            if (upto <= b0 || skip >= b0 + 16) continue;
+            const uint64_t a = (q == sub) ? lo : (q == 0 ? s0 : q == 1 ? s2 : s4);
+            const uint64_t b = (q == sub) ? hi : (q == 0 ? s1 : q == 1 ? s3 : s5);
+            const uint32_t from = skip > b0 ? skip - b0 : 0, to = upto < b0 + 16 ? upto - b0 : 16;
+            store16(blk + b0, a, b, from, to);
+        }
+    }
+    DW_DEV void advance()                        // the 16-byte sub-block in lo/hi is complete
+    {
+        if (sub == 3) { store_chunk(64); blk += 64; sub = 0; skip = 0; }
+        else {      // value selects, not conditional stores: keeps s0..s5 in registers
+            const bool z0 = sub == 0, z1 = sub == 1, z2 = sub == 2;
+            s0 = z0 ? lo : s0; s1 = z0 ? hi : s1; s2 = z1 ? lo : s2; s3 = z1 ? hi : s3; s4 = z2 ? lo : s4; s5 = z2 ? hi : s5;
+            ++sub;
+        }
+        lo = hi = 0; n = 0;
+    }
     DW_DEV void put(uint32_t b)
     {
         const uint64_t v = (uint64_t)b << (8 * (n & 7));
@@ -774,32 +807,22 @@ struct Writer {               // sequential byte stream -> 16-byte aligned dword
         else hi |= v << sh;
         const uint32_t total = n + cnt;
         if (total >= 16) {
-            const uint32_t over = total - 16;       // bytes that belong to the next block (0..7)
+            const uint32_t over = total - 16;       // bytes that belong to the next sub-block (0..7)
             const uint64_t carry = over ? v >> (8 * (cnt - over)) : 0;
             advance();
             lo = carry; n = over;
         } else n = total;
     }
-    DW_DEV void put4(uint32_t w)                 // four bytes, little-endian
-    {
-        const uint32_t sh = 8 * (n & 7);
-        const uint64_t v = (uint64_t)w << sh;
-        if (n < 8) { lo |= v; if (sh > 32) hi |= (uint64_t)w >> (64 - sh); }
-        else hi |= v;
-        if (n + 4 >= 16) {
-            const uint32_t over = n + 4 - 16;    // bytes that belong to the next block (0..3)
-            advance();
-            if (over) { lo = (uint64_t)w >> (8 * (4 - over)); n = over; }
-        } else n += 4;
-    }
-    DW_DEV void flush() { if (n > skip) store_block(n); }
+    DW_DEV void put4(uint32_t w) { putn((uint64_t)w, 4); }
+    DW_DEV void flush() { const uint32_t upto = 16 * sub + n; if (upto > skip) store_chunk(upto); }
 };
-struct Out2 {                 // the bwa stream of this read end and the interleaved bfast stream
-    Writer a, b; bool ea, eb;
-    DW_DEV void put(uint32_t c) { if (ea) a.put(c); if (eb) b.put(c); }
-    DW_DEV void put4(uint32_t w) { if (ea) a.put4(w); if (eb) b.put4(w); }
-    DW_DEV void putn(uint64_t v, uint32_t cnt) { if (ea) a.putn(v, cnt); if (eb) b.putn(v, cnt); }
-    DW_DEV void flush() { if (ea) a.flush(); if (eb) b.flush(); }
+template <int OUT>            // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream
+struct Out2 {
+    Writer a, b;
+    DW_DEV void put(uint32_t c) { if (OUT & 1) a.put(c); if (OUT & 2) b.put(c); }
+    DW_DEV void put4(uint32_t w) { if (OUT & 1) a.put4(w); if (OUT & 2) b.put4(w); }
+    DW_DEV void putn(uint64_t v, uint32_t cnt) { if (OUT & 1) a.putn(v, cnt); if (OUT & 2) b.putn(v, cnt); }
+    DW_DEV void flush() { if (OUT & 1) a.flush(); if (OUT & 2) b.flush(); }
 };
 DW_DEV uint32_t ndigits10(uint32_t v)
 {
@@ -808,7 +831,8 @@ DW_DEV uint32_t ndigits10(uint32_t v)
 DW_DEV uint32_t ndigits16(uint64_t v) { return v ? (uint32_t)(67 - __clzll((long long)v)) >> 2 : 1u; }
 // decimal digits of v as packed ASCII, most significant digit in the lowest byte (stream order);
 // lead = one separator byte to emit in front (0 = none).  Numbers above 10^7 take the two-part path.
-DW_DEV void put_dec(Out2 &o, uint32_t v, uint32_t lead)
+template <int OUT>
+DW_DEV void put_dec(Out2<OUT> &o, uint32_t v, uint32_t lead)
 {
     uint32_t low7 = 0; bool big = false;
     if (v >= 10000000u) { const uint32_t hi = v / 10000000u; low7 = v - hi * 10000000u; v = hi; big = true; }   // 8..10 digits
@@ -822,7 +846,8 @@ DW_DEV void put_dec(Out2 &o, uint32_t v, uint32_t lead)
         o.putn(w, 7);
     }
 }
-DW_DEV void put_hex(Out2 &o, uint64_t v)
+template <int OUT>
+DW_DEV void put_hex(Out2<OUT> &o, uint64_t v)
 {
     const uint32_t nd = ndigits16(v);
     for (uint32_t part = 0; part < 2; ++part) {      // up to 16 digits: the high (nd-8) first, then the low 8
@@ -848,7 +873,7 @@ DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull
 #define PH_MARK(k) do { } while (0)
 #endif
 
-template <int LPP>
+template <int LPP, int OUT>
 __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
@@ -985,9 +1010,9 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     PH_MARK(3);     // name lengths, block scan, look-back
     // ---- write the record(s) ----
     if (valid && s > 0) {
-        Out2 o;
-        o.ea = a.p.has_bwa != 0; o.eb = a.p.has_bfast != 0;
-        o.a.init((j ? a.out[1] : a.out[0]) + off_bwa); o.b.init(a.out[2] + off_bf);
+        Out2<OUT> o;
+        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
+        if (OUT & 2) o.b.init(a.out[2] + off_bf);
         {   // '@' + fixed part: whole words from LDS (first 256 bytes), any rest from HBM
             const uint32_t *fw = is_rand ? s_fixed[1] : s_fixed[0];
             const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed;
@@ -1012,8 +1037,8 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
             o.put('_');
             put_hex(o, ii);
         }
-        if (o.ea) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
-        if (o.eb) o.b.put('\n');
+        if (OUT & 1) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
+        if (OUT & 2) o.b.put('\n');
         PH_MARK(4); // header line
         // bases
         for (int w = 0; w * 8 < s; ++w) {
@@ -1128,8 +1153,17 @@ void launch_place(hipStream_t st, const SimArgs &a)
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
     const uint32_t nb = cdiv(a.n_pairs, PAIRS_PER_BLOCK);
-    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_simulate<2>, dim3(nb), dim3(PAIRS_PER_BLOCK * 2), (size_t)a.lds_words * PAIRS_PER_BLOCK * 2 * 4, st, a);
-    else hipLaunchKernelGGL(k_simulate<1>, dim3(nb), dim3(PAIRS_PER_BLOCK), (size_t)a.lds_words * PAIRS_PER_BLOCK * 4, st, a);
+    const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
+    const size_t lds2 = (size_t)a.lds_words * PAIRS_PER_BLOCK * 2 * 4, lds1 = (size_t)a.lds_words * PAIRS_PER_BLOCK * 4;
+    if (a.p.len[1] > 0) {
+        if (out == 1) hipLaunchKernelGGL((k_simulate<2, 1>), dim3(nb), dim3(PAIRS_PER_BLOCK * 2), lds2, st, a);
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<2, 2>), dim3(nb), dim3(PAIRS_PER_BLOCK * 2), lds2, st, a);
+        else hipLaunchKernelGGL((k_simulate<2, 3>), dim3(nb), dim3(PAIRS_PER_BLOCK * 2), lds2, st, a);
+    } else {
+        if (out == 1) hipLaunchKernelGGL((k_simulate<1, 1>), dim3(nb), dim3(PAIRS_PER_BLOCK), lds1, st, a);
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<1, 2>), dim3(nb), dim3(PAIRS_PER_BLOCK), lds1, st, a);
+        else hipLaunchKernelGGL((k_simulate<1, 3>), dim3(nb), dim3(PAIRS_PER_BLOCK), lds1, st, a);
+    }
 }
 
 } // namespace dw
