@@ -703,38 +703,41 @@ DW_DEV void read_geom(const SimArgs &a, const PairDraw &pd, int j, int64_t *star
 }
 
 // K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.
-__global__ void k_place(SimArgs a)
+// One lane per read end (LPP = 2: lanes 2q / 2q+1 test the two ends of pair q and exchange the verdict).
+template <int LPP>
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
 {
     __shared__ uint32_t sm[17];
-    const uint64_t pair = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + threadIdx.x;
+    const int tid = (int)threadIdx.x, j = (LPP == 2) ? (tid & 1) : 0;
+    const uint64_t pair = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);
     const bool valid = pair < a.n_pairs;
     const uint64_t ii = a.first_ii + pair;
     const RngKey key{a.p.seed, a.c.contig_index};
-    uint32_t att = 0; bool is_rand = false, failed = false;
-    if (valid) {
-        for (;;) {
+    const int sj = sel_len(a, j);
+    uint32_t att = 0; bool is_rand = false, failed = false, done = !valid;
+    while (__ballot(!done)) {                      // wave-uniform loop: the two lanes of a pair always agree on `done`
+        bool ok = true;
+        if (!done) {
             const PairDraw pd = draw_pair(a, key, ii, att);
-            if (pd.is_rand) { is_rand = true; break; }
-            bool ok = true;
-            const HapDev hp = sel_hap(a, pd.hap);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int sj = j ? a.p.len[1] : a.p.len[0];
-                if (sj <= 0 || !ok) continue;
+            if (pd.is_rand) { is_rand = true; done = true; }
+            else if (sj > 0) {
                 int64_t start; int step;
                 read_geom(a, pd, j, &start, &step);
-                const ReadRes r = gen_read<false>(hp, a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                const ReadRes r = gen_read<false>(sel_hap(a, pd.hap), a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
                 ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
             }
-            if (ok) break;
-            if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; break; }
         }
-        a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);
+        if (LPP == 2) { const int other = __shfl_xor((int)ok, 1); ok = ok && (other != 0); }   // every lane shuffles (no short-circuit)
+        if (!done) {
+            if (ok) done = true;
+            else if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; done = true; }
+        }
     }
+    if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);
     uint32_t total;
-    (void)block_excl_scan(is_rand ? 1u : 0u, sm, &total);
+    (void)block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &total);
     if (threadIdx.x == 0) a.block_rand[blockIdx.x] = total;
-    const uint32_t retries = wave_sum_u32(valid ? att : 0u);
+    const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u);
     if (lane_id() == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries);
     if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
 }
@@ -1148,7 +1151,8 @@ void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t
 }
 void launch_place(hipStream_t st, const SimArgs &a)
 {
-    hipLaunchKernelGGL(k_place, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), 0, st, a);
+    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_place<2>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK * 2), 0, st, a);
+    else hipLaunchKernelGGL(k_place<1>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), 0, st, a);
 }
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
