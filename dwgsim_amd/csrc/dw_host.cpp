@@ -49,6 +49,8 @@ struct DevBuf {                     // grow-only device buffer
 struct dwgsim_hip_ctx {
     dwgsim_hip_params_t prm;
     std::string read_prefix;
+    std::vector<uint8_t> flow;            // Ion Torrent flow order as base codes
+    uint8_t *d_flow = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -151,7 +153,15 @@ int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap)
     CHK(p->use_base_error, 0, 1, "-B"); CHK(p->is_hap, 0, 1, "-H");
     CHK(p->quality_std, 0, INT32_MAX, "-Q"); CHK(p->reads_output_type, 0, 2, "-o"); CHK(p->output_type, 0, 2, "-M"); CHK(p->amplicons, 0, 1, "-a");
     if (p->data_type == 2 && !p->flow_order) { if (msg) snprintf(msg, cap, "Error: command line option -f is required\n"); return DWGSIM_HIP_ERR_ARG; }
-    if (p->data_type != 0) { if (msg) snprintf(msg, cap, "dwgsim-hip: -c %d (SOLiD / Ion Torrent) is not on the accelerated path yet\n", p->data_type); return DWGSIM_HIP_ERR_UNSUP; }
+    if (p->data_type == 1) { if (msg) snprintf(msg, cap, "dwgsim-hip: -c 1 (SOLiD) is not on the accelerated path\n"); return DWGSIM_HIP_ERR_UNSUP; }
+    if (p->data_type == 2) {       // dwgsim_opt.c:338-343, :396-413
+        for (int i = 0; i < 2; ++i) if (p->e_end[i] != p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: a uniform error rate must be given for Ion Torrent data\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
+        if (p->use_base_error) { if (msg) snprintf(msg, cap, "dwgsim-hip: -B (per-base error calibration) is not on the accelerated path\n"); return DWGSIM_HIP_ERR_UNSUP; }
+        const size_t F = strlen(p->flow_order);
+        bool has[4] = {false, false, false, false};
+        for (size_t i = 0; i < F; ++i) { const uint8_t c = nt4((unsigned char)p->flow_order[i]); if (c < 4) has[c] = true; }
+        if (F == 0 || F > 64 || !(has[0] && has[1] && has[2] && has[3])) { if (msg) snprintf(msg, cap, "dwgsim-hip: the flow order (-f) must hold 1..64 flows and contain all of A, C, G, T\n"); return DWGSIM_HIP_ERR_UNSUP; }
+    }
     if (p->seed < 0) { if (msg) snprintf(msg, cap, "dwgsim-hip: the seed must be resolved (>= 0) before the context is created\n"); return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }
@@ -197,6 +207,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     dwgsim_hip_ctx *c = new dwgsim_hip_ctx();
     c->prm = *p;
     if (p->read_prefix) c->read_prefix = p->read_prefix;
+    if (p->data_type == 2) for (const char *q = p->flow_order; *q; ++q) c->flow.push_back(nt4((unsigned char)*q));
     c->prm.read_prefix = nullptr; c->prm.flow_order = nullptr;
     c->device = device;
     { const char *e = getenv("DWGSIM_HIP_JUSTIFY"); c->seq_justify = e && !strcmp(e, "seq"); }   // cross-check mode
@@ -226,6 +237,8 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
         }
         // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 256 bytes in LDS)
+        { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
+          HIPC(c, hipMalloc((void **)&c->d_flow, 64)); HIPC(c, hipMemcpy(c->d_flow, fl.data(), 64, hipMemcpyHostToDevice)); }
         std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";
         c->rand_fixed_len = (int32_t)rf.size();
         std::string rbuf = "@" + rf; rbuf.resize(rbuf.size() < 256 ? 272 : rbuf.size() + 16, '\0');
@@ -248,7 +261,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
-    hipFree(c->d_counters);
+    hipFree(c->d_counters); hipFree(c->d_flow);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -516,7 +529,13 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
     a.status[0] = (uint64_t *)c->status[0].p; a.status[1] = (uint64_t *)c->status[1].p;
     const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
-    a.lds_words = (lmax + 7) / 8;
+    a.cap = lmax;
+    if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
+        const double emax = p.e_start[0] > p.e_start[1] ? p.e_start[0] : p.e_start[1];
+        a.cap = lmax + 64 + (int)(lmax * 10.0 * emax);
+    }
+    a.lds_words = (a.cap + 7) / 8;
+    a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
     return 0;
 }
 
@@ -557,7 +576,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     const int fixed_max = kp->name_fixed_len > c->rand_fixed_len ? kp->name_fixed_len : c->rand_fixed_len;
     const size_t nreads = (size_t)n_pairs * (p.length[1] > 0 ? 2 : 1);
     size_t cap[3] = {0, 0, 0};
-    for (int j = 0; j < 2; ++j) if (p.length[j] > 0) cap[j] = (size_t)n_pairs * (size_t)(1 + fixed_max + 120 + 3 + 2 * p.length[j] + 4);
+    for (int j = 0; j < 2; ++j) if (p.length[j] > 0) cap[j] = (size_t)n_pairs * (size_t)(1 + fixed_max + 120 + 3 + 2 * (p.data_type == 2 ? a.cap : p.length[j]) + 4);
     cap[2] = cap[0] + cap[1];
     if (!a.p.has_bwa) cap[0] = cap[1] = 0;
     if (!a.p.has_bfast) cap[2] = 0;
@@ -575,6 +594,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->h_counters[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];
     if (getenv("DWGSIM_HIP_PHASES")) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)

@@ -22,6 +22,15 @@
 #include "dw_common.hpp"
 #include "dw_kernels.hpp"
 
+// The file is compiled in parts so the twelve k_simulate variants build in parallel (csrc/Makefile):
+//   DW_PART 0: mutation-walk kernels, k_place, host launchers and the k_simulate dispatcher
+//   DW_PART 1..4: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2)
+//   DW_PART -1 (default): everything in one translation unit
+#ifndef DW_PART
+#define DW_PART -1
+#endif
+#define DW_HAS(part) (DW_PART == -1 || DW_PART == (part))
+
 namespace dw {
 
 // ------------------------------------------------------------------------------------------------
@@ -48,6 +57,14 @@ DW_DEV uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *total)
     return inc - v + sm[wave];
 }
 
+DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
+{
+    uint32_t lo = 0, hi = h.n_ins;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)h.ins_pos[mid] < pos) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+#if DW_HAS(0)
 // ------------------------------------------------------------------------------------------------
 // K0: ASCII -> codes; both haplotypes start as the reference (mut.c:609)
 // ------------------------------------------------------------------------------------------------
@@ -280,12 +297,6 @@ __global__ void k_apply(Event *ev, uint32_t n_cand, const uint4 *flags, ContigDe
 // and unmutated (non-N) positions merely reset prev_del, so the walk visits the live events'
 // original footprints in order and treats the gaps between them in O(1).
 // ------------------------------------------------------------------------------------------------
-DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
-{
-    uint32_t lo = 0, hi = h.n_ins;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)h.ins_pos[mid] < pos) lo = mid + 1; else hi = mid; }
-    return lo;
-}
 DW_DEV void justify_ins(HapDev &h, int64_t i)          // mut.c:427-478
 {
     const uint32_t idx = ins_find(h, i);
@@ -505,6 +516,8 @@ __global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint
     if (k < n) cells[k] = (uint16_t)(h0[pos[k]] | (h1[pos[k]] << 8));
 }
 
+#endif // DW_HAS(0): mutation walk
+
 // ------------------------------------------------------------------------------------------------
 // Read simulation
 // ------------------------------------------------------------------------------------------------
@@ -702,6 +715,7 @@ DW_DEV void read_geom(const SimArgs &a, const PairDraw &pd, int j, int64_t *star
     }
 }
 
+#if DW_HAS(0)
 // K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.
 // One lane per read end (LPP = 2: lanes 2q / 2q+1 test the two ends of pair q and exchange the verdict).
 template <int LPP>
@@ -740,6 +754,104 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
     const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u);
     if (lane_id() == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries);
     if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
+}
+
+#endif // DW_HAS(0): k_place
+
+// ---- Ion Torrent flow-space errors: dwgsim.c:246-417 generate_errors_flows ----
+// The reference edits the read in place; both passes only ever insert/delete at the position being
+// examined, so they are replayed as transducers over packed 4-bit arrays in LDS (word w of a lane
+// at base[w * stride]).  Draws: narrow uniforms of domain D_FLOW0 + read end, one sequential slot
+// counter per read end.  The flow mask is per read (the reference's persistent mask is fully
+// rewritten by every read's pass 1).
+DW_DEV uint32_t nib_get(const uint32_t *base, int stride, int i) { return (base[(i >> 3) * stride] >> ((i & 7) * 4)) & 15u; }
+DW_DEV void nib_set(uint32_t *base, int stride, int i, uint32_t v)
+{
+    const uint32_t sh = (uint32_t)(i & 7) * 4; uint32_t w = base[(i >> 3) * stride];
+    base[(i >> 3) * stride] = (w & ~(15u << sh)) | (v << sh);
+}
+struct FlowRng {
+    RngKey key; uint32_t dom, att, slot; uint64_t ii; U4 blk;
+    DW_DEV uint32_t next()
+    {
+        if ((slot & 3) == 0) blk = rng_block(key, dom, ii, att, 0, slot >> 2);
+        const uint32_t k = slot & 3; ++slot;
+        return (k & 2) ? ((k & 1) ? blk.w : blk.z) : ((k & 1) ? blk.y : blk.x);
+    }
+    DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr) ++n; return n; }   // while (drand48() < e) n_err++
+};
+// returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated
+DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
+                       int len, int strand, int cap, int32_t *n_err_out)
+{
+    // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
+    auto in = [&](int t) -> uint32_t { const uint32_t v = nib_get(bufA, stride, strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
+    uint64_t mask = 0; int flow_i = 0, total = 0;
+    { const uint32_t c0 = in(0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
+    // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
+    int t = 0, n1 = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
+    for (;;) {
+        uint32_t c; bool from_pend = false;
+        if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(t); else break;
+        if (n1 >= cap) return -1;
+        while (c != flow[flow_i]) { mask &= ~(1ull << flow_i); flow_i = flow_i + 1 == F ? 0 : flow_i + 1; }
+        if (prev_c != c) {
+            mask &= ~(1ull << flow_i);
+            int n_err = rg.geometric(thr);
+            if (n_err > 0) {
+                if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
+                    nib_set(bufB, stride, n1++, c); pend_c = c; pend_n = n_err - 1;
+                    total += n_err; prev_c = c;
+                    continue;
+                }
+                int hp_l = 0; uint32_t next_c = c;              // delete: bounded by the homopolymer length
+                while (t + hp_l < len) { next_c = in(t + hp_l); if (next_c != c) break; ++hp_l; }
+                if (n_err > hp_l) n_err = hp_l;
+                t += n_err; mask |= 1ull << flow_i; total += n_err;
+                if (n_err == hp_l && (n1 == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
+                    if (next_c == c) return -1;                // the whole read was one deleted homopolymer (the reference asserts)
+                    int jj = 0; while (next_c != flow[(flow_i + jj) % F]) ++jj;
+                    const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
+                    nib_set(bufB, stride, n1++, flow[(flow_i + kk) % F]);
+                } else if (t < len) { nib_set(bufB, stride, n1++, in(t)); ++t; }   // the base now at this position is not examined
+                prev_c = c;
+                continue;
+            }
+            prev_c = c;
+        }
+        nib_set(bufB, stride, n1++, c);
+        if (from_pend) --pend_n; else ++t;
+    }
+    // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
+    // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order ----
+    int t2 = 0, n2 = 0, sp = 0;
+    for (;;) {
+        uint32_t x;
+        if (sp > 0) x = stk[(sp - 1) * stride] >> 16; else if (t2 < n1) x = nib_get(bufB, stride, t2); else break;
+        if (n2 >= cap) return -1;
+        int m = 0;
+        while (x != flow[flow_i]) {
+            const int n_err = rg.geometric(thr);
+            if (!((mask >> flow_i) & 1) && n_err > 0) {
+                if (sp >= 16) return -1;
+                stk[sp * stride] = ((uint32_t)flow[flow_i] << 16) | (uint32_t)n_err; ++sp;
+                total += n_err; ++m;
+            }
+            flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
+        }
+        if (m == 0 && sp == 0) { nib_set(bufA, stride, n2++, x); ++t2; }
+        else {      // take one base from the top run (the examined base itself when nothing was inserted)
+            const uint32_t top = stk[(sp - 1) * stride];
+            nib_set(bufA, stride, n2++, top >> 16);
+            if ((top & 0xffffu) <= 1) --sp; else stk[(sp - 1) * stride] = top - 1;
+        }
+    }
+    if (strand) for (int i = 0; i < n2 >> 1; ++i) {            // dwgsim.c:408-414
+        const uint32_t a = nib_get(bufA, stride, i), b = nib_get(bufA, stride, n2 - 1 - i);
+        nib_set(bufA, stride, i, b); nib_set(bufA, stride, n2 - 1 - i, a);
+    }
+    *n_err_out += total;
+    return n2;
 }
 
 // ---- FASTQ text assembly ----
@@ -876,7 +988,8 @@ DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull
 #define PH_MARK(k) do { } while (0)
 #endif
 
-template <int LPP, int OUT>
+// DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
+template <int LPP, int OUT, int DT>
 __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
@@ -884,12 +997,14 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_base[2];
     __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
+    __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK * LPP;
     const int wave = tid >> 6, lane = tid & 63;
     PH_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     if (tid < 64) s_fixed[0][tid] = reinterpret_cast<const uint32_t *>(a.name_fixed)[tid];      // buffers are padded to 256 + 16 bytes
     else if (tid < 128) s_fixed[1][tid - 64] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[tid - 64];
+    if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     __syncthreads();
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
     const int j = (LPP == 2) ? (tid & 1) : 0;
@@ -924,8 +1039,15 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
     // substituted base is drawn afterwards, only for the (few) marked bases
     int32_t n_err = 0;
+    int s_out = s;                              // read length after errors (changes only for Ion Torrent)
     const int nw = (s + 7) >> 3;
-    if (valid) {
+    if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
+        FlowRng rg; rg.key = key; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.blk = U4{0, 0, 0, 0};
+        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)2 * a.lds_words * nthr,
+                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
+        if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
+    }
+    if (valid && (DT == 0 || is_rand)) {
         const uint64_t *thr = j ? a.e_thr[1] : a.e_thr[0];
         for (int w = 0; w < nw; ++w) {
             const uint32_t word = is_rand ? 0u : lds[w * nthr];
@@ -986,7 +1108,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
                  + ndigits10((uint32_t)e1c) + 1 + ndigits10((uint32_t)u1) + 1 + ndigits10((uint32_t)i1) + 1
                  + ndigits16(ii);
     }
-    const uint32_t Lbwa = (valid && s > 0) ? (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s + 3u + (uint32_t)s + 1u) : 0u;
+    const uint32_t Lbwa = (valid && s_out > 0) ? (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s_out + 3u + (uint32_t)s_out + 1u) : 0u;
 
     // ---- record offsets: block scan + decoupled look-back over logical blocks ----
     uint32_t T1, T2;
@@ -1012,7 +1134,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
 
     PH_MARK(3);     // name lengths, block scan, look-back
     // ---- write the record(s) ----
-    if (valid && s > 0) {
+    if (valid && s_out > 0) {
         Out2<OUT> o;
         if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
         if (OUT & 2) o.b.init(a.out[2] + off_bf);
@@ -1044,9 +1166,9 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         if (OUT & 2) o.b.put('\n');
         PH_MARK(4); // header line
         // bases
-        for (int w = 0; w * 8 < s; ++w) {
+        for (int w = 0; w * 8 < s_out; ++w) {
             const uint32_t word = lds[w * nthr];
-            const int rem = s - w * 8;
+            const int rem = s_out - w * 8;
             if (rem >= 8) {
                 o.put4(base_char(word & 15) | base_char((word >> 4) & 15) << 8 | base_char((word >> 8) & 15) << 16 | base_char((word >> 12) & 15) << 24);
                 o.put4(base_char((word >> 16) & 15) | base_char((word >> 20) & 15) << 8 | base_char((word >> 24) & 15) << 16 | base_char(word >> 28) << 24);
@@ -1056,11 +1178,12 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         PH_MARK(5); // sequence line
         // qualities (dwgsim.c:899-918)
         const int8_t *qb = j ? a.qbase[1] : a.qbase[0];
-        if (a.p.fixed_quality >= 0) { for (int i = 0; i < s; ++i) o.put((uint32_t)a.p.fixed_quality); }
+        // (Ion Torrent: the error rate is uniform, dwgsim_opt.c:338-343, so positions past the table reuse its last entry)
+        if (a.p.fixed_quality >= 0) { for (int i = 0; i < s_out; ++i) o.put((uint32_t)a.p.fixed_quality); }
         else if (!(0 < a.p.quality_std)) {
-            for (int i = 0; i < s; ++i) { int32_t q = qb[i]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
+            for (int i = 0; i < s_out; ++i) { int32_t q = qb[i < s ? i : s - 1]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
         } else {
-            uint32_t qacc = 0, nq = 0, m = 0; int p = 0; const int np = (s + 1) >> 1;
+            uint32_t qacc = 0, nq = 0, m = 0; int p = 0; const int np = (s_out + 1) >> 1;
             while (p < np) {
                 const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, m, (uint32_t)p);
                 // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
@@ -1075,8 +1198,8 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
                 for (int h = 0; h < 2; ++h) {
                     const int i = 2 * p + h;
                     const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
-                    if (i < s) {
-                        int32_t q = (int8_t)(qb[i] + (int32_t)((nrm * a.p.quality_std) + 0.5));
+                    if (i < s_out) {
+                        int32_t q = (int8_t)(qb[i < s ? i : s - 1] + (int32_t)((nrm * a.p.quality_std) + 0.5));
                         if (q < 33) q = 33;
                         if (q > 73) q = 73;
                         qacc |= (uint32_t)q << (8 * nq);
@@ -1097,6 +1220,8 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
 // host-side launchers (declared in dw_launch.hpp)
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+#if DW_HAS(0)
 
 void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l)
 {
@@ -1154,20 +1279,42 @@ void launch_place(hipStream_t st, const SimArgs &a)
     if (a.p.len[1] > 0) hipLaunchKernelGGL(k_place<2>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK * 2), 0, st, a);
     else hipLaunchKernelGGL(k_place<1>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), 0, st, a);
 }
+// one launcher per (LPP, DT) family, each defined in its own part
+void launch_sim_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_2_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
     const uint32_t nb = cdiv(a.n_pairs, PAIRS_PER_BLOCK);
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const size_t lds2 = (size_t)a.lds_words * PAIRS_PER_BLOCK * 2 * 4, lds1 = (size_t)a.lds_words * PAIRS_PER_BLOCK * 4;
-    if (a.p.len[1] > 0) {
-        if (out == 1) hipLaunchKernelGGL((k_simulate<2, 1>), dim3(nb), dim3(PAIRS_PER_BLOCK * 2), lds2, st, a);
-        else if (out == 2) hipLaunchKernelGGL((k_simulate<2, 2>), dim3(nb), dim3(PAIRS_PER_BLOCK * 2), lds2, st, a);
-        else hipLaunchKernelGGL((k_simulate<2, 3>), dim3(nb), dim3(PAIRS_PER_BLOCK * 2), lds2, st, a);
-    } else {
-        if (out == 1) hipLaunchKernelGGL((k_simulate<1, 1>), dim3(nb), dim3(PAIRS_PER_BLOCK), lds1, st, a);
-        else if (out == 2) hipLaunchKernelGGL((k_simulate<1, 2>), dim3(nb), dim3(PAIRS_PER_BLOCK), lds1, st, a);
-        else hipLaunchKernelGGL((k_simulate<1, 3>), dim3(nb), dim3(PAIRS_PER_BLOCK), lds1, st, a);
-    }
+    const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
+    const uint32_t nthr = PAIRS_PER_BLOCK * (pe ? 2 : 1);
+    const size_t lds = (size_t)(ion ? 2 * a.lds_words + 16 : a.lds_words) * nthr * 4;   // Ion Torrent: two buffers + the pass-2 stack
+    if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
+    else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
 }
+#endif // DW_HAS(0): launchers
+
+#define DW_SIM_FAMILY(LPP, DT)                                                                                   \
+    void launch_sim_##LPP##_##DT(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out)             \
+    {                                                                                                            \
+        const uint32_t nthr = PAIRS_PER_BLOCK * LPP;                                                             \
+        if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, DT>), dim3(nb), dim3(nthr), lds, st, a);            \
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT>), dim3(nb), dim3(nthr), lds, st, a);       \
+        else hipLaunchKernelGGL((k_simulate<LPP, 3, DT>), dim3(nb), dim3(nthr), lds, st, a);                     \
+    }
+#if DW_HAS(1)
+DW_SIM_FAMILY(2, 0)
+#endif
+#if DW_HAS(2)
+DW_SIM_FAMILY(1, 0)
+#endif
+#if DW_HAS(3)
+DW_SIM_FAMILY(2, 2)
+#endif
+#if DW_HAS(4)
+DW_SIM_FAMILY(1, 2)
+#endif
 
 } // namespace dw

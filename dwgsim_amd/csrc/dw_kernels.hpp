@@ -69,7 +69,10 @@ struct SimArgs {
     uint64_t *counters;            // [0] ticket, [1] retries, [2] fail flag, [3] total random, [4..6] stream bytes
     uint64_t *status[2];           // look-back words of stream BWA1 / BWA2 record bytes
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
-    int32_t lds_words;             // uint32 words of packed bases per lane
+    int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
+    int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors
+    int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
+    const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes
 };
 
 } // namespace dw

@@ -37,7 +37,7 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -R FLOAT      fraction of mutations that are indels [%.2f]\n         -X FLOAT      probability an indel is extended [%.2f]\n", o->indel_frac, o->indel_extend);
     fprintf(stderr, "         -I INT        the minimum length indel [%d]\n         -y FLOAT      probability of a random DNA read [%.2f]\n", o->indel_min, o->rand_read);
     fprintf(stderr, "         -n INT        maximum number of Ns allowed in a given read [%d]\n", o->max_n);
-    fprintf(stderr, "         -c INT        generate reads for 0: Illumina (1: SOLiD and 2: Ion Torrent are not on the accelerated path) [%d]\n", o->data_type);
+    fprintf(stderr, "         -c INT        generate reads for 0: Illumina, 2: Ion Torrent (1: SOLiD is not on the accelerated path) [%d]\n", o->data_type);
     fprintf(stderr, "         -S INT        paired end orientation 0: default, 1: same strand, 2: opposite strand [%d]\n", o->strandedness);
     fprintf(stderr, "         -A INT        read one strand 0: random, 1: forward, 2: reverse [%d]\n", o->read_one_strand);
     fprintf(stderr, "         -H            haploid mode\n         -z INT        random seed (-1 uses the current time) [%d]\n", o->seed);
@@ -46,7 +46,8 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -Q FLOAT      standard deviation of the base quality scores [%.2lf]\n", o->quality_std);
     fprintf(stderr, "         -o INT        FASTQ output 0: bfast and bwa, 1: bwa only, 2: bfast only [%d]\n", o->reads_output_type);
     fprintf(stderr, "         -a            assume each contig is an amplicon\n         -h            print this message\n\n");
-    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -c 2 (-f, -B), -m, -b, -v, -x\n\n");
+    fprintf(stderr, "         -f STRING     the flow order for Ion Torrent data\n");
+    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -B, -m, -b, -v, -x\n\n");
     return 1;
 }
 
@@ -105,7 +106,7 @@ struct GzOut {
 int main(int argc, char **argv)
 {
     dwgsim_hip_params_t o; dwgsim_hip_params_default(&o);
-    std::string prefix_s, fixedq_s;
+    std::string prefix_s, fixedq_s, flow_s;
     int c, device = 0;
     if (const char *d = getenv("DWGSIM_HIP_DEVICE")) device = atoi(d);
     while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
@@ -138,7 +139,8 @@ int main(int argc, char **argv)
         case 'Q': o.quality_std = atof(optarg); break;
         case 'o': o.reads_output_type = atoi(optarg); break;
         case 'a': o.amplicons = 1; break;
-        case 'B': case 'f': case 'm': case 'b': case 'v': case 'x':
+        case 'f': flow_s = optarg; o.flow_order = flow_s.c_str(); break;
+        case 'B': case 'm': case 'b': case 'v': case 'x':
             fprintf(stderr, "dwgsim-hip: option -%c is not on the accelerated path (see DESIGN.md); use the reference dwgsim\n", c); return 1;
         default: fprintf(stderr, "Unrecognized option: -%c\n", c); return usage(&o);
         }

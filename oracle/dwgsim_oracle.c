@@ -60,7 +60,7 @@ enum {
     D_BASE0 = 8,       /* +j; index = ii; NARROW (32-bit) uniforms: word i = error test of base i / random-read base i */
     D_QUAL0 = 10,      /* +j; index = ii; NARROW: block p holds two polar tries (words 0,1 and 2,3) per retry index;
                           the accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) */
-    D_FLOW0 = 12,      /* +j; index = ii; slot = running draw count inside generate_errors_flows */
+    D_FLOW0 = 12,      /* +j; index = ii; NARROW: word = running draw count inside generate_errors_flows */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
     D_SUB0 = 16        /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
 };
@@ -593,7 +593,7 @@ static void flow_alloc(flowbuf_t *b, int len, int F)
     b->mem = (len + 2 > F + 2) ? len + 2 : F + 2;
     b->seq = calloc((size_t)b->mem, 1); b->mask = calloc((size_t)b->mem, 1);
 }
-#define FLOW_U() rng_u(r, dom, idx, att, 0, (*slot)++)
+#define FLOW_U() rng_u32(r, dom, idx, att, 0, (*slot)++)   /* mode B: narrow draws, sequential slot counter per read end */
 static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t *slot,
                        flowbuf_t *b, int len, int strand, double e, int *n_err_out)
 {
@@ -1000,7 +1000,13 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                     }
                     if (SOLID == o->data_type) for (int j = 0; j < 2; ++j) if (0 < s[j]) to_colors(tb[j].seq, s[j]);
                     if (IONTORRENT == o->data_type) { /* :861-864 */
-                        for (int j = 0; j < 2; ++j) { uint32_t slot = 0; s[j] = flow_errors(o, r, D_FLOW0 + (uint32_t)j, ii, att, &slot, &tb[j], s[j], strand[j], o->e[j].start, &n_err[j]); }
+                        for (int j = 0; j < 2; ++j) {
+                            uint32_t slot = 0;
+                            /* the reference's flow mask persists between reads (dwgsim.c:430, :450-451); a read visits every flow in
+                             * pass 1, so nothing stale survives -- mode B makes that explicit (per-read mask) to stay order-independent */
+                            if (r->mode == RNG_PHILOX) memset(tb[j].mask, 0, (size_t)tb[j].mem);
+                            s[j] = flow_errors(o, r, D_FLOW0 + (uint32_t)j, ii, att, &slot, &tb[j], s[j], strand[j], o->e[j].start, &n_err[j]);
+                        }
                     } else for (int j = 0; j < 2; ++j) if (0 < s[j]) { /* :233-244, :866-881 */
                         int i = strand[j] ? s[j] - 1 : 0, step = strand[j] ? -1 : 1;
                         for (; 0 <= i && i < s[j]; i += step) {

@@ -42,7 +42,9 @@ def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22):
     return res
 
 
-# (fasta under tests/golden, flags): the option surface of the accelerated (Illumina) path
+FLOW = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
+
+# (fasta under tests/golden, flags): the option surface of the accelerated path (Illumina and Ion Torrent)
 CASES = [
     ("ex1.fa", "-z 13 -N 10000"),                                  # the reference's bundled test configuration
     ("ex1.fa", "-z 13 -N 10000 -1 100 -2 100"),                   # BASELINE configs[0]
@@ -68,4 +70,9 @@ CASES = [
     ("tiny.fa", "-z 9 -N 300 -a"),
     ("tiny.fa", "-z 21 -N 3000 -F 0.2 -y 0.3 -Q 10"),
     ("tiny.fa", "-z 8 -N 2000 -1 33 -2 77 -d 300 -Q 40"),
+    # Ion Torrent flow-space error model (BASELINE configs[4] shape: -c 2 -f <flow> -1 400 -2 0)
+    ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW} -1 400 -2 0 -e 0.01"),
+    ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW} -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
+    ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 100 -2 0 -e 0.2 -o 1"),
+    ("odd.fa", f"-z 6 -N 3000 -c 2 -f {FLOW} -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2"),
 ]

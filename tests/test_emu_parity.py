@@ -15,6 +15,8 @@ EMU_CASES = [
     ("odd.fa", "-z 3 -N 1200 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50"),
     ("tiny.fa", "-z 9 -N 1000 -2 0 -n 2"),
     ("tiny.fa", "-z 9 -N 700 -o 1 -y 0.3 -P pfx -A 2"),
+    ("tiny.fa", "-z 9 -N 600 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 400 -2 0 -e 0.01"),
+    ("tiny.fa", "-z 9 -N 400 -c 2 -f TACG -1 100 -2 60 -e 0.2 -E 0.1 -d 300 -o 1"),
 ]
 
 
