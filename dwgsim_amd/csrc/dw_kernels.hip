@@ -764,71 +764,86 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
 // at base[w * stride]).  Draws: narrow uniforms of domain D_FLOW0 + read end, one sequential slot
 // counter per read end.  The flow mask is per read (the reference's persistent mask is fully
 // rewritten by every read's pass 1).
-DW_DEV uint32_t nib_get(const uint32_t *base, int stride, int i) { return (base[(i >> 3) * stride] >> ((i & 7) * 4)) & 15u; }
-DW_DEV void nib_set(uint32_t *base, int stride, int i, uint32_t v)
-{
-    const uint32_t sh = (uint32_t)(i & 7) * 4; uint32_t w = base[(i >> 3) * stride];
-    base[(i >> 3) * stride] = (w & ~(15u << sh)) | (v << sh);
-}
-struct FlowRng {
-    RngKey key; uint32_t dom, att, slot; uint64_t ii; U4 blk;
+// word-cached access to a lane's packed 4-bit array: the flow model reads and appends sequentially, so one
+// LDS access serves eight bases
+struct NibReader {
+    const uint32_t *base; int stride, cw; uint32_t word;
+    DW_DEV void init(const uint32_t *b, int st) { base = b; stride = st; cw = -1; word = 0; }
+    DW_DEV uint32_t get(int i) { const int w = i >> 3; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & 7) * 4)) & 15u; }
+};
+struct NibAppender {
+    uint32_t *base; int stride, n; uint32_t acc;
+    DW_DEV void init(uint32_t *b, int st) { base = b; stride = st; n = 0; acc = 0; }
+    DW_DEV void push(uint32_t v) { acc |= v << ((n & 7) * 4); if ((++n & 7) == 0) { base[((n >> 3) - 1) * stride] = acc; acc = 0; } }
+    DW_DEV void flush() { if (n & 7) base[(n >> 3) * stride] = acc; }
+};
+struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
+    uint32_t seed, contig, dom, att, slot, w0, w1, w2, w3; uint64_t ii;
     DW_DEV uint32_t next()
     {
-        if ((slot & 3) == 0) blk = rng_block(key, dom, ii, att, 0, slot >> 2);
+        if ((slot & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, 0, slot >> 2); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
         const uint32_t k = slot & 3; ++slot;
-        return (k & 2) ? ((k & 1) ? blk.w : blk.z) : ((k & 1) ? blk.y : blk.x);
+        const uint32_t lo = (k & 1) ? w1 : w0, hi = (k & 1) ? w3 : w2;
+        return (k & 2) ? hi : lo;
     }
     DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr) ++n; return n; }   // while (drand48() < e) n_err++
 };
-// returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated
+// Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  *result tells which
+// buffer holds the final read (bufA after pass 2, or bufB when the reverse-strand read was turned back).
 DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
-                       int len, int strand, int cap, int32_t *n_err_out)
+                       int len, int strand, int cap, int32_t *n_err_out, uint32_t **result)
 {
     // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
-    auto in = [&](int t) -> uint32_t { const uint32_t v = nib_get(bufA, stride, strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
+    NibReader rd, la; rd.init(bufA, stride); la.init(bufA, stride);
+    auto in = [&](NibReader &r, int t) -> uint32_t { const uint32_t v = r.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
     uint64_t mask = 0; int flow_i = 0, total = 0;
-    { const uint32_t c0 = in(0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
+    { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
     // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
-    int t = 0, n1 = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
+    NibAppender o1; o1.init(bufB, stride);
+    int t = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
     for (;;) {
         uint32_t c; bool from_pend = false;
-        if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(t); else break;
-        if (n1 >= cap) return -1;
+        if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
+        if (o1.n >= cap) return -1;
         while (c != flow[flow_i]) { mask &= ~(1ull << flow_i); flow_i = flow_i + 1 == F ? 0 : flow_i + 1; }
         if (prev_c != c) {
             mask &= ~(1ull << flow_i);
             int n_err = rg.geometric(thr);
             if (n_err > 0) {
                 if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
-                    nib_set(bufB, stride, n1++, c); pend_c = c; pend_n = n_err - 1;
+                    o1.push(c); pend_c = c; pend_n = n_err - 1;
                     total += n_err; prev_c = c;
                     continue;
                 }
                 int hp_l = 0; uint32_t next_c = c;              // delete: bounded by the homopolymer length
-                while (t + hp_l < len) { next_c = in(t + hp_l); if (next_c != c) break; ++hp_l; }
+                while (t + hp_l < len) { next_c = in(la, t + hp_l); if (next_c != c) break; ++hp_l; }
                 if (n_err > hp_l) n_err = hp_l;
                 t += n_err; mask |= 1ull << flow_i; total += n_err;
-                if (n_err == hp_l && (n1 == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
+                if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
                     if (next_c == c) return -1;                // the whole read was one deleted homopolymer (the reference asserts)
                     int jj = 0; while (next_c != flow[(flow_i + jj) % F]) ++jj;
                     const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
-                    nib_set(bufB, stride, n1++, flow[(flow_i + kk) % F]);
-                } else if (t < len) { nib_set(bufB, stride, n1++, in(t)); ++t; }   // the base now at this position is not examined
+                    o1.push(flow[(flow_i + kk) % F]);
+                } else if (t < len) { o1.push(in(rd, t)); ++t; }   // the base now at this position is not examined
                 prev_c = c;
                 continue;
             }
             prev_c = c;
         }
-        nib_set(bufB, stride, n1++, c);
+        o1.push(c);
         if (from_pend) --pend_n; else ++t;
     }
+    o1.flush();
+    const int n1 = o1.n;
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order ----
-    int t2 = 0, n2 = 0, sp = 0;
+    NibReader r2; r2.init(bufB, stride);
+    NibAppender o2; o2.init(bufA, stride);
+    int t2 = 0, sp = 0;
     for (;;) {
         uint32_t x;
-        if (sp > 0) x = stk[(sp - 1) * stride] >> 16; else if (t2 < n1) x = nib_get(bufB, stride, t2); else break;
-        if (n2 >= cap) return -1;
+        if (sp > 0) x = stk[(sp - 1) * stride] >> 16; else if (t2 < n1) x = r2.get(t2); else break;
+        if (o2.n >= cap) return -1;
         int m = 0;
         while (x != flow[flow_i]) {
             const int n_err = rg.geometric(thr);
@@ -839,16 +854,22 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
             }
             flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
         }
-        if (m == 0 && sp == 0) { nib_set(bufA, stride, n2++, x); ++t2; }
+        if (m == 0 && sp == 0) { o2.push(x); ++t2; }
         else {      // take one base from the top run (the examined base itself when nothing was inserted)
             const uint32_t top = stk[(sp - 1) * stride];
-            nib_set(bufA, stride, n2++, top >> 16);
+            o2.push(top >> 16);
             if ((top & 0xffffu) <= 1) --sp; else stk[(sp - 1) * stride] = top - 1;
         }
     }
-    if (strand) for (int i = 0; i < n2 >> 1; ++i) {            // dwgsim.c:408-414
-        const uint32_t a = nib_get(bufA, stride, i), b = nib_get(bufA, stride, n2 - 1 - i);
-        nib_set(bufA, stride, i, b); nib_set(bufA, stride, n2 - 1 - i, a);
+    o2.flush();
+    const int n2 = o2.n;
+    *result = bufA;
+    if (strand) {                                               // dwgsim.c:408-414: turn the read back (into bufB, which is free now)
+        NibReader rr; rr.init(bufA, stride);
+        NibAppender o3; o3.init(bufB, stride);
+        for (int i = n2 - 1; i >= 0; --i) o3.push(rr.get(i));
+        o3.flush();
+        *result = bufB;
     }
     *n_err_out += total;
     return n2;
@@ -1013,7 +1034,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     const uint64_t ii = a.first_ii + pair;
     const RngKey key{a.p.seed, a.c.contig_index};
     const int s = sel_len(a, j);
-    uint32_t *lds = dyn_lds + tid;
+    uint32_t *lds = dyn_lds + tid;              // this lane's packed bases: word w at lds[w * nthr]
 
     const uint32_t meta = valid ? a.meta[pair] : 0u;
     const uint32_t att = meta & 0x7fffffffu;
@@ -1042,10 +1063,12 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     int s_out = s;                              // read length after errors (changes only for Ion Torrent)
     const int nw = (s + 7) >> 3;
     if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
-        FlowRng rg; rg.key = key; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.blk = U4{0, 0, 0, 0};
+        FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
+        uint32_t *res = lds;
         s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)2 * a.lds_words * nthr,
-                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
+                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err, &res);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
+        lds = res;                                  // the sequence line is read from whichever buffer holds the final read
     }
     if (valid && (DT == 0 || is_rand)) {
         const uint64_t *thr = j ? a.e_thr[1] : a.e_thr[0];
