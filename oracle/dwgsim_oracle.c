@@ -62,7 +62,9 @@ enum {
                           the accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) */
     D_FLOW0 = 12,      /* +j; index = ii; NARROW: word = running draw count inside generate_errors_flows */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
-    D_SUB0 = 16        /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
+    D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
+    D_MUTIN = 18,      /* mutation-input files (-b): index = entry ordinal; slot 0 hom test, 1 het haplotype (mut.c:662-669) */
+    D_MUTIN_BASE = 19  /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
 };
 
 typedef struct {
@@ -251,6 +253,7 @@ typedef struct {
     char *fixed_quality; double quality_std;
     char *read_prefix; int reads_output_type, output_type, amplicons;
     /* oracle-only switches */
+    char *fn_muts; int muts_type;   /* -m (1, txt) / -b (0, bed) / -v (2, vcf): mut_input.h:29-33 */
     int rng_mode, use_libm_log, null_fastq, verbose;
     int64_t emit_first, emit_count;   /* --emit-range first:count (mode B only): emit only these read indices of every contig */
 } opt_t;
@@ -262,7 +265,7 @@ static void opt_defaults(opt_t *o) /* dwgsim_opt.c:40-80 */
     o->dist = 500; o->std_dev = 50; o->N = -1; o->C = 100;
     o->length[0] = o->length[1] = 70;
     o->mut_rate = 0.001; o->mut_freq = 0.5; o->indel_frac = 0.1; o->indel_extend = 0.3; o->indel_min = 1;
-    o->rand_read = 0.05; o->seed = -1; o->quality_std = 2.0;
+    o->rand_read = 0.05; o->seed = -1; o->quality_std = 2.0; o->muts_type = -1;
 }
 
 static uint8_t nt4(int ch) /* dwgsim.c:56-73 nst_nt4_table */
@@ -381,6 +384,208 @@ static void walk_contig(const opt_t *o, rng_t *r, const seq_t *seq, hap_t *h0, h
                 else { deleting = rng_u(r, D_WALK, (uint64_t)i, 0, 0, 5) < 0.5 ? 1 : 2; h[deleting - 1]->c[i] = T_DEL | c; }
                 dlen = 1;
             } else walk_add_ins(o, r, h0, h1, i, c);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Mutation-input files: mut_txt.c:40-133 (-m), mut_bed.c:37-137 (-b), mut_vcf.c:42-280 (-v) and their
+ * application in mut_diref, mut.c:644-745.  Entries keep file order; `contig` is the FASTA ordinal.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { char **name; int64_t *len; int n; } ctab_t;
+typedef struct { uint32_t contig, pos; uint8_t type, is_hap; char *bases; } min_txt_t;      /* mut_txt.h:23-29 */
+typedef struct { uint32_t contig, start, end; uint8_t type; char *bases; } min_bed_t;        /* mut_bed.h */
+typedef struct { int type; min_txt_t *t; int nt; min_bed_t *b; int nb; } mutin_t;
+
+static char iupac_and_base_to_mut(char iupac, char base) /* dwgsim.c:202-213 */
+{
+    static const char *codes = "XACMGRSVTWYHKDBN";
+    int b = nt4(base);
+    for (int i = 0; i < 4; ++i) if (codes[1 << (b & 3) | 1 << (i & 3)] == iupac) return "ACGTN"[i];
+    return 'X';
+}
+static int get_muttype(char *str) /* dwgsim.c:183-200 */
+{
+    for (char *q = str; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    if (!strcmp("snp", str) || !strcmp("substitute", str) || !strcmp("sub", str) || !strcmp("s", str)) return T_SUB;
+    if (!strcmp("insertion", str) || !strcmp("insert", str) || !strcmp("ins", str) || !strcmp("i", str)) return T_INS;
+    if (!strcmp("deletion", str) || !strcmp("delet", str) || !strcmp("del", str) || !strcmp("d", str)) return T_DEL;
+    return -1;
+}
+static void mi_push_txt(mutin_t *m, uint32_t contig, uint32_t pos, int type, uint32_t is_hap, const char *bases)
+{
+    m->t = realloc(m->t, sizeof(min_txt_t) * (size_t)(m->nt + 1));
+    min_txt_t *e = &m->t[m->nt++];
+    e->contig = contig; e->pos = pos; e->type = (uint8_t)type; e->is_hap = (uint8_t)is_hap; e->bases = bases ? strdup(bases) : NULL;
+}
+static void parse_txt(FILE *fp, const ctab_t *c, mutin_t *m) /* mut_txt.c:40-133 */
+{
+    char name[1024], mut[1024], ref; uint32_t pos, prev_pos = 0, is_hap; int i = 0;
+    (void)prev_pos;
+    while (0 < fscanf(fp, "%1023s\t%u\t%c\t%1023s\t%d", name, &pos, &ref, mut, &is_hap)) {
+        while (i < c->n && 0 != strcmp(name, c->name[i])) { i++; prev_pos = 0; }
+        if (c->n == i) { fprintf(stderr, "Error: mutation contig not found or out of order [%s]\n", name); exit(1); }
+        else if (pos <= 0 || c->len[i] < pos) { fprintf(stderr, "Error: start out of range [%s,%u]\n", name, pos); exit(1); }
+        else if (pos < prev_pos) { fprintf(stderr, "Error: out of order [%s,%u]\n", name, pos); exit(1); }   /* prev_pos is never advanced in the reference */
+        int type;
+        if ('-' == ref && '-' != mut[0]) type = T_INS;
+        else if ('-' != ref && '-' == mut[0]) type = T_DEL;
+        else if ('-' != ref && '-' != mut[0]) {
+            type = T_SUB;
+            if (is_hap < 3) {
+                if (nt4(mut[0]) < 4) { fprintf(stderr, "Error: heterozygous bases must be in IUPAC form\n"); exit(1); }
+                mut[0] = iupac_and_base_to_mut(mut[0], ref);
+                if ('X' == mut[0]) { fprintf(stderr, "Error: out of range\n"); exit(1); }
+                mut[1] = '\0';
+            }
+        } else { fprintf(stderr, "Error: out of range\n"); exit(1); }
+        mi_push_txt(m, (uint32_t)i, pos, type, is_hap, mut);
+    }
+}
+static void parse_bed(FILE *fp, const ctab_t *c, mutin_t *m) /* mut_bed.c:37-137 */
+{
+    char name[1024], type[1024], bases[1024]; uint32_t start, end, prev_contig = 0, max_end = 0; int i = 0;
+    while (0 < fscanf(fp, "%1023s\t%u\t%u\t%1023s\t%1023s", name, &start, &end, bases, type)) {
+        while (i < c->n && 0 != strcmp(name, c->name[i])) i++;
+        if (c->n == i) { fprintf(stderr, "Error: contig not found [%s]\n", name); exit(1); }
+        else if (c->len[i] <= start) { fprintf(stderr, "Error: start out of range [%s,%u]\n", name, start); exit(1); }
+        else if (c->len[i] < end) { fprintf(stderr, "Error: end out of range [%s,%u]\n", name, end); exit(1); }
+        else if (end <= start) { fprintf(stderr, "Error: end <= start [%s,%u,%u]\n", name, start, end); exit(1); }
+        else if (0 != strcmp("*", bases) && (end - start) != strlen(bases)) { fprintf(stderr, "Error: bases did not match start and end [%s,%u,%u,%s]\n", name, start, end, bases); exit(1); }
+        else if (prev_contig == (uint32_t)i && start + 1 <= max_end) { fprintf(stderr, "Warning: overlapping entries, ignoring entry [%s\t%u\t%u\t%s\t%s]\n", name, start, end, bases, type); continue; }
+        if (prev_contig != (uint32_t)i || max_end < end) { prev_contig = (uint32_t)i; max_end = end; }
+        int ty = get_muttype(type);
+        if (ty == T_INS && 26 < end - start) { fprintf(stderr, "Error: insertion of length %d exceeded the maximum supported length of %d\n", end - start, 26); exit(1); }
+        if (ty < 0) { fprintf(stderr, "Error: mutation type unrecognized [%s]\n", type); exit(1); }
+        m->b = realloc(m->b, sizeof(min_bed_t) * (size_t)(m->nb + 1));
+        min_bed_t *e = &m->b[m->nb++];
+        e->contig = (uint32_t)i; e->start = start; e->end = end; e->type = (uint8_t)ty; e->bases = strdup(bases);
+    }
+}
+static void parse_vcf(FILE *fp, const ctab_t *c, mutin_t *m) /* mut_vcf.c:42-280, line by line */
+{
+    static int warned = 0;
+    char *line = NULL; size_t cap = 0; ssize_t got;
+    /* the reference splits at '\n' or '\r' inside a 1 MiB window; whole lines are equivalent for lines shorter than that */
+    char *all = NULL; size_t n_all = 0, m_all = 0; int ch;
+    while ((ch = fgetc(fp)) != EOF) { if (n_all + 1 >= m_all) { m_all = m_all ? m_all * 2 : 1 << 16; all = realloc(all, m_all); } all[n_all++] = (char)ch; }
+    (void)line; (void)cap; (void)got;
+    int i = 0; uint32_t prev_pos = 0;
+    size_t s = 0;
+    while (s < n_all) {
+        size_t n = s;
+        while (n < n_all && all[n] != '\n' && all[n] != '\r') n++;
+        if (s == n) { s++; continue; }
+        if (all[s] == '#') { s = n; continue; }
+        char name[1024], id[1024], ref[1024], alt[1025]; uint32_t pos = 0, is_hap;
+        char save = n < n_all ? all[n] : 0; if (n < n_all) all[n] = 0;
+        if (EOF == sscanf(all + s, "%1023s\t%u\t%1023s\t%1023s\t%1024s", name, &pos, id, ref, alt)) { fprintf(stderr, "Error: VCF parsing error\n"); exit(1); }
+        if (n < n_all) all[n] = save;
+        is_hap = 4;
+        size_t q = s;
+        while (q + 4 < n) {
+            if (('\t' == all[q] || ';' == all[q]) && 'p' == all[q + 1] && 'l' == all[q + 2] && '=' == all[q + 3]) {
+                q += 4;
+                switch (all[q]) { case '1': is_hap = 1; break; case '2': is_hap = 2; break; case '3': is_hap = 3; break;
+                default: fprintf(stderr, "Error: Could not determine the strand of the mutation from the 'pl' tag.\n"); exit(1); }
+                break;
+            }
+            q++;
+        }
+        if (4 == is_hap && 0 == warned) { fprintf(stderr, "Warning: strand of the mutation not found; please use the 'pl' tag.\n"); warned = 1; is_hap = 3; }
+        while (i < c->n && 0 != strcmp(name, c->name[i])) { i++; prev_pos = 0; }
+        if (c->n == i) { fprintf(stderr, "Error: contig not found [%s]\n", name); exit(1); }
+        else if (pos <= 0 || c->len[i] < pos) { fprintf(stderr, "Error: start out of range [%s,%u]\n", name, pos); exit(1); }
+        else if (pos < prev_pos) { fprintf(stderr, "Error: out of order [%s,%u]\n", name, pos); exit(1); }
+        int ref_l = (int)strlen(ref), alt_l = (int)strlen(alt), j;
+        if (1 == ref_l && ref[0] == '.') { ref[0] = 0; ref_l = 0; }
+        if (1 == alt_l && alt[0] == '.') { alt[0] = 0; alt_l = 0; }
+        if (0 == alt_l && 0 == ref_l) { fprintf(stderr, "Error: empty alleles\n"); exit(1); }
+        for (j = 0; j < alt_l; ++j) if (',' == alt[j]) { fprintf(stderr, "Error: multiple alleles are not supported\n"); exit(1); }
+        for (j = 0; j < ref_l; ++j) { ref[j] = "ACGTNN"[nt4(ref[j])]; if ('N' == ref[j]) { fprintf(stderr, "Error: non-ACGT base found\n"); exit(1); } }
+        for (j = 0; j < alt_l; ++j) { alt[j] = "ACGTNN"[nt4(alt[j])]; if ('N' == alt[j]) { fprintf(stderr, "Error: non-ACGT base found\n"); exit(1); } }
+        if (ref_l == alt_l) {
+            for (j = 0; j < ref_l; ++j) { char b2[2] = { alt[j], 0 }; mi_push_txt(m, (uint32_t)i, pos + (uint32_t)j, T_SUB, is_hap, b2); }
+        } else if (ref_l < alt_l) {
+            for (j = 0; j < ref_l; ++j, ++pos) if (ref[j] != alt[j]) break;
+            mi_push_txt(m, (uint32_t)i, pos, T_INS, is_hap, alt + j);
+        } else {
+            for (j = 0; j < alt_l; ++j, ++pos) if (ref[j] != alt[j]) break;
+            if (j == ref_l) { fprintf(stderr, "Error: no deleted bases\n"); exit(1); }
+            for (; j < ref_l; ++j, ++pos) mi_push_txt(m, (uint32_t)i, pos, T_DEL, is_hap, NULL);
+        }
+        prev_pos = pos;
+        s = n;
+    }
+    free(all);
+}
+
+/* mut.c:282-377 mut_add_ins() with given bases (hap >= 0) or a given random length (bed "*") */
+static void input_add_ins(rng_t *r, hap_t *h0, hap_t *h1, int64_t i, uint8_t c, int hap, const char *bases, uint32_t num, uint64_t entry)
+{
+    if (bases) num = (uint32_t)strlen(bases);
+    uint8_t *P = malloc(num ? num : 1);
+    if (!bases) for (uint32_t j = 0; j < num; ++j) P[num - 1 - j] = (uint8_t)(uint64_t)(rng_u(r, D_MUTIN_BASE, entry, 0, 0, j) * 4.0);
+    else for (int64_t j = (int64_t)num - 1; j >= 0; --j) {     /* last base first: the order in which N / unknown bases consume draws (mut.c:317-321, :347-355) */
+        int b = nt4(bases[j]);
+        if (b >= 4) b = (int)(rng_u(r, D_MUTIN_BASE, entry, 0, 0, (uint32_t)j) * 4.0);
+        P[j] = (uint8_t)b;
+    }
+    hap_t *h[2] = { h0, h1 };
+    for (int x = 0; x < 2; ++x) if (hap & (1 << x)) {
+        /* a second insertion at the same cell replaces the first one's payload, as overwriting the reference's cell does */
+        int found = 0;
+        for (int k = h[x]->n_ins - 1; k >= 0 && h[x]->ins[k].pos >= i; --k) if (h[x]->ins[k].pos == i) { free(h[x]->ins[k].b); h[x]->ins[k].b = malloc(num ? num : 1); memcpy(h[x]->ins[k].b, P, num); h[x]->ins[k].n = num; found = 1; break; }
+        if (!found) {   /* keep the table sorted by position: input files need not be sorted within a contig for -b */
+            ins_push(h[x], i, num, P);
+            for (int k = h[x]->n_ins - 1; k > 0 && h[x]->ins[k - 1].pos > h[x]->ins[k].pos; --k) { ins_t t = h[x]->ins[k]; h[x]->ins[k] = h[x]->ins[k - 1]; h[x]->ins[k - 1] = t; }
+        }
+        h[x]->c[i] = T_INS | c;
+    }
+    free(P);
+}
+
+/* mut.c:644-745: the haplotypes start as the reference, then the file's entries for this contig are applied in file order */
+static void apply_mutation_input(const opt_t *o, rng_t *r, const seq_t *seq, hap_t *h0, hap_t *h1, uint32_t contig_i, const mutin_t *m)
+{
+    hap_t *h[2] = { h0, h1 };
+    for (int x = 0; x < 2; ++x) { h[x]->l = seq->l; h[x]->c = calloc((size_t)seq->l + 1, 1); h[x]->ins = NULL; h[x]->n_ins = h[x]->m_ins = 0; }
+    for (int64_t i = 0; i < seq->l; ++i) h0->c[i] = h1->c[i] = nt4(seq->s[i]);
+    if (m->type == 0) {
+        for (int k = 0; k < m->nb; ++k) {
+            const min_bed_t *e = &m->b[k];
+            if (e->contig == contig_i) {
+                int has_bases = strcmp("*", e->bases) != 0, is_hom = 0, hap, which = 0;
+                if (o->is_hap || rng_u(r, D_MUTIN, (uint64_t)k, 0, 0, 0) < 0.333333) { is_hom = 1; hap = 3; }
+                else { which = rng_u(r, D_MUTIN, (uint64_t)k, 0, 0, 1) < 0.5 ? 0 : 1; hap = 1 << which; }
+                if (e->type == T_SUB) {
+                    for (uint32_t j = e->start; j < e->end; ++j) {
+                        uint8_t c = nt4(seq->s[j]);
+                        if (!has_bases) { double rr = rng_u(r, D_MUTIN_BASE, (uint64_t)k, 0, 0, j - e->start); c = (uint8_t)((c + (uint64_t)(rr * 3.0 + 1)) & 3); }
+                        else c = nt4(e->bases[j - e->start]);
+                        if (is_hom) h0->c[j] = h1->c[j] = T_SUB | c; else h[which]->c[j] = T_SUB | c;
+                    }
+                } else if (e->type == T_DEL) {
+                    for (uint32_t j = e->start; j < e->end; ++j) {
+                        uint8_t c = nt4(seq->s[j]);
+                        if (is_hom) h0->c[j] = h1->c[j] = T_DEL | c; else h[which]->c[j] = T_DEL | c;
+                    }
+                } else {
+                    uint8_t c = nt4(seq->s[e->start]);
+                    if (!has_bases) input_add_ins(r, h0, h1, e->start, c, hap, NULL, e->end - e->start, (uint64_t)k);
+                    else input_add_ins(r, h0, h1, e->start, c, hap, e->bases, 0, (uint64_t)k);
+                }
+            } else if (contig_i < e->contig) break;
+        }
+    } else {
+        for (int k = 0; k < m->nt; ++k) {
+            const min_txt_t *e = &m->t[k];
+            if (e->contig != contig_i) continue;
+            const int64_t p = (int64_t)e->pos - 1;
+            uint8_t c = nt4(seq->s[p]);
+            if (e->type == T_DEL) { if (e->is_hap & 1) h0->c[p] |= T_DEL | c; if (e->is_hap & 2) h1->c[p] |= T_DEL | c; }
+            else if (e->type == T_SUB) { if (e->is_hap & 1) h0->c[p] = T_SUB | nt4(e->bases[0]); if (e->is_hap & 2) h1->c[p] = T_SUB | nt4(e->bases[0]); }
+            else input_add_ins(r, h0, h1, p, c, e->is_hap, e->bases, 0, (uint64_t)k);
         }
     }
 }
@@ -691,7 +896,7 @@ static int calibrate_flow_error(opt_t *o, rng_t *r);
 
 static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
 {
-    int c;
+    int c, muts_flags = 0;
     optind = 1;
     while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
         switch (c) {
@@ -720,8 +925,11 @@ static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
         case 'h': return 0;
         case 'z': o->seed = xatoi(optarg, 'z', 1); break;
         case 'M': o->output_type = xatoi(optarg, 'M', 0); break;
-        case 'm': case 'b': case 'v': case 'x':
-            fprintf(stderr, "oracle: option -%c (mutation-input / regions) is outside the oracle's scope\n", c); exit(3);
+        case 'm': free(o->fn_muts); o->fn_muts = strdup(optarg); o->muts_type = 1; muts_flags |= 1; break;
+        case 'b': free(o->fn_muts); o->fn_muts = strdup(optarg); o->muts_type = 0; muts_flags |= 2; break;
+        case 'v': free(o->fn_muts); o->fn_muts = strdup(optarg); o->muts_type = 2; muts_flags |= 4; break;
+        case 'x':
+            fprintf(stderr, "oracle: option -%c (regions) is outside the oracle's scope\n", c); exit(3);
         case 'P': free(o->read_prefix); o->read_prefix = strdup(optarg); break;
         case 'q': free(o->fixed_quality); o->fixed_quality = strdup(optarg); break;
         case 'Q': o->quality_std = atof(optarg); break;
@@ -752,6 +960,7 @@ static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
     if (o->fixed_quality && strlen(o->fixed_quality) != 1) { fprintf(stderr, "Error: command line option -q requires one character\n"); return 0; }
     CHECK(o->quality_std, 0, INT32_MAX, "-Q");
     CHECK(o->reads_output_type, 0, 2, "-o");
+    if (muts_flags != 0 && muts_flags != 1 && muts_flags != 2 && muts_flags != 4) { fprintf(stderr, "Error: -m/-b/-v cannot be used together\n"); return 0; }
 
     rng_seed(r, o->rng_mode, (-1 == o->seed) ? (int32_t)time(0) : o->seed);
     r->use_libm_log = o->use_libm_log;
@@ -878,6 +1087,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
     seq_t seq = { 0, 0, NULL };
     char name[4096];
     uint64_t tot_len = 0, ctr = 0, rand_ii = 0; int n_ref = 0; int64_t l, n_sim = 0;
+    ctab_t ct = { NULL, NULL, 0 }; mutin_t mi; memset(&mi, 0, sizeof mi); mi.type = o->muts_type;
     int lmax = o->length[0] > o->length[1] ? o->length[0] : o->length[1];
     flowbuf_t tb[2];
     for (int j = 0; j < 2; ++j) flow_alloc(&tb[j], lmax, o->flow_order_len);
@@ -890,12 +1100,14 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
         int ll, d0, d1, d2;
         while (0 < fscanf(fai, "%s\t%d\t%d\t%d\t%d", name, &ll, &d0, &d1, &d2)) {
             tot_len += (uint64_t)ll; ++n_ref;
+            ct.name = realloc(ct.name, sizeof(char *) * (size_t)(ct.n + 1)); ct.len = realloc(ct.len, sizeof(int64_t) * (size_t)(ct.n + 1)); ct.name[ct.n] = strdup(name); ct.len[ct.n++] = ll;
             if (out->has_mut) sink_printf(&out->vcf, "##contig=<ID=%s,length=%d>\n", name, ll);
         }
         fclose(fai);
     } else {
         while ((l = fasta_next(fp, &seq, name)) >= 0) {
             tot_len += (uint64_t)l; ++n_ref;
+            ct.name = realloc(ct.name, sizeof(char *) * (size_t)(ct.n + 1)); ct.len = realloc(ct.len, sizeof(int64_t) * (size_t)(ct.n + 1)); ct.name[ct.n] = strdup(name); ct.len[ct.n++] = l;
             if (out->has_mut) sink_printf(&out->vcf, "##contig=<ID=%s,length=%d>\n", name, (int)l);
         }
     }
@@ -906,6 +1118,12 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
         "##INFO=<ID=mt,Number=1,Type=String,Description=\"Variant Type: SUBSTITUTE/INSERT/DELETE\">\n"
         "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
 
+    if (o->muts_type >= 0) {   /* dwgsim.c:494-497 */
+        FILE *fm = fopen(o->fn_muts, "r");
+        if (!fm) { fprintf(stderr, "[oracle] fail to open file '%s'. Abort!\n", o->fn_muts); return 1; }
+        if (o->muts_type == 1) parse_txt(fm, &ct, &mi); else if (o->muts_type == 0) parse_bed(fm, &ct, &mi); else parse_vcf(fm, &ct, &mi);
+        fclose(fm);
+    }
     uint32_t contig_i = 0;
     while ((l = fasta_next(fp, &seq, name)) >= 0) {
         int64_t n_pairs = 0;
@@ -925,7 +1143,8 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
         }
         hap_t hap[2]; memset(hap, 0, sizeof hap);
         r->k1 = contig_i;
-        walk_contig(o, r, &seq, &hap[0], &hap[1]);           /* dwgsim.c:628-629 -> mut.c:591 */
+        if (o->muts_type >= 0) apply_mutation_input(o, r, &seq, &hap[0], &hap[1], contig_i, &mi);   /* mut.c:644-745 */
+        else walk_contig(o, r, &seq, &hap[0], &hap[1]);      /* dwgsim.c:628-629 -> mut.c:591 */
         left_justify(&seq, &hap[0], &hap[1]);                /* mut.c:756 */
         if (out->has_mut) print_mutations(name, &seq, &hap[0], &hap[1], &out->txt, &out->vcf);
 
