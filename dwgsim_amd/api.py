@@ -39,7 +39,7 @@ class Batch(C.Structure):
 EXPORTS = [
     "dwgsim_hip_params_default", "dwgsim_hip_params_check", "dwgsim_hip_pairs_for_contig", "dwgsim_hip_create",
     "dwgsim_hip_destroy", "dwgsim_hip_last_error", "dwgsim_hip_add_contig", "dwgsim_hip_drop_contig",
-    "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
+    "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
 ]
 
@@ -67,6 +67,7 @@ def load(path: str | None = None):
     lib.dwgsim_hip_last_error.argtypes = [C.c_void_p]
     lib.dwgsim_hip_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_uint32]
     lib.dwgsim_hip_drop_contig.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_set_mutation_input.argtypes = [C.c_void_p, C.c_int, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int]
     lib.dwgsim_hip_mutate_contig.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_mutations_text.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_size_t), P(C.c_void_p), P(C.c_size_t)]
     lib.dwgsim_hip_count_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, P(C.c_uint64)]
@@ -110,6 +111,7 @@ def parse_flags(flags: str, lib=None) -> Params:
     toks = shlex.split(flags)
     i = 0
     keep = []
+    mut_input = None
     while i < len(toks):
         t = toks[i]
         def arg():
@@ -144,10 +146,12 @@ def parse_flags(flags: str, lib=None) -> Params:
         elif t == "-Q": p.quality_std = float(arg())
         elif t == "-o": p.reads_output_type = int(arg())
         elif t == "-a": p.amplicons = 1
+        elif t in ("-m", "-b", "-v"): mut_input = ({"-b": 0, "-m": 1, "-v": 2}[t], arg())
         else:
             raise DwgsimError(f"option {t} is not on the accelerated path")
         i += 1
     p._keep = keep
+    p._mut_input = mut_input       # (type, path) of -b / -m / -v, applied by run_job through dwgsim_hip_set_mutation_input
     return p
 
 
@@ -225,6 +229,13 @@ class Context:
     def drop_contig(self, cid: int):
         self._chk(self.lib.dwgsim_hip_drop_contig(self.h, cid))
 
+    def set_mutation_input(self, mtype: int, path: str, contigs):
+        """contigs: the FASTA's (name, array-or-length) list in file order."""
+        n = len(contigs)
+        names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
+        lens = (C.c_int64 * n)(*[int(a) if isinstance(a, int) else len(a) for _, a in contigs])
+        self._chk(self.lib.dwgsim_hip_set_mutation_input(self.h, mtype, path.encode(), names, lens, n))
+
     def mutate(self, cid: int):
         self._chk(self.lib.dwgsim_hip_mutate_contig(self.h, cid))
 
@@ -274,6 +285,8 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
     rand_ii = 0
     n_ref = len(contigs)
     with Context(params, device, lib) as ctx:
+        if getattr(params, "_mut_input", None):
+            ctx.set_mutation_input(params._mut_input[0], params._mut_input[1], contigs)
         for ci, (name, arr) in enumerate(contigs):
             n_ref -= 1
             n_pairs = 0

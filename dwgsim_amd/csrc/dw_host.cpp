@@ -19,6 +19,7 @@
 #include "../../include/dwgsim_hip.h"
 #include "dw_kernels.hpp"
 #include "dw_launch.hpp"
+#include "dw_mutin.hpp"
 
 using namespace dw;
 
@@ -64,6 +65,8 @@ struct dwgsim_hip_ctx {
     DevBuf meta, block_rand, status[2], out[2][3], scratch_mask, scratch_cnt;
     DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
+    MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
+    DevBuf w_ppos, w_pcells;
     uint64_t *d_counters = nullptr;          // 8 x u64
     uint64_t *h_counters = nullptr;          // pinned mirror
     uint64_t out_bytes[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -258,7 +261,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_qbase[j]); hipFree(c->status[j].p); }
-    hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
+    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters); hipFree(c->d_flow);
@@ -315,6 +318,17 @@ static Contig *get_contig(dwgsim_hip_ctx_t *c, int contig)
     return &c->contigs[(size_t)contig];
 }
 
+int dwgsim_hip_set_mutation_input(dwgsim_hip_ctx_t *c, int type, const char *path, const char *const *names, const int64_t *lens, int n_contigs)
+{
+    if (!c || !path || type < 0 || type > 2 || n_contigs < 0 || (n_contigs && (!names || !lens))) { if (c) c->err = "bad mutation-input arguments"; return DWGSIM_HIP_ERR_ARG; }
+    std::vector<ContigName> tab;
+    for (int i = 0; i < n_contigs; ++i) tab.push_back(ContigName{names[i], lens[i]});
+    std::string err;
+    if (!parse_mutation_input(type, path, tab, c->mutin, err)) { c->err = err; c->has_mutin = false; return DWGSIM_HIP_ERR_ARG; }
+    c->has_mutin = true;
+    return DWGSIM_HIP_OK;
+}
+
 int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
 {
     Contig *kp = get_contig(c, contig);
@@ -332,6 +346,51 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     }
     k.mutated = true; k.n_cand = 0;
     if (l == 0) return DWGSIM_HIP_OK;
+    if (c->has_mutin) {      // file-driven mutations (mut.c:644-745): host resolves the entries, the GPU scatters and left-justifies
+        ResolvedContig rc;
+        resolve_mutation_input(c->mutin, k.contig_index, k.ascii.data(), l, (uint32_t)c->prm.seed, c->prm.is_hap != 0, rc);
+        const uint32_t np = (uint32_t)rc.pos.size();
+        std::vector<Event> evs;
+        for (uint32_t q = 0; q < np; ++q) if (rc.cells[q] & 0x3030) { Event e; e.pos = rc.pos[q]; e.type = 4; e.hap = 3; e.base = 0; e.live = 1; e.len = 1; evs.push_back(e); }
+        const uint32_t nev = (uint32_t)evs.size();
+        k.n_cand = nev;
+        if (np == 0) return DWGSIM_HIP_OK;
+        if (ensure(c, c->w_ppos, sizeof(int32_t) * np) || ensure(c, c->w_pcells, sizeof(uint16_t) * np) || ensure(c, c->w_ev, sizeof(Event) * (nev ? nev : 1)) ||
+            ensure(c, c->w_lo, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_sufmin, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_bound, nev ? nev : 1)) return DWGSIM_HIP_ERR_DEVICE;
+        HIPC(c, hipMemcpyAsync(c->w_ppos.p, rc.pos.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->w_pcells.p, rc.cells.data(), sizeof(uint16_t) * np, hipMemcpyHostToDevice, c->stream));
+        if (nev) HIPC(c, hipMemcpyAsync(c->w_ev.p, evs.data(), sizeof(Event) * nev, hipMemcpyHostToDevice, c->stream));
+        for (int h = 0; h < 2; ++h) {
+            const size_t n = rc.ins[h].size();
+            std::vector<int32_t> ip(n); std::vector<uint32_t> il(n), io(n); std::vector<uint8_t> ib;
+            for (size_t q = 0; q < n; ++q) { ip[q] = rc.ins[h][q].pos; il[q] = (uint32_t)rc.ins[h][q].bases.size(); io[q] = (uint32_t)ib.size(); ib.insert(ib.end(), rc.ins[h][q].bases.begin(), rc.ins[h][q].bases.end()); }
+            k.n_ins[h] = (uint32_t)n; k.n_ins_bases[h] = (uint32_t)ib.size();
+            const size_t nn = n ? n : 1, nb = ib.size() ? ib.size() : 1;
+            if (nn > k.cap_ins[h]) {
+                hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]);
+                k.cap_ins[h] = nn + nn / 4 + 64;
+                HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * k.cap_ins[h]));
+                HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * k.cap_ins[h]));
+                HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * k.cap_ins[h]));
+            }
+            if (nb > k.cap_bases[h]) { hipFree(k.d_ins_bases[h]); k.cap_bases[h] = nb + nb / 4 + 256; HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], k.cap_bases[h] + 16)); }
+            if (n) {
+                HIPC(c, hipMemcpy(k.d_ins_pos[h], ip.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(k.d_ins_len[h], il.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(k.d_ins_off[h], io.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(k.d_ins_bases[h], ib.data(), ib.size(), hipMemcpyHostToDevice));
+            }
+        }
+        launch_apply_patches(c->stream, (const int32_t *)c->w_ppos.p, (const uint16_t *)c->w_pcells.p, np, k.d_cells[0], k.d_cells[1]);
+        const ContigDev cd = contig_dev(k);
+        if (nev) {
+            if (c->seq_justify) launch_justify_seq(c->stream, (const Event *)c->w_ev.p, nev, cd);
+            else launch_justify(c->stream, (const Event *)c->w_ev.p, nev, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+        }
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipStreamSynchronize(c->stream));
+        return DWGSIM_HIP_OK;
+    }
     const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
     if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;

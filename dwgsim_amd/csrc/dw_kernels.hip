@@ -388,6 +388,33 @@ __global__ void k_justify_seq(const Event *ev, uint32_t n_cand, ContigDev c)
 // can reach the previous live event's footprint and an unmutated non-N position separates them
 // (prev_del is then 0, mut.c:585-587).  (4) k_jrun: one thread per cluster replays the exact
 // sequential semantics (justify_visit) over its events; clusters touch disjoint cells.
+DW_DEV int64_t reach_del(const ContigDev &c, int h, int64_t p)
+{
+    // period = the run of DELETE cells the sequential pass would measure at p (adjacent runs merge,
+    // mut.c:503 / :535 / :557) on haplotype h
+    const int64_t L = del_run(c.hap[h], p, c.l);
+    int64_t j = p - 1;
+    for (; j >= 0; --j) {
+        const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
+        if (!(mutated || (p + L < c.l && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
+    }
+    return j < 0 ? 0 : j;                              // last cell read
+}
+DW_DEV int64_t reach_ins(const ContigDev &c, int h, int64_t p)
+{
+    const uint32_t idx = ins_find(c.hap[h], p);
+    const uint32_t n = c.hap[h].ins_len[idx];
+    const uint8_t *P = c.hap[h].ins_bases + c.hap[h].ins_off[idx];
+    // rotating left by one makes the cell's base the new first base: after r rotations the last
+    // inserted base is P[n-1-r] while r < n, then ref[p-1-(r-n)] & 3 (bases rotated in earlier)
+    int64_t j = p - 1; int64_t r = 0;
+    for (; j >= 0; --j, ++r) {
+        const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
+        const uint32_t last = r < (int64_t)n ? (uint32_t)P[n - 1 - r] : (uint32_t)(c.ref[p - 1 - (r - n)] & 3);
+        if (!(mutated || last == (uint32_t)(c.ref[j] & 3))) break;
+    }
+    return j < 0 ? 0 : j;
+}
 __global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, int32_t *__restrict__ lo)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,35 +423,16 @@ __global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDe
     int64_t reach = 0x7fffffff;
     if (e.live) {
         const int64_t p = e.pos;
-        reach = p;
-        if (e.type == 2) {
-            // period = the run of DELETE cells the sequential pass would measure at p (adjacent runs merge,
-            // mut.c:503 / :535 / :557): haplotype 1 for hom and hap-1 events, haplotype 2 for hap-2 events
-            const int64_t L = del_run(c.hap[(e.hap & 1) ? 0 : 1], p, c.l);
-            int64_t j = p - 1;
-            for (; j >= 0; --j) {
-                const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
-                if (!(mutated || (p + L < c.l && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
+        reach = p;                                      // substitution: no scan; it only matters as a neighbour (prev_del)
+        if (e.type == 2) reach = reach_del(c, (e.hap & 1) ? 0 : 1, p);         // haplotype 1 for hom and hap-1 events
+        else if (e.type == 3) reach = reach_ins(c, (e.hap & 1) ? 0 : 1, p);    // both copies carry the same bases before justification
+        else if (e.type == 4) {                         // cell patched from a mutation-input file: whatever the two cells hold
+            for (int h = 0; h < 2; ++h) {
+                const uint8_t t = c.hap[h].cells[p] & TMASK;
+                int64_t r = p;
+                if (t == T_DEL) r = reach_del(c, h, p); else if (t == T_INS) r = reach_ins(c, h, p);
+                if (r < reach) reach = r;
             }
-            reach = j < 0 ? 0 : j;                     // last cell read
-        } else if (e.type == 3) {
-            // the copies on the two haplotypes carry the same bases before justification: follow one of them
-            const int h = (e.hap & 1) ? 0 : 1;
-            const uint32_t idx = ins_find(c.hap[h], p);
-            const uint32_t n = c.hap[h].ins_len[idx];
-            const uint8_t *P = c.hap[h].ins_bases + c.hap[h].ins_off[idx];
-            // rotating left by one makes the cell's base the new first base: after r rotations the last
-            // inserted base is P[n-1-r] while r < n, then ref[p-1-(r-n)] & 3 (bases rotated in earlier)
-            int64_t j = p - 1; int64_t r = 0;
-            for (; j >= 0; --j, ++r) {
-                const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
-                const uint32_t last = r < (int64_t)n ? (uint32_t)P[n - 1 - r] : (uint32_t)(c.ref[p - 1 - (r - n)] & 3);
-                if (!(mutated || last == (uint32_t)(c.ref[j] & 3))) break;
-            }
-            reach = j < 0 ? 0 : j;
-        } else if (p > 0) {
-            // substitution: no scan; it only matters as a neighbour (prev_del) of adjacent events
-            reach = p;
         }
     }
     lo[k] = (int32_t)reach;
@@ -490,6 +498,13 @@ __global__ void k_jrun(const Event *__restrict__ ev, uint32_t n_cand, ContigDev 
         for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
         last = right;
     }
+}
+
+// mutation-input files: the host resolved the file's entries into final cell values (dw_mutin.cpp); scatter them
+__global__ void k_apply_patches(const int32_t *__restrict__ pos, const uint16_t *__restrict__ cells, uint32_t n, uint8_t *h0, uint8_t *h1)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { h0[pos[k]] = (uint8_t)(cells[k] & 0xff); h1[pos[k]] = (uint8_t)(cells[k] >> 8); }
 }
 
 // mutated cells for the host's mutations.txt / .vcf writer
@@ -1242,7 +1257,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
 // ------------------------------------------------------------------------------------------------
 // host-side launchers (declared in dw_launch.hpp)
 // ------------------------------------------------------------------------------------------------
-static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+[[maybe_unused]] static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 #if DW_HAS(0)
 
@@ -1288,6 +1303,10 @@ void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c, in
     hipLaunchKernelGGL(k_sufmin, dim3(1), dim3(1024), 0, st, lo, n, sufmin);
     hipLaunchKernelGGL(k_jbound, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
     hipLaunchKernelGGL(k_jrun, dim3(cdiv(n, 64)), dim3(64), 0, st, ev, n, c, bound);
+}
+void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
+{
+    if (n) hipLaunchKernelGGL(k_apply_patches, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, cells, n, h0, h1);
 }
 void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count)
 {

@@ -47,7 +47,8 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -o INT        FASTQ output 0: bfast and bwa, 1: bwa only, 2: bfast only [%d]\n", o->reads_output_type);
     fprintf(stderr, "         -a            assume each contig is an amplicon\n         -h            print this message\n\n");
     fprintf(stderr, "         -f STRING     the flow order for Ion Torrent data\n");
-    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -B, -m, -b, -v, -x\n\n");
+    fprintf(stderr, "         -m FILE       the mutations txt file to re-create\n         -b FILE       the bed-like file set of candidate mutations\n         -v FILE       the vcf file set of candidate mutations (use pl tag for strand)\n");
+    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -B, -x\n\n");
     return 1;
 }
 
@@ -138,7 +139,7 @@ struct GzOut {
 int main(int argc, char **argv)
 {
     dwgsim_hip_params_t o; dwgsim_hip_params_default(&o);
-    std::string prefix_s, fixedq_s, flow_s;
+    std::string prefix_s, fixedq_s, flow_s, muts_fn; int muts_type = -1, muts_flags = 0;
     int c, device = 0;
     if (const char *d = getenv("DWGSIM_HIP_DEVICE")) device = atoi(d);
     while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
@@ -172,12 +173,16 @@ int main(int argc, char **argv)
         case 'o': o.reads_output_type = atoi(optarg); break;
         case 'a': o.amplicons = 1; break;
         case 'f': flow_s = optarg; o.flow_order = flow_s.c_str(); break;
-        case 'B': case 'm': case 'b': case 'v': case 'x':
+        case 'm': muts_fn = optarg; muts_type = 1; muts_flags |= 1; break;
+        case 'b': muts_fn = optarg; muts_type = 0; muts_flags |= 2; break;
+        case 'v': muts_fn = optarg; muts_type = 2; muts_flags |= 4; break;
+        case 'B': case 'x':
             fprintf(stderr, "dwgsim-hip: option -%c is not on the accelerated path (see DESIGN.md); use the reference dwgsim\n", c); return 1;
         default: fprintf(stderr, "Unrecognized option: -%c\n", c); return usage(&o);
         }
     }
     if (argc - optind < 2) return usage(&o);
+    if (muts_flags != 0 && muts_flags != 1 && muts_flags != 2 && muts_flags != 4) { fprintf(stderr, "Error: -m/-b/-v cannot be used together\n"); return usage(&o); }
     if (o.read_prefix) fprintf(stderr, "Warning: remember to use the -P option with dwgsim_eval\n");
     if (o.seed == -1) o.seed = (int32_t)(time(0) & 0x7fffffff);
     if (o.seed < 0) o.seed &= 0x7fffffff;
@@ -212,6 +217,11 @@ int main(int argc, char **argv)
     int err = 0;
     dwgsim_hip_ctx_t *ctx = dwgsim_hip_create(&o, device, &err);
     if (!ctx) { fprintf(stderr, "dwgsim-hip: cannot create a GPU context (error %d)\n", err); return 1; }
+    if (muts_type >= 0) {     // dwgsim.c:494-497
+        std::vector<const char *> nm; std::vector<int64_t> ln;
+        for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
+        if (dwgsim_hip_set_mutation_input(ctx, muts_type, muts_fn.c_str(), nm.data(), ln.data(), (int)nm.size()) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx)); dwgsim_hip_destroy(ctx); return 1; }
+    }
     const uint64_t BATCH = 1u << 22;
     unsigned nthreads = std::thread::hardware_concurrency(); if (nthreads == 0) nthreads = 4;
     if (const char *e = getenv("DWGSIM_HIP_THREADS")) nthreads = (unsigned)atoi(e);

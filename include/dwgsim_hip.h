@@ -110,6 +110,12 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *ctx, const char *name, const uint8_t
                           uint32_t contig_index);
 int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *ctx, int contig);
 
+/* Replaces muts_input_init() (src/mut_input.c:47-67, called at dwgsim.c:494-497): read a mutation file that then drives
+ * mutate_contig instead of the random walk (mut.c:644-745).  type: 0 = bed (-b), 1 = txt (-m), 2 = vcf (-v).
+ * names/lens = every contig of the FASTA in file order (the reference's contigs_add table, dwgsim.c:474-476). */
+int dwgsim_hip_set_mutation_input(dwgsim_hip_ctx_t *ctx, int type, const char *path, const char *const *names,
+                                  const int64_t *lens, int n_contigs);
+
 /* Replaces mut_diref() random branch + mut_left_justify() (mut.c:591-643, :481-589): builds the
  * two mutated haplotypes of the contig in HBM. */
 int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *ctx, int contig);

@@ -28,8 +28,12 @@ def first_diff(a: bytes, b: bytes):
     return f"length differs: got {len(a)} want {len(b)}"
 
 
+IN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs")
+
+
 def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22):
     """Returns the JobResult; raises AssertionError with a readable diff on any mismatch."""
+    flags = flags.replace("{IN}", IN_DIR)
     with tempfile.TemporaryDirectory() as t:
         want = run_oracle(oracle_bin, fasta, flags, t)
     params = api.parse_flags(flags, lib)
@@ -75,4 +79,12 @@ CASES = [
     ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW} -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
     ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 100 -2 0 -e 0.2 -o 1"),
     ("odd.fa", f"-z 6 -N 3000 -c 2 -f {FLOW} -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2"),
+    # mutation-input files: -m txt, -v vcf, -b bed
+    ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_generated.txt"),
+    ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_edge.txt"),
+    ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_edge.txt -H"),
+    ("tiny.fa", "-z 5 -N 3000 -v {IN}/muts_generated.vcf"),
+    ("tiny.fa", "-z 5 -N 3000 -v {IN}/muts_edge.vcf"),
+    ("tiny.fa", "-z 5 -N 3000 -b {IN}/muts_edge.bed"),
+    ("tiny.fa", "-z 5 -N 3000 -b {IN}/muts_edge.bed -H -o 1"),
 ]
