@@ -253,6 +253,7 @@ typedef struct {
     char *fixed_quality; double quality_std;
     char *read_prefix; int reads_output_type, output_type, amplicons;
     /* oracle-only switches */
+    char *fn_regions;               /* -x */
     char *fn_muts; int muts_type;   /* -m (1, txt) / -b (0, bed) / -v (2, vcf): mut_input.h:29-33 */
     int rng_mode, use_libm_log, null_fastq, verbose;
     int64_t emit_first, emit_count;   /* --emit-range first:count (mode B only): emit only these read indices of every contig */
@@ -928,8 +929,7 @@ static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
         case 'm': free(o->fn_muts); o->fn_muts = strdup(optarg); o->muts_type = 1; muts_flags |= 1; break;
         case 'b': free(o->fn_muts); o->fn_muts = strdup(optarg); o->muts_type = 0; muts_flags |= 2; break;
         case 'v': free(o->fn_muts); o->fn_muts = strdup(optarg); o->muts_type = 2; muts_flags |= 4; break;
-        case 'x':
-            fprintf(stderr, "oracle: option -%c (regions) is outside the oracle's scope\n", c); exit(3);
+        case 'x': free(o->fn_regions); o->fn_regions = strdup(optarg); break;
         case 'P': free(o->read_prefix); o->read_prefix = strdup(optarg); break;
         case 'q': free(o->fixed_quality); o->fixed_quality = strdup(optarg); break;
         case 'Q': o->quality_std = atof(optarg); break;
@@ -975,6 +975,7 @@ static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
         o->e[1].by = (o->e[1].end - o->e[1].start) / o->length[1];
     }
     CHECK(o->output_type, 0, 2, "-M");
+    if (o->amplicons == 1 && o->fn_regions) { fprintf(stderr, "Error: cannot use a regions BED file (-x) when simulating amplicons (-a)\n"); return 0; }
     return 1;
 }
 
@@ -1076,6 +1077,41 @@ static void to_colors(uint8_t *seq, int len) /* dwgsim.c:845-858, __gf_add dwgsi
     for (int i = 0; i < len; ++i) { int c2 = seq[i]; seq[i] = (uint8_t)((c1 >= 4 || c2 >= 4) ? 4 : (c1 ^ c2)); c1 = c2; }
 }
 
+/* regions_bed.c:38-125 regions_bed_init(): sorted BED, overlapping / touching intervals of a contig are merged */
+typedef struct { uint32_t *contig, *start, *end; int n; } regions_t;
+static void parse_regions(FILE *fp, const ctab_t *c, regions_t *r)
+{
+    char name[1024]; uint32_t start, end; int i = 0, b; int32_t prev_contig = -1, prev_start = -1, prev_end = -1;
+    while (0 < fscanf(fp, "%1023s\t%u\t%u", name, &start, &end)) {
+        while (i < c->n && 0 != strcmp(name, c->name[i])) i++;
+        if (c->n == i) { fprintf(stderr, "Error: contig not found [%s].  Are you sure your BED is coordinate sorted?\n", name); exit(1); }
+        else if (c->len[i] < start) { fprintf(stderr, "Error: start out of range [%s,%u]\n", name, start); exit(1); }
+        else if (c->len[i] < end) { fprintf(stderr, "Error: end out of range [%s,%u]\n", name, end); exit(1); }
+        else if (end < start) { fprintf(stderr, "Error: end < start [%s,%u,%u]\n", name, start, end); exit(1); }
+        else if (prev_contig == i && start < (uint32_t)prev_start) { fprintf(stderr, "Error: the input was not sorted [%s,%u,%u,%u]\n", name, start, end, end - start); exit(1); }
+        if (prev_contig == i && start <= (uint32_t)prev_end && (uint32_t)prev_start <= start) {
+            if ((uint32_t)prev_end < end) { r->end[r->n - 1] = end; prev_end = (int32_t)end; }
+        } else {
+            prev_contig = i; prev_start = (int32_t)start; prev_end = (int32_t)end;
+            r->contig = realloc(r->contig, sizeof(uint32_t) * (size_t)(r->n + 1)); r->start = realloc(r->start, sizeof(uint32_t) * (size_t)(r->n + 1)); r->end = realloc(r->end, sizeof(uint32_t) * (size_t)(r->n + 1));
+            r->contig[r->n] = (uint32_t)i; r->start[r->n] = start; r->end[r->n] = end; r->n++;
+        }
+        while (EOF != (b = fgetc(fp))) if ('\n' == b || '\r' == b) break;
+    }
+}
+static int regions_query(const regions_t *r, uint32_t contig, uint32_t start, uint32_t end) /* regions_bed.c:130-156 */
+{
+    int low = 0, high = r->n - 1;
+    while (low <= high) {
+        int mid = low + (high - low) / 2;
+        if (contig < r->contig[mid] || (contig == r->contig[mid] && start < r->start[mid])) high = mid - 1;
+        else if (r->contig[mid] < contig || (r->contig[mid] == contig && r->end[mid] < end)) low = mid + 1;
+        else if (r->contig[mid] == contig && r->start[mid] <= start && end <= r->end[mid]) return 1;
+        else break;
+    }
+    return 0;
+}
+
 typedef struct { uint64_t n_pairs_total, n_rand_total, n_attempt_fail; } stats_t;
 
 static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
@@ -1088,6 +1124,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
     char name[4096];
     uint64_t tot_len = 0, ctr = 0, rand_ii = 0; int n_ref = 0; int64_t l, n_sim = 0;
     ctab_t ct = { NULL, NULL, 0 }; mutin_t mi; memset(&mi, 0, sizeof mi); mi.type = o->muts_type;
+    regions_t rg = { NULL, NULL, NULL, 0 }; int have_rg = o->fn_regions != NULL;
     int lmax = o->length[0] > o->length[1] ? o->length[0] : o->length[1];
     flowbuf_t tb[2];
     for (int j = 0; j < 2; ++j) flow_alloc(&tb[j], lmax, o->flow_order_len);
@@ -1124,12 +1161,33 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
         if (o->muts_type == 1) parse_txt(fm, &ct, &mi); else if (o->muts_type == 0) parse_bed(fm, &ct, &mi); else parse_vcf(fm, &ct, &mi);
         fclose(fm);
     }
+    if (have_rg) {   /* dwgsim.c:499-506 */
+        FILE *fr = fopen(o->fn_regions, "r");
+        if (!fr) { fprintf(stderr, "[oracle] fail to open file '%s'. Abort!\n", o->fn_regions); return 1; }
+        parse_regions(fr, &ct, &rg); fclose(fr);
+        tot_len = 0;
+        for (int i = 0; i < rg.n; ++i) tot_len += rg.end[i] - rg.start[i];
+    }
     uint32_t contig_i = 0;
     while ((l = fasta_next(fp, &seq, name)) >= 0) {
         int64_t n_pairs = 0;
         n_ref--;
         if (o->output_type != 2) {
-            if (0 == n_ref && o->C < 0) n_pairs = o->N - n_sim;               /* dwgsim.c:535-537 */
+            if (0 == n_ref && o->C < 0) n_pairs = o->N - n_sim;               /* dwgsim.c:535-537 (NB: no region bookkeeping on this path) */
+            else if (have_rg) {                                                  /* :539-581 */
+                int64_t m = 0;
+                for (int i = 0; i < rg.n; ++i) if (contig_i == rg.contig[i]) m += rg.end[i] - rg.start[i];
+                if (0 == m) { contig_i++; continue; }                            /* #0 */
+                l = m;
+                int64_t num_n = 0;
+                for (int i = 0; i < rg.n; ++i) if (contig_i == rg.contig[i])
+                    for (int64_t q = rg.start[i]; q <= (int64_t)rg.end[i]; ++q) {   /* 1-based inclusive in the reference (App. B.10); s[-1] is out of bounds there: counted as non-ACGT */
+                        int ch = q >= 1 ? seq.s[q - 1] : 'N';
+                        if (nt4(ch) >= 4) num_n++;
+                    }
+                if (0.95 < num_n / (double)l) { contig_i++; continue; }           /* #1 */
+            }
+            if (0 == n_ref && o->C < 0) { }
             else if (0 < o->N) {                                                 /* :582-586 */
                 n_pairs = (int64_t)(uint64_t)((long double)l / tot_len * o->N + 0.5);
                 if (o->N - n_sim < n_pairs) n_pairs = o->N - n_sim;
@@ -1170,9 +1228,15 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                             } else d = 0;
                             int64_t range = (int64_t)l - d + 1;
                             pos = (int)(range * rng_u(r, D_PLACE, ii, att, 0, t));
+                            if (have_rg) for (int i = 0; i < rg.n; ++i) if (contig_i == rg.contig[i]) {   /* dwgsim.c:696-707 */
+                                int j = (int)(rg.end[i] - rg.start[i]);
+                                if (pos < j) { pos = (int)rg.start[i] + pos - 1; break; }
+                                else pos -= j;
+                            }
                             t++;
                         } while (pos < 0 || pos >= seq.l || pos + d - 1 >= seq.l
-                                 || (0 < s[1] && 0 == o->is_inner && ((0 < s[0] && d <= s[1]) || (d <= s[0] && 0 < s[1]))));
+                                 || (0 < s[1] && 0 == o->is_inner && ((0 < s[0] && d <= s[1]) || (d <= s[0] && 0 < s[1])))
+                                 || (have_rg && 0 == regions_query(&rg, contig_i, (uint32_t)pos, (uint32_t)(pos + d))));
                     }
                     hap_t *cur = &hap[rng_u(r, D_PAIR, ii, att, 0, 1) < o->mut_freq ? 0 : 1];  /* :716 */
                     switch (o->read_one_strand) {                                               /* :722-727 */
