@@ -39,6 +39,7 @@ class Batch(C.Structure):
 EXPORTS = [
     "dwgsim_hip_params_default", "dwgsim_hip_params_check", "dwgsim_hip_pairs_for_contig", "dwgsim_hip_create",
     "dwgsim_hip_destroy", "dwgsim_hip_last_error", "dwgsim_hip_add_contig", "dwgsim_hip_drop_contig",
+    "dwgsim_hip_set_regions", "dwgsim_hip_contig_region_length", "dwgsim_hip_contig_set_placement_length",
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
 ]
@@ -67,6 +68,10 @@ def load(path: str | None = None):
     lib.dwgsim_hip_last_error.argtypes = [C.c_void_p]
     lib.dwgsim_hip_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_uint32]
     lib.dwgsim_hip_drop_contig.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_set_regions.argtypes = [C.c_void_p, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int, P(C.c_uint64)]
+    lib.dwgsim_hip_contig_region_length.restype = C.c_int64
+    lib.dwgsim_hip_contig_region_length.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
+    lib.dwgsim_hip_contig_set_placement_length.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     lib.dwgsim_hip_set_mutation_input.argtypes = [C.c_void_p, C.c_int, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int]
     lib.dwgsim_hip_mutate_contig.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_mutations_text.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_size_t), P(C.c_void_p), P(C.c_size_t)]
@@ -112,6 +117,7 @@ def parse_flags(flags: str, lib=None) -> Params:
     i = 0
     keep = []
     mut_input = None
+    regions = None
     while i < len(toks):
         t = toks[i]
         def arg():
@@ -146,11 +152,13 @@ def parse_flags(flags: str, lib=None) -> Params:
         elif t == "-Q": p.quality_std = float(arg())
         elif t == "-o": p.reads_output_type = int(arg())
         elif t == "-a": p.amplicons = 1
+        elif t == "-x": regions = arg()
         elif t in ("-m", "-b", "-v"): mut_input = ({"-b": 0, "-m": 1, "-v": 2}[t], arg())
         else:
             raise DwgsimError(f"option {t} is not on the accelerated path")
         i += 1
     p._keep = keep
+    p._regions = regions           # -x path, applied by run_job through dwgsim_hip_set_regions
     p._mut_input = mut_input       # (type, path) of -b / -m / -v, applied by run_job through dwgsim_hip_set_mutation_input
     return p
 
@@ -229,6 +237,22 @@ class Context:
     def drop_contig(self, cid: int):
         self._chk(self.lib.dwgsim_hip_drop_contig(self.h, cid))
 
+    def set_regions(self, path: str, contigs) -> int:
+        n = len(contigs)
+        names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
+        lens = (C.c_int64 * n)(*[int(a) if isinstance(a, int) else len(a) for _, a in contigs])
+        tot = C.c_uint64(0)
+        self._chk(self.lib.dwgsim_hip_set_regions(self.h, path.encode(), names, lens, n, C.byref(tot)))
+        return tot.value
+
+    def region_length(self, contig_index: int, ascii_arr) -> int:
+        import numpy as np
+        arr = np.ascontiguousarray(ascii_arr, dtype=np.uint8)
+        return self.lib.dwgsim_hip_contig_region_length(self.h, contig_index, arr.ctypes.data_as(C.c_void_p), len(arr))
+
+    def set_placement_length(self, cid: int, l: int):
+        self._chk(self.lib.dwgsim_hip_contig_set_placement_length(self.h, cid, l))
+
     def set_mutation_input(self, mtype: int, path: str, contigs):
         """contigs: the FASTA's (name, array-or-length) list in file order."""
         n = len(contigs)
@@ -287,14 +311,25 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
     with Context(params, device, lib) as ctx:
         if getattr(params, "_mut_input", None):
             ctx.set_mutation_input(params._mut_input[0], params._mut_input[1], contigs)
+        have_regions = bool(getattr(params, "_regions", None))
+        if have_regions:
+            tot_len = ctx.set_regions(params._regions, contigs)          # dwgsim.c:499-506
         for ci, (name, arr) in enumerate(contigs):
             n_ref -= 1
             n_pairs = 0
+            l_eff = len(arr)
             if want_reads:
-                n_pairs = pairs_for_contig(params, len(arr), tot_len, n_ref == 0, n_sim, lib)
+                last_takes_rest = n_ref == 0 and params.C < 0               # dwgsim.c:535-537: no region bookkeeping on this path
+                if have_regions and not last_takes_rest:
+                    l_eff = ctx.region_length(ci, arr)                      # dwgsim.c:539-581
+                    if l_eff < 0:
+                        continue                                            # skip #0 / #1
+                n_pairs = pairs_for_contig(params, l_eff, tot_len, n_ref == 0, n_sim, lib)
                 if n_pairs < 0:
                     continue                      # skip rules #2-#5: no mutations either (dwgsim.c:596-623)
             cid = ctx.add_contig(name, arr, ci)
+            if have_regions:
+                ctx.set_placement_length(cid, l_eff)
             ctx.mutate(cid)
             if want_mut:
                 t, v = ctx.mutations_text(cid)

@@ -39,6 +39,8 @@ struct Contig {
     size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
     uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
     uint32_t n_cand = 0, n_events_live = 0;
+    int64_t l_place = 0;                // fragment-placement length (region length with -x)
+    int32_t *d_reg = nullptr; int32_t n_reg = 0;   // -x: [start[0..n), end[0..n)] of this contig
 };
 
 struct DevBuf {                     // grow-only device buffer
@@ -66,6 +68,7 @@ struct dwgsim_hip_ctx {
     DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
+    Regions regions; bool has_regions = false;                           // -x
     DevBuf w_ppos, w_pcells;
     uint64_t *d_counters = nullptr;          // 8 x u64
     uint64_t *h_counters = nullptr;          // pinned mirror
@@ -117,7 +120,7 @@ void free_contig(Contig &k)
 {
     hipFree(k.d_ref);
     for (int h = 0; h < 2; ++h) { hipFree(k.d_cells[h]); hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]); }
-    hipFree(k.d_name_fixed);
+    hipFree(k.d_name_fixed); hipFree(k.d_reg);
     k = Contig();
 }
 
@@ -293,6 +296,17 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *
     for (int h = 0; h < 2; ++h) HIPC(c, hipMemsetAsync(k.d_cells[h], 4, padded, c->stream));
     if (len > 0) launch_pack(c->stream, d_ascii, k.d_ref, k.d_cells[0], k.d_cells[1], len);
     HIPC(c, hipGetLastError());
+    k.l_place = len;
+    if (c->has_regions) {
+        std::vector<int32_t> st, en; int64_t tot = 0;
+        for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == contig_index) { st.push_back((int32_t)c->regions.start[q]); en.push_back((int32_t)c->regions.end[q]); tot += c->regions.end[q] - c->regions.start[q]; }
+        k.n_reg = (int32_t)st.size(); k.l_place = tot;
+        HIPC(c, hipMalloc((void **)&k.d_reg, sizeof(int32_t) * (2 * st.size() + 2)));
+        if (!st.empty()) {
+            HIPC(c, hipMemcpy(k.d_reg, st.data(), sizeof(int32_t) * st.size(), hipMemcpyHostToDevice));
+            HIPC(c, hipMemcpy(k.d_reg + st.size(), en.data(), sizeof(int32_t) * en.size(), hipMemcpyHostToDevice));
+        }
+    }
     std::string nf = c->read_prefix.empty() ? k.name : c->read_prefix + "_" + k.name;
     k.name_fixed_len = (int32_t)nf.size();
     std::string nbuf = "@" + nf; nbuf.resize(nbuf.size() < 256 ? 272 : nbuf.size() + 16, '\0');
@@ -316,6 +330,44 @@ static Contig *get_contig(dwgsim_hip_ctx_t *c, int contig)
 {
     if (!c || contig < 0 || (size_t)contig >= c->contigs.size() || !c->contigs[(size_t)contig].alive) { if (c) c->err = "unknown contig handle"; return nullptr; }
     return &c->contigs[(size_t)contig];
+}
+
+int dwgsim_hip_set_regions(dwgsim_hip_ctx_t *c, const char *path, const char *const *names, const int64_t *lens, int n_contigs, uint64_t *total_len)
+{
+    if (!c || !path || n_contigs < 0 || (n_contigs && (!names || !lens))) { if (c) c->err = "bad regions arguments"; return DWGSIM_HIP_ERR_ARG; }
+    if (c->prm.amplicons) { c->err = "Error: cannot use a regions BED file (-x) when simulating amplicons (-a)\n"; return DWGSIM_HIP_ERR_ARG; }
+    std::vector<ContigName> tab;
+    for (int i = 0; i < n_contigs; ++i) tab.push_back(ContigName{names[i], lens[i]});
+    std::string err;
+    if (!parse_regions(path, tab, c->regions, err)) { c->err = err; c->has_regions = false; return DWGSIM_HIP_ERR_ARG; }
+    c->has_regions = true;
+    uint64_t tot = 0;
+    for (size_t q = 0; q < c->regions.start.size(); ++q) tot += c->regions.end[q] - c->regions.start[q];
+    if (total_len) *total_len = tot;
+    return DWGSIM_HIP_OK;
+}
+
+int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *c, uint32_t contig_index, const uint8_t *ascii, int64_t len)
+{
+    if (!c || !c->has_regions) return len;
+    int64_t m = 0, num_n = 0;
+    for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == contig_index) {
+        m += c->regions.end[q] - c->regions.start[q];
+        // the reference walks start..end INCLUSIVE with 1-based indexing (dwgsim.c:558-559); its read of
+        // s[-1] for start == 0 is out of bounds there and is counted as non-ACGT here
+        for (int64_t p = c->regions.start[q]; p <= (int64_t)c->regions.end[q]; ++p) { const int ch = (p >= 1 && p - 1 < len) ? ascii[p - 1] : 'N'; if (nt4(ch) >= 4) ++num_n; }
+    }
+    if (m == 0) return -10;
+    if (0.95 < num_n / (double)m) return -11;
+    return m;
+}
+
+int dwgsim_hip_contig_set_placement_length(dwgsim_hip_ctx_t *c, int contig, int64_t l)
+{
+    Contig *kp = (c && contig >= 0 && (size_t)contig < c->contigs.size() && c->contigs[(size_t)contig].alive) ? &c->contigs[(size_t)contig] : nullptr;
+    if (!kp || l < 0) { if (c) c->err = "bad placement-length arguments"; return DWGSIM_HIP_ERR_ARG; }
+    kp->l_place = l;
+    return DWGSIM_HIP_OK;
 }
 
 int dwgsim_hip_set_mutation_input(dwgsim_hip_ctx_t *c, int type, const char *path, const char *const *names, const int64_t *lens, int n_contigs)
@@ -578,6 +630,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.p.seed = (uint32_t)p.seed;
     a.c = contig_dev(k);
     a.first_ii = first_ii; a.n_pairs = n_pairs; a.rand_base = rand_base;
+    a.l_place = k.l_place; a.have_regions = c->has_regions ? 1 : 0; a.n_reg = k.n_reg; a.reg_start = k.d_reg; a.reg_end = k.d_reg ? k.d_reg + k.n_reg : nullptr;
     for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.qbase[j] = c->d_qbase[j]; }
     a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
@@ -630,6 +683,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     SimArgs a;
     if (build_sim_args(c, *kp, first_ii, n_pairs, rand_base, a)) return DWGSIM_HIP_ERR_DEVICE;
+    if (c->has_regions && kp->n_reg == 0 && c->prm.rand_read < 1.0) { c->err = "dwgsim-hip: this contig has no target region (-x): the reference's placement loop would not terminate\n"; return DWGSIM_HIP_ERR_ARG; }
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     const dwgsim_hip_params_t &p = c->prm;
     const int fixed_max = kp->name_fixed_len > c->rand_fixed_len ? kp->name_fixed_len : c->rand_fixed_len;
@@ -653,6 +707,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->h_counters[2] & 4) { c->err = "dwgsim-hip: no fragment placement satisfied the target regions (-x) after 2^20 tries (the reference would not terminate)\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (c->h_counters[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];

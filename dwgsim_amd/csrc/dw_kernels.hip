@@ -658,10 +658,10 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t at
     pd.is_rand = !(a.p.rand_read < u_lo(b0));
     if (pd.is_rand) return pd;
     const int s0 = a.p.len[0], s1 = a.p.len[1];
-    const int64_t l = a.c.l;
-    if (a.p.amplicons) { pd.pos = 0; pd.d = (int32_t)l; }
+    const int64_t l = a.l_place, sl = a.c.l;          // placement length (region length with -x) vs contig length
+    if (a.p.amplicons) { pd.pos = 0; pd.d = (int32_t)sl; }
     else {
-        uint32_t t = 0; int32_t pos, d;
+        uint32_t t = 0; int32_t pos, d; bool continue_flag = false;
         do {
             if (s1 > 0) {
                 double v1, v2, rsq; uint32_t r = 0;
@@ -680,11 +680,31 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t at
             } else d = 0;
             const int64_t range = l - d + 1;
             pos = (int32_t)((double)range * rng_slot(key, D_PLACE, ii, att, t));
+            bool inside = true;
+            if (a.have_regions) {                         // dwgsim.c:696-707: region coordinate -> contig coordinate, then regions_bed_query (:712)
+                for (int q = 0; q < a.n_reg; ++q) {
+                    const int32_t jl = a.reg_end[q] - a.reg_start[q];
+                    if (pos < jl) { pos = a.reg_start[q] + pos - 1; break; }
+                    pos -= jl;
+                }
+                inside = false;                           // regions are sorted and disjoint: "some region contains [pos, pos + d)" (regions_bed.c:130-156)
+                int lo = 0, hi = a.n_reg - 1;
+                const uint32_t qs = (uint32_t)pos, qe = (uint32_t)(pos + d);
+                while (lo <= hi) {
+                    const int mid = lo + (hi - lo) / 2;
+                    if (qs < (uint32_t)a.reg_start[mid]) hi = mid - 1;
+                    else if ((uint32_t)a.reg_end[mid] < qe) lo = mid + 1;
+                    else { inside = true; break; }
+                }
+            }
             ++t;
-        } while (pos < 0 || pos >= l || (int64_t)pos + d - 1 >= l
+            if (t > (1u << 20)) { pd.hap = -1; break; }   // the reference would never terminate here; reported as an error by the caller
+            continue_flag = !inside;
+        } while (continue_flag || pos < 0 || pos >= sl || (int64_t)pos + d - 1 >= sl
                  || (s1 > 0 && !a.p.is_inner && ((s0 > 0 && d <= s1) || (d <= s0 && s1 > 0))));
         pd.pos = pos; pd.d = d;
     }
+    if (pd.hap < 0) { pd.hap = 0; pd.pos = 0; pd.d = (int32_t)(s0 + s1 < sl ? s0 + s1 : sl); atomicOr((unsigned long long *)&a.counters[2], 4ull); return pd; }
     pd.hap = u_hi(b0) < a.p.mut_freq ? 0 : 1;
     switch (a.p.read_one_strand) {
     case 0: pd.strand0 = rng_slot(key, D_PAIR, ii, att, 2) < 0.5 ? 1 : 0; break;

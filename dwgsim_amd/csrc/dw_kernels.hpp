@@ -60,6 +60,8 @@ struct SimArgs {
     SimParams p;
     ContigDev c;
     uint64_t first_ii, n_pairs, rand_base;
+    int64_t l_place;               // the `l` that sizes fragment placement: contig length, or the contig's region length with -x (dwgsim.c:552)
+    const int32_t *reg_start, *reg_end; int32_t n_reg, have_regions;   // -x: this contig's merged target regions (regions_bed.c)
     const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
     const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics
     const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"

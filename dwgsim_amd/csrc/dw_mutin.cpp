@@ -193,6 +193,30 @@ bool parse_mutation_input(int type, const char *path, const std::vector<ContigNa
     return ok;
 }
 
+bool parse_regions(const char *path, const std::vector<ContigName> &contigs, Regions &out, std::string &err)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp) { err = fmt("[dwgsim_core] fail to open file '%s'. Abort!\n", path); return false; }
+    out = Regions();
+    ContigCursor cur(contigs);
+    char name[1024]; uint32_t start, end; long prev_contig = -1; uint32_t prev_start = 0, prev_end = 0;
+    bool ok = true;
+    while (ok && 0 < fscanf(fp, "%1023s\t%u\t%u", name, &start, &end)) {
+        bool moved;
+        if (!cur.seek(name, &moved)) { err = fmt("Error: contig not found [%s].  Are you sure your BED is coordinate sorted?\n", name); ok = false; break; }
+        const int64_t len = contigs[cur.i].len; const long ci = (long)cur.i;
+        if (len < (int64_t)start) { err = fmt("Error: start out of range [%s,%u]\n", name, start); ok = false; break; }
+        if (len < (int64_t)end) { err = fmt("Error: end out of range [%s,%u]\n", name, end); ok = false; break; }
+        if (end < start) { err = fmt("Error: end < start [%s,%u,%u]\n", name, start, end); ok = false; break; }
+        if (prev_contig == ci && start < prev_start) { err = fmt("Error: the input was not sorted [%s,%u,%u,%u]\n", name, start, end, end - start); ok = false; break; }
+        if (prev_contig == ci && start <= prev_end && prev_start <= start) { if (prev_end < end) { out.end.back() = end; prev_end = end; } }   // merge
+        else { prev_contig = ci; prev_start = start; prev_end = end; out.contig.push_back((uint32_t)ci); out.start.push_back(start); out.end.push_back(end); }
+        int b; while (EOF != (b = fgetc(fp))) if (b == '\n' || b == '\r') break;     // the rest of the line is ignored
+    }
+    fclose(fp);
+    return ok;
+}
+
 void resolve_mutation_input(const MutInput &in, uint32_t contig, const uint8_t *ascii, int64_t l, uint32_t seed, bool is_hap_mode, ResolvedContig &out)
 {
     std::map<int32_t, uint16_t> cell;                         // touched cells, both haplotypes

@@ -44,4 +44,8 @@ struct ResolvedContig {
 void resolve_mutation_input(const MutInput &in, uint32_t contig, const uint8_t *ascii, int64_t l, uint32_t seed, bool is_hap_mode,
                             ResolvedContig &out);
 
+// ---- target regions (-x): regions_bed_init(), src/regions_bed.c:38-125 ----
+struct Regions { std::vector<uint32_t> contig, start, end; };      // sorted, overlapping / touching intervals merged
+bool parse_regions(const char *path, const std::vector<ContigName> &contigs, Regions &out, std::string &err);
+
 } // namespace dw

@@ -48,7 +48,8 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -a            assume each contig is an amplicon\n         -h            print this message\n\n");
     fprintf(stderr, "         -f STRING     the flow order for Ion Torrent data\n");
     fprintf(stderr, "         -m FILE       the mutations txt file to re-create\n         -b FILE       the bed-like file set of candidate mutations\n         -v FILE       the vcf file set of candidate mutations (use pl tag for strand)\n");
-    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -B, -x\n\n");
+    fprintf(stderr, "         -x FILE       the bed of regions to cover\n");
+    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -B\n\n");
     return 1;
 }
 
@@ -139,7 +140,7 @@ struct GzOut {
 int main(int argc, char **argv)
 {
     dwgsim_hip_params_t o; dwgsim_hip_params_default(&o);
-    std::string prefix_s, fixedq_s, flow_s, muts_fn; int muts_type = -1, muts_flags = 0;
+    std::string prefix_s, fixedq_s, flow_s, regions_fn, muts_fn; int muts_type = -1, muts_flags = 0;
     int c, device = 0;
     if (const char *d = getenv("DWGSIM_HIP_DEVICE")) device = atoi(d);
     while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
@@ -176,7 +177,8 @@ int main(int argc, char **argv)
         case 'm': muts_fn = optarg; muts_type = 1; muts_flags |= 1; break;
         case 'b': muts_fn = optarg; muts_type = 0; muts_flags |= 2; break;
         case 'v': muts_fn = optarg; muts_type = 2; muts_flags |= 4; break;
-        case 'B': case 'x':
+        case 'x': regions_fn = optarg; break;
+        case 'B':
             fprintf(stderr, "dwgsim-hip: option -%c is not on the accelerated path (see DESIGN.md); use the reference dwgsim\n", c); return 1;
         default: fprintf(stderr, "Unrecognized option: -%c\n", c); return usage(&o);
         }
@@ -217,6 +219,11 @@ int main(int argc, char **argv)
     int err = 0;
     dwgsim_hip_ctx_t *ctx = dwgsim_hip_create(&o, device, &err);
     if (!ctx) { fprintf(stderr, "dwgsim-hip: cannot create a GPU context (error %d)\n", err); return 1; }
+    if (!regions_fn.empty()) {   // dwgsim.c:499-506
+        std::vector<const char *> nm; std::vector<int64_t> ln;
+        for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
+        if (dwgsim_hip_set_regions(ctx, regions_fn.c_str(), nm.data(), ln.data(), (int)nm.size(), &tot_len) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx)); dwgsim_hip_destroy(ctx); return 1; }
+    }
     if (muts_type >= 0) {     // dwgsim.c:494-497
         std::vector<const char *> nm; std::vector<int64_t> ln;
         for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
@@ -230,9 +237,15 @@ int main(int argc, char **argv)
     for (size_t ci = 0; ci < fa.seqs.size() && rc == 0; ++ci) {
         const int64_t l = (int64_t)fa.seqs[ci].size(); const char *name = fa.names[ci].c_str();
         --n_ref;
-        int64_t n_pairs = 0;
+        int64_t n_pairs = 0, l_eff = l;
         if (want_reads) {
-            n_pairs = dwgsim_hip_pairs_for_contig(&o, l, tot_len, n_ref == 0, n_sim);
+            const bool last_takes_rest = n_ref == 0 && o.C < 0;     // dwgsim.c:535-537
+            if (!regions_fn.empty() && !last_takes_rest) {
+                l_eff = dwgsim_hip_contig_region_length(ctx, (uint32_t)ci, fa.seqs[ci].data(), l);
+                if (l_eff == -10) { fprintf(stderr, "[dwgsim_core] #0 skip sequence '%s' as it is not in the targeted region\n", name); continue; }
+                if (l_eff == -11) { fprintf(stderr, "[dwgsim_core] #1 skip sequence '%s' as more than 95%% of its targeted bases are non-ACGT\n", name); continue; }
+            }
+            n_pairs = dwgsim_hip_pairs_for_contig(&o, l_eff, tot_len, n_ref == 0, n_sim);
             if (n_pairs < 0) {
                 if (!prev_skip) fprintf(stderr, "\n");
                 prev_skip = 1;
@@ -245,6 +258,7 @@ int main(int argc, char **argv)
             prev_skip = 0;
         }
         const int cid = dwgsim_hip_add_contig(ctx, name, fa.seqs[ci].data(), l, (uint32_t)ci);
+        if (cid >= 0 && !regions_fn.empty()) dwgsim_hip_contig_set_placement_length(ctx, cid, l_eff);
         if (cid < 0 || dwgsim_hip_mutate_contig(ctx, cid) < 0) { fprintf(stderr, "dwgsim-hip: %s\n", dwgsim_hip_last_error(ctx)); rc = 1; break; }
         if (want_mut) {
             const char *t, *v; size_t tl, vl;

@@ -110,6 +110,21 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *ctx, const char *name, const uint8_t
                           uint32_t contig_index);
 int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *ctx, int contig);
 
+/* Replaces regions_bed_init() (src/regions_bed.c:38-125, dwgsim.c:499-506): target regions (-x).  names/lens as for
+ * dwgsim_hip_set_mutation_input.  *total_len receives the summed region length (the reference's tot_len, dwgsim.c:502-505).
+ * Call before add_contig. */
+int dwgsim_hip_set_regions(dwgsim_hip_ctx_t *ctx, const char *path, const char *const *names, const int64_t *lens,
+                           int n_contigs, uint64_t *total_len);
+
+/* dwgsim.c:539-581: the region length of a contig -- the `l` the reference then uses for pairs-per-contig, the skip rules
+ * and fragment placement -- or -10 (skip #0: not in the targeted region) / -11 (skip #1: > 95 % non-ACGT). */
+int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *ctx, uint32_t contig_index, const uint8_t *ascii, int64_t len);
+
+/* The `l` that sizes fragment placement on this contig (dwgsim.c:659-671): defaults to the contig length, or to its region
+ * length once regions are set.  The reference's last contig in -N mode keeps the full length (dwgsim.c:535-537 bypasses the
+ * region bookkeeping): a caller mirroring that passes len here. */
+int dwgsim_hip_contig_set_placement_length(dwgsim_hip_ctx_t *ctx, int contig, int64_t l);
+
 /* Replaces muts_input_init() (src/mut_input.c:47-67, called at dwgsim.c:494-497): read a mutation file that then drives
  * mutate_contig instead of the random walk (mut.c:644-745).  type: 0 = bed (-b), 1 = txt (-m), 2 = vcf (-v).
  * names/lens = every contig of the FASTA in file order (the reference's contigs_add table, dwgsim.c:474-476). */

@@ -87,4 +87,10 @@ CASES = [
     ("tiny.fa", "-z 5 -N 3000 -v {IN}/muts_edge.vcf"),
     ("tiny.fa", "-z 5 -N 3000 -b {IN}/muts_edge.bed"),
     ("tiny.fa", "-z 5 -N 3000 -b {IN}/muts_edge.bed -H -o 1"),
+    # target regions -x
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 3000"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 8"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_b.bed -N 2000 -d 200 -s 10 -1 50 -2 50 -n 5"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 2000 -2 0"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 5 -m {IN}/muts_edge.txt"),
 ]

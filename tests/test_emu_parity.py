@@ -21,6 +21,8 @@ EMU_CASES = [
     ("tiny.fa", "-z 5 -N 600 -v {IN}/muts_edge.vcf"),
     ("tiny.fa", "-z 5 -N 600 -b {IN}/muts_edge.bed"),
     ("tiny.fa", "-z 5 -M 2 -m {IN}/muts_generated.txt"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 700"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_b.bed -C 4 -d 200 -s 10 -1 50 -2 50 -n 5"),
 ]
 
 
