@@ -166,7 +166,8 @@ int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap)
         const size_t F = strlen(p->flow_order);
         bool has[4] = {false, false, false, false};
         for (size_t i = 0; i < F; ++i) { const uint8_t c = nt4((unsigned char)p->flow_order[i]); if (c < 4) has[c] = true; }
-        if (F == 0 || F > 64 || !(has[0] && has[1] && has[2] && has[3])) { if (msg) snprintf(msg, cap, "dwgsim-hip: the flow order (-f) must hold 1..64 flows and contain all of A, C, G, T\n"); return DWGSIM_HIP_ERR_UNSUP; }
+        bool only_acgt = true; for (size_t i = 0; i < F; ++i) if (nt4((unsigned char)p->flow_order[i]) >= 4) only_acgt = false;
+        if (F == 0 || F > 64 || !only_acgt || !(has[0] && has[1] && has[2] && has[3])) { if (msg) snprintf(msg, cap, "dwgsim-hip: the flow order (-f) must hold 1..64 flows and contain all of A, C, G, T\n"); return DWGSIM_HIP_ERR_UNSUP; }
     }
     if (p->seed < 0) { if (msg) snprintf(msg, cap, "dwgsim-hip: the seed must be resolved (>= 0) before the context is created\n"); return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
@@ -644,7 +645,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
         const double emax = p.e_start[0] > p.e_start[1] ? p.e_start[0] : p.e_start[1];
-        a.cap = lmax + 64 + (int)(lmax * 10.0 * emax);
+        a.cap = lmax + 32 + (int)(lmax * 10.0 * emax);     // (3 blocks per CU at -1 400 -e 0.01: 93 LDS words per lane)
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();

@@ -799,18 +799,22 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
 // at base[w * stride]).  Draws: narrow uniforms of domain D_FLOW0 + read end, one sequential slot
 // counter per read end.  The flow mask is per read (the reference's persistent mask is fully
 // rewritten by every read's pass 1).
-// word-cached access to a lane's packed 4-bit array: the flow model reads and appends sequentially, so one
-// LDS access serves eight bases
-struct NibReader {
+// word-cached access to a lane's packed array (BITS = 4: codes 0-5, BITS = 2: bases 0-3): the flow model reads and
+// appends sequentially, so one LDS access serves 8 / 16 bases
+template <int BITS>
+struct PackReader {
+    static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4; static constexpr uint32_t M = (1u << BITS) - 1;
     const uint32_t *base; int stride, cw; uint32_t word;
     DW_DEV void init(const uint32_t *b, int st) { base = b; stride = st; cw = -1; word = 0; }
-    DW_DEV uint32_t get(int i) { const int w = i >> 3; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & 7) * 4)) & 15u; }
+    DW_DEV uint32_t get(int i) { const int w = i >> SH; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & (PER - 1)) * BITS)) & M; }
 };
-struct NibAppender {
+template <int BITS>
+struct PackAppender {
+    static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4;
     uint32_t *base; int stride, n; uint32_t acc;
     DW_DEV void init(uint32_t *b, int st) { base = b; stride = st; n = 0; acc = 0; }
-    DW_DEV void push(uint32_t v) { acc |= v << ((n & 7) * 4); if ((++n & 7) == 0) { base[((n >> 3) - 1) * stride] = acc; acc = 0; } }
-    DW_DEV void flush() { if (n & 7) base[(n >> 3) * stride] = acc; }
+    DW_DEV void push(uint32_t v) { acc |= v << ((n & (PER - 1)) * BITS); if ((++n & (PER - 1)) == 0) { base[((n >> SH) - 1) * stride] = acc; acc = 0; } }
+    DW_DEV void flush() { if (n & (PER - 1)) base[(n >> SH) * stride] = acc; }
 };
 struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
     uint32_t seed, contig, dom, att, slot, w0, w1, w2, w3; uint64_t ii;
@@ -823,18 +827,19 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
     }
     DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr) ++n; return n; }   // while (drand48() < e) n_err++
 };
-// Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  *result tells which
-// buffer holds the final read (bufA after pass 2, or bufB when the reverse-strand read was turned back).
+// Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
+// bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
+// (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: 8 (base, count) runs, two per word.
 DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
-                       int len, int strand, int cap, int32_t *n_err_out, uint32_t **result)
+                       int len, int strand, int cap, int32_t *n_err_out)
 {
     // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
-    NibReader rd, la; rd.init(bufA, stride); la.init(bufA, stride);
-    auto in = [&](NibReader &r, int t) -> uint32_t { const uint32_t v = r.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
+    PackReader<4> rd, la; rd.init(bufA, stride); la.init(bufA, stride);
+    auto in = [&](PackReader<4> &r, int t) -> uint32_t { const uint32_t v = r.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
     uint64_t mask = 0; int flow_i = 0, total = 0;
     { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
     // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
-    NibAppender o1; o1.init(bufB, stride);
+    PackAppender<2> o1; o1.init(bufB, stride);
     int t = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
     for (;;) {
         uint32_t c; bool from_pend = false;
@@ -871,43 +876,35 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
     o1.flush();
     const int n1 = o1.n;
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
-    // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order ----
-    NibReader r2; r2.init(bufB, stride);
-    NibAppender o2; o2.init(bufA, stride);
+    // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order. ----
+    PackReader<2> r2; r2.init(bufB, stride);
+    PackAppender<4> o2; o2.init(bufA, stride);
+    auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
+    auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
     int t2 = 0, sp = 0;
     for (;;) {
         uint32_t x;
-        if (sp > 0) x = stk[(sp - 1) * stride] >> 16; else if (t2 < n1) x = r2.get(t2); else break;
+        if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else break;
         if (o2.n >= cap) return -1;
-        int m = 0;
-        while (x != flow[flow_i]) {
+        while (x != flow[flow_i]) {                 // empty flows in front of the examined base: each may insert
             const int n_err = rg.geometric(thr);
             if (!((mask >> flow_i) & 1) && n_err > 0) {
-                if (sp >= 16) return -1;
-                stk[sp * stride] = ((uint32_t)flow[flow_i] << 16) | (uint32_t)n_err; ++sp;
-                total += n_err; ++m;
+                if (sp >= 8 || n_err >= (1 << 14)) return -1;
+                stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp;
+                total += n_err;
             }
             flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
         }
-        if (m == 0 && sp == 0) { o2.push(x); ++t2; }
-        else {      // take one base from the top run (the examined base itself when nothing was inserted)
-            const uint32_t top = stk[(sp - 1) * stride];
-            o2.push(top >> 16);
-            if ((top & 0xffffu) <= 1) --sp; else stk[(sp - 1) * stride] = top - 1;
+        if (sp == 0) { o2.push(x); ++t2; }          // nothing in front of it: the base itself becomes final
+        else {                                      // the first base of the top run (the examined base stays behind it)
+            const uint32_t top = stk_get(sp - 1);
+            o2.push(top >> 14);
+            if ((top & 0x3fffu) <= 1) --sp; else stk_set(sp - 1, top - 1);
         }
     }
     o2.flush();
-    const int n2 = o2.n;
-    *result = bufA;
-    if (strand) {                                               // dwgsim.c:408-414: turn the read back (into bufB, which is free now)
-        NibReader rr; rr.init(bufA, stride);
-        NibAppender o3; o3.init(bufB, stride);
-        for (int i = n2 - 1; i >= 0; --i) o3.push(rr.get(i));
-        o3.flush();
-        *result = bufB;
-    }
     *n_err_out += total;
-    return n2;
+    return o2.n;
 }
 
 // ---- FASTQ text assembly ----
@@ -1096,14 +1093,15 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     // substituted base is drawn afterwards, only for the (few) marked bases
     int32_t n_err = 0;
     int s_out = s;                              // read length after errors (changes only for Ion Torrent)
+    bool flow_reversed = false;
     const int nw = (s + 7) >> 3;
     if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        uint32_t *res = lds;
-        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)2 * a.lds_words * nthr,
-                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err, &res);
+        const int wb = (a.cap + 15) >> 4;          // words of the 2-bit pass-1 buffer
+        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)(a.lds_words + wb) * nthr,
+                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
-        lds = res;                                  // the sequence line is read from whichever buffer holds the final read
+        flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
     }
     if (valid && (DT == 0 || is_rand)) {
         const uint64_t *thr = j ? a.e_thr[1] : a.e_thr[0];
@@ -1224,8 +1222,13 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
         if (OUT & 2) o.b.put('\n');
         PH_MARK(4); // header line
         // bases
+        PackReader<4> rev; rev.init(lds, nthr);
         for (int w = 0; w * 8 < s_out; ++w) {
-            const uint32_t word = lds[w * nthr];
+            uint32_t word;
+            if (DT == 2 && flow_reversed) {         // base i of the record = base s_out-1-i of the flow-model orientation
+                word = 0;
+                for (int b = 0; b < 8; ++b) { const int i = w * 8 + b; if (i < s_out) word |= rev.get(s_out - 1 - i) << (4 * b); }
+            } else word = lds[w * nthr];
             const int rem = s_out - w * 8;
             if (rem >= 8) {
                 o.put4(base_char(word & 15) | base_char((word >> 4) & 15) << 8 | base_char((word >> 8) & 15) << 16 | base_char((word >> 12) & 15) << 24);
@@ -1352,7 +1355,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = PAIRS_PER_BLOCK * (pe ? 2 : 1);
-    const size_t lds = (size_t)(ion ? 2 * a.lds_words + 16 : a.lds_words) * nthr * 4;   // Ion Torrent: two buffers + the pass-2 stack
+    const size_t lds = (size_t)(ion ? a.lds_words + ((a.cap + 15) >> 4) + 4 : a.lds_words) * nthr * 4;   // Ion Torrent: 4-bit buffer + 2-bit pass-1 buffer + the pass-2 stack (8 runs)
     if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
     else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
 }
