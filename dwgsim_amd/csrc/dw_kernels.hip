@@ -1068,25 +1068,41 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     const int s = sel_len(a, j);
     uint32_t *lds = dyn_lds + tid;              // this lane's packed bases: word w at lds[w * nthr]
 
-    const uint32_t meta = valid ? a.meta[pair] : 0u;
-    const uint32_t att = meta & 0x7fffffffu;
-    const bool is_rand = (meta >> 31) != 0;
-
-    // running random-read index (dwgsim.c:1042,1096): block prefix from k_place/k_scan + rank inside the block
-    uint32_t rtot;
-    const uint32_t rrank = block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &rtot);
-    const uint64_t rand_ii = a.rand_base + a.block_rand[t] + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
-
-    PH_MARK(0);     // ticket, meta, random-read rank
-    // ---- bases of this read end ----
+    PH_MARK(0);     // ticket, fixed strings
+    // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
+    // read end, N filter; the two lanes of a pair exchange their verdicts and retry together with attempt + 1 ----
     PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
     ReadRes rr{0, 0, 0, 0};
-    if (valid && !is_rand) {
-        pd = draw_pair(a, key, ii, att);
-        int64_t start; int step;
-        read_geom(a, pd, j, &start, &step);
-        rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
+    uint32_t att = 0; bool is_rand = false, done = !valid;
+    while (__ballot(!done)) {
+        bool ok = true;
+        if (!done) {
+            pd = draw_pair(a, key, ii, att);
+            if (pd.is_rand) { is_rand = true; done = true; rr = ReadRes{0, 0, 0, 0}; }
+            else if (s > 0) {
+                int64_t start; int step;
+                read_geom(a, pd, j, &start, &step);
+                rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
+                ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
+            }
+        }
+        if (LPP == 2) { const int other = __shfl_xor((int)ok, 1); ok = ok && (other != 0); }   // every lane shuffles
+        if (!done) {
+            if (ok) done = true;
+            else if (++att > (uint32_t)MAX_ATTEMPTS) { atomicOr((unsigned long long *)&a.counters[2], 1ull); done = true; }
+        }
     }
+    { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
+    // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
+    uint32_t rtot;
+    const uint32_t rrank = block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &rtot);
+    if (wave == 0) {
+        const uint64_t g = lookback_excl(a.status[2], t, rtot, 0);
+        if (lane == 0) { s_base[0] = g; if ((uint64_t)t + 1 == (a.n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK) a.counters[3] = g + rtot; }
+    }
+    __syncthreads();
+    const uint64_t rand_ii = a.rand_base + s_base[0] + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+    __syncthreads();                                   // s_base is reused by the byte look-backs below
     PH_MARK(1);     // placement + base extraction
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
