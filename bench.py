@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ecoli")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="analysis only: torch.distributed backend (gloo lets several ranks share one GPU on a 1-GPU box)")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     args = ap.parse_args()
 
@@ -62,11 +63,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the hot path)")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
+    coll_device = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
 
     lib = api.load()
     flags = args.flags or FLAGS
@@ -76,7 +82,7 @@ def main():
     tot_len = len(arr)
     n_pairs = api.pairs_for_contig(params, tot_len, tot_len, False, 0, lib)   # pairs of the 30x job = per-GPU share
 
-    ctx = api.Context(params, local_rank, lib)
+    ctx = api.Context(params, dev, lib)
     cid = ctx.add_contig(name, arr, 0)
     first_ii = rank * n_pairs
 
@@ -93,7 +99,7 @@ def main():
         ctx.mutate(cid)                                        # mutation walk on the GPU
         t1 = time.perf_counter()
         # one integer per rank (no data-path collective): random reads in the ranges of lower ranks
-        rand_base = shard.exchange_rand_base(ctx, cid, first_ii, n_pairs, rank, world, dist, device="cuda")
+        rand_base = shard.exchange_rand_base(ctx, cid, first_ii, n_pairs, rank, world, dist, device=coll_device)
         t2 = time.perf_counter()
         b = ctx.simulate(cid, first_ii, n_pairs, rand_base, 0)
         if record:
@@ -110,7 +116,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

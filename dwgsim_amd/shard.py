@@ -20,9 +20,9 @@ def exchange_rand_base(ctx, cid: int, first: int, n: int, rank: int, world: int,
         return rand_before_contig
     import torch
     mine = torch.tensor([ctx.count_random(cid, first, n)], dtype=torch.int64, device=device)
-    allc = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allc, mine)
-    return rand_before_contig + int(sum(int(x.item()) for x in allc[:rank]))
+    allc = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allc, mine)          # one int64 per rank; a single host read-back
+    return rand_before_contig + int(allc[:rank].sum().item())
 
 
 def simulate_shard(ctx, cid: int, n_pairs: int, rank: int, world: int, dist, device=None, rand_before_contig: int = 0, slot: int = 0):
