@@ -69,7 +69,7 @@ struct dwgsim_hip_ctx {
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
-    DevBuf w_ppos, w_pcells;
+    DevBuf w_ppos, w_pcells, flow_scratch;
     uint64_t *d_counters = nullptr;          // 8 x u64
     uint64_t *h_counters = nullptr;          // pinned mirror
     uint64_t out_bytes[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -266,7 +266,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_qbase[j]); }
     for (int j = 0; j < 3; ++j) hipFree(c->status[j].p);
-    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
+    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters); hipFree(c->d_flow);
@@ -650,6 +650,13 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
+    a.flow_scratch = nullptr;
+    if (p.data_type == 2) {
+        const size_t nthr = (size_t)PAIRS_PER_BLOCK * (p.length[1] > 0 ? 2 : 1);
+        const size_t words = (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr * (size_t)(nblk ? nblk : 1);
+        if (ensure(c, c->flow_scratch, words * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
+        a.flow_scratch = (uint32_t *)c->flow_scratch.p;
+    }
     return 0;
 }
 

@@ -1066,7 +1066,9 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     const uint64_t ii = a.first_ii + pair;
     const RngKey key{a.p.seed, a.c.contig_index};
     const int s = sel_len(a, j);
-    uint32_t *lds = dyn_lds + tid;              // this lane's packed bases: word w at lds[w * nthr]
+    // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
+    // read buffers live in a global scratch so that LDS does not cap residency; only the 4-word run stack stays in LDS
+    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr) + tid : dyn_lds + tid;
 
     PH_MARK(0);     // ticket, fixed strings
     // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
@@ -1114,7 +1116,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
     if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
         const int wb = (a.cap + 15) >> 4;          // words of the 2-bit pass-1 buffer
-        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)(a.lds_words + wb) * nthr,
+        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
                             nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
         flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
@@ -1371,7 +1373,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = PAIRS_PER_BLOCK * (pe ? 2 : 1);
-    const size_t lds = (size_t)(ion ? a.lds_words + ((a.cap + 15) >> 4) + 4 : a.lds_words) * nthr * 4;   // Ion Torrent: 4-bit buffer + 2-bit pass-1 buffer + the pass-2 stack (8 runs)
+    const size_t lds = (size_t)(ion ? 4 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack (8 runs); its read buffers are in a.flow_scratch
     if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
     else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
 }

@@ -74,6 +74,7 @@ struct SimArgs {
     int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
     int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors
     int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
+    uint32_t *flow_scratch;        // Ion Torrent: per-block read buffers in HBM, (lds_words + ceil(cap/16)) words per lane, word w of lane t at [w * nthr + t]
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes
 };
 
