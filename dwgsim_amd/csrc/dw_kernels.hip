@@ -30,6 +30,9 @@
 #define DW_PART -1
 #endif
 #define DW_HAS(part) (DW_PART == -1 || DW_PART == (part))
+#ifndef DW_ION_WAVES
+#define DW_ION_WAVES 1       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants
+#endif
 
 namespace dw {
 
@@ -1043,7 +1046,7 @@ DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull
 
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 template <int LPP, int OUT, int DT>
-__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES : 1)) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm[17];
