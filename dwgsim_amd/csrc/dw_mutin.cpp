@@ -5,8 +5,6 @@
 #include <string.h>
 #include <ctype.h>
 #include <map>
-#include <fstream>
-#include <sstream>
 #include <algorithm>
 
 namespace dw {
@@ -69,13 +67,6 @@ int mutation_type(std::string s)              // dwgsim.c:183-200 get_muttype
     if (s == "deletion" || s == "delet" || s == "del" || s == "d") return T_DEL;
     return -1;
 }
-
-// whitespace-delimited token reader with fscanf("%s") semantics
-struct Tokens {
-    FILE *fp;
-    bool word(std::string &w, size_t maxlen = 1023) { char buf[1100]; char f[16]; snprintf(f, sizeof f, "%%%zus", maxlen); if (fscanf(fp, f, buf) != 1) return false; w = buf; return true; }
-    bool u32(uint32_t &v) { return fscanf(fp, "%u", &v) == 1; }
-};
 
 bool read_txt(FILE *fp, const std::vector<ContigName> &contigs, MutInput &out, std::string &err)     // mut_txt.c:40-133
 {

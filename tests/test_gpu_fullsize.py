@@ -40,6 +40,24 @@ def test_ecoli_full_job_bit_exact(lib, oracle_bin, tmp_path):
     assert res.mutations_vcf == open(str(tmp_path / "o.mutations.vcf"), "rb").read()
 
 
+def test_iontorrent_config5_shape_bit_exact(lib, oracle_bin, tmp_path):
+    """BASELINE configs[4] shape on one contig: -c 2 -f <flow> -1 400 -2 0 -e 0.01 (uniform error, as the reference requires),
+    4.6 Mb, 6x (73 289 reads): FASTQ (variable read lengths) and mutation files bit-for-bit against the oracle."""
+    flow = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
+    flags = f"-z 17 -c 2 -f {flow} -1 400 -2 0 -C 6 -e 0.01 -o 1"
+    fa = str(tmp_path / "ecoli.fa")
+    contigs = synth.workload_contigs("ecoli")
+    synth.write_fasta(fa, contigs)
+    _oracle(oracle_bin, flags, fa, str(tmp_path / "o"))
+    res = api.run_job(api.parse_flags(flags, lib), contigs, lib=lib)
+    want = open(str(tmp_path / "o.bwa.read1.fastq"), "rb").read()
+    assert res.n_pairs == 73289 and len(res.streams[0]) == len(want)
+    assert hashlib.sha256(res.streams[0]).hexdigest() == hashlib.sha256(want).hexdigest()
+    lens = np.diff(np.flatnonzero(np.frombuffer(res.streams[0], dtype=np.uint8) == 10))[0::4]   # sequence-line lengths (+1)
+    assert lens.min() < 401 and lens.max() > 402       # flow errors really change read lengths
+    assert res.mutations_vcf == open(str(tmp_path / "o.mutations.vcf"), "rb").read()
+
+
 def test_chr20_sized_windows_and_invariants(lib, oracle_bin, tmp_path):
     flags = "-z 20 -1 150 -2 150 -C 30 -o 1 -r 0.001 -R 0.1"
     fa = str(tmp_path / "chr20.fa")
