@@ -144,7 +144,7 @@ def main():
                        "parallelism": f"read-index shards x{world}"},
             "breakdown_ms": {"walk": round(stats["walk_ms"] / K, 4), "rand_count_exchange": round(stats["count_ms"] / K, 4),
                              "batch_kernels": round(stats["kernel_ms"] / K, 4), "simulate_kernel": round(sim_ms, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_simulate<2,1,0>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": f"k_simulate<{2 if params.length[1] > 0 else 1},{[3, 1, 2][params.reads_output_type]},{params.data_type}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_PAIR * n_pairs),
                          "note": "863 algorithmic B/pair x pairs per launch / HIP-event time of the launch; the kernel is Philox+fp64 ALU bound, not HBM bound (DESIGN.md)"},

@@ -64,7 +64,7 @@ struct dwgsim_hip_ctx {
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
     // simulate() working set
-    DevBuf meta, block_rand, status[3], out[2][3], scratch_mask, scratch_cnt;
+    DevBuf meta, block_rand, status[4], out[2][3], scratch_mask, scratch_cnt;
     DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
@@ -159,7 +159,6 @@ int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap)
     CHK(p->use_base_error, 0, 1, "-B"); CHK(p->is_hap, 0, 1, "-H");
     CHK(p->quality_std, 0, INT32_MAX, "-Q"); CHK(p->reads_output_type, 0, 2, "-o"); CHK(p->output_type, 0, 2, "-M"); CHK(p->amplicons, 0, 1, "-a");
     if (p->data_type == 2 && !p->flow_order) { if (msg) snprintf(msg, cap, "Error: command line option -f is required\n"); return DWGSIM_HIP_ERR_ARG; }
-    if (p->data_type == 1) { if (msg) snprintf(msg, cap, "dwgsim-hip: -c 1 (SOLiD) is not on the accelerated path\n"); return DWGSIM_HIP_ERR_UNSUP; }
     if (p->data_type == 2) {       // dwgsim_opt.c:338-343, :396-413
         for (int i = 0; i < 2; ++i) if (p->e_end[i] != p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: a uniform error rate must be given for Ion Torrent data\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
         if (p->use_base_error) { if (msg) snprintf(msg, cap, "dwgsim-hip: -B (per-base error calibration) is not on the accelerated path\n"); return DWGSIM_HIP_ERR_UNSUP; }
@@ -265,7 +264,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_qbase[j]); }
-    for (int j = 0; j < 3; ++j) hipFree(c->status[j].p);
+    for (int j = 0; j < 4; ++j) hipFree(c->status[j].p);
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
@@ -639,9 +638,9 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     const uint64_t nblk = (n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
     if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
-    for (int j = 0; j < 3; ++j) if (ensure(c, c->status[j], sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    for (int j = 0; j < 4; ++j) if (ensure(c, c->status[j], sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
     a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
-    for (int j = 0; j < 3; ++j) a.status[j] = (uint64_t *)c->status[j].p;
+    for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status[j].p;
     const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
@@ -706,7 +705,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
     const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
     HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
-    for (int j = 0; j < 3; ++j) HIPC(c, hipMemsetAsync(a.status[j], 0, sizeof(uint64_t) * (size_t)nblk, c->stream));
+    for (int j = 0; j < 4; ++j) HIPC(c, hipMemsetAsync(a.status[j], 0, sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(c->ev[0], c->stream));
     HIPC(c, hipEventRecord(c->ev[1], c->stream));      // (the attempt loop is part of k_simulate: one kernel per batch)
     launch_simulate(c->stream, a);

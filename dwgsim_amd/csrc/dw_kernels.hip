@@ -24,7 +24,7 @@
 
 // The file is compiled in parts so the twelve k_simulate variants build in parallel (csrc/Makefile):
 //   DW_PART 0: mutation-walk kernels, k_place, host launchers and the k_simulate dispatcher
-//   DW_PART 1..4: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2)
+//   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1)
 //   DW_PART -1 (default): everything in one translation unit
 #ifndef DW_PART
 #define DW_PART -1
@@ -539,7 +539,7 @@ __global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint
 // ------------------------------------------------------------------------------------------------
 // Read simulation
 // ------------------------------------------------------------------------------------------------
-struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n; };
+struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n, n_ins; };   // n_ins: INSERT cells crossed (the reference's n_indel_first, dwgsim.c:98)
 
 // dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
 // The haplotype is read in 16-byte chunks with the next chunk prefetched; runs of up to 8 cells that
@@ -548,7 +548,7 @@ struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n; };
 template <bool STORE>
 DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
 {
-    ReadRes r{-10, 0, 0, 0};
+    ReadRes r{-10, 0, 0, 0, 0};
     int k = 0, kw = 0; uint64_t acc = 0; uint32_t nacc = 0;       // nacc nibbles pending in acc
     auto push = [&](uint64_t nibs, uint32_t cnt) {                 // append cnt packed nibbles
         if (STORE) {
@@ -617,7 +617,7 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         if (mt == T_DEL) { ++r.n_indel; if (strand) r.ext_coor--; }
         else if (mt == T_NONE || mt == T_SUB) { emit(c & 0xf); if (mt == T_SUB) ++r.n_sub; }
         else {
-            ++r.n_indel;
+            ++r.n_indel; ++r.n_ins;
             const uint32_t idx = ins_find(h, i);
             uint32_t n = h.ins_len[idx];
             const uint8_t *P = h.ins_bases + h.ins_off[idx];
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm[17];
     __shared__ uint32_t s_ticket;
-    __shared__ uint64_t s_base[2];
+    __shared__ uint64_t s_base[3];
     __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
     __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK * LPP;
@@ -1077,13 +1077,13 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
     // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
     // read end, N filter; the two lanes of a pair exchange their verdicts and retry together with attempt + 1 ----
     PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
-    ReadRes rr{0, 0, 0, 0};
+    ReadRes rr{0, 0, 0, 0, 0};
     uint32_t att = 0; bool is_rand = false, done = !valid;
     while (__ballot(!done)) {
         bool ok = true;
         if (!done) {
             pd = draw_pair(a, key, ii, att);
-            if (pd.is_rand) { is_rand = true; done = true; rr = ReadRes{0, 0, 0, 0}; }
+            if (pd.is_rand) { is_rand = true; done = true; rr = ReadRes{0, 0, 0, 0, 0}; }
             else if (s > 0) {
                 int64_t start; int step;
                 read_geom(a, pd, j, &start, &step);
@@ -1118,14 +1118,15 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
     const int nw = (s + 7) >> 3;
     if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int wb = (a.cap + 15) >> 4;          // words of the 2-bit pass-1 buffer
         s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
                             nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
         flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
     }
-    if (valid && (DT == 0 || is_rand)) {
+    int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
+    if (valid && (DT != 2 || is_rand)) {
         const uint64_t *thr = j ? a.e_thr[1] : a.e_thr[0];
+        uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
         for (int w = 0; w < nw; ++w) {
             const uint32_t word = is_rand ? 0u : lds[w * nthr];
             uint32_t out = 0;
@@ -1138,10 +1139,15 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
                 if (i < s) {
                     uint32_t c;
                     if (is_rand) c = rw[b] >> 30;                       // (int)(u * 4.0) & 3
-                    else {
-                        c = (word >> (4 * b)) & 15u;
+                    else c = (word >> (4 * b)) & 15u;
+                    if (DT == 1) {                                      // colour space: __gf_add(previous base, base), dwgsim.h:6, dwgsim.c:845-858 / :1022-1032
+                        const uint32_t base = c;
+                        c = (prev_base >= 4 || base >= 4) ? 4u : (prev_base ^ base);
+                        prev_base = base;
+                    }
+                    if (!is_rand) {
                         if (c >= 4) c = 4;
-                        else if ((uint64_t)rw[b] < thr[i]) { c |= 8u; ++n_err; }
+                        else if ((uint64_t)rw[b] < thr[i]) { c |= 8u; ++n_err; if (DT == 1 && i == 0) err_first = 1; }
                     }
                     out |= c << (4 * b);
                 }
@@ -1176,40 +1182,133 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
         if (j == 0) { e1c = o0; u1 = o1; i1 = o2; x1 = o3; }
         else { e1c = n_err; u1 = rr.n_sub; i1 = rr.n_indel; x1 = rr.ext_coor; e0 = o0; u0 = o1; i0 = o2; x0 = o3; }
     }
-    uint32_t tail_len, fixed_len;
-    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
+    // SOLiD: the BWA files print the counts "minus the first colour" (dwgsim.c:945-946); only n_err and n_indel can differ
+    int32_t e0w = e0, i0w = i0, e1w = e1c, i1w = i1;
+    if (DT == 1) {
+        int32_t f0 = err_first, g0 = rr.n_ins, f1 = 0, g1 = 0;
+        if (LPP == 2) {
+            const int32_t of = __shfl_xor(err_first, 1), og = __shfl_xor(rr.n_ins, 1);
+            if (j == 0) { f1 = of; g1 = og; } else { f1 = err_first; g1 = rr.n_ins; f0 = of; g0 = og; }
+        }
+        e0w = e0 - f0; i0w = i0 - g0; e1w = e1c - f1; i1w = i1 - g1;
+    }
+    uint32_t tail_len, tail_len_w, fixed_len;
+    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
     else {
         fixed_len = (uint32_t)a.name_fixed_len;
-        tail_len = 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
-                 + ndigits10((uint32_t)e0) + 1 + ndigits10((uint32_t)u0) + 1 + ndigits10((uint32_t)i0) + 1
-                 + ndigits10((uint32_t)e1c) + 1 + ndigits10((uint32_t)u1) + 1 + ndigits10((uint32_t)i1) + 1
-                 + ndigits16(ii);
+        const uint32_t common = 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
+                              + 1 + ndigits10((uint32_t)u0) + 1 + 1 + 1 + ndigits10((uint32_t)u1) + 1 + 1 + ndigits16(ii);
+        tail_len = common + ndigits10((uint32_t)e0) + ndigits10((uint32_t)i0) + ndigits10((uint32_t)e1c) + ndigits10((uint32_t)i1);
+        tail_len_w = (DT == 1) ? common + ndigits10((uint32_t)e0w) + ndigits10((uint32_t)i0w) + ndigits10((uint32_t)e1w) + ndigits10((uint32_t)i1w) : tail_len;
     }
-    const uint32_t Lbwa = (valid && s_out > 0) ? (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s_out + 3u + (uint32_t)s_out + 1u) : 0u;
+    const bool emits = valid && s_out > 0;
+    // record lengths.  SOLiD: BWA drops the first colour and its quality (dwgsim.c:950-955); BFAST prepends the adaptor 'A' (:968-975)
+    const uint32_t Lbwa = !emits ? 0u : (DT == 1) ? (1u + fixed_len + tail_len_w + 2u + 1u + 2u * (uint32_t)(s_out - 1) + 3u + 1u)
+                                                  : (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s_out + 3u + (uint32_t)s_out + 1u);
 
     // ---- record offsets: block scan + decoupled look-back over logical blocks ----
     uint32_t T1, T2;
     const uint32_t e1 = block_excl_scan(j == 0 ? Lbwa : 0u, sm, &T1);
     const uint32_t e2 = block_excl_scan(j == 1 ? Lbwa : 0u, sm, &T2);
-    if (wave == 0) { const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g; }
+    uint32_t eb = 0, Tb = 0;
+    if (DT == 1) eb = block_excl_scan(emits ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : 0u, sm, &Tb);
+    if (wave == 0) {
+        const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
+        if (DT == 1) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
+    }
     else if (wave == 1) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
     const uint64_t G1 = s_base[0], G2 = s_base[1];
     const uint64_t reads_before_block = (uint64_t)t * PAIRS_PER_BLOCK * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
-    const uint64_t off_bf = G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
+    // Illumina / Ion Torrent: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
+    const uint64_t off_bf = (DT == 1) ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
     if (tid == nthr - 1) {
         const uint64_t nblocks = (a.n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
         if ((uint64_t)t + 1 == nblocks) {
             const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
             a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
             a.counters[5] = a.p.has_bwa ? G2 + T2 : 0;
-            a.counters[6] = a.p.has_bfast ? G1 + T1 + G2 + T2 - 2 * nreads : 0;
+            a.counters[6] = !a.p.has_bfast ? 0 : (DT == 1) ? s_base[2] + Tb : G1 + T1 + G2 + T2 - 2 * nreads;
         }
     }
 
     PH_MARK(3);     // name lengths, block scan, look-back
+    // ---- SOLiD records (dwgsim.c:934-976, :1056-1094): the two outputs differ in name counts, suffix, alphabet and length ----
+    if (DT == 1) {
+        if (emits) {
+            const int8_t *qb = j ? a.qbase[1] : a.qbase[0];
+            for (int which = 0; which < 2; ++which) {            // 0: BWA stream of this end, 1: BFAST
+                if (!(OUT & (1 << which))) continue;
+                Out2<1> o;
+                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa);
+                {
+                    const uint32_t *fw = is_rand ? s_fixed[1] : s_fixed[0];
+                    const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed;
+                    const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
+                    uint32_t q = 0;
+                    for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
+                    if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
+                    for (q = inl; q < flen; ++q) o.put(fx[q]);
+                }
+                if (is_rand) {
+                    o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
+                    o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
+                    o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
+                    o.putn(0x5F303Aull, 3);                    // ":0_"
+                    put_hex(o, rand_ii);
+                } else {
+                    put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
+                    o.putn((uint64_t)'_' | ((uint64_t)('0' + pd.strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + pd.strand1) << 24)
+                               | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
+                    put_dec(o, (uint32_t)(which ? e0 : e0w), '_'); put_dec(o, (uint32_t)u0, ':'); put_dec(o, (uint32_t)(which ? i0 : i0w), ':');
+                    put_dec(o, (uint32_t)(which ? e1c : e1w), '_'); put_dec(o, (uint32_t)u1, ':'); put_dec(o, (uint32_t)(which ? i1 : i1w), ':');
+                    o.put('_');
+                    put_hex(o, ii);
+                }
+                if (which == 0) o.putn((uint64_t)'/' | ((uint64_t)('2' - j) << 8) | ((uint64_t)'\n' << 16), 3);      // F3 is annotated "/2", R3 "/1" (dwgsim.c:938-939)
+                else { o.put('\n'); o.put('A'); }
+                const int first = which ? 0 : 1;                // BWA skips the first colour
+                for (int i = first; i < s_out; ++i) {
+                    const uint32_t c = (lds[(i >> 3) * nthr] >> (4 * (i & 7))) & 15u;
+                    o.put(which ? (uint32_t)'0' + (c > 4 ? 4 : c) : base_char(c));
+                }
+                o.put('\n'); o.put('+'); o.put('\n');
+                // qualities (dwgsim.c:899-918): same draws for both outputs
+                if (a.p.fixed_quality >= 0) { for (int i = first; i < s_out; ++i) o.put((uint32_t)a.p.fixed_quality); }
+                else if (!(0 < a.p.quality_std)) {
+                    for (int i = first; i < s_out; ++i) { int32_t q = qb[i]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
+                } else {
+                    uint32_t m = 0; int p = 0; const int np = (s_out + 1) >> 1;
+                    while (p < np) {
+                        const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, m, (uint32_t)p);
+                        const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
+                        const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
+                        const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
+                        const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
+                        if (!oka && !okb) { ++m; continue; }
+                        const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
+                        const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int i = 2 * p + h;
+                            const double nrm = (h ? v1 : v2) * fac;
+                            if (i >= first && i < s_out) {
+                                int32_t q = (int8_t)(qb[i] + (int32_t)((nrm * a.p.quality_std) + 0.5));
+                                if (q < 33) q = 33;
+                                if (q > 73) q = 73;
+                                o.put((uint32_t)q);
+                            }
+                        }
+                        ++p; m = 0;
+                    }
+                }
+                o.put('\n');
+                o.flush();
+            }
+        }
+    } else
     // ---- write the record(s) ----
     if (valid && s_out > 0) {
         Out2<OUT> o;
@@ -1370,6 +1469,8 @@ void launch_sim_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, i
 void launch_sim_1_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_2_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_1_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
     const uint32_t nb = cdiv(a.n_pairs, PAIRS_PER_BLOCK);
@@ -1377,8 +1478,9 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = PAIRS_PER_BLOCK * (pe ? 2 : 1);
     const size_t lds = (size_t)(ion ? 4 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack (8 runs); its read buffers are in a.flow_scratch
-    if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
-    else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
+    const bool solid = a.p.data_type == 1;
+    if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else if (solid) launch_sim_2_1(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
+    else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else if (solid) launch_sim_1_1(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
 }
 #endif // DW_HAS(0): launchers
 
@@ -1401,6 +1503,12 @@ DW_SIM_FAMILY(2, 2)
 #endif
 #if DW_HAS(4)
 DW_SIM_FAMILY(1, 2)
+#endif
+#if DW_HAS(5)
+DW_SIM_FAMILY(2, 1)
+#endif
+#if DW_HAS(6)
+DW_SIM_FAMILY(1, 1)
 #endif
 
 } // namespace dw

@@ -69,7 +69,7 @@ struct SimArgs {
     uint32_t *meta;                // per pair: accepted attempt | is_random << 31
     uint32_t *block_rand;          // per 128-pair block: random pairs (k_place), then exclusive prefix (k_scan)
     uint64_t *counters;            // [0] ticket, [1] retries, [2] fail flag, [3] total random, [4..6] stream bytes
-    uint64_t *status[3];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count
+    uint64_t *status[4];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count, (SOLiD) BFAST bytes
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
     int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
     int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors

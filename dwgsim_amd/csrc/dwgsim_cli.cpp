@@ -37,7 +37,7 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -R FLOAT      fraction of mutations that are indels [%.2f]\n         -X FLOAT      probability an indel is extended [%.2f]\n", o->indel_frac, o->indel_extend);
     fprintf(stderr, "         -I INT        the minimum length indel [%d]\n         -y FLOAT      probability of a random DNA read [%.2f]\n", o->indel_min, o->rand_read);
     fprintf(stderr, "         -n INT        maximum number of Ns allowed in a given read [%d]\n", o->max_n);
-    fprintf(stderr, "         -c INT        generate reads for 0: Illumina, 2: Ion Torrent (1: SOLiD is not on the accelerated path) [%d]\n", o->data_type);
+    fprintf(stderr, "         -c INT        generate reads for 0: Illumina, 1: SOLiD, 2: Ion Torrent [%d]\n", o->data_type);
     fprintf(stderr, "         -S INT        paired end orientation 0: default, 1: same strand, 2: opposite strand [%d]\n", o->strandedness);
     fprintf(stderr, "         -A INT        read one strand 0: random, 1: forward, 2: reverse [%d]\n", o->read_one_strand);
     fprintf(stderr, "         -H            haploid mode\n         -z INT        random seed (-1 uses the current time) [%d]\n", o->seed);
@@ -49,7 +49,7 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -f STRING     the flow order for Ion Torrent data\n");
     fprintf(stderr, "         -m FILE       the mutations txt file to re-create\n         -b FILE       the bed-like file set of candidate mutations\n         -v FILE       the vcf file set of candidate mutations (use pl tag for strand)\n");
     fprintf(stderr, "         -x FILE       the bed of regions to cover\n");
-    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -c 1, -B\n\n");
+    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -B\n\n");
     return 1;
 }
 

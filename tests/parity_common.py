@@ -48,7 +48,7 @@ def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22):
 
 FLOW = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
 
-# (fasta under tests/golden, flags): the option surface of the accelerated path (Illumina and Ion Torrent)
+# (fasta under tests/golden, flags): the option surface of the accelerated path (Illumina, SOLiD and Ion Torrent)
 CASES = [
     ("ex1.fa", "-z 13 -N 10000"),                                  # the reference's bundled test configuration
     ("ex1.fa", "-z 13 -N 10000 -1 100 -2 100"),                   # BASELINE configs[0]
@@ -79,6 +79,12 @@ CASES = [
     ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW} -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
     ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 100 -2 0 -e 0.2 -o 1"),
     ("odd.fa", f"-z 6 -N 3000 -c 2 -f {FLOW} -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2"),
+    # SOLiD colour space: first-colour bookkeeping in the BWA names, "/2"-"/1" suffix swap, 'A'+digits for BFAST
+    ("ex1.fa", "-z 13 -N 5000 -c 1"),
+    ("tiny.fa", "-z 8 -N 4000 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1"),
+    ("tiny.fa", "-z 8 -N 3000 -c 1 -2 0 -o 1 -n 3"),
+    ("odd.fa", "-z 6 -N 3000 -c 1 -1 40 -2 40 -d 150 -s 10 -r 0.08 -R 0.8 -n 20 -o 2 -q 5"),
+    ("tiny.fa", "-z 8 -N 2000 -c 1 -1 1 -2 1 -d 50 -s 5 -Q 0"),
     # mutation-input files: -m txt, -v vcf, -b bed
     ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_generated.txt"),
     ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_edge.txt"),

@@ -35,7 +35,7 @@ def test_defaults_match_dwgsim_opt_init(lib):
 
 @pytest.mark.parametrize("flags,code", [
     ("-z 1 -N 10", 0), ("-z 1 -N 10 -C 5", 0), ("-z 1 -1 0 -N 5", -1), ("-z 1 -N 5 -r 1.5", -1), ("-z 1 -N 5 -y -0.1", -1),
-    ("-z 1 -N 5 -S 3", -1), ("-z 1 -N 5 -c 1", -4), ("-z 1 -N 5 -c 2 -f TACG -2 0", 0), ("-z 1 -N 5 -c 2 -f TAC -2 0", -4), ("-z 1 -N 5 -c 2 -f TACG -e 0.01-0.02", -1), ("-z 1 -N 5 -e 1.2", -1), ("-N 5", -1), ("-z 1 -N 5 -o 3", -1),
+    ("-z 1 -N 5 -S 3", -1), ("-z 1 -N 5 -c 1", 0), ("-z 1 -N 5 -c 2 -f TACG -2 0", 0), ("-z 1 -N 5 -c 2 -f TAC -2 0", -4), ("-z 1 -N 5 -c 2 -f TACG -e 0.01-0.02", -1), ("-z 1 -N 5 -e 1.2", -1), ("-N 5", -1), ("-z 1 -N 5 -o 3", -1),
 ])
 def test_option_checks(lib, flags, code):
     p = api.parse_flags(flags, lib)
