@@ -144,6 +144,7 @@ def parse_flags(flags: str, lib=None) -> Params:
         elif t == "-n": p.max_n = int(arg())
         elif t == "-y": p.rand_read = float(arg())
         elif t == "-f": keep.append(arg().encode()); p.flow_order = keep[-1]
+        elif t == "-B": p.use_base_error = 1
         elif t == "-H": p.is_hap = 1
         elif t == "-z": p.seed = int(arg())
         elif t == "-M": p.output_type = int(arg())

@@ -36,6 +36,7 @@ enum : uint32_t {
     D_QUAL0 = 10,       // +read end.  block p, retry m: polar tries 2m = words (0,1), 2m+1 = words (2,3); the accepted try gives
                         // quality normals 2p (v2*fac) and 2p+1 (v1*fac) (dwgsim.c:912, :156-175)
     D_FLOW0 = 12,       // +read end.  sequential slots inside generate_errors_flows (dwgsim.c:246-417)
+    D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
     D_SUB0 = 16         // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
 };
 

@@ -161,7 +161,6 @@ int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap)
     if (p->data_type == 2 && !p->flow_order) { if (msg) snprintf(msg, cap, "Error: command line option -f is required\n"); return DWGSIM_HIP_ERR_ARG; }
     if (p->data_type == 2) {       // dwgsim_opt.c:338-343, :396-413
         for (int i = 0; i < 2; ++i) if (p->e_end[i] != p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: a uniform error rate must be given for Ion Torrent data\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
-        if (p->use_base_error) { if (msg) snprintf(msg, cap, "dwgsim-hip: -B (per-base error calibration) is not on the accelerated path\n"); return DWGSIM_HIP_ERR_UNSUP; }
         const size_t F = strlen(p->flow_order);
         bool has[4] = {false, false, false, false};
         for (size_t i = 0; i < F; ++i) { const uint8_t c = nt4((unsigned char)p->flow_order[i]); if (c < 4) has[c] = true; }
@@ -224,6 +223,40 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         for (int i = 0; i < 4; ++i) HIPC(c, hipEventCreate(&c->ev[i]));
         HIPC(c, hipMalloc((void **)&c->d_counters, 16 * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_counters, 16 * sizeof(uint64_t), hipHostMallocDefault));
+        { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
+          HIPC(c, hipMalloc((void **)&c->d_flow, 64)); HIPC(c, hipMemcpy(c->d_flow, fl.data(), 64, hipMemcpyHostToDevice)); }
+        // -B (dwgsim_opt.c:415-457): rescale the flow error so that the per-base error rate of 10^6 random reads matches -e
+        if (c->prm.data_type == 2 && c->prm.use_base_error) {
+            double sf = 0.0;
+            for (int i = 0; i < 2; ++i) {
+                const int len = c->prm.length[i];
+                if (len <= 0) continue;
+                fprintf(stderr, "[dwgsim_core] Updating error rate for end %d\n", i + 1);
+                if (0 < i && len == c->prm.length[1 - i]) {
+                    c->prm.e_start[i] = c->prm.e_start[1 - i]; c->prm.e_end[i] = c->prm.e_end[1 - i];
+                    fprintf(stderr, "[dwgsim_core] Using scaling factor from previous end\n[dwgsim_core] Updated with scaling factor %.5lf\n", sf);
+                    continue;
+                }
+                const double e = c->prm.e_start[i];
+                CalibArgs ca;
+                ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
+                ca.thr = e <= 0 ? 0 : (uint64_t)ceil(e * 4294967296.0);
+                ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
+                ca.cap = len + 32 + (int)(len * 10.0 * e); ca.lds_words = (ca.cap + 7) / 8;
+                const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+                if (ensure(c, c->flow_scratch, (size_t)(ca.lds_words + ((ca.cap + 15) >> 4)) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
+                ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
+                HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
+                launch_calibrate(c->stream, ca);
+                HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+                HIPC(c, hipStreamSynchronize(c->stream));
+                if (c->h_counters[2]) { c->err = "-B calibration: a read outgrew its flow-space buffer"; return -1; }
+                const int32_t n_err = (int32_t)c->h_counters[8], counts = (int32_t)c->h_counters[9];       // int32 accumulators as in the reference
+                sf = e / (n_err / (1.0 * counts));
+                c->prm.e_end[i] *= sf; c->prm.e_start[i] = c->prm.e_end[i];
+                fprintf(stderr, "[dwgsim_core] Updated with scaling factor %.5lf!\n", sf);
+            }
+        }
         // per-position error thresholds and base qualities (dwgsim_opt.c:459-460, dwgsim.c:237, :906-910)
         for (int j = 0; j < 2; ++j) {
             const int n = c->prm.length[j];
@@ -243,8 +276,6 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
         }
         // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 256 bytes in LDS)
-        { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
-          HIPC(c, hipMalloc((void **)&c->d_flow, 64)); HIPC(c, hipMemcpy(c->d_flow, fl.data(), 64, hipMemcpyHostToDevice)); }
         std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";
         c->rand_fixed_len = (int32_t)rf.size();
         std::string rbuf = "@" + rf; rbuf.resize(rbuf.size() < 256 ? 272 : rbuf.size() + 16, '\0');

@@ -1503,6 +1503,42 @@ DW_SIM_FAMILY(2, 2)
 #endif
 #if DW_HAS(4)
 DW_SIM_FAMILY(1, 2)
+
+// -B (dwgsim_opt.c:415-457): lane = one random read of read end a.end pushed through the flow model on the forward strand; the block
+// adds its error and length sums to counters[8], [9].  Draws: bases = narrow words of (D_CALIB + end, read, attempt 0), flow model =
+// the sequential narrow stream of (D_CALIB + end, read, attempt 1).
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
+{
+    DW_DYN_SHARED(uint32_t, dyn_lds);
+    __shared__ uint8_t s_flow[64];
+    const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK;
+    if (tid < 64) s_flow[tid] = a.flow[tid];
+    __syncthreads();
+    const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
+    uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr) + tid;
+    int32_t n_err = 0; int s_out = 0;
+    if (jj < a.n_reads) {
+        const RngKey key{a.seed, 0u};
+        const uint32_t dom = D_CALIB + (uint32_t)a.end;
+        for (int w = 0; w * 8 < a.len; ++w) {
+            const U4 q0 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w)), q1 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w + 1));
+            const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) if (w * 8 + b < a.len) word |= (rw[b] >> 30) << (4 * b);      // (int)(u * 4.0) & 3
+            buf[w * nthr] = word;
+        }
+        FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.slot = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
+        s_out = flow_errors(rg, s_flow, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
+        if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; }
+    }
+    const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);
+    if ((tid & 63) == 0) { atomicAdd((unsigned long long *)&a.counters[8], (unsigned long long)es); atomicAdd((unsigned long long *)&a.counters[9], (unsigned long long)ls); }
+}
+void launch_calibrate(hipStream_t st, const CalibArgs &a)
+{
+    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)4 * PAIRS_PER_BLOCK * 4, st, a);
+}
 #endif
 #if DW_HAS(5)
 DW_SIM_FAMILY(2, 1)

@@ -56,6 +56,15 @@ struct SimParams {
     uint32_t seed;
 };
 
+// -B: per-base calibration of the Ion Torrent flow error (dwgsim_opt.c:415-457): n_reads random reads of `len` bases of read end `end`
+struct CalibArgs {
+    uint32_t seed; int32_t end, len; uint64_t n_reads;
+    uint64_t thr;                   // ceil(e * 2^32) of the uncalibrated -e
+    const uint8_t *flow; int32_t flow_len, cap, lds_words;
+    uint32_t *scratch;              // per block [lds_words + (cap + 15) / 16][PAIRS_PER_BLOCK] words
+    uint64_t *counters;             // [8] += errors, [9] += read lengths after errors, [2] |= 2 on a buffer overflow
+};
+
 struct SimArgs {
     SimParams p;
     ContigDev c;

@@ -18,4 +18,5 @@ void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, i
 void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells);
 void launch_place(hipStream_t st, const SimArgs &a);
 void launch_simulate(hipStream_t st, const SimArgs &a);
+void launch_calibrate(hipStream_t st, const CalibArgs &a);
 }

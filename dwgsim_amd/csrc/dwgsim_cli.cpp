@@ -49,7 +49,6 @@ static int usage(const dwgsim_hip_params_t *o)
     fprintf(stderr, "         -f STRING     the flow order for Ion Torrent data\n");
     fprintf(stderr, "         -m FILE       the mutations txt file to re-create\n         -b FILE       the bed-like file set of candidate mutations\n         -v FILE       the vcf file set of candidate mutations (use pl tag for strand)\n");
     fprintf(stderr, "         -x FILE       the bed of regions to cover\n");
-    fprintf(stderr, "Not on the accelerated path (use the reference dwgsim): -B\n\n");
     return 1;
 }
 
@@ -178,8 +177,7 @@ int main(int argc, char **argv)
         case 'b': muts_fn = optarg; muts_type = 0; muts_flags |= 2; break;
         case 'v': muts_fn = optarg; muts_type = 2; muts_flags |= 4; break;
         case 'x': regions_fn = optarg; break;
-        case 'B':
-            fprintf(stderr, "dwgsim-hip: option -%c is not on the accelerated path (see DESIGN.md); use the reference dwgsim\n", c); return 1;
+        case 'B': o.use_base_error = 1; break;
         default: fprintf(stderr, "Unrecognized option: -%c\n", c); return usage(&o);
         }
     }

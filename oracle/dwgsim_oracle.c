@@ -990,7 +990,9 @@ static int calibrate_flow_error(opt_t *o, rng_t *r)
         int n_err = 0, counts = 0; /* int32 accumulators as in the reference */
         for (int j = 0; j < 1000000; ++j) {
             uint32_t slot = 0;
-            for (int k = 0; k < o->length[i]; ++k) b.seq[k] = (uint8_t)((int)(rng_u(r, D_CALIB + i, (uint64_t)j, 0, 0, slot++) * 4.0) & 3);
+            /* mode B: bases = narrow words of attempt 0, the flow model's sequential stream = attempt 1; per-read mask (see core()) */
+            for (int k = 0; k < o->length[i]; ++k) b.seq[k] = (uint8_t)((int)(rng_u32(r, D_CALIB + i, (uint64_t)j, 0, 0, (uint32_t)k) * 4.0) & 3);
+            if (r->mode == RNG_PHILOX) memset(b.mask, 0, (size_t)b.mem);
             int cur = 0;
             int s = flow_errors(o, r, D_CALIB + i, (uint64_t)j, 1, &slot, &b, o->length[i], 0, o->e[i].start, &cur);
             n_err += cur; counts += s;

@@ -85,6 +85,9 @@ CASES = [
     ("tiny.fa", "-z 8 -N 3000 -c 1 -2 0 -o 1 -n 3"),
     ("odd.fa", "-z 6 -N 3000 -c 1 -1 40 -2 40 -d 150 -s 10 -r 0.08 -R 0.8 -n 20 -o 2 -q 5"),
     ("tiny.fa", "-z 8 -N 2000 -c 1 -1 1 -2 1 -d 50 -s 5 -Q 0"),
+    # -B: the flow error is calibrated on 10^6 random reads before the run (dwgsim_opt.c:415-457)
+    ("tiny.fa", f"-z 9 -N 1500 -c 2 -f {FLOW} -1 100 -2 0 -e 0.02 -B"),
+    ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 60 -2 40 -e 0.03 -E 0.01 -d 300 -B -o 1"),
     # mutation-input files: -m txt, -v vcf, -b bed
     ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_generated.txt"),
     ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_edge.txt"),
