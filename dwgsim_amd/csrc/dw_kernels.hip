@@ -1048,6 +1048,82 @@ DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull
 #define PH_MARK(k) do { } while (0)
 #endif
 
+// ---- pieces of a FASTQ record shared by the Illumina / Ion Torrent and the SOLiD write paths ----
+// '@' + "[prefix_]contig" (or "[prefix_]rand"): whole words from LDS (first 256 bytes), any rest from HBM
+template <int OUT>
+DW_DEV void put_name_fixed(Out2<OUT> &o, const uint32_t *fw, const uint8_t *fx, uint32_t fixed_len)
+{
+    const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
+    uint32_t q = 0;
+    for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
+    if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
+    for (q = inl; q < flen; ++q) o.put(fx[q]);
+}
+// "_0_0_0_0_1_1_0:0:0_0:0:0_<hex>" of a random read (dwgsim.c:1044-1048)
+template <int OUT>
+DW_DEV void put_rand_tail(Out2<OUT> &o, uint64_t rand_ii)
+{
+    o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
+    o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
+    o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
+    o.putn(0x5F303Aull, 3);                    // ":0_"
+    put_hex(o, rand_ii);
+}
+struct NameCounts { int32_t e0, u0, i0, e1, u1, i1; };     // n_err : n_sub : n_indel of read end 1 and 2
+// "_pos1_pos2_strand1_strand2_0_0_e:s:i_e:s:i_<hex>" (dwgsim.c:923-929)
+template <int OUT>
+DW_DEV void put_pair_tail(Out2<OUT> &o, int32_t x0, int32_t x1, uint32_t strand0, uint32_t strand1, const NameCounts &n, uint64_t ii)
+{
+    put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
+    o.putn((uint64_t)'_' | ((uint64_t)('0' + strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + strand1) << 24)
+               | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
+    put_dec(o, (uint32_t)n.e0, '_'); put_dec(o, (uint32_t)n.u0, ':'); put_dec(o, (uint32_t)n.i0, ':');
+    put_dec(o, (uint32_t)n.e1, '_'); put_dec(o, (uint32_t)n.u1, ':'); put_dec(o, (uint32_t)n.i1, ':');
+    o.put('_');
+    put_hex(o, ii);
+}
+DW_DEV uint32_t pair_tail_len(int32_t x0, int32_t x1, const NameCounts &n, uint64_t ii)
+{
+    return 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
+         + ndigits10((uint32_t)n.e0) + 1 + ndigits10((uint32_t)n.u0) + 1 + ndigits10((uint32_t)n.i0) + 1
+         + ndigits10((uint32_t)n.e1) + 1 + ndigits10((uint32_t)n.u1) + 1 + ndigits10((uint32_t)n.i1) + 1 + ndigits16(ii);
+}
+// Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qb = base quality per position
+// (positions >= nq reuse the last entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
+template <class F>
+DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const int8_t *qb, int nq, int n, F &&emit)
+{
+    if (p.fixed_quality >= 0) { for (int i = 0; i < n; ++i) emit(i, (uint32_t)p.fixed_quality); return; }
+    if (!(0 < p.quality_std)) {
+        for (int i = 0; i < n; ++i) { int32_t q = qb[i < nq ? i : nq - 1]; if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
+        return;
+    }
+    uint32_t m = 0; int pr = 0; const int np = (n + 1) >> 1;
+    while (pr < np) {
+        const U4 blk = rng_block(key, dom, ii, att, m, (uint32_t)pr);
+        // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
+        const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
+        const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
+        const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
+        const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
+        if (!oka && !okb) { ++m; continue; }
+        const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
+        const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * pr + h;
+            const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
+            if (i < n) {
+                int32_t q = (int8_t)(qb[i < nq ? i : nq - 1] + (int32_t)((nrm * p.quality_std) + 0.5));
+                if (q < 33) q = 33;
+                if (q > 73) q = 73;
+                emit(i, (uint32_t)q);
+            }
+        }
+        ++pr; m = 0;
+    }
+}
+
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 template <int LPP, int OUT, int DT>
 __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES - 1)) k_simulate(SimArgs a)
@@ -1196,14 +1272,13 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
         }
         e0w = e0 - f0; i0w = i0 - g0; e1w = e1c - f1; i1w = i1 - g1;
     }
+    const NameCounts nc{e0, u0, i0, e1c, u1, i1}, ncw{e0w, u0, i0w, e1w, u1, i1w};
     uint32_t tail_len, tail_len_w, fixed_len;
     if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
     else {
         fixed_len = (uint32_t)a.name_fixed_len;
-        const uint32_t common = 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
-                              + 1 + ndigits10((uint32_t)u0) + 1 + 1 + 1 + ndigits10((uint32_t)u1) + 1 + 1 + ndigits16(ii);
-        tail_len = common + ndigits10((uint32_t)e0) + ndigits10((uint32_t)i0) + ndigits10((uint32_t)e1c) + ndigits10((uint32_t)i1);
-        tail_len_w = (DT == 1) ? common + ndigits10((uint32_t)e0w) + ndigits10((uint32_t)i0w) + ndigits10((uint32_t)e1w) + ndigits10((uint32_t)i1w) : tail_len;
+        tail_len = pair_tail_len(x0, x1, nc, ii);
+        tail_len_w = (DT == 1) ? pair_tail_len(x0, x1, ncw, ii) : tail_len;
     }
     const bool emits = valid && s_out > 0;
     // record lengths.  SOLiD: BWA drops the first colour and its quality (dwgsim.c:950-955); BFAST prepends the adaptor 'A' (:968-975)
@@ -1242,72 +1317,24 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
     // ---- SOLiD records (dwgsim.c:934-976, :1056-1094): the two outputs differ in name counts, suffix, alphabet and length ----
     if (DT == 1) {
         if (emits) {
-            const int8_t *qb = j ? a.qbase[1] : a.qbase[0];
             for (int which = 0; which < 2; ++which) {            // 0: BWA stream of this end, 1: BFAST
                 if (!(OUT & (1 << which))) continue;
                 Out2<1> o;
                 o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa);
-                {
-                    const uint32_t *fw = is_rand ? s_fixed[1] : s_fixed[0];
-                    const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed;
-                    const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
-                    uint32_t q = 0;
-                    for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
-                    if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
-                    for (q = inl; q < flen; ++q) o.put(fx[q]);
-                }
-                if (is_rand) {
-                    o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
-                    o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
-                    o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
-                    o.putn(0x5F303Aull, 3);                    // ":0_"
-                    put_hex(o, rand_ii);
-                } else {
-                    put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
-                    o.putn((uint64_t)'_' | ((uint64_t)('0' + pd.strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + pd.strand1) << 24)
-                               | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
-                    put_dec(o, (uint32_t)(which ? e0 : e0w), '_'); put_dec(o, (uint32_t)u0, ':'); put_dec(o, (uint32_t)(which ? i0 : i0w), ':');
-                    put_dec(o, (uint32_t)(which ? e1c : e1w), '_'); put_dec(o, (uint32_t)u1, ':'); put_dec(o, (uint32_t)(which ? i1 : i1w), ':');
-                    o.put('_');
-                    put_hex(o, ii);
-                }
+                put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
+                if (is_rand) put_rand_tail(o, rand_ii);
+                else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1,           // (value selects: a struct select would go through memory)
+                                   NameCounts{which ? e0 : e0w, u0, which ? i0 : i0w, which ? e1c : e1w, u1, which ? i1 : i1w}, ii);
                 if (which == 0) o.putn((uint64_t)'/' | ((uint64_t)('2' - j) << 8) | ((uint64_t)'\n' << 16), 3);      // F3 is annotated "/2", R3 "/1" (dwgsim.c:938-939)
                 else { o.put('\n'); o.put('A'); }
-                const int first = which ? 0 : 1;                // BWA skips the first colour
+                const int first = which ? 0 : 1;                // BWA skips the first colour and its quality
                 for (int i = first; i < s_out; ++i) {
                     const uint32_t c = (lds[(i >> 3) * nthr] >> (4 * (i & 7))) & 15u;
                     o.put(which ? (uint32_t)'0' + (c > 4 ? 4 : c) : base_char(c));
                 }
                 o.put('\n'); o.put('+'); o.put('\n');
-                // qualities (dwgsim.c:899-918): same draws for both outputs
-                if (a.p.fixed_quality >= 0) { for (int i = first; i < s_out; ++i) o.put((uint32_t)a.p.fixed_quality); }
-                else if (!(0 < a.p.quality_std)) {
-                    for (int i = first; i < s_out; ++i) { int32_t q = qb[i]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
-                } else {
-                    uint32_t m = 0; int p = 0; const int np = (s_out + 1) >> 1;
-                    while (p < np) {
-                        const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, m, (uint32_t)p);
-                        const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
-                        const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
-                        const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
-                        const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
-                        if (!oka && !okb) { ++m; continue; }
-                        const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
-                        const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int i = 2 * p + h;
-                            const double nrm = (h ? v1 : v2) * fac;
-                            if (i >= first && i < s_out) {
-                                int32_t q = (int8_t)(qb[i] + (int32_t)((nrm * a.p.quality_std) + 0.5));
-                                if (q < 33) q = 33;
-                                if (q > 73) q = 73;
-                                o.put((uint32_t)q);
-                            }
-                        }
-                        ++p; m = 0;
-                    }
-                }
+                for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out,
+                                 [&](int i, uint32_t q) { if (i >= first) o.put(q); });       // same draws for both outputs
                 o.put('\n');
                 o.flush();
             }
@@ -1318,30 +1345,9 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
         Out2<OUT> o;
         if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
         if (OUT & 2) o.b.init(a.out[2] + off_bf);
-        {   // '@' + fixed part: whole words from LDS (first 256 bytes), any rest from HBM
-            const uint32_t *fw = is_rand ? s_fixed[1] : s_fixed[0];
-            const uint8_t *fx = is_rand ? a.rand_fixed : a.name_fixed;
-            const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
-            uint32_t q = 0;
-            for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
-            if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
-            for (q = inl; q < flen; ++q) o.put(fx[q]);
-        }
-        if (is_rand) {
-            o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
-            o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
-            o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
-            o.putn(0x5F303Aull, 3);                    // ":0_"
-            put_hex(o, rand_ii);
-        } else {
-            put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
-            o.putn((uint64_t)'_' | ((uint64_t)('0' + pd.strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + pd.strand1) << 24)
-                       | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
-            put_dec(o, (uint32_t)e0, '_'); put_dec(o, (uint32_t)u0, ':'); put_dec(o, (uint32_t)i0, ':');
-            put_dec(o, (uint32_t)e1c, '_'); put_dec(o, (uint32_t)u1, ':'); put_dec(o, (uint32_t)i1, ':');
-            o.put('_');
-            put_hex(o, ii);
-        }
+        put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
+        if (is_rand) put_rand_tail(o, rand_ii);
+        else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
         if (OUT & 1) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
         if (OUT & 2) o.b.put('\n');
         PH_MARK(4); // header line
@@ -1361,38 +1367,13 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
         }
         o.put('\n'); o.put('+'); o.put('\n');
         PH_MARK(5); // sequence line
-        // qualities (dwgsim.c:899-918)
-        const int8_t *qb = j ? a.qbase[1] : a.qbase[0];
-        // (Ion Torrent: the error rate is uniform, dwgsim_opt.c:338-343, so positions past the table reuse its last entry)
-        if (a.p.fixed_quality >= 0) { for (int i = 0; i < s_out; ++i) o.put((uint32_t)a.p.fixed_quality); }
-        else if (!(0 < a.p.quality_std)) {
-            for (int i = 0; i < s_out; ++i) { int32_t q = qb[i < s ? i : s - 1]; if (q < 33) q = 33; if (q > 73) q = 73; o.put((uint32_t)q); }
-        } else {
-            uint32_t qacc = 0, nq = 0, m = 0; int p = 0; const int np = (s_out + 1) >> 1;
-            while (p < np) {
-                const U4 blk = rng_block(key, D_QUAL0 + (uint32_t)j, ii, att, m, (uint32_t)p);
-                // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
-                const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
-                const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
-                const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
-                const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
-                if (!oka && !okb) { ++m; continue; }
-                const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
-                const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int i = 2 * p + h;
-                    const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
-                    if (i < s_out) {
-                        int32_t q = (int8_t)(qb[i < s ? i : s - 1] + (int32_t)((nrm * a.p.quality_std) + 0.5));
-                        if (q < 33) q = 33;
-                        if (q > 73) q = 73;
-                        qacc |= (uint32_t)q << (8 * nq);
-                        if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
-                    }
-                }
-                ++p; m = 0;
-            }
+        // qualities (dwgsim.c:899-918), four characters per store
+        {
+            uint32_t qacc = 0, nq = 0;
+            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out, [&](int, uint32_t q) {
+                qacc |= q << (8 * nq);
+                if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
+            });
             for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
         }
         o.put('\n');

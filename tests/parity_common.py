@@ -103,3 +103,40 @@ CASES = [
     ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 2000 -2 0"),
     ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 5 -m {IN}/muts_edge.txt"),
 ]
+
+
+# ---- the read-name contract dwgsim_eval consumes (src/dwgsim_eval.c; dwgsim.c:923-929): checked against the FASTA itself,
+# ---- independently of the oracle
+_COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
+
+
+def check_read_names_tell_the_truth(res, contigs, lengths, min_checked=200):
+    """@contig_pos1_pos2_strand1_strand2_0_0_e1:s1:i1_e2:s2:i2_hex/end -- for every non-random read without indels the
+    Hamming distance between the read and the stated reference window is at most its stated errors + SNPs (0 => identical)."""
+    ref = {name: bytes(arr).upper().translate(bytes.maketrans(b"RYMKWSBDHVX", b"N" * 11)) for name, arr in contigs}
+    checked = exact = 0
+    for end in (0, 1):
+        lines = res.streams[end].split(b"\n")
+        for k in range(0, len(lines) - 3, 4):
+            name, seq = lines[k], lines[k + 1]
+            assert name.startswith(b"@") and name.endswith(b"/%d" % (end + 1)) and lines[k + 2] == b"+" and len(lines[k + 3]) == len(seq)
+            f = name[1:-2].rsplit(b"_", 9)           # contig names may contain '_': split from the right as dwgsim_eval does
+            contig, pos, strand = f[0].decode(), [int(f[1]), int(f[2])], [int(f[3]), int(f[4])]
+            counts = [tuple(int(x) for x in f[7 + e].split(b":")) for e in (0, 1)]
+            int(f[9], 16)
+            if f[5] == b"1":                         # random read: "rand_0_0_0_0_1_1_0:0:0_0:0:0_<hex>"
+                assert contig.endswith("rand") and pos == [0, 0] and counts == [(0, 0, 0), (0, 0, 0)]
+                continue
+            assert len(seq) == lengths[end]
+            n_err, n_sub, n_indel = counts[end]
+            if n_indel:
+                continue
+            window = ref[contig][pos[end] - 1: pos[end] - 1 + len(seq)]
+            if strand[end]:
+                window = window.translate(_COMP)[::-1]
+            ham = sum(1 for a, b in zip(seq, window) if a != b and b != ord("N"))      # reads print N wherever the reference has a non-ACGT base
+            assert ham <= n_err + n_sub, (name, seq, window)
+            checked += 1
+            exact += (n_err + n_sub == 0)
+    assert checked >= min_checked and exact > 0
+    return checked, exact

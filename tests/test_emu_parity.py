@@ -37,3 +37,12 @@ def emu_lib():
 @pytest.mark.parametrize("fasta,flags", EMU_CASES, ids=[f"{f}:{fl}" for f, fl in EMU_CASES])
 def test_kernel_logic_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags):
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=700)
+
+
+def test_read_names_tell_the_truth_on_cpu_emulation(emu_lib, golden_dir):
+    """Oracle-independent check of the name contract (see parity_common.check_read_names_tell_the_truth)."""
+    from parity_common import check_read_names_tell_the_truth
+    params = api.parse_flags("-z 21 -N 800 -r 0.01 -R 0.2 -e 0.01 -E 0.02", emu_lib)
+    contigs = api.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    res = api.run_job(params, contigs, batch_pairs=700, lib=emu_lib)
+    check_read_names_tell_the_truth(res, contigs, [params.length[0], params.length[1]], min_checked=100)

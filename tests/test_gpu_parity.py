@@ -25,6 +25,16 @@ def test_batches_and_shards_are_order_independent(lib, oracle_bin, golden_dir):
     compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 3000 -y 0.2", batch_pairs=257)
 
 
+@pytest.mark.parametrize("flags", ["-z 21 -N 4000 -r 0.01 -R 0.2 -e 0.01 -E 0.02", "-z 22 -N 3000 -r 0 -e 0 -E 0 -1 70 -2 50 -S 1 -y 0.1"])
+def test_read_names_tell_the_truth(lib, golden_dir, flags):
+    """Oracle-independent: every read is found where its name says it is (the contract dwgsim_eval relies on)."""
+    from parity_common import check_read_names_tell_the_truth
+    params = api.parse_flags(flags, lib)
+    contigs = api.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    res = api.run_job(params, contigs, lib=lib)
+    check_read_names_tell_the_truth(res, contigs, [params.length[0], params.length[1]])
+
+
 @pytest.fixture(scope="module")
 def repeats_fa(tmp_path_factory):
     from dwgsim_amd import synth
