@@ -60,6 +60,7 @@ struct dwgsim_hip_ctx {
     std::string err;
     double e_by[2] = {0, 0};
     uint64_t *d_thr[2] = {nullptr, nullptr};
+    uint32_t *d_thr32[2] = {nullptr, nullptr}; int e_full = 0;
     int8_t *d_qbase[2] = {nullptr, nullptr};
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
@@ -273,6 +274,14 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             HIPC(c, hipMalloc((void **)&c->d_thr[j], sizeof(uint64_t) * (size_t)n));
             HIPC(c, hipMalloc((void **)&c->d_qbase[j], (size_t)n));
             HIPC(c, hipMemcpy(c->d_thr[j], thr.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
+            std::vector<uint32_t> t32(((size_t)n + 7) / 8 * 8, 0u);
+            for (int i = 0; i < n; ++i) {
+                if (thr[(size_t)i] >= 0x100000000ull) { t32[(size_t)i] = 0xFFFFFFFFu; c->e_full = 1; }
+                else t32[(size_t)i] = (uint32_t)thr[(size_t)i];
+            }
+            if (c->e_full) for (int i = 0; i < n; ++i) if (thr[(size_t)i] == 0xFFFFFFFFull) { c->err = "an error rate within 2^-32 of (but not equal to) 1 next to one equal to 1 is not representable"; return -1; }
+            HIPC(c, hipMalloc((void **)&c->d_thr32[j], sizeof(uint32_t) * t32.size()));
+            HIPC(c, hipMemcpy(c->d_thr32[j], t32.data(), sizeof(uint32_t) * t32.size(), hipMemcpyHostToDevice));
             HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
         }
         // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 256 bytes in LDS)
@@ -294,7 +303,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
-    for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_qbase[j]); }
+    for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     for (int j = 0; j < 4; ++j) hipFree(c->status[j].p);
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
@@ -663,7 +672,8 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.c = contig_dev(k);
     a.first_ii = first_ii; a.n_pairs = n_pairs; a.rand_base = rand_base;
     a.l_place = k.l_place; a.have_regions = c->has_regions ? 1 : 0; a.n_reg = k.n_reg; a.reg_start = k.d_reg; a.reg_end = k.d_reg ? k.d_reg + k.n_reg : nullptr;
-    for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.qbase[j] = c->d_qbase[j]; }
+    for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.e_thr32[j] = c->d_thr32[j]; a.qbase[j] = c->d_qbase[j]; }
+    a.e_full = c->e_full;
     a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
     const uint64_t nblk = (n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;

@@ -1205,34 +1205,47 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
     }
     int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
     if (valid && (DT != 2 || is_rand)) {
-        const uint64_t *thr = j ? a.e_thr[1] : a.e_thr[0];
+        // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
+        const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
         uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
         for (int w = 0; w < nw; ++w) {
-            const uint32_t word = is_rand ? 0u : lds[w * nthr];
-            uint32_t out = 0;
+            uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
+            if (!is_rand) { ta = *reinterpret_cast<const uint4 *>(thr + 8 * w); tb = *reinterpret_cast<const uint4 *>(thr + 8 * w + 4); }
             const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w));
             const U4 q1 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w + 1));
             const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const int rem = s - 8 * w;
+            const uint32_t live = rem >= 8 ? 0xFFFFFFFFu : ((1u << (4 * rem)) - 1u);      // nibbles of bases i < s
+            uint32_t word;
+            if (is_rand) {                                                      // random read: base = (int)(u * 4.0) & 3 (dwgsim.c:999-1001)
+                word = 0;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int i = w * 8 + b;
-                if (i < s) {
-                    uint32_t c;
-                    if (is_rand) c = rw[b] >> 30;                       // (int)(u * 4.0) & 3
-                    else c = (word >> (4 * b)) & 15u;
-                    if (DT == 1) {                                      // colour space: __gf_add(previous base, base), dwgsim.h:6, dwgsim.c:845-858 / :1022-1032
-                        const uint32_t base = c;
-                        c = (prev_base >= 4 || base >= 4) ? 4u : (prev_base ^ base);
-                        prev_base = base;
-                    }
-                    if (!is_rand) {
-                        if (c >= 4) c = 4;
-                        else if ((uint64_t)rw[b] < thr[i]) { c |= 8u; ++n_err; if (DT == 1 && i == 0) err_first = 1; }
-                    }
-                    out |= c << (4 * b);
-                }
+                for (int b = 0; b < 8; ++b) word |= (rw[b] >> 30) << (4 * b);
+            } else word = lds[w * nthr];
+            if (DT == 1) {                                                      // colour = __gf_add(previous base, base): dwgsim.h:6, dwgsim.c:845-858 / :1022-1032
+                const uint32_t prevw = (word << 4) | prev_base;
+                prev_base = word >> 28;
+                const uint32_t n = (word | prevw) & 0x44444444u;                // either base is not ACGT -> colour 4
+                word = ((word ^ prevw) & 0x33333333u & ~((n >> 1) | (n >> 2))) | n;
+            } else {
+                const uint32_t n4 = word & 0x44444444u;                         // if (c >= 4) c = 4 (dwgsim.c:235)
+                word &= ~((n4 >> 1) | (n4 >> 2));
             }
-            lds[w * nthr] = out;
+            if (!is_rand) {                                                     // drand48() < e[i]  <=>  w < thr[i]; an error marks bit 3 of the nibble
+                const uint32_t t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+                uint32_t hits = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) hits |= (rw[b] < t[b]) ? (8u << (4 * b)) : 0u;
+                if (a.e_full) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) hits |= (t[b] == 0xFFFFFFFFu) ? (8u << (4 * b)) : 0u;
+                }
+                hits &= ~((word & 0x44444444u) << 1) & live;                    // N bases / colours take no error
+                n_err += __popc(hits);
+                if (DT == 1 && w == 0) err_first = (int32_t)((hits >> 3) & 1u);
+                word |= hits;
+            }
+            lds[w * nthr] = word & live;
         }
         if (!is_rand) {
             int w = 0; uint32_t pend = 0;

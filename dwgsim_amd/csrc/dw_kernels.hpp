@@ -72,6 +72,8 @@ struct SimArgs {
     int64_t l_place;               // the `l` that sizes fragment placement: contig length, or the contig's region length with -x (dwgsim.c:552)
     const int32_t *reg_start, *reg_end; int32_t n_reg, have_regions;   // -x: this contig's merged target regions (regions_bed.c)
     const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
+    const uint32_t *e_thr32[2];    // the same as 32-bit words, zero padded to a multiple of 8 entries; a threshold of 2^32 (e = 1) is stored as
+    int32_t e_full;                // 0xFFFFFFFF and flagged here: those positions always err
     const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics
     const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"
     const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"
