@@ -52,6 +52,26 @@ DW_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
+// byte-wise table lookup: byte i of the result = byte sel.byte[i] (0..7) of the eight-byte table {hi, lo}; one v_perm_b32
+DW_DEV uint32_t lut8(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#ifndef DW_EMU
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t t = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) r |= (uint32_t)((t >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+#endif
+}
+// the four nibbles of v[15:0] spread into the four bytes of the result
+DW_DEV uint32_t spread4(uint32_t v)
+{
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    return (v | (v << 4)) & 0x0F0F0F0Fu;
+}
+
 DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll

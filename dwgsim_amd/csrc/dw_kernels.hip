@@ -1035,6 +1035,8 @@ DW_DEV void put_hex(Out2<OUT> &o, uint64_t v)
     }
 }
 DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull >> (8 * (v & 7))) & 0xff); }  // "ACGTNNNN"
+DW_DEV uint32_t base_chars4(uint32_t nibbles) { return lut8(0x4E4E4E4Eu, 0x54474341u, spread4(nibbles)); }        // four codes (<= 7) -> "ACGTNNNN"[code]
+DW_DEV uint32_t colour_digits4(uint32_t nibbles) { return lut8(0x34343434u, 0x33323130u, spread4(nibbles)); }     // four colours -> "01234444"[colour]
 
 // K6: one lane per read end (LPP = 2: lanes 2q / 2q+1 are the two ends of pair q; LPP = 1: single end).
 // Opt-in phase timing (tools/phase_profile.sh builds a separate library with -DDW_PHASE_TIMING; the
@@ -1100,6 +1102,9 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
     }
     uint32_t m = 0; int pr = 0; const int np = (n + 1) >> 1;
     while (pr < np) {
+        // (the two base qualities are fetched before the arithmetic that hides their latency)
+        const int i0 = 2 * pr, i1 = 2 * pr + 1;
+        const int32_t qb0 = qb[i0 < nq ? i0 : nq - 1], qb1 = qb[i1 < nq ? i1 : nq - 1];
         const U4 blk = rng_block(key, dom, ii, att, m, (uint32_t)pr);
         // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
         const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
@@ -1114,7 +1119,7 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
             const int i = 2 * pr + h;
             const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
             if (i < n) {
-                int32_t q = (int8_t)(qb[i < nq ? i : nq - 1] + (int32_t)((nrm * p.quality_std) + 0.5));
+                int32_t q = (int8_t)((h ? qb1 : qb0) + (int32_t)((nrm * p.quality_std) + 0.5));
                 if (q < 33) q = 33;
                 if (q > 73) q = 73;
                 emit(i, (uint32_t)q);
@@ -1341,9 +1346,12 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
                 if (which == 0) o.putn((uint64_t)'/' | ((uint64_t)('2' - j) << 8) | ((uint64_t)'\n' << 16), 3);      // F3 is annotated "/2", R3 "/1" (dwgsim.c:938-939)
                 else { o.put('\n'); o.put('A'); }
                 const int first = which ? 0 : 1;                // BWA skips the first colour and its quality
-                for (int i = first; i < s_out; ++i) {
-                    const uint32_t c = (lds[(i >> 3) * nthr] >> (4 * (i & 7))) & 15u;
-                    o.put(which ? (uint32_t)'0' + (c > 4 ? 4 : c) : base_char(c));
+                for (int w = 0; w * 8 < s_out; ++w) {
+                    const uint32_t word = lds[w * nthr];
+                    const uint32_t c0 = which ? colour_digits4(word) : base_chars4(word), c1 = which ? colour_digits4(word >> 16) : base_chars4(word >> 16);
+                    const int lo = w == 0 ? first : 0, hi = s_out - w * 8 < 8 ? s_out - w * 8 : 8;
+                    if (lo == 0 && hi == 8) { o.put4(c0); o.put4(c1); }
+                    else for (int b = lo; b < hi; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
                 }
                 o.put('\n'); o.put('+'); o.put('\n');
                 for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out,
@@ -1374,9 +1382,11 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
             } else word = lds[w * nthr];
             const int rem = s_out - w * 8;
             if (rem >= 8) {
-                o.put4(base_char(word & 15) | base_char((word >> 4) & 15) << 8 | base_char((word >> 8) & 15) << 16 | base_char((word >> 12) & 15) << 24);
-                o.put4(base_char((word >> 16) & 15) | base_char((word >> 20) & 15) << 8 | base_char((word >> 24) & 15) << 16 | base_char(word >> 28) << 24);
-            } else for (int b = 0; b < rem; ++b) o.put(base_char((word >> (4 * b)) & 15));
+                o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16));
+            } else {
+                const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16);
+                for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
+            }
         }
         o.put('\n'); o.put('+'); o.put('\n');
         PH_MARK(5); // sequence line
