@@ -676,7 +676,8 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.e_full = c->e_full;
     a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
-    const uint64_t nblk = (n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
+    const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block (<= PAIRS_PER_BLOCK of k_place)
+    const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
     if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
     for (int j = 0; j < 4; ++j) if (ensure(c, c->status[j], sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
@@ -692,7 +693,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
     a.flow_scratch = nullptr;
     if (p.data_type == 2) {
-        const size_t nthr = (size_t)PAIRS_PER_BLOCK * (p.length[1] > 0 ? 2 : 1);
+        const size_t nthr = (size_t)SIM_THREADS;
         const size_t words = (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr * (size_t)(nblk ? nblk : 1);
         if (ensure(c, c->flow_scratch, words * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
         a.flow_scratch = (uint32_t *)c->flow_scratch.p;
@@ -744,7 +745,8 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     if (!a.p.has_bfast) cap[2] = 0;
     (void)nreads;
     for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
-    const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+    const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));
+    const uint32_t nblk = (uint32_t)((n_pairs + sim_ppb - 1) / sim_ppb);
     HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
     for (int j = 0; j < 4; ++j) HIPC(c, hipMemsetAsync(a.status[j], 0, sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(c->ev[0], c->stream));
@@ -759,9 +761,9 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];
     if (getenv("DWGSIM_HIP_PHASES")) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)
-        uint64_t tot = 0; for (int k = 0; k < 7; ++k) tot += c->h_counters[8 + k];
+        uint64_t tot = 0; for (int k = 0; k < 8; ++k) tot += c->h_counters[8 + k];
         fprintf(stderr, "[phases]");
-        for (int k = 0; k < 7; ++k) fprintf(stderr, " p%d=%.1f%%", k, tot ? 100.0 * c->h_counters[8 + k] / tot : 0.0);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.1f%%", k, tot ? 100.0 * c->h_counters[8 + k] / tot : 0.0);
         fprintf(stderr, " (ticks %llu)\n", (unsigned long long)tot);
     }
     if (out) {

@@ -55,6 +55,7 @@ DW_DEV uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *total)
 {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
     const uint32_t inc = wave_incl_scan(v);
+    if (nw == 1) { *total = (uint32_t)__shfl((int)inc, 63); return inc - v; }      // single-wave block: no LDS, no barrier
     __syncthreads();                       // protect sm from a previous use
     if (lane == 63) sm[wave] = inc;
     __syncthreads();
@@ -62,6 +63,24 @@ DW_DEV uint32_t block_excl_scan(uint32_t v, uint32_t *sm, uint32_t *total)
     __syncthreads();
     *total = sm[16];
     return inc - v + sm[wave];
+}
+
+// N independent block-wide exclusive scans behind ONE barrier.  sm = N x 16 words of LDS that nothing else in the kernel touches
+// (no protective barrier before the write, no serial pass: every thread adds up the wave totals below its own wave).
+template <int N>
+DW_DEV void block_excl_scan_n(const uint32_t (&v)[N], uint32_t (*sm)[16], uint32_t (&excl)[N], uint32_t (&total)[N])
+{
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    uint32_t inc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) { inc[n] = wave_incl_scan(v[n]); if (lane == 63) sm[n][wave] = inc[n]; }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        uint32_t base = 0, tot = 0;
+        for (int w = 0; w < nw; ++w) { const uint32_t t = sm[n][w]; tot += t; base += w < wave ? t : 0u; }
+        excl[n] = inc[n] - v[n] + base; total[n] = tot;
+    }
 }
 
 DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
@@ -575,6 +594,14 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
         pb = cb + dirc;
         if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
+#ifndef DW_EMU
+        // touch the following 128-byte lines of the read's window now (results unused): their HBM latency overlaps with the first
+        // chunks instead of being met one line at a time by the chunk loop
+        for (int t = 1; t <= 3 && (t - 1) * 128 < s; ++t) {
+            const int64_t pa = start + (int64_t)dirc * 128 * t;
+            if (pa >= 0 && pa < l) (void)*reinterpret_cast<const volatile uint32_t *>(h.cells + (pa & ~(int64_t)3));
+        }
+#endif
     }
     int64_t i = start;
     while (i >= 0 && i < l && k < s) {
@@ -1131,25 +1158,26 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
 
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 template <int LPP, int OUT, int DT>
-__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES - 1)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES - 1)) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
-    __shared__ uint32_t sm[17];
+    __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
     __shared__ uint32_t s_ticket;
-    __shared__ uint64_t s_base[3];
+    __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
     __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
-    const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK * LPP;
+    constexpr int nthr = SIM_THREADS, PPB = SIM_THREADS / LPP, nwaves = SIM_THREADS / 64;      // PPB pairs per block
+    const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     PH_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
-    if (tid < 64) s_fixed[0][tid] = reinterpret_cast<const uint32_t *>(a.name_fixed)[tid];      // buffers are padded to 256 + 16 bytes
-    else if (tid < 128) s_fixed[1][tid - 64] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[tid - 64];
+    for (int q = tid; q < 128; q += nthr)                                                          // buffers are padded to 256 + 16 bytes
+        (&s_fixed[0][0])[q] = q < 64 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 64];
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     __syncthreads();
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
     const int j = (LPP == 2) ? (tid & 1) : 0;
-    const uint64_t pair = (uint64_t)t * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);
+    const uint64_t pair = (uint64_t)t * PPB + (uint64_t)(tid / LPP);
     const bool valid = pair < a.n_pairs;
     const uint64_t ii = a.first_ii + pair;
     const RngKey key{a.p.seed, a.c.contig_index};
@@ -1172,6 +1200,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
             else if (s > 0) {
                 int64_t start; int step;
                 read_geom(a, pd, j, &start, &step);
+                PH_MARK(7);     // placement draws (phase 1 below is then the base extraction alone)
                 rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
                 ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
             }
@@ -1184,15 +1213,14 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
     }
     { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
     // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
-    uint32_t rtot;
-    const uint32_t rrank = block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &rtot);
+    uint32_t rrank, rtot;
+    { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     if (wave == 0) {
         const uint64_t g = lookback_excl(a.status[2], t, rtot, 0);
-        if (lane == 0) { s_base[0] = g; if ((uint64_t)t + 1 == (a.n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK) a.counters[3] = g + rtot; }
+        if (lane == 0) { s_rbase = g; if ((uint64_t)t + 1 == (a.n_pairs + PPB - 1) / PPB) a.counters[3] = g + rtot; }
     }
     __syncthreads();
-    const uint64_t rand_ii = a.rand_base + s_base[0] + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
-    __syncthreads();                                   // s_base is reused by the byte look-backs below
+    const uint64_t rand_ii = a.rand_base + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
     PH_MARK(1);     // placement + base extraction
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
@@ -1304,25 +1332,30 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP, (DT == 2 ? DW_ION_WAVES 
                                                   : (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s_out + 3u + (uint32_t)s_out + 1u);
 
     // ---- record offsets: block scan + decoupled look-back over logical blocks ----
-    uint32_t T1, T2;
-    const uint32_t e1 = block_excl_scan(j == 0 ? Lbwa : 0u, sm, &T1);
-    const uint32_t e2 = block_excl_scan(j == 1 ? Lbwa : 0u, sm, &T2);
-    uint32_t eb = 0, Tb = 0;
-    if (DT == 1) eb = block_excl_scan(emits ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : 0u, sm, &Tb);
+    uint32_t e1, e2, eb = 0, T1, T2, Tb = 0;
+    if (DT == 1) {
+        const uint32_t v[3] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u, emits ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : 0u};
+        uint32_t ex[3], tot[3]; block_excl_scan_n<3>(v, sm_bytes, ex, tot);
+        e1 = ex[0]; e2 = ex[1]; eb = ex[2]; T1 = tot[0]; T2 = tot[1]; Tb = tot[2];
+    } else {
+        const uint32_t v[2] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u};
+        uint32_t ex[2], tot[2]; block_excl_scan_n<2>(v, sm_bytes, ex, tot);
+        e1 = ex[0]; e2 = ex[1]; T1 = tot[0]; T2 = tot[1];
+    }
     if (wave == 0) {
         const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
         if (DT == 1) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
     }
-    else if (wave == 1) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
+    if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
     const uint64_t G1 = s_base[0], G2 = s_base[1];
-    const uint64_t reads_before_block = (uint64_t)t * PAIRS_PER_BLOCK * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
+    const uint64_t reads_before_block = (uint64_t)t * PPB * (uint64_t)LPP;
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
     // Illumina / Ion Torrent: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
     const uint64_t off_bf = (DT == 1) ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
     if (tid == nthr - 1) {
-        const uint64_t nblocks = (a.n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
+        const uint64_t nblocks = (a.n_pairs + PPB - 1) / PPB;
         if ((uint64_t)t + 1 == nblocks) {
             const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
             a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
@@ -1481,10 +1514,10 @@ void launch_sim_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, i
 void launch_sim_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
-    const uint32_t nb = cdiv(a.n_pairs, PAIRS_PER_BLOCK);
-    const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
-    const uint32_t nthr = PAIRS_PER_BLOCK * (pe ? 2 : 1);
+    const uint32_t nb = cdiv(a.n_pairs, SIM_THREADS / (pe ? 2 : 1));
+    const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
+    const uint32_t nthr = SIM_THREADS;
     const size_t lds = (size_t)(ion ? 4 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack (8 runs); its read buffers are in a.flow_scratch
     const bool solid = a.p.data_type == 1;
     if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else if (solid) launch_sim_2_1(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
@@ -1495,7 +1528,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
 #define DW_SIM_FAMILY(LPP, DT)                                                                                   \
     void launch_sim_##LPP##_##DT(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out)             \
     {                                                                                                            \
-        const uint32_t nthr = PAIRS_PER_BLOCK * LPP;                                                             \
+        const uint32_t nthr = SIM_THREADS;                                                                       \
         if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, DT>), dim3(nb), dim3(nthr), lds, st, a);            \
         else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT>), dim3(nb), dim3(nthr), lds, st, a);       \
         else hipLaunchKernelGGL((k_simulate<LPP, 3, DT>), dim3(nb), dim3(nthr), lds, st, a);                     \

@@ -5,7 +5,11 @@
 
 namespace dw {
 
-constexpr int PAIRS_PER_BLOCK = 128;     // k_place and k_simulate partition pairs identically
+constexpr int PAIRS_PER_BLOCK = 128;     // k_place / k_calibrate: pairs (reads) per block
+#ifndef DW_SIM_THREADS
+#define DW_SIM_THREADS 256
+#endif
+constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_POS_PER_BLOCK = SCAN_POS_PER_THREAD * SCAN_THREADS;   // 4096
