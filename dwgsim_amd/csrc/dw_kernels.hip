@@ -594,10 +594,10 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
         pb = cb + dirc;
         if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
-#ifndef DW_EMU
+#if !defined(DW_EMU) && !defined(DW_NO_TOUCH)
         // touch the following 128-byte lines of the read's window now (results unused): their HBM latency overlaps with the first
         // chunks instead of being met one line at a time by the chunk loop
-        for (int t = 1; t <= 3 && (t - 1) * 128 < s; ++t) {
+        for (int t = 1; t <= 3 && t * 128 < s; ++t) {                    // only addresses the read is sure to reach: no over-fetch
             const int64_t pa = start + (int64_t)dirc * 128 * t;
             if (pa >= 0 && pa < l) (void)*reinterpret_cast<const volatile uint32_t *>(h.cells + (pa & ~(int64_t)3));
         }
@@ -1219,8 +1219,8 @@ __global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1
         const uint64_t g = lookback_excl(a.status[2], t, rtot, 0);
         if (lane == 0) { s_rbase = g; if ((uint64_t)t + 1 == (a.n_pairs + PPB - 1) / PPB) a.counters[3] = g + rtot; }
     }
-    __syncthreads();
-    const uint64_t rand_ii = a.rand_base + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+    // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
+    // overlaps with that work instead of idling three waves)
     PH_MARK(1);     // placement + base extraction
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
@@ -1299,6 +1299,8 @@ __global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1
             }
         }
     }
+    __syncthreads();
+    const uint64_t rand_ii = a.rand_base + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
     PH_MARK(2);     // error tests + substitutions
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
     int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
