@@ -88,6 +88,7 @@ CASES = [
     # -B: the flow error is calibrated on 10^6 random reads before the run (dwgsim_opt.c:415-457)
     ("tiny.fa", f"-z 9 -N 1500 -c 2 -f {FLOW} -1 100 -2 0 -e 0.02 -B"),
     ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 60 -2 40 -e 0.03 -E 0.01 -d 300 -B -o 1"),
+    ("tiny.fa", "-z 9 -N 800 -c 2 -f TACG -1 50 -2 50 -e 0.02 -E 0.04 -d 300 -B"),            # equal lengths: end 2 takes end 1's rate (dwgsim_opt.c:425-431)
     # mutation-input files: -m txt, -v vcf, -b bed
     ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_generated.txt"),
     ("tiny.fa", "-z 5 -N 3000 -m {IN}/muts_edge.txt"),
