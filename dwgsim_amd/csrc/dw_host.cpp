@@ -65,7 +65,7 @@ struct dwgsim_hip_ctx {
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
     // simulate() working set
-    DevBuf meta, block_rand, status[4], out[2][3], scratch_mask, scratch_cnt;
+    DevBuf meta, block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
     DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
@@ -304,7 +304,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
-    for (int j = 0; j < 4; ++j) hipFree(c->status[j].p);
+    hipFree(c->status_all.p);
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
@@ -680,9 +680,9 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
     if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
-    for (int j = 0; j < 4; ++j) if (ensure(c, c->status[j], sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
     a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
-    for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status[j].p;
+    for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)(nblk ? nblk : 1);
     const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
@@ -748,7 +748,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));
     const uint32_t nblk = (uint32_t)((n_pairs + sim_ppb - 1) / sim_ppb);
     HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
-    for (int j = 0; j < 4; ++j) HIPC(c, hipMemsetAsync(a.status[j], 0, sizeof(uint64_t) * (size_t)nblk, c->stream));
+    HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(c->ev[0], c->stream));
     HIPC(c, hipEventRecord(c->ev[1], c->stream));      // (the attempt loop is part of k_simulate: one kernel per batch)
     launch_simulate(c->stream, a);

@@ -34,6 +34,9 @@
 #define DW_SIM_WAVES 5       // minimum waves per SIMD requested for the Illumina variants (one less when both output families are written):
                              // the kernel sits 1-2 VGPRs above these occupancy steps without the hint; measured +4 % at 5 vs 4 waves, 6 spills (so do the SOLiD variants with any hint)
 #endif
+#ifndef DW_SIM_WAVES_BOTH
+#define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0)
+#endif
 #ifndef DW_ION_WAVES
 #define DW_ION_WAVES 1       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants
 #endif
@@ -1158,7 +1161,7 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
 
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 template <int LPP, int OUT, int DT>
-__global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES - 1)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
