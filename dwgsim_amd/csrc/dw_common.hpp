@@ -109,11 +109,44 @@ DW_DEV double rng_slot(RngKey k, uint32_t dom, uint64_t idx, uint32_t att, uint3
 DW_DEV uint64_t dbl_bits(double x) { union { double d; uint64_t u; } c; c.d = x; return c.u; }
 DW_DEV double bits_dbl(uint64_t u) { union { double d; uint64_t u; } c; c.u = u; return c.d; }
 
+// IEEE-754 binary64 x / y and sqrt(x) for operands far from the ends of the exponent range and without special values:
+// exactly the Newton-Raphson + correction sequences the compiler emits for `/` and sqrt() on gfx950 (LLVM AMDGPU LowerFDIV64 /
+// lowerFSQRTF64) minus their v_div_scale / v_div_fixup / ldexp / class-test range handling, which is the identity on such
+// operands.  Used where the operand range is known (quality normals: y, x in [2^-62, 2^70]); dwgsim_hip_selftest_fp64 compares
+// them bit for bit with the compiler's own `/` and sqrt() (tests/test_gpu_parity.py).
+DW_DEV double div_mid(double x, double y)
+{
+#ifndef DW_EMU
+    const double r0 = __builtin_amdgcn_rcp(y);
+    const double r1 = __builtin_fma(r0, __builtin_fma(-y, r0, 1.0), r0);
+    const double r2 = __builtin_fma(r1, __builtin_fma(-y, r1, 1.0), r1);
+    const double q0 = x * r2;
+    return __builtin_fma(__builtin_fma(-y, q0, x), r2, q0);
+#else
+    return x / y;
+#endif
+}
+DW_DEV double sqrt_mid(double x)
+{
+#ifndef DW_EMU
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y, h0 = y * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double g2 = __builtin_fma(__builtin_fma(-g1, g1, x), h1, g1);
+    return __builtin_fma(__builtin_fma(-g2, g2, x), h1, g2);
+#else
+    return sqrt(x);
+#endif
+}
+
 // Natural log for finite x > 0 with only IEEE-754 fp64 + - * / (compile with -ffp-contract=off):
 // argument reduction x = 2^k (1+f), s = f/(2+f), even polynomial in s -- the classic fdlibm
 // e_log algorithm ("(c) 1993 Sun Microsystems, Inc. Permission to use, copy, modify, and
 // distribute this software is freely granted, provided that this notice is preserved").
 // Bit-identical on gfx950 and x86-64; the libm/ocml logs are not.
+// NORMAL = true: the caller guarantees a normal (not subnormal) argument, the 2^54 pre-scaling test is dropped (same bits for such x)
+template <bool NORMAL = false>
 DW_DEV double det_log(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
@@ -122,14 +155,14 @@ DW_DEV double det_log(double x)
                  Lg7 = 1.479819860511658591e-01;
     uint64_t b = dbl_bits(x);
     int32_t hx = (int32_t)(b >> 32), k = 0;
-    if (hx < 0x00100000) { x *= 0x1p54; k = -54; b = dbl_bits(x); hx = (int32_t)(b >> 32); }
+    if (!NORMAL && hx < 0x00100000) { x *= 0x1p54; k = -54; b = dbl_bits(x); hx = (int32_t)(b >> 32); }
     k += (hx >> 20) - 1023;
     hx &= 0x000fffff;
     int32_t i = (hx + 0x95f64) & 0x100000;
     x = bits_dbl(((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (b & 0xFFFFFFFFull));
     k += (i >> 20);
     const double f = x - 1.0, dk = (double)k;
-    const double s = f / (2.0 + f);
+    const double s = NORMAL ? div_mid(f, 2.0 + f) : f / (2.0 + f);       // 2 + f in [1.7, 2.42], f = 0 or |f| >= 2^-53
     const double z = s * s, w = z * z;
     const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
     const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));

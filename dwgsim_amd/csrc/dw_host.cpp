@@ -297,6 +297,21 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     return c;
 }
 
+// Not part of the drop-in ABI (include/dwgsim_hip.h): a device self-test used by tests/test_gpu_parity.py.  Compares the
+// range-restricted fp64 division / sqrt / log of the quality path with the compiler's general forms on n operand sets;
+// out[0..2] = bitwise differences (division, sqrt, log), out[3] = comparisons made.
+extern "C" int dwgsim_hip_selftest_fp64(int device, uint32_t seed, uint64_t n, uint64_t *out)
+{
+    if (!out || hipSetDevice(device) != hipSuccess) return DWGSIM_HIP_ERR_DEVICE;
+    uint64_t *d = nullptr;
+    if (hipMalloc((void **)&d, 4 * sizeof(uint64_t)) != hipSuccess) return DWGSIM_HIP_ERR_NOMEM;
+    hipMemset(d, 0, 4 * sizeof(uint64_t));
+    launch_selftest_fp64(nullptr, seed, n, d);
+    const hipError_t e = hipMemcpy(out, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? DWGSIM_HIP_OK : DWGSIM_HIP_ERR_DEVICE;
+}
+
 void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
 {
     if (!c) return;

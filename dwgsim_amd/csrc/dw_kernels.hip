@@ -1143,7 +1143,8 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
         const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
         if (!oka && !okb) { ++m; continue; }
         const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
-        const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+        // rsq is a multiple of 2^-62 in (0, 1): -2 log(rsq) in [2^-52, 86], the quotient in [2^-52, 2^69] -- the range-restricted forms apply
+        const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = 2 * pr + h;
@@ -1504,6 +1505,44 @@ void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, i
 void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells)
 {
     if (n) hipLaunchKernelGGL(k_gather, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, n, h0, h1, cells);
+}
+// Self-test of the range-restricted fp64 forms (dw_common.hpp) against the compiler's own `/`, sqrt() and the general det_log:
+// operands drawn exactly as the quality path draws them, plus mantissa x exponent pairs over [2^-70, 2^70].  mism[0..2] count
+// bitwise differences of div_mid, sqrt_mid, det_log<true>; mism[3] counts the comparisons made.
+__global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n, uint64_t *mism)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t bad_div = 0, bad_sqrt = 0, bad_log = 0, done = 0;
+    if (i < n) {
+        const RngKey key{seed, 0u};
+        const U4 b = rng_block(key, 31, i, 0, 0, 0), c = rng_block(key, 31, i, 0, 0, 1);
+        const double a1 = (double)b.x * 0x1p-31 - 1.0, a2 = (double)b.y * 0x1p-31 - 1.0, r = a1 * a1 + a2 * a2;
+        if (r < 1.0 && r != 0.0) {
+            const double l1 = det_log(r), l2 = det_log<true>(r);
+            bad_log += dbl_bits(l1) != dbl_bits(l2);
+            const double x = -2.0 * l1, q1 = x / r, q2 = div_mid(x, r);
+            bad_div += dbl_bits(q1) != dbl_bits(q2);
+            bad_sqrt += dbl_bits(sqrt(q1)) != dbl_bits(sqrt_mid(q1));
+            const double f = bits_dbl((dbl_bits(r) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull) - 1.0;       // a det_log-style f / (2 + f)
+            bad_div += dbl_bits(f / (2.0 + f)) != dbl_bits(div_mid(f, 2.0 + f));
+            done += 4;
+        }
+        const double x = ldexp(1.0 + u53(c.x, c.y), (int)(b.z % 141u) - 70), y = ldexp(1.0 + u53(c.z, c.w), (int)(b.w % 141u) - 70);
+        bad_div += dbl_bits(x / y) != dbl_bits(div_mid(x, y));
+        bad_sqrt += dbl_bits(sqrt(x)) != dbl_bits(sqrt_mid(x));
+        done += 2;
+    }
+    const uint32_t s0 = wave_sum_u32(bad_div), s1 = wave_sum_u32(bad_sqrt), s2 = wave_sum_u32(bad_log), s3 = wave_sum_u32(done);
+    if ((threadIdx.x & 63) == 0) {
+        if (s0) atomicAdd((unsigned long long *)&mism[0], (unsigned long long)s0);
+        if (s1) atomicAdd((unsigned long long *)&mism[1], (unsigned long long)s1);
+        if (s2) atomicAdd((unsigned long long *)&mism[2], (unsigned long long)s2);
+        atomicAdd((unsigned long long *)&mism[3], (unsigned long long)s3);
+    }
+}
+void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
+{
+    hipLaunchKernelGGL(k_selftest_fp64, dim3(cdiv(n, 256)), dim3(256), 0, st, seed, n, mism);
 }
 void launch_place(hipStream_t st, const SimArgs &a)
 {

@@ -19,4 +19,5 @@ void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t
 void launch_place(hipStream_t st, const SimArgs &a);
 void launch_simulate(hipStream_t st, const SimArgs &a);
 void launch_calibrate(hipStream_t st, const CalibArgs &a);
+void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism);
 }

@@ -105,6 +105,7 @@ static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(1); return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }

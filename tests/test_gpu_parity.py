@@ -79,3 +79,16 @@ def test_cli_is_a_drop_in_for_the_dwgsim_command(oracle_bin, golden_dir, tmp_pat
         assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k]
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
+
+
+def test_range_restricted_fp64_forms_equal_the_general_ones(lib):
+    """The quality path uses a division / sqrt / log specialised to its operand range (dw_common.hpp: div_mid, sqrt_mid,
+    det_log<true>): on 2^28 operand sets drawn as that path draws them (plus a 2^-70..2^70 exponent sweep) they must give the
+    same bits as the compiler's `/`, sqrt() and the general det_log."""
+    import ctypes as C
+    out = (C.c_uint64 * 4)()
+    lib.dwgsim_hip_selftest_fp64.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.dwgsim_hip_selftest_fp64.restype = C.c_int
+    for seed in (1, 2):
+        assert lib.dwgsim_hip_selftest_fp64(0, seed, 1 << 28, out) == 0
+        assert out[3] > (1 << 29) and (out[0], out[1], out[2]) == (0, 0, 0), list(out)
