@@ -39,6 +39,7 @@ struct Contig {
     size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
     uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
     uint32_t n_cand = 0, n_events_live = 0;
+    uint16_t *d_summ[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries for count_random (built on demand)
     int64_t l_place = 0;                // fragment-placement length (region length with -x)
     int32_t *d_reg = nullptr; int32_t n_reg = 0;   // -x: [start[0..n), end[0..n)] of this contig
 };
@@ -121,7 +122,7 @@ void free_contig(Contig &k)
 {
     hipFree(k.d_ref);
     for (int h = 0; h < 2; ++h) { hipFree(k.d_cells[h]); hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]); }
-    hipFree(k.d_name_fixed); hipFree(k.d_reg);
+    hipFree(k.d_name_fixed); hipFree(k.d_reg); hipFree(k.d_summ[0]); hipFree(k.d_summ[1]);
     k = Contig();
 }
 
@@ -452,7 +453,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             k.n_ins[h] = k.n_ins_bases[h] = 0;
         }
     }
-    k.mutated = true; k.n_cand = 0;
+    k.mutated = true; k.n_cand = 0; k.summ_valid = false;
     if (l == 0) return DWGSIM_HIP_OK;
     if (c->has_mutin) {      // file-driven mutations (mut.c:644-745): host resolves the entries, the GPU scatters and left-justifies
         ResolvedContig rc;
@@ -690,6 +691,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.e_thr32[j] = c->d_thr32[j]; a.qbase[j] = c->d_qbase[j]; }
     a.e_full = c->e_full;
     a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
+    a.summ[0] = k.d_summ[0]; a.summ[1] = k.d_summ[1];      // null unless count_random built them
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
     const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block (<= PAIRS_PER_BLOCK of k_place)
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
@@ -724,6 +726,14 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, 
     HIPC(c, hipSetDevice(c->device));
     if (n_random) *n_random = 0;
     if (n_pairs == 0) return DWGSIM_HIP_OK;
+    if (!kp->summ_valid) {         // per-64-cell summaries of the two haplotypes: let k_place accept clean windows without walking them
+        const size_t nb = (size_t)((kp->l + SUMM_CELLS - 1) / SUMM_CELLS);
+        for (int h = 0; h < 2; ++h) {
+            if (!kp->d_summ[h]) HIPC(c, hipMalloc((void **)&kp->d_summ[h], sizeof(uint16_t) * (nb ? nb : 1)));
+            launch_summarize(c->stream, kp->d_cells[h], kp->l, kp->d_summ[h]);
+        }
+        kp->summ_valid = true;
+    }
     SimArgs a;
     if (build_sim_args(c, *kp, first_ii, n_pairs, 0, a)) return DWGSIM_HIP_ERR_DEVICE;
     HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));

@@ -788,6 +788,45 @@ DW_DEV void read_geom(const SimArgs &a, const PairDraw &pd, int j, int64_t *star
 }
 
 #if DW_HAS(0)
+// Haplotype summary for k_place: one word per SUMM_CELLS cells -- how many of them are INSERT / DELETE cells (bit 4 of the cell),
+// and whether any holds a base code >= 4 (N, '-').
+__global__ void __launch_bounds__(256) k_summarize(const uint8_t *cells, int64_t l, uint16_t *summ)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, first = b * SUMM_CELLS;
+    if (first >= l) return;
+    uint32_t indel = 0, non_acgt = 0;
+#pragma unroll
+    for (int q = 0; q < SUMM_CELLS / 16; ++q) {
+        const int64_t at = first + 16 * q;
+        if (at >= l) break;
+        const uint4 v = *reinterpret_cast<const uint4 *>(cells + at);          // cells are readable (padded) up to a multiple of 16 past l
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t rem = l - (at + 4 * k);                              // cells of this word that belong to the contig
+            const uint32_t live = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ((1u << (8 * (int)rem)) - 1u);
+            indel += (uint32_t)__popc(w[k] & live & 0x10101010u);
+            non_acgt |= w[k] & live & 0x0C0C0C0Cu;
+        }
+    }
+    summ[b] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
+}
+
+// A sufficient condition for an attempt to be accepted (dwgsim.c:824-843) without walking the read: take the 2s+3 cells from
+// `start` in travel direction.  If they all lie inside the contig, none holds a base code >= 4 and at most s of them are
+// INSERT / DELETE cells, then the walk of __gen_read (one base per NOCHANGE / SUBSTITUTE cell, inserted bases are never N)
+// collects its s bases within those cells: ext_coor >= 0, k == s, num_n == 0 <= max_n.  Evaluated on the block summaries that
+// cover the window (a superset, so still sufficient); anything else falls back to the exact walk.
+DW_DEV bool attempt_surely_accepted(const uint16_t *summ, int64_t l, int64_t start, int step, int s)
+{
+    const int64_t far = start + (int64_t)step * (2 * (int64_t)s + 2);
+    const int64_t lo = step > 0 ? start : far, hi = step > 0 ? far : start;
+    if (lo < 0 || hi >= l) return false;
+    uint32_t indel = 0, flags = 0;
+    for (int64_t b = lo / SUMM_CELLS; b <= hi / SUMM_CELLS; ++b) { const uint32_t v = summ[b]; indel += v & 0xffu; flags |= v; }
+    return !(flags & 0x8000u) && indel <= (uint32_t)s;
+}
+
 // K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.
 // One lane per read end (LPP = 2: lanes 2q / 2q+1 test the two ends of pair q and exchange the verdict).
 template <int LPP>
@@ -809,8 +848,10 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
             else if (sj > 0) {
                 int64_t start; int step;
                 read_geom(a, pd, j, &start, &step);
-                const ReadRes r = gen_read<false>(sel_hap(a, pd.hap), a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
-                ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
+                if (!attempt_surely_accepted(pd.hap ? a.summ[1] : a.summ[0], a.c.l, start, step, sj)) {     // rare: N, dense indels, contig ends
+                    const ReadRes r = gen_read<false>(sel_hap(a, pd.hap), a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                    ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
+                }
             }
         }
         if (LPP == 2) { const int other = __shfl_xor((int)ok, 1); ok = ok && (other != 0); }   // every lane shuffles (no short-circuit)
@@ -1543,6 +1584,11 @@ __global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
 {
     hipLaunchKernelGGL(k_selftest_fp64, dim3(cdiv(n, 256)), dim3(256), 0, st, seed, n, mism);
+}
+void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ)
+{
+    const uint64_t nb = (uint64_t)(l + SUMM_CELLS - 1) / SUMM_CELLS;
+    if (nb) hipLaunchKernelGGL(k_summarize, dim3(cdiv(nb, 256)), dim3(256), 0, st, cells, l, summ);
 }
 void launch_place(hipStream_t st, const SimArgs &a)
 {

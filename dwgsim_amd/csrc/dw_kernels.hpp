@@ -69,6 +69,8 @@ struct CalibArgs {
     uint64_t *counters;             // [8] += errors, [9] += read lengths after errors, [2] |= 2 on a buffer overflow
 };
 
+constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_summarize / k_place)
+
 struct SimArgs {
     SimParams p;
     ContigDev c;
@@ -76,6 +78,7 @@ struct SimArgs {
     int64_t l_place;               // the `l` that sizes fragment placement: contig length, or the contig's region length with -x (dwgsim.c:552)
     const int32_t *reg_start, *reg_end; int32_t n_reg, have_regions;   // -x: this contig's merged target regions (regions_bed.c)
     const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
+    const uint16_t *summ[2];       // k_place only (else null): per SUMM_CELLS cells of a haplotype, bits 0-7 = INSERT / DELETE cells, bit 15 = a base code >= 4
     const uint32_t *e_thr32[2];    // the same as 32-bit words, zero padded to a multiple of 8 entries; a threshold of 2^32 (e = 1) is stored as
     int32_t e_full;                // 0xFFFFFFFF and flagged here: those positions always err
     const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics

@@ -141,3 +141,36 @@ def check_read_names_tell_the_truth(res, contigs, lengths, min_checked=200):
             exact += (n_err + n_sub == 0)
     assert checked >= min_checked and exact > 0
     return checked, exact
+
+
+def check_count_random_matches_simulate(lib, fasta, flags, ranges=((0, None), (17, 900), (1000, 1500))):
+    """dwgsim_hip_count_random (k_place: accepts clean windows from the haplotype summaries, walks the rest) must agree with
+    the random reads k_simulate itself produces for the same read-index range, retries included."""
+    flags = flags.replace("{IN}", IN_DIR)
+    params = api.parse_flags(flags, lib)
+    contigs = api.read_fasta(fasta)
+    tot = sum(len(a) for _, a in contigs)
+    ctx = api.Context(params, 0, lib)
+    have_regions = bool(getattr(params, "_regions", None))
+    if have_regions:
+        tot = ctx.set_regions(params._regions, contigs)
+    checked = 0
+    for idx, (name, arr) in enumerate(contigs):
+        l_eff = ctx.region_length(idx, arr) if have_regions else len(arr)
+        if l_eff < 0:
+            continue
+        n_pairs = api.pairs_for_contig(params, l_eff, tot, False, 0, lib)
+        if n_pairs <= 0:
+            continue
+        cid = ctx.add_contig(name, arr, idx)
+        if have_regions:
+            ctx.set_placement_length(cid, l_eff)
+        ctx.mutate(cid)
+        for first, n in ranges:
+            first = min(first, n_pairs - 1)
+            n = n_pairs - first if n is None else min(n, n_pairs - first)
+            want = ctx.simulate(cid, first, n, 0, 0)
+            assert ctx.count_random(cid, first, n) == int(want.n_random), (name, first, n)
+            checked += 1
+        ctx.drop_contig(cid)
+    assert checked > 0

@@ -46,3 +46,12 @@ def test_read_names_tell_the_truth_on_cpu_emulation(emu_lib, golden_dir):
     contigs = api.read_fasta(os.path.join(golden_dir, "tiny.fa"))
     res = api.run_job(params, contigs, batch_pairs=700, lib=emu_lib)
     check_read_names_tell_the_truth(res, contigs, [params.length[0], params.length[1]], min_checked=100)
+
+
+@pytest.mark.parametrize("fasta,flags", [
+    ("tiny.fa", "-z 9 -C 3 -y 0.15 -n 0"),
+    ("odd.fa", "-z 6 -C 3 -1 40 -2 40 -d 150 -s 10 -r 0.08 -R 0.8 -X 0.6 -n 1 -y 0.1"),
+])
+def test_count_random_matches_simulate_on_cpu_emulation(emu_lib, golden_dir, fasta, flags):
+    from parity_common import check_count_random_matches_simulate
+    check_count_random_matches_simulate(emu_lib, os.path.join(golden_dir, fasta), flags, ranges=((0, None), (17, 300)))

@@ -92,3 +92,18 @@ def test_range_restricted_fp64_forms_equal_the_general_ones(lib):
     for seed in (1, 2):
         assert lib.dwgsim_hip_selftest_fp64(0, seed, 1 << 28, out) == 0
         assert out[3] > (1 << 29) and (out[0], out[1], out[2]) == (0, 0, 0), list(out)
+
+
+@pytest.mark.parametrize("which,flags", [
+    ("tiny", "-z 9 -C 40 -y 0.15 -n 0"),
+    ("odd", "-z 6 -C 40 -1 40 -2 40 -d 150 -s 10 -r 0.08 -R 0.8 -X 0.6 -n 1 -y 0.1"),
+    ("odd", "-z 6 -C 30 -2 0 -1 120 -r 0.05 -R 0.9 -I 40 -y 0.3 -n 3"),
+    ("repeats", "-z 34 -C 2 -1 100 -2 100 -r 0.03 -R 0.5 -X 0.4 -n 5 -y 0.05"),
+    ("tiny", "-z 5 -x {IN}/regions_a.bed -C 30 -y 0.2"),
+])
+def test_count_random_matches_simulate(lib, golden_dir, repeats_fa, which, flags):
+    """The sharding primitive: k_place (summary fast path + exact walk) against k_simulate's own count, on N-rich contigs,
+    dense long indels, contig ends and target regions."""
+    from parity_common import check_count_random_matches_simulate
+    fasta = repeats_fa if which == "repeats" else os.path.join(golden_dir, which + ".fa")
+    check_count_random_matches_simulate(lib, fasta, flags)
