@@ -1,4 +1,4 @@
-// dw_host.cpp -- C-ABI (include/dwgsim_hip.h) over the HIP kernels of dw_kernels.hip.
+// dw_host.cpp -- C-ABI (include/dwgsim_hip.h) over the HIP kernels of dw_walk.hip / dw_simulate.hip.
 //
 // Host responsibilities, mirroring what dwgsim_core() does around its two hot loops:
 //   * option defaults / checks / error-ramp tables      (dwgsim_opt.c:40-80, :307-371, :459-460)

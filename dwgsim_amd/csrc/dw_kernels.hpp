@@ -1,4 +1,4 @@
-// dw_kernels.hpp -- argument blocks shared by the HIP kernels (dw_kernels.hip) and the
+// dw_kernels.hpp -- argument blocks shared by the HIP kernels (dw_walk.hip, dw_simulate.hip) and the
 // C-ABI host code (dw_host.cpp).
 #pragma once
 #include <stdint.h>

@@ -1,4 +1,4 @@
-// dw_launch.hpp -- host-callable launchers of the kernels in dw_kernels.hip
+// dw_launch.hpp -- host-callable launchers of the kernels in dw_walk.hip and dw_simulate.hip
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dw_kernels.hpp"

@@ -1,0 +1,472 @@
+// dw_read.hpp -- device code of one simulated read end, shared by k_place and k_simulate (dw_simulate.hip):
+//   placement / geometry / base extraction through indels (dwgsim.c:649-843, :75-153), the Ion Torrent flow-space error
+//   model (dwgsim.c:246-417), and the FASTQ text assembly (64-byte burst writer, packed decimal / hex fields).
+#pragma once
+#include "dw_device.hpp"
+
+namespace dw {
+
+// ------------------------------------------------------------------------------------------------
+// Read simulation
+// ------------------------------------------------------------------------------------------------
+struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n, n_ins; };   // n_ins: INSERT cells crossed (the reference's n_indel_first, dwgsim.c:98)
+
+// dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
+// The haplotype is read in 16-byte chunks with the next chunk prefetched; runs of up to 8 cells that
+// hold no INSERT/DELETE cell (bit 4 clear) are handled at once with byte-parallel arithmetic, any other
+// cell goes through the reference's per-cell logic.
+template <bool STORE>
+DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
+{
+    ReadRes r{-10, 0, 0, 0, 0};
+    int k = 0, kw = 0; uint64_t acc = 0; uint32_t nacc = 0;       // nacc nibbles pending in acc
+    auto push = [&](uint64_t nibs, uint32_t cnt) {                 // append cnt packed nibbles
+        if (STORE) {
+            acc |= nibs << (4 * nacc); nacc += cnt;
+            if (nacc >= 8) { lds[kw * stride] = (uint32_t)acc; acc >>= 32; nacc -= 8; ++kw; }
+        }
+        k += (int)cnt;
+    };
+    auto emit = [&](uint32_t v) {
+        if (strand) v = v < 4 ? 3 - v : 4;                 // dwgsim.c:150-152
+        r.num_n += (v == 4);                                // dwgsim.c:824-831
+        push(v, 1);
+    };
+    const int64_t last_chunk = (l - 1) >> 4;
+    const int dirc = step > 0 ? 1 : -1;
+    int64_t cb = -1, pb = -1; uint64_t clo = 0, chi = 0, plo = 0, phi = 0;
+    if (start >= 0 && start < l) {
+        cb = start >> 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (cb << 4));
+        clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        pb = cb + dirc;
+        if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
+#if !defined(DW_EMU) && !defined(DW_NO_TOUCH)
+        // touch the following 128-byte lines of the read's window now (results unused): their HBM latency overlaps with the first
+        // chunks instead of being met one line at a time by the chunk loop
+        for (int t = 1; t <= 3 && t * 128 < s; ++t) {                    // only addresses the read is sure to reach: no over-fetch
+            const int64_t pa = start + (int64_t)dirc * 128 * t;
+            if (pa >= 0 && pa < l) (void)*reinterpret_cast<const volatile uint32_t *>(h.cells + (pa & ~(int64_t)3));
+        }
+#endif
+    }
+    int64_t i = start;
+    while (i >= 0 && i < l && k < s) {
+        if ((i >> 4) != cb) {
+            cb = i >> 4;
+            if (cb == pb) { clo = plo; chi = phi; }
+            else { const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (cb << 4)); clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+            pb = cb + dirc;
+            if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
+        }
+        const uint64_t half = (i & 8) ? chi : clo;
+        const uint32_t off = (uint32_t)(i & 7);
+        // cells of this 8-byte half in travel order, limited by the half, the read and the contig end
+        uint32_t want = step > 0 ? 8 - off : off + 1;
+        const uint32_t left = (uint32_t)(s - k);
+        if (want > left) want = left;
+        if (step > 0) { const int64_t room = l - i; if ((int64_t)want > room) want = (uint32_t)room; }
+        uint64_t cells = step > 0 ? half >> (8 * off) : __builtin_bswap64(half << (8 * (7 - off)));
+        if (want < 8) cells &= (1ull << (8 * want)) - 1;
+        if ((cells & 0x1010101010101010ull) == 0) {           // only NOCHANGE / SUBSTITUTE cells: one base each
+            if (r.ext_coor < 0) { r.ext_coor = (int32_t)i; if (strand) r.ext_coor -= s - 1; }
+            r.n_sub += __popcll(cells & 0x2020202020202020ull);
+            uint64_t codes = cells & 0x0f0f0f0f0f0f0f0full;
+            const uint64_t ge4 = (codes >> 2) & 0x0101010101010101ull;
+            if (strand) {
+                codes = ((codes ^ 0x0303030303030303ull) & ~(ge4 * 0x0f)) | (ge4 << 2);
+                if (want < 8) codes &= (1ull << (8 * want)) - 1;
+                r.num_n += __popcll(ge4);
+            } else r.num_n += __popcll(ge4 & ~codes);          // exactly code 4 (code 5, '-', is not counted on this strand)
+            uint64_t x = codes;
+            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+            push(x, want);
+            i += (int64_t)step * want;
+            continue;
+        }
+        const uint32_t c = (uint32_t)(half >> (8 * off)) & 0xffu, mt = c & TMASK;
+        if (r.ext_coor < 0) {
+            if (mt != T_NONE && mt != T_SUB) { i += step; continue; }
+            r.ext_coor = (int32_t)i;
+            if (strand) r.ext_coor -= s - 1;
+        }
+        if (mt == T_DEL) { ++r.n_indel; if (strand) r.ext_coor--; }
+        else if (mt == T_NONE || mt == T_SUB) { emit(c & 0xf); if (mt == T_SUB) ++r.n_sub; }
+        else {
+            ++r.n_indel; ++r.n_ins;
+            const uint32_t idx = ins_find(h, i);
+            uint32_t n = h.ins_len[idx];
+            const uint8_t *P = h.ins_bases + h.ins_off[idx];
+            if (!strand) {
+                if (k < s) emit(c & 0xf);
+                for (uint32_t t = 0; t < n && k < s; ++t) emit(P[t] & 3u);
+            } else {
+                while (n > 0 && k < s) { r.ext_coor++; emit(P[n - 1] & 3u); --n; }
+                if (k < s) emit(c & 0xf);
+            }
+        }
+        i += step;
+    }
+    if (STORE && nacc) lds[kw * stride] = (uint32_t)acc;
+    if (k != s) r.ext_coor = -10;
+    return r;
+}
+
+struct PairDraw { bool is_rand; int32_t pos, d; int hap, strand0, strand1; };
+
+// select-by-value accessors: dynamic indexing into the by-value kernel argument block would force a
+// private copy of the whole struct (promoted to LDS by the backend)
+DW_DEV HapDev sel_hap(const SimArgs &a, int h)
+{
+    HapDev r;
+    r.cells = h ? a.c.hap[1].cells : a.c.hap[0].cells;
+    r.ins_pos = h ? a.c.hap[1].ins_pos : a.c.hap[0].ins_pos;
+    r.ins_len = h ? a.c.hap[1].ins_len : a.c.hap[0].ins_len;
+    r.ins_off = h ? a.c.hap[1].ins_off : a.c.hap[0].ins_off;
+    r.ins_bases = h ? a.c.hap[1].ins_bases : a.c.hap[0].ins_bases;
+    r.n_ins = h ? a.c.hap[1].n_ins : a.c.hap[0].n_ins;
+    return r;
+}
+DW_DEV int sel_len(const SimArgs &a, int j) { return j ? a.p.len[1] : a.p.len[0]; }
+
+// dwgsim.c:649-742: random-read test, fragment size + position, haplotype, strands
+DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t att)
+{
+    PairDraw pd; pd.pos = 0; pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
+    const U4 b0 = rng_block(key, D_PAIR, ii, att, 0, 0);
+    pd.is_rand = !(a.p.rand_read < u_lo(b0));
+    if (pd.is_rand) return pd;
+    const int s0 = a.p.len[0], s1 = a.p.len[1];
+    const int64_t l = a.l_place, sl = a.c.l;          // placement length (region length with -x) vs contig length
+    if (a.p.amplicons) { pd.pos = 0; pd.d = (int32_t)sl; }
+    else {
+        uint32_t t = 0; int32_t pos, d; bool continue_flag = false;
+        do {
+            if (s1 > 0) {
+                double v1, v2, rsq; uint32_t r = 0;
+                do {
+                    const U4 b = rng_block(key, D_PLACE_NORM, ii, att, r, t);
+                    v1 = 2.0 * u_lo(b) - 1.0; v2 = 2.0 * u_hi(b) - 1.0;
+                    rsq = v1 * v1 + v2 * v2; ++r;
+                } while (rsq >= 1.0 || rsq == 0.0);
+                const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+                double ran = v2 * fac;
+                ran = ran * a.p.std_dev + a.p.dist;
+                d = (int32_t)(ran + 0.5);
+                const int32_t min_dist = s0 + s1;
+                if (d < min_dist) d = min_dist;
+                if ((int64_t)d > l) d = (int32_t)l;
+            } else d = 0;
+            const int64_t range = l - d + 1;
+            pos = (int32_t)((double)range * rng_slot(key, D_PLACE, ii, att, t));
+            bool inside = true;
+            if (a.have_regions) {                         // dwgsim.c:696-707: region coordinate -> contig coordinate, then regions_bed_query (:712)
+                for (int q = 0; q < a.n_reg; ++q) {
+                    const int32_t jl = a.reg_end[q] - a.reg_start[q];
+                    if (pos < jl) { pos = a.reg_start[q] + pos - 1; break; }
+                    pos -= jl;
+                }
+                inside = false;                           // regions are sorted and disjoint: "some region contains [pos, pos + d)" (regions_bed.c:130-156)
+                int lo = 0, hi = a.n_reg - 1;
+                const uint32_t qs = (uint32_t)pos, qe = (uint32_t)(pos + d);
+                while (lo <= hi) {
+                    const int mid = lo + (hi - lo) / 2;
+                    if (qs < (uint32_t)a.reg_start[mid]) hi = mid - 1;
+                    else if ((uint32_t)a.reg_end[mid] < qe) lo = mid + 1;
+                    else { inside = true; break; }
+                }
+            }
+            ++t;
+            if (t > (1u << 20)) { pd.hap = -1; break; }   // the reference would never terminate here; reported as an error by the caller
+            continue_flag = !inside;
+        } while (continue_flag || pos < 0 || pos >= sl || (int64_t)pos + d - 1 >= sl
+                 || (s1 > 0 && !a.p.is_inner && ((s0 > 0 && d <= s1) || (d <= s0 && s1 > 0))));
+        pd.pos = pos; pd.d = d;
+    }
+    if (pd.hap < 0) { pd.hap = 0; pd.pos = 0; pd.d = (int32_t)(s0 + s1 < sl ? s0 + s1 : sl); atomicOr((unsigned long long *)&a.counters[2], 4ull); return pd; }
+    pd.hap = u_hi(b0) < a.p.mut_freq ? 0 : 1;
+    switch (a.p.read_one_strand) {
+    case 0: pd.strand0 = rng_slot(key, D_PAIR, ii, att, 2) < 0.5 ? 1 : 0; break;
+    case 1: pd.strand0 = 0; break;
+    default: pd.strand0 = 1; break;
+    }
+    switch (a.p.strandedness) {
+    case 0: pd.strand1 = (a.p.data_type == 0) ? 1 - pd.strand0 : pd.strand0; break;
+    case 1: pd.strand1 = pd.strand0; break;
+    default: pd.strand1 = 1 - pd.strand0; break;
+    }
+    return pd;
+}
+
+// dwgsim.c:745-821: first cell and direction of read end j
+DW_DEV void read_geom(const SimArgs &a, const PairDraw &pd, int j, int64_t *start, int *step)
+{
+    const int64_t pos = pd.pos, d = pd.d, s0 = a.p.len[0], s1 = a.p.len[1], sl = a.c.l;
+    const bool amp = a.p.amplicons != 0, inner = a.p.is_inner != 0;
+    if (s1 > 0) {
+        const int64_t far_outer = pos + d - 1;
+        if (pd.strand0 == pd.strand1) {
+            if (pd.strand0 == 0) {
+                if (j == 0) { *start = amp ? sl - 1 : (inner ? pos + s1 + d - 1 : pos + d - s0); *step = 1; }
+                else { *start = pos; *step = 1; }
+            } else {
+                if (j == 0) { *start = pos + s0 - 1; *step = -1; }
+                else { *start = amp ? sl - 1 : (inner ? pos + s0 + d + s1 - 1 : far_outer); *step = -1; }
+            }
+        } else {
+            if (pd.strand0 == 0) {
+                if (j == 0) { *start = pos; *step = 1; }
+                else { *start = amp ? sl - 1 : (inner ? pos + s0 + d + s1 - 1 : far_outer); *step = -1; }
+            } else {
+                if (j == 0) { *start = amp ? sl - 1 : (inner ? pos + s1 + d + s0 - 1 : far_outer); *step = -1; }
+                else { *start = pos; *step = 1; }
+            }
+        }
+    } else {
+        if (pd.strand0 == 0) { *start = pos; *step = 1; }
+        else if (amp) { *start = sl - 1; *step = -1; }
+        else { *start = pos + s0 - 1; *step = -1; }
+    }
+}
+
+// ---- Ion Torrent flow-space errors: dwgsim.c:246-417 generate_errors_flows ----
+// The reference edits the read in place; both passes only ever insert/delete at the position being
+// examined, so they are replayed as transducers over packed 4-bit arrays in LDS (word w of a lane
+// at base[w * stride]).  Draws: narrow uniforms of domain D_FLOW0 + read end, one sequential slot
+// counter per read end.  The flow mask is per read (the reference's persistent mask is fully
+// rewritten by every read's pass 1).
+// word-cached access to a lane's packed array (BITS = 4: codes 0-5, BITS = 2: bases 0-3): the flow model reads and
+// appends sequentially, so one LDS access serves 8 / 16 bases
+template <int BITS>
+struct PackReader {
+    static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4; static constexpr uint32_t M = (1u << BITS) - 1;
+    const uint32_t *base; int stride, cw; uint32_t word;
+    DW_DEV void init(const uint32_t *b, int st) { base = b; stride = st; cw = -1; word = 0; }
+    DW_DEV uint32_t get(int i) { const int w = i >> SH; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & (PER - 1)) * BITS)) & M; }
+};
+template <int BITS>
+struct PackAppender {
+    static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4;
+    uint32_t *base; int stride, n; uint32_t acc;
+    DW_DEV void init(uint32_t *b, int st) { base = b; stride = st; n = 0; acc = 0; }
+    DW_DEV void push(uint32_t v) { acc |= v << ((n & (PER - 1)) * BITS); if ((++n & (PER - 1)) == 0) { base[((n >> SH) - 1) * stride] = acc; acc = 0; } }
+    DW_DEV void flush() { if (n & (PER - 1)) base[(n >> SH) * stride] = acc; }
+};
+struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
+    uint32_t seed, contig, dom, att, slot, w0, w1, w2, w3; uint64_t ii;
+    DW_DEV uint32_t next()
+    {
+        if ((slot & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, 0, slot >> 2); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
+        const uint32_t k = slot & 3; ++slot;
+        const uint32_t lo = (k & 1) ? w1 : w0, hi = (k & 1) ? w3 : w2;
+        return (k & 2) ? hi : lo;
+    }
+    DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr) ++n; return n; }   // while (drand48() < e) n_err++
+};
+// Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
+// bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
+// (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: 8 (base, count) runs, two per word.
+DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
+                       int len, int strand, int cap, int32_t *n_err_out)
+{
+    // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
+    PackReader<4> rd, la; rd.init(bufA, stride); la.init(bufA, stride);
+    auto in = [&](PackReader<4> &r, int t) -> uint32_t { const uint32_t v = r.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
+    uint64_t mask = 0; int flow_i = 0, total = 0;
+    { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
+    // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
+    PackAppender<2> o1; o1.init(bufB, stride);
+    int t = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
+    for (;;) {
+        uint32_t c; bool from_pend = false;
+        if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
+        if (o1.n >= cap) return -1;
+        while (c != flow[flow_i]) { mask &= ~(1ull << flow_i); flow_i = flow_i + 1 == F ? 0 : flow_i + 1; }
+        if (prev_c != c) {
+            mask &= ~(1ull << flow_i);
+            int n_err = rg.geometric(thr);
+            if (n_err > 0) {
+                if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
+                    o1.push(c); pend_c = c; pend_n = n_err - 1;
+                    total += n_err; prev_c = c;
+                    continue;
+                }
+                int hp_l = 0; uint32_t next_c = c;              // delete: bounded by the homopolymer length
+                while (t + hp_l < len) { next_c = in(la, t + hp_l); if (next_c != c) break; ++hp_l; }
+                if (n_err > hp_l) n_err = hp_l;
+                t += n_err; mask |= 1ull << flow_i; total += n_err;
+                if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
+                    if (next_c == c) return -1;                // the whole read was one deleted homopolymer (the reference asserts)
+                    int jj = 0; while (next_c != flow[(flow_i + jj) % F]) ++jj;
+                    const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
+                    o1.push(flow[(flow_i + kk) % F]);
+                } else if (t < len) { o1.push(in(rd, t)); ++t; }   // the base now at this position is not examined
+                prev_c = c;
+                continue;
+            }
+            prev_c = c;
+        }
+        o1.push(c);
+        if (from_pend) --pend_n; else ++t;
+    }
+    o1.flush();
+    const int n1 = o1.n;
+    // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
+    // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order. ----
+    PackReader<2> r2; r2.init(bufB, stride);
+    PackAppender<4> o2; o2.init(bufA, stride);
+    auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
+    auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
+    int t2 = 0, sp = 0;
+    for (;;) {
+        uint32_t x;
+        if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else break;
+        if (o2.n >= cap) return -1;
+        while (x != flow[flow_i]) {                 // empty flows in front of the examined base: each may insert
+            const int n_err = rg.geometric(thr);
+            if (!((mask >> flow_i) & 1) && n_err > 0) {
+                if (sp >= 8 || n_err >= (1 << 14)) return -1;
+                stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp;
+                total += n_err;
+            }
+            flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
+        }
+        if (sp == 0) { o2.push(x); ++t2; }          // nothing in front of it: the base itself becomes final
+        else {                                      // the first base of the top run (the examined base stays behind it)
+            const uint32_t top = stk_get(sp - 1);
+            o2.push(top >> 14);
+            if ((top & 0x3fffu) <= 1) --sp; else stk_set(sp - 1, top - 1);
+        }
+    }
+    o2.flush();
+    *n_err_out += total;
+    return o2.n;
+}
+
+// ---- FASTQ text assembly ----
+struct Writer {               // sequential byte stream -> bursts of 64-byte aligned chunks
+    // A lane's record is cut at 64-byte boundaries of the output buffer; a chunk is assembled in registers
+    // (three finished 16-byte sub-blocks in s0..s5, the one being filled in lo/hi) and leaves as four
+    // back-to-back dwordx4 stores, so L2 sees whole 64-byte request units instead of 16-byte crumbs
+    // (partially written lines were being evicted and written back 2.6x, profiles/r01_p3).
+    // Only the first / last chunk of a record is ragged: bytes [skip, upto) go out as dwords / bytes.
+    uint8_t *blk; uint64_t lo, hi, s0, s1, s2, s3, s4, s5; uint32_t n, sub, skip;
+    DW_DEV void init(uint8_t *p)
+    {
+        const uint32_t o = (uint32_t)((uintptr_t)p & 63);
+        blk = p - o; sub = o >> 4; n = o & 15; skip = o;
+        lo = hi = s0 = s1 = s2 = s3 = s4 = s5 = 0;
+    }
+    static DW_DEV void store16(uint8_t *dst, uint64_t a, uint64_t b, uint32_t from, uint32_t upto)   // bytes [from, upto) of a 16-byte block
+    {
+        if (from == 0 && upto == 16) { *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); return; }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t w = (uint32_t)((q < 2 ? a : b) >> (32 * (q & 1)));
+            const uint32_t b0 = 4 * q, b1 = b0 + 4;
+            if (from <= b0 && upto >= b1) *reinterpret_cast<uint32_t *>(dst + b0) = w;
+            else for (uint32_t k = b0; k < b1; ++k) if (k >= from && k < upto) dst[k] = (uint8_t)(w >> (8 * (k - b0)));
+        }
+    }
+    DW_DEV void store_chunk(uint32_t upto)       // bytes [skip, upto) of the current chunk
+    {
+        if (skip == 0 && upto == 64) {           // the common case: one 64-byte burst
+            uint4 *d = reinterpret_cast<uint4 *>(blk);
+            d[0] = make_uint4((uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32));
+            d[1] = make_uint4((uint32_t)s2, (uint32_t)(s2 >> 32), (uint32_t)s3, (uint32_t)(s3 >> 32));
+            d[2] = make_uint4((uint32_t)s4, (uint32_t)(s4 >> 32), (uint32_t)s5, (uint32_t)(s5 >> 32));
+            d[3] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            return;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t b0 = 16 * q;
+            if (upto <= b0 || skip >= b0 + 16) continue;
+            const uint64_t a = (q == sub) ? lo : (q == 0 ? s0 : q == 1 ? s2 : s4);
+            const uint64_t b = (q == sub) ? hi : (q == 0 ? s1 : q == 1 ? s3 : s5);
+            const uint32_t from = skip > b0 ? skip - b0 : 0, to = upto < b0 + 16 ? upto - b0 : 16;
+            store16(blk + b0, a, b, from, to);
+        }
+    }
+    DW_DEV void advance()                        // the 16-byte sub-block in lo/hi is complete
+    {
+        if (sub == 3) { store_chunk(64); blk += 64; sub = 0; skip = 0; }
+        else {      // value selects, not conditional stores: keeps s0..s5 in registers
+            const bool z0 = sub == 0, z1 = sub == 1, z2 = sub == 2;
+            s0 = z0 ? lo : s0; s1 = z0 ? hi : s1; s2 = z1 ? lo : s2; s3 = z1 ? hi : s3; s4 = z2 ? lo : s4; s5 = z2 ? hi : s5;
+            ++sub;
+        }
+        lo = hi = 0; n = 0;
+    }
+    DW_DEV void put(uint32_t b)
+    {
+        const uint64_t v = (uint64_t)b << (8 * (n & 7));
+        if (n < 8) lo |= v; else hi |= v;
+        if (++n == 16) advance();
+    }
+    DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes, little-endian in v, upper bytes zero
+    {
+        const uint32_t sh = 8 * (n & 7);
+        if (n < 8) { lo |= v << sh; if (sh) hi |= v >> (64 - sh); }
+        else hi |= v << sh;
+        const uint32_t total = n + cnt;
+        if (total >= 16) {
+            const uint32_t over = total - 16;       // bytes that belong to the next sub-block (0..7)
+            const uint64_t carry = over ? v >> (8 * (cnt - over)) : 0;
+            advance();
+            lo = carry; n = over;
+        } else n = total;
+    }
+    DW_DEV void put4(uint32_t w) { putn((uint64_t)w, 4); }
+    DW_DEV void flush() { const uint32_t upto = 16 * sub + n; if (upto > skip) store_chunk(upto); }
+};
+template <int OUT>            // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream
+struct Out2 {
+    Writer a, b;
+    DW_DEV void put(uint32_t c) { if (OUT & 1) a.put(c); if (OUT & 2) b.put(c); }
+    DW_DEV void put4(uint32_t w) { if (OUT & 1) a.put4(w); if (OUT & 2) b.put4(w); }
+    DW_DEV void putn(uint64_t v, uint32_t cnt) { if (OUT & 1) a.putn(v, cnt); if (OUT & 2) b.putn(v, cnt); }
+    DW_DEV void flush() { if (OUT & 1) a.flush(); if (OUT & 2) b.flush(); }
+};
+DW_DEV uint32_t ndigits10(uint32_t v)
+{
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+DW_DEV uint32_t ndigits16(uint64_t v) { return v ? (uint32_t)(67 - __clzll((long long)v)) >> 2 : 1u; }
+// decimal digits of v as packed ASCII, most significant digit in the lowest byte (stream order);
+// lead = one separator byte to emit in front (0 = none).  Numbers above 10^7 take the two-part path.
+template <int OUT>
+DW_DEV void put_dec(Out2<OUT> &o, uint32_t v, uint32_t lead)
+{
+    uint32_t low7 = 0; bool big = false;
+    if (v >= 10000000u) { const uint32_t hi = v / 10000000u; low7 = v - hi * 10000000u; v = hi; big = true; }   // 8..10 digits
+    uint64_t w = 0; uint32_t nd = 0;
+    do { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; ++nd; } while (v);
+    if (lead) { w = (w << 8) | lead; ++nd; }
+    o.putn(w, nd);
+    if (big) {                                 // the low seven digits, zero padded
+        w = 0;
+        for (int d = 0; d < 7; ++d) { const uint32_t q = low7 / 10u; w = (w << 8) | ('0' + (low7 - q * 10u)); low7 = q; }
+        o.putn(w, 7);
+    }
+}
+template <int OUT>
+DW_DEV void put_hex(Out2<OUT> &o, uint64_t v)
+{
+    const uint32_t nd = ndigits16(v);
+    for (uint32_t part = 0; part < 2; ++part) {      // up to 16 digits: the high (nd-8) first, then the low 8
+        const uint32_t cnt = part == 0 ? (nd > 8 ? nd - 8 : 0) : (nd > 8 ? 8 : nd);
+        if (!cnt) continue;
+        const uint64_t x = part == 0 ? v >> 32 : (nd > 8 ? (v & 0xFFFFFFFFull) : v);
+        uint64_t w = 0;
+        for (uint32_t d = 0; d < cnt; ++d) { const uint32_t hx = (uint32_t)(x >> (4 * d)) & 15u; w = (w << 8) | (hx < 10 ? '0' + hx : 'a' + (hx - 10)); }
+        o.putn(w, cnt);
+    }
+}
+DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull >> (8 * (v & 7))) & 0xff); }  // "ACGTNNNN"
+DW_DEV uint32_t base_chars4(uint32_t nibbles) { return lut8(0x4E4E4E4Eu, 0x54474341u, spread4(nibbles)); }        // four codes (<= 7) -> "ACGTNNNN"[code]
+DW_DEV uint32_t colour_digits4(uint32_t nibbles) { return lut8(0x34343434u, 0x33323130u, spread4(nibbles)); }     // four colours -> "01234444"[colour]
+
+} // namespace dw

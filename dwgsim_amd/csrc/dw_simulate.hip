@@ -1,0 +1,632 @@
+// dw_simulate.hip -- hand-written HIP kernels (gfx950 / MI355X) of the per-read-pair loop
+// (replaces the loop body src/dwgsim.c:636-1099 of the reference).
+//
+//     k_simulate      per read end: attempt loop (placement, haplotype, strands, base extraction through indels, N filter),
+//                     errors (Illumina base space / SOLiD colour space / Ion Torrent flow space), qualities, FASTQ formatting,
+//                     decoupled look-back for record offsets, 64-byte burst stores
+//     k_summarize, k_place   dwgsim_hip_count_random (sharding): random reads in a read-index range without producing them
+//     k_calibrate     -B: per-base calibration of the Ion Torrent flow error (dwgsim_opt.c:415-457)
+//     k_selftest_fp64 device self-test of the range-restricted fp64 forms (dw_common.hpp)
+//
+// Byte/integer work plus fp64 for the normals: no MFMA.  fp64 expressions mirror the reference's evaluation order; compile
+// with -ffp-contract=off.
+//
+// The file is compiled in parts so the k_simulate variants build in parallel (csrc/Makefile):
+//   DW_PART 0: k_summarize, k_place, k_selftest_fp64, host launchers and the k_simulate dispatcher
+//   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
+//   DW_PART -1 (default): everything in one translation unit
+#include "dw_read.hpp"
+#include "dw_launch.hpp"
+
+#ifndef DW_PART
+#define DW_PART -1
+#endif
+#define DW_HAS(part) (DW_PART == -1 || DW_PART == (part))
+#ifndef DW_SIM_WAVES
+#define DW_SIM_WAVES 5       // minimum waves per SIMD requested for the Illumina variants (one less when both output families are written):
+                             // the kernel sits 1-2 VGPRs above these occupancy steps without the hint; measured +4 % at 5 vs 4 waves, 6 spills (so do the SOLiD variants with any hint)
+#endif
+#ifndef DW_SIM_WAVES_BOTH
+#define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0)
+#endif
+#ifndef DW_ION_WAVES
+#define DW_ION_WAVES 1       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants
+#endif
+
+namespace dw {
+
+#if DW_HAS(0)
+// Haplotype summary for k_place: one word per SUMM_CELLS cells -- how many of them are INSERT / DELETE cells (bit 4 of the cell),
+// and whether any holds a base code >= 4 (N, '-').
+__global__ void __launch_bounds__(256) k_summarize(const uint8_t *cells, int64_t l, uint16_t *summ)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, first = b * SUMM_CELLS;
+    if (first >= l) return;
+    uint32_t indel = 0, non_acgt = 0;
+#pragma unroll
+    for (int q = 0; q < SUMM_CELLS / 16; ++q) {
+        const int64_t at = first + 16 * q;
+        if (at >= l) break;
+        const uint4 v = *reinterpret_cast<const uint4 *>(cells + at);          // cells are readable (padded) up to a multiple of 16 past l
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t rem = l - (at + 4 * k);                              // cells of this word that belong to the contig
+            const uint32_t live = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ((1u << (8 * (int)rem)) - 1u);
+            indel += (uint32_t)__popc(w[k] & live & 0x10101010u);
+            non_acgt |= w[k] & live & 0x0C0C0C0Cu;
+        }
+    }
+    summ[b] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
+}
+
+// A sufficient condition for an attempt to be accepted (dwgsim.c:824-843) without walking the read: take the 2s+3 cells from
+// `start` in travel direction.  If they all lie inside the contig, none holds a base code >= 4 and at most s of them are
+// INSERT / DELETE cells, then the walk of __gen_read (one base per NOCHANGE / SUBSTITUTE cell, inserted bases are never N)
+// collects its s bases within those cells: ext_coor >= 0, k == s, num_n == 0 <= max_n.  Evaluated on the block summaries that
+// cover the window (a superset, so still sufficient); anything else falls back to the exact walk.
+DW_DEV bool attempt_surely_accepted(const uint16_t *summ, int64_t l, int64_t start, int step, int s)
+{
+    const int64_t far = start + (int64_t)step * (2 * (int64_t)s + 2);
+    const int64_t lo = step > 0 ? start : far, hi = step > 0 ? far : start;
+    if (lo < 0 || hi >= l) return false;
+    uint32_t indel = 0, flags = 0;
+    for (int64_t b = lo / SUMM_CELLS; b <= hi / SUMM_CELLS; ++b) { const uint32_t v = summ[b]; indel += v & 0xffu; flags |= v; }
+    return !(flags & 0x8000u) && indel <= (uint32_t)s;
+}
+
+// K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.
+// One lane per read end (LPP = 2: lanes 2q / 2q+1 test the two ends of pair q and exchange the verdict).
+template <int LPP>
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
+{
+    __shared__ uint32_t sm[17];
+    const int tid = (int)threadIdx.x, j = (LPP == 2) ? (tid & 1) : 0;
+    const uint64_t pair = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);
+    const bool valid = pair < a.n_pairs;
+    const uint64_t ii = a.first_ii + pair;
+    const RngKey key{a.p.seed, a.c.contig_index};
+    const int sj = sel_len(a, j);
+    uint32_t att = 0; bool is_rand = false, failed = false, done = !valid;
+    while (__ballot(!done)) {                      // wave-uniform loop: the two lanes of a pair always agree on `done`
+        bool ok = true;
+        if (!done) {
+            const PairDraw pd = draw_pair(a, key, ii, att);
+            if (pd.is_rand) { is_rand = true; done = true; }
+            else if (sj > 0) {
+                int64_t start; int step;
+                read_geom(a, pd, j, &start, &step);
+                if (!attempt_surely_accepted(pd.hap ? a.summ[1] : a.summ[0], a.c.l, start, step, sj)) {     // rare: N, dense indels, contig ends
+                    const ReadRes r = gen_read<false>(sel_hap(a, pd.hap), a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                    ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
+                }
+            }
+        }
+        if (LPP == 2) { const int other = __shfl_xor((int)ok, 1); ok = ok && (other != 0); }   // every lane shuffles (no short-circuit)
+        if (!done) {
+            if (ok) done = true;
+            else if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; done = true; }
+        }
+    }
+    if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);
+    uint32_t total;
+    (void)block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &total);
+    if (threadIdx.x == 0) a.block_rand[blockIdx.x] = total;
+    const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u);
+    if (lane_id() == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries);
+    if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
+}
+#endif // DW_HAS(0): k_summarize, k_place
+
+// K6: one lane per read end (LPP = 2: lanes 2q / 2q+1 are the two ends of pair q; LPP = 1: single end).
+// Opt-in phase timing (tools/phase_profile.sh builds a separate library with -DDW_PHASE_TIMING; the
+// product build compiles these macros to nothing): per wave, shader-clock ticks spent in each phase
+// are added to counters[8 + phase].
+#ifdef DW_PHASE_TIMING
+#define PH_INIT() uint64_t ph_t = __builtin_amdgcn_s_memtime()
+#define PH_MARK(k) do { const uint64_t ph_n = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&a.counters[8 + (k)], (unsigned long long)(ph_n - ph_t)); ph_t = ph_n; } while (0)
+#else
+#define PH_INIT() do { } while (0)
+#define PH_MARK(k) do { } while (0)
+#endif
+
+// ---- pieces of a FASTQ record shared by the Illumina / Ion Torrent and the SOLiD write paths ----
+// '@' + "[prefix_]contig" (or "[prefix_]rand"): whole words from LDS (first 256 bytes), any rest from HBM
+template <int OUT>
+DW_DEV void put_name_fixed(Out2<OUT> &o, const uint32_t *fw, const uint8_t *fx, uint32_t fixed_len)
+{
+    const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
+    uint32_t q = 0;
+    for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
+    if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
+    for (q = inl; q < flen; ++q) o.put(fx[q]);
+}
+// "_0_0_0_0_1_1_0:0:0_0:0:0_<hex>" of a random read (dwgsim.c:1044-1048)
+template <int OUT>
+DW_DEV void put_rand_tail(Out2<OUT> &o, uint64_t rand_ii)
+{
+    o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
+    o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
+    o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
+    o.putn(0x5F303Aull, 3);                    // ":0_"
+    put_hex(o, rand_ii);
+}
+struct NameCounts { int32_t e0, u0, i0, e1, u1, i1; };     // n_err : n_sub : n_indel of read end 1 and 2
+// "_pos1_pos2_strand1_strand2_0_0_e:s:i_e:s:i_<hex>" (dwgsim.c:923-929)
+template <int OUT>
+DW_DEV void put_pair_tail(Out2<OUT> &o, int32_t x0, int32_t x1, uint32_t strand0, uint32_t strand1, const NameCounts &n, uint64_t ii)
+{
+    put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
+    o.putn((uint64_t)'_' | ((uint64_t)('0' + strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + strand1) << 24)
+               | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
+    put_dec(o, (uint32_t)n.e0, '_'); put_dec(o, (uint32_t)n.u0, ':'); put_dec(o, (uint32_t)n.i0, ':');
+    put_dec(o, (uint32_t)n.e1, '_'); put_dec(o, (uint32_t)n.u1, ':'); put_dec(o, (uint32_t)n.i1, ':');
+    o.put('_');
+    put_hex(o, ii);
+}
+DW_DEV uint32_t pair_tail_len(int32_t x0, int32_t x1, const NameCounts &n, uint64_t ii)
+{
+    return 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
+         + ndigits10((uint32_t)n.e0) + 1 + ndigits10((uint32_t)n.u0) + 1 + ndigits10((uint32_t)n.i0) + 1
+         + ndigits10((uint32_t)n.e1) + 1 + ndigits10((uint32_t)n.u1) + 1 + ndigits10((uint32_t)n.i1) + 1 + ndigits16(ii);
+}
+// Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qb = base quality per position
+// (positions >= nq reuse the last entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
+template <class F>
+DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const int8_t *qb, int nq, int n, F &&emit)
+{
+    if (p.fixed_quality >= 0) { for (int i = 0; i < n; ++i) emit(i, (uint32_t)p.fixed_quality); return; }
+    if (!(0 < p.quality_std)) {
+        for (int i = 0; i < n; ++i) { int32_t q = qb[i < nq ? i : nq - 1]; if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
+        return;
+    }
+    uint32_t m = 0; int pr = 0; const int np = (n + 1) >> 1;
+    while (pr < np) {
+        // (the two base qualities are fetched before the arithmetic that hides their latency)
+        const int i0 = 2 * pr, i1 = 2 * pr + 1;
+        const int32_t qb0 = qb[i0 < nq ? i0 : nq - 1], qb1 = qb[i1 < nq ? i1 : nq - 1];
+        const U4 blk = rng_block(key, dom, ii, att, m, (uint32_t)pr);
+        // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
+        const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
+        const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
+        const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
+        const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
+        if (!oka && !okb) { ++m; continue; }
+        const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
+        // rsq is a multiple of 2^-62 in (0, 1): -2 log(rsq) in [2^-52, 86], the quotient in [2^-52, 2^69] -- the range-restricted forms apply
+        const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * pr + h;
+            const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
+            if (i < n) {
+                int32_t q = (int8_t)((h ? qb1 : qb0) + (int32_t)((nrm * p.quality_std) + 0.5));
+                if (q < 33) q = 33;
+                if (q > 73) q = 73;
+                emit(i, (uint32_t)q);
+            }
+        }
+        ++pr; m = 0;
+    }
+}
+
+// DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
+template <int LPP, int OUT, int DT>
+__global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+{
+    DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
+    __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_rbase, s_base[3];
+    __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
+    __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
+    constexpr int nthr = SIM_THREADS, PPB = SIM_THREADS / LPP, nwaves = SIM_THREADS / 64;      // PPB pairs per block
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    PH_INIT();
+    if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
+    for (int q = tid; q < 128; q += nthr)                                                          // buffers are padded to 256 + 16 bytes
+        (&s_fixed[0][0])[q] = q < 64 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 64];
+    if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
+    __syncthreads();
+    const uint32_t t = s_ticket;                                  // logical block: predecessors have started
+    const int j = (LPP == 2) ? (tid & 1) : 0;
+    const uint64_t pair = (uint64_t)t * PPB + (uint64_t)(tid / LPP);
+    const bool valid = pair < a.n_pairs;
+    const uint64_t ii = a.first_ii + pair;
+    const RngKey key{a.p.seed, a.c.contig_index};
+    const int s = sel_len(a, j);
+    // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
+    // read buffers live in a global scratch so that LDS does not cap residency; only the 4-word run stack stays in LDS
+    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr) + tid : dyn_lds + tid;
+
+    PH_MARK(0);     // ticket, fixed strings
+    // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
+    // read end, N filter; the two lanes of a pair exchange their verdicts and retry together with attempt + 1 ----
+    PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
+    ReadRes rr{0, 0, 0, 0, 0};
+    uint32_t att = 0; bool is_rand = false, done = !valid;
+    while (__ballot(!done)) {
+        bool ok = true;
+        if (!done) {
+            pd = draw_pair(a, key, ii, att);
+            if (pd.is_rand) { is_rand = true; done = true; rr = ReadRes{0, 0, 0, 0, 0}; }
+            else if (s > 0) {
+                int64_t start; int step;
+                read_geom(a, pd, j, &start, &step);
+                PH_MARK(7);     // placement draws (phase 1 below is then the base extraction alone)
+                rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
+                ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
+            }
+        }
+        if (LPP == 2) { const int other = __shfl_xor((int)ok, 1); ok = ok && (other != 0); }   // every lane shuffles
+        if (!done) {
+            if (ok) done = true;
+            else if (++att > (uint32_t)MAX_ATTEMPTS) { atomicOr((unsigned long long *)&a.counters[2], 1ull); done = true; }
+        }
+    }
+    { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
+    // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
+    uint32_t rrank, rtot;
+    { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
+    if (wave == 0) {
+        const uint64_t g = lookback_excl(a.status[2], t, rtot, 0);
+        if (lane == 0) { s_rbase = g; if ((uint64_t)t + 1 == (a.n_pairs + PPB - 1) / PPB) a.counters[3] = g + rtot; }
+    }
+    // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
+    // overlaps with that work instead of idling three waves)
+    PH_MARK(1);     // placement + base extraction
+    // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
+    // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
+    // substituted base is drawn afterwards, only for the (few) marked bases
+    int32_t n_err = 0;
+    int s_out = s;                              // read length after errors (changes only for Ion Torrent)
+    bool flow_reversed = false;
+    const int nw = (s + 7) >> 3;
+    if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
+        FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
+        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
+                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
+        if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
+        flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
+    }
+    int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
+    if (valid && (DT != 2 || is_rand)) {
+        // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
+        const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
+        uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
+        for (int w = 0; w < nw; ++w) {
+            uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
+            if (!is_rand) { ta = *reinterpret_cast<const uint4 *>(thr + 8 * w); tb = *reinterpret_cast<const uint4 *>(thr + 8 * w + 4); }
+            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w));
+            const U4 q1 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w + 1));
+            const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const int rem = s - 8 * w;
+            const uint32_t live = rem >= 8 ? 0xFFFFFFFFu : ((1u << (4 * rem)) - 1u);      // nibbles of bases i < s
+            uint32_t word;
+            if (is_rand) {                                                      // random read: base = (int)(u * 4.0) & 3 (dwgsim.c:999-1001)
+                word = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) word |= (rw[b] >> 30) << (4 * b);
+            } else word = lds[w * nthr];
+            if (DT == 1) {                                                      // colour = __gf_add(previous base, base): dwgsim.h:6, dwgsim.c:845-858 / :1022-1032
+                const uint32_t prevw = (word << 4) | prev_base;
+                prev_base = word >> 28;
+                const uint32_t n = (word | prevw) & 0x44444444u;                // either base is not ACGT -> colour 4
+                word = ((word ^ prevw) & 0x33333333u & ~((n >> 1) | (n >> 2))) | n;
+            } else {
+                const uint32_t n4 = word & 0x44444444u;                         // if (c >= 4) c = 4 (dwgsim.c:235)
+                word &= ~((n4 >> 1) | (n4 >> 2));
+            }
+            if (!is_rand) {                                                     // drand48() < e[i]  <=>  w < thr[i]; an error marks bit 3 of the nibble
+                const uint32_t t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+                uint32_t hits = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) hits |= (rw[b] < t[b]) ? (8u << (4 * b)) : 0u;
+                if (a.e_full) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) hits |= (t[b] == 0xFFFFFFFFu) ? (8u << (4 * b)) : 0u;
+                }
+                hits &= ~((word & 0x44444444u) << 1) & live;                    // N bases / colours take no error
+                n_err += __popc(hits);
+                if (DT == 1 && w == 0) err_first = (int32_t)((hits >> 3) & 1u);
+                word |= hits;
+            }
+            lds[w * nthr] = word & live;
+        }
+        if (!is_rand) {
+            int w = 0; uint32_t pend = 0;
+            for (;;) {
+                while (pend == 0 && w < nw) { pend = lds[w * nthr] & 0x88888888u; if (!pend) ++w; }
+                if (!pend) break;
+                const int b = (__ffs((int)pend) - 1) >> 2;
+                pend &= pend - 1;
+                const int i = w * 8 + b;
+                const U4 q = rng_block(key, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)(i >> 2));
+                const uint32_t rwd = (i & 2) ? ((i & 1) ? q.w : q.z) : ((i & 1) ? q.y : q.x);
+                const uint32_t add = 1u + (uint32_t)(((uint64_t)rwd * 3u) >> 32);        // (int)(u * 3.0 + 1), exact
+                uint32_t word = lds[w * nthr];
+                const uint32_t c = (((word >> (4 * b)) & 7u) + add) & 3u;
+                word = (word & ~(0xFu << (4 * b))) | (c << (4 * b));
+                lds[w * nthr] = word;
+                if (!pend) ++w;
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t rand_ii = a.rand_base + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+    PH_MARK(2);     // error tests + substitutions
+    // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
+    int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
+    int32_t e1c = 0, u1 = 0, i1 = 0, x1 = 0;                                   // read end 2 (single-end: zeros, dwgsim.c:643)
+    if (LPP == 2) {
+        const int32_t o0 = __shfl_xor(n_err, 1), o1 = __shfl_xor(rr.n_sub, 1), o2 = __shfl_xor(rr.n_indel, 1), o3 = __shfl_xor(rr.ext_coor, 1);
+        if (j == 0) { e1c = o0; u1 = o1; i1 = o2; x1 = o3; }
+        else { e1c = n_err; u1 = rr.n_sub; i1 = rr.n_indel; x1 = rr.ext_coor; e0 = o0; u0 = o1; i0 = o2; x0 = o3; }
+    }
+    // SOLiD: the BWA files print the counts "minus the first colour" (dwgsim.c:945-946); only n_err and n_indel can differ
+    int32_t e0w = e0, i0w = i0, e1w = e1c, i1w = i1;
+    if (DT == 1) {
+        int32_t f0 = err_first, g0 = rr.n_ins, f1 = 0, g1 = 0;
+        if (LPP == 2) {
+            const int32_t of = __shfl_xor(err_first, 1), og = __shfl_xor(rr.n_ins, 1);
+            if (j == 0) { f1 = of; g1 = og; } else { f1 = err_first; g1 = rr.n_ins; f0 = of; g0 = og; }
+        }
+        e0w = e0 - f0; i0w = i0 - g0; e1w = e1c - f1; i1w = i1 - g1;
+    }
+    const NameCounts nc{e0, u0, i0, e1c, u1, i1}, ncw{e0w, u0, i0w, e1w, u1, i1w};
+    uint32_t tail_len, tail_len_w, fixed_len;
+    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
+    else {
+        fixed_len = (uint32_t)a.name_fixed_len;
+        tail_len = pair_tail_len(x0, x1, nc, ii);
+        tail_len_w = (DT == 1) ? pair_tail_len(x0, x1, ncw, ii) : tail_len;
+    }
+    const bool emits = valid && s_out > 0;
+    // record lengths.  SOLiD: BWA drops the first colour and its quality (dwgsim.c:950-955); BFAST prepends the adaptor 'A' (:968-975)
+    const uint32_t Lbwa = !emits ? 0u : (DT == 1) ? (1u + fixed_len + tail_len_w + 2u + 1u + 2u * (uint32_t)(s_out - 1) + 3u + 1u)
+                                                  : (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s_out + 3u + (uint32_t)s_out + 1u);
+
+    // ---- record offsets: block scan + decoupled look-back over logical blocks ----
+    uint32_t e1, e2, eb = 0, T1, T2, Tb = 0;
+    if (DT == 1) {
+        const uint32_t v[3] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u, emits ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : 0u};
+        uint32_t ex[3], tot[3]; block_excl_scan_n<3>(v, sm_bytes, ex, tot);
+        e1 = ex[0]; e2 = ex[1]; eb = ex[2]; T1 = tot[0]; T2 = tot[1]; Tb = tot[2];
+    } else {
+        const uint32_t v[2] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u};
+        uint32_t ex[2], tot[2]; block_excl_scan_n<2>(v, sm_bytes, ex, tot);
+        e1 = ex[0]; e2 = ex[1]; T1 = tot[0]; T2 = tot[1];
+    }
+    if (wave == 0) {
+        const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
+        if (DT == 1) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
+    }
+    if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
+    __syncthreads();
+    const uint64_t G1 = s_base[0], G2 = s_base[1];
+    const uint64_t reads_before_block = (uint64_t)t * PPB * (uint64_t)LPP;
+    const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
+    const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
+    // Illumina / Ion Torrent: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
+    const uint64_t off_bf = (DT == 1) ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
+    if (tid == nthr - 1) {
+        const uint64_t nblocks = (a.n_pairs + PPB - 1) / PPB;
+        if ((uint64_t)t + 1 == nblocks) {
+            const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
+            a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
+            a.counters[5] = a.p.has_bwa ? G2 + T2 : 0;
+            a.counters[6] = !a.p.has_bfast ? 0 : (DT == 1) ? s_base[2] + Tb : G1 + T1 + G2 + T2 - 2 * nreads;
+        }
+    }
+
+    PH_MARK(3);     // name lengths, block scan, look-back
+    // ---- SOLiD records (dwgsim.c:934-976, :1056-1094): the two outputs differ in name counts, suffix, alphabet and length ----
+    if (DT == 1) {
+        if (emits) {
+            for (int which = 0; which < 2; ++which) {            // 0: BWA stream of this end, 1: BFAST
+                if (!(OUT & (1 << which))) continue;
+                Out2<1> o;
+                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa);
+                put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
+                if (is_rand) put_rand_tail(o, rand_ii);
+                else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1,           // (value selects: a struct select would go through memory)
+                                   NameCounts{which ? e0 : e0w, u0, which ? i0 : i0w, which ? e1c : e1w, u1, which ? i1 : i1w}, ii);
+                if (which == 0) o.putn((uint64_t)'/' | ((uint64_t)('2' - j) << 8) | ((uint64_t)'\n' << 16), 3);      // F3 is annotated "/2", R3 "/1" (dwgsim.c:938-939)
+                else { o.put('\n'); o.put('A'); }
+                const int first = which ? 0 : 1;                // BWA skips the first colour and its quality
+                for (int w = 0; w * 8 < s_out; ++w) {
+                    const uint32_t word = lds[w * nthr];
+                    const uint32_t c0 = which ? colour_digits4(word) : base_chars4(word), c1 = which ? colour_digits4(word >> 16) : base_chars4(word >> 16);
+                    const int lo = w == 0 ? first : 0, hi = s_out - w * 8 < 8 ? s_out - w * 8 : 8;
+                    if (lo == 0 && hi == 8) { o.put4(c0); o.put4(c1); }
+                    else for (int b = lo; b < hi; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
+                }
+                o.put('\n'); o.put('+'); o.put('\n');
+                for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out,
+                                 [&](int i, uint32_t q) { if (i >= first) o.put(q); });       // same draws for both outputs
+                o.put('\n');
+                o.flush();
+            }
+        }
+    } else
+    // ---- write the record(s) ----
+    if (valid && s_out > 0) {
+        Out2<OUT> o;
+        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
+        if (OUT & 2) o.b.init(a.out[2] + off_bf);
+        put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
+        if (is_rand) put_rand_tail(o, rand_ii);
+        else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
+        if (OUT & 1) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
+        if (OUT & 2) o.b.put('\n');
+        PH_MARK(4); // header line
+        // bases
+        PackReader<4> rev; rev.init(lds, nthr);
+        for (int w = 0; w * 8 < s_out; ++w) {
+            uint32_t word;
+            if (DT == 2 && flow_reversed) {         // base i of the record = base s_out-1-i of the flow-model orientation
+                word = 0;
+                for (int b = 0; b < 8; ++b) { const int i = w * 8 + b; if (i < s_out) word |= rev.get(s_out - 1 - i) << (4 * b); }
+            } else word = lds[w * nthr];
+            const int rem = s_out - w * 8;
+            if (rem >= 8) {
+                o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16));
+            } else {
+                const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16);
+                for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
+            }
+        }
+        o.put('\n'); o.put('+'); o.put('\n');
+        PH_MARK(5); // sequence line
+        // qualities (dwgsim.c:899-918), four characters per store
+        {
+            uint32_t qacc = 0, nq = 0;
+            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out, [&](int, uint32_t q) {
+                qacc |= q << (8 * nq);
+                if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
+            });
+            for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
+        }
+        o.put('\n');
+        o.flush();
+    }
+    PH_MARK(6);     // quality line
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (declared in dw_launch.hpp)
+// ------------------------------------------------------------------------------------------------
+#if DW_HAS(0)
+// Self-test of the range-restricted fp64 forms (dw_common.hpp) against the compiler's own `/`, sqrt() and the general det_log:
+// operands drawn exactly as the quality path draws them, plus mantissa x exponent pairs over [2^-70, 2^70].  mism[0..2] count
+// bitwise differences of div_mid, sqrt_mid, det_log<true>; mism[3] counts the comparisons made.
+__global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n, uint64_t *mism)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t bad_div = 0, bad_sqrt = 0, bad_log = 0, done = 0;
+    if (i < n) {
+        const RngKey key{seed, 0u};
+        const U4 b = rng_block(key, 31, i, 0, 0, 0), c = rng_block(key, 31, i, 0, 0, 1);
+        const double a1 = (double)b.x * 0x1p-31 - 1.0, a2 = (double)b.y * 0x1p-31 - 1.0, r = a1 * a1 + a2 * a2;
+        if (r < 1.0 && r != 0.0) {
+            const double l1 = det_log(r), l2 = det_log<true>(r);
+            bad_log += dbl_bits(l1) != dbl_bits(l2);
+            const double x = -2.0 * l1, q1 = x / r, q2 = div_mid(x, r);
+            bad_div += dbl_bits(q1) != dbl_bits(q2);
+            bad_sqrt += dbl_bits(sqrt(q1)) != dbl_bits(sqrt_mid(q1));
+            const double f = bits_dbl((dbl_bits(r) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull) - 1.0;       // a det_log-style f / (2 + f)
+            bad_div += dbl_bits(f / (2.0 + f)) != dbl_bits(div_mid(f, 2.0 + f));
+            done += 4;
+        }
+        const double x = ldexp(1.0 + u53(c.x, c.y), (int)(b.z % 141u) - 70), y = ldexp(1.0 + u53(c.z, c.w), (int)(b.w % 141u) - 70);
+        bad_div += dbl_bits(x / y) != dbl_bits(div_mid(x, y));
+        bad_sqrt += dbl_bits(sqrt(x)) != dbl_bits(sqrt_mid(x));
+        done += 2;
+    }
+    const uint32_t s0 = wave_sum_u32(bad_div), s1 = wave_sum_u32(bad_sqrt), s2 = wave_sum_u32(bad_log), s3 = wave_sum_u32(done);
+    if ((threadIdx.x & 63) == 0) {
+        if (s0) atomicAdd((unsigned long long *)&mism[0], (unsigned long long)s0);
+        if (s1) atomicAdd((unsigned long long *)&mism[1], (unsigned long long)s1);
+        if (s2) atomicAdd((unsigned long long *)&mism[2], (unsigned long long)s2);
+        atomicAdd((unsigned long long *)&mism[3], (unsigned long long)s3);
+    }
+}
+void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
+{
+    hipLaunchKernelGGL(k_selftest_fp64, dim3(cdiv(n, 256)), dim3(256), 0, st, seed, n, mism);
+}
+void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ)
+{
+    const uint64_t nb = (uint64_t)(l + SUMM_CELLS - 1) / SUMM_CELLS;
+    if (nb) hipLaunchKernelGGL(k_summarize, dim3(cdiv(nb, 256)), dim3(256), 0, st, cells, l, summ);
+}
+void launch_place(hipStream_t st, const SimArgs &a)
+{
+    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_place<2>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK * 2), 0, st, a);
+    else hipLaunchKernelGGL(k_place<1>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), 0, st, a);
+}
+// one launcher per (LPP, DT) family, each defined in its own part
+void launch_sim_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_2_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_simulate(hipStream_t st, const SimArgs &a)
+{
+    const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
+    const uint32_t nb = cdiv(a.n_pairs, SIM_THREADS / (pe ? 2 : 1));
+    const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
+    const uint32_t nthr = SIM_THREADS;
+    const size_t lds = (size_t)(ion ? 4 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack (8 runs); its read buffers are in a.flow_scratch
+    const bool solid = a.p.data_type == 1;
+    if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else if (solid) launch_sim_2_1(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
+    else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else if (solid) launch_sim_1_1(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
+}
+#endif // DW_HAS(0): launchers
+
+#define DW_SIM_FAMILY(LPP, DT)                                                                                   \
+    void launch_sim_##LPP##_##DT(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out)             \
+    {                                                                                                            \
+        const uint32_t nthr = SIM_THREADS;                                                                       \
+        if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, DT>), dim3(nb), dim3(nthr), lds, st, a);            \
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT>), dim3(nb), dim3(nthr), lds, st, a);       \
+        else hipLaunchKernelGGL((k_simulate<LPP, 3, DT>), dim3(nb), dim3(nthr), lds, st, a);                     \
+    }
+#if DW_HAS(1)
+DW_SIM_FAMILY(2, 0)
+#endif
+#if DW_HAS(2)
+DW_SIM_FAMILY(1, 0)
+#endif
+#if DW_HAS(3)
+DW_SIM_FAMILY(2, 2)
+#endif
+#if DW_HAS(4)
+DW_SIM_FAMILY(1, 2)
+
+// -B (dwgsim_opt.c:415-457): lane = one random read of read end a.end pushed through the flow model on the forward strand; the block
+// adds its error and length sums to counters[8], [9].  Draws: bases = narrow words of (D_CALIB + end, read, attempt 0), flow model =
+// the sequential narrow stream of (D_CALIB + end, read, attempt 1).
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
+{
+    DW_DYN_SHARED(uint32_t, dyn_lds);
+    __shared__ uint8_t s_flow[64];
+    const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK;
+    if (tid < 64) s_flow[tid] = a.flow[tid];
+    __syncthreads();
+    const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
+    uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr) + tid;
+    int32_t n_err = 0; int s_out = 0;
+    if (jj < a.n_reads) {
+        const RngKey key{a.seed, 0u};
+        const uint32_t dom = D_CALIB + (uint32_t)a.end;
+        for (int w = 0; w * 8 < a.len; ++w) {
+            const U4 q0 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w)), q1 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w + 1));
+            const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) if (w * 8 + b < a.len) word |= (rw[b] >> 30) << (4 * b);      // (int)(u * 4.0) & 3
+            buf[w * nthr] = word;
+        }
+        FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.slot = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
+        s_out = flow_errors(rg, s_flow, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
+        if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; }
+    }
+    const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);
+    if ((tid & 63) == 0) { atomicAdd((unsigned long long *)&a.counters[8], (unsigned long long)es); atomicAdd((unsigned long long *)&a.counters[9], (unsigned long long)ls); }
+}
+void launch_calibrate(hipStream_t st, const CalibArgs &a)
+{
+    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)4 * PAIRS_PER_BLOCK * 4, st, a);
+}
+#endif
+#if DW_HAS(5)
+DW_SIM_FAMILY(2, 1)
+#endif
+#if DW_HAS(6)
+DW_SIM_FAMILY(1, 1)
+#endif
+
+} // namespace dw

@@ -1,0 +1,547 @@
+// dw_walk.hip -- hand-written HIP kernels (gfx950 / MI355X) of the mutation walk
+// (replaces src/mut.c:591-643 mut_diref + :481-589 mut_left_justify + the cell list behind :781-893 mut_print).
+//
+//     k_pack          ASCII -> base codes, initialises both haplotypes            HBM: 1 B in, 3 B out / base
+//     k_site_scan     one Philox draw per position: candidate sites (bitmask)     HBM: 1 B in / base; ALU (Philox)
+//     k_scan_excl     single-block exclusive scan of per-block counts
+//     k_compact       ordered compaction of a bitmask into a position list
+//     k_events        one thread per candidate: speculative event (type, ploidy, lengths)
+//     k_resolve       liveness of candidates (deletion runs swallow later candidates)
+//     k_apply         writes live events into the haplotype cells + insertion tables
+//     k_jreach / k_sufmin / k_jbound / k_jrun   left-justification of indels: exact sequential
+//                     semantics inside independent clusters, clusters in parallel
+//     k_apply_patches file-driven mutations (-m / -b / -v) resolved on the host, scattered here
+//     k_collect_mask / k_gather   list of mutated cells for the host's txt/vcf writer
+//
+// Byte/integer work only: no MFMA.  Host-callable launchers (dw_launch.hpp) are at the end.
+#include "dw_device.hpp"
+#include "dw_launch.hpp"
+
+namespace dw {
+
+// ------------------------------------------------------------------------------------------------
+// K0: ASCII -> codes; both haplotypes start as the reference (mut.c:609)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t *__restrict__ ascii, uint8_t *__restrict__ ref, uint8_t *__restrict__ h0,
+                       uint8_t *__restrict__ h1, int64_t l)
+{
+    const int64_t nchunk = (l + 15) >> 4;
+    for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p0 = ch << 4;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (p0 + 16 <= l) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ascii + p0);
+            const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w[q] |= code_of_ascii((in[q] >> (8 * b)) & 0xff) << (8 * b);
+        } else {
+            for (int b = 0; b < 16; ++b) { const uint32_t c = (p0 + b < l) ? code_of_ascii(ascii[p0 + b]) : 4u; w[b >> 2] |= c << (8 * (b & 3)); }
+        }
+        const uint4 o = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(ref + p0) = o;
+        *reinterpret_cast<uint4 *>(h0 + p0) = o;
+        *reinterpret_cast<uint4 *>(h1 + p0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: candidate sites.  mut.c:618 `c < 4 && drand48() < opt->mut_rate` with the draw taken from
+// (D_WALK, position, slot 1).  16 positions per thread, 4096 per block; emits a bitmask (uint16 per
+// thread) and the per-block candidate count.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkParams wp, uint32_t contig_index,
+                            uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count)
+{
+    __shared__ uint32_t sm[17];
+    const RngKey key{wp.seed, contig_index};
+    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    uint32_t bits = 0;
+    if (p0 < l) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(ref + p0);      // ref is padded: reading past l is safe
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint32_t c = (in[b >> 2] >> (8 * (b & 3))) & 0xff;
+            if (c < 4 && p0 + b < l) {
+                const U4 blk = rng_block(key, D_WALK, (uint64_t)(p0 + b), 0, 0, 0);
+                if ((((uint64_t)blk.z << 21) | (uint64_t)(blk.w >> 11)) < wp.mut_thr53) bits |= 1u << b;   // u53(w2,w3) < mut_rate
+            }
+        }
+    }
+    mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x] = (uint16_t)bits;
+    uint32_t total;
+    (void)block_excl_scan((uint32_t)__popc(bits), sm, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+// single-block exclusive scan (in place) of n uint32; optional 64-bit total
+__global__ void k_scan_excl(uint32_t *data, uint32_t n, uint64_t *total_out)
+{
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    uint64_t grand = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? data[i] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, sm, &total);
+        const uint32_t carry = carry_s;
+        if (i < n) data[i] = ex + carry;
+        grand += total;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (total_out && threadIdx.x == 0) *total_out = grand;
+}
+
+// ordered compaction: positions of set bits of `mask` (one uint16 per thread of the producing kernel)
+__global__ void k_compact(const uint16_t *__restrict__ mask, const uint32_t *__restrict__ block_base, int32_t *__restrict__ out)
+{
+    __shared__ uint32_t sm[17];
+    uint32_t bits = mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x];
+    uint32_t total;
+    uint32_t off = block_base[blockIdx.x] + block_excl_scan((uint32_t)__popc(bits), sm, &total);
+    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; out[off++] = (int32_t)(p0 + b); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a: one thread per candidate site: the event it would be if it is live.  mut.c:619-640, 287-308.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_events(const int32_t *__restrict__ cand, uint32_t n_cand, const uint8_t *__restrict__ ref, int64_t l,
+                         WalkParams wp, uint32_t contig_index, Event *__restrict__ ev, uint32_t *__restrict__ max_del)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_cand) {
+        const RngKey key{wp.seed, contig_index};
+        const int64_t p = cand[k];
+        const uint32_t c = ref[p];
+        const U4 b1 = rng_block(key, D_WALK, (uint64_t)p, 0, 0, 1);   // slots 2,3
+        const U4 b2 = rng_block(key, D_WALK, (uint64_t)p, 0, 0, 2);   // slots 4,5
+        Event e; e.pos = (int32_t)p; e.live = 1; e.len = 1; e.base = (uint8_t)c;
+        if (u_lo(b1) >= wp.indel_frac) {                 // substitution (mut.c:619-626)
+            e.type = 1;
+            e.base = (uint8_t)((c + (uint32_t)(uint64_t)(u_hi(b1) * 3.0 + 1)) & 3);
+            e.hap = (wp.is_hap || u_lo(b2) < 0.333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
+        } else if (u_hi(b1) < 0.5) {                     // deletion (mut.c:628-636) + its run (mut.c:610-617)
+            e.type = 2;
+            e.hap = (wp.is_hap || u_lo(b2) < 0.3333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
+            uint32_t len = 1;
+            for (int64_t q = p + 1; q < l; ++q) {
+                if ((int64_t)len < wp.indel_min || rng_slot(key, D_WALK, (uint64_t)q, 0, 0) < wp.indel_extend) ++len; else break;
+            }
+            e.len = len;
+            atomicMax(max_del, len);
+        } else {                                         // insertion (mut.c:637-639 -> :287-308)
+            e.type = 3;
+            uint64_t num = 0; uint32_t kk = 0;
+            do { ++num; } while (num < 0xFFFFFFFFull && ((int64_t)num < wp.indel_min || rng_slot(key, D_WALK_INSLEN, (uint64_t)p, 0, kk++) < wp.indel_extend));
+            e.len = (uint32_t)num;
+            e.hap = (wp.is_hap || u_lo(b2) < 0.333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
+        }
+        ev[k] = e;
+    }
+}
+
+// K2b: liveness.  In the sequential walk a candidate inside an active deletion run is never tested
+// (mut.c:610-615 `continue`).  Candidate k is dead iff a LIVE earlier deletion covers it.  Exact
+// parallel evaluation: a candidate no earlier deletion reaches at all is live; otherwise replay the
+// (tiny) chain from the nearest such anchor.
+DW_DEV bool reached_by_any(const Event *ev, uint32_t k, uint32_t max_del)
+{
+    const int64_t pk = ev[k].pos;
+    for (int64_t j = (int64_t)k - 1; j >= 0; --j) {
+        const int64_t pj = ev[j].pos;
+        if (pk - pj >= (int64_t)max_del) break;
+        if (ev[j].type == 2 && pj + (int64_t)ev[j].len - 1 >= pk) return true;
+    }
+    return false;
+}
+__global__ void k_resolve(Event *ev, uint32_t n_cand, const uint32_t *max_del_p, uint4 *flags)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    const uint32_t max_del = *max_del_p;
+    bool live = true;
+    if (max_del > 1 && reached_by_any(ev, k, max_del)) {
+        int64_t a = (int64_t)k - 1;
+        while (a > 0 && reached_by_any(ev, (uint32_t)a, max_del)) --a;     // anchor: definitely live (or first candidate)
+        int64_t reach = -1;
+        for (int64_t m = a; m <= (int64_t)k; ++m) {
+            const bool lv = ev[m].pos > reach;
+            if (lv && ev[m].type == 2) reach = (int64_t)ev[m].pos + ev[m].len - 1;
+            live = lv;
+        }
+    }
+    // (the live flag is written to a side array so that neighbours still read the speculative events)
+    const Event e = ev[k];
+    uint4 f;
+    f.x = (live && e.type == 3 && (e.hap & 1)) ? 1u : 0u;       // insertion count hap 1
+    f.y = (live && e.type == 3 && (e.hap & 1)) ? e.len : 0u;    // inserted bases hap 1
+    f.z = (live && e.type == 3 && (e.hap & 2)) ? 1u : 0u;
+    f.w = (live && e.type == 3 && (e.hap & 2)) ? e.len : 0u;
+    if (!live) f.x |= 0x80000000u;                               // dead marker
+    flags[k] = f;
+}
+
+// exclusive scan of the four insertion-allocation columns (single block); totals -> tot[0..3]
+__global__ void k_scan4(uint4 *flags, uint32_t n, uint32_t *tot)
+{
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t carry_s[4];
+    if (threadIdx.x < 4) carry_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < n) v = flags[i];
+        const uint32_t dead = v.x & 0x80000000u;
+        uint32_t in[4] = {v.x & 0x7fffffffu, v.y, v.z, v.w}, ex[4], total[4];
+        for (int c = 0; c < 4; ++c) ex[c] = block_excl_scan(in[c], sm, &total[c]) + carry_s[c];
+        if (i < n) flags[i] = make_uint4(ex[0] | dead, ex[1], ex[2], ex[3]);
+        __syncthreads();
+        if (threadIdx.x < 4) carry_s[threadIdx.x] += total[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) tot[threadIdx.x] = carry_s[threadIdx.x];
+}
+
+// K3: write live events into the cells and the insertion tables.
+__global__ void k_apply(Event *ev, uint32_t n_cand, const uint4 *flags, ContigDev c, WalkParams wp)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    const uint4 f = flags[k];
+    Event e = ev[k];
+    if (f.x & 0x80000000u) { ev[k].live = 0; return; }
+    const int64_t p = e.pos;
+    if (e.type == 1) {
+        if (e.hap & 1) c.hap[0].cells[p] = T_SUB | e.base;
+        if (e.hap & 2) c.hap[1].cells[p] = T_SUB | e.base;
+    } else if (e.type == 2) {
+        for (uint32_t q = 0; q < e.len; ++q) {
+            const uint8_t v = T_DEL | c.ref[p + q];
+            if (e.hap & 1) c.hap[0].cells[p + q] = v;
+            if (e.hap & 2) c.hap[1].cells[p + q] = v;
+        }
+    } else {
+        const RngKey key{wp.seed, c.contig_index};
+        const uint32_t idx[2] = {f.x & 0x7fffffffu, f.z}, off[2] = {f.y, f.w};
+        for (int h = 0; h < 2; ++h) if (e.hap & (1 << h)) {
+            c.hap[h].cells[p] = T_INS | e.base;
+            c.hap[h].ins_pos[idx[h]] = (int32_t)p;
+            c.hap[h].ins_len[idx[h]] = e.len;
+            c.hap[h].ins_off[idx[h]] = off[h];
+        }
+        for (uint32_t j = 0; j < e.len; ++j) {      // draw j lands at printed index len-1-j (mut.c:313-315, :347-365 read by :249-279)
+            const uint8_t b = (uint8_t)(uint64_t)(rng_slot(key, D_WALK_INSBASE, (uint64_t)p, 0, j) * 4.0);
+            if (e.hap & 1) c.hap[0].ins_bases[off[0] + e.len - 1 - j] = b;
+            if (e.hap & 2) c.hap[1].ins_bases[off[1] + e.len - 1 - j] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: left-justification (mut.c:427-589).  The reference scans every position; only mutated cells act
+// and unmutated (non-N) positions merely reset prev_del, so the walk visits the live events'
+// original footprints in order and treats the gaps between them in O(1).
+// ------------------------------------------------------------------------------------------------
+DW_DEV void justify_ins(HapDev &h, int64_t i)          // mut.c:427-478
+{
+    const uint32_t idx = ins_find(h, i);
+    const uint32_t n = h.ins_len[idx];
+    uint8_t *P = h.ins_bases + h.ins_off[idx];
+    int64_t j = i;
+    while (j > 0 && (h.cells[j - 1] & TMASK) == T_NONE && P[n - 1] == (h.cells[j - 1] & 3)) {
+        for (uint32_t t = n - 1; t > 0; --t) P[t] = P[t - 1];
+        P[0] = h.cells[j - 1] & 3;
+        h.cells[j] = h.cells[j] & 3;
+        --j;
+    }
+    h.cells[j] = T_INS | (h.cells[j] & 3);
+    h.ins_pos[idx] = (int32_t)j;
+}
+DW_DEV void del_swap(HapDev &h, int64_t j, int64_t dl)   // mut.c:515-516
+{
+    const uint8_t t = h.cells[j]; h.cells[j] = h.cells[j + dl]; h.cells[j + dl] = (uint8_t)((t | TMASK) ^ TMASK);
+}
+DW_DEV int64_t del_run(const HapDev &h, int64_t i, int64_t l)
+{
+    int64_t dl = 1;
+    for (int64_t j = i + 1; j < l && (h.cells[j] & TMASK) == T_DEL; ++j) ++dl;
+    return dl;
+}
+DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
+{
+    if (c.ref[i] >= 4) return;
+    HapDev &h0 = c.hap[0], &h1 = c.hap[1];
+    const uint8_t c1 = h0.cells[i], c2 = h1.cells[i];
+    if ((c1 & TMASK) == T_NONE && (c2 & TMASK) == T_NONE) { prev_del[0] = prev_del[1] = 0; return; }
+    if ((c1 & BTMASK) == (c2 & BTMASK)) {
+        if ((c1 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
+        else if ((c1 & TMASK) == T_DEL) {
+            if (prev_del[0] == 1 || prev_del[1] == 1) return;
+            prev_del[0] = prev_del[1] = 1;
+            const int64_t dl = del_run(h0, i, c.l);
+            if (c.l <= i + dl) return;
+            if (i > 0) for (int64_t j = i - 1;; --j) {
+                const uint8_t a = h0.cells[j], b = h1.cells[j];
+                if ((a & TMASK) != T_INS && (b & TMASK) != T_INS && (a & TMASK) != T_DEL && (b & TMASK) != T_DEL
+                    && (a & 3) == (h0.cells[j + dl] & 3) && (b & 3) == (h1.cells[j + dl] & 3)) { del_swap(h0, j, dl); del_swap(h1, j, dl); }
+                else break;
+                if (j == 0) break;
+            }
+        } else { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); justify_ins(h1, i); }
+    } else {
+        if ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
+        else if ((c1 & TMASK) == T_DEL || (c2 & TMASK) == T_DEL) {
+            const int x = ((c1 & TMASK) == T_DEL) ? 0 : 1;
+            if (prev_del[x] == 1) return;
+            prev_del[x] = 1;
+            HapDev &h = c.hap[x];
+            const int64_t dl = del_run(h, i, c.l);
+            if (c.l <= i + dl) return;
+            if (i > 0) for (int64_t j = i - 1;; --j) {
+                const uint8_t a = h.cells[j];
+                if ((a & TMASK) == T_NONE && (a & 3) == (h.cells[j + dl] & 3)) del_swap(h, j, dl); else break;
+                if (j == 0) break;
+            }
+        } else if ((c1 & TMASK) == T_INS) { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); }
+        else { prev_del[0] = prev_del[1] = 0; justify_ins(h1, i); }
+    }
+}
+// sequential cross-check (DWGSIM_HIP_JUSTIFY=seq): one thread walks every live event of the contig
+__global__ void k_justify_seq(const Event *ev, uint32_t n_cand, ContigDev c)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int prev_del[2] = {0, 0};
+    int64_t last = -1;
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const Event e = ev[k];
+        if (!e.live) continue;
+        const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
+        if (prev_del[0] | prev_del[1])
+            for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
+        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
+        last = right;
+    }
+}
+
+// ---- parallel left-justification --------------------------------------------------------------
+// The reference's pass is sequential, but an indel only interacts with what its leftward scan can
+// touch.  (1) k_jreach: per live event, a conservative lower bound `lo` of every cell its scan can
+// read or write: continue while the cell is mutated on either haplotype (pre-justify state) or the
+// reference is periodic there (deletion: ref[j]&3 == ref[j+L]&3, insertion: the rotated copy keeps
+// matching).  Shifts preserve (cell & 3) at every position, so the true scan never goes further.
+// (2) k_sufmin: suffix minimum of lo.  (3) k_jbound: event b starts a new cluster iff no event >= b
+// can reach the previous live event's footprint and an unmutated non-N position separates them
+// (prev_del is then 0, mut.c:585-587).  (4) k_jrun: one thread per cluster replays the exact
+// sequential semantics (justify_visit) over its events; clusters touch disjoint cells.
+DW_DEV int64_t reach_del(const ContigDev &c, int h, int64_t p)
+{
+    // period = the run of DELETE cells the sequential pass would measure at p (adjacent runs merge,
+    // mut.c:503 / :535 / :557) on haplotype h
+    const int64_t L = del_run(c.hap[h], p, c.l);
+    int64_t j = p - 1;
+    for (; j >= 0; --j) {
+        const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
+        if (!(mutated || (p + L < c.l && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
+    }
+    return j < 0 ? 0 : j;                              // last cell read
+}
+DW_DEV int64_t reach_ins(const ContigDev &c, int h, int64_t p)
+{
+    const uint32_t idx = ins_find(c.hap[h], p);
+    const uint32_t n = c.hap[h].ins_len[idx];
+    const uint8_t *P = c.hap[h].ins_bases + c.hap[h].ins_off[idx];
+    // rotating left by one makes the cell's base the new first base: after r rotations the last
+    // inserted base is P[n-1-r] while r < n, then ref[p-1-(r-n)] & 3 (bases rotated in earlier)
+    int64_t j = p - 1; int64_t r = 0;
+    for (; j >= 0; --j, ++r) {
+        const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
+        const uint32_t last = r < (int64_t)n ? (uint32_t)P[n - 1 - r] : (uint32_t)(c.ref[p - 1 - (r - n)] & 3);
+        if (!(mutated || last == (uint32_t)(c.ref[j] & 3))) break;
+    }
+    return j < 0 ? 0 : j;
+}
+__global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, int32_t *__restrict__ lo)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    const Event e = ev[k];
+    int64_t reach = 0x7fffffff;
+    if (e.live) {
+        const int64_t p = e.pos;
+        reach = p;                                      // substitution: no scan; it only matters as a neighbour (prev_del)
+        if (e.type == 2) reach = reach_del(c, (e.hap & 1) ? 0 : 1, p);         // haplotype 1 for hom and hap-1 events
+        else if (e.type == 3) reach = reach_ins(c, (e.hap & 1) ? 0 : 1, p);    // both copies carry the same bases before justification
+        else if (e.type == 4) {                         // cell patched from a mutation-input file: whatever the two cells hold
+            for (int h = 0; h < 2; ++h) {
+                const uint8_t t = c.hap[h].cells[p] & TMASK;
+                int64_t r = p;
+                if (t == T_DEL) r = reach_del(c, h, p); else if (t == T_INS) r = reach_ins(c, h, p);
+                if (r < reach) reach = r;
+            }
+        }
+    }
+    lo[k] = (int32_t)reach;
+}
+// single block: sufmin[k] = min(lo[k..n))
+__global__ void k_sufmin(const int32_t *__restrict__ lo, uint32_t n, int32_t *__restrict__ sufmin)
+{
+    __shared__ int32_t sm[16];
+    __shared__ int32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0x7fffffff;
+    __syncthreads();
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    const uint32_t nchunk = (n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t ch = 0; ch < nchunk; ++ch) {
+        // walk the array from its end: thread t handles element (n-1) - (ch*blockDim + t)
+        const int64_t i = (int64_t)n - 1 - ((int64_t)ch * blockDim.x + threadIdx.x);
+        int32_t v = i >= 0 ? lo[i] : 0x7fffffff;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d); if (lane >= d && o < v) v = o; }   // inclusive min-scan
+        if (lane == 63) sm[wave] = v;
+        __syncthreads();
+        int32_t pre = carry_s;
+        for (int w = 0; w < wave; ++w) if (sm[w] < pre) pre = sm[w];
+        if (pre < v) v = pre;
+        if (i >= 0) sufmin[i] = v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry_s = v;
+        (void)nw;
+        __syncthreads();
+    }
+}
+__global__ void k_jbound(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const int32_t *__restrict__ sufmin, uint8_t *__restrict__ bound)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_cand) return;
+    uint8_t b = 0;
+    if (ev[k].live) {
+        int64_t a = (int64_t)k - 1;
+        while (a >= 0 && !ev[a].live) --a;
+        if (a < 0) b = 1;
+        else {
+            const int64_t right_a = (int64_t)ev[a].pos + (ev[a].type == 2 ? (int64_t)ev[a].len - 1 : 0);
+            if ((int64_t)sufmin[k] > right_a) {
+                for (int64_t q = right_a + 1; q < (int64_t)ev[k].pos; ++q) if (c.ref[q] < 4) { b = 1; break; }
+            }
+        }
+    }
+    bound[k] = b;
+}
+__global__ void k_jrun(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const uint8_t *__restrict__ bound)
+{
+    const uint32_t k0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k0 >= n_cand || !bound[k0]) return;
+    int prev_del[2] = {0, 0};
+    int64_t last = -1;
+    for (uint32_t k = k0; k < n_cand; ++k) {
+        const Event e = ev[k];
+        if (!e.live) continue;
+        if (k > k0 && bound[k]) break;
+        const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
+        if (k > k0 && (prev_del[0] | prev_del[1]))      // an unmutated non-N position in the gap resets prev_del (mut.c:585-587)
+            for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
+        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
+        last = right;
+    }
+}
+
+// mutation-input files: the host resolved the file's entries into final cell values (dw_mutin.cpp); scatter them
+__global__ void k_apply_patches(const int32_t *__restrict__ pos, const uint16_t *__restrict__ cells, uint32_t n, uint8_t *h0, uint8_t *h1)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { h0[pos[k]] = (uint8_t)(cells[k] & 0xff); h1[pos[k]] = (uint8_t)(cells[k] >> 8); }
+}
+
+// mutated cells for the host's mutations.txt / .vcf writer
+__global__ void k_collect_mask(const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, int64_t l,
+                               uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count)
+{
+    __shared__ uint32_t sm[17];
+    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    uint32_t bits = 0;
+    if (p0 < l) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(h0 + p0), b = *reinterpret_cast<const uint4 *>(h1 + p0);
+        const uint32_t m[4] = {(a.x | b.x) & 0x30303030u, (a.y | b.y) & 0x30303030u, (a.z | b.z) & 0x30303030u, (a.w | b.w) & 0x30303030u};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (((m[q >> 2] >> (8 * (q & 3))) & 0xff) && p0 + q < l) bits |= 1u << q;
+    }
+    mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x] = (uint16_t)bits;
+    uint32_t total;
+    (void)block_excl_scan((uint32_t)__popc(bits), sm, &total);
+    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+__global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, uint16_t *__restrict__ cells)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) cells[k] = (uint16_t)(h0[pos[k]] | (h1[pos[k]] << 8));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (declared in dw_launch.hpp)
+// ------------------------------------------------------------------------------------------------
+void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l)
+{
+    const uint64_t nchunk = (uint64_t)(l + 15) >> 4;
+    uint32_t nb = cdiv(nchunk, 256); if (nb > (1u << 16)) nb = 1u << 16; if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, ascii, ref, h0, h1, l);
+}
+void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count)
+{
+    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, l, wp, contig_index, mask, block_count);
+}
+void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out)
+{
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, data, n, total_out);
+}
+void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l)
+{
+    hipLaunchKernelGGL(k_compact, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, mask, block_base, out);
+}
+void launch_events(hipStream_t st, const int32_t *cand, uint32_t n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del)
+{
+    if (n) hipLaunchKernelGGL(k_events, dim3(cdiv(n, 256)), dim3(256), 0, st, cand, n, ref, l, wp, contig_index, ev, max_del);
+}
+void launch_resolve(hipStream_t st, Event *ev, uint32_t n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4)
+{
+    if (n) hipLaunchKernelGGL(k_resolve, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, max_del, flags);
+    hipLaunchKernelGGL(k_scan4, dim3(1), dim3(1024), 0, st, flags, n, tot4);
+}
+void launch_apply(hipStream_t st, Event *ev, uint32_t n, const uint4 *flags, ContigDev c, WalkParams wp)
+{
+    if (n) hipLaunchKernelGGL(k_apply, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, flags, c, wp);
+}
+void launch_justify_seq(hipStream_t st, const Event *ev, uint32_t n, ContigDev c)
+{
+    if (n) hipLaunchKernelGGL(k_justify_seq, dim3(1), dim3(64), 0, st, ev, n, c);
+}
+void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_jreach, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, lo);
+    hipLaunchKernelGGL(k_sufmin, dim3(1), dim3(1024), 0, st, lo, n, sufmin);
+    hipLaunchKernelGGL(k_jbound, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
+    hipLaunchKernelGGL(k_jrun, dim3(cdiv(n, 64)), dim3(64), 0, st, ev, n, c, bound);
+}
+void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
+{
+    if (n) hipLaunchKernelGGL(k_apply_patches, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, cells, n, h0, h1);
+}
+void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count)
+{
+    hipLaunchKernelGGL(k_collect_mask, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, h0, h1, l, mask, block_count);
+}
+void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells)
+{
+    if (n) hipLaunchKernelGGL(k_gather, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, n, h0, h1, cells);
+}
+
+} // namespace dw

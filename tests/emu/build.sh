@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")"
 SRC=../../dwgsim_amd/csrc
-g++ -O2 -g -std=c++17 -ffp-contract=off -fPIC -shared -pthread -I. -x c++ $SRC/dw_kernels.hip $SRC/dw_host.cpp $SRC/dw_mutin.cpp hip_emu.cpp -o libdwgsim_emu.so
+g++ -O2 -g -std=c++17 -ffp-contract=off -fPIC -shared -pthread -I. -x c++ $SRC/dw_walk.hip $SRC/dw_simulate.hip $SRC/dw_host.cpp $SRC/dw_mutin.cpp hip_emu.cpp -o libdwgsim_emu.so
 echo built tests/emu/libdwgsim_emu.so
