@@ -76,6 +76,9 @@ DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+#ifndef DW_EMU
+        asm volatile("" : "+s"(k0), "+s"(k1));      // keep the round keys out of 20 hoisted SGPRs: two SALU adds per round instead
+#endif
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
