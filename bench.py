@@ -138,9 +138,9 @@ def main():
             "metric": "M read-pairs/sec (2x150 bp PE)", "value": round(value, 3), "unit": "M read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"S2 {name}: one {tot_len} bp uniform-random contig (BASELINE configs[1] stand-in), dwgsim {flags}, "
+            "config": {"workload": f"{'S3' if args.workload == 'chr20' else 'S2'} {name}: one {tot_len} bp uniform-random contig (BASELINE configs[{2 if args.workload == 'chr20' else 1}] stand-in), dwgsim {flags}, "
                                    f"{n_pairs} pairs per GPU per step; step = mutation walk + all pairs, FASTQ text left in HBM",
-                       "pairs_per_gpu": n_pairs, "fastq_bytes_per_step_per_gpu": stats["bytes"], "random_pairs": stats["n_random"],
+                       "pairs_per_gpu": n_pairs, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2), "random_pairs": stats["n_random"],
                        "parallelism": f"read-index shards x{world}"},
             "breakdown_ms": {"walk": round(stats["walk_ms"] / K, 4), "rand_count_exchange": round(stats["count_ms"] / K, 4),
                              "batch_kernels": round(stats["kernel_ms"] / K, 4), "simulate_kernel": round(sim_ms, 4)},
