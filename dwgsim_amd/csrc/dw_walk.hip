@@ -76,25 +76,19 @@ __global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkPara
     if (threadIdx.x == 0) block_count[blockIdx.x] = total;
 }
 
-// single-block exclusive scan (in place) of n uint32; optional 64-bit total
+// single-block exclusive scan (in place) of n uint32; optional 64-bit total.  One barrier per chunk: the LDS scratch alternates
+// between two areas and every thread carries the running total itself.
 __global__ void k_scan_excl(uint32_t *data, uint32_t n, uint64_t *total_out)
 {
-    __shared__ uint32_t sm[17];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    uint64_t grand = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
+    __shared__ uint32_t sm[2][1][16];
+    uint64_t grand = 0; int buf = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x, buf ^= 1) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? data[i] : 0;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, sm, &total);
-        const uint32_t carry = carry_s;
-        if (i < n) data[i] = ex + carry;
-        grand += total;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + total;
-        __syncthreads();
+        const uint32_t v[1] = {i < n ? data[i] : 0u};
+        uint32_t ex[1], total[1];
+        block_excl_scan_n<1>(v, sm[buf], ex, total);
+        if (i < n) data[i] = ex[0] + (uint32_t)grand;
+        grand += total[0];
     }
     if (total_out && threadIdx.x == 0) *total_out = grand;
 }
@@ -189,26 +183,23 @@ __global__ void k_resolve(Event *ev, uint32_t n_cand, const uint32_t *max_del_p,
     flags[k] = f;
 }
 
-// exclusive scan of the four insertion-allocation columns (single block); totals -> tot[0..3]
+// exclusive scan of the four insertion-allocation columns (single block, one barrier per chunk); totals -> tot[0..3]
 __global__ void k_scan4(uint4 *flags, uint32_t n, uint32_t *tot)
 {
-    __shared__ uint32_t sm[17];
-    __shared__ uint32_t carry_s[4];
-    if (threadIdx.x < 4) carry_s[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
+    __shared__ uint32_t sm[2][4][16];
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int buf = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x, buf ^= 1) {
         const uint32_t i = base + threadIdx.x;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (i < n) v = flags[i];
         const uint32_t dead = v.x & 0x80000000u;
-        uint32_t in[4] = {v.x & 0x7fffffffu, v.y, v.z, v.w}, ex[4], total[4];
-        for (int c = 0; c < 4; ++c) ex[c] = block_excl_scan(in[c], sm, &total[c]) + carry_s[c];
-        if (i < n) flags[i] = make_uint4(ex[0] | dead, ex[1], ex[2], ex[3]);
-        __syncthreads();
-        if (threadIdx.x < 4) carry_s[threadIdx.x] += total[threadIdx.x];
-        __syncthreads();
+        const uint32_t in[4] = {v.x & 0x7fffffffu, v.y, v.z, v.w};
+        uint32_t ex[4], total[4];
+        block_excl_scan_n<4>(in, sm[buf], ex, total);
+        if (i < n) flags[i] = make_uint4((ex[0] + c0) | dead, ex[1] + c1, ex[2] + c2, ex[3] + c3);
+        c0 += total[0]; c1 += total[1]; c2 += total[2]; c3 += total[3];
     }
-    if (threadIdx.x < 4) tot[threadIdx.x] = carry_s[threadIdx.x];
+    if (threadIdx.x == 0) { tot[0] = c0; tot[1] = c1; tot[2] = c2; tot[3] = c3; }
 }
 
 // K3: write live events into the cells and the insertion tables.
@@ -394,28 +385,23 @@ __global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDe
 // single block: sufmin[k] = min(lo[k..n))
 __global__ void k_sufmin(const int32_t *__restrict__ lo, uint32_t n, int32_t *__restrict__ sufmin)
 {
-    __shared__ int32_t sm[16];
-    __shared__ int32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0x7fffffff;
-    __syncthreads();
+    __shared__ int32_t sm[2][16];
+    int32_t carry = 0x7fffffff; int buf = 0;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
     const uint32_t nchunk = (n + blockDim.x - 1) / blockDim.x;
-    for (uint32_t ch = 0; ch < nchunk; ++ch) {
+    for (uint32_t ch = 0; ch < nchunk; ++ch, buf ^= 1) {
         // walk the array from its end: thread t handles element (n-1) - (ch*blockDim + t)
         const int64_t i = (int64_t)n - 1 - ((int64_t)ch * blockDim.x + threadIdx.x);
         int32_t v = i >= 0 ? lo[i] : 0x7fffffff;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d); if (lane >= d && o < v) v = o; }   // inclusive min-scan
-        if (lane == 63) sm[wave] = v;
+        if (lane == 63) sm[buf][wave] = v;
         __syncthreads();
-        int32_t pre = carry_s;
-        for (int w = 0; w < wave; ++w) if (sm[w] < pre) pre = sm[w];
+        int32_t pre = carry, all = carry;                    // minimum of everything before this wave / of the whole chunk so far
+        for (int w = 0; w < nw; ++w) { const int32_t t = sm[buf][w]; if (t < all) all = t; if (w < wave && t < pre) pre = t; }
         if (pre < v) v = pre;
         if (i >= 0) sufmin[i] = v;
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry_s = v;
-        (void)nw;
-        __syncthreads();
+        carry = all;
     }
 }
 __global__ void k_jbound(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const int32_t *__restrict__ sufmin, uint8_t *__restrict__ bound)
