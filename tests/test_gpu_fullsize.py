@@ -107,3 +107,45 @@ def test_chr20_sized_windows_and_invariants(lib, oracle_bin, tmp_path):
         assert seq_bytes[body].all()
         q = np.concatenate([data[a:a + 150] for a in starts[3::4][:: max(1, n_pairs // 20000)]])
         assert q.min() >= 33 and q.max() <= 73
+
+
+def _assembly_like():
+    """A scaffold-level assembly in miniature: 14 contigs from 150 bp to 3 Mb, names with underscores / dots / a 200-character
+    name, N-rich and all-N contigs, contigs shorter than a read or a fragment (skip rules #2-#5, dwgsim.c:595-618)."""
+    rc = synth.random_contig
+    return [
+        ("chr1_synth", rc(3_000_000, 101, [(0, 10_000), (1_500_000, 1_500_600)])),
+        ("scaffold_0001.1", rc(800_000, 102)),
+        ("tiny_a", rc(150, 103)),                                   # shorter than the fragment: skipped
+        ("all_N", np.full(50_000, ord("N"), dtype=np.uint8)),       # every attempt fails on it unless it gets no pairs
+        ("x" * 200, rc(400_000, 104, [(100, 400)])),
+        ("scaffold_0002", rc(1_200_000, 105, [(600_000, 600_050)])),
+        ("tiny_b", rc(420, 106)),
+        ("unplaced_17_random", rc(90_000, 107)),
+        ("scaffold_0003", rc(2_000_000, 108)),
+        ("mito", rc(16_569, 109)),
+        ("tiny_c", rc(299, 110)),
+        ("scaffold_0004", rc(650_000, 111, [(0, 200), (649_000, 650_000)])),
+        ("scaffold_0005", rc(33_000, 112)),
+        ("last_one", rc(500_000, 113)),
+    ]
+
+
+@pytest.mark.parametrize("flags", [
+    "-z 77 -N 60000 -1 100 -2 100 -d 350 -s 30 -r 0.002 -R 0.2 -y 0.03 -n 2",     # -N: the last contig takes the remainder (dwgsim.c:535-537)
+    "-z 78 -C 1.2 -1 125 -2 0 -r 0.001 -e 0.01-0.03 -o 2 -P lib1",                  # -C, single end, BFAST output only, read prefix
+])
+def test_assembly_like_multi_contig_job_bit_exact(lib, oracle_bin, tmp_path, flags):
+    """rand_ii and n_sim chained over many contigs, per-contig RNG keys, skip rules in the middle of the genome, long names."""
+    contigs = [c for c in _assembly_like() if c[0] != "all_N"] if "-N" in flags else _assembly_like()
+    fa = str(tmp_path / "asm.fa")
+    synth.write_fasta(fa, contigs)
+    _oracle(oracle_bin, flags, fa, str(tmp_path / "o"))
+    res = api.run_job(api.parse_flags(flags, lib), contigs, lib=lib)
+    for k, suf in ((0, "bwa.read1.fastq"), (1, "bwa.read2.fastq"), (2, "bfast.fastq")):
+        p = str(tmp_path / ("o." + suf))
+        want = open(p, "rb").read() if os.path.exists(p) else b""
+        assert len(res.streams[k]) == len(want) and hashlib.sha256(res.streams[k]).hexdigest() == hashlib.sha256(want).hexdigest(), suf
+    assert sum(len(s) for s in res.streams.values()) > 10_000_000
+    assert res.mutations_txt == open(str(tmp_path / "o.mutations.txt"), "rb").read()
+    assert res.mutations_vcf == open(str(tmp_path / "o.mutations.vcf"), "rb").read()
