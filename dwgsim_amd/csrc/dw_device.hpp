@@ -57,6 +57,10 @@ DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
     return lo;
 }
 
+DW_DEV uint32_t count_of(Count c) { if (!c.dev) return c.host; const uint64_t n = *c.dev; return n < (uint64_t)c.host ? (uint32_t)n : c.host; }
+// walk kernels: the insertion-table sizes come from the device while the host has not read them back yet
+DW_DEV void adopt_device_sizes(ContigDev &c) { if (c.tot4) { c.hap[0].n_ins = c.tot4[0]; c.hap[1].n_ins = c.tot4[2]; } }
+
 [[maybe_unused]] static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 } // namespace dw

@@ -115,6 +115,7 @@ ContigDev contig_dev(const Contig &k)
         d.hap[h].ins_off = k.d_ins_off[h]; d.hap[h].ins_bases = k.d_ins_bases[h]; d.hap[h].n_ins = k.n_ins[h];
     }
     d.ref = k.d_ref; d.l = k.l; d.contig_index = k.contig_index;
+    d.tot4 = nullptr; d.cap_bases[0] = d.cap_bases[1] = 0;
     return d;
 }
 
@@ -493,8 +494,8 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         launch_apply_patches(c->stream, (const int32_t *)c->w_ppos.p, (const uint16_t *)c->w_pcells.p, np, k.d_cells[0], k.d_cells[1]);
         const ContigDev cd = contig_dev(k);
         if (nev) {
-            if (c->seq_justify) launch_justify_seq(c->stream, (const Event *)c->w_ev.p, nev, cd);
-            else launch_justify(c->stream, (const Event *)c->w_ev.p, nev, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+            if (c->seq_justify) launch_justify_seq(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd);
+            else launch_justify(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
         }
         HIPC(c, hipGetLastError());
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -504,52 +505,71 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
     uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
-    // K1: candidate sites -> ordered list
-    launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt);
-    launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
-    HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    const uint32_t n_cand = (uint32_t)c->h_counters[7];
-    k.n_cand = n_cand;
-    if (n_cand == 0) return DWGSIM_HIP_OK;
-    if (ensure(c, c->w_cand, sizeof(int32_t) * (size_t)n_cand) || ensure(c, c->w_ev, sizeof(Event) * (size_t)n_cand) ||
-        ensure(c, c->w_flags, sizeof(uint4) * (size_t)n_cand) || ensure(c, c->w_small, 8 * sizeof(uint32_t)) ||
-        ensure(c, c->w_lo, sizeof(int32_t) * (size_t)n_cand) || ensure(c, c->w_sufmin, sizeof(int32_t) * (size_t)n_cand) ||
-        ensure(c, c->w_bound, (size_t)n_cand)) return DWGSIM_HIP_ERR_DEVICE;
-    int32_t *d_cand = (int32_t *)c->w_cand.p; Event *d_ev = (Event *)c->w_ev.p; uint4 *d_flags = (uint4 *)c->w_flags.p;
-    uint32_t *d_small = (uint32_t *)c->w_small.p;   // [0] max_del, [1..4] tot4
-    HIPC(c, hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), c->stream));
-    launch_compact(c->stream, d_mask, d_cnt, d_cand, l);
-    // K2: events, liveness, insertion-table allocation
-    launch_events(c->stream, d_cand, n_cand, k.d_ref, l, wp, k.contig_index, d_ev, &d_small[0]);
-    launch_resolve(c->stream, d_ev, n_cand, &d_small[0], d_flags, &d_small[1]);
-    uint32_t h_small[8];
-    HIPC(c, hipMemcpyAsync(h_small, d_small, sizeof h_small, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    for (int h = 0; h < 2; ++h) {
-        k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h];
-        const size_t n = k.n_ins[h] ? k.n_ins[h] : 1, nb = k.n_ins_bases[h] ? k.n_ins_bases[h] : 1;
-        if (n > k.cap_ins[h]) {
-            hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]);
-            k.cap_ins[h] = n + n / 4 + 64;
-            HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * k.cap_ins[h]));
-            HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * k.cap_ins[h]));
-            HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * k.cap_ins[h]));
+    // The whole walk is enqueued without an intermediate host read-back: buffers are sized for a capacity (candidate sites are a
+    // Binomial(l, mut_rate) draw: mean + 8 sigma), the kernels take their element counts from device memory, and the one
+    // synchronisation at the end also tells whether a capacity was exceeded -- then the walk is simply run again with exact sizes.
+    const double mean = (double)l * c->prm.mut_rate;
+    uint32_t cap = (uint32_t)std::min<double>((double)l, mean + 8.0 * sqrt(mean + 1.0) + 256.0);
+    size_t cap_bases = (size_t)cap * 8 + 4096;
+    if (const char *e = getenv("DWGSIM_HIP_WALK_CAP")) { cap = (uint32_t)atoi(e); cap_bases = 1; }      // tests: start too small, exercise the re-run
+    for (int attempt = 0; ; ++attempt) {
+        if (attempt > 0) {      // start again from the resident packed reference
+            const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
+            for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
         }
-        if (nb > k.cap_bases[h]) {
-            hipFree(k.d_ins_bases[h]);
-            k.cap_bases[h] = nb + nb / 4 + 256;
-            HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], k.cap_bases[h] + 16));
+        const size_t ncap = cap ? cap : 1;
+        if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
+            ensure(c, c->w_flags, sizeof(uint4) * ncap) || ensure(c, c->w_small, 8 * sizeof(uint32_t)) ||
+            ensure(c, c->w_lo, sizeof(int32_t) * ncap) || ensure(c, c->w_sufmin, sizeof(int32_t) * ncap) ||
+            ensure(c, c->w_bound, ncap)) return DWGSIM_HIP_ERR_DEVICE;
+        for (int h = 0; h < 2; ++h) {      // insertion tables: at most one entry per candidate; the base pools are checked on the device
+            if (ncap > k.cap_ins[h]) {
+                hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]);
+                k.cap_ins[h] = ncap + ncap / 4 + 64;
+                HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * k.cap_ins[h]));
+                HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * k.cap_ins[h]));
+                HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * k.cap_ins[h]));
+            }
+            if (cap_bases > k.cap_bases[h]) {
+                hipFree(k.d_ins_bases[h]);
+                k.cap_bases[h] = cap_bases + cap_bases / 4 + 256;
+                HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], k.cap_bases[h] + 16));
+            }
         }
+        int32_t *d_cand = (int32_t *)c->w_cand.p; Event *d_ev = (Event *)c->w_ev.p; uint4 *d_flags = (uint4 *)c->w_flags.p;
+        uint32_t *d_small = (uint32_t *)c->w_small.p;   // [0] max_del, [1..4] tot4
+        const Count nc{&c->d_counters[7], cap};
+        HIPC(c, hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), c->stream));
+        // K1: candidate sites -> ordered list
+        launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt);
+        launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
+        launch_compact(c->stream, d_mask, d_cnt, d_cand, l, cap);
+        // K2: events, liveness, insertion-table allocation
+        launch_events(c->stream, d_cand, nc, k.d_ref, l, wp, k.contig_index, d_ev, &d_small[0]);
+        launch_resolve(c->stream, d_ev, nc, &d_small[0], d_flags, &d_small[1]);
+        // K3 + K4
+        ContigDev cd = contig_dev(k);
+        cd.tot4 = &d_small[1]; cd.cap_bases[0] = (uint32_t)std::min<size_t>(k.cap_bases[0], 0xFFFFFFFFu); cd.cap_bases[1] = (uint32_t)std::min<size_t>(k.cap_bases[1], 0xFFFFFFFFu);
+        launch_apply(c->stream, d_ev, nc, d_flags, cd, wp);
+        if (c->seq_justify) launch_justify_seq(c->stream, d_ev, nc, cd);
+        else launch_justify(c->stream, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipMemcpyAsync(&c->h_counters[8], d_small, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));      // h_counters[8..11] as 8 x u32
+        HIPC(c, hipStreamSynchronize(c->stream));
+        const uint64_t n_cand = c->h_counters[7];
+        const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&c->h_counters[8]);
+        const bool fits = n_cand <= cap && h_small[2] <= k.cap_bases[0] && h_small[4] <= k.cap_bases[1];
+        if (fits || attempt >= 2) {
+            if (!fits) { c->err = "mutation walk: capacities still exceeded after an exact re-run"; return DWGSIM_HIP_ERR_FAILED; }
+            k.n_cand = (uint32_t)n_cand;
+            for (int h = 0; h < 2; ++h) { k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h]; }
+            return DWGSIM_HIP_OK;
+        }
+        // exact sizes (the counts read back are those of the complete candidate list unless it was truncated: take generous ones then)
+        cap = (uint32_t)std::min<uint64_t>((uint64_t)l, n_cand + 16);
+        cap_bases = std::max<size_t>(cap_bases, (size_t)std::max(h_small[2], h_small[4]) * 2 + (size_t)cap * 8 + 4096);
     }
-    // K3 + K4
-    const ContigDev cd = contig_dev(k);
-    launch_apply(c->stream, d_ev, n_cand, d_flags, cd, wp);
-    if (c->seq_justify) launch_justify_seq(c->stream, d_ev, n_cand, cd);
-    else launch_justify(c->stream, d_ev, n_cand, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
-    HIPC(c, hipGetLastError());
-    HIPC(c, hipStreamSynchronize(c->stream));
-    return DWGSIM_HIP_OK;
 }
 
 // ---- mutations.txt / mutations.vcf from the sparse list of mutated cells (mut.c:781-893) ----
@@ -598,7 +618,7 @@ int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt,
             int32_t *d_pos = nullptr; uint16_t *d_cells = nullptr;
             HIPC(c, hipMalloc((void **)&d_pos, sizeof(int32_t) * (size_t)n));
             HIPC(c, hipMalloc((void **)&d_cells, sizeof(uint16_t) * (size_t)n));
-            launch_compact(c->stream, d_mask, d_cnt, d_pos, l);
+            launch_compact(c->stream, d_mask, d_cnt, d_pos, l, n);
             launch_gather(c->stream, d_pos, n, k.d_cells[0], k.d_cells[1], d_cells);
             pos.resize(n); cells.resize(n);
             HIPC(c, hipMemcpyAsync(pos.data(), d_pos, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));

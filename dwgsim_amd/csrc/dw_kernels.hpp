@@ -44,7 +44,13 @@ struct ContigDev {
     const uint8_t *ref;     // [l + CELL_PAD] reference base codes
     int64_t l;
     uint32_t contig_index;  // RNG key
+    const uint32_t *tot4;   // walk kernels only (else null): device copy of {n_ins[0], n_ins_bases[0], n_ins[1], n_ins_bases[1]} still being produced
+    uint32_t cap_bases[2];  // ... and the capacity of the inserted-base pools
 };
+
+// An element count that is either known on the host or still being produced on the device: kernels are launched for `host`
+// elements (an exact count, or the capacity the buffers were sized for) and work on min(*dev, host).
+struct Count { const uint64_t *dev; uint32_t host; };
 
 struct WalkParams {
     double mut_rate, indel_frac, indel_extend;

@@ -7,12 +7,12 @@ namespace dw {
 void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l);
 void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count);
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out);
-void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l);
-void launch_events(hipStream_t st, const int32_t *cand, uint32_t n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del);
-void launch_resolve(hipStream_t st, Event *ev, uint32_t n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4);
-void launch_apply(hipStream_t st, Event *ev, uint32_t n, const uint4 *flags, ContigDev c, WalkParams wp);
-void launch_justify_seq(hipStream_t st, const Event *ev, uint32_t n, ContigDev c);
-void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound);
+void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l, uint32_t cap);
+void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del);
+void launch_resolve(hipStream_t st, Event *ev, Count n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4);
+void launch_apply(hipStream_t st, Event *ev, Count n, const uint4 *flags, ContigDev c, WalkParams wp);
+void launch_justify_seq(hipStream_t st, const Event *ev, Count n, ContigDev c);
+void launch_justify(hipStream_t st, const Event *ev, Count n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound);
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1);
 void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count);
 void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells);

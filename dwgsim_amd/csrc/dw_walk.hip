@@ -94,22 +94,23 @@ __global__ void k_scan_excl(uint32_t *data, uint32_t n, uint64_t *total_out)
 }
 
 // ordered compaction: positions of set bits of `mask` (one uint16 per thread of the producing kernel)
-__global__ void k_compact(const uint16_t *__restrict__ mask, const uint32_t *__restrict__ block_base, int32_t *__restrict__ out)
+__global__ void k_compact(const uint16_t *__restrict__ mask, const uint32_t *__restrict__ block_base, int32_t *__restrict__ out, uint32_t cap)
 {
     __shared__ uint32_t sm[17];
     uint32_t bits = mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x];
     uint32_t total;
     uint32_t off = block_base[blockIdx.x] + block_excl_scan((uint32_t)__popc(bits), sm, &total);
     const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
-    while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; out[off++] = (int32_t)(p0 + b); }
+    while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; if (off < cap) out[off] = (int32_t)(p0 + b); ++off; }   // (past the capacity: the host re-runs)
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2a: one thread per candidate site: the event it would be if it is live.  mut.c:619-640, 287-308.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_events(const int32_t *__restrict__ cand, uint32_t n_cand, const uint8_t *__restrict__ ref, int64_t l,
+__global__ void k_events(const int32_t *__restrict__ cand, Count nc, const uint8_t *__restrict__ ref, int64_t l,
                          WalkParams wp, uint32_t contig_index, Event *__restrict__ ev, uint32_t *__restrict__ max_del)
 {
+    const uint32_t n_cand = count_of(nc);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_cand) {
         const RngKey key{wp.seed, contig_index};
@@ -156,8 +157,9 @@ DW_DEV bool reached_by_any(const Event *ev, uint32_t k, uint32_t max_del)
     }
     return false;
 }
-__global__ void k_resolve(Event *ev, uint32_t n_cand, const uint32_t *max_del_p, uint4 *flags)
+__global__ void k_resolve(Event *ev, Count nc, const uint32_t *max_del_p, uint4 *flags)
 {
+    const uint32_t n_cand = count_of(nc);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_cand) return;
     const uint32_t max_del = *max_del_p;
@@ -184,8 +186,9 @@ __global__ void k_resolve(Event *ev, uint32_t n_cand, const uint32_t *max_del_p,
 }
 
 // exclusive scan of the four insertion-allocation columns (single block, one barrier per chunk); totals -> tot[0..3]
-__global__ void k_scan4(uint4 *flags, uint32_t n, uint32_t *tot)
+__global__ void k_scan4(uint4 *flags, Count nc, uint32_t *tot)
 {
+    const uint32_t n = count_of(nc);
     __shared__ uint32_t sm[2][4][16];
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int buf = 0;
     for (uint32_t base = 0; base < n; base += blockDim.x, buf ^= 1) {
@@ -203,8 +206,11 @@ __global__ void k_scan4(uint4 *flags, uint32_t n, uint32_t *tot)
 }
 
 // K3: write live events into the cells and the insertion tables.
-__global__ void k_apply(Event *ev, uint32_t n_cand, const uint4 *flags, ContigDev c, WalkParams wp)
+__global__ void k_apply(Event *ev, Count nc, const uint4 *flags, ContigDev c, WalkParams wp)
 {
+    const uint32_t n_cand = count_of(nc);
+    adopt_device_sizes(c);
+    if (c.tot4 && (c.tot4[1] > c.cap_bases[0] || c.tot4[3] > c.cap_bases[1])) return;      // the inserted-base pools are too small: the host re-runs with larger ones
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_cand) return;
     const uint4 f = flags[k];
@@ -307,8 +313,10 @@ DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
     }
 }
 // sequential cross-check (DWGSIM_HIP_JUSTIFY=seq): one thread walks every live event of the contig
-__global__ void k_justify_seq(const Event *ev, uint32_t n_cand, ContigDev c)
+__global__ void k_justify_seq(const Event *ev, Count nc, ContigDev c)
 {
+    const uint32_t n_cand = count_of(nc);
+    adopt_device_sizes(c);
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int prev_del[2] = {0, 0};
     int64_t last = -1;
@@ -360,8 +368,10 @@ DW_DEV int64_t reach_ins(const ContigDev &c, int h, int64_t p)
     }
     return j < 0 ? 0 : j;
 }
-__global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, int32_t *__restrict__ lo)
+__global__ void k_jreach(const Event *__restrict__ ev, Count nc, ContigDev c, int32_t *__restrict__ lo)
 {
+    const uint32_t n_cand = count_of(nc);
+    adopt_device_sizes(c);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_cand) return;
     const Event e = ev[k];
@@ -383,8 +393,9 @@ __global__ void k_jreach(const Event *__restrict__ ev, uint32_t n_cand, ContigDe
     lo[k] = (int32_t)reach;
 }
 // single block: sufmin[k] = min(lo[k..n))
-__global__ void k_sufmin(const int32_t *__restrict__ lo, uint32_t n, int32_t *__restrict__ sufmin)
+__global__ void k_sufmin(const int32_t *__restrict__ lo, Count nc, int32_t *__restrict__ sufmin)
 {
+    const uint32_t n = count_of(nc);
     __shared__ int32_t sm[2][16];
     int32_t carry = 0x7fffffff; int buf = 0;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
@@ -404,8 +415,10 @@ __global__ void k_sufmin(const int32_t *__restrict__ lo, uint32_t n, int32_t *__
         carry = all;
     }
 }
-__global__ void k_jbound(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const int32_t *__restrict__ sufmin, uint8_t *__restrict__ bound)
+__global__ void k_jbound(const Event *__restrict__ ev, Count nc, ContigDev c, const int32_t *__restrict__ sufmin, uint8_t *__restrict__ bound)
 {
+    const uint32_t n_cand = count_of(nc);
+    adopt_device_sizes(c);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_cand) return;
     uint8_t b = 0;
@@ -422,8 +435,10 @@ __global__ void k_jbound(const Event *__restrict__ ev, uint32_t n_cand, ContigDe
     }
     bound[k] = b;
 }
-__global__ void k_jrun(const Event *__restrict__ ev, uint32_t n_cand, ContigDev c, const uint8_t *__restrict__ bound)
+__global__ void k_jrun(const Event *__restrict__ ev, Count nc, ContigDev c, const uint8_t *__restrict__ bound)
 {
+    const uint32_t n_cand = count_of(nc);
+    adopt_device_sizes(c);
     const uint32_t k0 = blockIdx.x * blockDim.x + threadIdx.x;
     if (k0 >= n_cand || !bound[k0]) return;
     int prev_del[2] = {0, 0};
@@ -488,34 +503,35 @@ void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *tota
 {
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, data, n, total_out);
 }
-void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l)
+void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l, uint32_t cap)
 {
-    hipLaunchKernelGGL(k_compact, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, mask, block_base, out);
+    hipLaunchKernelGGL(k_compact, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, mask, block_base, out, cap);
 }
-void launch_events(hipStream_t st, const int32_t *cand, uint32_t n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del)
+// The launchers below size their grids for n.host elements (an exact count or a capacity); the kernels work on min(*n.dev, n.host).
+void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del)
 {
-    if (n) hipLaunchKernelGGL(k_events, dim3(cdiv(n, 256)), dim3(256), 0, st, cand, n, ref, l, wp, contig_index, ev, max_del);
+    if (n.host) hipLaunchKernelGGL(k_events, dim3(cdiv(n.host, 256)), dim3(256), 0, st, cand, n, ref, l, wp, contig_index, ev, max_del);
 }
-void launch_resolve(hipStream_t st, Event *ev, uint32_t n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4)
+void launch_resolve(hipStream_t st, Event *ev, Count n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4)
 {
-    if (n) hipLaunchKernelGGL(k_resolve, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, max_del, flags);
+    if (n.host) hipLaunchKernelGGL(k_resolve, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, max_del, flags);
     hipLaunchKernelGGL(k_scan4, dim3(1), dim3(1024), 0, st, flags, n, tot4);
 }
-void launch_apply(hipStream_t st, Event *ev, uint32_t n, const uint4 *flags, ContigDev c, WalkParams wp)
+void launch_apply(hipStream_t st, Event *ev, Count n, const uint4 *flags, ContigDev c, WalkParams wp)
 {
-    if (n) hipLaunchKernelGGL(k_apply, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, flags, c, wp);
+    if (n.host) hipLaunchKernelGGL(k_apply, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, flags, c, wp);
 }
-void launch_justify_seq(hipStream_t st, const Event *ev, uint32_t n, ContigDev c)
+void launch_justify_seq(hipStream_t st, const Event *ev, Count n, ContigDev c)
 {
-    if (n) hipLaunchKernelGGL(k_justify_seq, dim3(1), dim3(64), 0, st, ev, n, c);
+    if (n.host) hipLaunchKernelGGL(k_justify_seq, dim3(1), dim3(64), 0, st, ev, n, c);
 }
-void launch_justify(hipStream_t st, const Event *ev, uint32_t n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound)
+void launch_justify(hipStream_t st, const Event *ev, Count n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound)
 {
-    if (!n) return;
-    hipLaunchKernelGGL(k_jreach, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, lo);
+    if (!n.host) return;
+    hipLaunchKernelGGL(k_jreach, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, c, lo);
     hipLaunchKernelGGL(k_sufmin, dim3(1), dim3(1024), 0, st, lo, n, sufmin);
-    hipLaunchKernelGGL(k_jbound, dim3(cdiv(n, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
-    hipLaunchKernelGGL(k_jrun, dim3(cdiv(n, 64)), dim3(64), 0, st, ev, n, c, bound);
+    hipLaunchKernelGGL(k_jbound, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
+    hipLaunchKernelGGL(k_jrun, dim3(cdiv(n.host, 64)), dim3(64), 0, st, ev, n, c, bound);
 }
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
 {

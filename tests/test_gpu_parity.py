@@ -107,3 +107,9 @@ def test_count_random_matches_simulate(lib, golden_dir, repeats_fa, which, flags
     from parity_common import check_count_random_matches_simulate
     fasta = repeats_fa if which == "repeats" else os.path.join(golden_dir, which + ".fa")
     check_count_random_matches_simulate(lib, fasta, flags)
+
+
+def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa, monkeypatch):
+    """See tests/test_emu_parity.py: forced tiny capacities on the repeat-rich 1.8 Mb contigs."""
+    monkeypatch.setenv("DWGSIM_HIP_WALK_CAP", "100")
+    compare_case(lib, oracle_bin, repeats_fa, "-z 32 -M 2 -r 0.2 -R 0.9 -X 0.3 -I 2")
