@@ -185,21 +185,31 @@ __global__ void k_resolve(Event *ev, Count nc, const uint32_t *max_del_p, uint4 
     flags[k] = f;
 }
 
-// exclusive scan of the four insertion-allocation columns (single block, one barrier per chunk); totals -> tot[0..3]
+// exclusive scan of the four insertion-allocation columns (single block); totals -> tot[0..3].  Eight consecutive rows per thread
+// (all loads in flight at once, a sequential scan in registers), then one block scan of the thread totals: one barrier per 8192 rows.
 __global__ void k_scan4(uint4 *flags, Count nc, uint32_t *tot)
 {
     const uint32_t n = count_of(nc);
+    constexpr uint32_t ITEMS = 8;
     __shared__ uint32_t sm[2][4][16];
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int buf = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x, buf ^= 1) {
-        const uint32_t i = base + threadIdx.x;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i < n) v = flags[i];
-        const uint32_t dead = v.x & 0x80000000u;
-        const uint32_t in[4] = {v.x & 0x7fffffffu, v.y, v.z, v.w};
+    for (uint32_t base = 0; base < n; base += blockDim.x * ITEMS, buf ^= 1) {
+        const uint32_t i0 = base + threadIdx.x * ITEMS;
+        uint4 v[ITEMS];
+#pragma unroll
+        for (uint32_t q = 0; q < ITEMS; ++q) v[q] = i0 + q < n ? flags[i0 + q] : make_uint4(0, 0, 0, 0);
+        uint32_t t[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t q = 0; q < ITEMS; ++q) {         // row -> its exclusive prefix inside the thread (the dead flag stays in bit 31 of x)
+            const uint32_t dead = v[q].x & 0x80000000u, x = v[q].x & 0x7fffffffu, y = v[q].y, z = v[q].z, w = v[q].w;
+            v[q] = make_uint4(t[0] | dead, t[1], t[2], t[3]);
+            t[0] += x; t[1] += y; t[2] += z; t[3] += w;
+        }
         uint32_t ex[4], total[4];
-        block_excl_scan_n<4>(in, sm[buf], ex, total);
-        if (i < n) flags[i] = make_uint4((ex[0] + c0) | dead, ex[1] + c1, ex[2] + c2, ex[3] + c3);
+        block_excl_scan_n<4>(t, sm[buf], ex, total);
+#pragma unroll
+        for (uint32_t q = 0; q < ITEMS; ++q)
+            if (i0 + q < n) flags[i0 + q] = make_uint4(((v[q].x & 0x7fffffffu) + ex[0] + c0) | (v[q].x & 0x80000000u), v[q].y + ex[1] + c1, v[q].z + ex[2] + c2, v[q].w + ex[3] + c3);
         c0 += total[0]; c1 += total[1]; c2 += total[2]; c3 += total[3];
     }
     if (threadIdx.x == 0) { tot[0] = c0; tot[1] = c1; tot[2] = c2; tot[3] = c3; }
