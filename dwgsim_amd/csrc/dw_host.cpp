@@ -827,6 +827,15 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, 
     const size_t n = (size_t)c->out_bytes[slot][stream];
     if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
     if (n == 0) return DWGSIM_HIP_OK;
+    {   // a pinned (page-locked / registered) destination takes one direct copy at link speed
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, host_dst) == hipSuccess && at.type == hipMemoryTypeHost) {
+            HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            return DWGSIM_HIP_OK;
+        }
+        (void)hipGetLastError();      // pageable memory: the query reports an error that must not stick
+    }
     // double-buffered pinned staging: D2H of chunk k+1 overlaps the host copy of chunk k
     const size_t CH = (size_t)16 << 20;
     if (!c->h_stage) { HIPC(c, hipHostMalloc(&c->h_stage, 2 * CH, hipHostMallocDefault)); c->h_stage_cap = 2 * CH; }

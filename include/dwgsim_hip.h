@@ -153,7 +153,8 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii
 int dwgsim_hip_simulate(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
                         uint64_t rand_base, int slot, dwgsim_hip_batch_t *out);
 
-/* Copy one finished stream of a slot to host memory (pinned staging + hipMemcpyAsync inside). */
+/* Copy one finished stream of a slot to host memory.  A page-locked destination (hipHostMalloc / hipHostRegister) takes one direct
+ * hipMemcpyAsync at link speed; pageable memory goes through double-buffered pinned staging inside. */
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
 /* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
