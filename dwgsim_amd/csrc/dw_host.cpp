@@ -38,7 +38,7 @@ struct Contig {
     uint32_t n_ins[2] = {0, 0}, n_ins_bases[2] = {0, 0};
     size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
     uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
-    uint32_t n_cand = 0, n_events_live = 0;
+    uint32_t n_cand = 0;
     uint16_t *d_summ[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries for count_random (built on demand)
     int64_t l_place = 0;                // fragment-placement length (region length with -x)
     int32_t *d_reg = nullptr; int32_t n_reg = 0;   // -x: [start[0..n), end[0..n)] of this contig
@@ -66,7 +66,7 @@ struct dwgsim_hip_ctx {
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
     // simulate() working set
-    DevBuf meta, block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
+    DevBuf block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
     DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
@@ -323,7 +323,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     hipFree(c->status_all.p);
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
-    hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
+    hipFree(c->d_rand_fixed); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters); hipFree(c->d_flow);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -715,10 +715,9 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
     const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block (<= PAIRS_PER_BLOCK of k_place)
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
-    if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
-    a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
+    a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
     for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)(nblk ? nblk : 1);
     const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
     a.cap = lmax;

@@ -465,7 +465,6 @@ DW_DEV void put_hex(Out2<OUT> &o, uint64_t v)
         o.putn(w, cnt);
     }
 }
-DW_DEV uint32_t base_char(uint32_t v) { return (uint32_t)((0x4E4E4E4E54474341ull >> (8 * (v & 7))) & 0xff); }  // "ACGTNNNN"
 DW_DEV uint32_t base_chars4(uint32_t nibbles) { return lut8(0x4E4E4E4Eu, 0x54474341u, spread4(nibbles)); }        // four codes (<= 7) -> "ACGTNNNN"[code]
 DW_DEV uint32_t colour_digits4(uint32_t nibbles) { return lut8(0x34343434u, 0x33323130u, spread4(nibbles)); }     // four colours -> "01234444"[colour]
 

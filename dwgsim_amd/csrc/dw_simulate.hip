@@ -108,7 +108,6 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
             else if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; done = true; }
         }
     }
-    if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);
     uint32_t total;
     (void)block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &total);
     if (threadIdx.x == 0) a.block_rand[blockIdx.x] = total;
