@@ -22,7 +22,7 @@ ALGO_BYTES_PER_PAIR = 863.0        # 713 B FASTQ written + 150 B
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(contigs, sample_pairs=150000):
+def cpu_baseline(contigs, sample_pairs=250000):      # ~12 s of single-thread CPU work
     """The unmodified reference (oracle/_ref/dwgsim, kind 'reference') -- or the oracle port in drand48
     mode if the prebuilt binary is absent -- timed on this box's host cores on a bounded sample of the
     same workload (same contig, same flags, -N sample instead of -C 30)."""
