@@ -713,7 +713,17 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
     a.summ[0] = k.d_summ[0]; a.summ[1] = k.d_summ[1];      // null unless count_random built them
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
-    const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block (<= PAIRS_PER_BLOCK of k_place)
+    // lanes per k_simulate block: the staged read (lds_words per lane) must fit LDS; long Illumina / SOLiD reads get one-wave blocks
+    const int lmax0 = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
+    a.sim_threads = SIM_THREADS;
+    if (p.data_type != 2 && (size_t)((lmax0 + 7) / 8) * SIM_THREADS * 4 > SIM_LDS_BUDGET) {
+        a.sim_threads = SIM_THREADS_LONG;
+        if ((size_t)((lmax0 + 7) / 8) * SIM_THREADS_LONG * 4 > SIM_LDS_BUDGET) {
+            char b[160]; snprintf(b, sizeof b, "dwgsim-hip: reads longer than %d bases are not supported for -c 0 / -c 1\n", (int)(SIM_LDS_BUDGET / (SIM_THREADS_LONG * 4) * 8));
+            c->err = b; return DWGSIM_HIP_ERR_UNSUP;
+        }
+    }
+    const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
@@ -754,7 +764,7 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, 
         kp->summ_valid = true;
     }
     SimArgs a;
-    if (build_sim_args(c, *kp, first_ii, n_pairs, 0, a)) return DWGSIM_HIP_ERR_DEVICE;
+    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, 0, a)) return rc;
     HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
     launch_place(c->stream, a);
     const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
@@ -776,7 +786,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = 0;
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     SimArgs a;
-    if (build_sim_args(c, *kp, first_ii, n_pairs, rand_base, a)) return DWGSIM_HIP_ERR_DEVICE;
+    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, rand_base, a)) return rc;
     if (c->has_regions && kp->n_reg == 0 && c->prm.rand_read < 1.0) { c->err = "dwgsim-hip: this contig has no target region (-x): the reference's placement loop would not terminate\n"; return DWGSIM_HIP_ERR_ARG; }
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     const dwgsim_hip_params_t &p = c->prm;
@@ -789,7 +799,7 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     if (!a.p.has_bfast) cap[2] = 0;
     (void)nreads;
     for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
-    const uint64_t sim_ppb = (uint64_t)(SIM_THREADS / (p.length[1] > 0 ? 2 : 1));
+    const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));
     const uint32_t nblk = (uint32_t)((n_pairs + sim_ppb - 1) / sim_ppb);
     HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
     HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));

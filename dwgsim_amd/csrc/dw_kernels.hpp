@@ -10,6 +10,8 @@ constexpr int PAIRS_PER_BLOCK = 128;     // k_place / k_calibrate: pairs (reads)
 #define DW_SIM_THREADS 256
 #endif
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
+constexpr int SIM_THREADS_LONG = 64;          // ... for reads whose staged bases do not fit LDS at SIM_THREADS lanes (up to ~5 kb)
+constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for (160 KB per CU minus the static part)
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_POS_PER_BLOCK = SCAN_POS_PER_THREAD * SCAN_THREADS;   // 4096
@@ -96,6 +98,7 @@ struct SimArgs {
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
     int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
     int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors
+    int32_t sim_threads;          // lanes per k_simulate block chosen by the host: SIM_THREADS, or SIM_THREADS_LONG for long reads
     int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
     uint32_t *flow_scratch;        // Ion Torrent: per-block read buffers in HBM, (lds_words + ceil(cap/16)) words per lane, word w of lane t at [w * nthr + t]
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes

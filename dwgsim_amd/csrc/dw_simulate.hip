@@ -14,6 +14,7 @@
 // The file is compiled in parts so the k_simulate variants build in parallel (csrc/Makefile):
 //   DW_PART 0: k_summarize, k_place, k_selftest_fp64, host launchers and the k_simulate dispatcher
 //   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
+//   DW_PART 7, 8: the one-wave-per-block variants for long Illumina / SOLiD reads
 //   DW_PART -1 (default): everything in one translation unit
 #include "dw_read.hpp"
 #include "dw_launch.hpp"
@@ -210,8 +211,9 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
 }
 
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
-template <int LPP, int OUT, int DT>
-__global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+// NTHR: lanes per block.  SIM_THREADS_LONG (one wave) is the variant for reads too long to stage at SIM_THREADS lanes.
+template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS>
+__global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(SIM_THREADS, (DT == 2 ? DW_ION_WAVES : DT == 1
     __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
     __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
-    constexpr int nthr = SIM_THREADS, PPB = SIM_THREADS / LPP, nwaves = SIM_THREADS / 64;      // PPB pairs per block
+    constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     PH_INIT();
@@ -552,14 +554,23 @@ void launch_sim_2_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, i
 void launch_sim_1_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_long_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_long_1_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_long_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_long_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
-    const uint32_t nb = cdiv(a.n_pairs, SIM_THREADS / (pe ? 2 : 1));
+    const uint32_t nthr = (uint32_t)a.sim_threads;
+    const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const uint32_t nthr = SIM_THREADS;
     const size_t lds = (size_t)(ion ? 4 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack (8 runs); its read buffers are in a.flow_scratch
     const bool solid = a.p.data_type == 1;
+    if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
+        if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }
+        else { if (solid) launch_sim_long_1_1(st, a, nb, lds, out); else launch_sim_long_1_0(st, a, nb, lds, out); }
+        return;
+    }
     if (pe) { if (ion) launch_sim_2_2(st, a, nb, lds, out); else if (solid) launch_sim_2_1(st, a, nb, lds, out); else launch_sim_2_0(st, a, nb, lds, out); }
     else { if (ion) launch_sim_1_2(st, a, nb, lds, out); else if (solid) launch_sim_1_1(st, a, nb, lds, out); else launch_sim_1_0(st, a, nb, lds, out); }
 }
@@ -573,8 +584,24 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
         else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT>), dim3(nb), dim3(nthr), lds, st, a);       \
         else hipLaunchKernelGGL((k_simulate<LPP, 3, DT>), dim3(nb), dim3(nthr), lds, st, a);                     \
     }
+#define DW_SIM_FAMILY_LONG(LPP, DT)                                                                                             \
+    void launch_sim_long_##LPP##_##DT(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out)                          \
+    {                                                                                                                               \
+        const uint32_t nthr = SIM_THREADS_LONG;                                                                                     \
+        if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, DT, SIM_THREADS_LONG>), dim3(nb), dim3(nthr), lds, st, a);             \
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT, SIM_THREADS_LONG>), dim3(nb), dim3(nthr), lds, st, a);        \
+        else hipLaunchKernelGGL((k_simulate<LPP, 3, DT, SIM_THREADS_LONG>), dim3(nb), dim3(nthr), lds, st, a);                      \
+    }
 #if DW_HAS(1)
 DW_SIM_FAMILY(2, 0)
+#endif
+#if DW_HAS(7)
+DW_SIM_FAMILY_LONG(2, 0)
+DW_SIM_FAMILY_LONG(1, 0)
+#endif
+#if DW_HAS(8)
+DW_SIM_FAMILY_LONG(2, 1)
+DW_SIM_FAMILY_LONG(1, 1)
 #endif
 #if DW_HAS(2)
 DW_SIM_FAMILY(1, 0)

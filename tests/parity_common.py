@@ -79,6 +79,10 @@ CASES = [
     ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW} -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
     ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 100 -2 0 -e 0.2 -o 1"),
     ("odd.fa", f"-z 6 -N 3000 -c 2 -f {FLOW} -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2"),
+    # reads too long to stage in LDS at 256 lanes per block: the one-wave-per-block variants (up to ~4.8 kb)
+    ("tiny.fa", "-z 3 -N 400 -1 1500 -2 0 -n 40 -r 0.01 -R 0.3"),
+    ("tiny.fa", "-z 3 -N 300 -1 1300 -2 1400 -d 3600 -s 40 -n 60 -y 0.1"),
+    ("tiny.fa", "-z 3 -N 200 -c 1 -1 1400 -2 0 -n 60 -o 2"),
     # SOLiD colour space: first-colour bookkeeping in the BWA names, "/2"-"/1" suffix swap, 'A'+digits for BFAST
     ("ex1.fa", "-z 13 -N 5000 -c 1"),
     ("tiny.fa", "-z 8 -N 4000 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1"),

@@ -19,6 +19,7 @@ EMU_CASES = [
     ("tiny.fa", "-z 9 -N 400 -c 2 -f TACG -1 100 -2 60 -e 0.2 -E 0.1 -d 300 -o 1"),
     ("tiny.fa", "-z 8 -N 700 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1"),
     ("odd.fa", "-z 6 -N 500 -c 1 -2 0 -1 40 -r 0.08 -R 0.8 -n 20"),
+    ("tiny.fa", "-z 3 -N 200 -1 1300 -2 1400 -d 3600 -s 40 -n 60 -y 0.1"),
     ("tiny.fa", "-z 5 -N 600 -m {IN}/muts_edge.txt"),
     ("tiny.fa", "-z 5 -N 600 -v {IN}/muts_edge.vcf"),
     ("tiny.fa", "-z 5 -N 600 -b {IN}/muts_edge.bed"),
