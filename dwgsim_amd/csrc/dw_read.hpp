@@ -263,7 +263,9 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
         const uint32_t lo = (k & 1) ? w1 : w0, hi = (k & 1) ? w3 : w2;
         return (k & 2) ? hi : lo;
     }
-    DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr) ++n; return n; }   // while (drand48() < e) n_err++
+    // while (drand48() < e) n_err++ (dwgsim.c:296, :373).  Bounded: with e = 1 the reference never leaves this loop; 2^14 errors in one flow
+    // already overflow every buffer, so the caller reports the read as outgrown instead of spinning on the GPU.
+    DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
 };
 // Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
 // bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
@@ -287,6 +289,7 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
         if (prev_c != c) {
             mask &= ~(1ull << flow_i);
             int n_err = rg.geometric(thr);
+            if (n_err >= (1 << 14)) return -1;
             if (n_err > 0) {
                 if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
                     o1.push(c); pend_c = c; pend_n = n_err - 1;

@@ -389,9 +389,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                                                   : (1u + fixed_len + tail_len + 2u + 1u + (uint32_t)s_out + 3u + (uint32_t)s_out + 1u);
 
     // ---- record offsets: block scan + decoupled look-back over logical blocks ----
+    // The BFAST offsets get their own scan + look-back when a BFAST record is not simply "its BWA record minus the 2-byte suffix" for
+    // every lane: SOLiD (different lengths), Ion Torrent (a read the flow model gave up on emits nothing, and must not shift the others)
+    constexpr bool BF_SCAN = DT != 0;
     uint32_t e1, e2, eb = 0, T1, T2, Tb = 0;
-    if (DT == 1) {
-        const uint32_t v[3] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u, emits ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : 0u};
+    if (BF_SCAN) {
+        const uint32_t Lbf = !emits ? 0u : DT == 1 ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : Lbwa - 2u;
+        const uint32_t v[3] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u, Lbf};
         uint32_t ex[3], tot[3]; block_excl_scan_n<3>(v, sm_bytes, ex, tot);
         e1 = ex[0]; e2 = ex[1]; eb = ex[2]; T1 = tot[0]; T2 = tot[1]; Tb = tot[2];
     } else {
@@ -401,7 +405,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     }
     if (wave == 0) {
         const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
-        if (DT == 1) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
+        if (BF_SCAN) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
     }
     if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
@@ -409,15 +413,15 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const uint64_t reads_before_block = (uint64_t)t * PPB * (uint64_t)LPP;
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
-    // Illumina / Ion Torrent: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
-    const uint64_t off_bf = (DT == 1) ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
+    // Illumina: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
+    const uint64_t off_bf = BF_SCAN ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
     if (tid == nthr - 1) {
         const uint64_t nblocks = (a.n_pairs + PPB - 1) / PPB;
         if ((uint64_t)t + 1 == nblocks) {
             const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
             a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
             a.counters[5] = a.p.has_bwa ? G2 + T2 : 0;
-            a.counters[6] = !a.p.has_bfast ? 0 : (DT == 1) ? s_base[2] + Tb : G1 + T1 + G2 + T2 - 2 * nreads;
+            a.counters[6] = !a.p.has_bfast ? 0 : BF_SCAN ? s_base[2] + Tb : G1 + T1 + G2 + T2 - 2 * nreads;
         }
     }
 

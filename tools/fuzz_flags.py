@@ -1,0 +1,87 @@
+"""analysis / test helper: random option combinations through the HIP path and the oracle (Philox mode) -- byte-for-byte.
+usage: python tools/fuzz_flags.py <seed> <count>"""
+import os, random, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from dwgsim_amd import api
+from parity_common import compare_case
+
+def random_flags(rng):
+    f = [f"-z {rng.randrange(1, 10000)}"]
+    pe = rng.random() < 0.7
+    l1 = rng.choice([1, 2, 7, 8, 9, 16, 33, 50, 100, 150, 251])
+    l2 = rng.choice([1, 8, 31, 50, 100, 150]) if pe else 0
+    f += [f"-1 {l1}", f"-2 {l2}"]
+    if pe:
+        d = rng.choice([l1 + l2, l1 + l2 + 5, 200, 500, 900]); f += [f"-d {max(d, l1 + l2)}", f"-s {rng.choice([0, 1, 10, 50])}"]
+        if rng.random() < 0.2: f.append("-i")
+    f.append(rng.choice([f"-N {rng.choice([1, 2, 63, 64, 65, 257, 1000, 3000])}", f"-C {rng.choice([0.01, 0.5, 2, 7])}"]))
+    if rng.random() < 0.6: f.append(f"-r {rng.choice([0, 0.0001, 0.001, 0.01, 0.05, 0.3])}")
+    if rng.random() < 0.5: f.append(f"-R {rng.choice([0, 0.1, 0.5, 1.0])}")
+    if rng.random() < 0.4: f.append(f"-X {rng.choice([0, 0.3, 0.8, 0.95])}")
+    if rng.random() < 0.3: f.append(f"-I {rng.choice([1, 2, 10, 40])}")
+    if rng.random() < 0.4: f.append(f"-F {rng.choice([0, 0.3, 0.5, 1.0])}")
+    if rng.random() < 0.5: f.append(f"-e {rng.choice(['0', '0.001', '0.02', '0.0-0.1', '0.3', '1.0', '0.05-0.001'])}")
+    if rng.random() < 0.4: f.append(f"-E {rng.choice(['0', '0.01', '0.02-0.2', '0.5'])}")
+    if rng.random() < 0.4: f.append(f"-y {rng.choice([0, 0.01, 0.3, 1.0])}")
+    if rng.random() < 0.5: f.append(f"-n {rng.choice([0, 1, 3, 20, 1000])}")
+    if rng.random() < 0.3: f.append(f"-S {rng.choice([0, 1, 2])}")
+    if rng.random() < 0.3: f.append(f"-A {rng.choice([0, 1, 2])}")
+    if rng.random() < 0.2: f.append("-H")
+    if rng.random() < 0.3: f.append(f"-o {rng.choice([0, 1, 2])}")
+    if rng.random() < 0.2: f.append(f"-q {rng.choice(['5', 'I', '!', 'z'])}")
+    if rng.random() < 0.3: f.append(f"-Q {rng.choice([0, 0.5, 2, 10, 60])}")
+    if rng.random() < 0.2: f.append(f"-P {rng.choice(['p', 'lib_1', 'x' * 40])}")
+    c = rng.random()
+    if c < 0.15: f.append("-c 1")
+    elif c < 0.35 and "-" not in "".join(x for x in f if x.startswith("-e ") or x.startswith("-E "))[3:]:
+        f += ["-c 2", f"-f {rng.choice(['TACG', 'TACGTACGTCTGAGCATCGATCGATGTACAGC', 'GATC'])}"]
+    if rng.random() < 0.1: f.append("-a")
+    return " ".join(f)
+
+def one_case(flags, fasta):
+    """child process: exit code 0 = equal, 3 = oracle rejected the options / aborted, 4 = mismatch or HIP-path error"""
+    import subprocess
+    lib = api.load()
+    oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
+    with tempfile.TemporaryDirectory() as t:
+        try:
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=60)
+        except subprocess.TimeoutExpired:
+            print("ORACLE-TIMEOUT", flush=True); return 3
+    if r.returncode != 0:
+        try:
+            res = api.run_job(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib)
+            print("NOTE oracle rc", r.returncode, "but the HIP path produced", res.n_pairs, "pairs", flush=True)
+        except Exception as e:
+            print("both reject:", repr(e)[:120], flush=True)
+        return 3
+    try:
+        compare_case(lib, oracle, fasta, flags)
+    except AssertionError as e:
+        print("MISMATCH ::", str(e)[:300], flush=True); return 4
+    except Exception as e:
+        print("ERROR ::", repr(e)[:300], flush=True); return 4
+    return 0
+
+
+if __name__ == "__main__":
+    import subprocess
+    if sys.argv[1] == "--one":
+        sys.exit(one_case(sys.argv[2], sys.argv[3]))
+    seed, count = int(sys.argv[1]), int(sys.argv[2])
+    rng = random.Random(seed)
+    bad = rejected = 0
+    for k in range(count):
+        flags = random_flags(rng)
+        fasta = os.path.join(ROOT, "tests", "golden", rng.choice(["tiny.fa", "odd.fa", "ex1.fa"]))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", flags, fasta], capture_output=True, text=True, timeout=120)
+            rc, out = r.returncode, (r.stdout + r.stderr[-300:]).strip()
+        except subprocess.TimeoutExpired:
+            rc, out = 5, "TIMEOUT (120 s)"
+        if rc == 3: rejected += 1
+        if rc not in (0, 3) or "NOTE" in out or "TIMEOUT" in out:
+            bad += rc not in (0, 3)
+            print(f"[{k}] rc={rc} {os.path.basename(fasta)} {flags}\n      {out[-400:]}", flush=True)
+    print(f"fuzz seed {seed}: {count} cases, {rejected} rejected by the oracle, {bad} bad", flush=True)
