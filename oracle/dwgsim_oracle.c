@@ -837,6 +837,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
                     if (n_err == hp_l && (0 == i || prev_c == next_c)) { /* dot-fill */
                         j = 0;
                         while (next_c != o->flow_order[(flow_i + j) % F]) j++;
+                        if (j == 0) { fprintf(stderr, "oracle: assert(0 < j) (dwgsim.c:349) fails: the whole read was one deleted homopolymer\n"); exit(134); } /* the reference abort()s here */
                         k = (int)(FLOW_U() * j);
                         for (j = len - 1; i <= j; --j) b->seq[j + 1] = b->seq[j];
                         b->seq[i] = (uint8_t)o->flow_order[(flow_i + k) % F];
