@@ -200,6 +200,15 @@ int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t
     return DWGSIM_HIP_ABI_VERSION;
 }
 
+// Ion Torrent: room for a read after the flow model.  Every empty flow (about three per base) inserts Geometric(e) bases, inserted bases
+// are examined again: the mean growth is ~3 e / (1 - e) per base; four times that plus slack keeps overflow (reported as an error, never
+// written out of bounds) out of reach for realistic error rates and far away even for e = 0.3.
+static int flow_read_capacity(int len, double e)
+{
+    const double ec = e < 0 ? 0 : e > 0.9 ? 0.9 : e;
+    return len + 64 + (int)(len * 12.0 * ec / (1.0 - ec));
+}
+
 static int set_err(int *err, int v) { if (err) *err = v; return v; }
 
 dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, int *err)
@@ -245,9 +254,9 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = e <= 0 ? 0 : (uint64_t)ceil(e * 4294967296.0);
                 ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
-                ca.cap = len + 32 + (int)(len * 10.0 * e); ca.lds_words = (ca.cap + 7) / 8;
+                ca.cap = flow_read_capacity(len, e); ca.lds_words = (ca.cap + 7) / 8;
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-                if (ensure(c, c->flow_scratch, (size_t)(ca.lds_words + ((ca.cap + 15) >> 4)) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
+                if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
                 ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
                 HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
                 launch_calibrate(c->stream, ca);
@@ -733,14 +742,14 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
         const double emax = p.e_start[0] > p.e_start[1] ? p.e_start[0] : p.e_start[1];
-        a.cap = lmax + 32 + (int)(lmax * 10.0 * emax);     // (3 blocks per CU at -1 400 -e 0.01: 93 LDS words per lane)
+        a.cap = flow_read_capacity(lmax, emax);
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
     a.flow_scratch = nullptr;
     if (p.data_type == 2) {
         const size_t nthr = (size_t)SIM_THREADS;
-        const size_t words = (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr * (size_t)(nblk ? nblk : 1);
+        const size_t words = (size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr * (size_t)(nblk ? nblk : 1);
         if (ensure(c, c->flow_scratch, words * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
         a.flow_scratch = (uint32_t *)c->flow_scratch.p;
     }

@@ -10,6 +10,7 @@ constexpr int PAIRS_PER_BLOCK = 128;     // k_place / k_calibrate: pairs (reads)
 #define DW_SIM_THREADS 256
 #endif
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
+constexpr int FLOW_STACK_RUNS = 32;           // Ion Torrent pass 2: (base, count) runs that can be pending in front of the examined base (two per LDS word)
 constexpr int SIM_THREADS_LONG = 64;          // ... for reads whose staged bases do not fit LDS at SIM_THREADS lanes (up to ~5 kb)
 constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for (160 KB per CU minus the static part)
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
@@ -78,6 +79,10 @@ struct CalibArgs {
 };
 
 constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_summarize / k_place)
+
+// Ion Torrent scratch: words per lane of one block's read buffers (4-bit buffer + 2-bit pass-1 buffer), forced odd so that the
+// blocks' areas do not all start on the same HBM channels (a 96 KB stride cost 14 % against 89 KB)
+inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_words + ((cap + 15) >> 4)) | 1; }
 
 struct SimArgs {
     SimParams p;

@@ -269,7 +269,7 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
 };
 // Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
 // bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
-// (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: 8 (base, count) runs, two per word.
+// (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: FLOW_STACK_RUNS (base, count) runs, two per word.
 DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
@@ -330,7 +330,7 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
         while (x != flow[flow_i]) {                 // empty flows in front of the examined base: each may insert
             const int n_err = rg.geometric(thr);
             if (!((mask >> flow_i) & 1) && n_err > 0) {
-                if (sp >= 8 || n_err >= (1 << 14)) return -1;
+                if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) return -1;
                 stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp;
                 total += n_err;
             }

@@ -238,8 +238,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const RngKey key{a.p.seed, a.c.contig_index};
     const int s = sel_len(a, j);
     // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
-    // read buffers live in a global scratch so that LDS does not cap residency; only the 4-word run stack stays in LDS
-    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr) + tid : dyn_lds + tid;
+    // read buffers live in a global scratch so that LDS does not cap residency; only the run stack of pass 2 stays in LDS
+    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid : dyn_lds + tid;
 
     PH_MARK(0);     // ticket, fixed strings
     // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
@@ -568,7 +568,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const size_t lds = (size_t)(ion ? 4 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack (8 runs); its read buffers are in a.flow_scratch
+    const size_t lds = (size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     if (tid < 64) s_flow[tid] = a.flow[tid];
     __syncthreads();
     const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
-    uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr) + tid;
+    uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid;
     int32_t n_err = 0; int s_out = 0;
     if (jj < a.n_reads) {
         const RngKey key{a.seed, 0u};
@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
 }
 void launch_calibrate(hipStream_t st, const CalibArgs &a)
 {
-    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)4 * PAIRS_PER_BLOCK * 4, st, a);
+    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)(FLOW_STACK_RUNS / 2) * PAIRS_PER_BLOCK * 4, st, a);
 }
 #endif
 #if DW_HAS(5)
