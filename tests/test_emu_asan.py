@@ -22,7 +22,8 @@ for fasta, flags in [("ex1.fa", "-z 13 -N 300"), ("odd.fa", "-z 3 -N 300 -1 50 -
                      ("tiny.fa", "-z 3 -N 100 -1 1300 -2 1400 -d 3600 -s 40 -n 60")]:
     compare_case(lib, oracle, os.path.join(g, fasta), flags, batch_pairs=128)
 # reads the flow model gives up on (absurd per-flow error): the call must fail cleanly, with every write in bounds
-for flags in ["-z 4246 -1 9 -2 0 -N 300 -e 1.0 -y 0.3 -n 20 -c 2 -f TACG", "-z 8397 -1 100 -2 0 -N 64 -e 0.3 -o 0 -c 2 -f GATC"]:
+compare_case(lib, oracle, os.path.join(g, "ex1.fa"), "-z 8397 -1 100 -2 0 -N 64 -e 0.3 -o 0 -c 2 -f GATC", batch_pairs=128)      # deep insertion cascades
+for flags in ["-z 4246 -1 9 -2 0 -N 300 -e 1.0 -y 0.3 -n 20 -c 2 -f TACG", "-z 4246 -1 9 -2 9 -d 40 -N 300 -e 1.0 -o 0 -c 2 -f TACG"]:
     try:
         api.run_job(api.parse_flags(flags, lib), api.read_fasta(os.path.join(g, "ex1.fa")), lib=lib)
         raise SystemExit("expected an error for " + flags)
