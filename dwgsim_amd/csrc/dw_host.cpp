@@ -39,6 +39,7 @@ struct Contig {
     size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
     uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
     uint32_t n_cand = 0;
+    uint64_t fail_carry = 0;            // the reference's num_failed (dwgsim.c:635) carried between the batches of this contig
     uint16_t *d_summ[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries for count_random (built on demand)
     int64_t l_place = 0;                // fragment-placement length (region length with -x)
     int32_t *d_reg = nullptr; int32_t n_reg = 0;   // -x: [start[0..n), end[0..n)] of this contig
@@ -66,7 +67,7 @@ struct dwgsim_hip_ctx {
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
     // simulate() working set
-    DevBuf block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
+    DevBuf meta, fail_summ, block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
     DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
@@ -332,7 +333,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     hipFree(c->status_all.p);
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
-    hipFree(c->d_rand_fixed); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
+    hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->fail_summ.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters); hipFree(c->d_flow);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -736,6 +737,8 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
+    if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    a.meta = (uint32_t *)c->meta.p;
     a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
     for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)(nblk ? nblk : 1);
     const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
@@ -822,6 +825,22 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     if (c->h_counters[2] & 4) { c->err = "dwgsim-hip: no fragment placement satisfied the target regions (-x) after 2^20 tries (the reference would not terminate)\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (c->h_counters[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
+    {   // the reference's abort rule over the pairs of the contig in index order (dwgsim.c:635, :833-843), see k_failrule
+        if (first_ii == 0) kp->fail_carry = 0;
+        const uint64_t retries = c->h_counters[1], n_random_now = c->h_counters[3];
+        if (retries == 0) { if (n_random_now < n_pairs) kp->fail_carry = 0; }        // no new failure; any genomic read resets the counter
+        else {
+            const size_t nb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
+            if (ensure(c, c->fail_summ, (nb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
+            uint64_t *d_fs = (uint64_t *)c->fail_summ.p, *d_res = d_fs + nb * 4;
+            launch_failrule(c->stream, a.meta, n_pairs, kp->fail_carry, d_fs, d_res);
+            uint64_t h_res[2];
+            HIPC(c, hipMemcpyAsync(h_res, d_res, sizeof h_res, hipMemcpyDeviceToHost, c->stream));
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (h_res[0]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
+            kp->fail_carry = h_res[1];
+        }
+    }
     for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];
     if (getenv("DWGSIM_HIP_PHASES")) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)
         uint64_t tot = 0; for (int k = 0; k < 8; ++k) tot += c->h_counters[8 + k];

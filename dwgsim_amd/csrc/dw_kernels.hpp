@@ -97,6 +97,7 @@ struct SimArgs {
     const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics
     const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"
     const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"
+    uint32_t *meta;                // per pair: failed attempts | random read << 31 (input of the abort rule, k_failrule)
     uint32_t *block_rand;          // per 128-pair block: random pairs (k_place), then exclusive prefix (k_scan)
     uint64_t *counters;            // [0] ticket, [1] retries, [2] fail flag, [3] total random, [4..6] stream bytes
     uint64_t *status[4];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count, (SOLiD) BFAST bytes

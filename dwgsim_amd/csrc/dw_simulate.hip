@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             else if (++att > (uint32_t)MAX_ATTEMPTS) { atomicOr((unsigned long long *)&a.counters[2], 1ull); done = true; }
         }
     }
+    if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);      // failed attempts and outcome: input of the abort rule (k_failrule)
     { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
     // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
     uint32_t rrank, rtot;
@@ -540,6 +541,60 @@ __global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
 {
     hipLaunchKernelGGL(k_selftest_fp64, dim3(cdiv(n, 256)), dim3(256), 0, st, seed, n, mism);
+}
+// ---- the reference's abort rule (dwgsim.c:635, :833-843): one counter of failed attempts runs over the pairs of a contig in index order,
+// a pair that ends as a genomic read resets it, a pair that ends as a random read does not, and the job dies as soon as the counter
+// passes 10 000.  Pairs are simulated independently here, so the rule is evaluated afterwards from the per-pair record
+// meta[pair] = failed attempts | random << 31 -- only for batches that had a failed attempt at all.
+// A run of pairs is summarised as {P: fails before its first reset (all of them if it has none), S: fails after its last reset,
+// R: has a reset, bad: a run between two of its resets passed the limit}.
+struct FailSeg { uint64_t P, S; uint32_t R, bad; };
+DW_DEV FailSeg failseg_join(const FailSeg &a, const FailSeg &b)
+{
+    FailSeg r;
+    r.bad = a.bad | b.bad | ((a.R && a.S + b.P > (uint64_t)MAX_ATTEMPTS) ? 1u : 0u);
+    r.P = a.R ? a.P : a.P + b.P;                    // (the prefix of a run without a reset extends into the next one)
+    r.S = b.R ? b.S : a.S + b.S;
+    r.R = a.R | b.R;
+    return r;
+}
+constexpr int FAIL_PAIRS_PER_THREAD = 64;
+// A: thread = 64 consecutive pairs, block = 256 threads; one FailSeg per block into summ[4 * block .. +4)
+__global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__ meta, uint64_t n_pairs, uint64_t *__restrict__ summ)
+{
+    __shared__ FailSeg seg[256];
+    const uint64_t first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * FAIL_PAIRS_PER_THREAD;
+    FailSeg s{0, 0, 0, 0};
+    for (int q = 0; q < FAIL_PAIRS_PER_THREAD && first + q < n_pairs; ++q) {
+        const uint32_t m = meta[first + q];
+        const FailSeg e{m & 0x7fffffffu, 0, (m >> 31) ? 0u : 1u, 0};      // the pair's fails come before its outcome; a genomic read resets
+        FailSeg one = e; if (!one.R) one.S = one.P;                         // no reset: everything is both prefix and suffix
+        s = (q == 0) ? one : failseg_join(s, one);
+    }
+    seg[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FailSeg t = seg[0];
+        for (int k = 1; k < 256; ++k) t = failseg_join(t, seg[k]);
+        summ[4 * (uint64_t)blockIdx.x + 0] = t.P; summ[4 * (uint64_t)blockIdx.x + 1] = t.S;
+        summ[4 * (uint64_t)blockIdx.x + 2] = t.R; summ[4 * (uint64_t)blockIdx.x + 3] = t.bad;
+    }
+}
+// B: one thread joins the block summaries behind the carry of the earlier batches: result[0] = abort?, result[1] = carry out
+__global__ void k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t carry_in, uint64_t *__restrict__ result)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    FailSeg t{carry_in, carry_in, 0, 0};
+    for (uint32_t b = 0; b < n_blocks; ++b) t = failseg_join(t, FailSeg{summ[4 * (uint64_t)b], summ[4 * (uint64_t)b + 1], (uint32_t)summ[4 * (uint64_t)b + 2], (uint32_t)summ[4 * (uint64_t)b + 3]});
+    const bool abort_now = t.bad || t.P > (uint64_t)MAX_ATTEMPTS || (t.R && t.S > (uint64_t)MAX_ATTEMPTS) || (!t.R && t.S > (uint64_t)MAX_ATTEMPTS);
+    result[0] = abort_now ? 1 : 0;
+    result[1] = t.S;
+}
+void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t carry_in, uint64_t *summ, uint64_t *result)
+{
+    const uint32_t nb = cdiv(n_pairs, 256ull * FAIL_PAIRS_PER_THREAD);
+    hipLaunchKernelGGL(k_failrule_a, dim3(nb), dim3(256), 0, st, meta, n_pairs, summ);
+    hipLaunchKernelGGL(k_failrule_b, dim3(1), dim3(64), 0, st, summ, nb, carry_in, result);
 }
 void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ)
 {

@@ -179,3 +179,17 @@ def check_count_random_matches_simulate(lib, fasta, flags, ranges=((0, None), (1
             checked += 1
         ctx.drop_contig(cid)
     assert checked > 0
+
+
+def check_both_abort(lib, oracle_bin, fasta, flags):
+    """Jobs the reference gives up on ("failed to generate a read after 10001 trials", dwgsim.c:833-843: one counter of failed attempts
+    over the pairs of a contig, reset only by a genomic read): the oracle exits non-zero and the HIP path must return the same error."""
+    with tempfile.TemporaryDirectory() as t:
+        r = subprocess.run([oracle_bin, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, text=True)
+    assert r.returncode != 0 and "failed to generate a read" in r.stderr, r.stderr[-300:]
+    try:
+        api.run_job(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib)
+    except api.DwgsimError as e:
+        assert "failed to generate a read after 10001 trials" in str(e), str(e)
+        return
+    raise AssertionError("the HIP path produced output where the reference aborts: " + flags)

@@ -63,3 +63,12 @@ def test_walk_reruns_when_a_capacity_is_exceeded(emu_lib, oracle_bin, golden_dir
     pool must lead to an exact re-run with the same result."""
     monkeypatch.setenv("DWGSIM_HIP_WALK_CAP", "7")
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 30 -X 0.6", batch_pairs=700)
+
+
+def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):
+    """Amplicon mode on a contig whose read-1 window always holds an N: every genomic attempt fails, only random reads come out and
+    never reset the counter -- the reference dies at the 10 001st failure, and so must the HIP path (no pair exceeds the limit alone)."""
+    from parity_common import check_both_abort
+    check_both_abort(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 1200 -r 0 -e 0.0-0.1 -Q 0 -a")
+    # ... while the same job with fewer pairs stays under the limit and must match byte for byte
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 600 -r 0 -e 0.0-0.1 -Q 0 -a", batch_pairs=100)

@@ -113,3 +113,13 @@ def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa, mo
     """See tests/test_emu_parity.py: forced tiny capacities on the repeat-rich 1.8 Mb contigs."""
     monkeypatch.setenv("DWGSIM_HIP_WALK_CAP", "100")
     compare_case(lib, oracle_bin, repeats_fa, "-z 32 -M 2 -r 0.2 -R 0.9 -X 0.3 -I 2")
+
+
+def test_abort_rule_matches_the_reference(lib, oracle_bin, golden_dir):
+    """See tests/test_emu_parity.py; here also with small batches, so the counter is carried between simulate() calls."""
+    from parity_common import check_both_abort
+    flags = "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 1200 -r 0 -e 0.0-0.1 -Q 0 -a"
+    check_both_abort(lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), flags)
+    with pytest.raises(api.DwgsimError, match="failed to generate a read after 10001 trials"):
+        api.run_job(api.parse_flags(flags, lib), api.read_fasta(os.path.join(golden_dir, "odd.fa")), batch_pairs=37, lib=lib)
+    compare_case(lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), flags.replace("-N 1200", "-N 600"), batch_pairs=37)

@@ -39,6 +39,17 @@ def random_flags(rng):
     if rng.random() < 0.1: f.append("-a")
     return " ".join(f)
 
+
+IN = os.path.join(ROOT, "tests", "golden", "inputs")
+def random_flags_tiny_inputs(rng):
+    """tiny.fa only: mutation-input files, target regions, -B"""
+    f = random_flags(rng).split(" -a")[0]
+    c = rng.random()
+    if c < 0.5: f += " " + rng.choice([f"-m {IN}/muts_generated.txt", f"-m {IN}/muts_edge.txt", f"-v {IN}/muts_generated.vcf", f"-v {IN}/muts_edge.vcf", f"-b {IN}/muts_edge.bed"])
+    if rng.random() < 0.5: f += " " + rng.choice([f"-x {IN}/regions_a.bed", f"-x {IN}/regions_b.bed"])
+    if "-c 2" in f and rng.random() < 0.3: f += " -B"
+    return f
+
 def one_case(flags, fasta):
     """child process: exit code 0 = equal, 3 = oracle rejected the options / aborted, 4 = mismatch or HIP-path error"""
     import subprocess
@@ -73,8 +84,11 @@ if __name__ == "__main__":
     rng = random.Random(seed)
     bad = rejected = 0
     for k in range(count):
-        flags = random_flags(rng)
-        fasta = os.path.join(ROOT, "tests", "golden", rng.choice(["tiny.fa", "odd.fa", "ex1.fa"]))
+        if len(sys.argv) > 3 and sys.argv[3] == "inputs":
+            flags, fasta = random_flags_tiny_inputs(rng), os.path.join(ROOT, "tests", "golden", "tiny.fa")
+        else:
+            flags = random_flags(rng)
+            fasta = os.path.join(ROOT, "tests", "golden", rng.choice(["tiny.fa", "odd.fa", "ex1.fa"]))
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", flags, fasta], capture_output=True, text=True, timeout=120)
             rc, out = r.returncode, (r.stdout + r.stderr[-300:]).strip()
