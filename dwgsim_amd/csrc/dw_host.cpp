@@ -206,7 +206,7 @@ int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t
 // written out of bounds) out of reach for realistic error rates and far away even for e = 0.3.
 static int flow_read_capacity(int len, double e)
 {
-    const double ec = e < 0 ? 0 : e > 0.9 ? 0.9 : e;
+    const double ec = !(e > 0) ? 0 : e > 0.9 ? 0.9 : e;       // (NaN, e.g. -B with -e 0: no flow errors at all)
     return len + 64 + (int)(len * 12.0 * ec / (1.0 - ec));
 }
 
@@ -253,7 +253,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 const double e = c->prm.e_start[i];
                 CalibArgs ca;
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
-                ca.thr = e <= 0 ? 0 : (uint64_t)ceil(e * 4294967296.0);
+                ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
                 ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
                 ca.cap = flow_read_capacity(len, e); ca.lds_words = (ca.cap + 7) / 8;
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
@@ -278,7 +278,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             std::vector<uint64_t> thr((size_t)n); std::vector<int8_t> qb((size_t)n);
             for (int i = 0; i < n; ++i) {
                 const double ei = c->prm.e_start[j] + c->e_by[j] * i;
-                thr[(size_t)i] = ei <= 0 ? 0 : (uint64_t)ceil(ei * 4294967296.0);   // u = w * 2^-32 < ei  <=>  w < ceil(ei * 2^32) (exact: scaling by 2^32 is exact)
+                thr[(size_t)i] = !(ei > 0) ? 0 : ei >= 1.0 ? 0x100000000ull : (uint64_t)ceil(ei * 4294967296.0);   // u = w * 2^-32 < ei  <=>  w < ceil(ei * 2^32) (exact: scaling by 2^32 is exact)
                 char q;
                 if (ei > 0) q = (char)((int)(-10.0 * log(ei) / log(10.0) + 0.499) + '!'); else q = 40 + '!';
                 qb[(size_t)i] = (int8_t)q;
