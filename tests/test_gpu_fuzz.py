@@ -1,0 +1,15 @@
+"""-m gpu: random option combinations (tools/fuzz_flags.py) through the HIP path and the oracle, byte for byte.
+Every case runs in its own process with a time limit; option sets the oracle itself rejects or gives up on are skipped."""
+import os, subprocess, sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed,count,mode", [(101, 40, ""), (102, 25, "inputs")])
+def test_random_option_sets_bit_exact(oracle_bin, seed, count, mode):
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_flags.py"), str(seed), str(count)] + ([mode] if mode else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-2000:]
