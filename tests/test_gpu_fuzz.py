@@ -1,4 +1,5 @@
-"""-m gpu: random option combinations (tools/fuzz_flags.py) through the HIP path and the oracle, byte for byte.
+"""-m gpu: random option combinations (tools/fuzz_flags.py) through the HIP path (C-ABI, or the dwgsim-hip executable with "cli") and the
+oracle, byte for byte.
 Every case runs in its own process with a time limit; option sets the oracle itself rejects or gives up on are skipped."""
 import os, subprocess, sys
 import pytest
@@ -7,9 +8,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed,count,mode", [(101, 40, ""), (102, 25, "inputs")])
+@pytest.mark.parametrize("seed,count,mode", [(101, 40, ""), (102, 25, "inputs"), (103, 20, "cli"), (104, 10, "inputs cli")])
 def test_random_option_sets_bit_exact(oracle_bin, seed, count, mode):
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_flags.py"), str(seed), str(count)] + ([mode] if mode else [])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_flags.py"), str(seed), str(count)] + mode.split()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-2000:]

@@ -50,6 +50,34 @@ def random_flags_tiny_inputs(rng):
     if "-c 2" in f and rng.random() < 0.3: f += " -B"
     return f
 
+def one_case_cli(flags, fasta):
+    """child process, CLI flavour: dwgsim-hip <flags> ref.fa prefix against the oracle's five files (gunzipped)"""
+    import gzip, subprocess
+    oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
+    cli = os.path.join(ROOT, "dwgsim_amd", "dwgsim-hip")
+    with tempfile.TemporaryDirectory() as t:
+        try:
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=60)
+        except subprocess.TimeoutExpired:
+            print("ORACLE-TIMEOUT", flush=True); return 3
+        c = subprocess.run([cli] + flags.split() + [fasta, os.path.join(t, "c")], capture_output=True, text=True, timeout=100)
+        if r.returncode != 0:
+            if c.returncode == 0: print("NOTE oracle rc", r.returncode, "but dwgsim-hip succeeded", flush=True)
+            return 3
+        if c.returncode != 0:
+            print("ERROR :: dwgsim-hip rc", c.returncode, c.stderr[-300:], flush=True); return 4
+        for suf in ("bwa.read1.fastq", "bwa.read2.fastq", "bfast.fastq", "mutations.txt", "mutations.vcf"):
+            po = os.path.join(t, "o." + suf)
+            want = open(po, "rb").read() if os.path.exists(po) else None
+            pc = os.path.join(t, "c." + suf + (".gz" if suf.endswith("fastq") else ""))
+            got = None
+            if os.path.exists(pc):
+                got = gzip.open(pc, "rb").read() if pc.endswith(".gz") else open(pc, "rb").read()
+            if (want or b"") != (got or b""):
+                print("MISMATCH ::", suf, "oracle", None if want is None else len(want), "cli", None if got is None else len(got), flush=True); return 4
+    return 0
+
+
 def one_case(flags, fasta):
     """child process: exit code 0 = equal, 3 = oracle rejected the options / aborted, 4 = mismatch or HIP-path error"""
     import subprocess
@@ -80,17 +108,20 @@ if __name__ == "__main__":
     import subprocess
     if sys.argv[1] == "--one":
         sys.exit(one_case(sys.argv[2], sys.argv[3]))
+    if sys.argv[1] == "--one-cli":
+        sys.exit(one_case_cli(sys.argv[2], sys.argv[3]))
     seed, count = int(sys.argv[1]), int(sys.argv[2])
     rng = random.Random(seed)
     bad = rejected = 0
     for k in range(count):
-        if len(sys.argv) > 3 and sys.argv[3] == "inputs":
+        if "inputs" in sys.argv[3:]:
             flags, fasta = random_flags_tiny_inputs(rng), os.path.join(ROOT, "tests", "golden", "tiny.fa")
         else:
             flags = random_flags(rng)
             fasta = os.path.join(ROOT, "tests", "golden", rng.choice(["tiny.fa", "odd.fa", "ex1.fa"]))
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", flags, fasta], capture_output=True, text=True, timeout=120)
+            how = "--one-cli" if "cli" in sys.argv[3:] else "--one"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), how, flags, fasta], capture_output=True, text=True, timeout=120)
             rc, out = r.returncode, (r.stdout + r.stderr[-300:]).strip()
         except subprocess.TimeoutExpired:
             rc, out = 5, "TIMEOUT (120 s)"
