@@ -57,7 +57,7 @@ def one_case_cli(flags, fasta):
     cli = os.path.join(ROOT, "dwgsim_amd", "dwgsim-hip")
     with tempfile.TemporaryDirectory() as t:
         try:
-            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=60)
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=20)
         except subprocess.TimeoutExpired:
             print("ORACLE-TIMEOUT", flush=True); return 3
         c = subprocess.run([cli] + flags.split() + [fasta, os.path.join(t, "c")], capture_output=True, text=True, timeout=100)
@@ -85,7 +85,7 @@ def one_case(flags, fasta):
     oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
     with tempfile.TemporaryDirectory() as t:
         try:
-            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=60)
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=20)
         except subprocess.TimeoutExpired:
             print("ORACLE-TIMEOUT", flush=True); return 3
     if r.returncode != 0:
