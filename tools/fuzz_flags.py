@@ -78,6 +78,63 @@ def one_case_cli(flags, fasta):
     return 0
 
 
+def run_job_in_random_shards(params, contigs, lib, rng):
+    """api.run_job with every contig cut into random read-index ranges that are simulated out of order, each with its rand_base taken
+    from dwgsim_hip_count_random over the ranges before it (what independent ranks do, dwgsim_amd/shard.py)"""
+    streams = {0: b"", 1: b"", 2: b""}
+    tot_len = sum(len(a) for _, a in contigs)
+    n_sim = rand_ii = 0
+    n_ref = len(contigs)
+    with api.Context(params, 0, lib) as ctx:
+        for ci, (name, arr) in enumerate(contigs):
+            n_ref -= 1
+            n_pairs = api.pairs_for_contig(params, len(arr), tot_len, n_ref == 0, n_sim, lib)
+            if n_pairs < 0:
+                continue
+            cid = ctx.add_contig(name, arr, ci)
+            ctx.mutate(cid)
+            cuts = sorted(set([0, n_pairs] + [rng.randrange(0, n_pairs + 1) for _ in range(rng.randrange(0, 5))]))
+            ranges = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            order = list(range(len(ranges))); rng.shuffle(order)
+            parts = {}
+            n_rand_contig = 0
+            for k in order:
+                first, n = ranges[k]
+                base = rand_ii + (ctx.count_random(cid, 0, first) if first else 0)
+                b = ctx.simulate(cid, first, n, base, 0)
+                parts[k] = [ctx.fetch(0, s, b.bytes[s]) if b.bytes[s] else b"" for s in range(3)]
+                n_rand_contig += int(b.n_random)
+            for k in range(len(ranges)):
+                for s in range(3):
+                    streams[s] += parts[k][s]
+            rand_ii += n_rand_contig
+            n_sim += n_pairs
+            ctx.drop_contig(cid)
+    return streams
+
+
+def one_case_shards(flags, fasta, seed):
+    import subprocess
+    lib = api.load()
+    oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
+    with tempfile.TemporaryDirectory() as t:
+        try:
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=20)
+        except subprocess.TimeoutExpired:
+            print("ORACLE-TIMEOUT", flush=True); return 3
+        if r.returncode != 0:
+            return 3
+        want = {s: (open(os.path.join(t, "o." + suf), "rb").read() if os.path.exists(os.path.join(t, "o." + suf)) else b"") for s, suf in enumerate(("bwa.read1.fastq", "bwa.read2.fastq", "bfast.fastq"))}
+    try:
+        got = run_job_in_random_shards(api.parse_flags(flags, lib), api.read_fasta(fasta), lib, random.Random(seed))
+    except Exception as e:
+        print("ERROR ::", repr(e)[:300], flush=True); return 4
+    for s in range(3):
+        if got[s] != want[s]:
+            print("MISMATCH :: stream", s, len(got[s]), len(want[s]), flush=True); return 4
+    return 0
+
+
 def one_case(flags, fasta):
     """child process: exit code 0 = equal, 3 = oracle rejected the options / aborted, 4 = mismatch or HIP-path error"""
     import subprocess
@@ -108,6 +165,8 @@ if __name__ == "__main__":
     import subprocess
     if sys.argv[1] == "--one":
         sys.exit(one_case(sys.argv[2], sys.argv[3]))
+    if sys.argv[1] == "--one-shards":
+        sys.exit(one_case_shards(sys.argv[2], sys.argv[3], int(sys.argv[4])))
     if sys.argv[1] == "--one-cli":
         sys.exit(one_case_cli(sys.argv[2], sys.argv[3]))
     seed, count = int(sys.argv[1]), int(sys.argv[2])
@@ -120,8 +179,8 @@ if __name__ == "__main__":
             flags = random_flags(rng)
             fasta = os.path.join(ROOT, "tests", "golden", rng.choice(["tiny.fa", "odd.fa", "ex1.fa"]))
         try:
-            how = "--one-cli" if "cli" in sys.argv[3:] else "--one"
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), how, flags, fasta], capture_output=True, text=True, timeout=120)
+            how = "--one-cli" if "cli" in sys.argv[3:] else "--one-shards" if "shards" in sys.argv[3:] else "--one"
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), how, flags, fasta] + ([str(seed * 1000 + k)] if how == "--one-shards" else []), capture_output=True, text=True, timeout=120)
             rc, out = r.returncode, (r.stdout + r.stderr[-300:]).strip()
         except subprocess.TimeoutExpired:
             rc, out = 5, "TIMEOUT (120 s)"
