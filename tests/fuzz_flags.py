@@ -1,8 +1,8 @@
 """analysis / test helper: random option combinations through the HIP path and the oracle (Philox mode) -- byte-for-byte.
-usage: python tools/fuzz_flags.py <seed> <count>"""
+usage: python tests/fuzz_flags.py <seed> <count> [inputs] [cli | shards]"""
 import os, random, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))      # (test infrastructure: this file drives the oracle)
 from dwgsim_amd import api
 from parity_common import compare_case
 
