@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/cmp_ref.sh <fasta> <dwgsim options...>
+# tests/cmp_ref.sh <fasta> <dwgsim options...>
 # Dev-container check: run the unmodified reference (oracle/_ref/dwgsim) and the oracle in mode A
 # (sequential drand48) with the same options and compare all five outputs byte-for-byte
 # (FASTQ after gunzip, as the reference's own testdata/test.sh:21-26 does).
