@@ -580,15 +580,24 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
         summ[4 * (uint64_t)blockIdx.x + 2] = t.R; summ[4 * (uint64_t)blockIdx.x + 3] = t.bad;
     }
 }
-// B: one thread joins the block summaries behind the carry of the earlier batches: result[0] = abort?, result[1] = carry out
-__global__ void k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t carry_in, uint64_t *__restrict__ result)
+// B: the block summaries are joined in order behind the carry of the earlier batches (64 lanes stage them through LDS, lane 0 joins):
+// result[0] = abort?, result[1] = carry out
+__global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t carry_in, uint64_t *__restrict__ result)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    __shared__ uint64_t st[64 * 4];
     FailSeg t{carry_in, carry_in, 0, 0};
-    for (uint32_t b = 0; b < n_blocks; ++b) t = failseg_join(t, FailSeg{summ[4 * (uint64_t)b], summ[4 * (uint64_t)b + 1], (uint32_t)summ[4 * (uint64_t)b + 2], (uint32_t)summ[4 * (uint64_t)b + 3]});
-    const bool abort_now = t.bad || t.P > (uint64_t)MAX_ATTEMPTS || (t.R && t.S > (uint64_t)MAX_ATTEMPTS) || (!t.R && t.S > (uint64_t)MAX_ATTEMPTS);
-    result[0] = abort_now ? 1 : 0;
-    result[1] = t.S;
+    for (uint32_t base = 0; base < n_blocks; base += 64) {
+        const uint32_t cnt = n_blocks - base < 64 ? n_blocks - base : 64;
+        for (uint32_t q = threadIdx.x; q < cnt * 4; q += 64) st[q] = summ[4 * (uint64_t)base + q];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t b = 0; b < cnt; ++b) t = failseg_join(t, FailSeg{st[4 * b], st[4 * b + 1], (uint32_t)st[4 * b + 2], (uint32_t)st[4 * b + 3]});
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        result[0] = (t.bad || t.P > (uint64_t)MAX_ATTEMPTS || t.S > (uint64_t)MAX_ATTEMPTS) ? 1 : 0;
+        result[1] = t.S;
+    }
 }
 void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t carry_in, uint64_t *summ, uint64_t *result)
 {
