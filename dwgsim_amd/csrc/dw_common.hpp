@@ -35,7 +35,9 @@ enum : uint32_t {
     D_BASE0 = 8,        // +read end.  word i (block i>>2, word i&3): error test of base i (dwgsim.c:237) or random-read base i (:1000)
     D_QUAL0 = 10,       // +read end.  block p, retry m: polar tries 2m = words (0,1), 2m+1 = words (2,3); the accepted try gives
                         // quality normals 2p (v2*fac) and 2p+1 (v1*fac) (dwgsim.c:912, :156-175)
-    D_FLOW0 = 12,       // +read end.  sequential slots inside generate_errors_flows (dwgsim.c:246-417)
+    D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): one sub-stream per event -- block = ordinal of the homopolymer
+                        // start (pass 1) / of the examined base (pass 2), draw s of the event = word s & 3 of retry s >> 2
+    D_FLOW_PASS2 = 8,   // added to D_FLOW0 / D_CALIB (+read end) for the second pass of the flow model (domains 20-23)
     D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
     D_SUB0 = 16         // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
 };

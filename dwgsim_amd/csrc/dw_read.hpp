@@ -255,11 +255,15 @@ struct PackAppender {
     DW_DEV void flush() { if (n & (PER - 1)) base[(n >> SH) * stride] = acc; }
 };
 struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
-    uint32_t seed, contig, dom, att, slot, w0, w1, w2, w3; uint64_t ii;
+    // One private sub-stream per event of the flow model (a homopolymer start in pass 1, an examined base in pass 2): draw s of event
+    // `evt` is word s & 3 of the block (retry s >> 2, block evt).  Every lane opens its events in step with its own loop iterations, so a
+    // block is generated once per event instead of once per draw of whichever lane happens to cross a block boundary.
+    uint32_t seed, contig, dom, att, evt, s, w0, w1, w2, w3; uint64_t ii;
+    DW_DEV void open(uint32_t event) { evt = event; s = 0; }
     DW_DEV uint32_t next()
     {
-        if ((slot & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, 0, slot >> 2); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
-        const uint32_t k = slot & 3; ++slot;
+        if ((s & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, s >> 2, evt); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
+        const uint32_t k = s & 3; ++s;
         const uint32_t lo = (k & 1) ? w1 : w0, hi = (k & 1) ? w3 : w2;
         return (k & 2) ? hi : lo;
     }
@@ -280,7 +284,7 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
     { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
     // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
     PackAppender<2> o1; o1.init(bufB, stride);
-    int t = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
+    int t = 0; uint32_t prev_c = 4, pend_c = 0, n_events = 0; int pend_n = 0;
     for (;;) {
         uint32_t c; bool from_pend = false;
         if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
@@ -288,6 +292,7 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
         while (c != flow[flow_i]) { mask &= ~(1ull << flow_i); flow_i = flow_i + 1 == F ? 0 : flow_i + 1; }
         if (prev_c != c) {
             mask &= ~(1ull << flow_i);
+            rg.open(n_events++);
             int n_err = rg.geometric(thr);
             if (n_err >= (1 << 14)) return -1;
             if (n_err > 0) {
@@ -323,7 +328,9 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
     auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
     int t2 = 0, sp = 0;
-    for (;;) {
+    rg.dom += D_FLOW_PASS2;
+    for (uint32_t n2 = 0;; ++n2) {
+        rg.open(n2);
         uint32_t x;
         if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else break;
         if (o2.n >= cap) return -1;

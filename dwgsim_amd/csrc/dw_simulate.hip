@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     bool flow_reversed = false;
     const int nw = (s + 7) >> 3;
     if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
-        FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.slot = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
+        FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
         s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
                             nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
             for (int b = 0; b < 8; ++b) if (w * 8 + b < a.len) word |= (rw[b] >> 30) << (4 * b);      // (int)(u * 4.0) & 3
             buf[w * nthr] = word;
         }
-        FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.slot = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
+        FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
         s_out = flow_errors(rg, s_flow, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; }
     }

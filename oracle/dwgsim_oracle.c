@@ -62,6 +62,7 @@ enum {
                           the accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) */
     D_FLOW0 = 12,      /* +j; index = ii; NARROW: word = running draw count inside generate_errors_flows */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
+    D_FLOW_PASS2 = 8,  /* added to D_FLOW0 / D_CALIB (+j) for the second pass of generate_errors_flows: domains 20-23 */
     D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
     D_MUTIN = 18,      /* mutation-input files (-b): index = entry ordinal; slot 0 hom test, 1 het haplotype (mut.c:662-669) */
     D_MUTIN_BASE = 19  /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
@@ -799,12 +800,21 @@ static void flow_alloc(flowbuf_t *b, int len, int F)
     b->mem = (len + 2 > F + 2) ? len + 2 : F + 2;
     b->seq = calloc((size_t)b->mem, 1); b->mask = calloc((size_t)b->mem, 1);
 }
-#define FLOW_U() rng_u32(r, dom, idx, att, 0, (*slot)++)   /* mode B: narrow draws, sequential slot counter per read end */
+/* mode B: narrow draws, one private sub-stream per EVENT of the flow model -- pass 1: the n-th homopolymer start of the read (domain dom),
+ * pass 2: the n-th examined base (domain dom + D_FLOW_PASS2): draw s of an event is word s & 3 of the block (retry s >> 2, block n).
+ * An event almost always needs one block, generated without regard to how many draws other reads consumed before. */
+static inline double flow_u(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t evt, uint32_t *es)
+{
+    const uint32_t s = (*es)++;
+    return rng_u32(r, fdom, idx, att, s >> 2, (evt << 2) | (s & 3));
+}
+#define FLOW_U() flow_u(r, fdom, idx, att, evt, &es)
 static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t *slot,
                        flowbuf_t *b, int len, int strand, double e, int *n_err_out)
 {
     int i, j, k, hp_l, flow_i, n_err, F = o->flow_order_len;
     uint8_t prev_c, c;
+    uint32_t fdom = dom, evt = 0, es = 0, n_events = 0; (void)slot;
     for (i = 0; i < len; ++i) if (b->seq[i] >= 4) b->seq[i] = 0;
     if (strand == 1) for (i = 0; i < len >> 1; ++i) { c = b->seq[i]; b->seq[i] = b->seq[len - i - 1]; b->seq[len - i - 1] = c; }
     for (i = 0; i < F; ++i) {
@@ -819,6 +829,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
         while (c != o->flow_order[flow_i]) { b->mask[flow_i] = 0; flow_i = (flow_i + 1) % F; }
         if (prev_c != c) {
             b->mask[flow_i] = 0;
+            evt = n_events++; es = 0;
             n_err = 0;
             while (FLOW_U() < e) n_err++;
             if (0 < n_err) {
@@ -849,7 +860,9 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
             prev_c = c;
         }
     }
+    fdom = dom + D_FLOW_PASS2;
     for (i = 0; i < len; ++i) { /* second pass: empty flows (flow_i continues) */
+        evt = (uint32_t)i; es = 0;
         c = (4 <= b->seq[i]) ? 0 : b->seq[i];
         while (c != o->flow_order[flow_i]) {
             n_err = 0;
