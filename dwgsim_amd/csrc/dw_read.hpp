@@ -274,7 +274,17 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
 // Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
 // bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
 // (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: FLOW_STACK_RUNS (base, count) runs, two per word.
-DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
+// dist[4 * f + b]: flows from flow f (inclusive) to the first flow of base b, 0 .. F-1 (filled by fill_flow_dist, every base occurs in the order)
+DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, int nthr)
+{
+    for (int q = tid; q < 4 * F; q += nthr) {
+        const int f = q >> 2; const uint32_t b = (uint32_t)q & 3u;
+        int k = 0, g = f;
+        while (flow[g] != b) { ++k; g = g + 1 == F ? 0 : g + 1; }
+        dist[q] = (uint8_t)k;
+    }
+}
+DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
     // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
@@ -289,7 +299,15 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
         uint32_t c; bool from_pend = false;
         if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
         if (o1.n >= cap) return -1;
-        while (c != flow[flow_i]) { mask &= ~(1ull << flow_i); flow_i = flow_i + 1 == F ? 0 : flow_i + 1; }
+        {   // skip the flows in front of this base (dwgsim.c:285-288), clearing their mask bits: a cyclic range [flow_i, flow_i + k)
+            const int k = dist[4 * flow_i + (int)c];
+            if (k) {
+                const int n1 = k < F - flow_i ? k : F - flow_i, n2 = k - n1;
+                const uint64_t m1 = (n1 >= 64 ? ~0ull : ((1ull << n1) - 1)) << flow_i, m2 = n2 >= 64 ? ~0ull : ((1ull << n2) - 1);
+                mask &= ~(m1 | m2);
+                flow_i += k; if (flow_i >= F) flow_i -= F;
+            }
+        }
         if (prev_c != c) {
             mask &= ~(1ull << flow_i);
             rg.open(n_events++);
@@ -334,7 +352,16 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, int F, uint64_t thr, ui
         uint32_t x;
         if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else break;
         if (o2.n >= cap) return -1;
-        while (x != flow[flow_i]) {                 // empty flows in front of the examined base: each may insert
+        // empty flows in front of the examined base: each may insert (dwgsim.c:370-392).  Flow q of them draws word q of the event's
+        // stream unless an earlier one scored: if none of the first k words is below the threshold nothing happens at all
+        const int k_empty = dist[4 * flow_i + (int)x];
+        bool quiet = true;
+        for (int q = 0; q < k_empty && quiet; q += 4) {
+            const U4 b = rng_block(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)q >> 2, rg.evt);
+            quiet = !((uint64_t)b.x < thr || (q + 1 < k_empty && (uint64_t)b.y < thr) || (q + 2 < k_empty && (uint64_t)b.z < thr) || (q + 3 < k_empty && (uint64_t)b.w < thr));
+        }
+        if (quiet) { flow_i += k_empty; if (flow_i >= F) flow_i -= F; }
+        else while (x != flow[flow_i]) {            // (rare) replay the flows one by one from the start of the event's stream
             const int n_err = rg.geometric(thr);
             if (!((mask >> flow_i) & 1) && n_err > 0) {
                 if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) return -1;

@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
     __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
+    __shared__ uint8_t s_dist[256];              // ... and the flow-distance table (fill_flow_dist)
     constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -230,6 +231,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         (&s_fixed[0][0])[q] = q < 64 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 64];
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     __syncthreads();
+    if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
     const int j = (LPP == 2) ? (tid & 1) : 0;
     const uint64_t pair = (uint64_t)t * PPB + (uint64_t)(tid / LPP);
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const int nw = (s + 7) >> 3;
     if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        s_out = flow_errors(rg, s_flow, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
+        s_out = flow_errors(rg, s_flow, s_dist, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
                             nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
         flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
@@ -687,8 +689,11 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);
     __shared__ uint8_t s_flow[64];
+    __shared__ uint8_t s_dist[256];
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK;
     if (tid < 64) s_flow[tid] = a.flow[tid];
+    __syncthreads();
+    fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr);
     __syncthreads();
     const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
     uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid;
@@ -705,7 +710,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
             buf[w * nthr] = word;
         }
         FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        s_out = flow_errors(rg, s_flow, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
+        s_out = flow_errors(rg, s_flow, s_dist, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
         if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; }
     }
     const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);
