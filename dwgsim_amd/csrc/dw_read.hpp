@@ -284,13 +284,14 @@ DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, i
         dist[q] = (uint8_t)k;
     }
 }
-DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
-                       int len, int strand, int cap, int32_t *n_err_out)
+// Pass 1 of generate_errors_flows (dwgsim.c:253-364) for one lane: bufA (len bases) -> bufB (2 bits per base).  Returns the new length or
+// -1; leaves the flow mask, the flow position and the number of erroneous bases for pass 2.
+DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, int stride,
+                      int len, int strand, int cap, uint64_t &mask, int &flow_i, int &total)
 {
     // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
     PackReader<4> rd, la; rd.init(bufA, stride); la.init(bufA, stride);
     auto in = [&](PackReader<4> &r, int t) -> uint32_t { const uint32_t v = r.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
-    uint64_t mask = 0; int flow_i = 0, total = 0;
     { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
     // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
     PackAppender<2> o1; o1.init(bufB, stride);
@@ -338,45 +339,72 @@ DW_DEV int flow_errors(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, in
         if (from_pend) --pend_n; else ++t;
     }
     o1.flush();
-    const int n1 = o1.n;
+    return o1.n;
+}
+// Every lane of the wave must call this (pass 2 regroups lanes with wave ballots); lanes without a read pass active = false.
+DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
+                       int len, int strand, int cap, int32_t *n_err_out)
+{
+    int n1 = 0, total = 0, flow_i = 0; uint64_t mask = 0; bool failed = !active;
+    if (active) n1 = flow_pass1(rg, flow, dist, F, thr, bufA, bufB, stride, len, strand, cap, mask, flow_i, total);
+    if (n1 < 0) failed = true;
+
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
-    // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order. ----
+    // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
+    // With e = 0.01 some lane of a wave has a scoring flow at almost every position, so the lanes are regrouped: a lane whose examined
+    // base has a scoring flow parks, the others run on through quiet positions, and the flow-by-flow code is entered once for a batch of
+    // parked lanes (each lane still performs exactly its own sequence of operations, only their interleaving changes). ----
     PackReader<2> r2; r2.init(bufB, stride);
     PackAppender<4> o2; o2.init(bufA, stride);
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
     auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
-    int t2 = 0, sp = 0;
-    rg.dom += D_FLOW_PASS2;
-    for (uint32_t n2 = 0;; ++n2) {
-        rg.open(n2);
-        uint32_t x;
-        if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else break;
-        if (o2.n >= cap) return -1;
-        // empty flows in front of the examined base: each may insert (dwgsim.c:370-392).  Flow q of them draws word q of the event's
-        // stream unless an earlier one scored: if none of the first k words is below the threshold nothing happens at all
-        const int k_empty = dist[4 * flow_i + (int)x];
-        bool quiet = true;
-        for (int q = 0; q < k_empty && quiet; q += 4) {
-            const U4 b = rng_block(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)q >> 2, rg.evt);
-            quiet = !((uint64_t)b.x < thr || (q + 1 < k_empty && (uint64_t)b.y < thr) || (q + 2 < k_empty && (uint64_t)b.z < thr) || (q + 3 < k_empty && (uint64_t)b.w < thr));
-        }
-        if (quiet) { flow_i += k_empty; if (flow_i >= F) flow_i -= F; }
-        else while (x != flow[flow_i]) {            // (rare) replay the flows one by one from the start of the event's stream
-            const int n_err = rg.geometric(thr);
-            if (!((mask >> flow_i) & 1) && n_err > 0) {
-                if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) return -1;
-                stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp;
-                total += n_err;
-            }
-            flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
-        }
-        if (sp == 0) { o2.push(x); ++t2; }          // nothing in front of it: the base itself becomes final
-        else {                                      // the first base of the top run (the examined base stays behind it)
+    auto settle = [&](uint32_t x, int &t2, int &sp) {      // the position's final base: the examined base, or the first base of the top run
+        if (sp == 0) { o2.push(x); ++t2; }
+        else {
             const uint32_t top = stk_get(sp - 1);
             o2.push(top >> 14);
             if ((top & 0x3fffu) <= 1) --sp; else stk_set(sp - 1, top - 1);
         }
+    };
+    int t2 = 0, sp = 0;
+    rg.dom += D_FLOW_PASS2;
+    bool done = failed, parked = false; uint32_t n2 = 0, x = 0;
+    for (;;) {
+        if (!done && !parked) {
+            if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else done = true;
+            if (!done && o2.n >= cap) { failed = true; done = true; }
+            if (!done) {
+                // flow q of the empty flows in front of x draws word q of the position's stream unless an earlier one scored: if none of
+                // the first k words is below the threshold nothing happens at this position (dwgsim.c:370-392)
+                const int k_empty = dist[4 * flow_i + (int)x];
+                bool quiet = true;
+                for (int q = 0; q < k_empty && quiet; q += 4) {
+                    const U4 b = rng_block(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)q >> 2, n2);
+                    quiet = !((uint64_t)b.x < thr || (q + 1 < k_empty && (uint64_t)b.y < thr) || (q + 2 < k_empty && (uint64_t)b.z < thr) || (q + 3 < k_empty && (uint64_t)b.w < thr));
+                }
+                if (quiet) { flow_i += k_empty; if (flow_i >= F) flow_i -= F; settle(x, t2, sp); ++n2; }
+                else parked = true;
+            }
+        }
+        const uint64_t parked_lanes = __ballot(parked), running_lanes = __ballot(!done && !parked);
+        if (parked_lanes && (running_lanes == 0 || __popcll(parked_lanes) >= 16)) {
+            if (parked) {                               // the flows one by one from the start of the position's stream
+                rg.open(n2);
+                while (!failed && x != flow[flow_i]) {
+                    const int n_err = rg.geometric(thr);
+                    if (!((mask >> flow_i) & 1) && n_err > 0) {
+                        if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
+                        else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
+                    }
+                    flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
+                }
+                if (failed) done = true; else { settle(x, t2, sp); ++n2; }
+                parked = false;
+            }
+        }
+        if (__ballot(!done) == 0) break;
     }
+    if (failed) return -1;
     o2.flush();
     *n_err_out += total;
     return o2.n;

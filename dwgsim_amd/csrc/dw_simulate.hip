@@ -287,12 +287,16 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     int s_out = s;                              // read length after errors (changes only for Ion Torrent)
     bool flow_reversed = false;
     const int nw = (s + 7) >> 3;
-    if (DT == 2 && valid && !is_rand && s > 0) {  // dwgsim.c:861-864
+    if (DT == 2) {                              // dwgsim.c:861-864; every lane calls (the second pass regroups the lanes of a wave)
+        const bool flows = valid && !is_rand && s > 0;
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        s_out = flow_errors(rg, s_flow, s_dist, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
-                            nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
-        if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
-        flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
+        const int so = flow_errors(flows, rg, s_flow, s_dist, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, dyn_lds + tid,
+                                   nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
+        if (flows) {
+            s_out = so;
+            if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
+            flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
+        }
     }
     int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
     if (valid && (DT != 2 || is_rand)) {
@@ -698,9 +702,10 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
     uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid;
     int32_t n_err = 0; int s_out = 0;
-    if (jj < a.n_reads) {
-        const RngKey key{a.seed, 0u};
-        const uint32_t dom = D_CALIB + (uint32_t)a.end;
+    const bool live = jj < a.n_reads;
+    const RngKey key{a.seed, 0u};
+    const uint32_t dom = D_CALIB + (uint32_t)a.end;
+    if (live) {
         for (int w = 0; w * 8 < a.len; ++w) {
             const U4 q0 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w)), q1 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w + 1));
             const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -709,9 +714,11 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
             for (int b = 0; b < 8; ++b) if (w * 8 + b < a.len) word |= (rw[b] >> 30) << (4 * b);      // (int)(u * 4.0) & 3
             buf[w * nthr] = word;
         }
+    }
+    {   // every lane calls (the second pass regroups the lanes of a wave)
         FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        s_out = flow_errors(rg, s_flow, s_dist, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
-        if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; }
+        const int so = flow_errors(live, rg, s_flow, s_dist, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
+        if (live) { s_out = so; if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; } }
     }
     const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);
     if ((tid & 63) == 0) { atomicAdd((unsigned long long *)&a.counters[8], (unsigned long long)es); atomicAdd((unsigned long long *)&a.counters[9], (unsigned long long)ls); }
