@@ -737,7 +737,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
     if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
-    if (ensure(c, c->meta, sizeof(uint32_t) * (size_t)(n_pairs ? n_pairs : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
     a.meta = (uint32_t *)c->meta.p;
     a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
     for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)(nblk ? nblk : 1);

@@ -571,11 +571,17 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
     __shared__ FailSeg seg[256];
     const uint64_t first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * FAIL_PAIRS_PER_THREAD;
     FailSeg s{0, 0, 0, 0};
-    for (int q = 0; q < FAIL_PAIRS_PER_THREAD && first + q < n_pairs; ++q) {
-        const uint32_t m = meta[first + q];
-        const FailSeg e{m & 0x7fffffffu, 0, (m >> 31) ? 0u : 1u, 0};      // the pair's fails come before its outcome; a genomic read resets
-        FailSeg one = e; if (!one.R) one.S = one.P;                         // no reset: everything is both prefix and suffix
-        s = (q == 0) ? one : failseg_join(s, one);
+    for (int q4 = 0; q4 < FAIL_PAIRS_PER_THREAD && first + q4 < n_pairs; q4 += 4) {       // 16-byte loads (meta is padded to a multiple of four entries)
+        const uint4 v = *reinterpret_cast<const uint4 *>(meta + first + q4);
+        const uint32_t mm[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (first + q4 + u >= n_pairs) break;
+            const uint32_t m = mm[u];
+            FailSeg one{m & 0x7fffffffu, 0, (m >> 31) ? 0u : 1u, 0};           // the pair's fails come before its outcome; a genomic read resets
+            if (!one.R) one.S = one.P;                                          // no reset: everything is both prefix and suffix
+            s = (q4 + u == 0) ? one : failseg_join(s, one);
+        }
     }
     seg[threadIdx.x] = s;
     __syncthreads();
