@@ -86,12 +86,24 @@ def run_job_in_random_shards(params, contigs, lib, rng):
     n_sim = rand_ii = 0
     n_ref = len(contigs)
     with api.Context(params, 0, lib) as ctx:
+        if getattr(params, "_mut_input", None):
+            ctx.set_mutation_input(params._mut_input[0], params._mut_input[1], contigs)
+        have_regions = bool(getattr(params, "_regions", None))
+        if have_regions:
+            tot_len = ctx.set_regions(params._regions, contigs)
         for ci, (name, arr) in enumerate(contigs):
             n_ref -= 1
-            n_pairs = api.pairs_for_contig(params, len(arr), tot_len, n_ref == 0, n_sim, lib)
+            l_eff = len(arr)
+            if have_regions and not (n_ref == 0 and params.C < 0):      # as api.run_job (dwgsim.c:535-581)
+                l_eff = ctx.region_length(ci, arr)
+                if l_eff < 0:
+                    continue
+            n_pairs = api.pairs_for_contig(params, l_eff, tot_len, n_ref == 0, n_sim, lib)
             if n_pairs < 0:
                 continue
             cid = ctx.add_contig(name, arr, ci)
+            if have_regions:
+                ctx.set_placement_length(cid, l_eff)
             ctx.mutate(cid)
             cuts = sorted(set([0, n_pairs] + [rng.randrange(0, n_pairs + 1) for _ in range(rng.randrange(0, 5))]))
             ranges = [(a, b - a) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
