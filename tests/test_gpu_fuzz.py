@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed,count,mode", [(101, 40, ""), (102, 25, "inputs"), (103, 20, "cli"), (104, 10, "inputs cli"), (105, 25, "shards")])
+@pytest.mark.parametrize("seed,count,mode", [(101, 40, ""), (102, 25, "inputs"), (103, 20, "cli"), (104, 10, "inputs cli"), (105, 25, "shards"), (106, 15, "inputs shards")])
 def test_random_option_sets_bit_exact(oracle_bin, seed, count, mode):
     cmd = [sys.executable, os.path.join(ROOT, "tests", "fuzz_flags.py"), str(seed), str(count)] + mode.split()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
