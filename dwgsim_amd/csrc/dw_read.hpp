@@ -179,13 +179,17 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t at
                 }
             }
             ++t;
-            if (t > (1u << 20)) { pd.hap = -1; break; }   // the reference would never terminate here; reported as an error by the caller
+            // the reference would never terminate here; reported as an error by the caller.  Once one pair of the batch has given up the
+            // call is lost anyway: the others stop at their next 1024th try instead of spinning to 2^20 each
+            if (t > (1u << 20) || ((t & 1023u) == 0 && (__hip_atomic_load(&a.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4ull))) { pd.hap = -1; break; }
             continue_flag = !inside;
         } while (continue_flag || pos < 0 || pos >= sl || (int64_t)pos + d - 1 >= sl
                  || (s1 > 0 && !a.p.is_inner && ((s0 > 0 && d <= s1) || (d <= s0 && s1 > 0))));
         pd.pos = pos; pd.d = d;
     }
-    if (pd.hap < 0) { pd.hap = 0; pd.pos = 0; pd.d = (int32_t)(s0 + s1 < sl ? s0 + s1 : sl); atomicOr((unsigned long long *)&a.counters[2], 4ull); return pd; }
+    // no placement satisfied the target regions: the call will return an error; this pair ends here as a (discarded) random read so that
+    // the lane neither retries 10 000 times nor writes anything irregular
+    if (pd.hap < 0) { pd.hap = 0; pd.pos = 0; pd.d = 0; pd.is_rand = true; atomicOr((unsigned long long *)&a.counters[2], 4ull); return pd; }
     pd.hap = u_hi(b0) < a.p.mut_freq ? 0 : 1;
     switch (a.p.read_one_strand) {
     case 0: pd.strand0 = rng_slot(key, D_PAIR, ii, att, 2) < 0.5 ? 1 : 0; break;

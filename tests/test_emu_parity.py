@@ -72,3 +72,12 @@ def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):
     check_both_abort(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 1200 -r 0 -e 0.0-0.1 -Q 0 -a")
     # ... while the same job with fewer pairs stays under the limit and must match byte for byte
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 600 -r 0 -e 0.0-0.1 -Q 0 -a", batch_pairs=100)
+
+
+def test_hopeless_target_regions_end_with_an_error(emu_lib, golden_dir, tmp_path):
+    """Regions that pass the length checks but can never hold a fragment: the reference spins forever (dwgsim.c:677-713); here the
+    placement gives up after 2^20 tries, the rest of the batch stops early, and the call returns an error."""
+    bed = tmp_path / "r.bed"
+    bed.write_text("t1\t100\t500\nt1\t900\t1300\n")
+    with pytest.raises(api.DwgsimError, match="no fragment placement satisfied the target regions"):
+        api.run_job(api.parse_flags(f"-z 3 -N 130 -1 50 -2 50 -d 500 -s 5 -x {bed}", emu_lib), api.read_fasta(os.path.join(golden_dir, "tiny.fa")), lib=emu_lib)

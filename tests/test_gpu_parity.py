@@ -123,3 +123,12 @@ def test_abort_rule_matches_the_reference(lib, oracle_bin, golden_dir):
     with pytest.raises(api.DwgsimError, match="failed to generate a read after 10001 trials"):
         api.run_job(api.parse_flags(flags, lib), api.read_fasta(os.path.join(golden_dir, "odd.fa")), batch_pairs=37, lib=lib)
     compare_case(lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), flags.replace("-N 1200", "-N 600"), batch_pairs=37)
+
+
+def test_hopeless_target_regions_end_with_an_error(lib, golden_dir, tmp_path):
+    """Regions that pass the length checks but can never hold a fragment: the reference spins forever (dwgsim.c:677-713); here the
+    placement gives up after 2^20 tries, the rest of the batch stops early, and the call returns an error."""
+    bed = tmp_path / "r.bed"
+    bed.write_text("t1\t100\t500\nt1\t900\t1300\n")
+    with pytest.raises(api.DwgsimError, match="no fragment placement satisfied the target regions"):
+        api.run_job(api.parse_flags(f"-z 3 -N 130 -1 50 -2 50 -d 500 -s 5 -x {bed}", lib), api.read_fasta(os.path.join(golden_dir, "tiny.fa")), lib=lib)
