@@ -33,7 +33,11 @@ class Params(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("n_random", C.c_uint64), ("n_retries", C.c_uint64), ("bytes", C.c_uint64 * 3),
-                ("dev_ptr", C.c_void_p * 3), ("kernel_ms", C.c_float), ("sim_kernel_ms", C.c_float)]
+                ("dev_ptr", C.c_void_p * 3), ("kernel_ms", C.c_float), ("sim_kernel_ms", C.c_float),
+                ("fail_seg", C.c_uint64 * 4), ("fail_carry", C.c_uint64)]
+
+
+RAND_CHAIN = (1 << 64) - 1        # DWGSIM_HIP_RAND_CHAIN
 
 
 EXPORTS = [
@@ -42,6 +46,8 @@ EXPORTS = [
     "dwgsim_hip_set_regions", "dwgsim_hip_contig_region_length", "dwgsim_hip_contig_set_placement_length",
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
+    "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
+    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option",
 ]
 
 _lib = None
@@ -79,6 +85,18 @@ def load(path: str | None = None):
     lib.dwgsim_hip_simulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, P(Batch)]
     lib.dwgsim_hip_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.dwgsim_hip_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, P(C.c_int), P(C.c_size_t)]
+    lib.dwgsim_hip_simulate_async.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    lib.dwgsim_hip_wait.argtypes = [C.c_void_p, C.c_int, P(Batch)]
+    lib.dwgsim_hip_fetch_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.dwgsim_hip_fetch_wait.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_host_alloc.restype = C.c_void_p
+    lib.dwgsim_hip_host_alloc.argtypes = [C.c_size_t]
+    lib.dwgsim_hip_host_free.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_set_fail_carry.argtypes = [C.c_void_p, C.c_uint64]
+    lib.dwgsim_hip_failseg_join.argtypes = [P(C.c_uint64 * 4), P(C.c_uint64 * 4)]
+    lib.dwgsim_hip_shard_range.restype = None
+    lib.dwgsim_hip_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, P(C.c_uint64), P(C.c_uint64)]
+    lib.dwgsim_hip_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     if path is None:
         _lib = lib
     return lib
@@ -280,6 +298,26 @@ class Context:
         self._chk(self.lib.dwgsim_hip_simulate(self.h, cid, first_ii, n_pairs, rand_base, slot, C.byref(b)))
         return b
 
+    def simulate_async(self, cid: int, first_ii: int, n_pairs: int, rand_base: int = RAND_CHAIN, slot: int = 0):
+        self._chk(self.lib.dwgsim_hip_simulate_async(self.h, cid, first_ii, n_pairs, rand_base, slot))
+
+    def wait(self, slot: int = 0) -> Batch:
+        b = Batch()
+        self._chk(self.lib.dwgsim_hip_wait(self.h, slot, C.byref(b)))
+        return b
+
+    def fetch_async(self, slot: int, stream: int, host_ptr: int, cap: int):
+        self._chk(self.lib.dwgsim_hip_fetch_async(self.h, slot, stream, host_ptr, cap))
+
+    def fetch_wait(self, slot: int):
+        self._chk(self.lib.dwgsim_hip_fetch_wait(self.h, slot))
+
+    def set_fail_carry(self, carry: int):
+        self._chk(self.lib.dwgsim_hip_set_fail_carry(self.h, carry))
+
+    def debug_option(self, key: str, value: int):
+        self._chk(self.lib.dwgsim_hip_debug_option(self.h, key.encode(), value))
+
     def fetch(self, slot: int, stream: int, nbytes: int) -> bytes:
         buf = C.create_string_buffer(int(nbytes) if nbytes else 1)
         self._chk(self.lib.dwgsim_hip_fetch(self.h, slot, stream, buf, nbytes))
@@ -291,7 +329,14 @@ def pairs_for_contig(params: Params, l: int, tot_len: int, is_last: bool, n_sim:
     return lib.dwgsim_hip_pairs_for_contig(C.byref(params), l, tot_len, 1 if is_last else 0, n_sim)
 
 
-def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None) -> JobResult:
+def shard_range(n_pairs: int, rank: int, world: int, lib=None):
+    lib = lib or load()
+    first, n = C.c_uint64(0), C.c_uint64(0)
+    lib.dwgsim_hip_shard_range(n_pairs, rank, world, C.byref(first), C.byref(n))
+    return first.value, n.value
+
+
+def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None, debug_options=None) -> JobResult:
     """dwgsim_core (dwgsim.c:419-1121) over the C-ABI: header pass, then per contig
     schedule -> mutate -> mutations text -> simulate in read-index batches."""
     lib = lib or load()
@@ -310,6 +355,8 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
     rand_ii = 0
     n_ref = len(contigs)
     with Context(params, device, lib) as ctx:
+        for k, v in (debug_options or {}).items():
+            ctx.debug_option(k, v)
         if getattr(params, "_mut_input", None):
             ctx.set_mutation_input(params._mut_input[0], params._mut_input[1], contigs)
         have_regions = bool(getattr(params, "_regions", None))

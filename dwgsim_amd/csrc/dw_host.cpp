@@ -39,7 +39,6 @@ struct Contig {
     size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
     uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
     uint32_t n_cand = 0;
-    uint64_t fail_carry = 0;            // the reference's num_failed (dwgsim.c:635) carried between the batches of this contig
     uint16_t *d_summ[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries for count_random (built on demand)
     int64_t l_place = 0;                // fragment-placement length (region length with -x)
     int32_t *d_reg = nullptr; int32_t n_reg = 0;   // -x: [start[0..n), end[0..n)] of this contig
@@ -47,6 +46,15 @@ struct Contig {
 
 struct DevBuf {                     // grow-only device buffer
     void *p = nullptr; size_t cap = 0;
+};
+
+constexpr int N_COUNTERS = 32;      // u64 words of a counter block (SimArgs::counters)
+
+struct Slot {                       // one of the two batches a context can have in flight
+    uint64_t *d_counters = nullptr, *h_counters = nullptr;      // device block + pinned mirror
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_fetched = nullptr;
+    bool pending = false, empty = true, fetch_in_flight = false;
+    uint64_t n_pairs = 0, out_bytes[3] = {0, 0, 0};
 };
 
 } // namespace
@@ -58,7 +66,6 @@ struct dwgsim_hip_ctx {
     uint8_t *d_flow = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     double e_by[2] = {0, 0};
     uint64_t *d_thr[2] = {nullptr, nullptr};
@@ -73,9 +80,14 @@ struct dwgsim_hip_ctx {
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
     DevBuf w_ppos, w_pcells, flow_scratch;
-    uint64_t *d_counters = nullptr;          // 8 x u64
+    uint64_t *d_counters = nullptr;          // N_COUNTERS x u64: walk / calibrate / count_random (synchronous calls)
     uint64_t *h_counters = nullptr;          // pinned mirror
-    uint64_t out_bytes[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    Slot slot[2];                            // simulate(): two batches in flight (kernels of one overlap the copy-out of the other)
+    hipStream_t copy_stream = nullptr;       // device -> host copies of finished text
+    uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
+    int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
+    bool has_carry_override = false; uint64_t carry_override = 0;
+    int64_t walk_cap = -1; bool phases = false;             // dwgsim_hip_debug_option
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
     std::string txt, vcf;
 };
@@ -201,6 +213,25 @@ int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t
     return DWGSIM_HIP_ABI_VERSION;
 }
 
+int dwgsim_hip_failseg_join(uint64_t acc[4], const uint64_t next[4])      // the same monoid as failseg_join in dw_simulate.hip
+{
+    const uint64_t aP = acc[0], aS = acc[1], aR = acc[2], aB = acc[3], bP = next[0], bS = next[1], bR = next[2], bB = next[3];
+    acc[3] = (aB | bB | ((aR && aS + bP > (uint64_t)MAX_ATTEMPTS) ? 1u : 0u)) ? 1 : 0;
+    acc[0] = aR ? aP : aP + bP;
+    acc[1] = bR ? bS : aS + bS;
+    acc[2] = (aR | bR) ? 1 : 0;
+    return (acc[3] || acc[0] > (uint64_t)MAX_ATTEMPTS || acc[1] > (uint64_t)MAX_ATTEMPTS) ? 1 : 0;
+}
+
+void dwgsim_hip_shard_range(uint64_t n_pairs, int rank, int world, uint64_t *first, uint64_t *n)
+{
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    const uint64_t base = n_pairs / (uint64_t)world, rem = n_pairs % (uint64_t)world, r = (uint64_t)rank;
+    if (first) *first = r * base + (r < rem ? r : rem);
+    if (n) *n = base + (r < rem ? 1 : 0);
+}
+
 // Ion Torrent: room for a read after the flow model.  Every empty flow (about three per base) inserts Geometric(e) bases, inserted bases
 // are examined again: the mean growth is ~3 e / (1 - e) per base; four times that plus slack keeps overflow (reported as an error, never
 // written out of bounds) out of reach for realistic error rates and far away even for e = 0.3.
@@ -228,14 +259,20 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     if (p->data_type == 2) for (const char *q = p->flow_order; *q; ++q) c->flow.push_back(nt4((unsigned char)*q));
     c->prm.read_prefix = nullptr; c->prm.flow_order = nullptr;
     c->device = device;
-    { const char *e = getenv("DWGSIM_HIP_JUSTIFY"); c->seq_justify = e && !strcmp(e, "seq"); }   // cross-check mode
     auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, DWGSIM_HIP_ERR_DEVICE); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
     auto init = [&]() -> int {
         HIPC(c, hipSetDevice(device));
         HIPC(c, hipStreamCreate(&c->stream));
-        for (int i = 0; i < 4; ++i) HIPC(c, hipEventCreate(&c->ev[i]));
-        HIPC(c, hipMalloc((void **)&c->d_counters, 16 * sizeof(uint64_t)));
-        HIPC(c, hipHostMalloc((void **)&c->h_counters, 16 * sizeof(uint64_t), hipHostMallocDefault));
+        HIPC(c, hipStreamCreate(&c->copy_stream));
+        HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));
+        HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
+        HIPC(c, hipMalloc((void **)&c->d_chain, 4 * sizeof(uint64_t)));
+        HIPC(c, hipMemset(c->d_chain, 0, 4 * sizeof(uint64_t)));
+        for (Slot &sl : c->slot) {
+            HIPC(c, hipMalloc((void **)&sl.d_counters, N_COUNTERS * sizeof(uint64_t)));
+            HIPC(c, hipHostMalloc((void **)&sl.h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
+            HIPC(c, hipEventCreate(&sl.ev_k0)); HIPC(c, hipEventCreate(&sl.ev_k1)); HIPC(c, hipEventCreate(&sl.ev_done)); HIPC(c, hipEventCreate(&sl.ev_fetched));
+        }
         { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
           HIPC(c, hipMalloc((void **)&c->d_flow, 64)); HIPC(c, hipMemcpy(c->d_flow, fl.data(), 64, hipMemcpyHostToDevice)); }
         // -B (dwgsim_opt.c:415-457): rescale the flow error so that the per-base error rate of 10^6 random reads matches -e
@@ -259,9 +296,9 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
                 if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
                 ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
-                HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
+                HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
                 launch_calibrate(c->stream, ca);
-                HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+                HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
                 HIPC(c, hipStreamSynchronize(c->stream));
                 if (c->h_counters[2]) { c->err = "-B calibration: a read outgrew its flow-space buffer"; return -1; }
                 const int32_t n_err = (int32_t)c->h_counters[8], counts = (int32_t)c->h_counters[9];       // int32 accumulators as in the reference
@@ -324,21 +361,47 @@ extern "C" int dwgsim_hip_selftest_fp64(int device, uint32_t seed, uint64_t n, u
     return e == hipSuccess ? DWGSIM_HIP_OK : DWGSIM_HIP_ERR_DEVICE;
 }
 
+// Not part of the drop-in ABI either: self-test of the lazy quality normals (dw_simulate.hip k_selftest_lazy).  out[0..4] = counters of the
+// comparison with the exact form on n random blocks at quality_std = sigma, out[5] = max |estimate - exact| / eps, out[6..8] = worst error of
+// v_log_f32 / v_rcp_f32 / v_sqrt_f32 over EVERY float of their operand ranges, in units of the bounds the error budget assumes (doubles).
+extern "C" int dwgsim_hip_selftest_lazy(int device, uint32_t seed, uint64_t n, double sigma, int exhaustive, uint64_t *out)
+{
+    if (!out || hipSetDevice(device) != hipSuccess) return DWGSIM_HIP_ERR_DEVICE;
+    uint64_t *d = nullptr;
+    if (hipMalloc((void **)&d, 12 * sizeof(uint64_t)) != hipSuccess) return DWGSIM_HIP_ERR_NOMEM;
+    hipMemset(d, 0, 12 * sizeof(uint64_t));
+    launch_selftest_lazy(nullptr, 0, seed, n, sigma, d);
+    if (exhaustive) {
+        launch_selftest_lazy(nullptr, 1, 0, 0x3F800000u - 0x20800000u, 0, d);
+        launch_selftest_lazy(nullptr, 2, 0, 0x3F800000u - 0x20800000u, 0, d);
+        launch_selftest_lazy(nullptr, 3, 0, 0x62800000u - 0x3A000000u, 0, d);
+    }
+    const hipError_t e = hipMemcpy(out, d, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? DWGSIM_HIP_OK : DWGSIM_HIP_ERR_DEVICE;
+}
+
 void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     hipFree(c->status_all.p);
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->fail_summ.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
-    hipFree(c->d_counters); hipFree(c->d_flow);
+    hipFree(c->d_counters); hipFree(c->d_flow); hipFree(c->d_chain);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->h_stage) hipHostFree(c->h_stage);
-    for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    for (Slot &sl : c->slot) {
+        hipFree(sl.d_counters);
+        if (sl.h_counters) hipHostFree(sl.h_counters);
+        for (hipEvent_t e : {sl.ev_k0, sl.ev_k1, sl.ev_done, sl.ev_fetched}) if (e) hipEventDestroy(e);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -356,32 +419,38 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *
     k.name = name; k.l = len; k.contig_index = contig_index; k.ascii.assign(ascii, ascii + len); k.alive = true; k.mutated = false;
     const size_t padded = (size_t)((len + 15) & ~(int64_t)15) + CELL_PAD;
     uint8_t *d_ascii = nullptr;
-    HIPC(c, hipMalloc((void **)&d_ascii, padded));
-    HIPC(c, hipMalloc((void **)&k.d_ref, padded));
-    for (int h = 0; h < 2; ++h) HIPC(c, hipMalloc((void **)&k.d_cells[h], padded));
-    HIPC(c, hipMemcpyAsync(d_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipMemsetAsync(k.d_ref, 4, padded, c->stream));
-    for (int h = 0; h < 2; ++h) HIPC(c, hipMemsetAsync(k.d_cells[h], 4, padded, c->stream));
-    if (len > 0) launch_pack(c->stream, d_ascii, k.d_ref, k.d_cells[0], k.d_cells[1], len);
-    HIPC(c, hipGetLastError());
-    k.l_place = len;
-    if (c->has_regions) {
-        std::vector<int32_t> st, en; int64_t tot = 0;
-        for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == contig_index) { st.push_back((int32_t)c->regions.start[q]); en.push_back((int32_t)c->regions.end[q]); tot += c->regions.end[q] - c->regions.start[q]; }
-        k.n_reg = (int32_t)st.size(); k.l_place = tot;
-        HIPC(c, hipMalloc((void **)&k.d_reg, sizeof(int32_t) * (2 * st.size() + 2)));
-        if (!st.empty()) {
-            HIPC(c, hipMemcpy(k.d_reg, st.data(), sizeof(int32_t) * st.size(), hipMemcpyHostToDevice));
-            HIPC(c, hipMemcpy(k.d_reg + st.size(), en.data(), sizeof(int32_t) * en.size(), hipMemcpyHostToDevice));
+    auto fill = [&]() -> int {
+        HIPC(c, hipMalloc((void **)&d_ascii, padded));
+        HIPC(c, hipMalloc((void **)&k.d_ref, padded));
+        for (int h = 0; h < 2; ++h) HIPC(c, hipMalloc((void **)&k.d_cells[h], padded));
+        HIPC(c, hipMemcpyAsync(d_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipMemsetAsync(k.d_ref, 4, padded, c->stream));
+        for (int h = 0; h < 2; ++h) HIPC(c, hipMemsetAsync(k.d_cells[h], 4, padded, c->stream));
+        if (len > 0) launch_pack(c->stream, d_ascii, k.d_ref, k.d_cells[0], k.d_cells[1], len);
+        HIPC(c, hipGetLastError());
+        k.l_place = len;
+        if (c->has_regions) {
+            std::vector<int32_t> st, en; int64_t tot = 0;
+            for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == contig_index) { st.push_back((int32_t)c->regions.start[q]); en.push_back((int32_t)c->regions.end[q]); tot += c->regions.end[q] - c->regions.start[q]; }
+            k.n_reg = (int32_t)st.size(); k.l_place = tot;
+            HIPC(c, hipMalloc((void **)&k.d_reg, sizeof(int32_t) * (2 * st.size() + 2)));
+            if (!st.empty()) {
+                HIPC(c, hipMemcpy(k.d_reg, st.data(), sizeof(int32_t) * st.size(), hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(k.d_reg + st.size(), en.data(), sizeof(int32_t) * en.size(), hipMemcpyHostToDevice));
+            }
         }
-    }
-    std::string nf = c->read_prefix.empty() ? k.name : c->read_prefix + "_" + k.name;
-    k.name_fixed_len = (int32_t)nf.size();
-    std::string nbuf = "@" + nf; nbuf.resize(nbuf.size() < 256 ? 272 : nbuf.size() + 16, '\0');
-    HIPC(c, hipMalloc((void **)&k.d_name_fixed, nbuf.size()));
-    HIPC(c, hipMemcpyAsync(k.d_name_fixed, nbuf.data(), nbuf.size(), hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    HIPC(c, hipFree(d_ascii));
+        std::string nf = c->read_prefix.empty() ? k.name : c->read_prefix + "_" + k.name;
+        k.name_fixed_len = (int32_t)nf.size();
+        std::string nbuf = "@" + nf; nbuf.resize(nbuf.size() < 256 ? 272 : nbuf.size() + 16, '\0');
+        HIPC(c, hipMalloc((void **)&k.d_name_fixed, nbuf.size()));
+        HIPC(c, hipMemcpyAsync(k.d_name_fixed, nbuf.data(), nbuf.size(), hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    const int rc = fill();
+    (void)hipFree(d_ascii);
+    if (rc != 0) { (void)hipStreamSynchronize(c->stream); free_contig(k); return rc; }      // no half-built contig stays behind a failed call
+    if (c->chain_contig == id) c->chain_contig = -1;      // a recycled handle does not continue its predecessor's failure counter
     return id;
 }
 
@@ -390,7 +459,9 @@ int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *c, int contig)
     if (!c || contig < 0 || (size_t)contig >= c->contigs.size() || !c->contigs[(size_t)contig].alive) return DWGSIM_HIP_ERR_ARG;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->copy_stream);
     free_contig(c->contigs[(size_t)contig]);
+    if (c->chain_contig == contig) c->chain_contig = -1;
     return DWGSIM_HIP_OK;
 }
 
@@ -521,7 +592,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     const double mean = (double)l * c->prm.mut_rate;
     uint32_t cap = (uint32_t)std::min<double>((double)l, mean + 8.0 * sqrt(mean + 1.0) + 256.0);
     size_t cap_bases = (size_t)cap * 8 + 4096;
-    if (const char *e = getenv("DWGSIM_HIP_WALK_CAP")) { cap = (uint32_t)atoi(e); cap_bases = 1; }      // tests: start too small, exercise the re-run
+    if (c->walk_cap >= 0) { cap = (uint32_t)c->walk_cap; cap_bases = 1; }      // dwgsim_hip_debug_option("walk_cap"): start too small, exercise the re-run
     for (int attempt = 0; ; ++attempt) {
         if (attempt > 0) {      // start again from the resident packed reference
             const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
@@ -705,7 +776,7 @@ int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt,
 }
 
 // ---- read simulation ----
-static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, SimArgs &a)
+static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uint64_t n_pairs, SimArgs &a)
 {
     const dwgsim_hip_params_t &p = c->prm;
     memset(&a, 0, sizeof a);
@@ -715,8 +786,11 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.p.fixed_quality = p.fixed_quality; a.p.data_type = p.data_type;
     a.p.has_bfast = p.reads_output_type != 1; a.p.has_bwa = p.reads_output_type != 2;
     a.p.seed = (uint32_t)p.seed;
+    a.p.q_k = (float)(sqrt(2.0 * log(2.0)) * 0x1p-31 * p.quality_std);
+    a.p.q_eps = (float)(p.quality_std * 0x1p-14 + 0x1p-18);       // (+inf for an absurd -Q: every value then takes the exact path)
+    a.p.q_near1 = p.quality_std < 12.0 ? 1 : 0;
     a.c = contig_dev(k);
-    a.first_ii = first_ii; a.n_pairs = n_pairs; a.rand_base = rand_base;
+    a.first_ii = first_ii; a.n_pairs = n_pairs; a.chain = c->d_chain;
     a.l_place = k.l_place; a.have_regions = c->has_regions ? 1 : 0; a.n_reg = k.n_reg; a.reg_start = k.d_reg; a.reg_end = k.d_reg ? k.d_reg + k.n_reg : nullptr;
     for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.e_thr32[j] = c->d_thr32[j]; a.qbase[j] = c->d_qbase[j]; }
     a.e_full = c->e_full;
@@ -735,7 +809,9 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     }
     const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block
     const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
-    if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;
+    const uint64_t nblk_place = (n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;       // k_place (count_random) writes one entry per ITS block
+    const uint64_t nblk_rand = nblk > nblk_place ? nblk : nblk_place;
+    if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk_rand ? nblk_rand : 1))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
     if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
     a.meta = (uint32_t *)c->meta.p;
@@ -776,84 +852,152 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, 
         kp->summ_valid = true;
     }
     SimArgs a;
-    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, 0, a)) return rc;
-    HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
+    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, a)) return rc;
+    HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
     launch_place(c->stream, a);
     const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
     launch_scan_excl(c->stream, a.block_rand, nblk, &c->d_counters[3]);
-    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     if (n_random) *n_random = c->h_counters[3];
     return DWGSIM_HIP_OK;
 }
 
-int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, int slot, dwgsim_hip_batch_t *out)
+int dwgsim_hip_set_fail_carry(dwgsim_hip_ctx_t *c, uint64_t carry)
+{
+    if (!c) return DWGSIM_HIP_ERR_ARG;
+    c->carry_override = carry; c->has_carry_override = true;
+    return DWGSIM_HIP_OK;
+}
+
+// Enqueue one batch on the compute stream: [chain set] -> memsets -> k_simulate -> abort-rule epilogue -> counters to the slot's pinned
+// mirror -> event.  Nothing here waits for the GPU (buffers only grow between batches of different shapes, and hipFree synchronises).
+int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, int slot)
 {
     Contig *kp = get_contig(c, contig);
     if (!kp || slot < 0 || slot > 1) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
     if (!kp->mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    Slot &sl = c->slot[slot];
+    if (sl.pending) { c->err = "simulate: the slot still holds a batch that was not waited for"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
-    if (out) memset(out, 0, sizeof *out);
-    for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = 0;
+    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = 0;
+    sl.n_pairs = n_pairs; sl.empty = n_pairs == 0;
+    // the reference's failure counter (dwgsim.c:635) runs over the pairs of ONE contig in index order: it is carried from the previous
+    // batch only when this one continues it; any other range starts from zero unless the caller supplied the carry (sharded jobs)
+    const bool continues = c->chain_contig == contig && c->chain_next_ii == first_ii && first_ii != 0;
+    const bool set_carry = c->has_carry_override || !continues;
+    const uint64_t carry = c->has_carry_override ? c->carry_override : 0;
+    c->has_carry_override = false;
+    const bool set_rand = rand_base != DWGSIM_HIP_RAND_CHAIN;
+    if (set_rand || set_carry) launch_chain_set(c->stream, c->d_chain, rand_base, set_rand ? 1 : 0, carry, set_carry ? 1 : 0);
+    c->chain_contig = contig; c->chain_next_ii = first_ii + n_pairs;
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     SimArgs a;
-    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, rand_base, a)) return rc;
+    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, a)) return rc;
     if (c->has_regions && kp->n_reg == 0 && c->prm.rand_read < 1.0) { c->err = "dwgsim-hip: this contig has no target region (-x): the reference's placement loop would not terminate\n"; return DWGSIM_HIP_ERR_ARG; }
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     const dwgsim_hip_params_t &p = c->prm;
     const int fixed_max = kp->name_fixed_len > c->rand_fixed_len ? kp->name_fixed_len : c->rand_fixed_len;
-    const size_t nreads = (size_t)n_pairs * (p.length[1] > 0 ? 2 : 1);
     size_t cap[3] = {0, 0, 0};
     for (int j = 0; j < 2; ++j) if (p.length[j] > 0) cap[j] = (size_t)n_pairs * (size_t)(1 + fixed_max + 120 + 3 + 2 * (p.data_type == 2 ? a.cap : p.length[j]) + 4);
     cap[2] = cap[0] + cap[1];
     if (!a.p.has_bwa) cap[0] = cap[1] = 0;
     if (!a.p.has_bfast) cap[2] = 0;
-    (void)nreads;
     for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
+    a.counters = sl.d_counters;
     const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));
     const uint32_t nblk = (uint32_t)((n_pairs + sim_ppb - 1) / sim_ppb);
-    HIPC(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint64_t), c->stream));
+    const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
+    if (ensure(c, c->fail_summ, (nfb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
+    if (sl.fetch_in_flight) { HIPC(c, hipStreamWaitEvent(c->stream, sl.ev_fetched, 0)); sl.fetch_in_flight = false; }      // the slot's text is still being copied out
+    HIPC(c, hipMemsetAsync(sl.d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
     HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
-    HIPC(c, hipEventRecord(c->ev[0], c->stream));
-    HIPC(c, hipEventRecord(c->ev[1], c->stream));      // (the attempt loop is part of k_simulate: one kernel per batch)
+    HIPC(c, hipEventRecord(sl.ev_k0, c->stream));
     launch_simulate(c->stream, a);
-    HIPC(c, hipEventRecord(c->ev[2], c->stream));
+    HIPC(c, hipEventRecord(sl.ev_k1, c->stream));
+    launch_failrule(c->stream, a.meta, n_pairs, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    if (c->h_counters[2] & 4) { c->err = "dwgsim-hip: no fragment placement satisfied the target regions (-x) after 2^20 tries (the reference would not terminate)\n"; return DWGSIM_HIP_ERR_FAILED; }
-    if (c->h_counters[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
-    if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
-    {   // the reference's abort rule over the pairs of the contig in index order (dwgsim.c:635, :833-843), see k_failrule
-        if (first_ii == 0) kp->fail_carry = 0;
-        const uint64_t retries = c->h_counters[1], n_random_now = c->h_counters[3];
-        if (retries == 0) { if (n_random_now < n_pairs) kp->fail_carry = 0; }        // no new failure; any genomic read resets the counter
-        else {
-            const size_t nb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
-            if (ensure(c, c->fail_summ, (nb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
-            uint64_t *d_fs = (uint64_t *)c->fail_summ.p, *d_res = d_fs + nb * 4;
-            launch_failrule(c->stream, a.meta, n_pairs, kp->fail_carry, d_fs, d_res);
-            uint64_t h_res[2];
-            HIPC(c, hipMemcpyAsync(h_res, d_res, sizeof h_res, hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipStreamSynchronize(c->stream));
-            if (h_res[0]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
-            kp->fail_carry = h_res[1];
-        }
+    HIPC(c, hipMemcpyAsync(sl.h_counters, sl.d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipEventRecord(sl.ev_done, c->stream));
+    sl.pending = true;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
+{
+    if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad slot"; return DWGSIM_HIP_ERR_ARG; }
+    Slot &sl = c->slot[slot];
+    if (out) memset(out, 0, sizeof *out);
+    if (sl.empty) { sl.pending = false; return DWGSIM_HIP_OK; }
+    if (!sl.pending) { c->err = "wait: no batch was enqueued on this slot"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipEventSynchronize(sl.ev_done));
+    sl.pending = false;
+    const uint64_t *h = sl.h_counters;
+    if (h[2] & 4) { c->err = "dwgsim-hip: no fragment placement satisfied the target regions (-x) after 2^20 tries (the reference would not terminate)\n"; return DWGSIM_HIP_ERR_FAILED; }
+    if (h[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
+    if (h[2] || h[20]) {      // one pair used up its 10 001 attempts, or the counter of failed attempts over the pairs of the contig passed the limit (dwgsim.c:635, :833-843)
+        char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED;
     }
-    for (int t = 0; t < 3; ++t) c->out_bytes[slot][t] = c->h_counters[4 + t];
-    if (getenv("DWGSIM_HIP_PHASES")) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)
-        uint64_t tot = 0; for (int k = 0; k < 8; ++k) tot += c->h_counters[8 + k];
+    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = h[4 + t];
+    if (c->phases) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)
+        uint64_t tot = 0; for (int k = 0; k < 8; ++k) tot += h[8 + k];
         fprintf(stderr, "[phases]");
-        for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.1f%%", k, tot ? 100.0 * c->h_counters[8 + k] / tot : 0.0);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.1f%%", k, tot ? 100.0 * h[8 + k] / tot : 0.0);
         fprintf(stderr, " (ticks %llu)\n", (unsigned long long)tot);
     }
     if (out) {
-        out->n_pairs = n_pairs; out->n_random = c->h_counters[3]; out->n_retries = c->h_counters[1];
-        for (int t = 0; t < 3; ++t) { out->bytes[t] = c->out_bytes[slot][t]; out->dev_ptr[t] = c->out[slot][t].p; }
-        HIPC(c, hipEventElapsedTime(&out->kernel_ms, c->ev[0], c->ev[2]));
-        HIPC(c, hipEventElapsedTime(&out->sim_kernel_ms, c->ev[1], c->ev[2]));
+        out->n_pairs = sl.n_pairs; out->n_random = h[3]; out->n_retries = h[1];
+        for (int t = 0; t < 3; ++t) { out->bytes[t] = sl.out_bytes[t]; out->dev_ptr[t] = c->out[slot][t].p; }
+        for (int t = 0; t < 4; ++t) out->fail_seg[t] = h[16 + t];
+        out->fail_carry = h[21];
+        HIPC(c, hipEventElapsedTime(&out->sim_kernel_ms, sl.ev_k0, sl.ev_k1));
+        out->kernel_ms = out->sim_kernel_ms;
     }
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, int slot, dwgsim_hip_batch_t *out)
+{
+    if (out) memset(out, 0, sizeof *out);
+    const int rc = dwgsim_hip_simulate_async(c, contig, first_ii, n_pairs, rand_base, slot);
+    if (rc != DWGSIM_HIP_OK) return rc;
+    return dwgsim_hip_wait(c, slot, out);
+}
+
+void *dwgsim_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void dwgsim_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// Copies on the context's second stream: a batch that is being copied out of one slot overlaps with the kernels filling the other.
+int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)
+{
+    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) { if (c) c->err = "bad fetch arguments"; return DWGSIM_HIP_ERR_ARG; }
+    Slot &sl = c->slot[slot];
+    if (sl.pending) { c->err = "fetch: wait for the batch first (its sizes are not known yet)"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)sl.out_bytes[stream];
+    if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
+    if (n == 0) return DWGSIM_HIP_OK;
+    HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPC(c, hipEventRecord(sl.ev_fetched, c->copy_stream));
+    sl.fetch_in_flight = true;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *c, int slot)
+{
+    if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad slot"; return DWGSIM_HIP_ERR_ARG; }
+    Slot &sl = c->slot[slot];
+    if (!sl.fetch_in_flight) return DWGSIM_HIP_OK;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipEventSynchronize(sl.ev_fetched));
+    sl.fetch_in_flight = false;
     return DWGSIM_HIP_OK;
 }
 
@@ -861,14 +1005,16 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, 
 {
     if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) return DWGSIM_HIP_ERR_ARG;
     HIPC(c, hipSetDevice(c->device));
-    const size_t n = (size_t)c->out_bytes[slot][stream];
+    Slot &sl = c->slot[slot];
+    if (sl.pending) { c->err = "fetch: wait for the batch first (its sizes are not known yet)"; return DWGSIM_HIP_ERR_STATE; }
+    const size_t n = (size_t)sl.out_bytes[stream];
     if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
     if (n == 0) return DWGSIM_HIP_OK;
     {   // a pinned (page-locked / registered) destination takes one direct copy at link speed
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, host_dst) == hipSuccess && at.type == hipMemoryTypeHost) {
-            HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipStreamSynchronize(c->stream));
+            HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->copy_stream));
+            HIPC(c, hipStreamSynchronize(c->copy_stream));
             return DWGSIM_HIP_OK;
         }
         (void)hipGetLastError();      // pageable memory: the query reports an error that must not stick
@@ -880,14 +1026,27 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, 
     uint8_t *stage[2] = {(uint8_t *)c->h_stage, (uint8_t *)c->h_stage + CH};
     size_t done = 0; int b = 0;
     size_t cur = n < CH ? n : CH;
-    HIPC(c, hipMemcpyAsync(stage[0], src, cur, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(stage[0], src, cur, hipMemcpyDeviceToHost, c->copy_stream));
     while (done < n) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipStreamSynchronize(c->copy_stream));
         const size_t next_off = done + cur, next = next_off < n ? ((n - next_off) < CH ? (n - next_off) : CH) : 0;
-        if (next) HIPC(c, hipMemcpyAsync(stage[b ^ 1], src + next_off, next, hipMemcpyDeviceToHost, c->stream));
+        if (next) HIPC(c, hipMemcpyAsync(stage[b ^ 1], src + next_off, next, hipMemcpyDeviceToHost, c->copy_stream));
         memcpy((uint8_t *)host_dst + done, stage[b], cur);
         done += cur; cur = next; b ^= 1;
     }
+    return DWGSIM_HIP_OK;
+}
+
+// Test / analysis hooks (not part of the drop-in surface): "justify_seq" = 1 runs the left-justification from one thread (cross-check),
+// "walk_cap" = n starts the mutation walk with a capacity of n candidates and a 1-byte inserted-base pool (exercises the exact re-run),
+// "phases" = 1 prints the phase split of the -DDW_PHASE_TIMING analysis build.
+int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
+{
+    if (!c || !key) return DWGSIM_HIP_ERR_ARG;
+    if (!strcmp(key, "justify_seq")) c->seq_justify = value != 0;
+    else if (!strcmp(key, "walk_cap")) c->walk_cap = value;
+    else if (!strcmp(key, "phases")) c->phases = value != 0;
+    else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }
 

@@ -67,6 +67,9 @@ struct SimParams {
     int32_t dist, is_inner, len[2], max_n, strandedness, read_one_strand, amplicons, fixed_quality, data_type;
     int32_t has_bwa, has_bfast;
     uint32_t seed;
+    // lazy quality normals (dw_simulate.hip quality_pair_lazy): k = sqrt(2 ln 2) * 2^-31 * quality_std as a float, eps = the proven
+    // error bound of the fp32 estimate (quality_std * 2^-14 + 2^-18), near1 = quality_std < 12
+    float q_k, q_eps; int32_t q_near1;
 };
 
 // -B: per-base calibration of the Ion Torrent flow error (dwgsim_opt.c:415-457): n_reads random reads of `len` bases of read end `end`
@@ -87,7 +90,8 @@ inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_w
 struct SimArgs {
     SimParams p;
     ContigDev c;
-    uint64_t first_ii, n_pairs, rand_base;
+    uint64_t first_ii, n_pairs;
+    const uint64_t *chain;         // device words chained from batch to batch on the context's stream: [0] random reads emitted before this batch (rand_ii, dwgsim.c:1042,1096), [1] the abort rule's carry
     int64_t l_place;               // the `l` that sizes fragment placement: contig length, or the contig's region length with -x (dwgsim.c:552)
     const int32_t *reg_start, *reg_end; int32_t n_reg, have_regions;   // -x: this contig's merged target regions (regions_bed.c)
     const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
@@ -99,7 +103,7 @@ struct SimArgs {
     const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"
     uint32_t *meta;                // per pair: failed attempts | random read << 31 (input of the abort rule, k_failrule)
     uint32_t *block_rand;          // per 128-pair block: random pairs (k_place), then exclusive prefix (k_scan)
-    uint64_t *counters;            // [0] ticket, [1] retries, [2] fail flag, [3] total random, [4..6] stream bytes
+    uint64_t *counters;            // this batch's slot: [0] ticket, [1] retries, [2] fail flags, [3] total random, [4..6] stream bytes, [16..19] abort-rule segment of the batch, [20] abort, [21] carry out
     uint64_t *status[4];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count, (SOLiD) BFAST bytes
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
     int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)

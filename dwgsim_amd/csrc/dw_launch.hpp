@@ -20,6 +20,8 @@ void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t 
 void launch_place(hipStream_t st, const SimArgs &a);
 void launch_simulate(hipStream_t st, const SimArgs &a);
 void launch_calibrate(hipStream_t st, const CalibArgs &a);
-void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t carry_in, uint64_t *summ, uint64_t *result);
+void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t *summ, uint64_t *counters, uint64_t *chain);
+void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry);
+void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, uint64_t *out);
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism);
 }

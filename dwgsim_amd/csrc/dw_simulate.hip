@@ -170,6 +170,58 @@ DW_DEV uint32_t pair_tail_len(int32_t x0, int32_t x1, const NameCounts &n, uint6
          + ndigits10((uint32_t)n.e0) + 1 + ndigits10((uint32_t)n.u0) + 1 + ndigits10((uint32_t)n.i0) + 1
          + ndigits10((uint32_t)n.e1) + 1 + ndigits10((uint32_t)n.u1) + 1 + ndigits10((uint32_t)n.i1) + 1 + ndigits16(ii);
 }
+// ---- quality normals (dwgsim.c:156-175 ran_normal, :912): the integer offset (int)(nrm * sigma + 0.5) of two bases from one
+// Philox block = two polar tries (narrow uniforms).  EXACT form: fp64 arithmetic in the reference's evaluation order. ----
+// Returns false when both tries are rejected; k0 belongs to the first normal of the pair (v2 * fac, dwgsim.c:170), k1 to the cached one.
+DW_DEV bool quality_pair_exact(const U4 &blk, double sigma, int32_t &k0, int32_t &k1)
+{
+    // v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
+    const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
+    const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
+    const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
+    const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
+    if (!oka && !okb) return false;
+    const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
+    // rsq is a multiple of 2^-62 in (0, 1): -2 log(rsq) in [2^-52, 86], the quotient in [2^-52, 2^69] -- the range-restricted forms apply
+    const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
+    k0 = (int32_t)(((v2 * fac) * sigma) + 0.5);
+    k1 = (int32_t)(((v1 * fac) * sigma) + 0.5);
+    return true;
+}
+// LAZY form -- same results, a fraction of the work.  The only consumer of a quality normal is the truncation (int)(nrm * sigma + 0.5), so
+// an estimate y of x = nrm * sigma + 0.5 with a PROVEN bound |y - x| < eps decides the integer whenever y is further than eps from every
+// integer; only the rest (about 2 * eps of all values) takes the exact path.  The estimate is fp32: correctly rounded IEEE operations plus
+// v_log_f32 / v_rcp_f32 / v_sqrt_f32, whose errors on the operand ranges used here are established exhaustively on the device
+// (k_selftest_lazy: every float of the range).  Error budget (DESIGN.md "Lazy quality normals"): with s = w ^ 2^31 as int32 (v = s * 2^-31),
+//   R = fl(s1)^2 + fl(s2)^2 in fp32 has relative error <= 2^-22  =>  accept / reject is certain unless R lies within 2^-20 of 2^62;
+//   L' = -log2(R * 2^-62) has absolute error a <= 1.44 * 2^-22 (from R) + 2^-22 max(1, L') (v_log_f32, measured < 2^-23 (1 + L'));
+//   for L' >= 2^-10 that moves sqrt(L') by at most a / (2 sqrt L') <= 2^-16.7, i.e. nrm = v sqrt(2 ln 2 L' / r) by <= 1.1e-5 (|v| <= sqrt r);
+//   everything else is relative: v_rcp_f32 and v_sqrt_f32 (each measured < 2^-22), three multiplies, the conversions, the constant:
+//   < 2^-20.5 in all, times |nrm| <= 9.3: 6.3e-6.  So |est(nrm) - nrm| <= 1.8e-5 and |y - x| <= sigma * 1.8e-5 + the rounding of the last fma:
+//   eps = sigma * 2^-14 + 2^-18 leaves 3.4x room (k_selftest_lazy measures the largest |y - x| / eps on the device: 0.2);
+//   L' < 2^-10 means |nrm| < 0.0373: the offset is 0 without further work when sigma < 12 (|nrm * sigma| < 0.45), else the exact path runs.
+struct QualLazy { float k, eps; int32_t near1_zero; };
+DW_DEV int quality_pair_lazy(const U4 &blk, const QualLazy &ql, int32_t &k0, int32_t &k1)      // 0: both tries rejected, 1: done, 2: take the exact path
+{
+    const float xa1 = (float)(int32_t)(blk.x ^ 0x80000000u), xa2 = (float)(int32_t)(blk.y ^ 0x80000000u);
+    const float xb1 = (float)(int32_t)(blk.z ^ 0x80000000u), xb2 = (float)(int32_t)(blk.w ^ 0x80000000u);
+    const float Ra = __builtin_fmaf(xa1, xa1, xa2 * xa2), Rb = __builtin_fmaf(xb1, xb1, xb2 * xb2);     // r * 2^62
+    const float LO = 0x1p62f * (1.0f - 0x1p-20f), HI = 0x1p62f * (1.0f + 0x1p-20f);
+    const bool acc_a = Ra < LO && Ra != 0.0f, rej_a = Ra >= HI || Ra == 0.0f;        // R == 0 only for s1 = s2 = 0, which converts exactly
+    const bool acc_b = Rb < LO && Rb != 0.0f, rej_b = Rb >= HI || Rb == 0.0f;
+    if (!acc_a && !rej_a) return 2;                                                   // try a sits in the band around 1
+    if (rej_a && !acc_b) return rej_b ? 0 : 2;
+    const float x1 = acc_a ? xa1 : xb1, x2 = acc_a ? xa2 : xb2, R = acc_a ? Ra : Rb;
+    const float rt = R * 0x1p-62f;                                                    // exact scaling, in [2^-62, 1)
+    const float Lp = -__builtin_amdgcn_logf(rt);                                      // v_log_f32 (log2)
+    if (Lp < 0x1p-10f) { if (!ql.near1_zero) return 2; k0 = k1 = 0; return 1; }
+    const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
+    const float y0 = __builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = __builtin_fmaf(x1 * f, ql.k, 0.5f);
+    const float d0 = __builtin_fabsf(y0 - __builtin_rintf(y0)), d1 = __builtin_fabsf(y1 - __builtin_rintf(y1));
+    if (!(d0 >= ql.eps && d1 >= ql.eps)) return 2;                                    // (also catches an infinite eps: sigma out of the fp32 path's range)
+    k0 = (int32_t)y0; k1 = (int32_t)y1;
+    return 1;
+}
 // Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qb = base quality per position
 // (positions >= nq reuse the last entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
 template <class F>
@@ -180,27 +232,22 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
         for (int i = 0; i < n; ++i) { int32_t q = qb[i < nq ? i : nq - 1]; if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
         return;
     }
+    const QualLazy ql{p.q_k, p.q_eps, p.q_near1};
     uint32_t m = 0; int pr = 0; const int np = (n + 1) >> 1;
     while (pr < np) {
         // (the two base qualities are fetched before the arithmetic that hides their latency)
         const int i0 = 2 * pr, i1 = 2 * pr + 1;
         const int32_t qb0 = qb[i0 < nq ? i0 : nq - 1], qb1 = qb[i1 < nq ? i1 : nq - 1];
         const U4 blk = rng_block(key, dom, ii, att, m, (uint32_t)pr);
-        // two polar tries per block (narrow uniforms): v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
-        const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
-        const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
-        const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
-        const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
-        if (!oka && !okb) { ++m; continue; }
-        const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
-        // rsq is a multiple of 2^-62 in (0, 1): -2 log(rsq) in [2^-52, 86], the quotient in [2^-52, 2^69] -- the range-restricted forms apply
-        const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
+        int32_t k0 = 0, k1 = 0;
+        int st = quality_pair_lazy(blk, ql, k0, k1);
+        if (st == 2) st = quality_pair_exact(blk, p.quality_std, k0, k1) ? 1 : 0;
+        if (st == 0) { ++m; continue; }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = 2 * pr + h;
-            const double nrm = (h ? v1 : v2) * fac;       // first normal of the pair is v2*fac (dwgsim.c:170), the cached one v1*fac
             if (i < n) {
-                int32_t q = (int8_t)((h ? qb1 : qb0) + (int32_t)((nrm * p.quality_std) + 0.5));
+                int32_t q = (int8_t)((h ? qb1 : qb0) + (h ? k1 : k0));
                 if (q < 33) q = 33;
                 if (q > 73) q = 73;
                 emit(i, (uint32_t)q);
@@ -362,7 +409,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         }
     }
     __syncthreads();
-    const uint64_t rand_ii = a.rand_base + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+    const uint64_t rand_ii = a.chain[0] + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
     PH_MARK(2);     // error tests + substitutions
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
     int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
@@ -544,6 +591,70 @@ __global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n
         atomicAdd((unsigned long long *)&mism[3], (unsigned long long)s3);
     }
 }
+// Self-test of the lazy quality normals.  mode 0: n blocks drawn as the quality path draws them -- every decision of quality_pair_lazy is
+// compared with quality_pair_exact; out[0] = offsets that differ, out[1] = accept / reject verdicts that differ, out[2] = blocks the lazy form
+// decided, out[3] = blocks it handed to the exact path, out[4] = blocks, out[5] = max |y - x| / eps (double bits; estimate against the exact
+// fp64 value, over decided values).  mode 1 / 2 / 3: EVERY float of the operand range of v_log_f32 ([2^-62, 1)), v_rcp_f32 (same) and
+// v_sqrt_f32 ([2^-11, 2^70)) against fp64: out[6] = max |log2_hw - log2| / (2^-23 (1 + |log2|)), out[7], out[8] = max relative error / 2^-22.
+DW_DEV void atomic_max_pos_double(uint64_t *p, double v) { atomicMax((unsigned long long *)p, (unsigned long long)dbl_bits(v)); }
+__global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, uint64_t n, double sigma, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t bad_k = 0, bad_acc = 0, n_fast = 0, n_slow = 0, n_all = 0; double worst = 0.0;
+    if (i < n) {
+        if (mode == 0) {
+            const RngKey key{seed, 0u};
+            const U4 blk = rng_block(key, 30, i, 0, 0, 0);
+            const QualLazy ql{(float)(sqrt(2.0 * 0.693147180559945309417) * 0x1p-31 * sigma), (float)(sigma * 0x1p-14 + 0x1p-18), sigma < 12.0 ? 1 : 0};
+            int32_t k0 = 0, k1 = 0, e0 = 0, e1 = 0;
+            const int st = quality_pair_lazy(blk, ql, k0, k1);
+            const bool ok = quality_pair_exact(blk, sigma, e0, e1);
+            n_all = 1;
+            if (st == 2) n_slow = 1;
+            else {
+                n_fast = 1;
+                if ((st == 1) != ok) bad_acc = 1;
+                else if (ok) {
+                    bad_k = (k0 != e0) + (k1 != e1);
+                    // the estimate itself against the exact fp64 value (recomputed here as the lazy form computes it)
+                    const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0, b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
+                    const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
+                    const bool oka = !(ra >= 1.0 || ra == 0.0);
+                    const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
+                    const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+                    const float x1 = (float)(int32_t)((oka ? blk.x : blk.z) ^ 0x80000000u), x2 = (float)(int32_t)((oka ? blk.y : blk.w) ^ 0x80000000u);
+                    const float R = __builtin_fmaf(x1, x1, x2 * x2), rt = R * 0x1p-62f, Lp = -__builtin_amdgcn_logf(rt);
+                    if (!(Lp < 0x1p-10f)) {
+                        const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
+                        const double y0 = (double)__builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = (double)__builtin_fmaf(x1 * f, ql.k, 0.5f);
+                        const double d0 = fabs(y0 - ((v2 * fac) * sigma + 0.5)), d1 = fabs(y1 - ((v1 * fac) * sigma + 0.5));
+                        worst = (d0 > d1 ? d0 : d1) / (double)ql.eps;
+                    }
+                }
+            }
+        } else {
+            const uint32_t first = mode == 3 ? 0x3A000000u : 0x20800000u;       // 2^-11 : 2^-62
+            union { uint32_t u; float f; } c; c.u = first + (uint32_t)i;
+            const double x = (double)c.f;
+            if (mode == 1) { const double t = det_log(x) * 1.44269504088896340736; worst = fabs((double)__builtin_amdgcn_logf(c.f) - t) / (0x1p-23 * (1.0 + fabs(t))); }
+            else if (mode == 2) { const double t = 1.0 / x; worst = fabs((double)__builtin_amdgcn_rcpf(c.f) - t) / t / 0x1p-22; }
+            else { const double t = sqrt(x); worst = fabs((double)__builtin_amdgcn_sqrtf(c.f) - t) / t / 0x1p-22; }
+        }
+    }
+    const uint32_t s0 = wave_sum_u32(bad_k), s1 = wave_sum_u32(bad_acc), s2 = wave_sum_u32(n_fast), s3 = wave_sum_u32(n_slow), s4 = wave_sum_u32(n_all);
+    if ((threadIdx.x & 63) == 0) {
+        if (s0) atomicAdd((unsigned long long *)&out[0], (unsigned long long)s0);
+        if (s1) atomicAdd((unsigned long long *)&out[1], (unsigned long long)s1);
+        atomicAdd((unsigned long long *)&out[2], (unsigned long long)s2);
+        atomicAdd((unsigned long long *)&out[3], (unsigned long long)s3);
+        atomicAdd((unsigned long long *)&out[4], (unsigned long long)s4);
+    }
+    if (worst > 0.0) atomic_max_pos_double(&out[mode == 0 ? 5 : 5 + mode], worst);
+}
+void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, uint64_t *out)
+{
+    hipLaunchKernelGGL(k_selftest_lazy, dim3(cdiv(n, 256)), dim3(256), 0, st, mode, seed, n, sigma, out);
+}
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
 {
     hipLaunchKernelGGL(k_selftest_fp64, dim3(cdiv(n, 256)), dim3(256), 0, st, seed, n, mism);
@@ -565,10 +676,12 @@ DW_DEV FailSeg failseg_join(const FailSeg &a, const FailSeg &b)
     return r;
 }
 constexpr int FAIL_PAIRS_PER_THREAD = 64;
-// A: thread = 64 consecutive pairs, block = 256 threads; one FailSeg per block into summ[4 * block .. +4)
-__global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__ meta, uint64_t n_pairs, uint64_t *__restrict__ summ)
+// A: thread = 64 consecutive pairs, block = 256 threads; one FailSeg per block into summ[4 * block .. +4).  A batch without a single
+// failed attempt (counters[1] == 0, the usual case) is summarised by B from the counters alone.
+__global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__ meta, uint64_t n_pairs, const uint64_t *__restrict__ counters, uint64_t *__restrict__ summ)
 {
     __shared__ FailSeg seg[256];
+    if (counters[1] == 0) return;
     const uint64_t first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * FAIL_PAIRS_PER_THREAD;
     FailSeg s{0, 0, 0, 0};
     for (int q4 = 0; q4 < FAIL_PAIRS_PER_THREAD && first + q4 < n_pairs; q4 += 4) {       // 16-byte loads (meta is padded to a multiple of four entries)
@@ -592,30 +705,52 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
         summ[4 * (uint64_t)blockIdx.x + 2] = t.R; summ[4 * (uint64_t)blockIdx.x + 3] = t.bad;
     }
 }
-// B: the block summaries are joined in order behind the carry of the earlier batches (64 lanes stage them through LDS, lane 0 joins):
-// result[0] = abort?, result[1] = carry out
-__global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t carry_in, uint64_t *__restrict__ result)
+// B, the batch epilogue (one wave): the block summaries are joined in order (64 lanes stage them through LDS, lane 0 joins) into the
+// segment of this batch alone -> counters[16..19]; behind the carry of the earlier batches (chain[1]) that gives the verdict
+// counters[20] = abort? and the carry out counters[21] = chain[1]; the running random-read count chain[0] moves on by counters[3].
+__global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t n_pairs, uint64_t *__restrict__ counters, uint64_t *__restrict__ chain)
 {
     __shared__ uint64_t st[64 * 4];
-    FailSeg t{carry_in, carry_in, 0, 0};
-    for (uint32_t base = 0; base < n_blocks; base += 64) {
-        const uint32_t cnt = n_blocks - base < 64 ? n_blocks - base : 64;
-        for (uint32_t q = threadIdx.x; q < cnt * 4; q += 64) st[q] = summ[4 * (uint64_t)base + q];
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (uint32_t b = 0; b < cnt; ++b) t = failseg_join(t, FailSeg{st[4 * b], st[4 * b + 1], (uint32_t)st[4 * b + 2], (uint32_t)st[4 * b + 3]});
-        __syncthreads();
+    FailSeg t{0, 0, counters[3] < n_pairs ? 1u : 0u, 0};          // no failed attempt at all: any genomic read resets the counter
+    if (counters[1] != 0) {
+        for (uint32_t base = 0; base < n_blocks; base += 64) {
+            const uint32_t cnt = n_blocks - base < 64 ? n_blocks - base : 64;
+            for (uint32_t q = threadIdx.x; q < cnt * 4; q += 64) st[q] = summ[4 * (uint64_t)base + q];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (uint32_t b = 0; b < cnt; ++b) {
+                    const FailSeg nx{st[4 * b], st[4 * b + 1], (uint32_t)st[4 * b + 2], (uint32_t)st[4 * b + 3]};
+                    t = (base + b == 0) ? nx : failseg_join(t, nx);
+                }
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) {
-        result[0] = (t.bad || t.P > (uint64_t)MAX_ATTEMPTS || t.S > (uint64_t)MAX_ATTEMPTS) ? 1 : 0;
-        result[1] = t.S;
+        const uint64_t carry = chain[1];
+        const FailSeg all = failseg_join(FailSeg{carry, carry, 0, 0}, t);
+        counters[16] = t.P; counters[17] = t.S; counters[18] = t.R; counters[19] = t.bad;
+        counters[20] = (all.bad || all.P > (uint64_t)MAX_ATTEMPTS || all.S > (uint64_t)MAX_ATTEMPTS) ? 1 : 0;
+        counters[21] = all.S;
+        chain[1] = all.S;
+        chain[0] += counters[3];
     }
 }
-void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t carry_in, uint64_t *summ, uint64_t *result)
+void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t *summ, uint64_t *counters, uint64_t *chain)
 {
     const uint32_t nb = cdiv(n_pairs, 256ull * FAIL_PAIRS_PER_THREAD);
-    hipLaunchKernelGGL(k_failrule_a, dim3(nb), dim3(256), 0, st, meta, n_pairs, summ);
-    hipLaunchKernelGGL(k_failrule_b, dim3(1), dim3(64), 0, st, summ, nb, carry_in, result);
+    hipLaunchKernelGGL(k_failrule_a, dim3(nb), dim3(256), 0, st, meta, n_pairs, counters, summ);
+    hipLaunchKernelGGL(k_failrule_b, dim3(1), dim3(64), 0, st, summ, nb, n_pairs, counters, chain);
+}
+// chain[0] (random reads before the next batch) and / or chain[1] (the abort rule's carry) set in stream order
+__global__ void __launch_bounds__(64) k_chain_set(uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry)
+{
+    if (threadIdx.x != 0) return;
+    if (set_rand) chain[0] = rand_base;
+    if (set_carry) chain[1] = carry;
+}
+void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry)
+{
+    hipLaunchKernelGGL(k_chain_set, dim3(1), dim3(64), 0, st, chain, rand_base, set_rand, carry, set_carry);
 }
 void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ)
 {

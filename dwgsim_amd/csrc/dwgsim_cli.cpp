@@ -5,6 +5,17 @@
 //     <prefix>.mutations.txt / .mutations.vcf / .bfast.fastq.gz / .bwa.read1.fastq.gz / .bwa.read2.fastq.gz
 // Host-only work here: option parsing, FASTA reading (mut.c:49-87), contig scheduling, file I/O and
 // gzip (multi-member gzip: the reference's own test compares decompressed bytes, testdata/test.sh:23-25).
+//
+// Three overlapped stages replace the reference's gzprintf / gzputc stream (dwgsim.c:919-981):
+//     GPU kernels (batch k)  |  device -> pinned host copy (batch k-1)  |  deflate + ordered write (batches <= k-2)
+// and one or more GPUs work on disjoint read-index ranges of every contig (host threads, one context per device; the
+// only cross-device quantities are two integers per range: the random-read count that offsets rand_ii, dwgsim.c:1042,1096,
+// and the abort rule's failure counter, dwgsim.c:635).  Environment (all optional):
+//     DWGSIM_HIP_DEVICES   "0,1,2,3" or a count "4" (default: device DWGSIM_HIP_DEVICE or 0)
+//     DWGSIM_HIP_THREADS   deflate threads (default: all host cores)
+//     DWGSIM_HIP_GZIP_LEVEL  zlib level 0..9 (default 1: the text is produced ~1000x faster than zlib -6 packs it)
+//     DWGSIM_HIP_BATCH     read pairs per GPU batch (default 2^20)
+//     DWGSIM_HIP_MIN_SHARE a contig is spread over fewer devices while a device's share would be below this many pairs (default 65536)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,7 +27,13 @@
 #include <zlib.h>
 #include <string>
 #include <vector>
+#include <deque>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include <memory>
+#include <functional>
 #include "../../include/dwgsim_hip.h"
 
 #define PACKAGE_VERSION "0.1.17-hip"
@@ -70,78 +87,213 @@ static int xatoi(const char *a, char flag, int neg_ok)                     // dw
 
 struct Fasta { std::vector<std::string> names; std::vector<std::vector<uint8_t>> seqs; };
 
-static bool read_fasta(const char *fn, Fasta &fa)     // mut.c:49-87 seq_read_fasta
+// mut.c:49-87 seq_read_fasta: the name is the header up to the first blank, the sequence keeps isalpha, '-' and '.'; a '>' opens a new
+// record wherever it stands.  Whole lines of plain letters (the usual case) are appended with one copy.
+static bool read_fasta(const char *fn, Fasta &fa)
 {
     FILE *fp = strcmp(fn, "-") ? fopen(fn, "r") : stdin;
     if (!fp) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn); return false; }
-    std::vector<char> buf(1 << 22);
+    std::vector<char> buf((size_t)1 << 24);
     std::string name; std::vector<uint8_t> seq; int state = 0;   // 0 before first '>', 1 in name, 2 rest of header line, 3 sequence
     bool have = false;
+    static bool keep[256], init = false;
+    if (!init) { for (int c = 0; c < 256; ++c) keep[c] = isalpha(c) || c == '-' || c == '.'; init = true; }
     size_t n;
     while ((n = fread(buf.data(), 1, buf.size(), fp)) > 0) {
-        for (size_t i = 0; i < n; ++i) {
+        size_t i = 0;
+        while (i < n) {
             const int c = (unsigned char)buf[i];
+            if (state == 3) {
+                // the run of sequence characters from here
+                size_t j = i;
+                while (j < n && keep[(unsigned char)buf[j]]) ++j;
+                if (j > i) { seq.insert(seq.end(), (const uint8_t *)buf.data() + i, (const uint8_t *)buf.data() + j); i = j; continue; }
+                if (c == '>') { fa.names.push_back(name); fa.seqs.emplace_back(std::move(seq)); seq = std::vector<uint8_t>(); state = 1; name.clear(); }
+                ++i;
+                continue;
+            }
             if (state == 0) { if (c == '>') { state = 1; name.clear(); seq.clear(); have = true; } }
             else if (state == 1) { if (c == ' ' || c == '\t') state = 2; else if (c == '\n') state = 3; else if (c != '\r') name.push_back((char)c); }
             else if (state == 2) { if (c == '\n') state = 3; }
-            else {
-                if (c == '>') { fa.names.push_back(name); fa.seqs.push_back(seq); state = 1; name.clear(); seq.clear(); }
-                else if (isalpha(c) || c == '-' || c == '.') seq.push_back((uint8_t)c);
-            }
+            ++i;
         }
     }
-    if (have) { fa.names.push_back(name); fa.seqs.push_back(seq); }
+    if (have) { fa.names.push_back(name); fa.seqs.emplace_back(std::move(seq)); }
     if (fp != stdin) fclose(fp);
     return true;
 }
 
-// gzip writer: every batch of FASTQ text is cut into 4 MiB chunks, each chunk is deflated as an independent
-// gzip member by a pool of host threads, and the members are written in order.  A multi-member .gz
-// decompresses to exactly the concatenated text (the reference's own test compares decompressed bytes,
-// testdata/test.sh:23-25); the reference itself feeds zlib one byte at a time (dwgsim.c:930-931), which
-// is ~80 % of its wall time.
-struct GzOut {
-    FILE *f = nullptr;
-    bool open(const std::string &fn) { f = fopen(fn.c_str(), "wb"); return f != nullptr; }
-    static bool deflate_member(const char *src, size_t n, std::vector<unsigned char> &out)
-    {
-        z_stream zs; memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        out.resize(deflateBound(&zs, (uLong)n) + 64);
-        zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n; zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
-        const int rc = deflate(&zs, Z_FINISH);
-        out.resize(zs.total_out);
-        deflateEnd(&zs);
-        return rc == Z_STREAM_END;
-    }
-    bool write(const char *p, size_t n, unsigned nthreads)
-    {
-        const size_t CH = (size_t)4 << 20;
-        const size_t nch = (n + CH - 1) / CH;
-        std::vector<std::vector<unsigned char>> parts(nch);
-        std::vector<char> ok(nch, 1);
-        if (nthreads < 1) nthreads = 1;
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nthreads && t < nch; ++t)
-            th.emplace_back([&, t]() { for (size_t k = t; k < nch; k += nthreads) ok[k] = deflate_member(p + k * CH, (k + 1) * CH <= n ? CH : n - k * CH, parts[k]) ? 1 : 0; });
-        for (auto &x : th) x.join();
-        for (size_t k = 0; k < nch; ++k) { if (!ok[k]) return false; if (fwrite(parts[k].data(), 1, parts[k].size(), f) != parts[k].size()) return false; }
-        return true;
-    }
-    void close()
-    {
-        if (!f) return;
-        if (ftell(f) == 0) { std::vector<unsigned char> e; deflate_member("", 0, e); fwrite(e.data(), 1, e.size(), f); }   // empty stream: still a valid .gz
-        fclose(f); f = nullptr;
-    }
+// ------------------------------------------------------------------------------------------------
+// Output stage: text blocks -> independent gzip members (all host cores) -> files, in order.
+// A multi-member .gz decompresses to exactly the concatenated text (the reference's own test compares decompressed bytes,
+// testdata/test.sh:23-25); the reference itself feeds zlib one byte at a time (dwgsim.c:930-931), ~80 % of its wall time.
+// ------------------------------------------------------------------------------------------------
+static bool deflate_member(const char *src, size_t n, int level, std::vector<unsigned char> &out)
+{
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, (uLong)n) + 64);
+    zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n; zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
+
+// One pinned host buffer set: the text of one GPU batch (up to three streams).  `left` counts the deflate chunks still reading it.
+struct TextBuf {
+    char *p[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    std::atomic<int> left{0};
 };
+
+struct Chunk {             // one gzip member in flight
+    int stream = 0; const char *src = nullptr; size_t n = 0; TextBuf *owner = nullptr;
+    std::vector<unsigned char> gz; bool done = false, ok = true;
+};
+
+class Output {
+public:
+    // lanes: ordered producers (one per device); the writer drains lane 0 of a contig completely, then lane 1, ...
+    Output(FILE *f0, FILE *f1, FILE *f2, int n_lanes, unsigned n_threads, int level, int bufs_per_lane)
+        : level_(level), lanes_((size_t)n_lanes)
+    {
+        f_[0] = f0; f_[1] = f1; f_[2] = f2;
+        for (int l = 0; l < n_lanes; ++l)
+            for (int b = 0; b < bufs_per_lane; ++b) {
+                bufs_.push_back(std::make_unique<TextBuf>());
+                lanes_[(size_t)l].free_bufs.push_back(bufs_.back().get());
+            }
+        for (unsigned t = 0; t < (n_threads ? n_threads : 1); ++t) workers_.emplace_back([this]() { work(); });
+        writer_ = std::thread([this]() { write_loop(); });
+    }
+    ~Output() { finish(); for (auto &b : bufs_) for (int s = 0; s < 3; ++s) dwgsim_hip_host_free(b->p[s]); }
+    bool failed() const { return failed_; }
+    // a free buffer set of this lane with room for need[s] bytes per stream (blocks while all of them are still being deflated:
+    // back-pressure on the GPU stage).  Page-locked memory is sized by what the batches really produce, so small jobs pin little.
+    TextBuf *acquire(int lane, const uint64_t need[3])
+    {
+        TextBuf *b = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            Lane &L = lanes_[(size_t)lane];
+            cv_buf_.wait(lk, [&]() { return !L.free_bufs.empty() || failed_; });
+            if (L.free_bufs.empty()) return nullptr;
+            b = L.free_bufs.back(); L.free_bufs.pop_back();
+        }
+        for (int s = 0; s < 3; ++s) if (need[s] > b->cap[s]) {
+            dwgsim_hip_host_free(b->p[s]);
+            b->cap[s] = (size_t)need[s] + (size_t)need[s] / 8 + 4096;
+            b->p[s] = (char *)dwgsim_hip_host_alloc(b->cap[s]);
+            if (!b->p[s]) { fprintf(stderr, "dwgsim-hip: cannot allocate %zu bytes of page-locked host memory\n", b->cap[s]); b->cap[s] = 0; failed_ = true; return nullptr; }
+        }
+        return b;
+    }
+    // the text in `b` (b->n[s] bytes per stream) is the next output of this lane
+    void submit(int lane, TextBuf *b)
+    {
+        const size_t CH = (size_t)1 << 20;
+        std::vector<std::shared_ptr<Chunk>> cs;
+        for (int s = 0; s < 3; ++s)
+            for (size_t off = 0; off < b->n[s]; off += CH) {
+                auto c = std::make_shared<Chunk>();
+                c->stream = s; c->src = b->p[s] + off; c->n = b->n[s] - off < CH ? b->n[s] - off : CH; c->owner = b;
+                cs.push_back(std::move(c));
+            }
+        std::unique_lock<std::mutex> lk(m_);
+        if (cs.empty()) { lanes_[(size_t)lane].free_bufs.push_back(b); cv_buf_.notify_all(); return; }
+        b->left.store((int)cs.size());
+        b_lane_[b] = lane;
+        for (auto &c : cs) { lanes_[(size_t)lane].q.push_back(c); todo_.push_back(c); }
+        cv_work_.notify_all(); cv_write_.notify_all();
+    }
+    // this lane has nothing more for the current contig (the writer moves on to the next lane)
+    void end_lane(int lane) { std::unique_lock<std::mutex> lk(m_); lanes_[(size_t)lane].ends += 1; cv_write_.notify_all(); }
+    void finish()
+    {
+        { std::unique_lock<std::mutex> lk(m_); if (stop_) return; stop_ = true; cv_work_.notify_all(); cv_write_.notify_all(); }
+        writer_.join();
+        for (auto &w : workers_) w.join();
+    }
+    uint64_t bytes_in() const { return bytes_in_; }
+    uint64_t bytes_out() const { return bytes_out_; }
+
+private:
+    struct Lane { std::deque<std::shared_ptr<Chunk>> q; std::vector<TextBuf *> free_bufs; int ends = 0; };
+    void work()
+    {
+        for (;;) {
+            std::shared_ptr<Chunk> c;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [&]() { return !todo_.empty() || stop_; });
+                if (todo_.empty()) return;
+                c = todo_.front(); todo_.pop_front();
+            }
+            const bool ok = deflate_member(c->src, c->n, level_, c->gz);
+            std::unique_lock<std::mutex> lk(m_);
+            c->ok = ok; c->done = true;
+            if (c->owner->left.fetch_sub(1) == 1) { lanes_[(size_t)b_lane_[c->owner]].free_bufs.push_back(c->owner); cv_buf_.notify_all(); }
+            cv_write_.notify_all();
+        }
+    }
+    void write_loop()
+    {
+        size_t lane = 0;                           // lanes are drained in order, contig after contig
+        std::vector<int> consumed_ends(lanes_.size(), 0);
+        for (;;) {
+            std::shared_ptr<Chunk> c;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                for (;;) {
+                    Lane &L = lanes_[lane];
+                    if (!L.q.empty()) { if (L.q.front()->done) { c = L.q.front(); L.q.pop_front(); break; } }
+                    else if (L.ends > consumed_ends[lane]) { consumed_ends[lane] += 1; lane = (lane + 1) % lanes_.size(); continue; }
+                    else if (stop_) {              // shutting down (possibly after an error that left a lane without its end mark): drain what there is
+                        bool any = false; for (auto &x : lanes_) if (!x.q.empty()) any = true;
+                        if (!any) return;
+                        lane = (lane + 1) % lanes_.size(); continue;
+                    }
+                    cv_write_.wait(lk);
+                }
+            }
+            if (!c->ok || fwrite(c->gz.data(), 1, c->gz.size(), f_[c->stream]) != c->gz.size()) { std::unique_lock<std::mutex> lk(m_); failed_ = true; cv_buf_.notify_all(); }
+            bytes_in_ += c->n; bytes_out_ += c->gz.size();
+        }
+    }
+    FILE *f_[3]; int level_;
+    std::mutex m_; std::condition_variable cv_work_, cv_write_, cv_buf_;
+    std::vector<Lane> lanes_; std::deque<std::shared_ptr<Chunk>> todo_;
+    std::vector<std::unique_ptr<TextBuf>> bufs_;
+    std::vector<std::thread> workers_; std::thread writer_;
+    struct PtrMap {              // TextBuf -> lane (a handful of entries)
+        std::vector<std::pair<TextBuf *, int>> v;
+        int &operator[](TextBuf *b) { for (auto &e : v) if (e.first == b) return e.second; v.emplace_back(b, 0); return v.back().second; }
+    } b_lane_;
+    bool stop_ = false; std::atomic<bool> failed_{false};
+    std::atomic<uint64_t> bytes_in_{0}, bytes_out_{0};
+};
+
+static void close_gz(FILE *f, int level)
+{
+    if (!f) return;
+    if (ftell(f) == 0) { std::vector<unsigned char> e; deflate_member("", 0, level, e); fwrite(e.data(), 1, e.size(), f); }   // empty stream: still a valid .gz
+    fclose(f);
+}
+
+// run fn(d) for d = 0 .. n-1 on n host threads (one per device) and wait
+static void on_all(int n, const std::function<void(int)> &fn)
+{
+    if (n == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int d = 0; d < n; ++d) th.emplace_back(fn, d);
+    for (auto &t : th) t.join();
+}
 
 int main(int argc, char **argv)
 {
     dwgsim_hip_params_t o; dwgsim_hip_params_default(&o);
     std::string prefix_s, fixedq_s, flow_s, regions_fn, muts_fn; int muts_type = -1, muts_flags = 0;
-    int c, device = 0;
-    if (const char *d = getenv("DWGSIM_HIP_DEVICE")) device = atoi(d);
+    int c;
     while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
         switch (c) {
         case 'i': o.is_inner = 1; break;
@@ -190,6 +342,23 @@ int main(int argc, char **argv)
     if (dwgsim_hip_params_check(&o, msg, sizeof msg) != DWGSIM_HIP_OK) { fprintf(stderr, "%s", msg); return usage(&o); }
     if (o.output_type == 1) fprintf(stderr, "[dwgsim_core] note: the reference dereferences a NULL VCF handle with -M 1; dwgsim-hip simply writes no mutation files\n");
 
+    // devices
+    std::vector<int> devs;
+    if (const char *e = getenv("DWGSIM_HIP_DEVICES")) {
+        if (strchr(e, ',')) { for (const char *q = e; *q;) { devs.push_back(atoi(q)); const char *k = strchr(q, ','); if (!k) break; q = k + 1; } }
+        else { const int n = atoi(e); for (int d = 0; d < n; ++d) devs.push_back(d); }
+    }
+    if (devs.empty()) devs.push_back(getenv("DWGSIM_HIP_DEVICE") ? atoi(getenv("DWGSIM_HIP_DEVICE")) : 0);
+    const int ND = (int)devs.size();
+    unsigned nthreads = std::thread::hardware_concurrency(); if (nthreads == 0) nthreads = 4;
+    if (const char *e = getenv("DWGSIM_HIP_THREADS")) nthreads = (unsigned)atoi(e);
+    int gz_level = 1;
+    if (const char *e = getenv("DWGSIM_HIP_GZIP_LEVEL")) { gz_level = atoi(e); if (gz_level < 0 || gz_level > 9) gz_level = 1; }
+    uint64_t min_share = 65536;
+    if (const char *e = getenv("DWGSIM_HIP_MIN_SHARE")) min_share = (uint64_t)atoll(e);       // (tests: force tiny contigs onto several devices)
+    uint64_t BATCH = 1u << 20;
+    if (const char *e = getenv("DWGSIM_HIP_BATCH")) { const long long v = atoll(e); if (v > 0) BATCH = (uint64_t)v; }
+
     const char *fn_fa = argv[optind], *out_prefix = argv[optind + 1];
     Fasta fa;
     if (!read_fasta(fn_fa, fa)) return 1;
@@ -199,7 +368,7 @@ int main(int argc, char **argv)
 
     const bool want_mut = o.output_type != 1, want_reads = o.output_type != 2;
     const bool has_bfast = want_reads && o.reads_output_type != 1, has_bwa = want_reads && o.reads_output_type != 2;
-    FILE *fp_txt = nullptr, *fp_vcf = nullptr; GzOut gz[3];
+    FILE *fp_txt = nullptr, *fp_vcf = nullptr, *fgz[3] = {nullptr, nullptr, nullptr};
     std::string p = out_prefix;
     if (want_mut) {
         fp_txt = fopen((p + ".mutations.txt").c_str(), "w"); fp_vcf = fopen((p + ".mutations.vcf").c_str(), "w");
@@ -211,27 +380,39 @@ int main(int argc, char **argv)
                         "##INFO=<ID=mt,Number=1,Type=String,Description=\"Variant Type: SUBSTITUTE/INSERT/DELETE\">\n"
                         "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
     }
-    if (has_bwa && (!gz[0].open(p + ".bwa.read1.fastq.gz") || !gz[1].open(p + ".bwa.read2.fastq.gz"))) { fprintf(stderr, "fail to open FASTQ outputs\n"); return 1; }
-    if (has_bfast && !gz[2].open(p + ".bfast.fastq.gz")) { fprintf(stderr, "fail to open FASTQ outputs\n"); return 1; }
+    if (has_bwa) { fgz[0] = fopen((p + ".bwa.read1.fastq.gz").c_str(), "wb"); fgz[1] = fopen((p + ".bwa.read2.fastq.gz").c_str(), "wb"); if (!fgz[0] || !fgz[1]) { fprintf(stderr, "fail to open FASTQ outputs\n"); return 1; } }
+    if (has_bfast) { fgz[2] = fopen((p + ".bfast.fastq.gz").c_str(), "wb"); if (!fgz[2]) { fprintf(stderr, "fail to open FASTQ outputs\n"); return 1; } }
 
-    int err = 0;
-    dwgsim_hip_ctx_t *ctx = dwgsim_hip_create(&o, device, &err);
-    if (!ctx) { fprintf(stderr, "dwgsim-hip: cannot create a GPU context (error %d)\n", err); return 1; }
-    if (!regions_fn.empty()) {   // dwgsim.c:499-506
-        std::vector<const char *> nm; std::vector<int64_t> ln;
-        for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
-        if (dwgsim_hip_set_regions(ctx, regions_fn.c_str(), nm.data(), ln.data(), (int)nm.size(), &tot_len) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx)); dwgsim_hip_destroy(ctx); return 1; }
+    // one context per device
+    std::vector<dwgsim_hip_ctx_t *> ctx((size_t)ND, nullptr);
+    std::vector<const char *> nm; std::vector<int64_t> ln;
+    for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
+    auto destroy_all = [&]() { for (auto *x : ctx) if (x) dwgsim_hip_destroy(x); };
+    for (int d = 0; d < ND; ++d) {
+        int err = 0;
+        ctx[(size_t)d] = dwgsim_hip_create(&o, devs[(size_t)d], &err);
+        if (!ctx[(size_t)d]) { fprintf(stderr, "dwgsim-hip: cannot create a GPU context on device %d (error %d)\n", devs[(size_t)d], err); destroy_all(); return 1; }
+        if (!regions_fn.empty()) {   // dwgsim.c:499-506
+            uint64_t tl = 0;
+            if (dwgsim_hip_set_regions(ctx[(size_t)d], regions_fn.c_str(), nm.data(), ln.data(), (int)nm.size(), &tl) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx[(size_t)d])); destroy_all(); return 1; }
+            tot_len = tl;
+        }
+        if (muts_type >= 0 && dwgsim_hip_set_mutation_input(ctx[(size_t)d], muts_type, muts_fn.c_str(), nm.data(), ln.data(), (int)nm.size()) < 0) {     // dwgsim.c:494-497
+            fprintf(stderr, "%s", dwgsim_hip_last_error(ctx[(size_t)d])); destroy_all(); return 1;
+        }
     }
-    if (muts_type >= 0) {     // dwgsim.c:494-497
-        std::vector<const char *> nm; std::vector<int64_t> ln;
-        for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
-        if (dwgsim_hip_set_mutation_input(ctx, muts_type, muts_fn.c_str(), nm.data(), ln.data(), (int)nm.size()) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx)); dwgsim_hip_destroy(ctx); return 1; }
+
+    // host side of the output pipeline: per device three page-locked buffer sets sized for one batch
+    std::unique_ptr<Output> out;
+    if (want_reads) {
+        out = std::make_unique<Output>(fgz[0], fgz[1], fgz[2], ND, nthreads, gz_level, 3);
+        if (out->failed()) { destroy_all(); return 1; }
     }
-    const uint64_t BATCH = 1u << 22;
-    unsigned nthreads = std::thread::hardware_concurrency(); if (nthreads == 0) nthreads = 4;
-    if (const char *e = getenv("DWGSIM_HIP_THREADS")) nthreads = (unsigned)atoi(e);
-    std::vector<char> host[3];
-    int64_t n_sim = 0; uint64_t rand_ii = 0, ctr = 0; int n_ref = (int)fa.seqs.size(), prev_skip = 0, rc = 0;
+
+    int64_t n_sim = 0; uint64_t rand_ii = 0, ctr = 0; int n_ref = (int)fa.seqs.size(), prev_skip = 0;
+    std::atomic<int> rc{0};
+    std::mutex err_m;
+    auto fail = [&](const char *what) { std::lock_guard<std::mutex> g(err_m); if (rc.exchange(1) == 0) fprintf(stderr, "%s%s", what, (what[0] && what[strlen(what) - 1] != '\n') ? "\n" : ""); };
     for (size_t ci = 0; ci < fa.seqs.size() && rc == 0; ++ci) {
         const int64_t l = (int64_t)fa.seqs[ci].size(); const char *name = fa.names[ci].c_str();
         --n_ref;
@@ -239,7 +420,7 @@ int main(int argc, char **argv)
         if (want_reads) {
             const bool last_takes_rest = n_ref == 0 && o.C < 0;     // dwgsim.c:535-537
             if (!regions_fn.empty() && !last_takes_rest) {
-                l_eff = dwgsim_hip_contig_region_length(ctx, (uint32_t)ci, fa.seqs[ci].data(), l);
+                l_eff = dwgsim_hip_contig_region_length(ctx[0], (uint32_t)ci, fa.seqs[ci].data(), l);
                 if (l_eff == -10) { fprintf(stderr, "[dwgsim_core] #0 skip sequence '%s' as it is not in the targeted region\n", name); continue; }
                 if (l_eff == -11) { fprintf(stderr, "[dwgsim_core] #1 skip sequence '%s' as more than 95%% of its targeted bases are non-ACGT\n", name); continue; }
             }
@@ -255,33 +436,85 @@ int main(int argc, char **argv)
             }
             prev_skip = 0;
         }
-        const int cid = dwgsim_hip_add_contig(ctx, name, fa.seqs[ci].data(), l, (uint32_t)ci);
-        if (cid >= 0 && !regions_fn.empty()) dwgsim_hip_contig_set_placement_length(ctx, cid, l_eff);
-        if (cid < 0 || dwgsim_hip_mutate_contig(ctx, cid) < 0) { fprintf(stderr, "dwgsim-hip: %s\n", dwgsim_hip_last_error(ctx)); rc = 1; break; }
-        if (want_mut) {
+        // devices that take part in this contig: a share of less than 2^16 pairs per device is not worth a second copy of the contig
+        int nd = ND;
+        while (nd > 1 && (uint64_t)n_pairs / (uint64_t)nd < min_share) --nd;
+        std::vector<int> cid((size_t)nd, -1);
+        on_all(nd, [&](int d) {
+            dwgsim_hip_ctx_t *x = ctx[(size_t)d];
+            cid[(size_t)d] = dwgsim_hip_add_contig(x, name, fa.seqs[ci].data(), l, (uint32_t)ci);
+            if (cid[(size_t)d] >= 0 && !regions_fn.empty()) dwgsim_hip_contig_set_placement_length(x, cid[(size_t)d], l_eff);
+            if (cid[(size_t)d] < 0 || dwgsim_hip_mutate_contig(x, cid[(size_t)d]) < 0) fail((std::string("dwgsim-hip: ") + dwgsim_hip_last_error(x)).c_str());
+        });
+        if (rc == 0 && want_mut) {
             const char *t, *v; size_t tl, vl;
-            if (dwgsim_hip_mutations_text(ctx, cid, &t, &tl, &v, &vl) < 0) { fprintf(stderr, "dwgsim-hip: %s\n", dwgsim_hip_last_error(ctx)); rc = 1; break; }
-            fwrite(t, 1, tl, fp_txt); fwrite(v, 1, vl, fp_vcf);
+            if (dwgsim_hip_mutations_text(ctx[0], cid[0], &t, &tl, &v, &vl) < 0) fail((std::string("dwgsim-hip: ") + dwgsim_hip_last_error(ctx[0])).c_str());
+            else { fwrite(t, 1, tl, fp_txt); fwrite(v, 1, vl, fp_vcf); }
         }
-        for (uint64_t first = 0; want_reads && first < (uint64_t)n_pairs; first += BATCH) {
-            const uint64_t n = (uint64_t)n_pairs - first < BATCH ? (uint64_t)n_pairs - first : BATCH;
-            dwgsim_hip_batch_t b;
-            if (dwgsim_hip_simulate(ctx, cid, first, n, rand_ii, 0, &b) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx)); rc = 1; break; }
-            for (int s = 0; s < 3; ++s) if (b.bytes[s]) {
-                host[s].resize(b.bytes[s]);
-                if (dwgsim_hip_fetch(ctx, 0, s, host[s].data(), host[s].size()) < 0) { fprintf(stderr, "dwgsim-hip: %s\n", dwgsim_hip_last_error(ctx)); rc = 1; break; }
+        if (rc == 0 && want_reads) {
+            // read-index ranges, in order; rand_ii offsets from one integer per range (dwgsim.c:1042,1096)
+            std::vector<uint64_t> first((size_t)nd), cnt((size_t)nd), rnd((size_t)nd, 0), rbase((size_t)nd, rand_ii);
+            for (int d = 0; d < nd; ++d) dwgsim_hip_shard_range((uint64_t)n_pairs, d, nd, &first[(size_t)d], &cnt[(size_t)d]);
+            if (nd > 1) {
+                on_all(nd - 1, [&](int d) { if (dwgsim_hip_count_random(ctx[(size_t)d], cid[(size_t)d], first[(size_t)d], cnt[(size_t)d], &rnd[(size_t)d]) < 0) fail(dwgsim_hip_last_error(ctx[(size_t)d])); });
+                for (int d = 1; d < nd; ++d) rbase[(size_t)d] = rbase[(size_t)d - 1] + rnd[(size_t)d - 1];
             }
-            // deflate with all host cores (independent gzip members), write in stream order
-            for (int s = 0; s < 3; ++s) if (b.bytes[s] && gz[s].f && !gz[s].write(host[s].data(), host[s].size(), nthreads)) { fprintf(stderr, "dwgsim-hip: writing FASTQ failed\n"); rc = 1; break; }
-            rand_ii += b.n_random; n_sim += (int64_t)n; ctr += n;
+            // per range: the abort-rule summaries of its batches (joined across ranges below) and its random reads
+            std::vector<std::vector<uint64_t>> segs((size_t)nd);
+            std::vector<uint64_t> got_rand((size_t)nd, 0);
+            std::atomic<uint64_t> progress{ctr};
+            on_all(nd, [&](int d) {
+                dwgsim_hip_ctx_t *x = ctx[(size_t)d];
+                const uint64_t f0 = first[(size_t)d], n_all = cnt[(size_t)d];
+                struct Pending { bool live = false; int slot = 0; uint64_t n = 0; } prev;
+                auto finish_batch = [&](Pending &pb) {       // wait for the kernels, start and await the copies, hand the text to the deflate stage
+                    if (!pb.live) return;
+                    pb.live = false;
+                    dwgsim_hip_batch_t b;
+                    if (dwgsim_hip_wait(x, pb.slot, &b) < 0) { fail(dwgsim_hip_last_error(x)); return; }
+                    for (int q = 0; q < 4; ++q) segs[(size_t)d].push_back(b.fail_seg[q]);
+                    got_rand[(size_t)d] += b.n_random;
+                    TextBuf *tb = out->acquire(d, b.bytes);
+                    if (!tb) { fail("dwgsim-hip: writing FASTQ failed"); return; }
+                    for (int s = 0; s < 3; ++s) {
+                        tb->n[s] = b.bytes[s];
+                        if (b.bytes[s] && dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s]) < 0) { fail(dwgsim_hip_last_error(x)); tb->n[0] = tb->n[1] = tb->n[2] = 0; out->submit(d, tb); return; }
+                    }
+                    if (dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail(dwgsim_hip_last_error(x)); tb->n[0] = tb->n[1] = tb->n[2] = 0; }
+                    out->submit(d, tb);
+                    const uint64_t done = progress.fetch_add(pb.n) + pb.n;
+                    if (d == 0) fprintf(stderr, "\r[dwgsim_core] %llu", (unsigned long long)done);
+                };
+                int k = 0;
+                for (uint64_t off = 0; off < n_all && rc == 0; off += BATCH, ++k) {
+                    const uint64_t n = n_all - off < BATCH ? n_all - off : BATCH;
+                    const int slot = k & 1;
+                    if (dwgsim_hip_simulate_async(x, cid[(size_t)d], f0 + off, n, k == 0 ? rbase[(size_t)d] : DWGSIM_HIP_RAND_CHAIN, slot) < 0) { fail(dwgsim_hip_last_error(x)); break; }
+                    finish_batch(prev);                  // batch k-1 is copied out while batch k runs
+                    prev.live = true; prev.slot = slot; prev.n = n;
+                }
+                if (rc == 0) finish_batch(prev);
+                else if (prev.live) { dwgsim_hip_batch_t b; (void)dwgsim_hip_wait(x, prev.slot, &b); }
+                out->end_lane(d);
+            });
+            for (int d = nd; d < ND; ++d) out->end_lane(d);      // lanes that sat this contig out
+            // the reference's failure counter over the whole contig, ranges joined in read-index order (dwgsim.c:635, :833-843)
+            uint64_t acc[4] = {0, 0, 0, 0}; bool aborted = false;
+            for (int d = 0; d < nd && !aborted; ++d)
+                for (size_t q = 0; q + 4 <= segs[(size_t)d].size(); q += 4) if (dwgsim_hip_failseg_join(acc, &segs[(size_t)d][q])) { aborted = true; break; }
+            if (aborted && rc == 0) fail("\r[dwgsim_core] failed to generate a read after 10001 trials\n");
+            for (int d = 0; d < nd; ++d) rand_ii += got_rand[(size_t)d];
+            n_sim += n_pairs; ctr += (uint64_t)n_pairs;
             fprintf(stderr, "\r[dwgsim_core] %llu", (unsigned long long)ctr);
         }
-        dwgsim_hip_drop_contig(ctx, cid);
+        for (int d = 0; d < nd; ++d) if (cid[(size_t)d] >= 0) dwgsim_hip_drop_contig(ctx[(size_t)d], cid[(size_t)d]);
     }
+    if (out) { out->finish(); if (out->failed() && rc == 0) { fprintf(stderr, "dwgsim-hip: writing FASTQ failed\n"); rc = 1; } }
     fprintf(stderr, "\n[dwgsim_core] Complete!\n");
-    dwgsim_hip_destroy(ctx);
+    destroy_all();
+    out.reset();
     if (fp_txt) fclose(fp_txt);
     if (fp_vcf) fclose(fp_vcf);
-    for (int s = 0; s < 3; ++s) gz[s].close();
-    return rc;
+    for (int s = 0; s < 3; ++s) close_gz(fgz[s], gz_level);
+    return rc.load();
 }

@@ -20,13 +20,38 @@ def _splitmix64(n: int, seed: int) -> np.ndarray:
     return z
 
 
+_LUT4 = None
+
+
+def _lut4() -> np.ndarray:
+    """byte (four 2-bit codes, lowest bits first) -> the four ASCII bases as one little-endian uint32"""
+    global _LUT4
+    if _LUT4 is None:
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8).astype(np.uint32)
+        b = np.arange(256, dtype=np.uint32)
+        _LUT4 = acgt[b & 3] | (acgt[(b >> 2) & 3] << 8) | (acgt[(b >> 4) & 3] << 16) | (acgt[(b >> 6) & 3] << 24)
+    return _LUT4
+
+
 def random_contig(length: int, seed: int, n_runs=()) -> np.ndarray:
-    """uint8 ASCII array of `length` bases; n_runs = iterable of (start, end) half-open N blocks."""
+    """uint8 ASCII array of `length` bases; n_runs = iterable of (start, end) half-open N blocks.
+    Base i = "ACGT"[(w[i // 32] >> 2 * (i % 32)) & 3] with w = splitmix64(seed); generated in chunks through a byte -> 4-base
+    table, so a 250 Mb contig takes seconds and no 32x temporary."""
     nwords = (length + 31) // 32
-    w = _splitmix64(nwords, seed)
-    shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))
-    codes = ((w[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.uint8).reshape(-1)[:length]
-    out = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+    out = np.empty(nwords * 32, dtype=np.uint8)
+    out32 = out.view(np.uint32)
+    lut = _lut4()
+    CH = 1 << 20
+    with np.errstate(over="ignore"):
+        for a in range(0, nwords, CH):
+            b = min(nwords, a + CH)
+            k = np.arange(a + 1, b + 1, dtype=np.uint64)
+            z = np.uint64(seed) + k * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            out32[a * 8:b * 8] = lut[z.view(np.uint8)]       # little-endian: byte j of word k holds bases 32k + 4j .. +3
+    out = out[:length]
     for a, b in n_runs:
         out[a:b] = ord("N")
     return out
@@ -82,7 +107,30 @@ def workload_contigs(name: str):
         return [("ecoli_synth", random_contig(4_641_652, 1))]
     if name == "chr20":           # S3: chr20-length with telomere / internal N blocks
         return [("chr20_synth", random_contig(64_444_167, 2, [(0, 60_000), (26_400_000, 26_900_000), (64_334_167, 64_444_167)]))]
+    if name in ("grch38", "grch38_mini"):      # S4 (and S5 with the Ion Torrent flags): 24 contigs with the GRCh38 primary-assembly lengths
+        scale = 1 if name == "grch38" else 64   # grch38_mini: every length / 64 (48 Mb), same layout -- for CPU-side checks of the multi-contig plumbing
+        return [(nm, random_contig(l // scale, 1000 + i, [(a // scale, b // scale) for a, b in grch38_n_runs(nm, l)])) for i, (nm, l) in enumerate(GRCH38_PRIMARY)]
     raise ValueError(name)
+
+
+# GRCh38 primary assembly (chr1-22, X, Y) sequence lengths, GCA_000001405.15
+GRCH38_PRIMARY = [
+    ("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
+    ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+    ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
+    ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415),
+]
+
+
+def grch38_n_runs(name: str, l: int):
+    """Telomere / centromere-like N blocks (~5 % of the genome in all): 10 kb at both ends, a centromere block of
+    3 % of the length at 40 %, the short arms of the acrocentric chromosomes (first 15 %), and the unresolved tail of chrY (last 30 %)."""
+    runs = [(0, 10_000), (l - 10_000, l), (int(l * 0.40), int(l * 0.40) + int(l * 0.03))]
+    if name in ("chr13", "chr14", "chr15", "chr21", "chr22"):
+        runs.append((0, int(l * 0.15)))
+    if name == "chrY":
+        runs.append((int(l * 0.70), l))
+    return runs
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DWGSIM_HIP_ABI_VERSION 1
+#define DWGSIM_HIP_ABI_VERSION 2
 
 /* error codes (negative) */
 #define DWGSIM_HIP_OK            0
@@ -80,7 +80,17 @@ typedef struct dwgsim_hip_batch {
     const void *dev_ptr[3];    /* device addresses of the packed text (valid until the slot is reused) */
     float    kernel_ms;        /* HIP-event time of the batch's kernels on the context's stream */
     float    sim_kernel_ms;    /* ... of the dominant kernel (simulate_pairs) alone */
+    /* The reference's abort rule (one counter of failed attempts over the pairs of a contig, reset by every genomic read, fatal above
+     * 10 000: dwgsim.c:635, :833-843) as a mergeable summary of THIS batch alone: {fails before its first reset (all of them if it has
+     * none), fails after its last reset, has a reset, a run between two of its resets passed the limit}.  A host that shards one contig
+     * over several contexts joins the summaries in read-index order (dwgsim_hip_failseg_join) to get the exact verdict. */
+    uint64_t fail_seg[4];
+    uint64_t fail_carry;       /* the counter after this batch, given the carry it started from */
 } dwgsim_hip_batch_t;
+
+/* rand_base value meaning "continue the running count after the previous batch of this context" (kept on the device, so successive
+ * batches can be enqueued without a host round trip) */
+#define DWGSIM_HIP_RAND_CHAIN UINT64_MAX
 
 /* dwgsim_opt_init() defaults (dwgsim_opt.c:40-80) */
 void dwgsim_hip_params_default(dwgsim_hip_params_t *p);
@@ -147,15 +157,46 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii
 
 /* Replaces the loop body dwgsim.c:636-1099 for the read-index range [first_ii, first_ii+n_pairs)
  * of one contig.  rand_base = number of random reads emitted before first_ii (over all contigs).
- * slot in {0,1}: which of the context's double-buffered output sets to fill.  The call enqueues
- * the kernels and returns after they completed; FASTQ text stays in HBM (out->dev_ptr) until
- * dwgsim_hip_fetch copies it out. */
+ * slot in {0,1}: which of the context's double-buffered output sets to fill.  Blocking form:
+ * returns after the kernels completed; FASTQ text stays in HBM (out->dev_ptr) until a fetch copies it out.
+ * Replaces, together with the fetch calls, the gzprintf / gzputc stream of dwgsim.c:919-981. */
 int dwgsim_hip_simulate(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
                         uint64_t rand_base, int slot, dwgsim_hip_batch_t *out);
+
+/* The same in two halves, so that two batches can be in flight (slot 0 / 1): simulate_async only enqueues -- kernels, the abort-rule
+ * epilogue and the read-back of the batch's counters on the context's compute stream -- and returns; wait blocks until that batch has
+ * finished, reports its errors and fills *out.  Batch k+1 may be enqueued (other slot, rand_base = DWGSIM_HIP_RAND_CHAIN) before
+ * batch k was waited for; a slot is reused only after its wait(), and its kernels wait on the device for any fetch still reading it. */
+int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
+                              uint64_t rand_base, int slot);
+int dwgsim_hip_wait(dwgsim_hip_ctx_t *ctx, int slot, dwgsim_hip_batch_t *out);
+
+/* The failure counter carried into the next simulate call (default: the previous batch's counter when the call continues the
+ * same contig at the next read index, else 0).  For sharded jobs: the carry out of the preceding shard. */
+int dwgsim_hip_set_fail_carry(dwgsim_hip_ctx_t *ctx, uint64_t carry);
+
+/* acc = acc . next in read-index order (both as dwgsim_hip_batch_t::fail_seg).  Returns 1 when the joined run passes the limit
+ * (the reference would have aborted), else 0.  Start from {carry, carry, 0, 0}. */
+int dwgsim_hip_failseg_join(uint64_t acc[4], const uint64_t next[4]);
+
+/* Contiguous near-equal read-index ranges, in order: shard `rank` of `world` over [0, n_pairs). */
+void dwgsim_hip_shard_range(uint64_t n_pairs, int rank, int world, uint64_t *first, uint64_t *n);
+
+/* Page-locked host memory for fetch destinations (hipHostMalloc / hipHostFree for callers that do not link the HIP runtime). */
+void *dwgsim_hip_host_alloc(size_t bytes);
+void dwgsim_hip_host_free(void *p);
+
+/* Asynchronous copy of one finished stream of a waited-for slot into PAGE-LOCKED host memory, on the context's copy stream (it
+ * overlaps with the kernels of the other slot); fetch_wait blocks until every copy enqueued for the slot has landed. */
+int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
+int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *ctx, int slot);
 
 /* Copy one finished stream of a slot to host memory.  A page-locked destination (hipHostMalloc / hipHostRegister) takes one direct
  * hipMemcpyAsync at link speed; pageable memory goes through double-buffered pinned staging inside. */
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
+
+/* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases" (see dw_host.cpp). */
+int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
 
 /* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);

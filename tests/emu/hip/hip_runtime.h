@@ -79,11 +79,17 @@ static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned lo
 
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicOr(unsigned long long *p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = __atomic_load_n(p, __ATOMIC_RELAXED); while (o < v && !__atomic_compare_exchange_n(p, &o, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)); return o; }
 static inline uint32_t atomicMax(uint32_t *p, uint32_t v) { uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED); while (o < v && !__atomic_compare_exchange_n(p, &o, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)); return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
+
+// hardware transcendentals used only inside estimates with a guard band (quality_pair_lazy): libm stand-ins are at least as accurate
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 
 // ---- host runtime ----
 typedef int hipError_t;
@@ -115,6 +121,8 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(hipemu_event)); return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

@@ -31,14 +31,14 @@ def first_diff(a: bytes, b: bytes):
 IN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs")
 
 
-def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22):
+def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22, debug_options=None):
     """Returns the JobResult; raises AssertionError with a readable diff on any mismatch."""
     flags = flags.replace("{IN}", IN_DIR)
     with tempfile.TemporaryDirectory() as t:
         want = run_oracle(oracle_bin, fasta, flags, t)
     params = api.parse_flags(flags, lib)
     contigs = api.read_fasta(fasta)
-    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib)
+    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib, debug_options=debug_options)
     assert res.mutations_txt == want["txt"], "mutations.txt: " + first_diff(res.mutations_txt, want["txt"])
     assert res.mutations_vcf == want["vcf"], "mutations.vcf: " + first_diff(res.mutations_vcf, want["vcf"])
     for k in STREAMS:

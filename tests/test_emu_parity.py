@@ -58,11 +58,10 @@ def test_count_random_matches_simulate_on_cpu_emulation(emu_lib, golden_dir, fas
     check_count_random_matches_simulate(emu_lib, os.path.join(golden_dir, fasta), flags, ranges=((0, None), (17, 300)))
 
 
-def test_walk_reruns_when_a_capacity_is_exceeded(emu_lib, oracle_bin, golden_dir, monkeypatch):
+def test_walk_reruns_when_a_capacity_is_exceeded(emu_lib, oracle_bin, golden_dir):
     """The walk is enqueued with estimated capacities and checked once at the end; too small a candidate list or inserted-base
     pool must lead to an exact re-run with the same result."""
-    monkeypatch.setenv("DWGSIM_HIP_WALK_CAP", "7")
-    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 30 -X 0.6", batch_pairs=700)
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 30 -X 0.6", batch_pairs=700, debug_options={"walk_cap": 7})
 
 
 def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):

@@ -55,12 +55,11 @@ def test_mutation_walk_on_repeat_rich_contigs(lib, oracle_bin, repeats_fa, flags
     compare_case(lib, oracle_bin, repeats_fa, flags)
 
 
-def test_parallel_justify_equals_sequential_crosscheck(lib, repeats_fa, monkeypatch):
+def test_parallel_justify_equals_sequential_crosscheck(lib, repeats_fa):
     params = api.parse_flags("-z 35 -M 2 -r 0.1 -R 0.8 -X 0.6", lib)
     contigs = api.read_fasta(repeats_fa)
     par = api.run_job(params, contigs, lib=lib)
-    monkeypatch.setenv("DWGSIM_HIP_JUSTIFY", "seq")
-    seq = api.run_job(params, contigs, lib=lib)
+    seq = api.run_job(params, contigs, lib=lib, debug_options={"justify_seq": 1})
     assert par.mutations_txt == seq.mutations_txt and par.mutations_vcf == seq.mutations_vcf
     assert len(par.mutations_txt) > 100000
 
@@ -94,6 +93,27 @@ def test_range_restricted_fp64_forms_equal_the_general_ones(lib):
         assert out[3] > (1 << 29) and (out[0], out[1], out[2]) == (0, 0, 0), list(out)
 
 
+def test_lazy_quality_normals_decide_exactly_what_the_exact_form_decides(lib):
+    """quality_pair_lazy (fp32 estimate + proven error bound, exact fp64 path only near a rounding boundary) against quality_pair_exact on
+    2^28 blocks per quality_std, and the hardware operations the bound rests on (v_log_f32, v_rcp_f32, v_sqrt_f32) against fp64 on EVERY
+    float of their operand ranges."""
+    import ctypes as C, struct
+    out = (C.c_uint64 * 12)()
+    lib.dwgsim_hip_selftest_lazy.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_double, C.c_int, C.POINTER(C.c_uint64)]
+    lib.dwgsim_hip_selftest_lazy.restype = C.c_int
+    dbl = lambda u: struct.unpack("<d", struct.pack("<Q", u))[0]
+    for k, sigma in enumerate((2.0, 0.3, 10.0, 40.0, 5000.0, 1e7)):
+        assert lib.dwgsim_hip_selftest_lazy(0, 100 + k, 1 << 28, sigma, 1 if k == 0 else 0, out) == 0
+        assert out[4] == 1 << 28 and out[2] + out[3] == out[4], list(out)
+        assert out[0] == 0 and out[1] == 0, (sigma, list(out))                  # not one offset, not one accept / reject verdict differs
+        assert dbl(out[5]) < 0.5, (sigma, dbl(out[5]))                           # the estimate stays well inside its proven bound
+        if sigma <= 10:
+            assert out[3] < 0.01 * out[4], (sigma, out[3] / out[4])              # ... and the exact path is rare at realistic -Q
+        if k == 0:
+            assert 0 < dbl(out[6]) <= 1.0 and 0 < dbl(out[7]) <= 1.0 and 0 < dbl(out[8]) <= 1.0, [dbl(out[q]) for q in (6, 7, 8)]
+        print(f"sigma {sigma}: exact-path share {out[3] / out[4]:.5f}, max |y - x| / eps {dbl(out[5]):.3f}", [round(dbl(out[q]), 3) for q in (6, 7, 8)] if k == 0 else "")
+
+
 @pytest.mark.parametrize("which,flags", [
     ("tiny", "-z 9 -C 40 -y 0.15 -n 0"),
     ("odd", "-z 6 -C 40 -1 40 -2 40 -d 150 -s 10 -r 0.08 -R 0.8 -X 0.6 -n 1 -y 0.1"),
@@ -109,10 +129,9 @@ def test_count_random_matches_simulate(lib, golden_dir, repeats_fa, which, flags
     check_count_random_matches_simulate(lib, fasta, flags)
 
 
-def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa, monkeypatch):
+def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa):
     """See tests/test_emu_parity.py: forced tiny capacities on the repeat-rich 1.8 Mb contigs."""
-    monkeypatch.setenv("DWGSIM_HIP_WALK_CAP", "100")
-    compare_case(lib, oracle_bin, repeats_fa, "-z 32 -M 2 -r 0.2 -R 0.9 -X 0.3 -I 2")
+    compare_case(lib, oracle_bin, repeats_fa, "-z 32 -M 2 -r 0.2 -R 0.9 -X 0.3 -I 2", debug_options={"walk_cap": 100})
 
 
 def test_abort_rule_matches_the_reference(lib, oracle_bin, golden_dir):
