@@ -390,6 +390,50 @@ static void walk_contig(const opt_t *o, rng_t *r, const seq_t *seq, hap_t *h0, h
     }
 }
 
+/* mut.c:379-425 mut_debug(): the consistency asserts the reference runs over both haplotypes before AND after the left-justification
+ * (mut.c:753, :757).  They are live in the reference build (no -DNDEBUG): a mutation input that makes one fail -- e.g. `-m` with a
+ * homozygous SNP whose alt base equals the reference base -- ends the reference with SIGABRT (rc 134) before anything is written.
+ * Restated on the byte cells; the vacuous asserts (n1 == n2 with both read from hap1, n <= UINT32_MAX, ...) are omitted.  Returns the
+ * text of the first failing assert (NULL if none) and its 0-based position. */
+static const char *mut_debug(const seq_t *seq, hap_t *h0, hap_t *h1, int64_t *at)
+{
+    for (int64_t i = 0; i < seq->l; ++i) {
+        const uint8_t c0 = nt4(seq->s[i]), c1 = h0->c[i], c2 = h1->c[i];
+        if (c0 >= 4) continue;
+        if ((c1 & TMASK) == T_NONE && (c2 & TMASK) == T_NONE) continue;
+        *at = i;
+        if ((c1 & BT_MASK) == (c2 & BT_MASK)) {                       /* hom, mut.c:391-405 */
+            if ((c1 & TMASK) == T_SUB) { if ((c0 & 3) == (c1 & 3)) return "(c[0]&0x3) != (c[1]&0x3)"; }
+            else if ((c1 & TMASK) == T_INS) {
+                uint32_t n = 0; for (int q = 0; q < h0->n_ins; ++q) if (h0->ins[q].pos == i) n = h0->ins[q].n;
+                if (n == 0) return "n1 > 0";
+            }
+        } else {                                                      /* het, mut.c:406-422 */
+            if ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB) {
+                if ((c1 & 3) == (c2 & 3)) return "(c[1]&0x3) != (c[2]&0x3)";
+                if (!((c0 & 3) == (c1 & 3) || (c0 & 3) == (c2 & 3))) return "(c[0]&0x3) == (c[1]&0x3) || (c[0]&0x3) == (c[2]&0x3)";
+            } else if ((c1 & TMASK) == T_DEL || (c2 & TMASK) == T_DEL) { }
+            else if ((c1 & TMASK) == T_INS) {
+                uint32_t n = 0; for (int q = 0; q < h0->n_ins; ++q) if (h0->ins[q].pos == i) n = h0->ins[q].n;
+                if (n == 0) return "n > 0";
+            } else if ((c2 & TMASK) == T_INS) {
+                uint32_t n = 0; for (int q = 0; q < h1->n_ins; ++q) if (h1->ins[q].pos == i) n = h1->ins[q].n;
+                if (n == 0) return "n > 0";
+            }
+        }
+    }
+    return NULL;
+}
+static void mut_debug_or_abort(const char *name, const seq_t *seq, hap_t *h0, hap_t *h1)
+{
+    int64_t at = 0;
+    const char *what = mut_debug(seq, h0, h1, &at);
+    if (!what) return;
+    fprintf(stderr, "dwgsim: src/mut.c: mut_debug: Assertion `%s' failed. [%s:%lld]\n", what, name, (long long)at + 1);
+    fflush(NULL);
+    abort();                                                          /* as assert() does: SIGABRT, shell rc 134 */
+}
+
 /* ------------------------------------------------------------------------------------------
  * Mutation-input files: mut_txt.c:40-133 (-m), mut_bed.c:37-137 (-b), mut_vcf.c:42-280 (-v) and their
  * application in mut_diref, mut.c:644-745.  Entries keep file order; `contig` is the FASTA ordinal.
@@ -1219,7 +1263,9 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
         r->k1 = contig_i;
         if (o->muts_type >= 0) apply_mutation_input(o, r, &seq, &hap[0], &hap[1], contig_i, &mi);   /* mut.c:644-745 */
         else walk_contig(o, r, &seq, &hap[0], &hap[1]);      /* dwgsim.c:628-629 -> mut.c:591 */
+        mut_debug_or_abort(name, &seq, &hap[0], &hap[1]);    /* mut.c:753 */
         left_justify(&seq, &hap[0], &hap[1]);                /* mut.c:756 */
+        mut_debug_or_abort(name, &seq, &hap[0], &hap[1]);    /* mut.c:757 */
         if (out->has_mut) print_mutations(name, &seq, &hap[0], &hap[1], &out->txt, &out->vcf);
 
         if (o->output_type != 2) {
