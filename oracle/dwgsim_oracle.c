@@ -258,6 +258,11 @@ typedef struct {
     char *fn_muts; int muts_type;   /* -m (1, txt) / -b (0, bed) / -v (2, vcf): mut_input.h:29-33 */
     int rng_mode, use_libm_log, null_fastq, verbose;
     int64_t emit_first, emit_count;   /* --emit-range first:count (mode B only): emit only these read indices of every contig */
+    /* Whole-genome checks without walking the whole genome (mode B only: every decision has its own RNG slot, so nothing else carries over):
+     * --as-contig K,TOT,AFTER,NSIM  the FASTA holds ONE contig of a larger genome: it is contig number K (RNG key), the genome's total length is
+     *                               TOT, AFTER contigs follow it, NSIM pairs were simulated before it (dwgsim.c:519-537, :582-590)
+     * --range-rand-base R           with --emit-range: start the pair loop AT the window, with R random reads emitted before it (dwgsim.c:1042,1096) */
+    int64_t as_contig, as_tot, as_after, as_nsim, range_rand_base;
 } opt_t;
 
 static void opt_defaults(opt_t *o) /* dwgsim_opt.c:40-80 */
@@ -1229,6 +1234,14 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
         for (int i = 0; i < rg.n; ++i) tot_len += rg.end[i] - rg.start[i];
     }
     uint32_t contig_i = 0;
+    if (o->as_contig >= 0) {
+        if (r->mode != RNG_PHILOX) { fprintf(stderr, "oracle: --as-contig needs --rng philox\n"); return 1; }
+        contig_i = (uint32_t)o->as_contig; tot_len = (uint64_t)o->as_tot; n_ref += (int)o->as_after; n_sim = o->as_nsim;
+    }
+    if (o->range_rand_base >= 0) {
+        if (r->mode != RNG_PHILOX || o->emit_count < 0) { fprintf(stderr, "oracle: --range-rand-base needs --rng philox and --emit-range\n"); return 1; }
+        rand_ii = (uint64_t)o->range_rand_base;
+    }
     while ((l = fasta_next(fp, &seq, name)) >= 0) {
         int64_t n_pairs = 0;
         n_ref--;
@@ -1270,7 +1283,13 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
 
         if (o->output_type != 2) {
             int num_failed = 0; uint32_t att = 0;
-            for (uint64_t ii = 0; ii != (uint64_t)n_pairs; ++ii, ++ctr) {
+            uint64_t ii_first = 0, ii_end = (uint64_t)n_pairs;
+            if (o->range_rand_base >= 0) {      /* jump to the window */
+                ii_first = (uint64_t)o->emit_first < ii_end ? (uint64_t)o->emit_first : ii_end;
+                if ((uint64_t)(o->emit_first + o->emit_count) < ii_end) ii_end = (uint64_t)(o->emit_first + o->emit_count);
+                n_sim += (int64_t)ii_first;
+            }
+            for (uint64_t ii = ii_first; ii != ii_end; ++ii, ++ctr) {
                 int s[2] = { size[0], size[1] }, strand[2] = { 0, 0 }, d = 0, pos = 0;
                 readinfo_t ri[2]; memset(ri, 0, sizeof ri);
                 int n_err[2] = { 0, 0 }, n_err_first[2] = { 0, 0 };
@@ -1417,7 +1436,7 @@ static FILE *open_out(const char *prefix, const char *suffix)
 
 int oracle_main(int argc, char **argv)
 {
-    opt_t o; rng_t r; opt_defaults(&o); o.emit_first = 0; o.emit_count = -1;
+    opt_t o; rng_t r; opt_defaults(&o); o.emit_first = 0; o.emit_count = -1; o.as_contig = -1; o.as_tot = o.as_after = o.as_nsim = 0; o.range_rand_base = -1;
     /* strip the oracle's own long options */
     char **av = malloc(sizeof(char *) * (size_t)(argc + 1)); int ac = 0;
     for (int i = 0; i < argc; ++i) {
@@ -1426,6 +1445,8 @@ int oracle_main(int argc, char **argv)
         else if (!strcmp(argv[i], "--null-fastq")) o.null_fastq = 1;
         else if (!strcmp(argv[i], "--verbose")) o.verbose = 1;
         else if (!strcmp(argv[i], "--emit-range") && i + 1 < argc) { ++i; long long a = 0, b = 0; sscanf(argv[i], "%lld:%lld", &a, &b); o.emit_first = a; o.emit_count = b; }
+        else if (!strcmp(argv[i], "--as-contig") && i + 1 < argc) { ++i; long long a = 0, b = 0, c = 0, d = 0; sscanf(argv[i], "%lld,%lld,%lld,%lld", &a, &b, &c, &d); o.as_contig = a; o.as_tot = b; o.as_after = c; o.as_nsim = d; }
+        else if (!strcmp(argv[i], "--range-rand-base") && i + 1 < argc) { ++i; o.range_rand_base = atoll(argv[i]); }
         else av[ac++] = argv[i];
     }
     av[ac] = NULL;

@@ -1,5 +1,6 @@
 // tests/emu/hip_emu.cpp -- runtime of the CPU SIMT emulation (TEST INFRASTRUCTURE ONLY, see hip/hip_runtime.h)
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 namespace hipemu {
 thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
@@ -18,6 +19,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
     const unsigned nt = block.x;
     if (nt == 0 || grid.x == 0) return;
     if (nt % 64 != 0 || nt > 1024) { fprintf(stderr, "hipemu: block size %u unsupported\n", nt); abort(); }
+    static std::mutex one_launch;                 // static __shared__ storage, global barriers: one kernel at a time, whichever host thread launches
+    std::lock_guard<std::mutex> lock(one_launch);
     g_dyn.assign(shmem + 64, 0);
     pthread_barrier_init(&g_block_bar, nullptr, nt);
     for (unsigned w = 0; w < nt / 64; ++w) pthread_barrier_init(&g_wave_bar[w], nullptr, 64);

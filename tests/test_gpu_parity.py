@@ -4,6 +4,7 @@ import os
 import pytest
 
 from dwgsim_amd import api
+FLOW_ORDER = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
 from parity_common import CASES, compare_case
 
 pytestmark = pytest.mark.gpu
@@ -78,6 +79,86 @@ def test_cli_is_a_drop_in_for_the_dwgsim_command(oracle_bin, golden_dir, tmp_pat
         assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k]
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
+
+
+@pytest.mark.parametrize("fasta,flags", [
+    ("tiny.fa", "-z 9 -N 3000 -P pfx -r 0.01 -R 0.3 -y 0.2"),
+    ("tiny.fa", "-z 8 -N 4000 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1"),
+    ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW_ORDER} -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
+    ("odd.fa", "-z 6 -C 30 -2 0 -1 120 -r 0.05 -R 0.9 -I 40 -y 0.3 -n 3"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 8 -m {IN}/muts_edge.txt"),
+])
+def test_cli_on_several_contexts_writes_the_same_files(oracle_bin, golden_dir, tmp_path, fasta, flags):
+    """dwgsim-hip with three contexts (here all on GPU 0: the multi-GPU code path on a 1-GPU box), tiny batches and every contig
+    split into read-index ranges: host threads, per-range rand_ii bases from count_random, ordered merge of the deflated
+    members -- the five files must equal the oracle's (= the single-context run's) after gunzip."""
+    import gzip, subprocess
+    from parity_common import run_oracle, IN_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "dwgsim_amd", "dwgsim-hip")
+    flags = flags.replace("{IN}", IN_DIR)
+    want = run_oracle(oracle_bin, os.path.join(golden_dir, fasta), flags, str(tmp_path))
+    env = dict(os.environ, DWGSIM_HIP_DEVICES="0,0,0", DWGSIM_HIP_MIN_SHARE="40", DWGSIM_HIP_BATCH="333", DWGSIM_HIP_THREADS="4")
+    subprocess.run([cli] + flags.split() + [os.path.join(golden_dir, fasta), str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL, env=env)
+    for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz"), (2, "bfast.fastq.gz")]:
+        assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k], suf
+    assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
+    assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
+
+
+def test_cli_abort_rule_across_contexts(oracle_bin, golden_dir, tmp_path):
+    """The failure counter of dwgsim.c:635 runs over the pairs of a contig in index order; with the contig split over contexts no single
+    range reaches 10 000 failures in this job, the joined summaries do: dwgsim-hip must die as the reference does -- and must not when
+    the job is shortened below the limit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "dwgsim_amd", "dwgsim-hip")
+    env = dict(os.environ, DWGSIM_HIP_DEVICES="0,0", DWGSIM_HIP_MIN_SHARE="10", DWGSIM_HIP_BATCH="150", DWGSIM_HIP_THREADS="2")
+    fa = os.path.join(golden_dir, "odd.fa")
+    base = "-z 6466 -1 33 -2 150 -d 900 -s 50 -r 0 -e 0.0-0.1 -Q 0 -a"
+    r = subprocess.run([cli] + (base + " -N 1200").split() + [fa, str(tmp_path / "a")], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "failed to generate a read after 10001 trials" in r.stderr, r.stderr[-300:]
+    r = subprocess.run([cli] + (base + " -N 600").split() + [fa, str(tmp_path / "b")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-300:]
+
+
+def test_async_two_slot_pipeline_equals_blocking_calls(lib, golden_dir):
+    """simulate_async / wait / fetch_async / fetch_wait with two batches in flight and the device-chained rand_ii (DWGSIM_HIP_RAND_CHAIN)
+    against the blocking simulate / fetch calls on the same ranges."""
+    import ctypes as C
+    params = api.parse_flags("-z 41 -C 60 -1 100 -2 100 -y 0.2 -r 0.01 -R 0.3", lib)
+    name, arr = api.read_fasta(os.path.join(golden_dir, "tiny.fa"))[0]
+    n_pairs, batch = 1800, 250
+    with api.Context(params, 0, lib) as ctx:
+        cid = ctx.add_contig(name, arr, 0)
+        ctx.mutate(cid)
+        want = [b"", b"", b""]; rr = 7
+        for first in range(0, n_pairs, batch):
+            b = ctx.simulate(cid, first, min(batch, n_pairs - first), rr, 0)
+            for s in range(3):
+                want[s] += ctx.fetch(0, s, b.bytes[s])
+            rr += b.n_random
+        got = [b"", b"", b""]
+        cap = 1 << 20
+        bufs = [[lib.dwgsim_hip_host_alloc(cap) for _ in range(3)] for _ in range(2)]
+        pending = []
+
+        def finish(slot):
+            b = ctx.wait(slot)
+            for s in range(3):
+                ctx.fetch_async(slot, s, bufs[slot][s], cap)
+            ctx.fetch_wait(slot)
+            for s in range(3):
+                got[s] += C.string_at(bufs[slot][s], b.bytes[s])
+        for k, first in enumerate(range(0, n_pairs, batch)):
+            ctx.simulate_async(cid, first, min(batch, n_pairs - first), 7 if k == 0 else api.RAND_CHAIN, k & 1)
+            if k > 0:
+                finish((k - 1) & 1)
+        finish(k & 1)
+        for slot in range(2):
+            for s in range(3):
+                lib.dwgsim_hip_host_free(bufs[slot][s])
+    assert got == want and len(want[2]) > 100000
 
 
 def test_range_restricted_fp64_forms_equal_the_general_ones(lib):

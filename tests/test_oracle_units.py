@@ -44,3 +44,39 @@ def test_det_log_accuracy(oracle_lib):
         worst = max(worst, abs(ia - ib))
     assert worst <= 1, worst   # within 1 ulp of glibc everywhere
     assert oracle_lib.oracle_det_log(1.0) == 0.0
+
+
+def test_single_contig_window_equals_the_slice_of_the_whole_genome_run(oracle_bin, golden_dir, tmp_path):
+    """--as-contig / --range-rand-base (mode B): one contig of a larger genome, one read-index window of it, simulated without walking
+    the rest -- must be byte-identical to that window of the whole-genome run (what the whole-GRCh38 GPU tests rely on)."""
+    import os, subprocess
+    from dwgsim_amd import api, synth
+    contigs = api.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    flags = "-z 31 -N 3000 -1 60 -2 60 -d 200 -s 15 -y 0.2 -r 0.01 -o 1"
+    full = str(tmp_path / "full")
+    subprocess.run([oracle_bin, "--rng", "philox"] + flags.split() + [os.path.join(golden_dir, "tiny.fa"), full], check=True, stderr=subprocess.DEVNULL)
+    recs = open(full + ".bwa.read1.fastq", "rb").read().split(b"\n")
+    recs = [b"\n".join(recs[k:k + 4]) + b"\n" for k in range(0, len(recs) - 1, 4)]
+    assert len(recs) == 3000
+    lib = None
+    try:
+        lib = api.load()
+    except RuntimeError:
+        pass
+    tot = sum(len(a) for _, a in contigs)
+    # pairs per contig (dwgsim.c:582-586; the last contig takes the remainder, the 300-bp contig is skipped by rule #3)
+    n1 = int(len(contigs[0][1]) / tot * 3000 + 0.5)
+    k, first, cnt = 1, 100, 250                                   # contig t2, pairs [100, 350)
+    lo = n1 + first
+    rand_base = sum(1 for r in recs[:lo] if r.startswith(b"@rand_"))
+    fa1 = str(tmp_path / "t2.fa")
+    synth.write_fasta(fa1, [contigs[k]])
+    win = str(tmp_path / "win")
+    subprocess.run([oracle_bin, "--rng", "philox", "--as-contig", f"{k},{tot},{len(contigs) - 1 - k},{n1}", "--emit-range", f"{first}:{cnt}",
+                    "--range-rand-base", str(rand_base)] + flags.split() + [fa1, win], check=True, stderr=subprocess.DEVNULL)
+    got = open(win + ".bwa.read1.fastq", "rb").read()
+    assert got == b"".join(recs[lo:lo + cnt])
+    assert any(r.startswith(b"@rand_") for r in recs[lo:lo + cnt])
+    # the mutation body lines of that contig are those of the whole-genome run
+    want_txt = b"".join(l + b"\n" for l in open(full + ".mutations.txt", "rb").read().split(b"\n") if l.startswith(contigs[k][0].encode() + b"\t"))
+    assert open(win + ".mutations.txt", "rb").read() == want_txt and len(want_txt) > 0
