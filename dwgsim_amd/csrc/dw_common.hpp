@@ -32,14 +32,17 @@ enum : uint32_t {
     D_PLACE = 5,        // slot t = position uniform of placement try t (dwgsim.c:671)
     D_PLACE_NORM = 6,   // block t, retry r = polar tries of the insert-size normal of try t (dwgsim.c:657)
     // NARROW domains: a draw is one 32-bit word w of a block, u = w * 2^-32, four draws per Philox block
-    D_BASE0 = 8,        // +read end.  word i (block i>>2, word i&3): error test of base i (dwgsim.c:237) or random-read base i (:1000)
-    D_QUAL0 = 10,       // +read end.  block p, retry m: polar tries 2m = words (0,1), 2m+1 = words (2,3); the accepted try gives
-                        // quality normals 2p (v2*fac) and 2p+1 (v1*fac) (dwgsim.c:912, :156-175)
+    D_BASE0 = 8,        // +read end.  16-bit draws, eight per block: halfword i (block i>>3, word (i&7)>>1, low half first) = the HIGH half of the 32-bit
+                        // uniform of base i: error test (dwgsim.c:237) or random-read base (:1000); the low half is halfword i of D_BASE_REF0
+    D_QUAL0 = 10,       // +read end.  the sequential stream of polar tries of the read's quality normals (dwgsim.c:912, :156-175): try t = words
+                        // 2 (t&1), 2 (t&1) + 1 of block t>>1; every accepted try delivers two normals (v2*fac, then the cached v1*fac)
     D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): one sub-stream per event -- block = ordinal of the homopolymer
                         // start (pass 1) / of the examined base (pass 2), draw s of the event = word s & 3 of retry s >> 2
     D_FLOW_PASS2 = 8,   // added to D_FLOW0 / D_CALIB (+read end) for the second pass of the flow model (domains 20-23)
     D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
-    D_SUB0 = 16         // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
+    D_SUB0 = 16,        // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
+    D_BASE_REF0 = 24    // +read end.  halfword i = the LOW half of base i's uniform; it decides u < e only when the high halves of u and e agree
+                        // (probability 2^-16), so it is drawn lazily
 };
 
 struct U4 { uint32_t x, y, z, w; };

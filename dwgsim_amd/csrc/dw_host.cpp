@@ -112,6 +112,22 @@ uint8_t nt4(int ch)      // dwgsim.c:56-73
     switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
 }
 
+// Parameters of the lazy quality normals (error budget: dw_simulate.hip quality_try_lazy).  Polar radii with L' = -log2(r) < lmin give
+// |nrm| < sqrt(2 ln 2 lmin): lmin is the largest value (<= 2^-4) for which that keeps |nrm * sigma| below 0.45, so the offset is 0 there
+// without further work; when sigma is too large for that (lmin would fall below 2^-10) the exact path handles those radii instead.
+void lazy_quality_params(double sigma, float *k, float *eps, float *lmin, int32_t *near1_zero)
+{
+    const double two_ln2 = 2.0 * log(2.0);
+    double lm = 0.98 * (0.45 / sigma) * (0.45 / sigma) / two_ln2;
+    if (!(lm < 0x1p-4)) lm = 0x1p-4;
+    *near1_zero = lm >= 0x1p-10 ? 1 : 0;
+    if (lm < 0x1p-10) lm = 0x1p-10;
+    *lmin = (float)lm;
+    lm = (double)*lmin * (1.0 - 0x1p-20);         // (what the budget may assume after the rounding to float)
+    *k = (float)(sqrt(two_ln2) * 0x1p-31 * sigma);
+    *eps = (float)(1.5 * sigma * (3.4e-7 / sqrt(lm) + 7.2e-6) + 0x1p-18);       // (+inf for an absurd -Q: every value then takes the exact path)
+}
+
 WalkParams walk_params(const dwgsim_hip_ctx *c)
 {
     WalkParams w; w.mut_rate = c->prm.mut_rate; w.indel_frac = c->prm.indel_frac; w.indel_extend = c->prm.indel_extend;
@@ -370,11 +386,13 @@ extern "C" int dwgsim_hip_selftest_lazy(int device, uint32_t seed, uint64_t n, d
     uint64_t *d = nullptr;
     if (hipMalloc((void **)&d, 12 * sizeof(uint64_t)) != hipSuccess) return DWGSIM_HIP_ERR_NOMEM;
     hipMemset(d, 0, 12 * sizeof(uint64_t));
-    launch_selftest_lazy(nullptr, 0, seed, n, sigma, d);
+    float qk, qeps, qlmin; int32_t qnear1;
+    lazy_quality_params(sigma, &qk, &qeps, &qlmin, &qnear1);
+    launch_selftest_lazy(nullptr, 0, seed, n, sigma, qk, qeps, qlmin, qnear1, d);
     if (exhaustive) {
-        launch_selftest_lazy(nullptr, 1, 0, 0x3F800000u - 0x20800000u, 0, d);
-        launch_selftest_lazy(nullptr, 2, 0, 0x3F800000u - 0x20800000u, 0, d);
-        launch_selftest_lazy(nullptr, 3, 0, 0x62800000u - 0x3A000000u, 0, d);
+        launch_selftest_lazy(nullptr, 1, 0, 0x3F800000u - 0x20800000u, 0, 0, 0, 0, 0, d);
+        launch_selftest_lazy(nullptr, 2, 0, 0x3F800000u - 0x20800000u, 0, 0, 0, 0, 0, d);
+        launch_selftest_lazy(nullptr, 3, 0, 0x62800000u - 0x3A000000u, 0, 0, 0, 0, 0, d);
     }
     const hipError_t e = hipMemcpy(out, d, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost);
     hipFree(d);
@@ -786,9 +804,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.p.fixed_quality = p.fixed_quality; a.p.data_type = p.data_type;
     a.p.has_bfast = p.reads_output_type != 1; a.p.has_bwa = p.reads_output_type != 2;
     a.p.seed = (uint32_t)p.seed;
-    a.p.q_k = (float)(sqrt(2.0 * log(2.0)) * 0x1p-31 * p.quality_std);
-    a.p.q_eps = (float)(p.quality_std * 0x1p-14 + 0x1p-18);       // (+inf for an absurd -Q: every value then takes the exact path)
-    a.p.q_near1 = p.quality_std < 12.0 ? 1 : 0;
+    lazy_quality_params(p.quality_std, &a.p.q_k, &a.p.q_eps, &a.p.q_lmin, &a.p.q_near1);
     a.c = contig_dev(k);
     a.first_ii = first_ii; a.n_pairs = n_pairs; a.chain = c->d_chain;
     a.l_place = k.l_place; a.have_regions = c->has_regions ? 1 : 0; a.n_reg = k.n_reg; a.reg_start = k.d_reg; a.reg_end = k.d_reg ? k.d_reg + k.n_reg : nullptr;

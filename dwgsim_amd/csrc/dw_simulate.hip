@@ -170,23 +170,28 @@ DW_DEV uint32_t pair_tail_len(int32_t x0, int32_t x1, const NameCounts &n, uint6
          + ndigits10((uint32_t)n.e0) + 1 + ndigits10((uint32_t)n.u0) + 1 + ndigits10((uint32_t)n.i0) + 1
          + ndigits10((uint32_t)n.e1) + 1 + ndigits10((uint32_t)n.u1) + 1 + ndigits10((uint32_t)n.i1) + 1 + ndigits16(ii);
 }
-// ---- quality normals (dwgsim.c:156-175 ran_normal, :912): the integer offset (int)(nrm * sigma + 0.5) of two bases from one
-// Philox block = two polar tries (narrow uniforms).  EXACT form: fp64 arithmetic in the reference's evaluation order. ----
-// Returns false when both tries are rejected; k0 belongs to the first normal of the pair (v2 * fac, dwgsim.c:170), k1 to the cached one.
-DW_DEV bool quality_pair_exact(const U4 &blk, double sigma, int32_t &k0, int32_t &k1)
+// ---- quality normals (dwgsim.c:156-175 ran_normal, :912): the integer offsets (int)(nrm * sigma + 0.5) that one Philox block delivers.
+// The polar tries of a read's quality string form one sequential stream: try t = words 2 (t & 1), 2 (t & 1) + 1 of block t >> 1 (narrow
+// uniforms); an accepted try delivers two normals, v2 * fac first and the cached v1 * fac second (dwgsim.c:170-174).  A block = tries a, b.
+// EXACT form: fp64 arithmetic in the reference's evaluation order.  acc bit 0 / 1: try a / b accepted; k[0], k[1] = offsets of try a,
+// k[2], k[3] of try b. ----
+DW_DEV void quality_try_exact(uint32_t w1, uint32_t w2, double sigma, bool &ok, int32_t &k0, int32_t &k1)
 {
-    // v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
-    const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0;
-    const double b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
-    const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
-    const bool oka = !(ra >= 1.0 || ra == 0.0), okb = !(rb >= 1.0 || rb == 0.0);
-    if (!oka && !okb) return false;
-    const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
+    const double v1 = (double)w1 * 0x1p-31 - 1.0, v2 = (double)w2 * 0x1p-31 - 1.0;          // v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
+    const double rsq = v1 * v1 + v2 * v2;
+    ok = !(rsq >= 1.0 || rsq == 0.0);
+    if (!ok) return;
     // rsq is a multiple of 2^-62 in (0, 1): -2 log(rsq) in [2^-52, 86], the quotient in [2^-52, 2^69] -- the range-restricted forms apply
     const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
     k0 = (int32_t)(((v2 * fac) * sigma) + 0.5);
     k1 = (int32_t)(((v1 * fac) * sigma) + 0.5);
-    return true;
+}
+DW_DEV uint32_t quality_block_exact(const U4 &blk, double sigma, int32_t (&k)[4])
+{
+    bool oka, okb;
+    quality_try_exact(blk.x, blk.y, sigma, oka, k[0], k[1]);
+    quality_try_exact(blk.z, blk.w, sigma, okb, k[2], k[3]);
+    return (oka ? 1u : 0u) | (okb ? 2u : 0u);
 }
 // LAZY form -- same results, a fraction of the work.  The only consumer of a quality normal is the truncation (int)(nrm * sigma + 0.5), so
 // an estimate y of x = nrm * sigma + 0.5 with a PROVEN bound |y - x| < eps decides the integer whenever y is further than eps from every
@@ -194,33 +199,37 @@ DW_DEV bool quality_pair_exact(const U4 &blk, double sigma, int32_t &k0, int32_t
 // v_log_f32 / v_rcp_f32 / v_sqrt_f32, whose errors on the operand ranges used here are established exhaustively on the device
 // (k_selftest_lazy: every float of the range).  Error budget (DESIGN.md "Lazy quality normals"): with s = w ^ 2^31 as int32 (v = s * 2^-31),
 //   R = fl(s1)^2 + fl(s2)^2 in fp32 has relative error <= 2^-22  =>  accept / reject is certain unless R lies within 2^-20 of 2^62;
-//   L' = -log2(R * 2^-62) has absolute error a <= 1.44 * 2^-22 (from R) + 2^-22 max(1, L') (v_log_f32, measured < 2^-23 (1 + L'));
-//   for L' >= 2^-10 that moves sqrt(L') by at most a / (2 sqrt L') <= 2^-16.7, i.e. nrm = v sqrt(2 ln 2 L' / r) by <= 1.1e-5 (|v| <= sqrt r);
-//   everything else is relative: v_rcp_f32 and v_sqrt_f32 (each measured < 2^-22), three multiplies, the conversions, the constant:
-//   < 2^-20.5 in all, times |nrm| <= 9.3: 6.3e-6.  So |est(nrm) - nrm| <= 1.8e-5 and |y - x| <= sigma * 1.8e-5 + the rounding of the last fma:
-//   eps = sigma * 2^-14 + 2^-18 leaves 3.4x room (k_selftest_lazy measures the largest |y - x| / eps on the device: 0.2);
-//   L' < 2^-10 means |nrm| < 0.0373: the offset is 0 without further work when sigma < 12 (|nrm * sigma| < 0.45), else the exact path runs.
-struct QualLazy { float k, eps; int32_t near1_zero; };
-DW_DEV int quality_pair_lazy(const U4 &blk, const QualLazy &ql, int32_t &k0, int32_t &k1)      // 0: both tries rejected, 1: done, 2: take the exact path
+//   L' = -log2(R * 2^-62) has absolute error a <= 1.44 * 2^-22 (from R) + 2^-23 (1 + L') (v_log_f32, measured on every float), <= 1.22 * 2^-21 for L' <= 1;
+//   for L' >= Lmin that moves sqrt(L') by at most a / (2 sqrt Lmin), i.e. nrm = v sqrt(2 ln 2 L' / r) by <= 3.4e-7 / sqrt(Lmin) (|v| <= sqrt r);
+//   everything else is relative: v_rcp_f32 and v_sqrt_f32 (each measured < 2^-23), three multiplies, the conversions, the constant, the
+//   relative error of L' above 1: < 2^-20.3 in all, times |nrm| <= 9.3: 7.2e-6.  So |y - x| <= sigma (3.4e-7 / sqrt(Lmin) + 7.2e-6) + the rounding of
+//   the last fma; eps = 1.5 x that + 2^-18 (host: lazy_quality_params), and k_selftest_lazy measures the largest |y - x| / eps on the device;
+//   L' < Lmin means |nrm| < sqrt(2 ln 2 Lmin): Lmin is chosen by the host so that |nrm * sigma| < 0.45 there -- the offset is 0 without
+//   further work (near1_zero) -- or, for a large sigma, Lmin = 2^-10 and the exact path runs.
+struct QualLazy { float k, eps, lmin; int32_t near1_zero; };
+DW_DEV int quality_try_lazy(float x1, float x2, float R, const QualLazy &ql, int32_t &k0, int32_t &k1)      // 0: rejected, 1: accepted + decided, 2: take the exact path
 {
-    const float xa1 = (float)(int32_t)(blk.x ^ 0x80000000u), xa2 = (float)(int32_t)(blk.y ^ 0x80000000u);
-    const float xb1 = (float)(int32_t)(blk.z ^ 0x80000000u), xb2 = (float)(int32_t)(blk.w ^ 0x80000000u);
-    const float Ra = __builtin_fmaf(xa1, xa1, xa2 * xa2), Rb = __builtin_fmaf(xb1, xb1, xb2 * xb2);     // r * 2^62
     const float LO = 0x1p62f * (1.0f - 0x1p-20f), HI = 0x1p62f * (1.0f + 0x1p-20f);
-    const bool acc_a = Ra < LO && Ra != 0.0f, rej_a = Ra >= HI || Ra == 0.0f;        // R == 0 only for s1 = s2 = 0, which converts exactly
-    const bool acc_b = Rb < LO && Rb != 0.0f, rej_b = Rb >= HI || Rb == 0.0f;
-    if (!acc_a && !rej_a) return 2;                                                   // try a sits in the band around 1
-    if (rej_a && !acc_b) return rej_b ? 0 : 2;
-    const float x1 = acc_a ? xa1 : xb1, x2 = acc_a ? xa2 : xb2, R = acc_a ? Ra : Rb;
+    if (R >= HI || R == 0.0f) return 0;                                               // R == 0 only for s1 = s2 = 0, which converts exactly
+    if (!(R < LO)) return 2;                                                          // the band around 1
     const float rt = R * 0x1p-62f;                                                    // exact scaling, in [2^-62, 1)
     const float Lp = -__builtin_amdgcn_logf(rt);                                      // v_log_f32 (log2)
-    if (Lp < 0x1p-10f) { if (!ql.near1_zero) return 2; k0 = k1 = 0; return 1; }
+    if (Lp < ql.lmin) { if (!ql.near1_zero) return 2; k0 = k1 = 0; return 1; }
     const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
     const float y0 = __builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = __builtin_fmaf(x1 * f, ql.k, 0.5f);
     const float d0 = __builtin_fabsf(y0 - __builtin_rintf(y0)), d1 = __builtin_fabsf(y1 - __builtin_rintf(y1));
     if (!(d0 >= ql.eps && d1 >= ql.eps)) return 2;                                    // (also catches an infinite eps: sigma out of the fp32 path's range)
     k0 = (int32_t)y0; k1 = (int32_t)y1;
     return 1;
+}
+DW_DEV bool quality_block_lazy(const U4 &blk, const QualLazy &ql, int32_t (&k)[4], uint32_t &acc)      // false: take the exact path for the block
+{
+    const float xa1 = (float)(int32_t)(blk.x ^ 0x80000000u), xa2 = (float)(int32_t)(blk.y ^ 0x80000000u);
+    const float xb1 = (float)(int32_t)(blk.z ^ 0x80000000u), xb2 = (float)(int32_t)(blk.w ^ 0x80000000u);
+    const float Ra = __builtin_fmaf(xa1, xa1, xa2 * xa2), Rb = __builtin_fmaf(xb1, xb1, xb2 * xb2);     // r * 2^62
+    const int sa = quality_try_lazy(xa1, xa2, Ra, ql, k[0], k[1]), sb = quality_try_lazy(xb1, xb2, Rb, ql, k[2], k[3]);
+    acc = (sa == 1 ? 1u : 0u) | (sb == 1 ? 2u : 0u);
+    return sa != 2 && sb != 2;
 }
 // Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qb = base quality per position
 // (positions >= nq reuse the last entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
@@ -232,28 +241,34 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
         for (int i = 0; i < n; ++i) { int32_t q = qb[i < nq ? i : nq - 1]; if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
         return;
     }
-    const QualLazy ql{p.q_k, p.q_eps, p.q_near1};
-    uint32_t m = 0; int pr = 0; const int np = (n + 1) >> 1;
-    while (pr < np) {
-        // (the two base qualities are fetched before the arithmetic that hides their latency)
-        const int i0 = 2 * pr, i1 = 2 * pr + 1;
-        const int32_t qb0 = qb[i0 < nq ? i0 : nq - 1], qb1 = qb[i1 < nq ? i1 : nq - 1];
-        const U4 blk = rng_block(key, dom, ii, att, m, (uint32_t)pr);
-        int32_t k0 = 0, k1 = 0;
-        int st = quality_pair_lazy(blk, ql, k0, k1);
-        if (st == 2) st = quality_pair_exact(blk, p.quality_std, k0, k1) ? 1 : 0;
-        if (st == 0) { ++m; continue; }
+    const QualLazy ql{p.q_k, p.q_eps, p.q_lmin, p.q_near1};
+    int pos = 0; uint32_t t = 0;
+    while (pos < n) {
+        // (the base qualities the block may need are fetched before the arithmetic that hides their latency)
+        int32_t qbv[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int i = 2 * pr + h;
-            if (i < n) {
-                int32_t q = (int8_t)((h ? qb1 : qb0) + (h ? k1 : k0));
-                if (q < 33) q = 33;
-                if (q > 73) q = 73;
-                emit(i, (uint32_t)q);
+        for (int h = 0; h < 4; ++h) { const int i = pos + h; qbv[h] = qb[i < nq ? i : nq - 1]; }
+        const U4 blk = rng_block(key, dom, ii, att, 0, t++);
+        int32_t k[4] = {0, 0, 0, 0}; uint32_t acc;
+        if (!quality_block_lazy(blk, ql, k, acc)) acc = quality_block_exact(blk, p.quality_std, k);
+        // try a, then try b: two offsets each, in order
+        int used = 0;
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr) {
+            if (!(acc & (1u << tr))) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = pos + used;
+                if (i < n) {
+                    int32_t q = (int8_t)((used == 0 ? qbv[0] : used == 1 ? qbv[1] : used == 2 ? qbv[2] : qbv[3]) + k[2 * tr + h]);
+                    if (q < 33) q = 33;
+                    if (q > 73) q = 73;
+                    emit(i, (uint32_t)q);
+                }
+                ++used;
             }
         }
-        ++pr; m = 0;
+        pos += used;
     }
 }
 
@@ -328,8 +343,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // overlaps with that work instead of idling three waves)
     PH_MARK(1);     // placement + base extraction
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
-    // narrow draws: one Philox block tests four bases; an error marks bit 3 of the base's nibble and its
-    // substituted base is drawn afterwards, only for the (few) marked bases
+    // 16-bit draws: one Philox block tests eight bases (the low half of a uniform is drawn lazily, see below); an error marks bit 3 of
+    // the base's nibble and its substituted base is drawn afterwards, only for the (few) marked bases
     int32_t n_err = 0;
     int s_out = s;                              // read length after errors (changes only for Ion Torrent)
     bool flow_reversed = false;
@@ -353,16 +368,16 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         for (int w = 0; w < nw; ++w) {
             uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
             if (!is_rand) { ta = *reinterpret_cast<const uint4 *>(thr + 8 * w); tb = *reinterpret_cast<const uint4 *>(thr + 8 * w + 4); }
-            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w));
-            const U4 q1 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(2 * w + 1));
-            const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            // 16-bit draws, eight per Philox block: halfword b of block w is the HIGH half of base 8w + b's 32-bit uniform, moved to the top of a word
+            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)w);
+            const uint32_t hw[8] = {q0.x << 16, q0.x & 0xFFFF0000u, q0.y << 16, q0.y & 0xFFFF0000u, q0.z << 16, q0.z & 0xFFFF0000u, q0.w << 16, q0.w & 0xFFFF0000u};
             const int rem = s - 8 * w;
             const uint32_t live = rem >= 8 ? 0xFFFFFFFFu : ((1u << (4 * rem)) - 1u);      // nibbles of bases i < s
             uint32_t word;
             if (is_rand) {                                                      // random read: base = (int)(u * 4.0) & 3 (dwgsim.c:999-1001)
                 word = 0;
 #pragma unroll
-                for (int b = 0; b < 8; ++b) word |= (rw[b] >> 30) << (4 * b);
+                for (int b = 0; b < 8; ++b) word |= (hw[b] >> 30) << (4 * b);
             } else word = lds[w * nthr];
             if (DT == 1) {                                                      // colour = __gf_add(previous base, base): dwgsim.h:6, dwgsim.c:845-858 / :1022-1032
                 const uint32_t prevw = (word << 4) | prev_base;
@@ -373,11 +388,20 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                 const uint32_t n4 = word & 0x44444444u;                         // if (c >= 4) c = 4 (dwgsim.c:235)
                 word &= ~((n4 >> 1) | (n4 >> 2));
             }
-            if (!is_rand) {                                                     // drand48() < e[i]  <=>  w < thr[i]; an error marks bit 3 of the nibble
+            if (!is_rand) {                                                     // drand48() < e[i]  <=>  u32 < thr[i]; an error marks bit 3 of the nibble
                 const uint32_t t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-                uint32_t hits = 0;
+                // u32 = high half | low half.  With the low half taken as 0: (high < thr) is the answer unless the high halves of u32 and thr are
+                // equal -- probability 2^-16 per base -- and only then is the low half drawn (halfword b of the D_BASE_REF0 stream's block w)
+                uint32_t hits = 0, closest = 0xFFFFFFFFu;
 #pragma unroll
-                for (int b = 0; b < 8; ++b) hits |= (rw[b] < t[b]) ? (8u << (4 * b)) : 0u;
+                for (int b = 0; b < 8; ++b) { hits |= (hw[b] < t[b]) ? (8u << (4 * b)) : 0u; const uint32_t x = hw[b] ^ t[b]; closest = x < closest ? x : closest; }
+                if (closest < 0x10000u) {
+                    const U4 r0 = rng_block(key, D_BASE_REF0 + (uint32_t)j, ii, att, 0, (uint32_t)w);
+                    const uint32_t lw[8] = {r0.x & 0xFFFFu, r0.x >> 16, r0.y & 0xFFFFu, r0.y >> 16, r0.z & 0xFFFFu, r0.z >> 16, r0.w & 0xFFFFu, r0.w >> 16};
+                    hits = 0;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) hits |= ((hw[b] | lw[b]) < t[b]) ? (8u << (4 * b)) : 0u;
+                }
                 if (a.e_full) {
 #pragma unroll
                     for (int b = 0; b < 8; ++b) hits |= (t[b] == 0xFFFFFFFFu) ? (8u << (4 * b)) : 0u;
@@ -591,13 +615,13 @@ __global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n
         atomicAdd((unsigned long long *)&mism[3], (unsigned long long)s3);
     }
 }
-// Self-test of the lazy quality normals.  mode 0: n blocks drawn as the quality path draws them -- every decision of quality_pair_lazy is
-// compared with quality_pair_exact; out[0] = offsets that differ, out[1] = accept / reject verdicts that differ, out[2] = blocks the lazy form
+// Self-test of the lazy quality normals.  mode 0: n blocks drawn as the quality path draws them -- every decision of quality_block_lazy is
+// compared with quality_block_exact; out[0] = offsets that differ, out[1] = accept / reject verdicts that differ, out[2] = blocks the lazy form
 // decided, out[3] = blocks it handed to the exact path, out[4] = blocks, out[5] = max |y - x| / eps (double bits; estimate against the exact
 // fp64 value, over decided values).  mode 1 / 2 / 3: EVERY float of the operand range of v_log_f32 ([2^-62, 1)), v_rcp_f32 (same) and
-// v_sqrt_f32 ([2^-11, 2^70)) against fp64: out[6] = max |log2_hw - log2| / (2^-23 (1 + |log2|)), out[7], out[8] = max relative error / 2^-22.
+// v_sqrt_f32 ([2^-11, 2^70)) against fp64: out[6] = max |log2_hw - log2| / (2^-23 (1 + |log2|)), out[7], out[8] = max relative error / 2^-23.
 DW_DEV void atomic_max_pos_double(uint64_t *p, double v) { atomicMax((unsigned long long *)p, (unsigned long long)dbl_bits(v)); }
-__global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, uint64_t n, double sigma, uint64_t *out)
+__global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t bad_k = 0, bad_acc = 0, n_fast = 0, n_slow = 0, n_all = 0; double worst = 0.0;
@@ -605,30 +629,33 @@ __global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, 
         if (mode == 0) {
             const RngKey key{seed, 0u};
             const U4 blk = rng_block(key, 30, i, 0, 0, 0);
-            const QualLazy ql{(float)(sqrt(2.0 * 0.693147180559945309417) * 0x1p-31 * sigma), (float)(sigma * 0x1p-14 + 0x1p-18), sigma < 12.0 ? 1 : 0};
-            int32_t k0 = 0, k1 = 0, e0 = 0, e1 = 0;
-            const int st = quality_pair_lazy(blk, ql, k0, k1);
-            const bool ok = quality_pair_exact(blk, sigma, e0, e1);
+            const QualLazy ql{qk, qeps, qlmin, qnear1};
+            int32_t k[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}; uint32_t acc = 0;
+            const bool decided = quality_block_lazy(blk, ql, k, acc);
+            const uint32_t eacc = quality_block_exact(blk, sigma, e);
             n_all = 1;
-            if (st == 2) n_slow = 1;
+            if (!decided) n_slow = 1;
             else {
                 n_fast = 1;
-                if ((st == 1) != ok) bad_acc = 1;
-                else if (ok) {
-                    bad_k = (k0 != e0) + (k1 != e1);
-                    // the estimate itself against the exact fp64 value (recomputed here as the lazy form computes it)
-                    const double a1 = (double)blk.x * 0x1p-31 - 1.0, a2 = (double)blk.y * 0x1p-31 - 1.0, b1 = (double)blk.z * 0x1p-31 - 1.0, b2 = (double)blk.w * 0x1p-31 - 1.0;
-                    const double ra = a1 * a1 + a2 * a2, rb = b1 * b1 + b2 * b2;
-                    const bool oka = !(ra >= 1.0 || ra == 0.0);
-                    const double v1 = oka ? a1 : b1, v2 = oka ? a2 : b2, rsq = oka ? ra : rb;
-                    const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
-                    const float x1 = (float)(int32_t)((oka ? blk.x : blk.z) ^ 0x80000000u), x2 = (float)(int32_t)((oka ? blk.y : blk.w) ^ 0x80000000u);
-                    const float R = __builtin_fmaf(x1, x1, x2 * x2), rt = R * 0x1p-62f, Lp = -__builtin_amdgcn_logf(rt);
-                    if (!(Lp < 0x1p-10f)) {
-                        const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
-                        const double y0 = (double)__builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = (double)__builtin_fmaf(x1 * f, ql.k, 0.5f);
-                        const double d0 = fabs(y0 - ((v2 * fac) * sigma + 0.5)), d1 = fabs(y1 - ((v1 * fac) * sigma + 0.5));
-                        worst = (d0 > d1 ? d0 : d1) / (double)ql.eps;
+                if (acc != eacc) bad_acc = 1;
+                else {
+                    const uint32_t w[4] = {blk.x, blk.y, blk.z, blk.w};
+                    for (int tr = 0; tr < 2; ++tr) if (acc & (1u << tr)) {
+                        bad_k += (k[2 * tr] != e[2 * tr]) + (k[2 * tr + 1] != e[2 * tr + 1]);
+                        // the estimate itself against the exact fp64 value (recomputed here as the lazy form computes it)
+                        const double v1 = (double)w[2 * tr] * 0x1p-31 - 1.0, v2 = (double)w[2 * tr + 1] * 0x1p-31 - 1.0, rsq = v1 * v1 + v2 * v2;
+                        const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+                        const float x1 = (float)(int32_t)(w[2 * tr] ^ 0x80000000u), x2 = (float)(int32_t)(w[2 * tr + 1] ^ 0x80000000u);
+                        const float R = __builtin_fmaf(x1, x1, x2 * x2), rt = R * 0x1p-62f, Lp = -__builtin_amdgcn_logf(rt);
+                        if (!(Lp < ql.lmin)) {
+                            const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
+                            const double y0 = (double)__builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = (double)__builtin_fmaf(x1 * f, ql.k, 0.5f);
+                            const double d0 = fabs(y0 - ((v2 * fac) * sigma + 0.5)), d1 = fabs(y1 - ((v1 * fac) * sigma + 0.5));
+                            const double wv = (d0 > d1 ? d0 : d1) / (double)ql.eps;
+                            worst = wv > worst ? wv : worst;
+                        } else {     // "offset 0 without further work": the exact value must really truncate to 0
+                            bad_k += (e[2 * tr] != 0) + (e[2 * tr + 1] != 0);
+                        }
                     }
                 }
             }
@@ -637,8 +664,8 @@ __global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, 
             union { uint32_t u; float f; } c; c.u = first + (uint32_t)i;
             const double x = (double)c.f;
             if (mode == 1) { const double t = det_log(x) * 1.44269504088896340736; worst = fabs((double)__builtin_amdgcn_logf(c.f) - t) / (0x1p-23 * (1.0 + fabs(t))); }
-            else if (mode == 2) { const double t = 1.0 / x; worst = fabs((double)__builtin_amdgcn_rcpf(c.f) - t) / t / 0x1p-22; }
-            else { const double t = sqrt(x); worst = fabs((double)__builtin_amdgcn_sqrtf(c.f) - t) / t / 0x1p-22; }
+            else if (mode == 2) { const double t = 1.0 / x; worst = fabs((double)__builtin_amdgcn_rcpf(c.f) - t) / t / 0x1p-23; }
+            else { const double t = sqrt(x); worst = fabs((double)__builtin_amdgcn_sqrtf(c.f) - t) / t / 0x1p-23; }
         }
     }
     const uint32_t s0 = wave_sum_u32(bad_k), s1 = wave_sum_u32(bad_acc), s2 = wave_sum_u32(n_fast), s3 = wave_sum_u32(n_slow), s4 = wave_sum_u32(n_all);
@@ -651,9 +678,9 @@ __global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, 
     }
     if (worst > 0.0) atomic_max_pos_double(&out[mode == 0 ? 5 : 5 + mode], worst);
 }
-void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, uint64_t *out)
+void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out)
 {
-    hipLaunchKernelGGL(k_selftest_lazy, dim3(cdiv(n, 256)), dim3(256), 0, st, mode, seed, n, sigma, out);
+    hipLaunchKernelGGL(k_selftest_lazy, dim3(cdiv(n, 256)), dim3(256), 0, st, mode, seed, n, sigma, qk, qeps, qlmin, qnear1, out);
 }
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
 {

@@ -206,8 +206,9 @@ public:
         for (auto &c : cs) { lanes_[(size_t)lane].q.push_back(c); todo_.push_back(c); }
         cv_work_.notify_all(); cv_write_.notify_all();
     }
-    // this lane has nothing more for the current contig (the writer moves on to the next lane)
-    void end_lane(int lane) { std::unique_lock<std::mutex> lk(m_); lanes_[(size_t)lane].ends += 1; cv_write_.notify_all(); }
+    // this lane has nothing more for the current contig: an end mark IN the lane's queue (the lane may already be filling in the next
+    // contig's text behind it while the writer is still busy with other lanes)
+    void end_lane(int lane) { std::unique_lock<std::mutex> lk(m_); lanes_[(size_t)lane].q.push_back(nullptr); cv_write_.notify_all(); }
     void finish()
     {
         { std::unique_lock<std::mutex> lk(m_); if (stop_) return; stop_ = true; cv_work_.notify_all(); cv_write_.notify_all(); }
@@ -218,7 +219,7 @@ public:
     uint64_t bytes_out() const { return bytes_out_; }
 
 private:
-    struct Lane { std::deque<std::shared_ptr<Chunk>> q; std::vector<TextBuf *> free_bufs; int ends = 0; };
+    struct Lane { std::deque<std::shared_ptr<Chunk>> q; std::vector<TextBuf *> free_bufs; };       // q: chunks in order, nullptr = end of the lane's share of a contig
     void work()
     {
         for (;;) {
@@ -239,16 +240,16 @@ private:
     void write_loop()
     {
         size_t lane = 0;                           // lanes are drained in order, contig after contig
-        std::vector<int> consumed_ends(lanes_.size(), 0);
         for (;;) {
             std::shared_ptr<Chunk> c;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 for (;;) {
                     Lane &L = lanes_[lane];
-                    if (!L.q.empty()) { if (L.q.front()->done) { c = L.q.front(); L.q.pop_front(); break; } }
-                    else if (L.ends > consumed_ends[lane]) { consumed_ends[lane] += 1; lane = (lane + 1) % lanes_.size(); continue; }
-                    else if (stop_) {              // shutting down (possibly after an error that left a lane without its end mark): drain what there is
+                    if (!L.q.empty()) {
+                        if (!L.q.front()) { L.q.pop_front(); lane = (lane + 1) % lanes_.size(); continue; }      // end mark: on to the next lane
+                        if (L.q.front()->done) { c = L.q.front(); L.q.pop_front(); break; }
+                    } else if (stop_) {            // shutting down (possibly after an error that left a lane without its end mark): drain what there is
                         bool any = false; for (auto &x : lanes_) if (!x.q.empty()) any = true;
                         if (!any) return;
                         lane = (lane + 1) % lanes_.size(); continue;

@@ -57,15 +57,18 @@ enum {
     D_PAIR = 4,        /* index = ii; slot 0 rand-read test, 1 haplotype, 2 strand */
     D_PLACE = 5,       /* index = ii; slot t = position uniform of placement try t */
     D_PLACE_NORM = 6,  /* index = ii; block t = polar tries of placement try t */
-    D_BASE0 = 8,       /* +j; index = ii; NARROW (32-bit) uniforms: word i = error test of base i / random-read base i */
-    D_QUAL0 = 10,      /* +j; index = ii; NARROW: block p holds two polar tries (words 0,1 and 2,3) per retry index;
-                          the accepted try gives quality normals 2p (v2*fac) and 2p+1 (v1*fac) */
+    D_BASE0 = 8,       /* +j; index = ii; 16-bit draws, eight per block: halfword i (block i >> 3, word (i & 7) >> 1, low half first) = the HIGH half of
+                          the 32-bit uniform of base i (error test / random-read base); the low half is halfword i of D_BASE_REF0 + j */
+    D_QUAL0 = 10,      /* +j; index = ii; NARROW: the sequential stream of polar tries of the read's quality normals -- try t = words
+                          2 (t & 1), 2 (t & 1) + 1 of block t >> 1; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
     D_FLOW0 = 12,      /* +j; index = ii; NARROW: word = running draw count inside generate_errors_flows */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
     D_FLOW_PASS2 = 8,  /* added to D_FLOW0 / D_CALIB (+j) for the second pass of generate_errors_flows: domains 20-23 */
     D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
     D_MUTIN = 18,      /* mutation-input files (-b): index = entry ordinal; slot 0 hom test, 1 het haplotype (mut.c:662-669) */
-    D_MUTIN_BASE = 19  /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
+    D_MUTIN_BASE = 19, /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
+    D_BASE_REF0 = 24   /* +j; index = ii; halfword i = the LOW half of the 32-bit uniform of base i (it only matters when the high half alone
+                          does not decide u < e, i.e. with probability 2^-16: the kernels draw it lazily) */
 };
 
 typedef struct {
@@ -162,6 +165,24 @@ static inline double rng_u32(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att,
     return oracle_philox_uniform32(r->k0, r->k1, dom, idx, att, retry, slot);
 }
 
+/* The uniform of base i of read end j (error test dwgsim.c:237, random-read base :1000).  Mode B: 32 bits, u = ((h << 16) | l) * 2^-32 with
+ * h = halfword i of the D_BASE0 + j stream and l = halfword i of the D_BASE_REF0 + j stream (eight 16-bit draws per Philox block). */
+static inline uint32_t philox_halfword(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t i)
+{
+    uint32_t ctr[4], key[2], w[4];
+    ctr[0] = (uint32_t)idx; ctr[1] = (uint32_t)((idx >> 32) & 0xFFFFu); ctr[2] = (dom << 24) | (att & 0xFFFFFFu); ctr[3] = i >> 3;
+    key[0] = r->k0; key[1] = r->k1;
+    oracle_philox4x32_10(ctr, key, w);
+    return (w[(i & 7) >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+}
+static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
+    const uint32_t h = philox_halfword(r, D_BASE0 + (uint32_t)j, idx, att, i), l = philox_halfword(r, D_BASE_REF0 + (uint32_t)j, idx, att, i);
+    return (double)((h << 16) | l) * 0x1p-32;
+}
+
 /* Deterministic natural log for x > 0 finite: the classic fdlibm/FreeBSD-msun e_log.c
  * algorithm (argument reduction x = 2^k (1+f), s = f/(2+f), degree-14 even polynomial in s)
  * restated with only IEEE + - * / in fp64, so gcc/x86-64 and hipcc/gfx950 (both compiled
@@ -201,9 +222,11 @@ double oracle_det_log(double x)
     return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
-/* A stream of normals.  Mode A ignores it (global cache + sequential draws).  Mode B: polar
+/* A stream of normals.  Mode A ignores it (global cache + sequential draws).  Mode B, wide (placement): polar
  * tries r = 0,1,.. of block p; the accepted try gives normal 2p (= v2*fac) and, if `cache`,
- * normal 2p+1 (= v1*fac); p advances after every accepted try. */
+ * normal 2p+1 (= v1*fac); p advances after every accepted try.  Mode B, narrow (quality strings): the tries form ONE sequential
+ * stream t = 0,1,2,.. (field p counts tries): try t = words 2 (t & 1), 2 (t & 1) + 1 of block t >> 1 -- the reference's own
+ * consumption pattern (a rejected try costs two uniforms, an accepted one delivers two normals) with Philox words as the uniforms. */
 typedef struct { uint32_t dom; uint64_t idx; uint32_t att; uint32_t p; int cache; int has; double g; int narrow; } nstream_t;
 
 /* dwgsim.c:156-175 ran_normal(): Marsaglia polar method */
@@ -215,9 +238,10 @@ static double ran_normal(rng_t *r, nstream_t *ns)
         double v1, v2, rsq, fac, lg;
         uint32_t retry = 0;
         do {
-            if (ns->narrow) { /* two tries per Philox block: try `retry` uses words 2*(retry&1), +1 of block p, retry index retry>>1 */
-                v1 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, retry >> 1, 4 * ns->p + 2 * (retry & 1)) - 1.0;
-                v2 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, retry >> 1, 4 * ns->p + 2 * (retry & 1) + 1) - 1.0;
+            if (ns->narrow) {
+                v1 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, 0, 2 * ns->p) - 1.0;
+                v2 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, 0, 2 * ns->p + 1) - 1.0;
+                ns->p++;
             } else {
                 v1 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p) - 1.0;
                 v2 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p + 1) - 1.0;
@@ -230,7 +254,7 @@ static double ran_normal(rng_t *r, nstream_t *ns)
         fac = sqrt(-2.0 * lg / rsq);
         *gset = v1 * fac;
         *iset = (r->mode == RNG_DRAND48) ? 1 : ns->cache;
-        ns->p++;
+        if (!ns->narrow) ns->p++;
         return v2 * fac;
     }
     *iset = 0;
@@ -1376,7 +1400,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                         for (; 0 <= i && i < s[j]; i += step) {
                             uint8_t c = tb[j].seq[i];
                             if (c >= 4) c = 4;
-                            else if (rng_u32(r, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i) < o->e[j].start + o->e[j].by * i) {
+                            else if (rng_base_u(r, j, ii, att, (uint32_t)i) < o->e[j].start + o->e[j].by * i) {
                                 c = (uint8_t)((c + (uint64_t)(rng_u32(r, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 3.0 + 1)) & 3);
                                 ++n_err[j];
                                 if (0 == i) ++n_err_first[j];
@@ -1399,7 +1423,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                     const int in_win = o->emit_count < 0 || ((int64_t)ii >= o->emit_first && (int64_t)ii < o->emit_first + o->emit_count);
                     for (int j = 0; j < 2 && in_win; ++j) {
                         if (s[j] <= 0) continue;
-                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_u32(r, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 4.0) & 3);
+                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_base_u(r, j, ii, att, (uint32_t)i) * 4.0) & 3);
                         make_quals(o, r, j, ii, att, s[j], qstr);
                         if (SOLID == o->data_type) to_colors(tb[j].seq, s[j]);
                         emit_read(o, out, j, "rand", 0, 0, 0, 0, 1, 1, zero6, zero6, rand_ii, tb[j].seq, s[j], qstr);

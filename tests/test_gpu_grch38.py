@@ -37,7 +37,7 @@ def genome():
 
 class _DevView:
     def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
 def _dev_tensor(ptr, n):
