@@ -47,7 +47,7 @@ EXPORTS = [
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
-    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option",
+    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def load(path: str | None = None):
     lib.dwgsim_hip_shard_range.restype = None
     lib.dwgsim_hip_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.dwgsim_hip_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.dwgsim_hip_debug_count_byte.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_uint64)]
     if path is None:
         _lib = lib
     return lib
@@ -314,6 +315,18 @@ class Context:
 
     def set_fail_carry(self, carry: int):
         self._chk(self.lib.dwgsim_hip_set_fail_carry(self.h, carry))
+
+    def count_byte(self, slot: int, stream: int, byte: int) -> int:
+        n = C.c_uint64(0)
+        self._chk(self.lib.dwgsim_hip_debug_count_byte(self.h, slot, stream, byte, C.byref(n)))
+        return n.value
+
+    def fetch_np(self, slot: int, stream: int, nbytes: int):
+        """The stream as a numpy uint8 array (page-locked staging inside the library)."""
+        import numpy as np
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        self._chk(self.lib.dwgsim_hip_fetch(self.h, slot, stream, out.ctypes.data_as(C.c_void_p), int(nbytes)))
+        return out
 
     def debug_option(self, key: str, value: int):
         self._chk(self.lib.dwgsim_hip_debug_option(self.h, key.encode(), value))

@@ -1053,6 +1053,21 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, 
     return DWGSIM_HIP_OK;
 }
 
+// Test / analysis hook (not part of the drop-in surface): occurrences of `byte` in one finished stream of a waited-for slot, counted on the device.
+int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *c, int slot, int stream, int byte, uint64_t *count)
+{
+    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || !count) return DWGSIM_HIP_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    Slot &sl = c->slot[slot];
+    if (sl.pending) { c->err = "count_byte: wait for the batch first"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipMemsetAsync(&c->d_counters[15], 0, sizeof(uint64_t), c->stream));
+    if (sl.out_bytes[stream]) launch_count_byte(c->stream, (const uint8_t *)c->out[slot][stream].p, sl.out_bytes[stream], (uint32_t)(byte & 0xff), &c->d_counters[15]);
+    HIPC(c, hipMemcpyAsync(&c->h_counters[15], &c->d_counters[15], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    *count = c->h_counters[15];
+    return DWGSIM_HIP_OK;
+}
+
 // Test / analysis hooks (not part of the drop-in surface): "justify_seq" = 1 runs the left-justification from one thread (cross-check),
 // "walk_cap" = n starts the mutation walk with a capacity of n candidates and a 1-byte inserted-base pool (exercises the exact re-run),
 // "phases" = 1 prints the phase split of the -DDW_PHASE_TIMING analysis build.

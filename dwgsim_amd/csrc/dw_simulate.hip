@@ -779,6 +779,26 @@ void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int s
 {
     hipLaunchKernelGGL(k_chain_set, dim3(1), dim3(64), 0, st, chain, rand_base, set_rand, carry, set_carry);
 }
+// test / analysis hook: how many bytes of text[0 .. n) equal `byte` (size-independent checks of whole outputs without copying them out)
+__global__ void __launch_bounds__(256) k_count_byte(const uint8_t *__restrict__ text, uint64_t n, uint32_t byte, uint64_t *out)
+{
+    const uint32_t pat = byte * 0x01010101u;
+    uint32_t cnt = 0;
+    const uint64_t nvec = n / 16;
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * 256) {
+        const uint4 q = reinterpret_cast<const uint4 *>(text)[v];
+        const uint32_t w[4] = {q.x ^ pat, q.y ^ pat, q.z ^ pat, q.w ^ pat};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt += (uint32_t)__popc(~(((w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[k] | 0x7F7F7F7Fu));      // zero bytes of w[k]
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (uint64_t q = nvec * 16; q < n; ++q) cnt += text[q] == byte;
+    const uint32_t s = wave_sum_u32(cnt);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long *)out, (unsigned long long)s);
+}
+void launch_count_byte(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t byte, uint64_t *out)
+{
+    hipLaunchKernelGGL(k_count_byte, dim3(4096), dim3(256), 0, st, text, n, byte, out);
+}
 void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ)
 {
     const uint64_t nb = (uint64_t)(l + SUMM_CELLS - 1) / SUMM_CELLS;

@@ -290,8 +290,12 @@ static void on_all(int n, const std::function<void(int)> &fn)
     for (auto &t : th) t.join();
 }
 
+static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
 int main(int argc, char **argv)
 {
+    const double t_start = now_s();
+    const bool timing = getenv("DWGSIM_HIP_TIMING") != nullptr;      // stage times on stderr
     dwgsim_hip_params_t o; dwgsim_hip_params_default(&o);
     std::string prefix_s, fixedq_s, flow_s, regions_fn, muts_fn; int muts_type = -1, muts_flags = 0;
     int c;
@@ -363,6 +367,7 @@ int main(int argc, char **argv)
     const char *fn_fa = argv[optind], *out_prefix = argv[optind + 1];
     Fasta fa;
     if (!read_fasta(fn_fa, fa)) return 1;
+    const double t_fasta = now_s();
     uint64_t tot_len = 0;
     for (size_t i = 0; i < fa.seqs.size(); ++i) { fprintf(stderr, "[dwgsim_core] %s length: %d\n", fa.names[i].c_str(), (int)fa.seqs[i].size()); tot_len += fa.seqs[i].size(); }
     fprintf(stderr, "[dwgsim_core] %d sequences, total length: %llu\n", (int)fa.seqs.size(), (unsigned long long)tot_len);
@@ -410,6 +415,8 @@ int main(int argc, char **argv)
         if (out->failed()) { destroy_all(); return 1; }
     }
 
+    const double t_ctx = now_s();
+    double t_walk = 0, t_sim = 0;
     int64_t n_sim = 0; uint64_t rand_ii = 0, ctr = 0; int n_ref = (int)fa.seqs.size(), prev_skip = 0;
     std::atomic<int> rc{0};
     std::mutex err_m;
@@ -441,6 +448,7 @@ int main(int argc, char **argv)
         int nd = ND;
         while (nd > 1 && (uint64_t)n_pairs / (uint64_t)nd < min_share) --nd;
         std::vector<int> cid((size_t)nd, -1);
+        const double t_c0 = now_s();
         on_all(nd, [&](int d) {
             dwgsim_hip_ctx_t *x = ctx[(size_t)d];
             cid[(size_t)d] = dwgsim_hip_add_contig(x, name, fa.seqs[ci].data(), l, (uint32_t)ci);
@@ -452,6 +460,7 @@ int main(int argc, char **argv)
             if (dwgsim_hip_mutations_text(ctx[0], cid[0], &t, &tl, &v, &vl) < 0) fail((std::string("dwgsim-hip: ") + dwgsim_hip_last_error(ctx[0])).c_str());
             else { fwrite(t, 1, tl, fp_txt); fwrite(v, 1, vl, fp_vcf); }
         }
+        const double t_c1 = now_s(); t_walk += t_c1 - t_c0;
         if (rc == 0 && want_reads) {
             // read-index ranges, in order; rand_ii offsets from one integer per range (dwgsim.c:1042,1096)
             std::vector<uint64_t> first((size_t)nd), cnt((size_t)nd), rnd((size_t)nd, 0), rbase((size_t)nd, rand_ii);
@@ -508,10 +517,17 @@ int main(int argc, char **argv)
             n_sim += n_pairs; ctr += (uint64_t)n_pairs;
             fprintf(stderr, "\r[dwgsim_core] %llu", (unsigned long long)ctr);
         }
+        t_sim += now_s() - t_c1;
         for (int d = 0; d < nd; ++d) if (cid[(size_t)d] >= 0) dwgsim_hip_drop_contig(ctx[(size_t)d], cid[(size_t)d]);
     }
+    const double t_gpu_done = now_s();
     if (out) { out->finish(); if (out->failed() && rc == 0) { fprintf(stderr, "dwgsim-hip: writing FASTQ failed\n"); rc = 1; } }
+    const double t_out_done = now_s();
     fprintf(stderr, "\n[dwgsim_core] Complete!\n");
+    if (timing) fprintf(stderr, "[dwgsim-hip] read FASTA %.2f s | contexts, files, inputs %.2f s | upload + walk + mutation text %.2f s | simulate + copy (deflate running behind) %.2f s | "
+                                "drain deflate + write %.2f s | total %.2f s; text %.2f GB -> gz %.2f GB, %d device(s), %u deflate threads, zlib level %d\n",
+                        t_fasta - t_start, t_ctx - t_fasta, t_walk, t_sim, t_out_done - t_gpu_done, t_out_done - t_start,
+                        out ? out->bytes_in() / 1e9 : 0.0, out ? out->bytes_out() / 1e9 : 0.0, ND, nthreads, gz_level);
     destroy_all();
     out.reset();
     if (fp_txt) fclose(fp_txt);

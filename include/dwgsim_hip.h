@@ -197,6 +197,8 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst
 
 /* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases" (see dw_host.cpp). */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
+/* ... and: occurrences of `byte` in one finished stream of a slot, counted on the device (whole-output checks without a copy-out). */
+int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int byte, uint64_t *count);
 
 /* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);
