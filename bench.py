@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the host_landed / end_to_end legs")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
+    ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
     args = ap.parse_args()
 
@@ -200,6 +201,8 @@ def main():
     paired = params.length[1] > 0
 
     ctx = api.Context(params, dev, lib)
+    if args.phases:
+        ctx.debug_option("phases", 1)
     # the job: pairs per contig exactly as dwgsim_core schedules them (dwgsim.c:582-590); every contig stays resident
     job = []
     n_sim = 0

@@ -70,7 +70,7 @@ struct dwgsim_hip_ctx {
     double e_by[2] = {0, 0};
     uint64_t *d_thr[2] = {nullptr, nullptr};
     uint32_t *d_thr32[2] = {nullptr, nullptr}; int e_full = 0;
-    int8_t *d_qbase[2] = {nullptr, nullptr};
+    uint32_t *d_qbase[2] = {nullptr, nullptr}; int32_t qb_words = 1;
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Contig> contigs;
     // simulate() working set
@@ -337,7 +337,14 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 qb[(size_t)i] = (int8_t)q;
             }
             HIPC(c, hipMalloc((void **)&c->d_thr[j], sizeof(uint64_t) * (size_t)n));
-            HIPC(c, hipMalloc((void **)&c->d_qbase[j], (size_t)n));
+            {   // packed table: n entries, then the last one repeated (>= 4 copies), the same word count for both read ends
+                const int lmax = c->prm.length[0] > c->prm.length[1] ? c->prm.length[0] : c->prm.length[1];
+                c->qb_words = (lmax + 4 + 3) / 4 + 1;
+                std::vector<int8_t> padded((size_t)c->qb_words * 4, qb[(size_t)n - 1]);
+                memcpy(padded.data(), qb.data(), (size_t)n);
+                HIPC(c, hipMalloc((void **)&c->d_qbase[j], padded.size()));
+                HIPC(c, hipMemcpy(c->d_qbase[j], padded.data(), padded.size(), hipMemcpyHostToDevice));
+            }
             HIPC(c, hipMemcpy(c->d_thr[j], thr.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
             std::vector<uint32_t> t32(((size_t)n + 7) / 8 * 8, 0u);
             for (int i = 0; i < n; ++i) {
@@ -347,7 +354,6 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             if (c->e_full) for (int i = 0; i < n; ++i) if (thr[(size_t)i] == 0xFFFFFFFFull) { c->err = "an error rate within 2^-32 of (but not equal to) 1 next to one equal to 1 is not representable"; return -1; }
             HIPC(c, hipMalloc((void **)&c->d_thr32[j], sizeof(uint32_t) * t32.size()));
             HIPC(c, hipMemcpy(c->d_thr32[j], t32.data(), sizeof(uint32_t) * t32.size(), hipMemcpyHostToDevice));
-            HIPC(c, hipMemcpy(c->d_qbase[j], qb.data(), (size_t)n, hipMemcpyHostToDevice));
         }
         // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 256 bytes in LDS)
         std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";
@@ -808,7 +814,8 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.c = contig_dev(k);
     a.first_ii = first_ii; a.n_pairs = n_pairs; a.chain = c->d_chain;
     a.l_place = k.l_place; a.have_regions = c->has_regions ? 1 : 0; a.n_reg = k.n_reg; a.reg_start = k.d_reg; a.reg_end = k.d_reg ? k.d_reg + k.n_reg : nullptr;
-    for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.e_thr32[j] = c->d_thr32[j]; a.qbase[j] = c->d_qbase[j]; }
+    for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.e_thr32[j] = c->d_thr32[j]; a.qbase[j] = c->d_qbase[j] ? c->d_qbase[j] : c->d_qbase[0]; }
+    a.qb_words = c->qb_words;
     a.e_full = c->e_full;
     a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
     a.summ[0] = k.d_summ[0]; a.summ[1] = k.d_summ[1];      // null unless count_random built them
@@ -816,10 +823,11 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     // lanes per k_simulate block: the staged read (lds_words per lane) must fit LDS; long Illumina / SOLiD reads get one-wave blocks
     const int lmax0 = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
     a.sim_threads = SIM_THREADS;
-    if (p.data_type != 2 && (size_t)((lmax0 + 7) / 8) * SIM_THREADS * 4 > SIM_LDS_BUDGET) {
+    auto lds_need = [&](int lanes) { return ((size_t)((lmax0 + 7) / 8) * (size_t)lanes + 2 * (size_t)c->qb_words) * 4; };     // staged bases + the two base-quality tables
+    if (p.data_type != 2 && lds_need(SIM_THREADS) > SIM_LDS_BUDGET) {
         a.sim_threads = SIM_THREADS_LONG;
-        if ((size_t)((lmax0 + 7) / 8) * SIM_THREADS_LONG * 4 > SIM_LDS_BUDGET) {
-            char b[160]; snprintf(b, sizeof b, "dwgsim-hip: reads longer than %d bases are not supported for -c 0 / -c 1\n", (int)(SIM_LDS_BUDGET / (SIM_THREADS_LONG * 4) * 8));
+        if (lds_need(SIM_THREADS_LONG) > SIM_LDS_BUDGET) {
+            char b[160]; snprintf(b, sizeof b, "dwgsim-hip: reads longer than %d bases are not supported for -c 0 / -c 1\n", (int)(SIM_LDS_BUDGET / (SIM_THREADS_LONG * 4 + 2) * 8));
             c->err = b; return DWGSIM_HIP_ERR_UNSUP;
         }
     }

@@ -98,7 +98,8 @@ struct SimArgs {
     const uint16_t *summ[2];       // k_place only (else null): per SUMM_CELLS cells of a haplotype, bits 0-7 = INSERT / DELETE cells, bit 15 = a base code >= 4
     const uint32_t *e_thr32[2];    // the same as 32-bit words, zero padded to a multiple of 8 entries; a threshold of 2^32 (e = 1) is stored as
     int32_t e_full;                // 0xFFFFFFFF and flagged here: those positions always err
-    const int8_t *qbase[2];        // per-position base quality characters (dwgsim.c:907), signed-char semantics
+    const uint32_t *qbase[2];      // per-position base quality characters (dwgsim.c:907; signed-char semantics) packed four to a word: len entries, then the last one
+    int32_t qb_words;              // repeated up to qb_words words (>= len + 4 entries, the same for both read ends); the kernel stages both tables in LDS
     const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"
     const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"
     uint32_t *meta;                // per pair: failed attempts | random read << 31 (input of the abort rule, k_failrule)

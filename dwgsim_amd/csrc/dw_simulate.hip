@@ -231,23 +231,26 @@ DW_DEV bool quality_block_lazy(const U4 &blk, const QualLazy &ql, int32_t (&k)[4
     acc = (sa == 1 ? 1u : 0u) | (sb == 1 ? 2u : 0u);
     return sa != 2 && sb != 2;
 }
-// Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qb = base quality per position
-// (positions >= nq reuse the last entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
+// Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qbw = the base quality characters per
+// position, staged in LDS as packed bytes: nq entries followed by at least four copies of the last one (positions >= nq reuse the last
+// entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
+DW_DEV uint32_t qbase4(const uint32_t *qbw, int nq, int pos)          // the four entries from pos on, as bytes
+{
+    const int pc = pos < nq ? pos : nq;
+    return __builtin_amdgcn_alignbyte(qbw[(pc >> 2) + 1], qbw[pc >> 2], (uint32_t)pc & 3u);
+}
 template <class F>
-DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const int8_t *qb, int nq, int n, F &&emit)
+DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const uint32_t *qbw, int nq, int n, F &&emit)
 {
     if (p.fixed_quality >= 0) { for (int i = 0; i < n; ++i) emit(i, (uint32_t)p.fixed_quality); return; }
     if (!(0 < p.quality_std)) {
-        for (int i = 0; i < n; ++i) { int32_t q = qb[i < nq ? i : nq - 1]; if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
+        for (int i = 0; i < n; ++i) { int32_t q = (int8_t)(qbase4(qbw, nq, i) & 0xffu); if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
         return;
     }
     const QualLazy ql{p.q_k, p.q_eps, p.q_lmin, p.q_near1};
     int pos = 0; uint32_t t = 0;
     while (pos < n) {
-        // (the base qualities the block may need are fetched before the arithmetic that hides their latency)
-        int32_t qbv[4];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) { const int i = pos + h; qbv[h] = qb[i < nq ? i : nq - 1]; }
+        const uint32_t qb4 = qbase4(qbw, nq, pos);           // the base qualities of the (up to four) positions this block can fill
         const U4 blk = rng_block(key, dom, ii, att, 0, t++);
         int32_t k[4] = {0, 0, 0, 0}; uint32_t acc;
         if (!quality_block_lazy(blk, ql, k, acc)) acc = quality_block_exact(blk, p.quality_std, k);
@@ -260,7 +263,7 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
             for (int h = 0; h < 2; ++h) {
                 const int i = pos + used;
                 if (i < n) {
-                    int32_t q = (int8_t)((used == 0 ? qbv[0] : used == 1 ? qbv[1] : used == 2 ? qbv[2] : qbv[3]) + k[2 * tr + h]);
+                    int32_t q = (int8_t)((int32_t)(int8_t)((qb4 >> (8 * used)) & 0xffu) + k[2 * tr + h]);
                     if (q < 33) q = 33;
                     if (q > 73) q = 73;
                     emit(i, (uint32_t)q);
@@ -292,6 +295,9 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     for (int q = tid; q < 128; q += nthr)                                                          // buffers are padded to 256 + 16 bytes
         (&s_fixed[0][0])[q] = q < 64 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 64];
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
+    // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
+    uint32_t *const s_qb = dyn_lds + (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr;
+    for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     __syncthreads();
     if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
@@ -526,7 +532,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                     else for (int b = lo; b < hi; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
                 }
                 o.put('\n'); o.put('+'); o.put('\n');
-                for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out,
+                for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out,
                                  [&](int i, uint32_t q) { if (i >= first) o.put(q); });       // same draws for both outputs
                 o.put('\n');
                 o.flush();
@@ -565,7 +571,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         // qualities (dwgsim.c:899-918), four characters per store
         {
             uint32_t qacc = 0, nq = 0;
-            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, j ? a.qbase[1] : a.qbase[0], s, s_out, [&](int, uint32_t q) {
+            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, [&](int, uint32_t q) {
                 qacc |= q << (8 * nq);
                 if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
             });
@@ -826,7 +832,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const size_t lds = (size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr * 4;   // Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch
+    const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4;   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }

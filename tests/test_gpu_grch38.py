@@ -120,7 +120,10 @@ def test_whole_grch38_2x150_30x_on_one_gpu(lib, oracle_bin, genome, tmp_path):
     assert n_sim == sum(r[1] for r in report) and 320e6 < n_sim < 330e6, n_sim
     assert tot_nl[0] == tot_nl[1] == 4 * n_sim and tot_bytes[0] == tot_bytes[1] and tot_bytes[0] > 100e9
     assert n_N == 0                                           # -n 0: no read with an N base is emitted
-    assert abs(n_rand / n_sim - 0.05) < 4 * (0.05 * 0.95 / n_sim) ** 0.5 + 1e-4, n_rand / n_sim
+    # a pair whose genomic attempt fails (N blocks: ~5.6 % of the positions) is retried FROM the random-read test (dwgsim.c:649, :833-842),
+    # so random reads make up y / (y + (1 - y)(1 - f)) of the output, f = the failing share of genomic attempts
+    f_lo, f_hi = 0.050, 0.065
+    assert 0.05 / (0.05 + 0.95 * (1 - f_lo)) < n_rand / n_sim < 0.05 / (0.05 + 0.95 * (1 - f_hi)), n_rand / n_sim
 
 
 def test_whole_grch38_iontorrent_400bp_50x_on_one_gpu(lib, oracle_bin, genome, tmp_path):
@@ -129,7 +132,7 @@ def test_whole_grch38_iontorrent_400bp_50x_on_one_gpu(lib, oracle_bin, genome, t
     n_sim, n_rand, tot_bytes, tot_nl, n_N, report = _run_genome(lib, oracle_bin, tmp_path, genome, flags, window_contigs=(0, 23), batch=1 << 21, cnt=1000)
     assert 400e6 < n_sim < 412e6, n_sim
     assert tot_nl[0] == 4 * n_sim and tot_bytes[0] > 300e9
-    assert abs(n_rand / n_sim - 0.05) < 1e-3
+    assert 0.0520 < n_rand / n_sim < 0.0540, n_rand / n_sim
 
 
 def test_grch38_last_contig_takes_the_remainder_under_N(lib, oracle_bin, genome, tmp_path):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/phase_profile.sh -- analysis only: build a phase-timing variant of the library
 # (dwgsim_amd/libdwgsim_hip_phases.so, -DDW_PHASE_TIMING) next to the product library.
-# Use:  DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so DWGSIM_HIP_PHASES=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+# Use:  DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so python bench.py --phases --steps 3 --warmup 1 --no-legs --no-cpu-baseline
 set -e
 cd "$(dirname "$0")/../dwgsim_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DDW_PHASE_TIMING -Wno-unused-value -shared dw_walk.hip dw_simulate.hip dw_host.cpp dw_mutin.cpp -o ../libdwgsim_hip_phases.so
