@@ -823,7 +823,8 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     // lanes per k_simulate block: the staged read (lds_words per lane) must fit LDS; long Illumina / SOLiD reads get one-wave blocks
     const int lmax0 = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
     a.sim_threads = SIM_THREADS;
-    auto lds_need = [&](int lanes) { return ((size_t)((lmax0 + 7) / 8) * (size_t)lanes + 2 * (size_t)c->qb_words) * 4; };     // staged bases + the two base-quality tables
+    const size_t rings = (p.reads_output_type == 0 && p.data_type != 1) ? 2 : 1;
+    auto lds_need = [&](int lanes) { return ((size_t)((lmax0 + 7) / 8) * (size_t)lanes + 2 * (size_t)c->qb_words) * 4 + (size_t)lanes * 64 * rings; };     // staged bases + the two base-quality tables + the output rings
     if (p.data_type != 2 && lds_need(SIM_THREADS) > SIM_LDS_BUDGET) {
         a.sim_threads = SIM_THREADS_LONG;
         if (lds_need(SIM_THREADS_LONG) > SIM_LDS_BUDGET) {

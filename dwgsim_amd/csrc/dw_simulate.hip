@@ -297,6 +297,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
     uint32_t *const s_qb = dyn_lds + (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr;
+    // ... and the lanes' output rings (Writer, dw_read.hpp): eight 8-byte slots per lane and output family, slot-major
+    uint64_t *const s_ring = reinterpret_cast<uint64_t *>(s_qb + 2 * a.qb_words) + tid;
     for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     __syncthreads();
     if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
@@ -326,6 +328,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                 int64_t start; int step;
                 read_geom(a, pd, j, &start, &step);
                 PH_MARK(7);     // placement draws (phase 1 below is then the base extraction alone)
+                if (DW_KNOCK & 8) { rr = ReadRes{(int32_t)start, 0, 0, 0, 0}; for (int w = 0; w * 8 < s; ++w) lds[w * nthr] = 0x32103210u; }
+                else
                 rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
                 ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
             }
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         }
     }
     int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
-    if (valid && (DT != 2 || is_rand)) {
+    if (valid && (DT != 2 || is_rand) && !(DW_KNOCK & 4)) {
         // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
         const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
         uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
@@ -516,7 +520,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             for (int which = 0; which < 2; ++which) {            // 0: BWA stream of this end, 1: BFAST
                 if (!(OUT & (1 << which))) continue;
                 Out2<1> o;
-                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa);
+                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa, s_ring, nthr);
                 put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
                 if (is_rand) put_rand_tail(o, rand_ii);
                 else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1,           // (value selects: a struct select would go through memory)
@@ -542,11 +546,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // ---- write the record(s) ----
     if (valid && s_out > 0) {
         Out2<OUT> o;
-        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
-        if (OUT & 2) o.b.init(a.out[2] + off_bf);
+        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa, s_ring, nthr);
+        if (OUT & 2) o.b.init(a.out[2] + off_bf, s_ring + (OUT == 3 ? 8 * nthr : 0), nthr);
+        if (!(DW_KNOCK & 16)) {
         put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
         if (is_rand) put_rand_tail(o, rand_ii);
         else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
+        }
         if (OUT & 1) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
         if (OUT & 2) o.b.put('\n');
         PH_MARK(4); // header line
@@ -560,7 +566,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             } else word = lds[w * nthr];
             const int rem = s_out - w * 8;
             if (rem >= 8) {
-                o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16));
+                o.put8(base_chars8(word));
             } else {
                 const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16);
                 for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
@@ -570,12 +576,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         PH_MARK(5); // sequence line
         // qualities (dwgsim.c:899-918), four characters per store
         {
-            uint32_t qacc = 0, nq = 0;
-            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, [&](int, uint32_t q) {
-                qacc |= q << (8 * nq);
-                if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
-            });
-            for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
+            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, [&](int, uint32_t q) { o.put(q); });
         }
         o.put('\n');
         o.flush();
@@ -832,7 +833,9 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4;   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
+    const bool solid_early = a.p.data_type == 1;       // SOLiD writes its two outputs one after the other through one ring
+    const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4      // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
+                     + (size_t)nthr * 64 * (out == 3 && !solid_early ? 2 : 1);                                      // + the output rings
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }
