@@ -419,75 +419,92 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
 #ifndef DW_KNOCK
 #define DW_KNOCK 0
 #endif
-struct Writer {               // sequential byte stream -> 64-byte aligned bursts, assembled in LDS
-    // A lane's record is cut at 64-byte boundaries of the output buffer.  The chunk being filled lives in an eight-slot ring of 8-byte words
-    // in LDS (slot-major: slot s of lane t at ring[s * stride], so whatever slots the lanes of a wave are at, their accesses never share a
-    // bank); the slot under the write position is kept in `acc` until it is full.  put8 -- the call of the sequence and quality lines -- is
-    // straight-line code: one shift pair, one aligned ds_write_b64.  A full chunk leaves as four back-to-back dwordx4 stores, so L2 sees
-    // whole 64-byte request units (partially written lines were being evicted and written back 2.6x, profiles/r01_p3).  Only the first /
-    // last chunk of a record is ragged: bytes [skip, upto) go out as 8-byte words / bytes.
-    // Invariant: acc holds bytes [8 (n >> 3), n) of the chunk, zero above.
-    uint8_t *g; uint64_t *ring; uint64_t acc; uint32_t n, skip; int stride;
-    DW_DEV void init(uint8_t *p, uint64_t *ring_, int stride_)
+struct Writer {               // sequential byte stream -> bursts of 64-byte aligned chunks
+    // A lane's record is cut at 64-byte boundaries of the output buffer; a chunk is assembled in registers
+    // (three finished 16-byte sub-blocks in s0..s5, the one being filled in lo/hi) and leaves as four
+    // back-to-back dwordx4 stores, so L2 sees whole 64-byte request units instead of 16-byte crumbs
+    // (partially written lines were being evicted and written back 2.6x, profiles/r01_p3).
+    // Only the first / last chunk of a record is ragged: bytes [skip, upto) go out as dwords / bytes.
+    uint8_t *blk; uint64_t lo, hi, s0, s1, s2, s3, s4, s5; uint32_t n, sub, skip;
+    DW_DEV void init(uint8_t *p)
     {
         const uint32_t o = (uint32_t)((uintptr_t)p & 63);
-        g = p - o; n = o; skip = o; acc = 0; ring = ring_; stride = stride_;
+        blk = p - o; sub = o >> 4; n = o & 15; skip = o;
+        lo = hi = s0 = s1 = s2 = s3 = s4 = s5 = 0;
     }
-    DW_DEV void store_range(uint32_t from, uint32_t upto, uint32_t in_lds)     // bytes [from, upto) of the chunk; slots below in_lds / 8 are in the ring, the next one in acc
+    static DW_DEV void store16(uint8_t *dst, uint64_t a, uint64_t b, uint32_t from, uint32_t upto)   // bytes [from, upto) of a 16-byte block
     {
-        if (DW_KNOCK & 2) { asm volatile("" :: "v"(acc), "v"(upto)); return; }     // assembled, kept alive, not stored
-        for (uint32_t k = from >> 3; 8 * k < upto; ++k) {
-            const uint64_t w = 8 * k < in_lds ? ring[k * stride] : acc;
-            const uint32_t b0 = from > 8 * k ? from - 8 * k : 0, b1 = upto - 8 * k < 8 ? upto - 8 * k : 8;
-            if (b0 == 0 && b1 == 8) *reinterpret_cast<uint64_t *>(g + 8 * k) = w;
-            else for (uint32_t b = b0; b < b1; ++b) g[8 * k + b] = (uint8_t)(w >> (8 * b));
+        if (from == 0 && upto == 16) { *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); return; }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t w = (uint32_t)((q < 2 ? a : b) >> (32 * (q & 1)));
+            const uint32_t b0 = 4 * q, b1 = b0 + 4;
+            if (from <= b0 && upto >= b1) *reinterpret_cast<uint32_t *>(dst + b0) = w;
+            else for (uint32_t k = b0; k < b1; ++k) if (k >= from && k < upto) dst[k] = (uint8_t)(w >> (8 * (k - b0)));
         }
     }
-    DW_DEV void flush64()                        // the chunk is complete (n >= 64): all eight slots are in the ring
+    DW_DEV void store_chunk(uint32_t upto)       // bytes [skip, upto) of the current chunk
     {
-        if (skip == 0) {                         // the common case: one 64-byte burst
-            if (DW_KNOCK & 2) asm volatile("" :: "v"(acc));
-            else {
-                uint4 *d = reinterpret_cast<uint4 *>(g);
+        if (DW_KNOCK & 2) { asm volatile("" :: "v"(lo), "v"(hi), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(upto)); return; }     // assembled, kept alive, not stored
+        if (skip == 0 && upto == 64) {           // the common case: one 64-byte burst
+            uint4 *d = reinterpret_cast<uint4 *>(blk);
+            d[0] = make_uint4((uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32));
+            d[1] = make_uint4((uint32_t)s2, (uint32_t)(s2 >> 32), (uint32_t)s3, (uint32_t)(s3 >> 32));
+            d[2] = make_uint4((uint32_t)s4, (uint32_t)(s4 >> 32), (uint32_t)s5, (uint32_t)(s5 >> 32));
+            d[3] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            return;
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const uint64_t lo = ring[(2 * q) * stride], hi = ring[(2 * q + 1) * stride]; d[q] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)); }
-            }
-        } else store_range(skip, 64, 64);
-        g += 64; n -= 64; skip = 0;
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t b0 = 16 * q;
+            if (upto <= b0 || skip >= b0 + 16) continue;
+            const uint64_t a = (q == sub) ? lo : (q == 0 ? s0 : q == 1 ? s2 : s4);
+            const uint64_t b = (q == sub) ? hi : (q == 0 ? s1 : q == 1 ? s3 : s5);
+            const uint32_t from = skip > b0 ? skip - b0 : 0, to = upto < b0 + 16 ? upto - b0 : 16;
+            store16(blk + b0, a, b, from, to);
+        }
     }
-    DW_DEV void put8(uint64_t v)                 // eight bytes
+    DW_DEV void advance()                        // the 16-byte sub-block in lo/hi is complete
+    {
+        if (sub == 3) { store_chunk(64); blk += 64; sub = 0; skip = 0; }
+        else {      // value selects, not conditional stores: keeps s0..s5 in registers
+            const bool z0 = sub == 0, z1 = sub == 1, z2 = sub == 2;
+            s0 = z0 ? lo : s0; s1 = z0 ? hi : s1; s2 = z1 ? lo : s2; s3 = z1 ? hi : s3; s4 = z2 ? lo : s4; s5 = z2 ? hi : s5;
+            ++sub;
+        }
+        lo = hi = 0; n = 0;
+    }
+    DW_DEV void put(uint32_t b)
     {
         if (DW_KNOCK & 1) return;
-        if (DW_KNOCK & 64) { asm volatile("" :: "v"(v)); return; }
-        const uint32_t sh = 8 * (n & 7);
-        ring[(n >> 3) * stride] = acc | (v << sh);
-        acc = (v >> 1) >> (63 - sh);             // the bytes that spill into the next slot (none when sh == 0)
-        n += 8;
-        if (n >= 64) flush64();
+        if (DW_KNOCK & 64) { asm volatile("" :: "v"(b)); return; }       // producers kept alive, no assembly
+        const uint64_t v = (uint64_t)b << (8 * (n & 7));
+        if (n < 8) lo |= v; else hi |= v;
+        if (++n == 16) advance();
     }
     DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes, little-endian in v, upper bytes zero
     {
         if (DW_KNOCK & 1) return;
         if (DW_KNOCK & 64) { asm volatile("" :: "v"(v), "v"(cnt)); return; }
-        const uint32_t sh = 8 * (n & 7), k = n >> 3;
-        acc |= v << sh;
-        n += cnt;
-        if ((n >> 3) != k) {                     // the slot is full
-            ring[k * stride] = acc;
-            acc = (v >> 1) >> (63 - sh);
-            if (n >= 64) flush64();
-        }
+        const uint32_t sh = 8 * (n & 7);
+        if (n < 8) { lo |= v << sh; if (sh) hi |= v >> (64 - sh); }
+        else hi |= v << sh;
+        const uint32_t total = n + cnt;
+        if (total >= 16) {
+            const uint32_t over = total - 16;       // bytes that belong to the next sub-block (0..7)
+            const uint64_t carry = over ? v >> (8 * (cnt - over)) : 0;
+            advance();
+            lo = carry; n = over;
+        } else n = total;
     }
-    DW_DEV void put(uint32_t b) { putn((uint64_t)b, 1); }
     DW_DEV void put4(uint32_t w) { putn((uint64_t)w, 4); }
-    DW_DEV void flush() { if (n > skip) store_range(skip, n, n & ~7u); }
+    DW_DEV void flush() { const uint32_t upto = 16 * sub + n; if (upto > skip) store_chunk(upto); }
 };
 template <int OUT>            // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream
 struct Out2 {
     Writer a, b;
     DW_DEV void put(uint32_t c) { if (OUT & 1) a.put(c); if (OUT & 2) b.put(c); }
     DW_DEV void put4(uint32_t w) { if (OUT & 1) a.put4(w); if (OUT & 2) b.put4(w); }
-    DW_DEV void put8(uint64_t v) { if (OUT & 1) a.put8(v); if (OUT & 2) b.put8(v); }
     DW_DEV void putn(uint64_t v, uint32_t cnt) { if (OUT & 1) a.putn(v, cnt); if (OUT & 2) b.putn(v, cnt); }
     DW_DEV void flush() { if (OUT & 1) a.flush(); if (OUT & 2) b.flush(); }
 };
@@ -527,7 +544,6 @@ DW_DEV void put_hex(Out2<OUT> &o, uint64_t v)
     }
 }
 DW_DEV uint32_t base_chars4(uint32_t nibbles) { return lut8(0x4E4E4E4Eu, 0x54474341u, spread4(nibbles)); }        // four codes (<= 7) -> "ACGTNNNN"[code]
-DW_DEV uint64_t base_chars8(uint32_t nibbles) { return (uint64_t)base_chars4(nibbles) | ((uint64_t)base_chars4(nibbles >> 16) << 32); }
 DW_DEV uint32_t colour_digits4(uint32_t nibbles) { return lut8(0x34343434u, 0x33323130u, spread4(nibbles)); }     // four colours -> "01234444"[colour]
 
 } // namespace dw

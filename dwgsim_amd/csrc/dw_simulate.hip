@@ -297,8 +297,6 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
     uint32_t *const s_qb = dyn_lds + (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr;
-    // ... and the lanes' output rings (Writer, dw_read.hpp): eight 8-byte slots per lane and output family, slot-major
-    uint64_t *const s_ring = reinterpret_cast<uint64_t *>(s_qb + 2 * a.qb_words) + tid;
     for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     __syncthreads();
     if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
@@ -503,6 +501,11 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
     // Illumina: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
     const uint64_t off_bf = BF_SCAN ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
+    if (OUT == 1 && a.rec_info != nullptr && valid) {       // -o 0: what k_bfast_copy needs to derive this read's BFAST record
+        const uint64_t idx = pair * (uint64_t)LPP + (uint64_t)j;
+        const uint32_t h = emits ? 1u + fixed_len + tail_len : 0u;      // '@' + name: the "/1" suffix follows
+        a.rec_info[idx] = RecInfo{off_bwa, off_bf, Lbwa, h, (uint32_t)j, 0u};
+    }
     if (tid == nthr - 1) {
         const uint64_t nblocks = (a.n_pairs + PPB - 1) / PPB;
         if ((uint64_t)t + 1 == nblocks) {
@@ -520,7 +523,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             for (int which = 0; which < 2; ++which) {            // 0: BWA stream of this end, 1: BFAST
                 if (!(OUT & (1 << which))) continue;
                 Out2<1> o;
-                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa, s_ring, nthr);
+                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa);
                 put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
                 if (is_rand) put_rand_tail(o, rand_ii);
                 else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1,           // (value selects: a struct select would go through memory)
@@ -546,8 +549,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // ---- write the record(s) ----
     if (valid && s_out > 0) {
         Out2<OUT> o;
-        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa, s_ring, nthr);
-        if (OUT & 2) o.b.init(a.out[2] + off_bf, s_ring + (OUT == 3 ? 8 * nthr : 0), nthr);
+        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
+        if (OUT & 2) o.b.init(a.out[2] + off_bf);
         if (!(DW_KNOCK & 16)) {
         put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
         if (is_rand) put_rand_tail(o, rand_ii);
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             } else word = lds[w * nthr];
             const int rem = s_out - w * 8;
             if (rem >= 8) {
-                o.put8(base_chars8(word));
+                o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16));
             } else {
                 const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16);
                 for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
@@ -576,7 +579,12 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         PH_MARK(5); // sequence line
         // qualities (dwgsim.c:899-918), four characters per store
         {
-            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, [&](int, uint32_t q) { o.put(q); });
+            uint32_t qacc = 0, nq = 0;
+            for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, [&](int, uint32_t q) {
+                qacc |= q << (8 * nq);
+                if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
+            });
+            for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
         }
         o.put('\n');
         o.flush();
@@ -786,6 +794,35 @@ void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int s
 {
     hipLaunchKernelGGL(k_chain_set, dim3(1), dim3(64), 0, st, chain, rand_base, set_rand, carry, set_carry);
 }
+// -o 0 (both output families, the reference's default): the BFAST stream derived from the two finished BWA streams -- one wave per read, one
+// destination-aligned dword per lane and step.  Record = '@' name "/1" '\n' bases '\n' '+' '\n' qualities '\n'; the BFAST copy drops the two
+// suffix bytes at [h, h + 2) (dwgsim.c:957-981).  Bandwidth-bound (reads and writes the text once more), instead of a second formatting pass
+// with its own scans inside k_simulate.
+__global__ void __launch_bounds__(256) k_bfast_copy(const RecInfo *__restrict__ rec_info, uint64_t n_reads, const uint8_t *__restrict__ bwa1, const uint8_t *__restrict__ bwa2, uint8_t *__restrict__ bfast)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const RecInfo ri = rec_info[r];
+    const uint32_t L = ri.len, h = ri.name_len;
+    if (L == 0) return;
+    const uint8_t *src = (ri.end ? bwa2 : bwa1) + ri.off_bwa;
+    uint8_t *dst = bfast + ri.off_bf;
+    const int32_t Lb = (int32_t)L - 2, phase = (int32_t)((uintptr_t)dst & 3);
+    for (int32_t q = (int32_t)(threadIdx.x & 63); 4 * q - phase < Lb; q += 64) {
+        const int32_t r0 = 4 * q - phase;                        // record-relative position of this dword's first byte (negative before the record)
+        if (r0 >= 0 && r0 + 3 < Lb && (r0 + 3 < (int32_t)h || r0 >= (int32_t)h)) {
+            const uint8_t *sp = src + r0 + (r0 >= (int32_t)h ? 2 : 0);
+            const uint32_t *al = reinterpret_cast<const uint32_t *>((uintptr_t)sp & ~(uintptr_t)3);
+            *reinterpret_cast<uint32_t *>(dst + r0) = __builtin_amdgcn_alignbyte(al[1], al[0], (uint32_t)((uintptr_t)sp & 3));
+        } else {
+            for (int b = 0; b < 4; ++b) { const int32_t rr = r0 + b; if (rr >= 0 && rr < Lb) dst[rr] = src[rr < (int32_t)h ? rr : rr + 2]; }
+        }
+    }
+}
+void launch_bfast_copy(hipStream_t st, const RecInfo *rec_info, uint64_t n_reads, const uint8_t *bwa1, const uint8_t *bwa2, uint8_t *bfast)
+{
+    if (n_reads) hipLaunchKernelGGL(k_bfast_copy, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, rec_info, n_reads, bwa1, bwa2, bfast);
+}
 // test / analysis hook: how many bytes of text[0 .. n) equal `byte` (size-independent checks of whole outputs without copying them out)
 __global__ void __launch_bounds__(256) k_count_byte(const uint8_t *__restrict__ text, uint64_t n, uint32_t byte, uint64_t *out)
 {
@@ -832,10 +869,8 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
-    const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const bool solid_early = a.p.data_type == 1;       // SOLiD writes its two outputs one after the other through one ring
-    const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4      // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
-                     + (size_t)nthr * 64 * (out == 3 && !solid_early ? 2 : 1);                                      // + the output rings
+    const int out = a.rec_info ? 1 : (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);       // (-o 0 with the BFAST stream derived afterwards: the BWA-only variant)
+    const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4;   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }
