@@ -79,7 +79,7 @@ struct dwgsim_hip_ctx {
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
-    DevBuf w_ppos, w_pcells, flow_scratch, rec_info;
+    DevBuf w_ppos, w_pcells, flow_scratch;
     uint64_t *d_counters = nullptr;          // N_COUNTERS x u64: walk / calibrate / count_random (synchronous calls)
     uint64_t *h_counters = nullptr;          // pinned mirror
     Slot slot[2];                            // simulate(): two batches in flight (kernels of one overlap the copy-out of the other)
@@ -414,7 +414,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     hipFree(c->status_all.p);
-    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->rec_info.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
+    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->fail_summ.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters); hipFree(c->d_flow); hipFree(c->d_chain);
@@ -930,13 +930,6 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii
     if (!a.p.has_bfast) cap[2] = 0;
     for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
     a.counters = sl.d_counters;
-    // -o 0 (Illumina, Ion Torrent): the kernel writes the two BWA streams; the BFAST stream is derived from them by k_bfast_copy
-    const bool split_bfast = a.p.has_bwa && a.p.has_bfast && p.data_type != 1;
-    const uint64_t n_reads = n_pairs * (uint64_t)(p.length[1] > 0 ? 2 : 1);
-    if (split_bfast) {
-        if (ensure(c, c->rec_info, (size_t)n_reads * sizeof(RecInfo))) return DWGSIM_HIP_ERR_DEVICE;
-        a.rec_info = (RecInfo *)c->rec_info.p;
-    }
     const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));
     const uint32_t nblk = (uint32_t)((n_pairs + sim_ppb - 1) / sim_ppb);
     const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
@@ -946,7 +939,6 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii
     HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(sl.ev_k0, c->stream));
     launch_simulate(c->stream, a);
-    if (split_bfast) launch_bfast_copy(c->stream, a.rec_info, n_reads, a.out[0], a.out[1], a.out[2]);
     HIPC(c, hipEventRecord(sl.ev_k1, c->stream));
     launch_failrule(c->stream, a.meta, n_pairs, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
     HIPC(c, hipGetLastError());

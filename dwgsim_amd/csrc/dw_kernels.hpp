@@ -87,9 +87,6 @@ constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_s
 // blocks' areas do not all start on the same HBM channels (a 96 KB stride cost 14 % against 89 KB)
 inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_words + ((cap + 15) >> 4)) | 1; }
 
-// -o 0: what k_bfast_copy needs per read (written by k_simulate)
-struct RecInfo { uint64_t off_bwa, off_bf; uint32_t len, name_len, end, pad; };
-
 struct SimArgs {
     SimParams p;
     ContigDev c;
@@ -110,9 +107,6 @@ struct SimArgs {
     uint64_t *counters;            // this batch's slot: [0] ticket, [1] retries, [2] fail flags, [3] total random, [4..6] stream bytes, [16..19] abort-rule segment of the batch, [20] abort, [21] carry out
     uint64_t *status[4];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count, (SOLiD) BFAST bytes
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
-    RecInfo *rec_info;             // -o 0 for Illumina / Ion Torrent: k_simulate writes the two BWA streams only and leaves, per read, {offset in its BWA stream, offset in the
-                                   // BFAST stream, record length, name length} here; k_bfast_copy then derives the BFAST stream (a BFAST record = the BWA record
-                                   // without its "/1" / "/2" suffix, dwgsim.c:957-981).  Null otherwise.
     int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
     int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors
     int32_t sim_threads;          // lanes per k_simulate block chosen by the host: SIM_THREADS, or SIM_THREADS_LONG for long reads

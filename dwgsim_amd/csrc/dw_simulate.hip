@@ -501,11 +501,6 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
     // Illumina: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
     const uint64_t off_bf = BF_SCAN ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
-    if (OUT == 1 && a.rec_info != nullptr && valid) {       // -o 0: what k_bfast_copy needs to derive this read's BFAST record
-        const uint64_t idx = pair * (uint64_t)LPP + (uint64_t)j;
-        const uint32_t h = emits ? 1u + fixed_len + tail_len : 0u;      // '@' + name: the "/1" suffix follows
-        a.rec_info[idx] = RecInfo{off_bwa, off_bf, Lbwa, h, (uint32_t)j, 0u};
-    }
     if (tid == nthr - 1) {
         const uint64_t nblocks = (a.n_pairs + PPB - 1) / PPB;
         if ((uint64_t)t + 1 == nblocks) {
@@ -794,35 +789,6 @@ void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int s
 {
     hipLaunchKernelGGL(k_chain_set, dim3(1), dim3(64), 0, st, chain, rand_base, set_rand, carry, set_carry);
 }
-// -o 0 (both output families, the reference's default): the BFAST stream derived from the two finished BWA streams -- one wave per read, one
-// destination-aligned dword per lane and step.  Record = '@' name "/1" '\n' bases '\n' '+' '\n' qualities '\n'; the BFAST copy drops the two
-// suffix bytes at [h, h + 2) (dwgsim.c:957-981).  Bandwidth-bound (reads and writes the text once more), instead of a second formatting pass
-// with its own scans inside k_simulate.
-__global__ void __launch_bounds__(256) k_bfast_copy(const RecInfo *__restrict__ rec_info, uint64_t n_reads, const uint8_t *__restrict__ bwa1, const uint8_t *__restrict__ bwa2, uint8_t *__restrict__ bfast)
-{
-    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_reads) return;
-    const RecInfo ri = rec_info[r];
-    const uint32_t L = ri.len, h = ri.name_len;
-    if (L == 0) return;
-    const uint8_t *src = (ri.end ? bwa2 : bwa1) + ri.off_bwa;
-    uint8_t *dst = bfast + ri.off_bf;
-    const int32_t Lb = (int32_t)L - 2, phase = (int32_t)((uintptr_t)dst & 3);
-    for (int32_t q = (int32_t)(threadIdx.x & 63); 4 * q - phase < Lb; q += 64) {
-        const int32_t r0 = 4 * q - phase;                        // record-relative position of this dword's first byte (negative before the record)
-        if (r0 >= 0 && r0 + 3 < Lb && (r0 + 3 < (int32_t)h || r0 >= (int32_t)h)) {
-            const uint8_t *sp = src + r0 + (r0 >= (int32_t)h ? 2 : 0);
-            const uint32_t *al = reinterpret_cast<const uint32_t *>((uintptr_t)sp & ~(uintptr_t)3);
-            *reinterpret_cast<uint32_t *>(dst + r0) = __builtin_amdgcn_alignbyte(al[1], al[0], (uint32_t)((uintptr_t)sp & 3));
-        } else {
-            for (int b = 0; b < 4; ++b) { const int32_t rr = r0 + b; if (rr >= 0 && rr < Lb) dst[rr] = src[rr < (int32_t)h ? rr : rr + 2]; }
-        }
-    }
-}
-void launch_bfast_copy(hipStream_t st, const RecInfo *rec_info, uint64_t n_reads, const uint8_t *bwa1, const uint8_t *bwa2, uint8_t *bfast)
-{
-    if (n_reads) hipLaunchKernelGGL(k_bfast_copy, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, rec_info, n_reads, bwa1, bwa2, bfast);
-}
 // test / analysis hook: how many bytes of text[0 .. n) equal `byte` (size-independent checks of whole outputs without copying them out)
 __global__ void __launch_bounds__(256) k_count_byte(const uint8_t *__restrict__ text, uint64_t n, uint32_t byte, uint64_t *out)
 {
@@ -869,7 +835,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
-    const int out = a.rec_info ? 1 : (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);       // (-o 0 with the BFAST stream derived afterwards: the BWA-only variant)
+    const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
     const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4;   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
