@@ -544,6 +544,16 @@ int dwgsim_hip_set_mutation_input(dwgsim_hip_ctx_t *c, int type, const char *pat
     return DWGSIM_HIP_OK;
 }
 
+// mut_debug (mut.c:379-425): where the reference's asserts end the run (SIGABRT) the call returns DWGSIM_HIP_ERR_FAILED with the assert's text
+static int mut_debug_verdict(dwgsim_hip_ctx_t *c, const Contig &k, uint64_t v)
+{
+    if (v == ~0ull) return DWGSIM_HIP_OK;
+    static const char *what[4] = {"", "(c[0]&0x3) != (c[1]&0x3)", "(c[1]&0x3) != (c[2]&0x3)", "(c[0]&0x3) == (c[1]&0x3) || (c[0]&0x3) == (c[2]&0x3)"};
+    char b[256]; snprintf(b, sizeof b, "dwgsim: src/mut.c: mut_debug: Assertion `%s' failed. [%s:%lld]\n", what[v & 3], k.name.c_str(), (long long)(v >> 8) + 1);
+    c->err = b;
+    return DWGSIM_HIP_ERR_FAILED;
+}
+
 int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
 {
     Contig *kp = get_contig(c, contig);
@@ -598,13 +608,18 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         }
         launch_apply_patches(c->stream, (const int32_t *)c->w_ppos.p, (const uint16_t *)c->w_pcells.p, np, k.d_cells[0], k.d_cells[1]);
         const ContigDev cd = contig_dev(k);
+        HIPC(c, hipMemsetAsync(&c->d_counters[12], 0xff, 2 * sizeof(uint64_t), c->stream));
+        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[12]);      // mut.c:753
         if (nev) {
             if (c->seq_justify) launch_justify_seq(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd);
             else launch_justify(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
         }
+        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
         HIPC(c, hipGetLastError());
+        HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
-        return DWGSIM_HIP_OK;
+        if (const int rc = mut_debug_verdict(c, k, c->h_counters[12])) return rc;
+        return mut_debug_verdict(c, k, c->h_counters[13]);
     }
     const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
     if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
@@ -656,9 +671,13 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         ContigDev cd = contig_dev(k);
         cd.tot4 = &d_small[1]; cd.cap_bases[0] = (uint32_t)std::min<size_t>(k.cap_bases[0], 0xFFFFFFFFu); cd.cap_bases[1] = (uint32_t)std::min<size_t>(k.cap_bases[1], 0xFFFFFFFFu);
         launch_apply(c->stream, d_ev, nc, d_flags, cd, wp);
+        HIPC(c, hipMemsetAsync(&c->d_counters[12], 0xff, 2 * sizeof(uint64_t), c->stream));
+        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[12]);      // mut.c:753
         if (c->seq_justify) launch_justify_seq(c->stream, d_ev, nc, cd);
         else launch_justify(c->stream, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
         HIPC(c, hipGetLastError());
+        HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipMemcpyAsync(&c->h_counters[8], d_small, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));      // h_counters[8..11] as 8 x u32
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -669,7 +688,8 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             if (!fits) { c->err = "mutation walk: capacities still exceeded after an exact re-run"; return DWGSIM_HIP_ERR_FAILED; }
             k.n_cand = (uint32_t)n_cand;
             for (int h = 0; h < 2; ++h) { k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h]; }
-            return DWGSIM_HIP_OK;
+            if (const int rc = mut_debug_verdict(c, k, c->h_counters[12])) return rc;
+            return mut_debug_verdict(c, k, c->h_counters[13]);
         }
         // exact sizes (the counts read back are those of the complete candidate list unless it was truncated: take generous ones then)
         cap = (uint32_t)std::min<uint64_t>((uint64_t)l, n_cand + 16);

@@ -151,6 +151,8 @@ bool read_vcf(FILE *fp, const std::vector<ContigName> &contigs, MutInput &out, s
         std::string r = ref, a = alt;
         if (r == ".") r.clear();
         if (a == ".") a.clear();
+        // (the reference indexes past the contig here -- undefined behaviour; a library call must not: same message as for a start out of range)
+        if (contigs[cur.i].len < (int64_t)pos + (int64_t)r.size() - 1) { err = fmt("Error: start out of range [%s,%u]\n", name, pos + (uint32_t)r.size() - 1); return false; }
         if (r.empty() && a.empty()) { err = "Error: empty alleles\n"; return false; }
         if (a.find(',') != std::string::npos) { err = "Error: multiple alleles are not supported\n"; return false; }
         for (auto *str : {&r, &a}) for (auto &ch : *str) { ch = "ACGTNN"[code_of(ch)]; if (ch == 'N') { err = "Error: non-ACGT base found\n"; return false; } }

@@ -543,6 +543,37 @@ void launch_justify(hipStream_t st, const Event *ev, Count n, ContigDev c, int32
     hipLaunchKernelGGL(k_jbound, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
     hipLaunchKernelGGL(k_jrun, dim3(cdiv(n.host, 64)), dim3(64), 0, st, ev, n, c, bound);
 }
+// mut.c:379-425 mut_debug(): the consistency asserts the reference runs over both haplotypes before and after the left-justification
+// (mut.c:753, :757; live in its build -- a violating mutation input ends the reference with SIGABRT).  16 positions per thread; the smallest
+// failing position and which assert it fails go to *verdict as (position << 8 | code), code 1..3:
+//   1 hom substitution whose base equals the reference's   (c[0]&0x3) != (c[1]&0x3)
+//   2 het substitution, both haplotypes carry the same base (c[1]&0x3) != (c[2]&0x3)
+//   3 het substitution, neither haplotype keeps the reference base
+// (the insertion-length asserts cannot fail here: every insertion is created with at least one base.)
+__global__ void __launch_bounds__(SCAN_THREADS) k_mut_debug(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, int64_t l, uint64_t *verdict)
+{
+    const int64_t first = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    if (first >= l) return;
+    const uint4 a = *reinterpret_cast<const uint4 *>(h0 + first), b = *reinterpret_cast<const uint4 *>(h1 + first);
+    if ((((a.x | a.y | a.z | a.w) | (b.x | b.y | b.z | b.w)) & 0x30303030u) == 0) return;       // no mutated cell among these 16 (cells are padded past l with unmutated N)
+    const uint4 r = *reinterpret_cast<const uint4 *>(ref + first);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, rw[4] = {r.x, r.y, r.z, r.w};
+    for (int q = 0; q < SCAN_POS_PER_THREAD && first + q < l; ++q) {
+        const uint32_t c0 = (rw[q >> 2] >> (8 * (q & 3))) & 0xffu, c1 = (aw[q >> 2] >> (8 * (q & 3))) & 0xffu, c2 = (bw[q >> 2] >> (8 * (q & 3))) & 0xffu;
+        if (c0 >= 4 || ((c1 & TMASK) == T_NONE && (c2 & TMASK) == T_NONE)) continue;
+        uint32_t code = 0;
+        if ((c1 & BTMASK) == (c2 & BTMASK)) { if ((c1 & TMASK) == T_SUB && (c0 & 3) == (c1 & 3)) code = 1; }
+        else if ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB) {
+            if ((c1 & 3) == (c2 & 3)) code = 2;
+            else if (!((c0 & 3) == (c1 & 3) || (c0 & 3) == (c2 & 3))) code = 3;
+        }
+        if (code) { atomicMin((unsigned long long *)verdict, ((unsigned long long)(first + q) << 8) | code); return; }
+    }
+}
+void launch_mut_debug(hipStream_t st, const uint8_t *ref, const uint8_t *h0, const uint8_t *h1, int64_t l, uint64_t *verdict)
+{
+    if (l > 0) hipLaunchKernelGGL(k_mut_debug, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, h0, h1, l, verdict);
+}
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
 {
     if (n) hipLaunchKernelGGL(k_apply_patches, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, cells, n, h0, h1);

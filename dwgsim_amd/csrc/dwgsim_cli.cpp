@@ -368,9 +368,17 @@ int main(int argc, char **argv)
     Fasta fa;
     if (!read_fasta(fn_fa, fa)) return 1;
     const double t_fasta = now_s();
+    // the contig table -- names, lengths, their number and sum -- comes from <in.ref.fa>.fai when that file exists (dwgsim.c:465-478:
+    // the VCF header, tot_len, n_ref and the table the mutation / region files are checked against), else from the FASTA itself
+    std::vector<std::string> tab_names; std::vector<int64_t> tab_lens;
+    if (FILE *fai = fopen((std::string(fn_fa) + ".fai").c_str(), "r")) {
+        char nmbuf[4096]; int ll, d0, d1, d2;
+        while (0 < fscanf(fai, "%4095s\t%d\t%d\t%d\t%d", nmbuf, &ll, &d0, &d1, &d2)) { tab_names.push_back(nmbuf); tab_lens.push_back(ll); }
+        fclose(fai);
+    } else for (size_t i = 0; i < fa.seqs.size(); ++i) { tab_names.push_back(fa.names[i]); tab_lens.push_back((int64_t)fa.seqs[i].size()); }
     uint64_t tot_len = 0;
-    for (size_t i = 0; i < fa.seqs.size(); ++i) { fprintf(stderr, "[dwgsim_core] %s length: %d\n", fa.names[i].c_str(), (int)fa.seqs[i].size()); tot_len += fa.seqs[i].size(); }
-    fprintf(stderr, "[dwgsim_core] %d sequences, total length: %llu\n", (int)fa.seqs.size(), (unsigned long long)tot_len);
+    for (size_t i = 0; i < tab_names.size(); ++i) { fprintf(stderr, "[dwgsim_core] %s length: %d\n", tab_names[i].c_str(), (int)tab_lens[i]); tot_len += (uint64_t)tab_lens[i]; }
+    fprintf(stderr, "[dwgsim_core] %d sequences, total length: %llu\n", (int)tab_names.size(), (unsigned long long)tot_len);
 
     const bool want_mut = o.output_type != 1, want_reads = o.output_type != 2;
     const bool has_bfast = want_reads && o.reads_output_type != 1, has_bwa = want_reads && o.reads_output_type != 2;
@@ -380,7 +388,7 @@ int main(int argc, char **argv)
         fp_txt = fopen((p + ".mutations.txt").c_str(), "w"); fp_vcf = fopen((p + ".mutations.vcf").c_str(), "w");
         if (!fp_txt || !fp_vcf) { fprintf(stderr, "[main] fail to open mutation files for '%s'. Abort!\n", out_prefix); return 1; }
         fprintf(fp_vcf, "##fileformat=VCFv4.1\n");
-        for (size_t i = 0; i < fa.seqs.size(); ++i) fprintf(fp_vcf, "##contig=<ID=%s,length=%d>\n", fa.names[i].c_str(), (int)fa.seqs[i].size());
+        for (size_t i = 0; i < tab_names.size(); ++i) fprintf(fp_vcf, "##contig=<ID=%s,length=%d>\n", tab_names[i].c_str(), (int)tab_lens[i]);
         fprintf(fp_vcf, "##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n"
                         "##INFO=<ID=pl,Number=1,Type=Integer,Description=\"Phasing: 1 - HET contig 1, #2 - HET contig #2, 3 - HOM both contigs\">\n"
                         "##INFO=<ID=mt,Number=1,Type=String,Description=\"Variant Type: SUBSTITUTE/INSERT/DELETE\">\n"
@@ -392,7 +400,7 @@ int main(int argc, char **argv)
     // one context per device
     std::vector<dwgsim_hip_ctx_t *> ctx((size_t)ND, nullptr);
     std::vector<const char *> nm; std::vector<int64_t> ln;
-    for (size_t i = 0; i < fa.seqs.size(); ++i) { nm.push_back(fa.names[i].c_str()); ln.push_back((int64_t)fa.seqs[i].size()); }
+    for (size_t i = 0; i < tab_names.size(); ++i) { nm.push_back(tab_names[i].c_str()); ln.push_back(tab_lens[i]); }
     auto destroy_all = [&]() { for (auto *x : ctx) if (x) dwgsim_hip_destroy(x); };
     for (int d = 0; d < ND; ++d) {
         int err = 0;
@@ -417,7 +425,7 @@ int main(int argc, char **argv)
 
     const double t_ctx = now_s();
     double t_walk = 0, t_sim = 0;
-    int64_t n_sim = 0; uint64_t rand_ii = 0, ctr = 0; int n_ref = (int)fa.seqs.size(), prev_skip = 0;
+    int64_t n_sim = 0; uint64_t rand_ii = 0, ctr = 0; int n_ref = (int)tab_names.size(), prev_skip = 0;
     std::atomic<int> rc{0};
     std::mutex err_m;
     auto fail = [&](const char *what) { std::lock_guard<std::mutex> g(err_m); if (rc.exchange(1) == 0) fprintf(stderr, "%s%s", what, (what[0] && what[strlen(what) - 1] != '\n') ? "\n" : ""); };

@@ -193,3 +193,27 @@ def check_both_abort(lib, oracle_bin, fasta, flags):
         assert "failed to generate a read after 10001 trials" in str(e), str(e)
         return
     raise AssertionError("the HIP path produced output where the reference aborts: " + flags)
+
+
+def check_mut_debug_aborts(lib, oracle_bin, golden_dir):
+    """Mutation inputs on which the reference's mut_debug asserts end the run (mut.c:379-425; reference-pinned in tests/golden/MANIFEST.json,
+    cases G6_abort_*): the oracle aborts on the same assert, and the product returns an error carrying the assert's text instead of output."""
+    import json
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["cases"]
+    n = 0
+    for name, c in sorted(man.items()):
+        if "aborts" not in c:
+            continue
+        flags = c["flags"].replace("{IN}", IN_DIR)
+        fasta = os.path.join(golden_dir, c["fasta"])
+        with tempfile.TemporaryDirectory() as t:
+            r = subprocess.run([oracle_bin, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, text=True)
+        assert r.returncode == -6 and c["aborts"]["assertion"] in r.stderr
+        try:
+            api.run_job(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib)
+        except api.DwgsimError as e:
+            assert "mut_debug: Assertion `" + c["aborts"]["assertion"] + "' failed" in str(e), str(e)
+            n += 1
+            continue
+        raise AssertionError("the product produced output where the reference aborts: " + name)
+    assert n == 2

@@ -101,3 +101,26 @@ def test_command_line_on_several_contexts_on_cpu_emulation(emu_lib, oracle_bin, 
         assert (gzip.open(p, "rb").read() if os.path.exists(p) else b"") == want[k], suf
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
+
+
+def test_mut_debug_aborts_on_cpu_emulation(emu_lib, oracle_bin, golden_dir):
+    from parity_common import check_mut_debug_aborts
+    check_mut_debug_aborts(emu_lib, oracle_bin, golden_dir)
+
+
+def test_command_line_honours_a_fai_index_as_the_reference_does(emu_lib, oracle_bin, golden_dir, tmp_path):
+    """dwgsim.c:465-478: with <in.fa>.fai present, the contig table (VCF header, total length, number of contigs -- hence pairs per contig
+    and which contig "is the last") comes from the index, not from the FASTA.  An index that disagrees with the FASTA shows it."""
+    import gzip, shutil
+    from parity_common import run_oracle
+    fa = str(tmp_path / "g.fa")
+    shutil.copy(os.path.join(golden_dir, "tiny.fa"), fa)
+    open(fa + ".fai", "w").write("t1\t5000\t4\t60\t61\nt2\t4000\t6110\t60\t61\nshort\t300\t10180\t60\t61\nphantom\t2500\t10500\t60\t61\n")
+    flags = "-z 11 -N 1500 -1 50 -2 50 -d 200 -s 10 -o 1"
+    want = run_oracle(oracle_bin, fa, flags, str(tmp_path))
+    subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + [fa, str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL,
+                   env=dict(os.environ, DWGSIM_HIP_THREADS="2"))
+    for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz")]:
+        assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k], suf
+    assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"] and b"phantom" in want["vcf"]
+    assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]

@@ -232,3 +232,8 @@ def test_hopeless_target_regions_end_with_an_error(lib, golden_dir, tmp_path):
     bed.write_text("t1\t100\t500\nt1\t900\t1300\n")
     with pytest.raises(api.DwgsimError, match="no fragment placement satisfied the target regions"):
         api.run_job(api.parse_flags(f"-z 3 -N 130 -1 50 -2 50 -d 500 -s 5 -x {bed}", lib), api.read_fasta(os.path.join(golden_dir, "tiny.fa")), lib=lib)
+
+
+def test_mut_debug_aborts_like_the_reference(lib, oracle_bin, golden_dir):
+    from parity_common import check_mut_debug_aborts
+    check_mut_debug_aborts(lib, oracle_bin, golden_dir)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""tools/make_counters_json.py <workload-key> <gpurun_out/tag> [profiles/r02_counters.json] -- analysis only: fold the PMC passes of
+tools/profile_round.sh into the JSON that bench.py quotes (roofline.traffic, roofline.valu).  Units and corrections as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as
+64 bytes, so it is doubled; separate --pmc passes."""
+import json, os, re, sys
+
+key, d = sys.argv[1], sys.argv[2]
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_counters.json")
+vals = {}
+for line in open(os.path.join(d, "pmc.txt")):
+    m = re.match(r"^.*k_simulate.*?\s([A-Z][A-Z0-9_]+)\s+([0-9.]+)\s+n=", line)
+    if m:
+        vals[m.group(1)] = float(m.group(2))
+bench = json.load(open(os.path.join(d, "bench_line.json")))
+pairs = bench["config"]["pairs_per_gpu_per_step"]
+waves = vals.get("SQ_WAVES")
+out = {"source": f"profiles/{os.path.basename(d)}_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
+       "kernel": bench["roofline"]["kernel"], "pairs_per_launch": pairs}
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    out.update({"fetch_size_kib": vals["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kib": vals["WRITE_SIZE"],
+                "traffic_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)})
+if waves:
+    out.update({"valu_instr_per_wave": round(vals["SQ_INSTS_VALU"] / waves), "salu_instr_per_wave": round(vals["SQ_INSTS_SALU"] / waves),
+                "valu_instr_per_pair": round(vals["SQ_INSTS_VALU"] * 64 / pairs)})
+    if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles per SE-level SQ; GRBM_GUI_ACTIVE is summed over the 8 XCDs (profiles/r01: same formula)
+        out["valu_issue_active_pct"] = round(100.0 * vals["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * vals["GRBM_GUI_ACTIVE"] / 8), 1)
+allj = json.load(open(dst)) if os.path.exists(dst) else {}
+allj[key] = out
+json.dump(allj, open(dst, "w"), indent=1, sort_keys=True)
+print(json.dumps(out))
