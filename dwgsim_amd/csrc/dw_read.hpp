@@ -259,71 +259,21 @@ struct PackAppender {
     DW_DEV void flush() { if (n & (PER - 1)) base[(n >> SH) * stride] = acc; }
 };
 struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
-    // Each pass of the flow model consumes ONE sequential stream of 32-bit uniforms in the reference's order: draw t = (h << 16 | l) * 2^-32,
-    // h = halfword t of the (dom, retry 0) Philox stream, l = halfword t of the (dom, retry 1) stream -- eight draws per block.  Almost every
-    // draw is the test u < e of a quiet flow: `hm` holds, for the halfwords of the current block that are still to come, whether the HIGH half
-    // alone can make the draw a hit (h <= thr >> 16; bit 0 = the next draw), so a run of quiet flows is one mask test, and the low half is
-    // only generated for a tie (h == thr >> 16, probability 2^-16).
-    uint32_t seed, contig, dom, att, pos, nleft, hm, w0, w1, w2, w3; uint64_t ii, thr;
-    DW_DEV void start(uint32_t domain, uint64_t threshold) { dom = domain; thr = threshold; pos = 0; nleft = 0; hm = 0; }
-    DW_DEV void refill()            // the block of halfwords pos .. pos + 7 (pos is a multiple of 8 here)
+    // One private sub-stream per event of the flow model (a homopolymer start in pass 1, an examined base in pass 2): draw s of event
+    // `evt` is word s & 3 of the block (retry s >> 2, block evt).  Every lane opens its events in step with its own loop iterations, so a
+    // block is generated once per event instead of once per draw of whichever lane happens to cross a block boundary.
+    uint32_t seed, contig, dom, att, evt, s, w0, w1, w2, w3; uint64_t ii;
+    DW_DEV void open(uint32_t event) { evt = event; s = 0; }
+    DW_DEV uint32_t next()
     {
-        const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, 0, pos >> 3);
-        w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w;
-        const uint32_t t16 = (uint32_t)(thr >> 16);        // 0 .. 65536
-        hm = ((w0 & 0xFFFFu) <= t16 ? 1u : 0u) | ((w0 >> 16) <= t16 ? 2u : 0u) | ((w1 & 0xFFFFu) <= t16 ? 4u : 0u) | ((w1 >> 16) <= t16 ? 8u : 0u)
-           | ((w2 & 0xFFFFu) <= t16 ? 16u : 0u) | ((w2 >> 16) <= t16 ? 32u : 0u) | ((w3 & 0xFFFFu) <= t16 ? 64u : 0u) | ((w3 >> 16) <= t16 ? 128u : 0u);
-        nleft = 8;
-    }
-    DW_DEV uint32_t high_half()      // of the next draw (the block is present)
-    {
-        const uint32_t k = pos & 7u, lo = (k & 2) ? w1 : w0, hi = (k & 2) ? w3 : w2, w = (k & 4) ? hi : lo;
-        return (k & 1) ? w >> 16 : w & 0xFFFFu;
-    }
-    DW_DEV uint32_t low_half()       // of the next draw: generated on demand (ties, and the dot-fill's (int)(u * j))
-    {
-        const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, 1, pos >> 3);
-        const uint32_t k = pos & 7u, lo = (k & 2) ? b.y : b.x, hi = (k & 2) ? b.w : b.z, w = (k & 4) ? hi : lo;
-        return (k & 1) ? w >> 16 : w & 0xFFFFu;
-    }
-    DW_DEV void consume(uint32_t k) { pos += k; nleft -= k; hm >>= k; }
-    DW_DEV bool hit()                // u < e for the next draw, consuming it
-    {
-        if (nleft == 0) refill();
-        bool h = false;
-        if (hm & 1u) {               // the high half does not rule a hit out
-            const uint32_t hh = high_half(), t16 = (uint32_t)(thr >> 16);
-            h = hh < t16 || (uint64_t)((hh << 16) | low_half()) < thr;
-        }
-        consume(1);
-        return h;
-    }
-    DW_DEV uint32_t next_high()      // the high half of the next draw, consuming it (u < 0.5  <=>  half < 0x8000)
-    {
-        if (nleft == 0) refill();
-        const uint32_t hh = high_half();
-        consume(1);
-        return hh;
-    }
-    DW_DEV uint32_t next_u32()       // the whole next draw, consuming it
-    {
-        if (nleft == 0) refill();
-        const uint32_t u = (high_half() << 16) | low_half();
-        consume(1);
-        return u;
+        if ((s & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, s >> 2, evt); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
+        const uint32_t k = s & 3; ++s;
+        const uint32_t lo = (k & 1) ? w1 : w0, hi = (k & 1) ? w3 : w2;
+        return (k & 2) ? hi : lo;
     }
     // while (drand48() < e) n_err++ (dwgsim.c:296, :373).  Bounded: with e = 1 the reference never leaves this loop; 2^14 errors in one flow
     // already overflow every buffer, so the caller reports the read as outgrown instead of spinning on the GPU.
-    DW_DEV int geometric() { int n = 0; while (n < (1 << 14) && hit()) ++n; return n; }
-    // k quiet flows in a row?  (true: all k draws consumed, none was a hit; false: nothing consumed, take the flows one by one)
-    DW_DEV bool quiet_run(uint32_t k)
-    {
-        if (k == 0) return true;
-        if (nleft == 0) refill();
-        if (k > nleft || (hm & ((1u << k) - 1u))) return false;
-        consume(k);
-        return true;
-    }
+    DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
 };
 // Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
 // bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
@@ -340,7 +290,7 @@ DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, i
 }
 // Pass 1 of generate_errors_flows (dwgsim.c:253-364) for one lane: bufA (len bases) -> bufB (2 bits per base).  Returns the new length or
 // -1; leaves the flow mask, the flow position and the number of erroneous bases for pass 2.
-DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint32_t *bufA, uint32_t *bufB, int stride,
+DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, int stride,
                       int len, int strand, int cap, uint64_t &mask, int &flow_i, int &total)
 {
     // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
@@ -349,7 +299,7 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
     { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
     // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
     PackAppender<2> o1; o1.init(bufB, stride);
-    int t = 0; uint32_t prev_c = 4, pend_c = 0; int pend_n = 0;
+    int t = 0; uint32_t prev_c = 4, pend_c = 0, n_events = 0; int pend_n = 0;
     for (;;) {
         uint32_t c; bool from_pend = false;
         if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
@@ -365,10 +315,11 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
         }
         if (prev_c != c) {
             mask &= ~(1ull << flow_i);
-            int n_err = rg.quiet_run(1) ? 0 : rg.geometric();
+            rg.open(n_events++);
+            int n_err = rg.geometric(thr);
             if (n_err >= (1 << 14)) return -1;
             if (n_err > 0) {
-                if (rg.next_high() < 0x8000u) {                 // insert n_err copies in front of the homopolymer
+                if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
                     o1.push(c); pend_c = c; pend_n = n_err - 1;
                     total += n_err; prev_c = c;
                     continue;
@@ -380,7 +331,7 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
                 if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
                     if (next_c == c) return -1;                // the whole read was one deleted homopolymer (the reference asserts)
                     int jj = 0; while (next_c != flow[(flow_i + jj) % F]) ++jj;
-                    const int kk = (int)(((uint64_t)rg.next_u32() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
+                    const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
                     o1.push(flow[(flow_i + kk) % F]);
                 } else if (t < len) { o1.push(in(rd, t)); ++t; }   // the base now at this position is not examined
                 prev_c = c;
@@ -395,18 +346,18 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
     return o1.n;
 }
 // Every lane of the wave must call this (pass 2 regroups lanes with wave ballots); lanes without a read pass active = false.
-DW_DEV int flow_errors(bool active, FlowRng &rg, uint32_t dom, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
+DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
     int n1 = 0, total = 0, flow_i = 0; uint64_t mask = 0; bool failed = !active;
-    rg.start(dom, thr);
-    if (active) n1 = flow_pass1(rg, flow, dist, F, bufA, bufB, stride, len, strand, cap, mask, flow_i, total);
+    if (active) n1 = flow_pass1(rg, flow, dist, F, thr, bufA, bufB, stride, len, strand, cap, mask, flow_i, total);
     if (n1 < 0) failed = true;
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
-        // A scoring flow needs no new Philox block (the draws are one sequential stream, FlowRng), so the flow-by-flow code is short and simply
-    // runs under divergence. ----
+    // With e = 0.01 some lane of a wave has a scoring flow at almost every position, so the lanes are regrouped: a lane whose examined
+    // base has a scoring flow parks, the others run on through quiet positions, and the flow-by-flow code is entered once for a batch of
+    // parked lanes (each lane still performs exactly its own sequence of operations, only their interleaving changes). ----
     PackReader<2> r2; r2.init(bufB, stride);
     PackAppender<4> o2; o2.init(bufA, stride);
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
@@ -420,26 +371,42 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, uint32_t dom, const uint8_t *fl
         }
     };
     int t2 = 0, sp = 0;
-    rg.start(dom + D_FLOW_PASS2, thr);
-    bool done = failed; uint32_t x = 0;
-    while (!done) {
-        if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else break;
-        if (o2.n >= cap) { failed = true; break; }
-        // the empty flows in front of x: one draw each unless one scores (dwgsim.c:370-392); a quiet stretch is one mask test
-        const int k_empty = dist[4 * flow_i + (int)x];
-        if (rg.quiet_run((uint32_t)k_empty)) { flow_i += k_empty; if (flow_i >= F) flow_i -= F; }
-        else {                                       // the flows one by one
-            while (!failed && x != flow[flow_i]) {
-                const int n_err = rg.geometric();
-                if (!((mask >> flow_i) & 1) && n_err > 0) {
-                    if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
-                    else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
+    rg.dom += D_FLOW_PASS2;
+    bool done = failed, parked = false; uint32_t n2 = 0, x = 0;
+    for (;;) {
+        if (!done && !parked) {
+            if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else done = true;
+            if (!done && o2.n >= cap) { failed = true; done = true; }
+            if (!done) {
+                // flow q of the empty flows in front of x draws word q of the position's stream unless an earlier one scored: if none of
+                // the first k words is below the threshold nothing happens at this position (dwgsim.c:370-392)
+                const int k_empty = dist[4 * flow_i + (int)x];
+                bool quiet = true;
+                for (int q = 0; q < k_empty && quiet; q += 4) {
+                    const U4 b = rng_block(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)q >> 2, n2);
+                    quiet = !((uint64_t)b.x < thr || (q + 1 < k_empty && (uint64_t)b.y < thr) || (q + 2 < k_empty && (uint64_t)b.z < thr) || (q + 3 < k_empty && (uint64_t)b.w < thr));
                 }
-                flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
+                if (quiet) { flow_i += k_empty; if (flow_i >= F) flow_i -= F; settle(x, t2, sp); ++n2; }
+                else parked = true;
             }
-            if (failed) break;
         }
-        settle(x, t2, sp);
+        const uint64_t parked_lanes = __ballot(parked), running_lanes = __ballot(!done && !parked);
+        if (parked_lanes && (running_lanes == 0 || __popcll(parked_lanes) >= 16)) {
+            if (parked) {                               // the flows one by one from the start of the position's stream
+                rg.open(n2);
+                while (!failed && x != flow[flow_i]) {
+                    const int n_err = rg.geometric(thr);
+                    if (!((mask >> flow_i) & 1) && n_err > 0) {
+                        if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
+                        else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
+                    }
+                    flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
+                }
+                if (failed) done = true; else { settle(x, t2, sp); ++n2; }
+                parked = false;
+            }
+        }
+        if (__ballot(!done) == 0) break;
     }
     if (failed) return -1;
     o2.flush();

@@ -61,7 +61,7 @@ enum {
                           the 32-bit uniform of base i (error test / random-read base); the low half is halfword i of D_BASE_REF0 + j */
     D_QUAL0 = 10,      /* +j; index = ii; NARROW: the sequential stream of polar tries of the read's quality normals -- try t = words
                           2 (t & 1), 2 (t & 1) + 1 of block t >> 1; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
-    D_FLOW0 = 12,      /* +j; index = ii; the flow model's sequential stream of pass 1 (16-bit halves: see flow_u) */
+    D_FLOW0 = 12,      /* +j; index = ii; NARROW: word = running draw count inside generate_errors_flows */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
     D_FLOW_PASS2 = 8,  /* added to D_FLOW0 / D_CALIB (+j) for the second pass of generate_errors_flows: domains 20-23 */
     D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
@@ -167,15 +167,14 @@ static inline double rng_u32(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att,
 
 /* The uniform of base i of read end j (error test dwgsim.c:237, random-read base :1000).  Mode B: 32 bits, u = ((h << 16) | l) * 2^-32 with
  * h = halfword i of the D_BASE0 + j stream and l = halfword i of the D_BASE_REF0 + j stream (eight 16-bit draws per Philox block). */
-static inline uint32_t philox_halfword_r(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t retry, uint32_t i)
+static inline uint32_t philox_halfword(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t i)
 {
     uint32_t ctr[4], key[2], w[4];
-    ctr[0] = (uint32_t)idx; ctr[1] = (uint32_t)((idx >> 32) & 0xFFFFu) | (retry << 16); ctr[2] = (dom << 24) | (att & 0xFFFFFFu); ctr[3] = i >> 3;
+    ctr[0] = (uint32_t)idx; ctr[1] = (uint32_t)((idx >> 32) & 0xFFFFu); ctr[2] = (dom << 24) | (att & 0xFFFFFFu); ctr[3] = i >> 3;
     key[0] = r->k0; key[1] = r->k1;
     oracle_philox4x32_10(ctr, key, w);
     return (w[(i & 7) >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
 }
-static inline uint32_t philox_halfword(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t i) { return philox_halfword_r(r, dom, idx, att, 0, i); }
 static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
 {
     r->n_draws++;
@@ -874,18 +873,13 @@ static void flow_alloc(flowbuf_t *b, int len, int F)
     b->mem = (len + 2 > F + 2) ? len + 2 : F + 2;
     b->seq = calloc((size_t)b->mem, 1); b->mask = calloc((size_t)b->mem, 1);
 }
-/* mode B: each pass of the flow model consumes ONE sequential stream of 32-bit uniforms, in the reference's order: draw t of pass 1 (domain dom)
- * / pass 2 (domain dom + D_FLOW_PASS2) is u = ((h << 16) | l) * 2^-32 with h = halfword t of the (domain, retry 0) stream and l = halfword t
- * of the (domain, retry 1) stream (eight 16-bit draws per Philox block; the low half only matters when h alone does not decide: the kernels
- * draw it lazily). */
+/* mode B: narrow draws, one private sub-stream per EVENT of the flow model -- pass 1: the n-th homopolymer start of the read (domain dom),
+ * pass 2: the n-th examined base (domain dom + D_FLOW_PASS2): draw s of an event is word s & 3 of the block (retry s >> 2, block n).
+ * An event almost always needs one block, generated without regard to how many draws other reads consumed before. */
 static inline double flow_u(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t evt, uint32_t *es)
 {
-    (void)evt;
-    r->n_draws++;
-    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    const uint32_t t = (*es)++;
-    const uint32_t h = philox_halfword_r(r, fdom, idx, att, 0, t), l = philox_halfword_r(r, fdom, idx, att, 1, t);
-    return (double)((h << 16) | l) * 0x1p-32;
+    const uint32_t s = (*es)++;
+    return rng_u32(r, fdom, idx, att, s >> 2, (evt << 2) | (s & 3));
 }
 #define FLOW_U() flow_u(r, fdom, idx, att, evt, &es)
 static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t *slot,
@@ -893,7 +887,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
 {
     int i, j, k, hp_l, flow_i, n_err, F = o->flow_order_len;
     uint8_t prev_c, c;
-    uint32_t fdom = dom, evt = 0, es = 0; (void)slot;
+    uint32_t fdom = dom, evt = 0, es = 0, n_events = 0; (void)slot;
     for (i = 0; i < len; ++i) if (b->seq[i] >= 4) b->seq[i] = 0;
     if (strand == 1) for (i = 0; i < len >> 1; ++i) { c = b->seq[i]; b->seq[i] = b->seq[len - i - 1]; b->seq[len - i - 1] = c; }
     for (i = 0; i < F; ++i) {
@@ -908,6 +902,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
         while (c != o->flow_order[flow_i]) { b->mask[flow_i] = 0; flow_i = (flow_i + 1) % F; }
         if (prev_c != c) {
             b->mask[flow_i] = 0;
+            evt = n_events++; es = 0;
             n_err = 0;
             while (FLOW_U() < e) n_err++;
             if (0 < n_err) {
@@ -938,8 +933,9 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
             prev_c = c;
         }
     }
-    fdom = dom + D_FLOW_PASS2; es = 0;
+    fdom = dom + D_FLOW_PASS2;
     for (i = 0; i < len; ++i) { /* second pass: empty flows (flow_i continues) */
+        evt = (uint32_t)i; es = 0;
         c = (4 <= b->seq[i]) ? 0 : b->seq[i];
         while (c != o->flow_order[flow_i]) {
             n_err = 0;
