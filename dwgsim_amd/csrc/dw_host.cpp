@@ -31,7 +31,7 @@ struct Contig {
     int64_t l = 0;
     uint32_t contig_index = 0;
     bool alive = false, mutated = false;
-    uint8_t *d_ref = nullptr, *d_cells[2] = {nullptr, nullptr};
+    uint8_t *d_ref = nullptr, *d_cells[2] = {nullptr, nullptr}, *d_view[2] = {nullptr, nullptr};      // reference codes, byte cells, 4-bit read views
     int32_t *d_ins_pos[2] = {nullptr, nullptr};
     uint32_t *d_ins_len[2] = {nullptr, nullptr}, *d_ins_off[2] = {nullptr, nullptr};
     uint8_t *d_ins_bases[2] = {nullptr, nullptr};
@@ -140,7 +140,7 @@ ContigDev contig_dev(const Contig &k)
 {
     ContigDev d;
     for (int h = 0; h < 2; ++h) {
-        d.hap[h].cells = k.d_cells[h]; d.hap[h].ins_pos = k.d_ins_pos[h]; d.hap[h].ins_len = k.d_ins_len[h];
+        d.hap[h].cells = k.d_cells[h]; d.hap[h].view = k.d_view[h]; d.hap[h].ins_pos = k.d_ins_pos[h]; d.hap[h].ins_len = k.d_ins_len[h];
         d.hap[h].ins_off = k.d_ins_off[h]; d.hap[h].ins_bases = k.d_ins_bases[h]; d.hap[h].n_ins = k.n_ins[h];
     }
     d.ref = k.d_ref; d.l = k.l; d.contig_index = k.contig_index;
@@ -151,7 +151,7 @@ ContigDev contig_dev(const Contig &k)
 void free_contig(Contig &k)
 {
     hipFree(k.d_ref);
-    for (int h = 0; h < 2; ++h) { hipFree(k.d_cells[h]); hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]); }
+    for (int h = 0; h < 2; ++h) { hipFree(k.d_cells[h]); hipFree(k.d_view[h]); hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]); }
     hipFree(k.d_name_fixed); hipFree(k.d_reg); hipFree(k.d_summ[0]); hipFree(k.d_summ[1]);
     k = Contig();
 }
@@ -446,7 +446,7 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *
     auto fill = [&]() -> int {
         HIPC(c, hipMalloc((void **)&d_ascii, padded));
         HIPC(c, hipMalloc((void **)&k.d_ref, padded));
-        for (int h = 0; h < 2; ++h) HIPC(c, hipMalloc((void **)&k.d_cells[h], padded));
+        for (int h = 0; h < 2; ++h) { HIPC(c, hipMalloc((void **)&k.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&k.d_view[h], padded / 2 + 32)); }
         HIPC(c, hipMemcpyAsync(d_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, c->stream));
         HIPC(c, hipMemsetAsync(k.d_ref, 4, padded, c->stream));
         for (int h = 0; h < 2; ++h) HIPC(c, hipMemsetAsync(k.d_cells[h], 4, padded, c->stream));
@@ -570,6 +570,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         }
     }
     k.mutated = true; k.n_cand = 0; k.summ_valid = false;
+    const size_t padded_cells = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
     if (l == 0) return DWGSIM_HIP_OK;
     if (c->has_mutin) {      // file-driven mutations (mut.c:644-745): host resolves the entries, the GPU scatters and left-justifies
         ResolvedContig rc;
@@ -579,7 +580,11 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         for (uint32_t q = 0; q < np; ++q) if (rc.cells[q] & 0x3030) { Event e; e.pos = rc.pos[q]; e.type = 4; e.hap = 3; e.base = 0; e.live = 1; e.len = 1; evs.push_back(e); }
         const uint32_t nev = (uint32_t)evs.size();
         k.n_cand = nev;
-        if (np == 0) return DWGSIM_HIP_OK;
+        if (np == 0) {      // nothing listed for this contig: both haplotypes are the reference
+            for (int h = 0; h < 2; ++h) launch_make_view(c->stream, k.d_cells[h], (int64_t)padded_cells, k.d_view[h]);
+            HIPC(c, hipGetLastError()); HIPC(c, hipStreamSynchronize(c->stream));
+            return DWGSIM_HIP_OK;
+        }
         if (ensure(c, c->w_ppos, sizeof(int32_t) * np) || ensure(c, c->w_pcells, sizeof(uint16_t) * np) || ensure(c, c->w_ev, sizeof(Event) * (nev ? nev : 1)) ||
             ensure(c, c->w_lo, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_sufmin, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_bound, nev ? nev : 1)) return DWGSIM_HIP_ERR_DEVICE;
         HIPC(c, hipMemcpyAsync(c->w_ppos.p, rc.pos.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, c->stream));
@@ -615,6 +620,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             else launch_justify(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
         }
         launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
+        for (int h = 0; h < 2; ++h) launch_make_view(c->stream, k.d_cells[h], (int64_t)padded_cells, k.d_view[h]);
         HIPC(c, hipGetLastError());
         HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -676,6 +682,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         if (c->seq_justify) launch_justify_seq(c->stream, d_ev, nc, cd);
         else launch_justify(c->stream, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
         launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
+        for (int h = 0; h < 2; ++h) launch_make_view(c->stream, k.d_cells[h], (int64_t)padded_cells, k.d_view[h]);
         HIPC(c, hipGetLastError());
         HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

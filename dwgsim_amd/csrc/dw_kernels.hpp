@@ -35,6 +35,9 @@ struct Event {
 // one haplotype of one contig, resident in HBM
 struct HapDev {
     uint8_t *cells;         // [l + CELL_PAD]  bits 0-3 base code (0-3 ACGT, 4 N, 5 '-'), bits 4-5 type
+    const uint8_t *view;    // the read view of the cells, one NIBBLE per cell (cell i in byte i >> 1, even cells low): 0-3 unmutated A C G T, 4-7 substituted
+                            // to A C G T, 8 unmutated N, >= 9 "look at the byte cell" (INSERT / DELETE cells, '-').  Built by k_make_view after the walk;
+                            // base extraction reads 32 cells per 16-byte load from it and touches the byte cells only for the escapes
     int32_t *ins_pos;       // sorted positions of INSERT cells
     uint32_t *ins_len;
     uint32_t *ins_off;      // offset of the inserted bases P[0..n) (printed order) in ins_bases

@@ -12,81 +12,82 @@ namespace dw {
 struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n, n_ins; };   // n_ins: INSERT cells crossed (the reference's n_indel_first, dwgsim.c:98)
 
 // dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
-// The haplotype is read in 16-byte chunks with the next chunk prefetched; runs of up to 8 cells that
-// hold no INSERT/DELETE cell (bit 4 clear) are handled at once with byte-parallel arithmetic, any other
-// cell goes through the reference's per-cell logic.
+// The haplotype is read through its 4-bit view (HapDev::view) in 16-byte chunks = 32 cells, the next chunk prefetched; up to 16 cells in
+// travel order are handled at once with nibble-parallel arithmetic as long as none of them is an escape (an INSERT / DELETE cell or a '-':
+// nibble >= 9); an escape cell goes through the reference's per-cell logic on the byte cells.
+DW_DEV uint64_t reverse_nibbles(uint64_t x)
+{
+    x = __builtin_bswap64(x);
+    return ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+}
 template <bool STORE>
 DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
 {
     ReadRes r{-10, 0, 0, 0, 0};
-    int k = 0, kw = 0; uint64_t acc = 0; uint32_t nacc = 0;       // nacc nibbles pending in acc
-    auto push = [&](uint64_t nibs, uint32_t cnt) {                 // append cnt packed nibbles
+    int k = 0, kw = 0; uint64_t acc = 0; uint32_t nacc = 0;       // nacc (< 8) nibbles pending in acc
+    auto push8 = [&](uint32_t nibs, uint32_t cnt) {                // append cnt (<= 8) packed nibbles
         if (STORE) {
-            acc |= nibs << (4 * nacc); nacc += cnt;
+            acc |= (uint64_t)nibs << (4 * nacc); nacc += cnt;
             if (nacc >= 8) { lds[kw * stride] = (uint32_t)acc; acc >>= 32; nacc -= 8; ++kw; }
         }
-        k += (int)cnt;
     };
     auto emit = [&](uint32_t v) {
         if (strand) v = v < 4 ? 3 - v : 4;                 // dwgsim.c:150-152
         r.num_n += (v == 4);                                // dwgsim.c:824-831
-        push(v, 1);
+        push8(v, 1); ++k;
     };
-    const int64_t last_chunk = (l - 1) >> 4;
+    const int64_t last_chunk = (l - 1) >> 5;
     const int dirc = step > 0 ? 1 : -1;
     int64_t cb = -1, pb = -1; uint64_t clo = 0, chi = 0, plo = 0, phi = 0;
     if (start >= 0 && start < l) {
-        cb = start >> 4;
-        const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (cb << 4));
+        cb = start >> 5;
+        const uint4 v = *reinterpret_cast<const uint4 *>(h.view + (cb << 4));
         clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
         pb = cb + dirc;
-        if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
+        if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.view + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
 #if !defined(DW_EMU) && !defined(DW_NO_TOUCH)
-        // touch the following 128-byte lines of the read's window now (results unused): their HBM latency overlaps with the first
-        // chunks instead of being met one line at a time by the chunk loop
-        for (int t = 1; t <= 3 && t * 128 < s; ++t) {                    // only addresses the read is sure to reach: no over-fetch
-            const int64_t pa = start + (int64_t)dirc * 128 * t;
-            if (pa >= 0 && pa < l) (void)*reinterpret_cast<const volatile uint32_t *>(h.cells + (pa & ~(int64_t)3));
+        // touch the following 128-byte lines (256 cells each) of the read's window now (results unused): their HBM latency overlaps with
+        // the first chunks instead of being met one line at a time by the chunk loop
+        for (int t = 1; t <= 3 && t * 256 < s; ++t) {                    // only addresses the read is sure to reach: no over-fetch
+            const int64_t pa = start + (int64_t)dirc * 256 * t;
+            if (pa >= 0 && pa < l) (void)*reinterpret_cast<const volatile uint32_t *>(h.view + ((pa >> 1) & ~(int64_t)3));
         }
 #endif
     }
     int64_t i = start;
     while (i >= 0 && i < l && k < s) {
-        if ((i >> 4) != cb) {
-            cb = i >> 4;
+        if ((i >> 5) != cb) {
+            cb = i >> 5;
             if (cb == pb) { clo = plo; chi = phi; }
-            else { const uint4 v = *reinterpret_cast<const uint4 *>(h.cells + (cb << 4)); clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+            else { const uint4 v = *reinterpret_cast<const uint4 *>(h.view + (cb << 4)); clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32); }
             pb = cb + dirc;
-            if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.cells + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
+            if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.view + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
         }
-        const uint64_t half = (i & 8) ? chi : clo;
-        const uint32_t off = (uint32_t)(i & 7);
-        // cells of this 8-byte half in travel order, limited by the half, the read and the contig end
-        uint32_t want = step > 0 ? 8 - off : off + 1;
+        const uint64_t half = (i & 16) ? chi : clo;
+        const uint32_t off = (uint32_t)(i & 15);
+        // cells of this 16-cell half in travel order, limited by the half, the read and the contig end
+        uint32_t want = step > 0 ? 16 - off : off + 1;
         const uint32_t left = (uint32_t)(s - k);
         if (want > left) want = left;
         if (step > 0) { const int64_t room = l - i; if ((int64_t)want > room) want = (uint32_t)room; }
-        uint64_t cells = step > 0 ? half >> (8 * off) : __builtin_bswap64(half << (8 * (7 - off)));
-        if (want < 8) cells &= (1ull << (8 * want)) - 1;
-        if ((cells & 0x1010101010101010ull) == 0) {           // only NOCHANGE / SUBSTITUTE cells: one base each
+        uint64_t x = step > 0 ? half >> (4 * off) : reverse_nibbles(half << (4 * (15 - off)));
+        const uint64_t live = want < 16 ? (1ull << (4 * want)) - 1 : ~0ull;
+        x &= live;
+        const uint64_t isn = (x >> 3) & 0x1111111111111111ull;                                 // nibble >= 8
+        if ((isn & (x | (x >> 1) | (x >> 2))) == 0) {         // no escape (nibble >= 9) among them: one base per cell
             if (r.ext_coor < 0) { r.ext_coor = (int32_t)i; if (strand) r.ext_coor -= s - 1; }
-            r.n_sub += __popcll(cells & 0x2020202020202020ull);
-            uint64_t codes = cells & 0x0f0f0f0f0f0f0f0full;
-            const uint64_t ge4 = (codes >> 2) & 0x0101010101010101ull;
-            if (strand) {
-                codes = ((codes ^ 0x0303030303030303ull) & ~(ge4 * 0x0f)) | (ge4 << 2);
-                if (want < 8) codes &= (1ull << (8 * want)) - 1;
-                r.num_n += __popcll(ge4);
-            } else r.num_n += __popcll(ge4 & ~codes);          // exactly code 4 (code 5, '-', is not counted on this strand)
-            uint64_t x = codes;
-            x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-            x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-            x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-            push(x, want);
+            r.n_sub += __popcll(x & 0x4444444444444444ull);                                    // nibbles 4-7: substituted cells
+            r.num_n += __popcll(isn);                                                          // nibble 8: an N
+            uint64_t codes = x & 0x3333333333333333ull;
+            if (strand) codes = (codes ^ 0x3333333333333333ull) & ~(isn * 3) & live;           // complement, dwgsim.c:150-152 (N stays N)
+            codes |= isn << 2;                                                                  // N = code 4
+            push8((uint32_t)codes, want < 8 ? want : 8);
+            if (want > 8) push8((uint32_t)(codes >> 32), want - 8);
+            k += (int)want;
             i += (int64_t)step * want;
             continue;
         }
-        const uint32_t c = (uint32_t)(half >> (8 * off)) & 0xffu, mt = c & TMASK;
+        const uint32_t c = h.cells[i], mt = c & TMASK;          // an escape in the stretch: this cell by the reference's per-cell logic
         if (r.ext_coor < 0) {
             if (mt != T_NONE && mt != T_SUB) { i += step; continue; }
             r.ext_coor = (int32_t)i;
@@ -122,6 +123,7 @@ DW_DEV HapDev sel_hap(const SimArgs &a, int h)
 {
     HapDev r;
     r.cells = h ? a.c.hap[1].cells : a.c.hap[0].cells;
+    r.view = h ? a.c.hap[1].view : a.c.hap[0].view;
     r.ins_pos = h ? a.c.hap[1].ins_pos : a.c.hap[0].ins_pos;
     r.ins_len = h ? a.c.hap[1].ins_len : a.c.hap[0].ins_len;
     r.ins_off = h ? a.c.hap[1].ins_off : a.c.hap[0].ins_off;

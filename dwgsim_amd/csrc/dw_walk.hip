@@ -12,6 +12,8 @@
 //                     semantics inside independent clusters, clusters in parallel
 //     k_apply_patches file-driven mutations (-m / -b / -v) resolved on the host, scattered here
 //     k_collect_mask / k_gather   list of mutated cells for the host's txt/vcf writer
+//     k_mut_debug     the reference's consistency asserts (mut.c:379-425)
+//     k_make_view     4-bit read view of a finished haplotype (what base extraction reads)
 //
 // Byte/integer work only: no MFMA.  Host-callable launchers (dw_launch.hpp) are at the end.
 #include "dw_device.hpp"
@@ -573,6 +575,31 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_mut_debug(const uint8_t *__res
 void launch_mut_debug(hipStream_t st, const uint8_t *ref, const uint8_t *h0, const uint8_t *h1, int64_t l, uint64_t *verdict)
 {
     if (l > 0) hipLaunchKernelGGL(k_mut_debug, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, h0, h1, l, verdict);
+}
+// The read view of a finished haplotype (HapDev::view): one nibble per cell, 32 cells per thread.
+__global__ void __launch_bounds__(256) k_make_view(const uint8_t *__restrict__ cells, int64_t n_cells, uint8_t *__restrict__ view)
+{
+    const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 32;
+    if (first >= n_cells) return;                                  // n_cells (the padded length) is a multiple of 16
+    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (first + 16 * q >= n_cells) break;
+        const uint4 v = *reinterpret_cast<const uint4 *>(cells + first + 16 * q);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint32_t c = (w[b >> 2] >> (8 * (b & 3))) & 0xffu, t = c & TMASK, base = c & 0xfu;
+            const uint32_t nib = t == T_NONE ? (base < 4 ? base : base == 4 ? 8u : 9u) : (t == T_SUB && base < 4) ? 4u + base : 15u;
+            const int cell = 16 * q + b;
+            out[cell >> 3] |= nib << (4 * (cell & 7));
+        }
+    }
+    *reinterpret_cast<uint4 *>(view + (first >> 1)) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+void launch_make_view(hipStream_t st, const uint8_t *cells, int64_t n_cells, uint8_t *view)
+{
+    if (n_cells > 0) hipLaunchKernelGGL(k_make_view, dim3(cdiv((uint64_t)n_cells, 256 * 32)), dim3(256), 0, st, cells, n_cells, view);
 }
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
 {
