@@ -40,6 +40,23 @@ def _tmpdir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
 
+def effective_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(contigs, flags, sample_pairs=250000):
     """The unmodified reference (oracle/_ref/dwgsim, kind 'reference') -- or the oracle port in drand48 mode if the prebuilt
     binary is absent -- timed on this box's host cores on a bounded sample of the same workload (same contig, same flags,
@@ -47,7 +64,7 @@ def cpu_baseline(contigs, flags, sample_pairs=250000):
     no-ops (LD_PRELOAD shim oracle/build/libnullgz.so: what the simulation itself costs), (3) one process per host core,
     each with its own seed, all at once (the reference is single-threaded; this is how a user would fill the box)."""
     from dwgsim_amd import synth
-    ncores = os.cpu_count() or 1
+    ncores = effective_cores()
     with tempfile.TemporaryDirectory(dir=_tmpdir()) as t:
         fa = os.path.join(t, "ref.fa")
         synth.write_fasta(fa, contigs)
@@ -85,7 +102,7 @@ def cpu_baseline(contigs, flags, sample_pairs=250000):
         dtn = time.time() - t0
     out = {"value": round(sample_pairs / dt1 / 1e6, 6), "unit": "M read-pairs/s", "cores": 1, "kind": kind,
            "sample": f"{sample_pairs} pairs of the same workload (same contig and flags, -N {sample_pairs}; gzip FASTQ as the reference writes it), {dt1:.1f} s wall, one thread (the reference is single-threaded)",
-           "all_cores": {"value": round(per * ncores / dtn / 1e6, 6), "cores": ncores, "sample": f"{ncores} processes x {per} pairs (same flags, S2 contig), seeds 100.., {dtn:.1f} s wall"}}
+           "all_cores": {"value": round(per * ncores / dtn / 1e6, 6), "cores": ncores, "hardware_threads": os.cpu_count(), "sample": f"{ncores} processes x {per} pairs (same flags, S2 contig), seeds 100.., {dtn:.1f} s wall"}}
     if dt_null is not None:
         out["null_sink"] = {"value": round(sample_pairs / dt_null / 1e6, 6), "cores": 1, "sample": f"the same run with gzopen/gzwrite/gzputc/gzclose made no-ops by LD_PRELOAD, {dt_null:.1f} s wall"}
     return out
@@ -159,7 +176,7 @@ def end_to_end_leg(contigs, flags, n_pairs):
             return {"error": r.stderr.decode(errors="replace")[-300:]}
         gz = sum(os.path.getsize(os.path.join(t, f)) for f in os.listdir(t) if f.endswith(".gz"))
     return {"seconds": round(dt, 2), "value": round(n_pairs / dt / 1e6, 3), "unit": "M read-pairs/s", "gz_bytes": gz,
-            "deflate": {"threads": os.cpu_count(), "zlib_level": int(os.environ.get("DWGSIM_HIP_GZIP_LEVEL", "1")), "members": "independent 1 MiB gzip members"},
+            "deflate": {"threads": effective_cores(), "zlib_level": int(os.environ.get("DWGSIM_HIP_GZIP_LEVEL", "1")), "members": "independent 1 MiB gzip members"},
             "note": "wall time of `dwgsim-hip <flags> ref.fa out` (process start to exit), outputs on " + ("tmpfs" if _tmpdir() else "the temp dir")}
 
 

@@ -23,6 +23,7 @@
 #include <ctype.h>
 #include <time.h>
 #include <unistd.h>
+#include <sched.h>
 #include <limits.h>
 #include <zlib.h>
 #include <string>
@@ -290,6 +291,24 @@ static void on_all(int n, const std::function<void(int)> &fn)
     for (auto &t : th) t.join();
 }
 
+// host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (containers)
+static unsigned usable_cores()
+{
+    unsigned n = std::thread::hardware_concurrency(); if (n == 0) n = 4;
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (unsigned)c < n) n = (unsigned)c; }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long p = 0;
+        if (fscanf(f, "%63s %lld", q, &p) == 2 && strcmp(q, "max") && p > 0) { const unsigned lim = (unsigned)((atof(q) / (double)p) + 0.5); if (lim >= 1 && lim < n) n = lim; }
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long long q = 0, p = 0; if (fscanf(g, "%lld", &q) != 1) q = 0; fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &p) != 1) p = 0; fclose(h); }
+        if (q > 0 && p > 0) { const unsigned lim = (unsigned)((double)q / (double)p + 0.5); if (lim >= 1 && lim < n) n = lim; }
+    }
+    return n;
+}
+
 static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
 int main(int argc, char **argv)
@@ -355,7 +374,7 @@ int main(int argc, char **argv)
     }
     if (devs.empty()) devs.push_back(getenv("DWGSIM_HIP_DEVICE") ? atoi(getenv("DWGSIM_HIP_DEVICE")) : 0);
     const int ND = (int)devs.size();
-    unsigned nthreads = std::thread::hardware_concurrency(); if (nthreads == 0) nthreads = 4;
+    unsigned nthreads = usable_cores();
     if (const char *e = getenv("DWGSIM_HIP_THREADS")) nthreads = (unsigned)atoi(e);
     int gz_level = 1;
     if (const char *e = getenv("DWGSIM_HIP_GZIP_LEVEL")) { gz_level = atoi(e); if (gz_level < 0 || gz_level > 9) gz_level = 1; }
