@@ -159,9 +159,9 @@ def host_landed_leg(api, ctx, cid, n_pairs, params, steps=2, batch=1 << 20):
             "note": "FASTQ text landed in page-locked host memory: simulate_async / wait / fetch_async on two slots, copies on a second stream overlapped with the kernels of the next batch"}
 
 
-def end_to_end_leg(contigs, flags, n_pairs):
-    """The dwgsim-hip executable on the same job: FASTA parse, upload, walk, mutation files, reads, page-locked copies, deflate on the
-    host cores, the five output files written (to tmpfs when there is one)."""
+def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu"):
+    """The dwgsim-hip executable on the same job: FASTA parse, upload, walk, mutation files, reads, gzip (members made on the GPU, or
+    zlib on the host cores with DWGSIM_HIP_GZIP=cpu), page-locked copies, the five output files written (to tmpfs when there is one)."""
     from dwgsim_amd import synth
     exe = os.path.join(ROOT, "dwgsim_amd", "dwgsim-hip")
     if not os.path.exists(exe):
@@ -170,13 +170,17 @@ def end_to_end_leg(contigs, flags, n_pairs):
         fa = os.path.join(t, "ref.fa")
         synth.write_fasta(fa, contigs)
         t0 = time.time()
-        r = subprocess.run([exe] + flags.split() + [fa, os.path.join(t, "out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        r = subprocess.run([exe] + flags.split() + [fa, os.path.join(t, "out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                           env=dict(os.environ, DWGSIM_HIP_GZIP=gzip_mode, DWGSIM_HIP_TIMING="1"))
         dt = time.time() - t0
         if r.returncode != 0:
             return {"error": r.stderr.decode(errors="replace")[-300:]}
         gz = sum(os.path.getsize(os.path.join(t, f)) for f in os.listdir(t) if f.endswith(".gz"))
-    return {"seconds": round(dt, 2), "value": round(n_pairs / dt / 1e6, 3), "unit": "M read-pairs/s", "gz_bytes": gz,
-            "deflate": {"threads": effective_cores(), "zlib_level": int(os.environ.get("DWGSIM_HIP_GZIP_LEVEL", "1")), "members": "independent 1 MiB gzip members"},
+        stages = [ln for ln in r.stderr.decode(errors="replace").splitlines() if ln.startswith("[dwgsim-hip]")]
+    gzinfo = ({"where": "gpu", "members": "64 KiB of text each, dynamic Huffman codes (k_gzip)"} if gzip_mode == "gpu" else
+              {"where": "cpu", "threads": effective_cores(), "zlib_level": int(os.environ.get("DWGSIM_HIP_GZIP_LEVEL", "1")), "members": "independent 1 MiB gzip members"})
+    return {"seconds": round(dt, 2), "value": round(n_pairs / dt / 1e6, 3), "unit": "M read-pairs/s", "gz_bytes": gz, "gzip": gzinfo,
+            "stages": stages[-1][13:] if stages else None,
             "note": "wall time of `dwgsim-hip <flags> ref.fa out` (process start to exit), outputs on " + ("tmpfs" if _tmpdir() else "the temp dir")}
 
 
@@ -338,6 +342,9 @@ def main():
         ctx.close(); ctx = None
         if world == 1 and not args.no_legs and args.workload in ("ecoli", "chr20"):
             out["end_to_end"] = end_to_end_leg(contigs, flags, job_pairs)
+            cpu_gz = end_to_end_leg(contigs, flags, job_pairs, "cpu")
+            if cpu_gz and "seconds" in cpu_gz:
+                out["end_to_end"]["with_zlib_on_host"] = {k: cpu_gz[k] for k in ("seconds", "value", "gz_bytes", "gzip")}
         if world == 1 and not args.no_cpu_baseline:
             base_contigs = contigs[:1] if len(contigs) == 1 else [c for c in contigs if c[0] == "chr20"] or contigs[:1]      # (whole-genome jobs: the chr20-sized contig)
             out["cpu_baseline"] = cpu_baseline(base_contigs, flags)

@@ -34,7 +34,7 @@ class Params(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("n_random", C.c_uint64), ("n_retries", C.c_uint64), ("bytes", C.c_uint64 * 3),
                 ("dev_ptr", C.c_void_p * 3), ("kernel_ms", C.c_float), ("sim_kernel_ms", C.c_float),
-                ("fail_seg", C.c_uint64 * 4), ("fail_carry", C.c_uint64)]
+                ("fail_seg", C.c_uint64 * 4), ("fail_carry", C.c_uint64), ("gz_bytes", C.c_uint64 * 3)]
 
 
 RAND_CHAIN = (1 << 64) - 1        # DWGSIM_HIP_RAND_CHAIN
@@ -47,7 +47,7 @@ EXPORTS = [
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
-    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte",
+    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async",
 ]
 
 _lib = None
@@ -98,6 +98,8 @@ def load(path: str | None = None):
     lib.dwgsim_hip_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.dwgsim_hip_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.dwgsim_hip_debug_count_byte.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_uint64)]
+    lib.dwgsim_hip_set_gzip.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_fetch_gz_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     if path is None:
         _lib = lib
     return lib
@@ -315,6 +317,21 @@ class Context:
 
     def set_fail_carry(self, carry: int):
         self._chk(self.lib.dwgsim_hip_set_fail_carry(self.h, carry))
+
+    def set_gzip(self, on: bool = True):
+        self._chk(self.lib.dwgsim_hip_set_gzip(self.h, 1 if on else 0))
+
+    def fetch_gz(self, slot: int, stream: int, nbytes: int) -> bytes:
+        """The .gz form of a finished stream (GPU gzip), through a page-locked bounce buffer."""
+        if not nbytes:
+            return b""
+        p = self.lib.dwgsim_hip_host_alloc(int(nbytes))
+        try:
+            self._chk(self.lib.dwgsim_hip_fetch_gz_async(self.h, slot, stream, p, int(nbytes)))
+            self._chk(self.lib.dwgsim_hip_fetch_wait(self.h, slot))
+            return C.string_at(p, int(nbytes))
+        finally:
+            self.lib.dwgsim_hip_host_free(p)
 
     def count_byte(self, slot: int, stream: int, byte: int) -> int:
         n = C.c_uint64(0)

@@ -54,7 +54,8 @@ struct Slot {                       // one of the two batches a context can have
     uint64_t *d_counters = nullptr, *h_counters = nullptr;      // device block + pinned mirror
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_fetched = nullptr;
     bool pending = false, empty = true, fetch_in_flight = false;
-    uint64_t n_pairs = 0, out_bytes[3] = {0, 0, 0};
+    uint64_t n_pairs = 0, out_bytes[3] = {0, 0, 0}, gz_bytes[3] = {0, 0, 0};
+    DevBuf gz_out[3], gz_status;        // GPU gzip: the members of each stream, look-back words
 };
 
 } // namespace
@@ -88,6 +89,7 @@ struct dwgsim_hip_ctx {
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
     int64_t walk_cap = -1; bool phases = false;             // dwgsim_hip_debug_option
+    bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
     std::string txt, vcf;
 };
@@ -417,11 +419,12 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->fail_summ.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
-    hipFree(c->d_counters); hipFree(c->d_flow); hipFree(c->d_chain);
+    hipFree(c->d_counters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (Slot &sl : c->slot) {
-        hipFree(sl.d_counters);
+        hipFree(sl.d_counters); hipFree(sl.gz_status.p);
+        for (int t = 0; t < 3; ++t) hipFree(sl.gz_out[t].p);
         if (sl.h_counters) hipHostFree(sl.h_counters);
         for (hipEvent_t e : {sl.ev_k0, sl.ev_k1, sl.ev_done, sl.ev_fetched}) if (e) hipEventDestroy(e);
     }
@@ -932,7 +935,7 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "simulate: the slot still holds a batch that was not waited for"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
-    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = 0;
+    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = sl.gz_bytes[t] = 0;
     sl.n_pairs = n_pairs; sl.empty = n_pairs == 0;
     // the reference's failure counter (dwgsim.c:635) runs over the pairs of ONE contig in index order: it is carried from the previous
     // batch only when this one continues it; any other range starts from zero unless the caller supplied the carry (sharded jobs)
@@ -968,6 +971,22 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii
     launch_simulate(c->stream, a);
     HIPC(c, hipEventRecord(sl.ev_k1, c->stream));
     launch_failrule(c->stream, a.meta, n_pairs, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
+    if (c->gzip_on) {      // the .gz form of every stream, enqueued behind the text (lengths are read on the device: counters[4 + t])
+        size_t nch[3], off = 0;
+        for (int t = 0; t < 3; ++t) { nch[t] = (size_t)gz_chunks(cap[t]); off += nch[t]; }
+        if (ensure(c, sl.gz_status, sizeof(uint64_t) * (off ? off : 1))) return DWGSIM_HIP_ERR_DEVICE;
+        HIPC(c, hipMemsetAsync(sl.gz_status.p, 0, sizeof(uint64_t) * (off ? off : 1), c->stream));
+        off = 0;
+        for (int t = 0; t < 3; ++t) {
+            if (cap[t] == 0) continue;
+            const size_t gcap = (size_t)gz_capacity(cap[t]);
+            if (ensure(c, sl.gz_out[t], gcap + 64)) return DWGSIM_HIP_ERR_DEVICE;
+            HIPC(c, hipMemsetAsync(sl.gz_out[t].p, 0, gcap + 64, c->stream));
+            launch_gzip(c->stream, a.out[t], &sl.d_counters[4 + t], cap[t], (uint8_t *)sl.gz_out[t].p, gcap, (uint64_t *)sl.gz_status.p + off, &sl.d_counters[28 + t], &sl.d_counters[24 + t], &sl.d_counters[2],
+                        c->d_crc_table, c->d_crc_shift);
+            off += nch[t];
+        }
+    }
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sl.h_counters, sl.d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipEventRecord(sl.ev_done, c->stream));
@@ -988,10 +1007,11 @@ int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
     const uint64_t *h = sl.h_counters;
     if (h[2] & 4) { c->err = "dwgsim-hip: no fragment placement satisfied the target regions (-x) after 2^20 tries (the reference would not terminate)\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (h[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
-    if (h[2] || h[20]) {      // one pair used up its 10 001 attempts, or the counter of failed attempts over the pairs of the contig passed the limit (dwgsim.c:635, :833-843)
+    if ((h[2] & ~8ull) || h[20]) {      // one pair used up its 10 001 attempts, or the counter of failed attempts over the pairs of the contig passed the limit (dwgsim.c:635, :833-843)
         char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED;
     }
-    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = h[4 + t];
+    if (h[2] & 8) { c->err = "dwgsim-hip: the gzip output buffer is too small for this text\n"; return DWGSIM_HIP_ERR_FAILED; }
+    for (int t = 0; t < 3; ++t) { sl.out_bytes[t] = h[4 + t]; sl.gz_bytes[t] = h[24 + t]; }
     if (c->phases) {   // only meaningful with the -DDW_PHASE_TIMING build (tools/phase_profile.sh)
         uint64_t tot = 0; for (int k = 0; k < 8; ++k) tot += h[8 + k];
         fprintf(stderr, "[phases]");
@@ -1001,6 +1021,7 @@ int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
     if (out) {
         out->n_pairs = sl.n_pairs; out->n_random = h[3]; out->n_retries = h[1];
         for (int t = 0; t < 3; ++t) { out->bytes[t] = sl.out_bytes[t]; out->dev_ptr[t] = c->out[slot][t].p; }
+        for (int t = 0; t < 3; ++t) out->gz_bytes[t] = sl.gz_bytes[t];
         for (int t = 0; t < 4; ++t) out->fail_seg[t] = h[16 + t];
         out->fail_carry = h[21];
         HIPC(c, hipEventElapsedTime(&out->sim_kernel_ms, sl.ev_k0, sl.ev_k1));
@@ -1036,6 +1057,36 @@ int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *host
     if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
     if (n == 0) return DWGSIM_HIP_OK;
     HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPC(c, hipEventRecord(sl.ev_fetched, c->copy_stream));
+    sl.fetch_in_flight = true;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_set_gzip(dwgsim_hip_ctx_t *c, int on)
+{
+    if (!c) return DWGSIM_HIP_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (on && !c->d_crc_table) {
+        std::vector<uint32_t> tab(256), sh(8 * 1024);
+        gz_host_tables(tab.data(), sh.data());
+        HIPC(c, hipMalloc((void **)&c->d_crc_table, tab.size() * 4)); HIPC(c, hipMalloc((void **)&c->d_crc_shift, sh.size() * 4));
+        HIPC(c, hipMemcpy(c->d_crc_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(c->d_crc_shift, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->gzip_on = on != 0;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)
+{
+    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) { if (c) c->err = "bad fetch arguments"; return DWGSIM_HIP_ERR_ARG; }
+    Slot &sl = c->slot[slot];
+    if (sl.pending) { c->err = "fetch: wait for the batch first (its sizes are not known yet)"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)sl.gz_bytes[stream];
+    if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
+    if (n == 0) return DWGSIM_HIP_OK;
+    HIPC(c, hipMemcpyAsync(host_dst, sl.gz_out[stream].p, n, hipMemcpyDeviceToHost, c->copy_stream));
     HIPC(c, hipEventRecord(sl.ev_fetched, c->copy_stream));
     sl.fetch_in_flight = true;
     return DWGSIM_HIP_OK;

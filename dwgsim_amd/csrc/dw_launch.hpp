@@ -25,6 +25,11 @@ void launch_calibrate(hipStream_t st, const CalibArgs &a);
 void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t *summ, uint64_t *counters, uint64_t *chain);
 void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry);
 void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out);
+uint64_t gz_chunks(uint64_t n);
+uint64_t gz_capacity(uint64_t n);
+void gz_host_tables(uint32_t *crc_table, uint32_t *crc_shift);
+void launch_gzip(hipStream_t st, const uint8_t *text, const uint64_t *n_dev, uint64_t text_cap, uint8_t *out, uint64_t out_cap, uint64_t *status, uint64_t *ticket, uint64_t *total, uint64_t *flags,
+                 const uint32_t *crc_table, const uint32_t *crc_shift);
 void launch_count_byte(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t byte, uint64_t *out);
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism);
 }

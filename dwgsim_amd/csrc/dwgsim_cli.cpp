@@ -13,7 +13,9 @@
 // and the abort rule's failure counter, dwgsim.c:635).  Environment (all optional):
 //     DWGSIM_HIP_DEVICES   "0,1,2,3" or a count "4" (default: device DWGSIM_HIP_DEVICE or 0)
 //     DWGSIM_HIP_THREADS   deflate threads (default: all host cores)
-//     DWGSIM_HIP_GZIP_LEVEL  zlib level 0..9 (default 1: the text is produced ~1000x faster than zlib -6 packs it)
+//     DWGSIM_HIP_GZIP      "gpu" (default): the gzip members are made on the GPU (dwgsim_hip_set_gzip: Huffman-coded 64 KiB members, ~0.49 of the
+//                          text), the host only writes them; "cpu": zlib on all host cores at DWGSIM_HIP_GZIP_LEVEL (smaller files, deflate-bound)
+//     DWGSIM_HIP_GZIP_LEVEL  zlib level 0..9 for DWGSIM_HIP_GZIP=cpu (default 1: the text is produced ~1000x faster than zlib -6 packs it)
 //     DWGSIM_HIP_BATCH     read pairs per GPU batch (default 2^20)
 //     DWGSIM_HIP_MIN_SHARE a contig is spread over fewer devices while a device's share would be below this many pairs (default 65536)
 #include <stdio.h>
@@ -143,13 +145,14 @@ static bool deflate_member(const char *src, size_t n, int level, std::vector<uns
 
 // One pinned host buffer set: the text of one GPU batch (up to three streams).  `left` counts the deflate chunks still reading it.
 struct TextBuf {
+    bool raw = false; size_t text_n[3] = {0, 0, 0};      // raw: the buffers hold finished gzip members (GPU gzip) of text_n[s] bytes of text
     char *p[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}, n[3] = {0, 0, 0};
     std::atomic<int> left{0};
 };
 
 struct Chunk {             // one gzip member in flight
     int stream = 0; const char *src = nullptr; size_t n = 0; TextBuf *owner = nullptr;
-    std::vector<unsigned char> gz; bool done = false, ok = true;
+    std::vector<unsigned char> gz; bool done = false, ok = true, raw = false; size_t text_n = 0;
 };
 
 class Output {
@@ -195,7 +198,13 @@ public:
         const size_t CH = (size_t)1 << 20;
         std::vector<std::shared_ptr<Chunk>> cs;
         for (int s = 0; s < 3; ++s)
-            for (size_t off = 0; off < b->n[s]; off += CH) {
+            for (size_t off = 0; off < b->n[s]; off += b->raw ? b->n[s] : CH) {
+                if (b->raw) {          // already gzip members: written as they are, the buffer is released by the writer
+                    auto c = std::make_shared<Chunk>();
+                    c->stream = s; c->src = b->p[s]; c->n = b->n[s]; c->owner = b; c->raw = true; c->done = true; c->text_n = b->text_n[s];
+                    cs.push_back(std::move(c));
+                    continue;
+                }
                 auto c = std::make_shared<Chunk>();
                 c->stream = s; c->src = b->p[s] + off; c->n = b->n[s] - off < CH ? b->n[s] - off : CH; c->owner = b;
                 cs.push_back(std::move(c));
@@ -204,7 +213,7 @@ public:
         if (cs.empty()) { lanes_[(size_t)lane].free_bufs.push_back(b); cv_buf_.notify_all(); return; }
         b->left.store((int)cs.size());
         b_lane_[b] = lane;
-        for (auto &c : cs) { lanes_[(size_t)lane].q.push_back(c); todo_.push_back(c); }
+        for (auto &c : cs) { lanes_[(size_t)lane].q.push_back(c); if (!c->raw) todo_.push_back(c); }
         cv_work_.notify_all(); cv_write_.notify_all();
     }
     // this lane has nothing more for the current contig: an end mark IN the lane's queue (the lane may already be filling in the next
@@ -258,8 +267,13 @@ private:
                     cv_write_.wait(lk);
                 }
             }
-            if (!c->ok || fwrite(c->gz.data(), 1, c->gz.size(), f_[c->stream]) != c->gz.size()) { std::unique_lock<std::mutex> lk(m_); failed_ = true; cv_buf_.notify_all(); }
-            bytes_in_ += c->n; bytes_out_ += c->gz.size();
+            const void *data = c->raw ? (const void *)c->src : (const void *)c->gz.data(); const size_t nb = c->raw ? c->n : c->gz.size();
+            if (!c->ok || fwrite(data, 1, nb, f_[c->stream]) != nb) { std::unique_lock<std::mutex> lk(m_); failed_ = true; cv_buf_.notify_all(); }
+            bytes_in_ += c->raw ? c->text_n : c->n; bytes_out_ += nb;
+            if (c->raw) {
+                std::unique_lock<std::mutex> lk(m_);
+                if (c->owner->left.fetch_sub(1) == 1) { lanes_[(size_t)b_lane_[c->owner]].free_bufs.push_back(c->owner); cv_buf_.notify_all(); }
+            }
         }
     }
     FILE *f_[3]; int level_;
@@ -366,6 +380,7 @@ int main(int argc, char **argv)
     if (dwgsim_hip_params_check(&o, msg, sizeof msg) != DWGSIM_HIP_OK) { fprintf(stderr, "%s", msg); return usage(&o); }
     if (o.output_type == 1) fprintf(stderr, "[dwgsim_core] note: the reference dereferences a NULL VCF handle with -M 1; dwgsim-hip simply writes no mutation files\n");
 
+    const bool want_mut = o.output_type != 1, want_reads = o.output_type != 2;
     // devices
     std::vector<int> devs;
     if (const char *e = getenv("DWGSIM_HIP_DEVICES")) {
@@ -376,6 +391,11 @@ int main(int argc, char **argv)
     const int ND = (int)devs.size();
     unsigned nthreads = usable_cores();
     if (const char *e = getenv("DWGSIM_HIP_THREADS")) nthreads = (unsigned)atoi(e);
+    bool gpu_gzip = true;
+    if (const char *e = getenv("DWGSIM_HIP_GZIP")) {
+        if (!strcmp(e, "cpu")) gpu_gzip = false;
+        else if (strcmp(e, "gpu")) { fprintf(stderr, "dwgsim-hip: DWGSIM_HIP_GZIP must be gpu or cpu\n"); return 1; }
+    }
     int gz_level = 1;
     if (const char *e = getenv("DWGSIM_HIP_GZIP_LEVEL")) { gz_level = atoi(e); if (gz_level < 0 || gz_level > 9) gz_level = 1; }
     uint64_t min_share = 65536;
@@ -399,7 +419,6 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < tab_names.size(); ++i) { fprintf(stderr, "[dwgsim_core] %s length: %d\n", tab_names[i].c_str(), (int)tab_lens[i]); tot_len += (uint64_t)tab_lens[i]; }
     fprintf(stderr, "[dwgsim_core] %d sequences, total length: %llu\n", (int)tab_names.size(), (unsigned long long)tot_len);
 
-    const bool want_mut = o.output_type != 1, want_reads = o.output_type != 2;
     const bool has_bfast = want_reads && o.reads_output_type != 1, has_bwa = want_reads && o.reads_output_type != 2;
     FILE *fp_txt = nullptr, *fp_vcf = nullptr, *fgz[3] = {nullptr, nullptr, nullptr};
     std::string p = out_prefix;
@@ -430,6 +449,7 @@ int main(int argc, char **argv)
             if (dwgsim_hip_set_regions(ctx[(size_t)d], regions_fn.c_str(), nm.data(), ln.data(), (int)nm.size(), &tl) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx[(size_t)d])); destroy_all(); return 1; }
             tot_len = tl;
         }
+        if (gpu_gzip && want_reads && dwgsim_hip_set_gzip(ctx[(size_t)d], 1) < 0) { fprintf(stderr, "%s", dwgsim_hip_last_error(ctx[(size_t)d])); destroy_all(); return 1; }
         if (muts_type >= 0 && dwgsim_hip_set_mutation_input(ctx[(size_t)d], muts_type, muts_fn.c_str(), nm.data(), ln.data(), (int)nm.size()) < 0) {     // dwgsim.c:494-497
             fprintf(stderr, "%s", dwgsim_hip_last_error(ctx[(size_t)d])); destroy_all(); return 1;
         }
@@ -511,11 +531,12 @@ int main(int argc, char **argv)
                     if (dwgsim_hip_wait(x, pb.slot, &b) < 0) { fail(dwgsim_hip_last_error(x)); return; }
                     for (int q = 0; q < 4; ++q) segs[(size_t)d].push_back(b.fail_seg[q]);
                     got_rand[(size_t)d] += b.n_random;
-                    TextBuf *tb = out->acquire(d, b.bytes);
+                    TextBuf *tb = out->acquire(d, gpu_gzip ? b.gz_bytes : b.bytes);
                     if (!tb) { fail("dwgsim-hip: writing FASTQ failed"); return; }
+                    tb->raw = gpu_gzip;
                     for (int s = 0; s < 3; ++s) {
-                        tb->n[s] = b.bytes[s];
-                        if (b.bytes[s] && dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s]) < 0) { fail(dwgsim_hip_last_error(x)); tb->n[0] = tb->n[1] = tb->n[2] = 0; out->submit(d, tb); return; }
+                        tb->n[s] = gpu_gzip ? b.gz_bytes[s] : b.bytes[s]; tb->text_n[s] = b.bytes[s];
+                        if (tb->n[s] && (gpu_gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail(dwgsim_hip_last_error(x)); tb->n[0] = tb->n[1] = tb->n[2] = 0; out->submit(d, tb); return; }
                     }
                     if (dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail(dwgsim_hip_last_error(x)); tb->n[0] = tb->n[1] = tb->n[2] = 0; }
                     out->submit(d, tb);
@@ -552,9 +573,10 @@ int main(int argc, char **argv)
     const double t_out_done = now_s();
     fprintf(stderr, "\n[dwgsim_core] Complete!\n");
     if (timing) fprintf(stderr, "[dwgsim-hip] read FASTA %.2f s | contexts, files, inputs %.2f s | upload + walk + mutation text %.2f s | simulate + copy (deflate running behind) %.2f s | "
-                                "drain deflate + write %.2f s | total %.2f s; text %.2f GB -> gz %.2f GB, %d device(s), %u deflate threads, zlib level %d\n",
+                                "drain deflate + write %.2f s | total %.2f s; text %.2f GB -> gz %.2f GB, %d device(s), %s\n",
                         t_fasta - t_start, t_ctx - t_fasta, t_walk, t_sim, t_out_done - t_gpu_done, t_out_done - t_start,
-                        out ? out->bytes_in() / 1e9 : 0.0, out ? out->bytes_out() / 1e9 : 0.0, ND, nthreads, gz_level);
+                        out ? out->bytes_in() / 1e9 : 0.0, out ? out->bytes_out() / 1e9 : 0.0, ND,
+                        gpu_gzip ? "gzip members made on the GPU" : (std::string("zlib level ") + std::to_string(gz_level) + " on " + std::to_string(nthreads) + " host threads").c_str());
     destroy_all();
     out.reset();
     if (fp_txt) fclose(fp_txt);

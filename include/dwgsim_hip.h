@@ -86,6 +86,7 @@ typedef struct dwgsim_hip_batch {
      * over several contexts joins the summaries in read-index order (dwgsim_hip_failseg_join) to get the exact verdict. */
     uint64_t fail_seg[4];
     uint64_t fail_carry;       /* the counter after this batch, given the carry it started from */
+    uint64_t gz_bytes[3];      /* with dwgsim_hip_set_gzip(ctx, 1): bytes of the .gz form of each stream (a sequence of complete gzip members) */
 } dwgsim_hip_batch_t;
 
 /* rand_base value meaning "continue the running count after the previous batch of this context" (kept on the device, so successive
@@ -190,6 +191,13 @@ void dwgsim_hip_host_free(void *p);
  * overlaps with the kernels of the other slot); fetch_wait blocks until every copy enqueued for the slot has landed. */
 int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *ctx, int slot);
+
+/* gzip on the GPU (replaces the gzopen / gzprintf / gzputc output of dwgsim.c:919-981, :1150-1158): once switched on, every simulate call also
+ * leaves each finished stream in HBM as a sequence of complete gzip members (one per 64 KiB of text, dynamic Huffman codes; concatenating the
+ * members of successive batches gives a valid .gz whose decompressed bytes are exactly the text), and fetch_gz_async copies THAT to page-locked
+ * host memory: a third of the bytes cross PCIe and the host only writes them. */
+int dwgsim_hip_set_gzip(dwgsim_hip_ctx_t *ctx, int on);
+int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
 /* Copy one finished stream of a slot to host memory.  A page-locked destination (hipHostMalloc / hipHostRegister) takes one direct
  * hipMemcpyAsync at link speed; pageable memory goes through double-buffered pinned staging inside. */

@@ -82,25 +82,31 @@ def test_hopeless_target_regions_end_with_an_error(emu_lib, golden_dir, tmp_path
         api.run_job(api.parse_flags(f"-z 3 -N 130 -1 50 -2 50 -d 500 -s 5 -x {bed}", emu_lib), api.read_fasta(os.path.join(golden_dir, "tiny.fa")), lib=emu_lib)
 
 
-@pytest.mark.parametrize("fasta,flags", [
-    ("tiny.fa", "-z 9 -N 900 -P pfx -r 0.01 -R 0.3 -y 0.2"),
-    ("tiny.fa", "-z 9 -N 500 -c 2 -f TACG -1 100 -2 60 -e 0.05 -E 0.02 -d 300"),
-    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 3 -m {IN}/muts_edge.txt -o 1"),
+@pytest.mark.parametrize("fasta,flags,gz", [
+    ("tiny.fa", "-z 9 -N 900 -P pfx -r 0.01 -R 0.3 -y 0.2", "gpu"),
+    ("tiny.fa", "-z 9 -N 900 -P pfx -r 0.01 -R 0.3 -y 0.2", "cpu"),
+    ("tiny.fa", "-z 9 -N 500 -c 2 -f TACG -1 100 -2 60 -e 0.05 -E 0.02 -d 300", "gpu"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 3 -m {IN}/muts_edge.txt -o 1", "cpu"),
 ])
-def test_command_line_on_several_contexts_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, tmp_path, fasta, flags):
+def test_command_line_on_several_contexts_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, tmp_path, fasta, flags, gz):
     """The dwgsim-hip host code (three contexts on host threads, read-index ranges with count_random bases, two batches in flight per
     context, deflate pool, ordered merge) linked against the emulated library: the five files equal the oracle's after gunzip."""
     import gzip
     from parity_common import run_oracle, IN_DIR
     flags = flags.replace("{IN}", IN_DIR)
     want = run_oracle(oracle_bin, os.path.join(golden_dir, fasta), flags, str(tmp_path))
-    env = dict(os.environ, DWGSIM_HIP_DEVICES="0,0,0", DWGSIM_HIP_MIN_SHARE="40", DWGSIM_HIP_BATCH="150", DWGSIM_HIP_THREADS="3")
+    env = dict(os.environ, DWGSIM_HIP_DEVICES="0,0,0", DWGSIM_HIP_MIN_SHARE="40", DWGSIM_HIP_BATCH="150", DWGSIM_HIP_THREADS="3", DWGSIM_HIP_GZIP=gz)
     subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + [os.path.join(golden_dir, fasta), str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL, env=env)
     for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz"), (2, "bfast.fastq.gz")]:
         p = str(tmp_path / ("cli." + suf))
         assert (gzip.open(p, "rb").read() if os.path.exists(p) else b"") == want[k], suf
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
+
+
+def test_gzip_members_made_by_the_kernels_on_cpu_emulation(emu_lib, golden_dir):
+    from parity_common import check_gpu_gzip
+    check_gpu_gzip(emu_lib, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", sizes=(700, 1, 90))
 
 
 def test_mut_debug_aborts_on_cpu_emulation(emu_lib, oracle_bin, golden_dir):

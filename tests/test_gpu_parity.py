@@ -88,7 +88,8 @@ def test_cli_is_a_drop_in_for_the_dwgsim_command(oracle_bin, golden_dir, tmp_pat
     ("odd.fa", "-z 6 -C 30 -2 0 -1 120 -r 0.05 -R 0.9 -I 40 -y 0.3 -n 3"),
     ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -C 8 -m {IN}/muts_edge.txt"),
 ])
-def test_cli_on_several_contexts_writes_the_same_files(oracle_bin, golden_dir, tmp_path, fasta, flags):
+@pytest.mark.parametrize("gz", ["gpu", "cpu"])
+def test_cli_on_several_contexts_writes_the_same_files(oracle_bin, golden_dir, tmp_path, fasta, flags, gz):
     """dwgsim-hip with three contexts (here all on GPU 0: the multi-GPU code path on a 1-GPU box), tiny batches and every contig
     split into read-index ranges: host threads, per-range rand_ii bases from count_random, ordered merge of the deflated
     members -- the five files must equal the oracle's (= the single-context run's) after gunzip."""
@@ -98,12 +99,22 @@ def test_cli_on_several_contexts_writes_the_same_files(oracle_bin, golden_dir, t
     cli = os.path.join(root, "dwgsim_amd", "dwgsim-hip")
     flags = flags.replace("{IN}", IN_DIR)
     want = run_oracle(oracle_bin, os.path.join(golden_dir, fasta), flags, str(tmp_path))
-    env = dict(os.environ, DWGSIM_HIP_DEVICES="0,0,0", DWGSIM_HIP_MIN_SHARE="40", DWGSIM_HIP_BATCH="333", DWGSIM_HIP_THREADS="4")
+    env = dict(os.environ, DWGSIM_HIP_DEVICES="0,0,0", DWGSIM_HIP_MIN_SHARE="40", DWGSIM_HIP_BATCH="333", DWGSIM_HIP_THREADS="4", DWGSIM_HIP_GZIP=gz)
     subprocess.run([cli] + flags.split() + [os.path.join(golden_dir, fasta), str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL, env=env)
     for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz"), (2, "bfast.fastq.gz")]:
         assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k], suf
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
+
+
+@pytest.mark.parametrize("flags,sizes", [
+    ("-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", (40000, 1, 900, 333333)),
+    (f"-z 3 -c 2 -f {FLOW_ORDER} -1 200 -2 0 -e 0.02 -o 1", (20000, 7)),
+    ("-z 4 -c 1 -1 50 -2 50 -o 2", (50000, 129)),
+])
+def test_gzip_members_made_on_the_gpu(lib, golden_dir, flags, sizes):
+    from parity_common import check_gpu_gzip
+    check_gpu_gzip(lib, os.path.join(golden_dir, "tiny.fa"), flags, sizes)
 
 
 def test_cli_abort_rule_across_contexts(oracle_bin, golden_dir, tmp_path):
