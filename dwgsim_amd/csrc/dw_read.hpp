@@ -421,60 +421,21 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
 #ifndef DW_KNOCK
 #define DW_KNOCK 0
 #endif
-struct Writer {               // sequential byte stream -> bursts of 64-byte aligned chunks
-    // A lane's record is cut at 64-byte boundaries of the output buffer; a chunk is assembled in registers
-    // (three finished 16-byte sub-blocks in s0..s5, the one being filled in lo/hi) and leaves as four
-    // back-to-back dwordx4 stores, so L2 sees whole 64-byte request units instead of 16-byte crumbs
-    // (partially written lines were being evicted and written back 2.6x, profiles/r01_p3).
-    // Only the first / last chunk of a record is ragged: bytes [skip, upto) go out as dwords / bytes.
-    uint8_t *blk; uint64_t lo, hi, s0, s1, s2, s3, s4, s5; uint32_t n, sub, skip;
-    DW_DEV void init(uint8_t *p)
+struct __attribute__((packed, aligned(1))) Unal16 { uint64_t a, b; };      // stores at any byte address: gfx950 global memory takes unaligned
+struct __attribute__((packed, aligned(1))) Unal8 { uint64_t v; };           // dword / dwordx2 / dwordx4 accesses as they are (one instruction)
+struct __attribute__((packed, aligned(1))) Unal4 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) Unal2 { uint16_t v; };
+struct Writer {               // sequential byte stream of one record -> 16-byte stores at the record's own (arbitrary) byte phase
+    // The bytes are gathered in lo / hi RELATIVE TO THE SECTION START p, so whole groups (16 bases, 16 qualities) go out with no funnel
+    // shift at all: put16 is one unaligned dwordx4 store.  flush() writes the ragged rest (8 + 4 + 2 + 1 bytes) and starts a new section
+    // at the next byte, which is how the callers re-phase before the base line and before the quality line.
+    uint8_t *p; uint64_t lo, hi; uint32_t n;
+    DW_DEV void init(uint8_t *q) { p = q; lo = hi = 0; n = 0; }
+    DW_DEV void emit()
     {
-        const uint32_t o = (uint32_t)((uintptr_t)p & 63);
-        blk = p - o; sub = o >> 4; n = o & 15; skip = o;
-        lo = hi = s0 = s1 = s2 = s3 = s4 = s5 = 0;
-    }
-    static DW_DEV void store16(uint8_t *dst, uint64_t a, uint64_t b, uint32_t from, uint32_t upto)   // bytes [from, upto) of a 16-byte block
-    {
-        if (from == 0 && upto == 16) { *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)); return; }
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t w = (uint32_t)((q < 2 ? a : b) >> (32 * (q & 1)));
-            const uint32_t b0 = 4 * q, b1 = b0 + 4;
-            if (from <= b0 && upto >= b1) *reinterpret_cast<uint32_t *>(dst + b0) = w;
-            else for (uint32_t k = b0; k < b1; ++k) if (k >= from && k < upto) dst[k] = (uint8_t)(w >> (8 * (k - b0)));
-        }
-    }
-    DW_DEV void store_chunk(uint32_t upto)       // bytes [skip, upto) of the current chunk
-    {
-        if (DW_KNOCK & 2) { asm volatile("" :: "v"(lo), "v"(hi), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(upto)); return; }     // assembled, kept alive, not stored
-        if (skip == 0 && upto == 64) {           // the common case: one 64-byte burst
-            uint4 *d = reinterpret_cast<uint4 *>(blk);
-            d[0] = make_uint4((uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)s1, (uint32_t)(s1 >> 32));
-            d[1] = make_uint4((uint32_t)s2, (uint32_t)(s2 >> 32), (uint32_t)s3, (uint32_t)(s3 >> 32));
-            d[2] = make_uint4((uint32_t)s4, (uint32_t)(s4 >> 32), (uint32_t)s5, (uint32_t)(s5 >> 32));
-            d[3] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-            return;
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t b0 = 16 * q;
-            if (upto <= b0 || skip >= b0 + 16) continue;
-            const uint64_t a = (q == sub) ? lo : (q == 0 ? s0 : q == 1 ? s2 : s4);
-            const uint64_t b = (q == sub) ? hi : (q == 0 ? s1 : q == 1 ? s3 : s5);
-            const uint32_t from = skip > b0 ? skip - b0 : 0, to = upto < b0 + 16 ? upto - b0 : 16;
-            store16(blk + b0, a, b, from, to);
-        }
-    }
-    DW_DEV void advance()                        // the 16-byte sub-block in lo/hi is complete
-    {
-        if (sub == 3) { store_chunk(64); blk += 64; sub = 0; skip = 0; }
-        else {      // value selects, not conditional stores: keeps s0..s5 in registers
-            const bool z0 = sub == 0, z1 = sub == 1, z2 = sub == 2;
-            s0 = z0 ? lo : s0; s1 = z0 ? hi : s1; s2 = z1 ? lo : s2; s3 = z1 ? hi : s3; s4 = z2 ? lo : s4; s5 = z2 ? hi : s5;
-            ++sub;
-        }
-        lo = hi = 0; n = 0;
+        if (DW_KNOCK & 2) asm volatile("" :: "v"(lo), "v"(hi), "v"(p));      // assembled, kept alive, not stored
+        else { Unal16 v; v.a = lo; v.b = hi; *reinterpret_cast<Unal16 *>(p) = v; }
+        p += 16; lo = hi = 0; n = 0;
     }
     DW_DEV void put(uint32_t b)
     {
@@ -482,7 +443,7 @@ struct Writer {               // sequential byte stream -> bursts of 64-byte ali
         if (DW_KNOCK & 64) { asm volatile("" :: "v"(b)); return; }       // producers kept alive, no assembly
         const uint64_t v = (uint64_t)b << (8 * (n & 7));
         if (n < 8) lo |= v; else hi |= v;
-        if (++n == 16) advance();
+        if (++n == 16) emit();
     }
     DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes, little-endian in v, upper bytes zero
     {
@@ -493,14 +454,30 @@ struct Writer {               // sequential byte stream -> bursts of 64-byte ali
         else hi |= v << sh;
         const uint32_t total = n + cnt;
         if (total >= 16) {
-            const uint32_t over = total - 16;       // bytes that belong to the next sub-block (0..7)
+            const uint32_t over = total - 16;       // bytes that belong to the next 16 (0..7)
             const uint64_t carry = over ? v >> (8 * (cnt - over)) : 0;
-            advance();
+            emit();
             lo = carry; n = over;
         } else n = total;
     }
     DW_DEV void put4(uint32_t w) { putn((uint64_t)w, 4); }
-    DW_DEV void flush() { const uint32_t upto = 16 * sub + n; if (upto > skip) store_chunk(upto); }
+    DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)       // sixteen bytes; one store when the section stands at a multiple of 16
+    {
+        if (DW_KNOCK & 1) return;
+        if (DW_KNOCK & 64) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d)); return; }
+        const uint64_t x = (uint64_t)a | ((uint64_t)b << 32), y = (uint64_t)c | ((uint64_t)d << 32);
+        if (n == 0) { lo = x; hi = y; emit(); }
+        else { putn(x, 8); putn(y, 8); }
+    }
+    DW_DEV void flush()                          // the n < 16 gathered bytes; the next byte starts a new section
+    {
+        if (DW_KNOCK & 2) { asm volatile("" :: "v"(lo), "v"(hi), "v"(p), "v"(n)); p += n; lo = hi = 0; n = 0; return; }
+        if (n & 8) { Unal8 v; v.v = lo; *reinterpret_cast<Unal8 *>(p) = v; p += 8; lo = hi; }
+        if (n & 4) { Unal4 v; v.v = (uint32_t)lo; *reinterpret_cast<Unal4 *>(p) = v; p += 4; lo >>= 32; }
+        if (n & 2) { Unal2 v; v.v = (uint16_t)lo; *reinterpret_cast<Unal2 *>(p) = v; p += 2; lo >>= 16; }
+        if (n & 1) { *p = (uint8_t)lo; p += 1; }
+        lo = hi = 0; n = 0;
+    }
 };
 template <int OUT>            // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream
 struct Out2 {
@@ -508,6 +485,7 @@ struct Out2 {
     DW_DEV void put(uint32_t c) { if (OUT & 1) a.put(c); if (OUT & 2) b.put(c); }
     DW_DEV void put4(uint32_t w) { if (OUT & 1) a.put4(w); if (OUT & 2) b.put4(w); }
     DW_DEV void putn(uint64_t v, uint32_t cnt) { if (OUT & 1) a.putn(v, cnt); if (OUT & 2) b.putn(v, cnt); }
+    DW_DEV void put16(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { if (OUT & 1) a.put16(x, y, z, w); if (OUT & 2) b.put16(x, y, z, w); }
     DW_DEV void flush() { if (OUT & 1) a.flush(); if (OUT & 2) b.flush(); }
 };
 DW_DEV uint32_t ndigits10(uint32_t v)

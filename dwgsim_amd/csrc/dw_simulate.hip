@@ -554,9 +554,16 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         if (OUT & 1) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
         if (OUT & 2) o.b.put('\n');
         PH_MARK(4); // header line
-        // bases
+        // bases: a new section of the writer, so that sixteen bases are one store
+        o.flush();
         PackReader<4> rev; rev.init(lds, nthr);
-        for (int w = 0; w * 8 < s_out; ++w) {
+        int w = 0;
+        if (!(DT == 2 && flow_reversed))
+            for (; (w + 2) * 8 <= s_out; w += 2) {
+                const uint32_t w0 = lds[w * nthr], w1 = lds[(w + 1) * nthr];
+                o.put16(base_chars4(w0), base_chars4(w0 >> 16), base_chars4(w1), base_chars4(w1 >> 16));
+            }
+        for (; w * 8 < s_out; ++w) {
             uint32_t word;
             if (DT == 2 && flow_reversed) {         // base i of the record = base s_out-1-i of the flow-model orientation
                 word = 0;
@@ -571,15 +578,25 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             }
         }
         o.put('\n'); o.put('+'); o.put('\n');
+        o.flush();
         PH_MARK(5); // sequence line
-        // qualities (dwgsim.c:899-918), four characters per store
+        // qualities (dwgsim.c:899-918), sixteen characters per store
         {
-            uint32_t qacc = 0, nq = 0;
+            uint32_t q0 = 0, q1 = 0, q2 = 0, qacc = 0, nq = 0;
             for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, [&](int, uint32_t q) {
-                qacc |= q << (8 * nq);
-                if (++nq == 4) { o.put4(qacc); qacc = 0; nq = 0; }
+                qacc |= q << (8 * (nq & 3));
+                if ((++nq & 3) == 0) {
+                    const uint32_t k = nq >> 2;
+                    if (k == 4) { o.put16(q0, q1, q2, qacc); nq = 0; }
+                    else { q0 = k == 1 ? qacc : q0; q1 = k == 2 ? qacc : q1; q2 = k == 3 ? qacc : q2; }
+                    qacc = 0;
+                }
             });
-            for (uint32_t q = 0; q < nq; ++q) o.put((qacc >> (8 * q)) & 0xff);
+            const uint32_t k = nq >> 2;
+            if (k > 0) o.put4(q0);
+            if (k > 1) o.put4(q1);
+            if (k > 2) o.put4(q2);
+            for (uint32_t q = 0; q < (nq & 3); ++q) o.put((qacc >> (8 * q)) & 0xff);
         }
         o.put('\n');
         o.flush();
