@@ -12,6 +12,11 @@ constexpr int PAIRS_PER_BLOCK = 128;     // k_place / k_calibrate: pairs (reads)
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
 constexpr int FLOW_STACK_RUNS = 32;           // Ion Torrent pass 2: (base, count) runs that can be pending in front of the examined base (two per LDS word)
 constexpr int SIM_THREADS_LONG = 64;          // ... for reads whose staged bases do not fit LDS at SIM_THREADS lanes (up to ~5 kb)
+constexpr int SIM_FIFO_BYTES = 40;            // per lane: the text FIFO of the record writer (one 32-byte burst + the overshoot of an 8-byte put)
+// dynamic LDS of a k_simulate block: [words_per_lane][lanes] staged bases | the two base-quality tables | [lanes] text FIFOs (16-byte aligned)
+inline size_t sim_lds_bytes(size_t words_per_lane, size_t lanes, size_t qb_words, bool fifo) { return ((words_per_lane * lanes + 2 * qb_words + 3) & ~(size_t)3) * 4 + (fifo ? lanes * (size_t)SIM_FIFO_BYTES : 0); }
+// blocks of SIM_THREADS lanes a CU holds at this much dynamic LDS (160 KB per CU in granules of 1280 bytes, ~0.6 KB static per block), at most `cap` (the register limit)
+inline int sim_blocks_per_cu(size_t dyn_lds, int cap) { const size_t per = (dyn_lds + 640 + 1279) / 1280 * 1280; const int b = (int)(163840 / per); return b < cap ? b : cap; }
 constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for (160 KB per CU minus the static part)
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
 constexpr int SCAN_THREADS = 256;
@@ -112,6 +117,7 @@ struct SimArgs {
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
     int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
     int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors
+    int32_t fifo;                 // 1: the records leave through the per-lane LDS FIFO (32-byte aligned bursts); 0: 16-byte pieces straight from registers (when the FIFO would cost a block per CU)
     int32_t sim_threads;          // lanes per k_simulate block chosen by the host: SIM_THREADS, or SIM_THREADS_LONG for long reads
     int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
     uint32_t *flow_scratch;        // Ion Torrent: per-block read buffers in HBM, (lds_words + ceil(cap/16)) words per lane, word w of lane t at [w * nthr + t]

@@ -431,6 +431,7 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
     // at the next byte, which is how the callers re-phase before the base line and before the quality line.
     uint8_t *p; uint64_t lo, hi; uint32_t n;
     DW_DEV void init(uint8_t *q) { p = q; lo = hi = 0; n = 0; }
+    DW_DEV void init(uint8_t *, uint8_t *q) { init(q); }
     DW_DEV void emit()
     {
         if (DW_KNOCK & 2) asm volatile("" :: "v"(lo), "v"(hi), "v"(p));      // assembled, kept alive, not stored
@@ -479,14 +480,72 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
         lo = hi = 0; n = 0;
     }
 };
-template <int OUT>            // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream
+// The record writer of the primary output: a 40-byte FIFO per lane in LDS.  Bytes are appended at any byte position with plain (unaligned)
+// LDS stores of up to 8 bytes -- the LDS does the byte shifting, no VALU -- and leave as 32-byte ALIGNED bursts (two dwordx4 stores): the L2
+// of gfx950 does not merge a lane's pieces over time (41 k lanes per XCD write 41 k different lines), so what leaves the L2 is 32 bytes per
+// touched sector per burst: 16-byte pieces cost 2.5x-3.3x the text, aligned 32-byte bursts 1.1x (tools/ubench_write_bursts.hip,
+// profiles/r02_ubench_write_bursts.txt).  FIFO position 0 always stands for the 32-byte aligned address dst; a record starts at position
+// skip = its address mod 32.  40 bytes, not 48 with 16-byte appends: LDS is what limits the blocks per CU (5 at 2 x 150 bp).
+struct FifoWriter {
+    uint8_t *f, *dst; uint32_t wp, skip;
+    DW_DEV void init(uint8_t *fifo, uint8_t *rec) { const uint32_t h = (uint32_t)((uintptr_t)rec & 31u); f = fifo; dst = rec - h; wp = skip = h; }
+    DW_DEV uint64_t ld8(uint32_t b) const { return *reinterpret_cast<const uint64_t *>(f + b); }
+    DW_DEV void st16(uint32_t b) const { *reinterpret_cast<uint4 *>(dst + b) = make_uint4((uint32_t)ld8(b), (uint32_t)(ld8(b) >> 32), (uint32_t)ld8(b + 8), (uint32_t)(ld8(b + 8) >> 32)); }
+    DW_DEV void store_range(uint32_t from, uint32_t upto)        // bytes [from, upto) of the unit (ragged first / last unit of a record), from LDS
+    {
+        uint32_t b = from;       // rising sizes until b is aligned (or the next piece would pass upto), then falling sizes
+        if ((b & 1u) && b + 1 <= upto) { dst[b] = f[b]; b += 1; }
+        if ((b & 2u) && b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
+        if ((b & 4u) && b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
+        if ((b & 8u) && b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
+        if (b + 16 <= upto) { st16(b); b += 16; }
+        if (b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
+        if (b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
+        if (b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
+        if (b + 1 <= upto) { dst[b] = f[b]; }
+    }
+    DW_DEV void drain()                          // wp >= 32: one unit leaves
+    {
+        if (!(DW_KNOCK & 2)) {
+            if (skip == 0) { st16(0); st16(16); }
+            else store_range(skip, 32);
+        }
+        skip = 0;
+        *reinterpret_cast<uint64_t *>(f) = ld8(32);      // the (< 8) bytes past the unit move to the front
+        dst += 32; wp -= 32;
+    }
+    DW_DEV void put(uint32_t b) { if (DW_KNOCK & 1) return; f[wp] = (uint8_t)b; if (++wp >= 32u) drain(); }
+    DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes; the bytes above them are overwritten by the next put
+    {
+        if (DW_KNOCK & 1) return;
+        Unal8 x; x.v = v; *reinterpret_cast<Unal8 *>(f + wp) = x;
+        wp += cnt; if (wp >= 32u) drain();
+    }
+    DW_DEV void put4(uint32_t w) { if (DW_KNOCK & 1) return; Unal4 x; x.v = w; *reinterpret_cast<Unal4 *>(f + wp) = x; wp += 4; if (wp >= 32u) drain(); }
+    DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { putn((uint64_t)a | ((uint64_t)b << 32), 8); putn((uint64_t)c | ((uint64_t)d << 32), 8); }
+    DW_DEV void flush() { if (wp > skip && !(DW_KNOCK & 2)) store_range(skip, wp); dst += wp; wp = skip = 0; }
+};
+// OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream.  The (first) output goes through the FIFO writer (WR = 1)
+// or the register writer (WR = 0: the host found that the FIFO's LDS would cost a resident block per CU); with both outputs (-o 0) the
+// bfast stream always takes the register writer.
+template <int WR> struct PrimaryWriter { typedef FifoWriter type; };
+template <> struct PrimaryWriter<0> { typedef Writer type; };
+template <int OUT, int WR = 1>
 struct Out2 {
-    Writer a, b;
-    DW_DEV void put(uint32_t c) { if (OUT & 1) a.put(c); if (OUT & 2) b.put(c); }
-    DW_DEV void put4(uint32_t w) { if (OUT & 1) a.put4(w); if (OUT & 2) b.put4(w); }
-    DW_DEV void putn(uint64_t v, uint32_t cnt) { if (OUT & 1) a.putn(v, cnt); if (OUT & 2) b.putn(v, cnt); }
-    DW_DEV void put16(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { if (OUT & 1) a.put16(x, y, z, w); if (OUT & 2) b.put16(x, y, z, w); }
-    DW_DEV void flush() { if (OUT & 1) a.flush(); if (OUT & 2) b.flush(); }
+    typename PrimaryWriter<WR>::type a; Writer b;
+    DW_DEV void init(uint8_t *fifo, uint8_t *bwa, uint8_t *bfast) { a.init(fifo, (OUT & 1) ? bwa : bfast); if (OUT == 3) b.init(bfast); }
+    DW_DEV void put(uint32_t c) { a.put(c); if (OUT == 3) b.put(c); }
+    DW_DEV void put4(uint32_t w) { a.put4(w); if (OUT == 3) b.put4(w); }
+    DW_DEV void putn(uint64_t v, uint32_t cnt) { a.putn(v, cnt); if (OUT == 3) b.putn(v, cnt); }
+    DW_DEV void put16(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { a.put16(x, y, z, w); if (OUT == 3) b.put16(x, y, z, w); }
+    // the end of the name line differs between the two families: "/1\n" (bwa) and "\n" (bfast)
+    DW_DEV void put_suffix(uint64_t v_bwa, uint32_t n_bwa, uint64_t v_bf, uint32_t n_bf)
+    {
+        if (OUT & 1) a.putn(v_bwa, n_bwa); else a.putn(v_bf, n_bf);
+        if (OUT == 3) b.putn(v_bf, n_bf);
+    }
+    DW_DEV void rebase() { if (WR == 0) a.flush(); if (OUT == 3) b.flush(); }      // a new section of the register writer(s); the FIFO needs none
+    DW_DEV void flush() { a.flush(); if (OUT == 3) b.flush(); }
 };
 DW_DEV uint32_t ndigits10(uint32_t v)
 {
@@ -495,8 +554,8 @@ DW_DEV uint32_t ndigits10(uint32_t v)
 DW_DEV uint32_t ndigits16(uint64_t v) { return v ? (uint32_t)(67 - __clzll((long long)v)) >> 2 : 1u; }
 // decimal digits of v as packed ASCII, most significant digit in the lowest byte (stream order);
 // lead = one separator byte to emit in front (0 = none).  Numbers above 10^7 take the two-part path.
-template <int OUT>
-DW_DEV void put_dec(Out2<OUT> &o, uint32_t v, uint32_t lead)
+template <class O>
+DW_DEV void put_dec(O &o, uint32_t v, uint32_t lead)
 {
     uint32_t low7 = 0; bool big = false;
     if (v >= 10000000u) { const uint32_t hi = v / 10000000u; low7 = v - hi * 10000000u; v = hi; big = true; }   // 8..10 digits
@@ -510,8 +569,8 @@ DW_DEV void put_dec(Out2<OUT> &o, uint32_t v, uint32_t lead)
         o.putn(w, 7);
     }
 }
-template <int OUT>
-DW_DEV void put_hex(Out2<OUT> &o, uint64_t v)
+template <class O>
+DW_DEV void put_hex(O &o, uint64_t v)
 {
     const uint32_t nd = ndigits16(v);
     for (uint32_t part = 0; part < 2; ++part) {      // up to 16 digits: the high (nd-8) first, then the low 8

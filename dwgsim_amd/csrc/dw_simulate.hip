@@ -131,19 +131,19 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
 #endif
 
 // ---- pieces of a FASTQ record shared by the Illumina / Ion Torrent and the SOLiD write paths ----
-// '@' + "[prefix_]contig" (or "[prefix_]rand"): whole words from LDS (first 256 bytes), any rest from HBM
-template <int OUT>
-DW_DEV void put_name_fixed(Out2<OUT> &o, const uint32_t *fw, const uint8_t *fx, uint32_t fixed_len)
+// '@' + "[prefix_]contig" (or "[prefix_]rand"): whole words from LDS (first 128 bytes), any rest from HBM
+template <class O>
+DW_DEV void put_name_fixed(O &o, const uint32_t *fw, const uint8_t *fx, uint32_t fixed_len)
 {
-    const uint32_t flen = fixed_len + 1, inl = flen < 256u ? flen : 256u;
+    const uint32_t flen = fixed_len + 1, inl = flen < 128u ? flen : 128u;
     uint32_t q = 0;
     for (; q + 4 <= inl; q += 4) o.put4(fw[q >> 2]);
     if (q < inl) o.putn((uint64_t)fw[q >> 2] & ((1ull << (8 * (inl - q))) - 1), inl - q);
     for (q = inl; q < flen; ++q) o.put(fx[q]);
 }
 // "_0_0_0_0_1_1_0:0:0_0:0:0_<hex>" of a random read (dwgsim.c:1044-1048)
-template <int OUT>
-DW_DEV void put_rand_tail(Out2<OUT> &o, uint64_t rand_ii)
+template <class O>
+DW_DEV void put_rand_tail(O &o, uint64_t rand_ii)
 {
     o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
     o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
@@ -153,8 +153,8 @@ DW_DEV void put_rand_tail(Out2<OUT> &o, uint64_t rand_ii)
 }
 struct NameCounts { int32_t e0, u0, i0, e1, u1, i1; };     // n_err : n_sub : n_indel of read end 1 and 2
 // "_pos1_pos2_strand1_strand2_0_0_e:s:i_e:s:i_<hex>" (dwgsim.c:923-929)
-template <int OUT>
-DW_DEV void put_pair_tail(Out2<OUT> &o, int32_t x0, int32_t x1, uint32_t strand0, uint32_t strand1, const NameCounts &n, uint64_t ii)
+template <class O>
+DW_DEV void put_pair_tail(O &o, int32_t x0, int32_t x1, uint32_t strand0, uint32_t strand1, const NameCounts &n, uint64_t ii)
 {
     put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
     o.putn((uint64_t)'_' | ((uint64_t)('0' + strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + strand1) << 24)
@@ -277,14 +277,15 @@ DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint6
 
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 // NTHR: lanes per block.  SIM_THREADS_LONG (one wave) is the variant for reads too long to stage at SIM_THREADS lanes.
-template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS>
+// WR = 1: records leave through the per-lane LDS FIFO; 0: straight from registers (dw_read.hpp FifoWriter / Writer)
+template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1>
 __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
     __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_rbase, s_base[3];
-    __shared__ uint32_t s_fixed[2][64];          // "@[prefix_]contig" and "@[prefix_]rand", first 256 bytes
+    __shared__ uint32_t s_fixed[2][32];          // "@[prefix_]contig" and "@[prefix_]rand", first 128 bytes
     __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
     __shared__ uint8_t s_dist[256];              // ... and the flow-distance table (fill_flow_dist)
     constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
@@ -292,12 +293,14 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const int wave = tid >> 6, lane = tid & 63;
     PH_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
-    for (int q = tid; q < 128; q += nthr)                                                          // buffers are padded to 256 + 16 bytes
-        (&s_fixed[0][0])[q] = q < 64 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 64];
+    for (int q = tid; q < 64; q += nthr)                                                           // buffers are padded to 256 + 16 bytes
+        (&s_fixed[0][0])[q] = q < 32 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 32];
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
     uint32_t *const s_qb = dyn_lds + (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr;
     for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
+    // this lane's text FIFO (record writer), behind the tables
+    uint8_t *const s_fifo = reinterpret_cast<uint8_t *>(dyn_lds + ((((size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) + 3) & ~(size_t)3)) + (size_t)tid * SIM_FIFO_BYTES;
     __syncthreads();
     if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
     const uint32_t t = s_ticket;                                  // logical block: predecessors have started
@@ -517,8 +520,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         if (emits) {
             for (int which = 0; which < 2; ++which) {            // 0: BWA stream of this end, 1: BFAST
                 if (!(OUT & (1 << which))) continue;
-                Out2<1> o;
-                o.a.init(which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa);
+                Out2<1, WR> o;
+                o.init(s_fifo, which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa, nullptr);
                 put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
                 if (is_rand) put_rand_tail(o, rand_ii);
                 else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1,           // (value selects: a struct select would go through memory)
@@ -543,19 +546,17 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     } else
     // ---- write the record(s) ----
     if (valid && s_out > 0) {
-        Out2<OUT> o;
-        if (OUT & 1) o.a.init((j ? a.out[1] : a.out[0]) + off_bwa);
-        if (OUT & 2) o.b.init(a.out[2] + off_bf);
+        Out2<OUT, WR> o;
+        o.init(s_fifo, (OUT & 1) ? (j ? a.out[1] : a.out[0]) + off_bwa : nullptr, (OUT & 2) ? a.out[2] + off_bf : nullptr);
         if (!(DW_KNOCK & 16)) {
         put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
         if (is_rand) put_rand_tail(o, rand_ii);
         else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
         }
-        if (OUT & 1) o.a.putn((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3);
-        if (OUT & 2) o.b.put('\n');
+        o.put_suffix((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3, (uint64_t)'\n', 1);
         PH_MARK(4); // header line
-        // bases: a new section of the writer, so that sixteen bases are one store
-        o.flush();
+        // bases (the second writer of -o 0 starts a new section, so that sixteen bases are one store)
+        o.rebase();
         PackReader<4> rev; rev.init(lds, nthr);
         int w = 0;
         if (!(DT == 2 && flow_reversed))
@@ -578,7 +579,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             }
         }
         o.put('\n'); o.put('+'); o.put('\n');
-        o.flush();
+        o.rebase();
         PH_MARK(5); // sequence line
         // qualities (dwgsim.c:899-918), sixteen characters per store
         {
@@ -853,7 +854,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    const size_t lds = ((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) * 4;   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables
+    const size_t lds = sim_lds_bytes((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables + the text FIFOs
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }
@@ -869,6 +870,12 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     void launch_sim_##LPP##_##DT(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out)             \
     {                                                                                                            \
         const uint32_t nthr = SIM_THREADS;                                                                       \
+        if (DT == 0 && !a.fifo) {                                                                                \
+            if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, DT == 0 ? 0 : DT, SIM_THREADS, DT == 0 ? 0 : 1>), dim3(nb), dim3(nthr), lds, st, a);      \
+            else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT == 0 ? 0 : DT, SIM_THREADS, DT == 0 ? 0 : 1>), dim3(nb), dim3(nthr), lds, st, a); \
+            else hipLaunchKernelGGL((k_simulate<LPP, 3, DT == 0 ? 0 : DT, SIM_THREADS, DT == 0 ? 0 : 1>), dim3(nb), dim3(nthr), lds, st, a);               \
+            return;                                                                                              \
+        }                                                                                                        \
         if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, DT>), dim3(nb), dim3(nthr), lds, st, a);            \
         else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT>), dim3(nb), dim3(nthr), lds, st, a);       \
         else hipLaunchKernelGGL((k_simulate<LPP, 3, DT>), dim3(nb), dim3(nthr), lds, st, a);                     \

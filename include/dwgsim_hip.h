@@ -195,7 +195,7 @@ int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *ctx, int slot);
 /* gzip on the GPU (replaces the gzopen / gzprintf / gzputc output of dwgsim.c:919-981, :1150-1158): once switched on, every simulate call also
  * leaves each finished stream in HBM as a sequence of complete gzip members (one per 64 KiB of text, dynamic Huffman codes; concatenating the
  * members of successive batches gives a valid .gz whose decompressed bytes are exactly the text), and fetch_gz_async copies THAT to page-locked
- * host memory: a third of the bytes cross PCIe and the host only writes them. */
+ * host memory: half of the bytes cross PCIe and the host only writes them. */
 int dwgsim_hip_set_gzip(dwgsim_hip_ctx_t *ctx, int on);
 int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
@@ -203,7 +203,7 @@ int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void 
  * hipMemcpyAsync at link speed; pageable memory goes through double-buffered pinned staging inside. */
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
-/* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases" (see dw_host.cpp). */
+/* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases", "writer" (see dw_host.cpp). */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
 /* ... and: occurrences of `byte` in one finished stream of a slot, counted on the device (whole-output checks without a copy-out). */
 int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int byte, uint64_t *count);

@@ -257,3 +257,29 @@ def check_gpu_gzip(lib, fasta, flags, sizes):
         ctx.set_gzip(False)
         b = ctx.simulate(cid, 0, sizes[0], 0, 0)
         assert list(b.gz_bytes) == [0, 0, 0] and [ctx.fetch(0, s, b.bytes[s]) for s in range(3)] == keep
+
+
+WRITER_CASES = [      # (flags, contig-name length): record sizes, read lengths and name lengths that move every piece of the record writers
+    ("-z 31 -N 1500 -1 150 -2 150 -y 0.1", 0),
+    ("-z 32 -N 1500 -1 33 -2 17 -d 120 -s 8 -o 0", 0),
+    ("-z 33 -N 1200 -1 1 -2 1 -d 40 -s 3 -o 1", 0),              # records shorter than one burst
+    ("-z 34 -N 1200 -1 64 -2 31 -d 200 -P some_prefix -o 2", 0),
+    ("-z 35 -N 1000 -1 129 -2 0 -e 0.02 -o 0", 200),             # a name longer than the part kept in LDS
+    ("-z 36 -N 1000 -1 250 -2 250 -d 600 -o 1", 131),
+]
+
+
+def check_record_writers(lib, oracle_bin, tmpdir, flags, name_len):
+    """Both record writers of the Illumina kernels (dw_read.hpp: the LDS FIFO with 32-byte aligned bursts, and 16-byte pieces from
+    registers; the host picks one by LDS occupancy, the "writer" hook forces it) against the oracle, byte for byte."""
+    import random
+    rnd = random.Random(name_len + 7)
+    seq = "".join(rnd.choice("ACGT") for _ in range(6000))
+    name = ("ctg" + "x" * name_len)[:max(3, name_len)]
+    fa = os.path.join(tmpdir, f"w{name_len}.fa")
+    with open(fa, "w") as f:
+        f.write(f">{name}\n")
+        for i in range(0, len(seq), 70):
+            f.write(seq[i:i + 70] + "\n")
+    for writer in (0, 1):
+        compare_case(lib, oracle_bin, fa, flags, batch_pairs=700, debug_options={"writer": writer})

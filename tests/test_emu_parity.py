@@ -104,6 +104,12 @@ def test_command_line_on_several_contexts_on_cpu_emulation(emu_lib, oracle_bin, 
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
 
 
+@pytest.mark.parametrize("k", range(6))
+def test_both_record_writers_on_cpu_emulation(emu_lib, oracle_bin, tmp_path, k):
+    from parity_common import WRITER_CASES, check_record_writers
+    check_record_writers(emu_lib, oracle_bin, str(tmp_path), *WRITER_CASES[k])
+
+
 def test_gzip_members_made_by_the_kernels_on_cpu_emulation(emu_lib, golden_dir):
     from parity_common import check_gpu_gzip
     check_gpu_gzip(emu_lib, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", sizes=(700, 1, 90))

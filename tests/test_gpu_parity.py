@@ -117,6 +117,12 @@ def test_gzip_members_made_on_the_gpu(lib, golden_dir, flags, sizes):
     check_gpu_gzip(lib, os.path.join(golden_dir, "tiny.fa"), flags, sizes)
 
 
+@pytest.mark.parametrize("k", range(6))
+def test_both_record_writers(lib, oracle_bin, tmp_path, k):
+    from parity_common import WRITER_CASES, check_record_writers
+    check_record_writers(lib, oracle_bin, str(tmp_path), *WRITER_CASES[k])
+
+
 def test_cli_abort_rule_across_contexts(oracle_bin, golden_dir, tmp_path):
     """The failure counter of dwgsim.c:635 runs over the pairs of a contig in index order; with the contig split over contexts no single
     range reaches 10 000 failures in this job, the joined summaries do: dwgsim-hip must die as the reference does -- and must not when

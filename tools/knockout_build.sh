@@ -9,6 +9,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-valu
 /opt/rocm/bin/hipcc $F -c dw_walk.hip -o build/knock/walk.o &
 /opt/rocm/bin/hipcc $F -c dw_host.cpp -o build/knock/host.o &
 /opt/rocm/bin/hipcc $F -c dw_mutin.cpp -o build/knock/mutin.o &
+/opt/rocm/bin/hipcc $F -c dw_gzip.hip -o build/knock/gzip.o &
 /opt/rocm/bin/hipcc $F -DDW_PART=0 -c dw_simulate.hip -o build/knock/s0.o &
 for p in 2 3 4 5 6 7 8; do /opt/rocm/bin/hipcc $F -DDW_PART=$p -c dw_simulate.hip -o build/knock/s$p.o & done
 wait
@@ -17,6 +18,6 @@ for k in 2 64; do
 done
 wait
 for k in 2 64; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/knock/walk.o build/knock/host.o build/knock/mutin.o build/knock/s0.o build/knock/s1_k$k.o build/knock/s[2-8].o -o ../libdwgsim_hip_knock$k.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/knock/walk.o build/knock/gzip.o build/knock/host.o build/knock/mutin.o build/knock/s0.o build/knock/s1_k$k.o build/knock/s[2-8].o -o ../libdwgsim_hip_knock$k.so
 done
 echo built knock libs

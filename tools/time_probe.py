@@ -1,0 +1,19 @@
+"""tools/time_probe.py <flags> -- analysis only: kernel-resident time of whole-contig chr20 simulate calls with the given dwgsim flags (library: DWGSIM_HIP_LIB)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dwgsim_amd import api, synth
+lib = api.load()
+flags = sys.argv[1]
+contigs = synth.workload_contigs("chr20")
+params = api.parse_flags(flags, lib)
+with api.Context(params, 0, lib) as ctx:
+    name, arr = contigs[0]
+    cid = ctx.add_contig(name, arr, 0)
+    ctx.mutate(cid)
+    n = api.pairs_for_contig(params, len(arr), len(arr), True, 0, lib)
+    ctx.simulate(cid, 0, n, 0, 0)
+    t = time.time()
+    for i in range(10):
+        b = ctx.simulate(cid, 0, n, 0, 0)
+    dt = (time.time() - t) / 10
+    print("%-50s %9d pairs  %8.3f ms  %7.1f M pairs/s  %6.1f GB/s" % (flags, n, dt * 1e3, n / dt / 1e6, sum(b.bytes) / dt / 1e9), flush=True)
