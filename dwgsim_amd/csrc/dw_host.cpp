@@ -76,7 +76,7 @@ struct dwgsim_hip_ctx {
     std::vector<Contig> contigs;
     // simulate() working set
     DevBuf meta, fail_summ, block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
-    DevBuf w_cand, w_ev, w_flags, w_small, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
+    DevBuf w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
@@ -416,7 +416,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (auto &k : c->contigs) if (k.alive) free_contig(k);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     hipFree(c->status_all.p);
-    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_small.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
+    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
     hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->fail_summ.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_counters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
@@ -584,7 +584,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         const uint32_t nev = (uint32_t)evs.size();
         k.n_cand = nev;
         if (np == 0) {      // nothing listed for this contig: both haplotypes are the reference
-            for (int h = 0; h < 2; ++h) launch_make_view(c->stream, k.d_cells[h], (int64_t)padded_cells, k.d_view[h]);
+            launch_make_view(c->stream, k.d_cells[0], k.d_cells[1], (int64_t)padded_cells, k.d_view[0], k.d_view[1]);
             HIPC(c, hipGetLastError()); HIPC(c, hipStreamSynchronize(c->stream));
             return DWGSIM_HIP_OK;
         }
@@ -623,7 +623,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             else launch_justify(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
         }
         launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
-        for (int h = 0; h < 2; ++h) launch_make_view(c->stream, k.d_cells[h], (int64_t)padded_cells, k.d_view[h]);
+        launch_make_view(c->stream, k.d_cells[0], k.d_cells[1], (int64_t)padded_cells, k.d_view[0], k.d_view[1]);
         HIPC(c, hipGetLastError());
         HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -648,7 +648,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         }
         const size_t ncap = cap ? cap : 1;
         if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
-            ensure(c, c->w_flags, sizeof(uint4) * ncap) || ensure(c, c->w_small, 8 * sizeof(uint32_t)) ||
+            ensure(c, c->w_flags, sizeof(uint4) * ncap) ||
             ensure(c, c->w_lo, sizeof(int32_t) * ncap) || ensure(c, c->w_sufmin, sizeof(int32_t) * ncap) ||
             ensure(c, c->w_bound, ncap)) return DWGSIM_HIP_ERR_DEVICE;
         for (int h = 0; h < 2; ++h) {      // insertion tables: at most one entry per candidate; the base pools are checked on the device
@@ -666,9 +666,9 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             }
         }
         int32_t *d_cand = (int32_t *)c->w_cand.p; Event *d_ev = (Event *)c->w_ev.p; uint4 *d_flags = (uint4 *)c->w_flags.p;
-        uint32_t *d_small = (uint32_t *)c->w_small.p;   // [0] max_del, [1..4] tot4
+        uint32_t *d_small = reinterpret_cast<uint32_t *>(&c->d_counters[8]);   // [0] max_del, [1..4] tot4: eight words in counters[8..11], so that one copy brings counters[7..11] back
         const Count nc{&c->d_counters[7], cap};
-        HIPC(c, hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), c->stream));
+        HIPC(c, hipMemsetAsync(&c->d_counters[7], 0, 5 * sizeof(uint64_t), c->stream));
         // K1: candidate sites -> ordered list
         launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt);
         launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
@@ -680,16 +680,15 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         ContigDev cd = contig_dev(k);
         cd.tot4 = &d_small[1]; cd.cap_bases[0] = (uint32_t)std::min<size_t>(k.cap_bases[0], 0xFFFFFFFFu); cd.cap_bases[1] = (uint32_t)std::min<size_t>(k.cap_bases[1], 0xFFFFFFFFu);
         launch_apply(c->stream, d_ev, nc, d_flags, cd, wp);
-        HIPC(c, hipMemsetAsync(&c->d_counters[12], 0xff, 2 * sizeof(uint64_t), c->stream));
-        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[12]);      // mut.c:753
+        // mut_debug (mut.c:753, :757) cannot fire on randomly drawn mutations and is not run here: a substitution always changes the base
+        // ((c + 1..3) & 3, mut.c:621), a homozygous one writes the same cell to both haplotypes and a heterozygous one leaves the other
+        // haplotype's cell as it was -- the reference base, also under a deletion or an insertion, before and after left-justification
+        // (which only moves an indel over bases equal to its own).  File-driven mutations (-m / -b / -v, above) can violate all three.
         if (c->seq_justify) launch_justify_seq(c->stream, d_ev, nc, cd);
         else launch_justify(c->stream, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
-        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
-        for (int h = 0; h < 2; ++h) launch_make_view(c->stream, k.d_cells[h], (int64_t)padded_cells, k.d_view[h]);
+        launch_make_view(c->stream, k.d_cells[0], k.d_cells[1], (int64_t)padded_cells, k.d_view[0], k.d_view[1]);
         HIPC(c, hipGetLastError());
-        HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipMemcpyAsync(&c->h_counters[8], d_small, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));      // h_counters[8..11] as 8 x u32
+        HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));      // [7] candidates, [8..11] the eight words
         HIPC(c, hipStreamSynchronize(c->stream));
         const uint64_t n_cand = c->h_counters[7];
         const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&c->h_counters[8]);
@@ -698,8 +697,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             if (!fits) { c->err = "mutation walk: capacities still exceeded after an exact re-run"; return DWGSIM_HIP_ERR_FAILED; }
             k.n_cand = (uint32_t)n_cand;
             for (int h = 0; h < 2; ++h) { k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h]; }
-            if (const int rc = mut_debug_verdict(c, k, c->h_counters[12])) return rc;
-            return mut_debug_verdict(c, k, c->h_counters[13]);
+            return DWGSIM_HIP_OK;
         }
         // exact sizes (the counts read back are those of the complete candidate list unless it was truncated: take generous ones then)
         cap = (uint32_t)std::min<uint64_t>((uint64_t)l, n_cand + 16);

@@ -577,8 +577,10 @@ void launch_mut_debug(hipStream_t st, const uint8_t *ref, const uint8_t *h0, con
     if (l > 0) hipLaunchKernelGGL(k_mut_debug, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, h0, h1, l, verdict);
 }
 // The read view of a finished haplotype (HapDev::view): one nibble per cell, 32 cells per thread.
-__global__ void __launch_bounds__(256) k_make_view(const uint8_t *__restrict__ cells, int64_t n_cells, uint8_t *__restrict__ view)
+__global__ void __launch_bounds__(256) k_make_view(const uint8_t *__restrict__ cells0, const uint8_t *__restrict__ cells1, int64_t n_cells, uint8_t *__restrict__ view0, uint8_t *__restrict__ view1)
 {
+    const uint8_t *__restrict__ cells = blockIdx.y ? cells1 : cells0;       // grid.y = haplotype
+    uint8_t *__restrict__ view = blockIdx.y ? view1 : view0;
     const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 32;
     if (first >= n_cells) return;                                  // n_cells (the padded length) is a multiple of 16
     uint32_t out[4] = {0, 0, 0, 0};
@@ -597,9 +599,9 @@ __global__ void __launch_bounds__(256) k_make_view(const uint8_t *__restrict__ c
     }
     *reinterpret_cast<uint4 *>(view + (first >> 1)) = make_uint4(out[0], out[1], out[2], out[3]);
 }
-void launch_make_view(hipStream_t st, const uint8_t *cells, int64_t n_cells, uint8_t *view)
+void launch_make_view(hipStream_t st, const uint8_t *cells0, const uint8_t *cells1, int64_t n_cells, uint8_t *view0, uint8_t *view1)
 {
-    if (n_cells > 0) hipLaunchKernelGGL(k_make_view, dim3(cdiv((uint64_t)n_cells, 256 * 32)), dim3(256), 0, st, cells, n_cells, view);
+    if (n_cells > 0) hipLaunchKernelGGL(k_make_view, dim3(cdiv((uint64_t)n_cells, 256 * 32), 2), dim3(256), 0, st, cells0, cells1, n_cells, view0, view1);
 }
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
 {

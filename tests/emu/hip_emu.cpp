@@ -28,12 +28,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
     th.reserve(nt);
     for (unsigned t = 0; t < nt; ++t)
         th.emplace_back([=, &fn]() {
-            t_threadIdx = Idx{t, 0, 0}; t_blockDim = Idx{nt, 1, 1}; t_gridDim = Idx{grid.x, 1, 1};
-            for (unsigned b = 0; b < grid.x; ++b) {      // blocks run one after the other (static __shared__ storage)
-                t_blockIdx = Idx{b, 0, 0};
-                fn();
-                pthread_barrier_wait(&g_block_bar);
-            }
+            const unsigned gy = grid.y ? grid.y : 1;
+            t_threadIdx = Idx{t, 0, 0}; t_blockDim = Idx{nt, 1, 1}; t_gridDim = Idx{grid.x, gy, 1};
+            for (unsigned y = 0; y < gy; ++y)
+                for (unsigned b = 0; b < grid.x; ++b) {      // blocks run one after the other (static __shared__ storage)
+                    t_blockIdx = Idx{b, y, 0};
+                    fn();
+                    pthread_barrier_wait(&g_block_bar);
+                }
         });
     for (auto &x : th) x.join();
     pthread_barrier_destroy(&g_block_bar);

@@ -7,6 +7,8 @@ flags = sys.argv[1]
 contigs = synth.workload_contigs("chr20")
 params = api.parse_flags(flags, lib)
 with api.Context(params, 0, lib) as ctx:
+    if os.environ.get("WRITER"):
+        ctx.debug_option("writer", int(os.environ["WRITER"]))
     name, arr = contigs[0]
     cid = ctx.add_contig(name, arr, 0)
     ctx.mutate(cid)
@@ -16,4 +18,4 @@ with api.Context(params, 0, lib) as ctx:
     for i in range(10):
         b = ctx.simulate(cid, 0, n, 0, 0)
     dt = (time.time() - t) / 10
-    print("%-50s %9d pairs  %8.3f ms  %7.1f M pairs/s  %6.1f GB/s" % (flags, n, dt * 1e3, n / dt / 1e6, sum(b.bytes) / dt / 1e9), flush=True)
+    print(os.environ.get("WRITER", "-"), "%-50s %9d pairs  %8.3f ms  %7.1f M pairs/s  %6.1f GB/s" % (flags, n, dt * 1e3, n / dt / 1e6, sum(b.bytes) / dt / 1e9), flush=True)
