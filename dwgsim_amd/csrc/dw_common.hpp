@@ -36,8 +36,11 @@ enum : uint32_t {
                         // uniform of base i: error test (dwgsim.c:237) or random-read base (:1000); the low half is halfword i of D_BASE_REF0
     D_QUAL0 = 10,       // +read end.  the sequential stream of polar tries of the read's quality normals (dwgsim.c:912, :156-175): try t = words
                         // 2 (t&1), 2 (t&1) + 1 of block t>>1; every accepted try delivers two normals (v2*fac, then the cached v1*fac)
-    D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): one sub-stream per event -- block = ordinal of the homopolymer
-                        // start (pass 1) / of the examined base (pass 2), draw s of the event = word s & 3 of retry s >> 2
+    D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): 16-bit draws, eight per block -- halfword h is the HIGH half of the FIRST
+                        // uniform of event h: the homopolymer start at position h of the evolving read (pass 1), the h-th empty flow of the read
+                        // (pass 2, + D_FLOW_PASS2); low halves: + D_FLOW_REF (lazy); every further draw of an event: its private stream + D_FLOW_EV
+    D_FLOW_REF = 32,    // added to a flow-model domain: halfword h = the LOW half of first uniform h
+    D_FLOW_EV = 64,     // added to a flow-model domain: draw s of event h = word s & 3 of the block (retry s >> 2, block h)
     D_FLOW_PASS2 = 8,   // added to D_FLOW0 / D_CALIB (+read end) for the second pass of the flow model (domains 20-23)
     D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
     D_SUB0 = 16,        // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)

@@ -93,7 +93,10 @@ constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_s
 
 // Ion Torrent scratch: words per lane of one block's read buffers (4-bit buffer + 2-bit pass-1 buffer), forced odd so that the
 // blocks' areas do not all start on the same HBM channels (a 96 KB stride cost 14 % against 89 KB)
-inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_words + ((cap + 15) >> 4)) | 1; }
+// Ion Torrent scratch of one lane: the read at 4 bits per base (lds_words), the pass-1 output at 2 bits, and the hit bitmap of the first
+// flow_hit_bits(cap) empty flows of pass 2 (later ones -- long cascades -- are drawn one by one)
+inline constexpr int flow_hit_bits(int cap) { return (2 * cap + 256 + 31) & ~31; }
+inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_words + ((cap + 15) >> 4) + (flow_hit_bits(cap) >> 5)) | 1; }
 
 struct SimArgs {
     SimParams p;

@@ -260,22 +260,53 @@ struct PackAppender {
     DW_DEV void push(uint32_t v) { acc |= v << ((n & (PER - 1)) * BITS); if ((++n & (PER - 1)) == 0) { base[((n >> SH) - 1) * stride] = acc; acc = 0; } }
     DW_DEV void flush() { if (n & (PER - 1)) base[(n >> SH) * stride] = acc; }
 };
+#ifndef DW_KNOCK
+#define DW_KNOCK 0
+#endif
+// First draws of the flow model's events as bits: bit k of the result = (first uniform of event 8 * blk + k) < e, e as thr = e * 2^32
+// (dw_common.hpp D_FLOW0: sixteen-bit halves, the low halves drawn only when a high half ties with thr's).
+DW_DEV uint32_t flow_hits8(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t blk, uint64_t thr)
+{
+    const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
+    const U4 b = rng_block(key, dom, ii, att, 0, blk);
+    const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
+    uint32_t lt = 0, eq = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; eq |= (hw[k] == t_hi ? 1u : 0u) << k; }
+    if (eq && t_lo) {
+        const U4 r = rng_block(key, dom + D_FLOW_REF, ii, att, 0, blk);
+        const uint32_t lw[8] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16, r.z & 0xFFFFu, r.z >> 16, r.w & 0xFFFFu, r.w >> 16};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lt |= (((eq >> k) & 1u) && lw[k] < t_lo ? 1u : 0u) << k;
+    }
+    return lt;
+}
 struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
-    // One private sub-stream per event of the flow model (a homopolymer start in pass 1, an examined base in pass 2): draw s of event
-    // `evt` is word s & 3 of the block (retry s >> 2, block evt).  Every lane opens its events in step with its own loop iterations, so a
-    // block is generated once per event instead of once per draw of whichever lane happens to cross a block boundary.
+    // The private stream of one event (its draws AFTER the first): draw s = word s & 3 of the block (retry s >> 2, block evt) of dom + D_FLOW_EV.
     uint32_t seed, contig, dom, att, evt, s, w0, w1, w2, w3; uint64_t ii;
     DW_DEV void open(uint32_t event) { evt = event; s = 0; }
     DW_DEV uint32_t next()
     {
-        if ((s & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom, ii, att, s >> 2, evt); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
+        if ((s & 3) == 0) { const U4 b = rng_block(RngKey{seed, contig}, dom + D_FLOW_EV, ii, att, s >> 2, evt); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
         const uint32_t k = s & 3; ++s;
         const uint32_t lo = (k & 1) ? w1 : w0, hi = (k & 1) ? w3 : w2;
         return (k & 2) ? hi : lo;
     }
-    // while (drand48() < e) n_err++ (dwgsim.c:296, :373).  Bounded: with e = 1 the reference never leaves this loop; 2^14 errors in one flow
-    // already overflow every buffer, so the caller reports the read as outgrown instead of spinning on the GPU.
-    DW_DEV int geometric(uint64_t thr) { int n = 0; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
+    // the rest of `while (drand48() < e) n_err++` (dwgsim.c:296, :373) after a first draw below e.  Bounded: with e = 1 the reference never
+    // leaves this loop; 2^14 errors in one flow already overflow every buffer, so the caller reports the read as outgrown.
+    DW_DEV int more_errors(uint64_t thr) { int n = 1; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
+};
+// Sequential reader of a lane's hit bitmap (word w at base[w * stride]): up to 31 bits at a non-decreasing bit position
+struct BitWindow {
+    const uint32_t *base; int stride, cw, nw; uint32_t lo, hi;
+    DW_DEV void init(const uint32_t *b, int st, int nwords) { base = b; stride = st; nw = nwords; cw = 0; lo = nw > 0 ? base[0] : 0u; hi = nw > 1 ? base[stride] : 0u; }
+    DW_DEV uint32_t peek(uint32_t g, uint32_t k)
+    {
+        const int w = (int)(g >> 5);
+        while (cw < w) { ++cw; lo = hi; hi = (cw + 1 < nw) ? base[(size_t)(cw + 1) * stride] : 0u; }
+        const uint64_t v = (((uint64_t)hi << 32) | lo) >> (g & 31u);
+        return (uint32_t)v & ((1u << k) - 1u);
+    }
 };
 // Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
 // bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
@@ -301,11 +332,14 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
     { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
     // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
     PackAppender<2> o1; o1.init(bufB, stride);
-    int t = 0; uint32_t prev_c = 4, pend_c = 0, n_events = 0; int pend_n = 0;
+    int t = 0; uint32_t prev_c = 4, pend_c = 0, hits8 = 0; int pend_n = 0;
     for (;;) {
         uint32_t c; bool from_pend = false;
         if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
         if (o1.n >= cap) return -1;
+        // every iteration appends exactly one base, so o1.n is the reference's loop index i (dwgsim.c:281) and the same in every lane of the
+        // wave: the first draws of positions 8 m .. 8 m + 7 come from one block, generated by all lanes together
+        if ((o1.n & 7) == 0) hits8 = flow_hits8(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)o1.n >> 3, thr);
         {   // skip the flows in front of this base (dwgsim.c:285-288), clearing their mask bits: a cyclic range [flow_i, flow_i + k)
             const int k = dist[4 * flow_i + (int)c];
             if (k) {
@@ -317,10 +351,10 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
         }
         if (prev_c != c) {
             mask &= ~(1ull << flow_i);
-            rg.open(n_events++);
-            int n_err = rg.geometric(thr);
-            if (n_err >= (1 << 14)) return -1;
-            if (n_err > 0) {
+            if ((hits8 >> (o1.n & 7)) & 1u) {
+                rg.open((uint32_t)o1.n);
+                int n_err = rg.more_errors(thr);
+                if (n_err >= (1 << 14)) return -1;
                 if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
                     o1.push(c); pend_c = c; pend_n = n_err - 1;
                     total += n_err; prev_c = c;
@@ -348,20 +382,34 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
     return o1.n;
 }
 // Every lane of the wave must call this (pass 2 regroups lanes with wave ballots); lanes without a read pass active = false.
-DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *stk, int stride,
+// bm: this lane's hit bitmap of pass 2 (flow_hit_bits(cap) bits, word w at bm[w * stride]), filled here.
+DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *bm, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
     int n1 = 0, total = 0, flow_i = 0; uint64_t mask = 0; bool failed = !active;
+    // the first draws of the first G0 empty flows of pass 2 as a bitmap: 32 flows per word, four Philox blocks each, every lane in step
+    const int G0 = flow_hit_bits(cap), nbw = G0 >> 5;
+    const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
+    if (active)
+        for (int w = 0; w < nbw; ++w) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, 4u * (uint32_t)w + q, thr) << (8 * q);
+            bm[(size_t)w * stride] = bits;
+        }
     if (active) n1 = flow_pass1(rg, flow, dist, F, thr, bufA, bufB, stride, len, strand, cap, mask, flow_i, total);
     if (n1 < 0) failed = true;
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
-    // With e = 0.01 some lane of a wave has a scoring flow at almost every position, so the lanes are regrouped: a lane whose examined
-    // base has a scoring flow parks, the others run on through quiet positions, and the flow-by-flow code is entered once for a batch of
-    // parked lanes (each lane still performs exactly its own sequence of operations, only their interleaving changes). ----
+    // g counts the empty flows examined so far: flow g's first draw is bit g of the bitmap, so "nothing happens in the k empty flows in
+    // front of this base" is one bit-field test.  With e = 0.01 some lane of a wave has a scoring flow at almost every position, so the
+    // lanes are regrouped: a lane whose examined base has a scoring flow parks, the others run on through quiet positions, and the
+    // scoring flows are handled for a batch of parked lanes (each lane still performs exactly its own sequence of operations, only
+    // their interleaving changes); there the quiet flows between two scoring ones are skipped with a find-first-set. ----
     PackReader<2> r2; r2.init(bufB, stride);
     PackAppender<4> o2; o2.init(bufA, stride);
+    BitWindow bw; bw.init(bm, stride, active ? nbw : 0);
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
     auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
     auto settle = [&](uint32_t x, int &t2, int &sp) {      // the position's final base: the examined base, or the first base of the top run
@@ -373,38 +421,42 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
         }
     };
     int t2 = 0, sp = 0;
-    rg.dom += D_FLOW_PASS2;
-    bool done = failed, parked = false; uint32_t n2 = 0, x = 0;
+    rg.dom = dom2;
+    bool done = failed, parked = false; uint32_t g = 0, x = 0;
     for (;;) {
         if (!done && !parked) {
             if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else done = true;
             if (!done && o2.n >= cap) { failed = true; done = true; }
             if (!done) {
-                // flow q of the empty flows in front of x draws word q of the position's stream unless an earlier one scored: if none of
-                // the first k words is below the threshold nothing happens at this position (dwgsim.c:370-392)
-                const int k_empty = dist[4 * flow_i + (int)x];
-                bool quiet = true;
-                for (int q = 0; q < k_empty && quiet; q += 4) {
-                    const U4 b = rng_block(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)q >> 2, n2);
-                    quiet = !((uint64_t)b.x < thr || (q + 1 < k_empty && (uint64_t)b.y < thr) || (q + 2 < k_empty && (uint64_t)b.z < thr) || (q + 3 < k_empty && (uint64_t)b.w < thr));
-                }
-                if (quiet) { flow_i += k_empty; if (flow_i >= F) flow_i -= F; settle(x, t2, sp); ++n2; }
+                const uint32_t k_empty = dist[4 * flow_i + (int)x];
+                if (g + k_empty <= (uint32_t)G0 && bw.peek(g, k_empty) == 0) { flow_i += (int)k_empty; if (flow_i >= F) flow_i -= F; g += k_empty; settle(x, t2, sp); }
                 else parked = true;
             }
         }
         const uint64_t parked_lanes = __ballot(parked), running_lanes = __ballot(!done && !parked);
         if (parked_lanes && (running_lanes == 0 || __popcll(parked_lanes) >= 16)) {
-            if (parked) {                               // the flows one by one from the start of the position's stream
-                rg.open(n2);
-                while (!failed && x != flow[flow_i]) {
-                    const int n_err = rg.geometric(thr);
-                    if (!((mask >> flow_i) & 1) && n_err > 0) {
+            if (parked) {
+                uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
+                while (!failed && left > 0) {
+                    uint32_t skip;                              // quiet flows before the next scoring one
+                    if (g + left <= (uint32_t)G0) { const uint32_t bits = bw.peek(g, left); skip = bits ? (uint32_t)__ffs((int)bits) - 1u : left; }
+                    else {                                      // beyond the bitmap (a long cascade): flow by flow
+                        skip = 0;
+                        while (skip < left && !((flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, (g + skip) >> 3, thr) >> ((g + skip) & 7u)) & 1u)) ++skip;
+                    }
+                    flow_i += (int)skip; if (flow_i >= F) flow_i -= F;
+                    g += skip; left -= skip;
+                    if (left == 0) break;
+                    rg.open(g);                                 // flow g scores: while (drand48() < e) n_err++ goes on in its private stream
+                    const int n_err = rg.more_errors(thr);
+                    if (!((mask >> flow_i) & 1)) {
                         if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
                         else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
                     }
                     flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
+                    ++g; --left;
                 }
-                if (failed) done = true; else { settle(x, t2, sp); ++n2; }
+                if (failed) done = true; else settle(x, t2, sp);
                 parked = false;
             }
         }
@@ -418,9 +470,6 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
 
 // ---- FASTQ text assembly ----
 // (analysis builds only, tools/knockout_build.sh: -DDW_KNOCK=<bits> switches parts of k_simulate off to weigh them; the product build has none of it)
-#ifndef DW_KNOCK
-#define DW_KNOCK 0
-#endif
 struct __attribute__((packed, aligned(1))) Unal16 { uint64_t a, b; };      // stores at any byte address: gfx950 global memory takes unaligned
 struct __attribute__((packed, aligned(1))) Unal8 { uint64_t v; };           // dword / dwordx2 / dwordx4 accesses as they are (one instruction)
 struct __attribute__((packed, aligned(1))) Unal4 { uint32_t v; };

@@ -61,12 +61,16 @@ enum {
                           the 32-bit uniform of base i (error test / random-read base); the low half is halfword i of D_BASE_REF0 + j */
     D_QUAL0 = 10,      /* +j; index = ii; NARROW: the sequential stream of polar tries of the read's quality normals -- try t = words
                           2 (t & 1), 2 (t & 1) + 1 of block t >> 1; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
-    D_FLOW0 = 12,      /* +j; index = ii; NARROW: word = running draw count inside generate_errors_flows */
+    D_FLOW0 = 12,      /* +j; index = ii; generate_errors_flows: 16-bit draws, eight per block -- halfword h is the HIGH half of the FIRST uniform of
+                          the homopolymer event examined at position h of the evolving read (pass 1; + D_FLOW_PASS2: of the h-th empty flow of
+                          pass 2); low halves in + D_FLOW_REF, every further draw of an event in its private stream + D_FLOW_EV (see flow_first) */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
     D_FLOW_PASS2 = 8,  /* added to D_FLOW0 / D_CALIB (+j) for the second pass of generate_errors_flows: domains 20-23 */
     D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
     D_MUTIN = 18,      /* mutation-input files (-b): index = entry ordinal; slot 0 hom test, 1 het haplotype (mut.c:662-669) */
     D_MUTIN_BASE = 19, /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
+    D_FLOW_REF = 32,   /* added to a flow-model domain: halfword h = the LOW half of first uniform h (matters with probability 2^-16, drawn lazily) */
+    D_FLOW_EV = 64,    /* added to a flow-model domain: the private stream of event h -- draw s = word s & 3 of the block (retry s >> 2, block h) */
     D_BASE_REF0 = 24   /* +j; index = ii; halfword i = the LOW half of the 32-bit uniform of base i (it only matters when the high half alone
                           does not decide u < e, i.e. with probability 2^-16: the kernels draw it lazily) */
 };
@@ -873,13 +877,23 @@ static void flow_alloc(flowbuf_t *b, int len, int F)
     b->mem = (len + 2 > F + 2) ? len + 2 : F + 2;
     b->seq = calloc((size_t)b->mem, 1); b->mask = calloc((size_t)b->mem, 1);
 }
-/* mode B: narrow draws, one private sub-stream per EVENT of the flow model -- pass 1: the n-th homopolymer start of the read (domain dom),
- * pass 2: the n-th examined base (domain dom + D_FLOW_PASS2): draw s of an event is word s & 3 of the block (retry s >> 2, block n).
- * An event almost always needs one block, generated without regard to how many draws other reads consumed before. */
+/* mode B draws of the flow model.  An "event" is a homopolymer start in pass 1 (index h = its position in the evolving read, the loop
+ * index i of dwgsim.c:281) or an empty flow in pass 2 (h = the number of empty flows examined before it in this read).  Its FIRST uniform
+ * -- 99 % of the events draw nothing else -- is a 16 + 16 bit draw: the high half is halfword h of the domain's stream (eight per Philox
+ * block, as D_BASE0), the low half halfword h of domain + D_FLOW_REF.  So the kernels can turn a whole stream into a bitmap of "first
+ * draw < e" with one block per eight events, before the serial part starts.  Every further draw of the event (more errors, insert or
+ * delete, the dot-fill flow) is word s & 3 of the block (retry s >> 2, block h) of domain + D_FLOW_EV, s = 0, 1, ... */
+static inline double flow_first(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t h)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
+    const uint32_t hi = philox_halfword(r, fdom, idx, att, h), lo = philox_halfword(r, fdom + D_FLOW_REF, idx, att, h);
+    return (double)((hi << 16) | lo) * 0x1p-32;
+}
 static inline double flow_u(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t evt, uint32_t *es)
 {
     const uint32_t s = (*es)++;
-    return rng_u32(r, fdom, idx, att, s >> 2, (evt << 2) | (s & 3));
+    return rng_u32(r, fdom + D_FLOW_EV, idx, att, s >> 2, (evt << 2) | (s & 3));
 }
 #define FLOW_U() flow_u(r, fdom, idx, att, evt, &es)
 static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t *slot,
@@ -887,7 +901,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
 {
     int i, j, k, hp_l, flow_i, n_err, F = o->flow_order_len;
     uint8_t prev_c, c;
-    uint32_t fdom = dom, evt = 0, es = 0, n_events = 0; (void)slot;
+    uint32_t fdom = dom, evt = 0, es = 0, g = 0; (void)slot;
     for (i = 0; i < len; ++i) if (b->seq[i] >= 4) b->seq[i] = 0;
     if (strand == 1) for (i = 0; i < len >> 1; ++i) { c = b->seq[i]; b->seq[i] = b->seq[len - i - 1]; b->seq[len - i - 1] = c; }
     for (i = 0; i < F; ++i) {
@@ -902,9 +916,9 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
         while (c != o->flow_order[flow_i]) { b->mask[flow_i] = 0; flow_i = (flow_i + 1) % F; }
         if (prev_c != c) {
             b->mask[flow_i] = 0;
-            evt = n_events++; es = 0;
+            evt = (uint32_t)i; es = 0;
             n_err = 0;
-            while (FLOW_U() < e) n_err++;
+            if (flow_first(r, fdom, idx, att, evt) < e) { n_err = 1; while (FLOW_U() < e) n_err++; } /* while(drand48() < e) n_err++ (dwgsim.c:296) */
             if (0 < n_err) {
                 if (FLOW_U() < 0.5) { /* insert */
                     flow_grow(b, len + n_err);
@@ -935,11 +949,11 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
     }
     fdom = dom + D_FLOW_PASS2;
     for (i = 0; i < len; ++i) { /* second pass: empty flows (flow_i continues) */
-        evt = (uint32_t)i; es = 0;
         c = (4 <= b->seq[i]) ? 0 : b->seq[i];
         while (c != o->flow_order[flow_i]) {
+            evt = g++; es = 0;
             n_err = 0;
-            while (FLOW_U() < e) n_err++;
+            if (flow_first(r, fdom, idx, att, evt) < e) { n_err = 1; while (FLOW_U() < e) n_err++; } /* dwgsim.c:373 */
             if (0 == b->mask[flow_i] && 0 < n_err) {
                 flow_grow(b, len + n_err);
                 for (j = len - 1; i <= j; --j) b->seq[j + n_err] = b->seq[j];

@@ -19,3 +19,10 @@ with api.Context(params, 0, lib) as ctx:
         b = ctx.simulate(cid, 0, n, 0, 0)
     dt = (time.time() - t) / 10
     print(os.environ.get("WRITER", "-"), "%-50s %9d pairs  %8.3f ms  %7.1f M pairs/s  %6.1f GB/s" % (flags, n, dt * 1e3, n / dt / 1e6, sum(b.bytes) / dt / 1e9), flush=True)
+    if os.environ.get("PLACE"):
+        ctx.count_random(cid, 0, n)
+        t = time.time()
+        for i in range(10):
+            r = ctx.count_random(cid, 0, n)
+        dt = (time.time() - t) / 10
+        print("count_random (k_summarize once + k_place + scan): %8.3f ms  random=%d" % (dt * 1e3, r), flush=True)
