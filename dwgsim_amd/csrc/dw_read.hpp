@@ -270,10 +270,13 @@ DW_DEV uint32_t flow_hits8(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, 
     const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
     const U4 b = rng_block(key, dom, ii, att, 0, blk);
     const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
-    uint32_t lt = 0, eq = 0;
+    uint32_t lt = 0, closest = 0xFFFFFFFFu;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; eq |= (hw[k] == t_hi ? 1u : 0u) << k; }
-    if (eq && t_lo) {
+    for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; const uint32_t d = hw[k] ^ t_hi; closest = d < closest ? d : closest; }
+    if (closest == 0 && t_lo) {      // a high half ties with the threshold's (probability 2^-13 per block): the low halves decide
+        uint32_t eq = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) eq |= (hw[k] == t_hi ? 1u : 0u) << k;
         const U4 r = rng_block(key, dom + D_FLOW_REF, ii, att, 0, blk);
         const uint32_t lw[8] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16, r.z & 0xFFFFu, r.z >> 16, r.w & 0xFFFFu, r.w >> 16};
 #pragma unroll
@@ -304,8 +307,7 @@ struct BitWindow {
     {
         const int w = (int)(g >> 5);
         while (cw < w) { ++cw; lo = hi; hi = (cw + 1 < nw) ? base[(size_t)(cw + 1) * stride] : 0u; }
-        const uint64_t v = (((uint64_t)hi << 32) | lo) >> (g & 31u);
-        return (uint32_t)v & ((1u << k) - 1u);
+        return __builtin_amdgcn_alignbit(hi, lo, g & 31u) & ((1u << k) - 1u);
     }
 };
 // Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
@@ -323,8 +325,11 @@ DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, i
 }
 // Pass 1 of generate_errors_flows (dwgsim.c:253-364) for one lane: bufA (len bases) -> bufB (2 bits per base).  Returns the new length or
 // -1; leaves the flow mask, the flow position and the number of erroneous bases for pass 2.
+// The reference's flow mask (dwgsim.c:283-333) never has more than one bit set: a deletion marks the flow the pointer stands on, and the mark is
+// cleared as soon as the pointer moves (the range of skipped flows starts at the pointer) or a new homopolymer starts on that flow.  So the
+// mask is one flag -- "the flow under the pointer is marked" -- and what pass 2 sees is that flag together with the final pointer.
 DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, int stride,
-                      int len, int strand, int cap, uint64_t &mask, int &flow_i, int &total)
+                      int len, int strand, int cap, bool &marked, int &flow_i, int &total)
 {
     // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
     PackReader<4> rd, la; rd.init(bufA, stride); la.init(bufA, stride);
@@ -338,19 +343,16 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
         if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
         if (o1.n >= cap) return -1;
         // every iteration appends exactly one base, so o1.n is the reference's loop index i (dwgsim.c:281) and the same in every lane of the
-        // wave: the first draws of positions 8 m .. 8 m + 7 come from one block, generated by all lanes together
+        // wave: the first draws of positions 8 m .. 8 m + 7 come from one block, generated by all lanes together.  (The event code below runs
+        // for whichever lanes score in this iteration -- some lane in four iterations out of ten at e = 0.01; collecting the scoring lanes
+        // into batches as pass 2 does was measured and loses: the event is too short to pay for the waiting.)
         if ((o1.n & 7) == 0) hits8 = flow_hits8(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)o1.n >> 3, thr);
         {   // skip the flows in front of this base (dwgsim.c:285-288), clearing their mask bits: a cyclic range [flow_i, flow_i + k)
             const int k = dist[4 * flow_i + (int)c];
-            if (k) {
-                const int n1 = k < F - flow_i ? k : F - flow_i, n2 = k - n1;
-                const uint64_t m1 = (n1 >= 64 ? ~0ull : ((1ull << n1) - 1)) << flow_i, m2 = n2 >= 64 ? ~0ull : ((1ull << n2) - 1);
-                mask &= ~(m1 | m2);
-                flow_i += k; if (flow_i >= F) flow_i -= F;
-            }
+            if (k) { marked = false; flow_i += k; if (flow_i >= F) flow_i -= F; }
         }
         if (prev_c != c) {
-            mask &= ~(1ull << flow_i);
+            marked = false;
             if ((hits8 >> (o1.n & 7)) & 1u) {
                 rg.open((uint32_t)o1.n);
                 int n_err = rg.more_errors(thr);
@@ -363,7 +365,7 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
                 int hp_l = 0; uint32_t next_c = c;              // delete: bounded by the homopolymer length
                 while (t + hp_l < len) { next_c = in(la, t + hp_l); if (next_c != c) break; ++hp_l; }
                 if (n_err > hp_l) n_err = hp_l;
-                t += n_err; mask |= 1ull << flow_i; total += n_err;
+                t += n_err; marked = true; total += n_err;
                 if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
                     if (next_c == c) return -1;                // the whole read was one deleted homopolymer (the reference asserts)
                     int jj = 0; while (next_c != flow[(flow_i + jj) % F]) ++jj;
@@ -386,7 +388,7 @@ DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int
 DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *bm, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
-    int n1 = 0, total = 0, flow_i = 0; uint64_t mask = 0; bool failed = !active;
+    int n1 = 0, total = 0, flow_i = 0; bool marked = false; bool failed = !active;
     // the first draws of the first G0 empty flows of pass 2 as a bitmap: 32 flows per word, four Philox blocks each, every lane in step
     const int G0 = flow_hit_bits(cap), nbw = G0 >> 5;
     const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
@@ -397,8 +399,9 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
             for (uint32_t q = 0; q < 4; ++q) bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, 4u * (uint32_t)w + q, thr) << (8 * q);
             bm[(size_t)w * stride] = bits;
         }
-    if (active) n1 = flow_pass1(rg, flow, dist, F, thr, bufA, bufB, stride, len, strand, cap, mask, flow_i, total);
+    if (active) n1 = flow_pass1(rg, flow, dist, F, thr, bufA, bufB, stride, len, strand, cap, marked, flow_i, total);
     if (n1 < 0) failed = true;
+    const int marked_flow = marked ? flow_i : -1;      // the one flow of the (persistent) mask that pass 2 finds set
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
@@ -434,7 +437,9 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
             }
         }
         const uint64_t parked_lanes = __ballot(parked), running_lanes = __ballot(!done && !parked);
-        if (parked_lanes && (running_lanes == 0 || __popcll(parked_lanes) >= 16)) {
+        // a batch of parked lanes runs once eight have gathered, or as many as are still running (measured: 1 / 2 / 4 / 8 / 16 / 24 / 32 lanes ->
+        // 5.66 / 5.36 / 5.17 / 5.06 / 5.15 / 5.37 / 5.55 ms for 848 k reads of 400 bp at e = 0.01; waiting for the last runners alone costs 5 %)
+        if (parked_lanes && (__popcll(parked_lanes) >= 8 || __popcll(parked_lanes) >= __popcll(running_lanes))) {
             if (parked) {
                 uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
                 while (!failed && left > 0) {
@@ -449,7 +454,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
                     if (left == 0) break;
                     rg.open(g);                                 // flow g scores: while (drand48() < e) n_err++ goes on in its private stream
                     const int n_err = rg.more_errors(thr);
-                    if (!((mask >> flow_i) & 1)) {
+                    if (flow_i != marked_flow) {
                         if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
                         else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
                     }

@@ -90,6 +90,7 @@ static inline uint32_t atomicMax(uint32_t *p, uint32_t v) { uint32_t o = __atomi
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 
 // hardware transcendentals used only inside estimates with a guard band (quality_pair_lazy): libm stand-ins are at least as accurate
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
 static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3))); }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
