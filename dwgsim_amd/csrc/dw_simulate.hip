@@ -557,19 +557,22 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         PH_MARK(4); // header line
         // bases (the second writer of -o 0 starts a new section, so that sixteen bases are one store)
         o.rebase();
-        PackReader<4> rev; rev.init(lds, nthr);
+        // word w of the record (bases 8w .. 8w + 7).  Ion Torrent, reverse strand: base i of the record = base s_out-1-i of the flow-model
+        // orientation (dwgsim.c:408-414): the eight cells ending at s_out-1-8w, fetched as one window and turned nibble by nibble
+        auto rec_word = [&](int w) -> uint32_t {
+            if (!(DT == 2 && flow_reversed)) return lds[w * nthr];
+            const int lo = s_out - 8 - 8 * w;                   // first cell of the window (negative in the last, partial word)
+            if (lo < 0) return (uint32_t)(reverse_nibbles((uint64_t)lds[0]) >> 32) >> (4 * (-lo));
+            const uint32_t a0 = lds[(lo >> 3) * nthr], a1 = (lo & 7) ? lds[((lo >> 3) + 1) * nthr] : 0u;
+            return (uint32_t)(reverse_nibbles((uint64_t)__builtin_amdgcn_alignbit(a1, a0, 4u * (uint32_t)(lo & 7))) >> 32);
+        };
         int w = 0;
-        if (!(DT == 2 && flow_reversed))
-            for (; (w + 2) * 8 <= s_out; w += 2) {
-                const uint32_t w0 = lds[w * nthr], w1 = lds[(w + 1) * nthr];
-                o.put16(base_chars4(w0), base_chars4(w0 >> 16), base_chars4(w1), base_chars4(w1 >> 16));
-            }
+        for (; (w + 2) * 8 <= s_out; w += 2) {
+            const uint32_t w0 = rec_word(w), w1 = rec_word(w + 1);
+            o.put16(base_chars4(w0), base_chars4(w0 >> 16), base_chars4(w1), base_chars4(w1 >> 16));
+        }
         for (; w * 8 < s_out; ++w) {
-            uint32_t word;
-            if (DT == 2 && flow_reversed) {         // base i of the record = base s_out-1-i of the flow-model orientation
-                word = 0;
-                for (int b = 0; b < 8; ++b) { const int i = w * 8 + b; if (i < s_out) word |= rev.get(s_out - 1 - i) << (4 * b); }
-            } else word = lds[w * nthr];
+            const uint32_t word = rec_word(w);
             const int rem = s_out - w * 8;
             if (rem >= 8) {
                 o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16));
