@@ -168,6 +168,7 @@ public:
                 lanes_[(size_t)l].free_bufs.push_back(bufs_.back().get());
             }
         for (unsigned t = 0; t < (n_threads ? n_threads : 1); ++t) workers_.emplace_back([this]() { work(); });
+        for (int s = 0; s < 3; ++s) if (f_[s]) file_thr_[s] = std::thread([this, s]() { file_loop(s); });
         writer_ = std::thread([this]() { write_loop(); });
     }
     ~Output() { finish(); for (auto &b : bufs_) for (int s = 0; s < 3; ++s) dwgsim_hip_host_free(b->p[s]); }
@@ -223,6 +224,8 @@ public:
     {
         { std::unique_lock<std::mutex> lk(m_); if (stop_) return; stop_ = true; cv_work_.notify_all(); cv_write_.notify_all(); }
         writer_.join();
+        { std::unique_lock<std::mutex> lk(fm_); files_stop_ = true; cv_file_.notify_all(); }
+        for (int s = 0; s < 3; ++s) if (file_thr_[s].joinable()) file_thr_[s].join();
         for (auto &w : workers_) w.join();
     }
     uint64_t bytes_in() const { return bytes_in_; }
@@ -267,20 +270,37 @@ private:
                     cv_write_.wait(lk);
                 }
             }
+            // the chunk is next in its file: hand it to that file's writer (the three files are written side by side)
+            std::unique_lock<std::mutex> lk(fm_);
+            fq_[c->stream].push_back(c);
+            cv_file_.notify_all();
+        }
+    }
+    void file_loop(int s)
+    {
+        for (;;) {
+            std::shared_ptr<Chunk> c;
+            {
+                std::unique_lock<std::mutex> lk(fm_);
+                cv_file_.wait(lk, [&]() { return !fq_[s].empty() || files_stop_; });
+                if (fq_[s].empty()) return;
+                c = fq_[s].front(); fq_[s].pop_front();
+            }
             const void *data = c->raw ? (const void *)c->src : (const void *)c->gz.data(); const size_t nb = c->raw ? c->n : c->gz.size();
-            if (!c->ok || fwrite(data, 1, nb, f_[c->stream]) != nb) { std::unique_lock<std::mutex> lk(m_); failed_ = true; cv_buf_.notify_all(); }
+            if (!c->ok || fwrite(data, 1, nb, f_[s]) != nb) { std::unique_lock<std::mutex> lk(m_); failed_ = true; cv_buf_.notify_all(); }
             bytes_in_ += c->raw ? c->text_n : c->n; bytes_out_ += nb;
             if (c->raw) {
                 std::unique_lock<std::mutex> lk(m_);
                 if (c->owner->left.fetch_sub(1) == 1) { lanes_[(size_t)b_lane_[c->owner]].free_bufs.push_back(c->owner); cv_buf_.notify_all(); }
-            }
+            } else c->gz = std::vector<unsigned char>();
         }
     }
     FILE *f_[3]; int level_;
     std::mutex m_; std::condition_variable cv_work_, cv_write_, cv_buf_;
     std::vector<Lane> lanes_; std::deque<std::shared_ptr<Chunk>> todo_;
     std::vector<std::unique_ptr<TextBuf>> bufs_;
-    std::vector<std::thread> workers_; std::thread writer_;
+    std::vector<std::thread> workers_; std::thread writer_, file_thr_[3];
+    std::mutex fm_; std::condition_variable cv_file_; std::deque<std::shared_ptr<Chunk>> fq_[3]; bool files_stop_ = false;
     struct PtrMap {              // TextBuf -> lane (a handful of entries)
         std::vector<std::pair<TextBuf *, int>> v;
         int &operator[](TextBuf *b) { for (auto &e : v) if (e.first == b) return e.second; v.emplace_back(b, 0); return v.back().second; }
