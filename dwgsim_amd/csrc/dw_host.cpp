@@ -987,7 +987,6 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii
             if (cap[t] == 0) continue;
             const size_t gcap = (size_t)gz_capacity(cap[t]);
             if (ensure(c, sl.gz_out[t], gcap + 64)) return DWGSIM_HIP_ERR_DEVICE;
-            HIPC(c, hipMemsetAsync(sl.gz_out[t].p, 0, gcap + 64, c->stream));
             launch_gzip(c->stream, a.out[t], &sl.d_counters[4 + t], cap[t], (uint8_t *)sl.gz_out[t].p, gcap, (uint64_t *)sl.gz_status.p + off, &sl.d_counters[28 + t], &sl.d_counters[24 + t], &sl.d_counters[2],
                         c->d_crc_table, c->d_crc_shift);
             off += nch[t];
@@ -1073,7 +1072,7 @@ int dwgsim_hip_set_gzip(dwgsim_hip_ctx_t *c, int on)
     if (!c) return DWGSIM_HIP_ERR_ARG;
     HIPC(c, hipSetDevice(c->device));
     if (on && !c->d_crc_table) {
-        std::vector<uint32_t> tab(256), sh(8 * 1024);
+        std::vector<uint32_t> tab(4 * 256), sh(16 * 1024);
         gz_host_tables(tab.data(), sh.data());
         HIPC(c, hipMalloc((void **)&c->d_crc_table, tab.size() * 4)); HIPC(c, hipMalloc((void **)&c->d_crc_shift, sh.size() * 4));
         HIPC(c, hipMemcpy(c->d_crc_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));

@@ -13,7 +13,7 @@
 // and the abort rule's failure counter, dwgsim.c:635).  Environment (all optional):
 //     DWGSIM_HIP_DEVICES   "0,1,2,3" or a count "4" (default: device DWGSIM_HIP_DEVICE or 0)
 //     DWGSIM_HIP_THREADS   deflate threads (default: all host cores)
-//     DWGSIM_HIP_GZIP      "gpu" (default): the gzip members are made on the GPU (dwgsim_hip_set_gzip: Huffman-coded 64 KiB members, ~0.49 of the
+//     DWGSIM_HIP_GZIP      "gpu" (default): the gzip members are made on the GPU (dwgsim_hip_set_gzip: Huffman-coded 32 KiB members, ~0.49 of the
 //                          text), the host only writes them; "cpu": zlib on all host cores at DWGSIM_HIP_GZIP_LEVEL (smaller files, deflate-bound)
 //     DWGSIM_HIP_GZIP_LEVEL  zlib level 0..9 for DWGSIM_HIP_GZIP=cpu (default 1: the text is produced ~1000x faster than zlib -6 packs it)
 //     DWGSIM_HIP_BATCH     read pairs per GPU batch (default 2^20)

@@ -193,7 +193,7 @@ int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *ho
 int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *ctx, int slot);
 
 /* gzip on the GPU (replaces the gzopen / gzprintf / gzputc output of dwgsim.c:919-981, :1150-1158): once switched on, every simulate call also
- * leaves each finished stream in HBM as a sequence of complete gzip members (one per 64 KiB of text, dynamic Huffman codes; concatenating the
+ * leaves each finished stream in HBM as a sequence of complete gzip members (one per 32 KiB of text, dynamic Huffman codes; concatenating the
  * members of successive batches gives a valid .gz whose decompressed bytes are exactly the text), and fetch_gz_async copies THAT to page-locked
  * host memory: half of the bytes cross PCIe and the host only writes them. */
 int dwgsim_hip_set_gzip(dwgsim_hip_ctx_t *ctx, int on);

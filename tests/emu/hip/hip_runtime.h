@@ -90,6 +90,13 @@ static inline uint32_t atomicMax(uint32_t *p, uint32_t v) { uint32_t o = __atomi
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 
 // hardware transcendentals used only inside estimates with a guard band (quality_pair_lazy): libm stand-ins are at least as accurate
+#ifndef __clang__
+static inline uint32_t __builtin_bitreverse32(uint32_t x)
+{
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4); return __builtin_bswap32(x);
+}
+#endif
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
 static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3))); }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }

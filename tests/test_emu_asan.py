@@ -12,7 +12,7 @@ DRIVER = r'''
 import os, re, sys
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from dwgsim_amd import api
-from parity_common import compare_case
+from parity_common import compare_case, check_gpu_gzip, check_record_writers, WRITER_CASES
 lib = api.load(LIB)
 oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
 g = os.path.join(ROOT, "tests", "golden")
@@ -29,6 +29,12 @@ for flags in ["-z 4246 -1 9 -2 0 -N 300 -e 1.0 -y 0.3 -n 20 -c 2 -f TACG", "-z 4
         raise SystemExit("expected an error for " + flags)
     except api.DwgsimError as e:
         assert "flow-error model" in str(e), str(e)
+# the gzip kernel (members of a long and of a one-record stream) and both record writers
+check_gpu_gzip(lib, os.path.join(g, "tiny.fa"), "-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", sizes=(300, 1))
+import tempfile
+with tempfile.TemporaryDirectory() as td:
+    check_record_writers(lib, oracle, td, WRITER_CASES[1][0].replace("-N 1500", "-N 200"), 0)
+    check_record_writers(lib, oracle, td, WRITER_CASES[4][0].replace("-N 1000", "-N 150"), 200)
 print("ASAN-CLEAN")
 '''
 
@@ -39,7 +45,7 @@ def test_kernel_sources_are_asan_clean_on_the_emulator(oracle_bin, tmp_path):
         pytest.skip("libasan not available")
     lib = str(tmp_path / "libdwgsim_emu_asan.so")
     subprocess.run(["g++", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-                    "-I" + os.path.join(HERE, "emu"), "-x", "c++", os.path.join(SRC, "dw_walk.hip"), os.path.join(SRC, "dw_simulate.hip"),
+                    "-I" + os.path.join(HERE, "emu"), "-x", "c++", os.path.join(SRC, "dw_walk.hip"), os.path.join(SRC, "dw_gzip.hip"), os.path.join(SRC, "dw_simulate.hip"),
                     os.path.join(SRC, "dw_host.cpp"), os.path.join(SRC, "dw_mutin.cpp"), os.path.join(HERE, "emu", "hip_emu.cpp"), "-o", lib], check=True)
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\nLIB = {lib!r}\n" + DRIVER], capture_output=True, text=True, env=env, timeout=1200)
