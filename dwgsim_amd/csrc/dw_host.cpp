@@ -88,7 +88,7 @@ struct dwgsim_hip_ctx {
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
-    int64_t walk_cap = -1; bool phases = false; int writer = -1;      // dwgsim_hip_debug_option
+    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0;      // dwgsim_hip_debug_option
     bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
     std::string txt, vcf;
@@ -860,7 +860,7 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
         if (c->writer >= 0) a.fifo = c->writer ? 1 : 0;
     }
     auto lds_need = [&](int lanes) { return sim_lds_bytes((size_t)((lmax0 + 7) / 8), (size_t)lanes, (size_t)c->qb_words, a.fifo != 0); };     // staged bases + the two base-quality tables + the text FIFOs
-    if (p.data_type != 2 && lds_need(SIM_THREADS) > SIM_LDS_BUDGET) {
+    if (p.data_type != 2 && (lds_need(SIM_THREADS) > SIM_LDS_BUDGET || c->force_threads == SIM_THREADS_LONG)) {
         a.sim_threads = SIM_THREADS_LONG; a.fifo = 1;
         if (lds_need(SIM_THREADS_LONG) > SIM_LDS_BUDGET) {
             char b[160]; snprintf(b, sizeof b, "dwgsim-hip: reads longer than %d bases are not supported for -c 0 / -c 1\n", (int)((SIM_LDS_BUDGET - SIM_THREADS_LONG * SIM_FIFO_BYTES) / (SIM_THREADS_LONG * 4 + 2) * 8));
@@ -1162,7 +1162,8 @@ int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *c, int slot, int stream, int b
 // Test / analysis hooks (not part of the drop-in surface): "justify_seq" = 1 runs the left-justification from one thread (cross-check),
 // "walk_cap" = n starts the mutation walk with a capacity of n candidates and a 1-byte inserted-base pool (exercises the exact re-run),
 // "phases" = 1 prints the phase split of the -DDW_PHASE_TIMING analysis build,
-// "writer" = 0 / 1 forces the register / FIFO record writer of the Illumina kernels (-1: chosen by LDS occupancy).
+// "writer" = 0 / 1 forces the register / FIFO record writer of the Illumina kernels (-1: chosen by LDS occupancy),
+// "sim_threads" = 64 forces the one-wave blocks of the long-read variant (measured: 25 % slower on 2 x 150 bp, small jobs included).
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
 {
     if (!c || !key) return DWGSIM_HIP_ERR_ARG;
@@ -1170,6 +1171,7 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "walk_cap")) c->walk_cap = value;
     else if (!strcmp(key, "phases")) c->phases = value != 0;
     else if (!strcmp(key, "writer")) c->writer = (int)value;
+    else if (!strcmp(key, "sim_threads")) c->force_threads = (int)value;
     else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }

@@ -4,9 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dwgsim_amd import api, synth
 lib = api.load()
 flags = sys.argv[1]
-contigs = synth.workload_contigs("chr20")
+contigs = synth.workload_contigs(os.environ.get("WL", "chr20"))
 params = api.parse_flags(flags, lib)
 with api.Context(params, 0, lib) as ctx:
+    if os.environ.get("SIMT"):
+        ctx.debug_option("sim_threads", int(os.environ["SIMT"]))
     if os.environ.get("WRITER"):
         ctx.debug_option("writer", int(os.environ["WRITER"]))
     name, arr = contigs[0]
