@@ -30,11 +30,11 @@ for flags in ["-z 4246 -1 9 -2 0 -N 300 -e 1.0 -y 0.3 -n 20 -c 2 -f TACG", "-z 4
     except api.DwgsimError as e:
         assert "flow-error model" in str(e), str(e)
 # the gzip kernel (members of a long and of a one-record stream) and both record writers
-check_gpu_gzip(lib, os.path.join(g, "tiny.fa"), "-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", sizes=(300, 1))
+check_gpu_gzip(lib, os.path.join(g, "tiny.fa"), "-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", sizes=(60, 1))
 import tempfile
 with tempfile.TemporaryDirectory() as td:
-    check_record_writers(lib, oracle, td, WRITER_CASES[1][0].replace("-N 1500", "-N 200"), 0)
-    check_record_writers(lib, oracle, td, WRITER_CASES[4][0].replace("-N 1000", "-N 150"), 200)
+    check_record_writers(lib, oracle, td, WRITER_CASES[1][0].replace("-N 1500", "-N 150"), 0)
+    check_record_writers(lib, oracle, td, WRITER_CASES[4][0].replace("-N 1000", "-N 100"), 200)
 print("ASAN-CLEAN")
 '''
 
