@@ -47,7 +47,7 @@ EXPORTS = [
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
-    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async",
+    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
 ]
 
 _lib = None
@@ -98,6 +98,7 @@ def load(path: str | None = None):
     lib.dwgsim_hip_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.dwgsim_hip_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.dwgsim_hip_debug_count_byte.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_uint64)]
+    lib.dwgsim_hip_debug_gzip.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, P(C.c_size_t)]
     lib.dwgsim_hip_set_gzip.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_fetch_gz_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     if path is None:
@@ -317,6 +318,14 @@ class Context:
 
     def set_fail_carry(self, carry: int):
         self._chk(self.lib.dwgsim_hip_set_fail_carry(self.h, carry))
+
+    def debug_gzip(self, data: bytes) -> bytes:
+        """Test hook: the gzip kernel's members for arbitrary bytes."""
+        cap = len(data) + len(data) // 8 + 512 * (len(data) // 32768 + 1) + 64
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(0)
+        self._chk(self.lib.dwgsim_hip_debug_gzip(self.h, data, len(data), out, cap, C.byref(n)))
+        return out.raw[:n.value]
 
     def set_gzip(self, on: bool = True):
         self._chk(self.lib.dwgsim_hip_set_gzip(self.h, 1 if on else 0))

@@ -1159,6 +1159,36 @@ int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *c, int slot, int stream, int b
     return DWGSIM_HIP_OK;
 }
 
+// Test hook (not part of the drop-in surface): the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text): the members
+// of `n` bytes of `text` into `out` (cap bytes), *out_n = their total size.  Synchronous.
+int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *c, const void *text, size_t n, void *out, size_t cap, size_t *out_n)
+{
+    if (!c || (!text && n) || !out_n) return DWGSIM_HIP_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (const int rc = dwgsim_hip_set_gzip(c, c->gzip_on ? 1 : 0); rc < 0) return rc;
+    if (!c->d_crc_table) { const bool was = c->gzip_on; if (const int rc = dwgsim_hip_set_gzip(c, 1); rc < 0) return rc; c->gzip_on = was; }
+    *out_n = 0;
+    if (n == 0) return DWGSIM_HIP_OK;
+    const size_t gcap = (size_t)gz_capacity(n), nch = (size_t)gz_chunks(n);
+    uint8_t *d_text = nullptr, *d_out = nullptr; uint64_t *d_aux = nullptr;       // aux: [0] length, [1] ticket, [2] total, [3] flags, [4..] look-back words
+    auto cleanup = [&]() { hipFree(d_text); hipFree(d_out); hipFree(d_aux); };
+    if (hipMalloc((void **)&d_text, n + 64) != hipSuccess || hipMalloc((void **)&d_out, gcap + 64) != hipSuccess || hipMalloc((void **)&d_aux, sizeof(uint64_t) * (4 + nch)) != hipSuccess) { cleanup(); c->err = "out of device memory"; return DWGSIM_HIP_ERR_DEVICE; }
+    const uint64_t n64 = n;
+    bool ok = hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream) == hipSuccess && hipMemsetAsync(d_aux, 0, sizeof(uint64_t) * (4 + nch), c->stream) == hipSuccess &&
+              hipMemcpyAsync(d_aux, &n64, sizeof n64, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (ok) {
+        launch_gzip(c->stream, d_text, &d_aux[0], n, d_out, gcap, &d_aux[4], &d_aux[1], &d_aux[2], &d_aux[3], c->d_crc_table, c->d_crc_shift);
+        uint64_t res[4] = {0, 0, 0, 0};
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(res, d_aux, sizeof res, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        if (ok && (res[3] & 8)) { cleanup(); c->err = "dwgsim-hip: the gzip output buffer is too small for this text\n"; return DWGSIM_HIP_ERR_FAILED; }
+        if (ok && res[2] > cap) { cleanup(); c->err = "debug_gzip: destination too small"; return DWGSIM_HIP_ERR_ARG; }
+        if (ok) { ok = hipMemcpy(out, d_out, (size_t)res[2], hipMemcpyDeviceToHost) == hipSuccess; *out_n = (size_t)res[2]; }
+    }
+    cleanup();
+    if (!ok) { c->err = "debug_gzip: device error"; return DWGSIM_HIP_ERR_DEVICE; }
+    return DWGSIM_HIP_OK;
+}
+
 // Test / analysis hooks (not part of the drop-in surface): "justify_seq" = 1 runs the left-justification from one thread (cross-check),
 // "walk_cap" = n starts the mutation walk with a capacity of n candidates and a 1-byte inserted-base pool (exercises the exact re-run),
 // "phases" = 1 prints the phase split of the -DDW_PHASE_TIMING analysis build,

@@ -205,6 +205,8 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst
 
 /* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases", "writer", "sim_threads" (see dw_host.cpp). */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
+/* ... and: the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text). */
+int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *ctx, const void *text, size_t n, void *out, size_t cap, size_t *out_n);
 /* ... and: occurrences of `byte` in one finished stream of a slot, counted on the device (whole-output checks without a copy-out). */
 int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int byte, uint64_t *count);
 

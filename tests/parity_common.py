@@ -283,3 +283,27 @@ def check_record_writers(lib, oracle_bin, tmpdir, flags, name_len):
             f.write(seq[i:i + 70] + "\n")
     for writer in (0, 1):
         compare_case(lib, oracle_bin, fa, flags, batch_pairs=700, debug_options={"writer": writer})
+
+
+def check_gzip_kernel_on_hard_inputs(lib, scale=0):
+    """k_gzip on bytes the simulator never produces: one repeated byte, every byte value, random bytes (incompressible: the member must still
+    fit its image), a Fibonacci histogram (unlimited Huffman codes would be 20+ bits deep: the counts are halved until 15 suffice), sizes
+    around the 32 KiB member boundary.  gunzip(members) must give the input back."""
+    import gzip, random
+    rnd = random.Random(5)
+    fib = [1, 1]
+    while len(fib) < 22:
+        fib.append(fib[-1] + fib[-2])
+    fib_bytes = b"".join(bytes([65 + k]) * f for k, f in enumerate(fib))        # 28 656 bytes, depth 21 without a limit
+    fib_mixed = bytearray(fib_bytes); rnd.shuffle(fib_mixed)
+    cases = [b"A", b"AB", b"\n" * 7, b"G" * 32769, bytes(range(256)) * 3, bytes(rnd.randrange(256) for _ in range(33000)), bytes(fib_mixed)]
+    if scale:       # (the emulation needs seconds per member: the long cases run on the GPU only)
+        cases += [b"G" * 32768, bytes(rnd.randrange(256) for _ in range(40000 * scale)), bytes(fib_mixed) * (3 * scale), b"ACGT" * 8191 + b"N",
+                  (b"@r\nACGT\n+\nIIII\n") * (2100 * scale), bytes(rnd.choice(b"ACGT") for _ in range(32767)), bytes(rnd.choice(b"ACGT") for _ in range(65536 * scale + 1))]
+    params = api.parse_flags("-z 1 -N 10", lib)
+    with api.Context(params, 0, lib) as ctx:
+        assert ctx.debug_gzip(b"") == b""
+        for data in cases:
+            gz = ctx.debug_gzip(data)
+            assert gzip.decompress(gz) == data, (len(data), data[:16])
+            assert len(gz) % 4 == 0 and len(gz) <= len(data) + 300 * (len(data) // 32768 + 1)

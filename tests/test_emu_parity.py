@@ -115,6 +115,11 @@ def test_gzip_members_made_by_the_kernels_on_cpu_emulation(emu_lib, golden_dir):
     check_gpu_gzip(emu_lib, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 900 -1 70 -2 50 -r 0.01 -y 0.1", sizes=(250, 1))
 
 
+def test_gzip_kernel_on_hard_inputs_on_cpu_emulation(emu_lib):
+    from parity_common import check_gzip_kernel_on_hard_inputs
+    check_gzip_kernel_on_hard_inputs(emu_lib)
+
+
 def test_mut_debug_aborts_on_cpu_emulation(emu_lib, oracle_bin, golden_dir):
     from parity_common import check_mut_debug_aborts
     check_mut_debug_aborts(emu_lib, oracle_bin, golden_dir)

@@ -123,6 +123,11 @@ def test_both_record_writers(lib, oracle_bin, tmp_path, k):
     check_record_writers(lib, oracle_bin, str(tmp_path), *WRITER_CASES[k])
 
 
+def test_gzip_kernel_on_hard_inputs(lib):
+    from parity_common import check_gzip_kernel_on_hard_inputs
+    check_gzip_kernel_on_hard_inputs(lib, scale=8)
+
+
 def test_cli_abort_rule_across_contexts(oracle_bin, golden_dir, tmp_path):
     """The failure counter of dwgsim.c:635 runs over the pairs of a contig in index order; with the contig split over contexts no single
     range reaches 10 000 failures in this job, the joined summaries do: dwgsim-hip must die as the reference does -- and must not when
