@@ -589,7 +589,7 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
             return DWGSIM_HIP_OK;
         }
         if (ensure(c, c->w_ppos, sizeof(int32_t) * np) || ensure(c, c->w_pcells, sizeof(uint16_t) * np) || ensure(c, c->w_ev, sizeof(Event) * (nev ? nev : 1)) ||
-            ensure(c, c->w_lo, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_sufmin, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_bound, nev ? nev : 1)) return DWGSIM_HIP_ERR_DEVICE;
+            ensure(c, c->w_lo, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_sufmin, sizeof(int32_t) * ((nev ? nev : 1) + 64)) || ensure(c, c->w_bound, nev ? nev : 1)) return DWGSIM_HIP_ERR_DEVICE;      // (+ 64: segment minima of k_sufmin)
         HIPC(c, hipMemcpyAsync(c->w_ppos.p, rc.pos.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, c->stream));
         HIPC(c, hipMemcpyAsync(c->w_pcells.p, rc.cells.data(), sizeof(uint16_t) * np, hipMemcpyHostToDevice, c->stream));
         if (nev) HIPC(c, hipMemcpyAsync(c->w_ev.p, evs.data(), sizeof(Event) * nev, hipMemcpyHostToDevice, c->stream));
@@ -648,8 +648,8 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         }
         const size_t ncap = cap ? cap : 1;
         if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
-            ensure(c, c->w_flags, sizeof(uint4) * ncap) ||
-            ensure(c, c->w_lo, sizeof(int32_t) * ncap) || ensure(c, c->w_sufmin, sizeof(int32_t) * ncap) ||
+            ensure(c, c->w_flags, sizeof(uint4) * (ncap + 64)) ||      // (+ 64 rows / entries: the segment totals of k_scan4, the segment minima of k_sufmin)
+            ensure(c, c->w_lo, sizeof(int32_t) * ncap) || ensure(c, c->w_sufmin, sizeof(int32_t) * (ncap + 64)) ||
             ensure(c, c->w_bound, ncap)) return DWGSIM_HIP_ERR_DEVICE;
         for (int h = 0; h < 2; ++h) {      // insertion tables: at most one entry per candidate; the base pools are checked on the device
             if (ncap > k.cap_ins[h]) {
@@ -1193,7 +1193,8 @@ int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *c, const void *text, size_t n, void 
 // "walk_cap" = n starts the mutation walk with a capacity of n candidates and a 1-byte inserted-base pool (exercises the exact re-run),
 // "phases" = 1 prints the phase split of the -DDW_PHASE_TIMING analysis build,
 // "writer" = 0 / 1 forces the register / FIFO record writer of the Illumina kernels (-1: chosen by LDS occupancy),
-// "sim_threads" = 64 forces the one-wave blocks of the long-read variant (measured: 25 % slower on 2 x 150 bp, small jobs included).
+// "sim_threads" = 64 forces the one-wave blocks of the long-read variant (measured: 25 % slower on 2 x 150 bp, small jobs included),
+// "walk_seg_min" = n runs the walk's two serial scans in their segmented form from a capacity of n candidates on (default 16384; 0 restores it).
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
 {
     if (!c || !key) return DWGSIM_HIP_ERR_ARG;
@@ -1202,6 +1203,7 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "phases")) c->phases = value != 0;
     else if (!strcmp(key, "writer")) c->writer = (int)value;
     else if (!strcmp(key, "sim_threads")) c->force_threads = (int)value;
+    else if (!strcmp(key, "walk_seg_min")) walk_debug_seg_min((uint32_t)value);      // (process-wide)
     else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }

@@ -9,6 +9,7 @@ void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams 
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out);
 void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l, uint32_t cap);
 void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del);
+void walk_debug_seg_min(uint32_t rows);      // test hook: candidate capacity from which k_scan4 / k_sufmin run segmented (0 = default)
 void launch_resolve(hipStream_t st, Event *ev, Count n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4);
 void launch_apply(hipStream_t st, Event *ev, Count n, const uint4 *flags, ContigDev c, WalkParams wp);
 void launch_justify_seq(hipStream_t st, const Event *ev, Count n, ContigDev c);

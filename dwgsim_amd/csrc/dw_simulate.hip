@@ -759,15 +759,29 @@ DW_DEV FailSeg failseg_join(const FailSeg &a, const FailSeg &b)
     r.R = a.R | b.R;
     return r;
 }
+// the join of the segments held by lanes 0 .. cnt-1 of a wave, in lane order (a tree of ordered joins: the monoid is associative); result in lane 0
+DW_DEV FailSeg failseg_wave_join(FailSeg x, int cnt)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        FailSeg o;
+        o.P = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(x.P >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)x.P, d);
+        o.S = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(x.S >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)x.S, d);
+        o.R = (uint32_t)__shfl_down((int)x.R, d); o.bad = (uint32_t)__shfl_down((int)x.bad, d);
+        if ((lane & (2 * d - 1)) == 0 && lane + d < cnt) x = failseg_join(x, o);
+    }
+    return x;
+}
 constexpr int FAIL_PAIRS_PER_THREAD = 64;
 // A: thread = 64 consecutive pairs, block = 256 threads; one FailSeg per block into summ[4 * block .. +4).  A batch without a single
 // failed attempt (counters[1] == 0, the usual case) is summarised by B from the counters alone.
 __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__ meta, uint64_t n_pairs, const uint64_t *__restrict__ counters, uint64_t *__restrict__ summ)
 {
-    __shared__ FailSeg seg[256];
+    __shared__ FailSeg seg[4];
     if (counters[1] == 0) return;
     const uint64_t first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * FAIL_PAIRS_PER_THREAD;
-    FailSeg s{0, 0, 0, 0};
+    FailSeg s{0, 0, 0, 0};                                          // (a thread past the end holds the neutral element: nothing failed, no reset)
     for (int q4 = 0; q4 < FAIL_PAIRS_PER_THREAD && first + q4 < n_pairs; q4 += 4) {       // 16-byte loads (meta is padded to a multiple of four entries)
         const uint4 v = *reinterpret_cast<const uint4 *>(meta + first + q4);
         const uint32_t mm[4] = {v.x, v.y, v.z, v.w};
@@ -780,11 +794,12 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
             s = (q4 + u == 0) ? one : failseg_join(s, one);
         }
     }
-    seg[threadIdx.x] = s;
+    s = failseg_wave_join(s, 64);
+    if ((threadIdx.x & 63) == 0) seg[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         FailSeg t = seg[0];
-        for (int k = 1; k < 256; ++k) t = failseg_join(t, seg[k]);
+        for (int k = 1; k < 4; ++k) t = failseg_join(t, seg[k]);
         summ[4 * (uint64_t)blockIdx.x + 0] = t.P; summ[4 * (uint64_t)blockIdx.x + 1] = t.S;
         summ[4 * (uint64_t)blockIdx.x + 2] = t.R; summ[4 * (uint64_t)blockIdx.x + 3] = t.bad;
     }
@@ -794,20 +809,15 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
 // counters[20] = abort? and the carry out counters[21] = chain[1]; the running random-read count chain[0] moves on by counters[3].
 __global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t n_pairs, uint64_t *__restrict__ counters, uint64_t *__restrict__ chain)
 {
-    __shared__ uint64_t st[64 * 4];
     FailSeg t{0, 0, counters[3] < n_pairs ? 1u : 0u, 0};          // no failed attempt at all: any genomic read resets the counter
-    if (counters[1] != 0) {
-        for (uint32_t base = 0; base < n_blocks; base += 64) {
-            const uint32_t cnt = n_blocks - base < 64 ? n_blocks - base : 64;
-            for (uint32_t q = threadIdx.x; q < cnt * 4; q += 64) st[q] = summ[4 * (uint64_t)base + q];
-            __syncthreads();
-            if (threadIdx.x == 0)
-                for (uint32_t b = 0; b < cnt; ++b) {
-                    const FailSeg nx{st[4 * b], st[4 * b + 1], (uint32_t)st[4 * b + 2], (uint32_t)st[4 * b + 3]};
-                    t = (base + b == 0) ? nx : failseg_join(t, nx);
-                }
-            __syncthreads();
+    if (counters[1] != 0) {                                       // lane k joins its slice of the block summaries, the wave joins the slices in order
+        const uint32_t per = (n_blocks + 63) / 64, b0 = threadIdx.x * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+        FailSeg x{0, 0, 0, 0};
+        for (uint32_t b = b0; b < b1; ++b) {
+            const FailSeg nx{summ[4 * (uint64_t)b], summ[4 * (uint64_t)b + 1], (uint32_t)summ[4 * (uint64_t)b + 2], (uint32_t)summ[4 * (uint64_t)b + 3]};
+            x = (b == b0) ? nx : failseg_join(x, nx);
         }
+        t = failseg_wave_join(x, per ? (int)((n_blocks + per - 1) / per) : 0);
     }
     if (threadIdx.x == 0) {
         const uint64_t carry = chain[1];

@@ -187,19 +187,25 @@ __global__ void k_resolve(Event *ev, Count nc, const uint32_t *max_del_p, uint4 
     flags[k] = f;
 }
 
-// exclusive scan of the four insertion-allocation columns (single block); totals -> tot[0..3].  Eight consecutive rows per thread
-// (all loads in flight at once, a sequential scan in registers), then one block scan of the thread totals: one barrier per 8192 rows.
-__global__ void k_scan4(uint4 *flags, Count nc, uint32_t *tot)
+// exclusive scan of the four insertion-allocation columns; totals -> tot[0..3].  Eight consecutive rows per thread (all loads in flight at
+// once, a sequential scan in registers), then one block scan of the thread totals: one barrier per 8192 rows.  One block does it all for
+// short candidate lists (seglen = 0); long ones (a chr20-sized contig has 64 k candidates, chr1 250 k) are cut into WALK_SEGS segments
+// scanned by one block each, k_scan4_fix then adds the totals of the segments in front.
+constexpr uint32_t WALK_SEGS = 32;
+static uint32_t g_walk_seg_min_rows = 16384;            // capacity from which the segmented form is used (tests lower it: dwgsim_hip_debug_option("walk_seg_min"))
+void walk_debug_seg_min(uint32_t rows) { g_walk_seg_min_rows = rows ? rows : 16384; }
+__global__ void k_scan4(uint4 *flags, Count nc, uint32_t *tot, uint32_t seglen, uint4 *part)
 {
     const uint32_t n = count_of(nc);
+    const uint32_t lo = seglen ? blockIdx.x * seglen : 0u, hi = seglen ? (lo + seglen < n ? lo + seglen : n) : n;
     constexpr uint32_t ITEMS = 8;
     __shared__ uint32_t sm[2][4][16];
     uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int buf = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x * ITEMS, buf ^= 1) {
+    for (uint32_t base = lo; base < hi; base += blockDim.x * ITEMS, buf ^= 1) {
         const uint32_t i0 = base + threadIdx.x * ITEMS;
         uint4 v[ITEMS];
 #pragma unroll
-        for (uint32_t q = 0; q < ITEMS; ++q) v[q] = i0 + q < n ? flags[i0 + q] : make_uint4(0, 0, 0, 0);
+        for (uint32_t q = 0; q < ITEMS; ++q) v[q] = i0 + q < hi ? flags[i0 + q] : make_uint4(0, 0, 0, 0);
         uint32_t t[4] = {0, 0, 0, 0};
 #pragma unroll
         for (uint32_t q = 0; q < ITEMS; ++q) {         // row -> its exclusive prefix inside the thread (the dead flag stays in bit 31 of x)
@@ -211,10 +217,18 @@ __global__ void k_scan4(uint4 *flags, Count nc, uint32_t *tot)
         block_excl_scan_n<4>(t, sm[buf], ex, total);
 #pragma unroll
         for (uint32_t q = 0; q < ITEMS; ++q)
-            if (i0 + q < n) flags[i0 + q] = make_uint4(((v[q].x & 0x7fffffffu) + ex[0] + c0) | (v[q].x & 0x80000000u), v[q].y + ex[1] + c1, v[q].z + ex[2] + c2, v[q].w + ex[3] + c3);
+            if (i0 + q < hi) flags[i0 + q] = make_uint4(((v[q].x & 0x7fffffffu) + ex[0] + c0) | (v[q].x & 0x80000000u), v[q].y + ex[1] + c1, v[q].z + ex[2] + c2, v[q].w + ex[3] + c3);
         c0 += total[0]; c1 += total[1]; c2 += total[2]; c3 += total[3];
     }
-    if (threadIdx.x == 0) { tot[0] = c0; tot[1] = c1; tot[2] = c2; tot[3] = c3; }
+    if (threadIdx.x == 0) { if (seglen) part[blockIdx.x] = make_uint4(c0, c1, c2, c3); else { tot[0] = c0; tot[1] = c1; tot[2] = c2; tot[3] = c3; } }
+}
+__global__ void k_scan4_fix(uint4 *flags, Count nc, uint32_t *tot, uint32_t seglen, const uint4 *part)
+{
+    const uint32_t n = count_of(nc), i = blockIdx.x * blockDim.x + threadIdx.x, s = i / seglen;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    for (uint32_t q = 0; q < WALK_SEGS; ++q) { const uint4 p = part[q]; if (q < s) { a0 += p.x; a1 += p.y; a2 += p.z; a3 += p.w; } t0 += p.x; t1 += p.y; t2 += p.z; t3 += p.w; }
+    if (i == 0) { tot[0] = t0; tot[1] = t1; tot[2] = t2; tot[3] = t3; }
+    if (i < n && s) { const uint4 f = flags[i]; flags[i] = make_uint4(((f.x & 0x7fffffffu) + a0) | (f.x & 0x80000000u), f.y + a1, f.z + a2, f.w + a3); }
 }
 
 // K3: write live events into the cells and the insertion tables.
@@ -404,18 +418,20 @@ __global__ void k_jreach(const Event *__restrict__ ev, Count nc, ContigDev c, in
     }
     lo[k] = (int32_t)reach;
 }
-// single block: sufmin[k] = min(lo[k..n))
-__global__ void k_sufmin(const int32_t *__restrict__ lo, Count nc, int32_t *__restrict__ sufmin)
+// sufmin[k] = min(lo[k..n)): one block walks the array (or, seglen > 0, its segment of it) from the end; k_sufmin_fix folds in the minima of
+// the segments behind
+__global__ void k_sufmin(const int32_t *__restrict__ lo, Count nc, int32_t *__restrict__ sufmin, uint32_t seglen, int32_t *part)
 {
     const uint32_t n = count_of(nc);
+    const int64_t a = seglen ? (int64_t)blockIdx.x * seglen : 0, b = seglen ? (a + seglen < (int64_t)n ? a + seglen : (int64_t)n) : (int64_t)n;
     __shared__ int32_t sm[2][16];
     int32_t carry = 0x7fffffff; int buf = 0;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-    const uint32_t nchunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t nchunk = b > a ? (uint32_t)((b - a + blockDim.x - 1) / blockDim.x) : 0u;
     for (uint32_t ch = 0; ch < nchunk; ++ch, buf ^= 1) {
-        // walk the array from its end: thread t handles element (n-1) - (ch*blockDim + t)
-        const int64_t i = (int64_t)n - 1 - ((int64_t)ch * blockDim.x + threadIdx.x);
-        int32_t v = i >= 0 ? lo[i] : 0x7fffffff;
+        // walk the range from its end: thread t handles element (b-1) - (ch*blockDim + t)
+        const int64_t i = b - 1 - ((int64_t)ch * blockDim.x + threadIdx.x);
+        int32_t v = i >= a ? lo[i] : 0x7fffffff;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d); if (lane >= d && o < v) v = o; }   // inclusive min-scan
         if (lane == 63) sm[buf][wave] = v;
@@ -423,9 +439,17 @@ __global__ void k_sufmin(const int32_t *__restrict__ lo, Count nc, int32_t *__re
         int32_t pre = carry, all = carry;                    // minimum of everything before this wave / of the whole chunk so far
         for (int w = 0; w < nw; ++w) { const int32_t t = sm[buf][w]; if (t < all) all = t; if (w < wave && t < pre) pre = t; }
         if (pre < v) v = pre;
-        if (i >= 0) sufmin[i] = v;
+        if (i >= a) sufmin[i] = v;
         carry = all;
     }
+    if (seglen && threadIdx.x == 0) part[blockIdx.x] = carry;
+}
+__global__ void k_sufmin_fix(int32_t *__restrict__ sufmin, Count nc, uint32_t seglen, const int32_t *__restrict__ part)
+{
+    const uint32_t n = count_of(nc), i = blockIdx.x * blockDim.x + threadIdx.x, s = i / seglen;
+    int32_t m = 0x7fffffff;
+    for (uint32_t q = 0; q < WALK_SEGS; ++q) { const int32_t p = part[q]; if (q > s && p < m) m = p; }
+    if (i < n && m < sufmin[i]) sufmin[i] = m;
 }
 __global__ void k_jbound(const Event *__restrict__ ev, Count nc, ContigDev c, const int32_t *__restrict__ sufmin, uint8_t *__restrict__ bound)
 {
@@ -527,7 +551,10 @@ void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *
 void launch_resolve(hipStream_t st, Event *ev, Count n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4)
 {
     if (n.host) hipLaunchKernelGGL(k_resolve, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, max_del, flags);
-    hipLaunchKernelGGL(k_scan4, dim3(1), dim3(1024), 0, st, flags, n, tot4);
+    if (n.host < g_walk_seg_min_rows) { hipLaunchKernelGGL(k_scan4, dim3(1), dim3(1024), 0, st, flags, n, tot4, 0u, (uint4 *)nullptr); return; }
+    const uint32_t seglen = (n.host + WALK_SEGS - 1) / WALK_SEGS;                    // (flags has room for WALK_SEGS more rows behind its n.host: the segment totals)
+    hipLaunchKernelGGL(k_scan4, dim3(WALK_SEGS), dim3(1024), 0, st, flags, n, tot4, seglen, flags + n.host);
+    hipLaunchKernelGGL(k_scan4_fix, dim3(cdiv(n.host, 256)), dim3(256), 0, st, flags, n, tot4, seglen, (const uint4 *)(flags + n.host));
 }
 void launch_apply(hipStream_t st, Event *ev, Count n, const uint4 *flags, ContigDev c, WalkParams wp)
 {
@@ -541,7 +568,12 @@ void launch_justify(hipStream_t st, const Event *ev, Count n, ContigDev c, int32
 {
     if (!n.host) return;
     hipLaunchKernelGGL(k_jreach, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, c, lo);
-    hipLaunchKernelGGL(k_sufmin, dim3(1), dim3(1024), 0, st, lo, n, sufmin);
+    if (n.host < g_walk_seg_min_rows) hipLaunchKernelGGL(k_sufmin, dim3(1), dim3(1024), 0, st, lo, n, sufmin, 0u, (int32_t *)nullptr);
+    else {                                                                          // (sufmin has room for WALK_SEGS more entries behind its n.host: the segment minima)
+        const uint32_t seglen = (n.host + WALK_SEGS - 1) / WALK_SEGS;
+        hipLaunchKernelGGL(k_sufmin, dim3(WALK_SEGS), dim3(1024), 0, st, lo, n, sufmin, seglen, sufmin + n.host);
+        hipLaunchKernelGGL(k_sufmin_fix, dim3(cdiv(n.host, 256)), dim3(256), 0, st, sufmin, n, seglen, (const int32_t *)(sufmin + n.host));
+    }
     hipLaunchKernelGGL(k_jbound, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, c, sufmin, bound);
     hipLaunchKernelGGL(k_jrun, dim3(cdiv(n.host, 64)), dim3(64), 0, st, ev, n, c, bound);
 }

@@ -203,7 +203,7 @@ int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void 
  * hipMemcpyAsync at link speed; pageable memory goes through double-buffered pinned staging inside. */
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
-/* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases", "writer", "sim_threads" (see dw_host.cpp). */
+/* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases", "writer", "sim_threads", "walk_seg_min" (see dw_host.cpp). */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
 /* ... and: the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text). */
 int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *ctx, const void *text, size_t n, void *out, size_t cap, size_t *out_n);

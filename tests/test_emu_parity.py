@@ -64,6 +64,15 @@ def test_walk_reruns_when_a_capacity_is_exceeded(emu_lib, oracle_bin, golden_dir
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 30 -X 0.6", batch_pairs=700, debug_options={"walk_cap": 7})
 
 
+def test_walk_scans_in_their_segmented_form(emu_lib, oracle_bin, golden_dir):
+    """k_scan4 / k_sufmin cut into 32 segments + fix-up kernels (what long contigs use), forced on a small one: mutations and reads as the oracle's."""
+    try:
+        compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.05 -R 0.6 -I 3 -X 0.5", batch_pairs=700, debug_options={"walk_seg_min": 1})
+    finally:
+        with api.Context(api.parse_flags("-z 1 -N 1", emu_lib), 0, emu_lib) as ctx:
+            ctx.debug_option("walk_seg_min", 0)
+
+
 def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):
     """Amplicon mode on a contig whose read-1 window always holds an N: every genomic attempt fails, only random reads come out and
     never reset the counter -- the reference dies at the 10 001st failure, and so must the HIP path (no pair exceeds the limit alone)."""
