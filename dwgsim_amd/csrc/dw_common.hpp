@@ -28,6 +28,8 @@ enum : uint32_t {
                         // 4 hom test (:622,:629, mut.c:301), 5 het haplotype (:625,:633, mut.c:303)
     D_WALK_INSLEN = 2,  // slot k = k-th insertion length-extension test (mut.c:292)
     D_WALK_INSBASE = 3, // slot k = k-th inserted-base draw (mut.c:314 / :351)
+    D_WALK_SITE = 7,    // index = 0.  halfword p (block p >> 3, laid out as D_BASE0) = the HIGH half of the uniform of "mutate position p?" (mut.c:618);
+    D_WALK_SITE_REF = 26, // ... its LOW half, drawn only when the high halves of the uniform and of mut_rate * 2^32 agree
     D_PAIR = 4,         // index = ii.  slot 0 random-read test (dwgsim.c:649), 1 haplotype (:716), 2 strand (:723)
     D_PLACE = 5,        // slot t = position uniform of placement try t (dwgsim.c:671)
     D_PLACE_NORM = 6,   // block t, retry r = polar tries of the insert-size normal of try t (dwgsim.c:657)

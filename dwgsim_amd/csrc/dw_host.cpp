@@ -134,7 +134,7 @@ WalkParams walk_params(const dwgsim_hip_ctx *c)
 {
     WalkParams w; w.mut_rate = c->prm.mut_rate; w.indel_frac = c->prm.indel_frac; w.indel_extend = c->prm.indel_extend;
     w.indel_min = c->prm.indel_min; w.is_hap = c->prm.is_hap; w.seed = (uint32_t)c->prm.seed;
-    w.mut_thr53 = c->prm.mut_rate <= 0 ? 0 : (uint64_t)ceil(c->prm.mut_rate * 9007199254740992.0);   // exact scaling by 2^53
+    w.mut_thr = !(c->prm.mut_rate > 0) ? 0 : c->prm.mut_rate >= 1.0 ? 0x100000000ull : (uint64_t)ceil(c->prm.mut_rate * 4294967296.0);   // exact scaling by 2^32
     return w;
 }
 

@@ -65,7 +65,7 @@ struct Count { const uint64_t *dev; uint32_t host; };
 
 struct WalkParams {
     double mut_rate, indel_frac, indel_extend;
-    uint64_t mut_thr53;            // ceil(mut_rate * 2^53): u53 < mut_rate  <=>  k53 < mut_thr53
+    uint64_t mut_thr;              // ceil(mut_rate * 2^32) (2^32 for a rate of 1): u < mut_rate  <=>  the 32-bit draw < mut_thr
     int32_t indel_min, is_hap;
     uint32_t seed;
 };

@@ -2,7 +2,7 @@
 // (replaces src/mut.c:591-643 mut_diref + :481-589 mut_left_justify + the cell list behind :781-893 mut_print).
 //
 //     k_pack          ASCII -> base codes, initialises both haplotypes            HBM: 1 B in, 3 B out / base
-//     k_site_scan     one Philox draw per position: candidate sites (bitmask)     HBM: 1 B in / base; ALU (Philox)
+//     k_site_scan     one 16-bit draw per position (a Philox block per eight): candidate sites (bitmask)     HBM: 1 B in / base
 //     k_scan_excl     single-block exclusive scan of per-block counts
 //     k_compact       ordered compaction of a bitmask into a position list
 //     k_events        one thread per candidate: speculative event (type, ploidy, lengths)
@@ -49,10 +49,26 @@ __global__ void k_pack(const uint8_t *__restrict__ ascii, uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: candidate sites.  mut.c:618 `c < 4 && drand48() < opt->mut_rate` with the draw taken from
-// (D_WALK, position, slot 1).  16 positions per thread, 4096 per block; emits a bitmask (uint16 per
-// thread) and the per-block candidate count.
+// K1: candidate sites.  mut.c:618 `c < 4 && drand48() < opt->mut_rate`: the draw of position p is halfword p of the D_WALK_SITE stream (16 + 16
+// bits, the low halves drawn only on a tie with the threshold's high half), so one Philox block serves EIGHT positions.  16 positions per
+// thread, 4096 per block; emits a bitmask (uint16 per thread) and the per-block candidate count.
 // ------------------------------------------------------------------------------------------------
+DW_DEV uint32_t site_hits8(RngKey key, uint32_t blk, uint64_t thr)      // bit k: the draw of position 8 * blk + k is below mut_rate
+{
+    const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
+    const U4 b = rng_block(key, D_WALK_SITE, 0, 0, 0, blk);
+    const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
+    uint32_t lt = 0, closest = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; const uint32_t d = hw[k] ^ t_hi; closest = d < closest ? d : closest; }
+    if (closest == 0 && t_lo) {
+        const U4 r = rng_block(key, D_WALK_SITE_REF, 0, 0, 0, blk);
+        const uint32_t lw[8] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16, r.z & 0xFFFFu, r.z >> 16, r.w & 0xFFFFu, r.w >> 16};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lt |= ((hw[k] == t_hi && lw[k] < t_lo) ? 1u : 0u) << k;
+    }
+    return lt;
+}
 __global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkParams wp, uint32_t contig_index,
                             uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count)
 {
@@ -63,14 +79,10 @@ __global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkPara
     if (p0 < l) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ref + p0);      // ref is padded: reading past l is safe
         const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+        uint32_t acgt = 0;                                               // positions that hold A, C, G or T (and lie inside the contig)
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const uint32_t c = (in[b >> 2] >> (8 * (b & 3))) & 0xff;
-            if (c < 4 && p0 + b < l) {
-                const U4 blk = rng_block(key, D_WALK, (uint64_t)(p0 + b), 0, 0, 0);
-                if ((((uint64_t)blk.z << 21) | (uint64_t)(blk.w >> 11)) < wp.mut_thr53) bits |= 1u << b;   // u53(w2,w3) < mut_rate
-            }
-        }
+        for (int b = 0; b < 16; ++b) { const uint32_t c = (in[b >> 2] >> (8 * (b & 3))) & 0xff; if (c < 4 && p0 + b < l) acgt |= 1u << b; }
+        if (acgt) bits = (site_hits8(key, (uint32_t)(p0 >> 3), wp.mut_thr) | (site_hits8(key, (uint32_t)(p0 >> 3) + 1u, wp.mut_thr) << 8)) & acgt;
     }
     mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x] = (uint16_t)bits;
     uint32_t total;

@@ -51,7 +51,10 @@ enum { RNG_DRAND48 = 0, RNG_PHILOX = 1 };
 
 /* mode-B domains (c2 = domain << 24 | attempt) */
 enum {
-    D_WALK = 1,        /* index = position; slots 0..5 (see walk_contig) */
+    D_WALK = 1,        /* index = position; slots 0, 2..5 (see walk_contig); the "mutate this base?" test (mut.c:618) is a 16 + 16 bit draw of its own: */
+    D_WALK_SITE = 7,   /* index = 0; halfword p (block p >> 3, eight per block, laid out as D_BASE0) = the HIGH half of position p's uniform; the LOW
+                          half is halfword p of D_WALK_SITE_REF (matters with probability 2^-16, drawn lazily by the kernel) */
+    D_WALK_SITE_REF = 26,
     D_WALK_INSLEN = 2, /* index = position; slot k = k-th length-extension test */
     D_WALK_INSBASE = 3,/* index = position; slot k = k-th inserted-base draw */
     D_PAIR = 4,        /* index = ii; slot 0 rand-read test, 1 haplotype, 2 strand */
@@ -184,6 +187,15 @@ static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uin
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
     const uint32_t h = philox_halfword(r, D_BASE0 + (uint32_t)j, idx, att, i), l = philox_halfword(r, D_BASE_REF0 + (uint32_t)j, idx, att, i);
+    return (double)((h << 16) | l) * 0x1p-32;
+}
+
+/* mut.c:618 drand48() < opt->mut_rate, one per non-N position: by far the most frequent draw of the walk, so it is a narrow one, eight per block */
+static inline double walk_site_u(rng_t *r, uint32_t p)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
+    const uint32_t h = philox_halfword(r, D_WALK_SITE, 0, 0, p), l = philox_halfword(r, D_WALK_SITE_REF, 0, 0, p);
     return (double)((h << 16) | l) * 0x1p-32;
 }
 
@@ -408,7 +420,7 @@ static void walk_contig(const opt_t *o, rng_t *r, const seq_t *seq, hap_t *h0, h
             }
             deleting = 0; dlen = 0;
         }
-        if (c < 4 && rng_u(r, D_WALK, (uint64_t)i, 0, 0, 1) < o->mut_rate) {
+        if (c < 4 && walk_site_u(r, (uint32_t)i) < o->mut_rate) {
             if (rng_u(r, D_WALK, (uint64_t)i, 0, 0, 2) >= o->indel_frac) { /* substitution */
                 double rr = rng_u(r, D_WALK, (uint64_t)i, 0, 0, 3);
                 uint8_t c2 = (uint8_t)((c + (uint64_t)(rr * 3.0 + 1)) & 3);
