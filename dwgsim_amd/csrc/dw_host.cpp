@@ -565,12 +565,11 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
     HIPC(c, hipSetDevice(c->device));
     const WalkParams wp = walk_params(c);
     const int64_t l = k.l;
-    if (k.mutated) {       // re-run: start again from the resident packed reference
+    const bool again = k.mutated;      // walked before: the cells start again from the resident packed reference
+    if (again) for (int h = 0; h < 2; ++h) k.n_ins[h] = k.n_ins_bases[h] = 0;
+    if (again && c->has_mutin) {
         const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
-        for (int h = 0; h < 2; ++h) {
-            HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
-            k.n_ins[h] = k.n_ins_bases[h] = 0;
-        }
+        for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
     }
     k.mutated = true; k.n_cand = 0; k.summ_valid = false;
     const size_t padded_cells = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
@@ -670,7 +669,8 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
         const Count nc{&c->d_counters[7], cap};
         HIPC(c, hipMemsetAsync(&c->d_counters[7], 0, 5 * sizeof(uint64_t), c->stream));
         // K1: candidate sites -> ordered list
-        launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt);
+        const bool reset = again && attempt == 0;      // (a capacity re-run has just copied the cells back; a first walk finds them fresh from k_pack)
+        launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt, reset ? k.d_cells[0] : nullptr, reset ? k.d_cells[1] : nullptr);
         launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
         launch_compact(c->stream, d_mask, d_cnt, d_cand, l, cap);
         // K2: events, liveness, insertion-table allocation

@@ -69,8 +69,9 @@ DW_DEV uint32_t site_hits8(RngKey key, uint32_t blk, uint64_t thr)      // bit k
     }
     return lt;
 }
+// reset0 / reset1 (a contig that is walked AGAIN): the 16 cells of both haplotypes are set back to the reference on the way.
 __global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkParams wp, uint32_t contig_index,
-                            uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count)
+                            uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count, uint8_t *__restrict__ reset0, uint8_t *__restrict__ reset1)
 {
     __shared__ uint32_t sm[17];
     const RngKey key{wp.seed, contig_index};
@@ -78,6 +79,7 @@ __global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkPara
     uint32_t bits = 0;
     if (p0 < l) {
         const uint4 v = *reinterpret_cast<const uint4 *>(ref + p0);      // ref is padded: reading past l is safe
+        if (reset0) { *reinterpret_cast<uint4 *>(reset0 + p0) = v; *reinterpret_cast<uint4 *>(reset1 + p0) = v; }
         const uint32_t in[4] = {v.x, v.y, v.z, v.w};
         uint32_t acgt = 0;                                               // positions that hold A, C, G or T (and lie inside the contig)
 #pragma unroll
@@ -543,9 +545,9 @@ void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0
     uint32_t nb = cdiv(nchunk, 256); if (nb > (1u << 16)) nb = 1u << 16; if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, ascii, ref, h0, h1, l);
 }
-void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count)
+void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1)
 {
-    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, l, wp, contig_index, mask, block_count);
+    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, l, wp, contig_index, mask, block_count, reset0, reset1);
 }
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out)
 {

@@ -307,3 +307,22 @@ def check_gzip_kernel_on_hard_inputs(lib, scale=0):
             gz = ctx.debug_gzip(data)
             assert gzip.decompress(gz) == data, (len(data), data[:16])
             assert len(gz) % 4 == 0 and len(gz) <= len(data) + 300 * (len(data) // 32768 + 1)
+
+
+def check_walking_a_contig_again(lib, fasta, flags, n=400):
+    """dwgsim_hip_mutate_contig on a contig that was walked before starts again from the resident reference (the cells are reset inside the
+    site scan): same mutation files, same reads -- also when the first walk of the second round has to be re-run for capacity."""
+    contigs = api.read_fasta(fasta)
+    params = api.parse_flags(flags, lib)
+    name, arr = contigs[0]
+    with api.Context(params, 0, lib) as ctx:
+        cid = ctx.add_contig(name, arr, 0)
+        got = []
+        for rnd in range(3):
+            if rnd == 2:
+                ctx.debug_option("walk_cap", 5)
+            ctx.mutate(cid)
+            b = ctx.simulate(cid, 0, n, 0, rnd & 1)
+            got.append((ctx.mutations_text(cid), [ctx.fetch(rnd & 1, s, b.bytes[s]) for s in range(3)]))
+        assert got[0] == got[1] == got[2]
+        assert len(got[0][0][0]) > 200

@@ -73,6 +73,11 @@ def test_walk_scans_in_their_segmented_form(emu_lib, oracle_bin, golden_dir):
             ctx.debug_option("walk_seg_min", 0)
 
 
+def test_walking_a_contig_again_on_cpu_emulation(emu_lib, golden_dir):
+    from parity_common import check_walking_a_contig_again
+    check_walking_a_contig_again(emu_lib, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 3 -X 0.6")
+
+
 def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):
     """Amplicon mode on a contig whose read-1 window always holds an N: every genomic attempt fails, only random reads come out and
     never reset the counter -- the reference dies at the 10 001st failure, and so must the HIP path (no pair exceeds the limit alone)."""

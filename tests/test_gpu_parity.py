@@ -123,6 +123,11 @@ def test_both_record_writers(lib, oracle_bin, tmp_path, k):
     check_record_writers(lib, oracle_bin, str(tmp_path), *WRITER_CASES[k])
 
 
+def test_walking_a_contig_again(lib, golden_dir):
+    from parity_common import check_walking_a_contig_again
+    check_walking_a_contig_again(lib, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 3 -X 0.6", n=600)
+
+
 def test_gzip_kernel_on_hard_inputs(lib):
     from parity_common import check_gzip_kernel_on_hard_inputs
     check_gzip_kernel_on_hard_inputs(lib, scale=8)
