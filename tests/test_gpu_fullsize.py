@@ -149,3 +149,31 @@ def test_assembly_like_multi_contig_job_bit_exact(lib, oracle_bin, tmp_path, fla
     assert sum(len(s) for s in res.streams.values()) > 10_000_000
     assert res.mutations_txt == open(str(tmp_path / "o.mutations.txt"), "rb").read()
     assert res.mutations_vcf == open(str(tmp_path / "o.mutations.vcf"), "rb").read()
+
+
+def test_gzip_members_of_a_full_batch(lib):
+    """GPU gzip at the size dwgsim-hip runs it: one 2^20-pair batch of the chr20-sized job (2 x 380 MB of text, 11 600 members per stream made
+    by one k_gzip launch each, member offsets by look-back across all of them): gunzip(members) == text, for both writers' slots."""
+    import zlib
+    contigs = synth.workload_contigs("chr20")
+    params = api.parse_flags("-z 13 -1 150 -2 150 -C 30 -o 1", lib)
+    name, arr = contigs[0]
+    with api.Context(params, 0, lib) as ctx:
+        ctx.set_gzip(True)
+        cid = ctx.add_contig(name, arr, 0)
+        ctx.mutate(cid)
+        for slot, first in ((0, 0), (1, 3_000_000)):
+            b = ctx.simulate(cid, first, 1 << 20, 0, slot)
+            for s in (0, 1):
+                txt = ctx.fetch_np(slot, s, b.bytes[s])
+                gz = ctx.fetch_gz(slot, s, b.gz_bytes[s])
+                assert 0.4 * len(txt) < len(gz) < 0.55 * len(txt)
+                out = []; n_members = 0; off = 0; view = memoryview(gz)
+                while off < len(gz):                          # member by member (zlib stops at the end of each; a member is < 40 000 bytes)
+                    d = zlib.decompressobj(31)
+                    chunk = bytes(view[off:off + 40000])
+                    out.append(d.decompress(chunk)); assert d.eof
+                    off += len(chunk) - len(d.unused_data); n_members += 1
+                back = np.frombuffer(b"".join(out), dtype=np.uint8)
+                assert n_members == (len(txt) + 32767) // 32768
+                assert len(back) == len(txt) and np.array_equal(back, txt), (slot, s)
