@@ -246,12 +246,14 @@ def check_gpu_gzip(lib, fasta, flags, sizes):
                     continue
                 assert gzip.decompress(gz) == txt, (n, s)
                 # member by member: each is a complete gzip file of at most 32 KiB of text (a multiple of 4 bytes long)
-                rest, n_members, total = gz, 0, 0
-                while rest:
+                off, n_members, total, view = 0, 0, 0, memoryview(gz)
+                while off < len(gz):
                     d = zlib.decompressobj(31)
-                    part = d.decompress(rest)
-                    assert d.eof and 0 < len(part) <= 32768 and (len(rest) - len(d.unused_data)) % 4 == 0
-                    total += len(part); n_members += 1; rest = d.unused_data
+                    chunk = bytes(view[off:off + 40000])          # (a member is < 40 000 bytes)
+                    part = d.decompress(chunk)
+                    used = len(chunk) - len(d.unused_data)
+                    assert d.eof and 0 < len(part) <= 32768 and used % 4 == 0
+                    total += len(part); n_members += 1; off += used
                 assert total == len(txt) and n_members == (len(txt) + 32767) // 32768
                 assert len(gz) < 0.6 * len(txt) + 300 * n_members
         ctx.set_gzip(False)
