@@ -16,10 +16,10 @@ from parity_common import compare_case, check_gpu_gzip, check_record_writers, WR
 lib = api.load(LIB)
 oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
 g = os.path.join(ROOT, "tests", "golden")
-for fasta, flags in [("ex1.fa", "-z 13 -N 300"), ("odd.fa", "-z 3 -N 300 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50 -y 0.1"),
-                     ("tiny.fa", "-z 8 -N 300 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05"),
+for fasta, flags in [("ex1.fa", "-z 13 -N 160"), ("odd.fa", "-z 3 -N 200 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50 -y 0.1"),
+                     ("tiny.fa", "-z 8 -N 200 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05"),
                      ("tiny.fa", "-z 9 -N 200 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
-                     ("tiny.fa", "-z 3 -N 100 -1 1300 -2 1400 -d 3600 -s 40 -n 60")]:
+                     ("tiny.fa", "-z 3 -N 40 -1 1300 -2 1400 -d 3600 -s 40 -n 60")]:
     compare_case(lib, oracle, os.path.join(g, fasta), flags, batch_pairs=128)
 # reads the flow model gives up on (absurd per-flow error): the call must fail cleanly, with every write in bounds
 compare_case(lib, oracle, os.path.join(g, "ex1.fa"), "-z 8397 -1 100 -2 0 -N 64 -e 0.3 -o 0 -c 2 -f GATC", batch_pairs=128)      # deep insertion cascades
