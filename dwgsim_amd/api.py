@@ -37,6 +37,11 @@ class Batch(C.Structure):
                 ("fail_seg", C.c_uint64 * 4), ("fail_carry", C.c_uint64), ("gz_bytes", C.c_uint64 * 3)]
 
 
+class Range(C.Structure):
+    """dwgsim_hip_range_t: a read-index range of one contig"""
+    _fields_ = [("contig", C.c_int32), ("reserved", C.c_int32), ("first_ii", C.c_uint64), ("n_pairs", C.c_uint64)]
+
+
 RAND_CHAIN = (1 << 64) - 1        # DWGSIM_HIP_RAND_CHAIN
 
 
@@ -47,6 +52,7 @@ EXPORTS = [
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
+    "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
     "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
 ]
 
@@ -74,6 +80,14 @@ def load(path: str | None = None):
     lib.dwgsim_hip_last_error.argtypes = [C.c_void_p]
     lib.dwgsim_hip_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_uint32]
     lib.dwgsim_hip_drop_contig.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_add_contigs.argtypes = [C.c_void_p, C.c_int, P(C.c_char_p), P(C.c_void_p), P(C.c_int64), P(C.c_uint32)]
+    lib.dwgsim_hip_group_layout.restype = C.c_int64
+    lib.dwgsim_hip_group_layout.argtypes = [P(C.c_int64), C.c_int, P(C.c_int64)]
+    lib.dwgsim_hip_mutate_async.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_mutate_wait.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_count_random_ranges.argtypes = [C.c_void_p, P(Range), C.c_int, P(C.c_uint64)]
+    lib.dwgsim_hip_simulate_ranges_async.argtypes = [C.c_void_p, P(Range), C.c_int, C.c_uint64, C.c_int]
+    lib.dwgsim_hip_device_count.argtypes = []
     lib.dwgsim_hip_set_regions.argtypes = [C.c_void_p, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int, P(C.c_uint64)]
     lib.dwgsim_hip_contig_region_length.restype = C.c_int64
     lib.dwgsim_hip_contig_region_length.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
@@ -260,6 +274,43 @@ class Context:
     def drop_contig(self, cid: int):
         self._chk(self.lib.dwgsim_hip_drop_contig(self.h, cid))
 
+    def add_contigs(self, contigs, first_index: int = 0, indices=None) -> int:
+        """contigs: [(name, uint8 array)] resident together as one group; returns the handle of the first (contig k: handle + k)."""
+        import numpy as np
+        n = len(contigs)
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for _, a in contigs]
+        names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_int64 * n)(*[len(a) for a in arrs])
+        idx = (C.c_uint32 * n)(*(indices if indices is not None else range(first_index, first_index + n)))
+        return self._chk(self.lib.dwgsim_hip_add_contigs(self.h, n, names, ptrs, lens, idx))
+
+    def mutate_async(self, cid: int):
+        self._chk(self.lib.dwgsim_hip_mutate_async(self.h, cid))
+
+    def mutate_wait(self, cid: int):
+        self._chk(self.lib.dwgsim_hip_mutate_wait(self.h, cid))
+
+    @staticmethod
+    def _ranges(ranges):
+        arr = (Range * len(ranges))()
+        for k, (cid, first, n) in enumerate(ranges):
+            arr[k].contig, arr[k].first_ii, arr[k].n_pairs = cid, first, n
+        return arr
+
+    def count_random_ranges(self, ranges) -> int:
+        """ranges: [(contig handle, first read index, pairs)] in file order, contigs of one group"""
+        n = C.c_uint64(0)
+        self._chk(self.lib.dwgsim_hip_count_random_ranges(self.h, self._ranges(ranges), len(ranges), C.byref(n)))
+        return n.value
+
+    def simulate_ranges_async(self, ranges, rand_base: int = RAND_CHAIN, slot: int = 0):
+        self._chk(self.lib.dwgsim_hip_simulate_ranges_async(self.h, self._ranges(ranges), len(ranges), rand_base, slot))
+
+    def simulate_ranges(self, ranges, rand_base: int, slot: int = 0) -> Batch:
+        self.simulate_ranges_async(ranges, rand_base, slot)
+        return self.wait(slot)
+
     def set_regions(self, path: str, contigs) -> int:
         n = len(contigs)
         names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
@@ -375,12 +426,55 @@ def shard_range(n_pairs: int, rank: int, world: int, lib=None):
     return first.value, n.value
 
 
-def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None, debug_options=None) -> JobResult:
-    """dwgsim_core (dwgsim.c:419-1121) over the C-ABI: header pass, then per contig
-    schedule -> mutate -> mutations text -> simulate in read-index batches."""
+def schedule_contigs(params: Params, contigs, ctx, lib=None):
+    """The scheduling half of dwgsim_core's contig loop (dwgsim.c:519-625): which contigs are simulated, with how many pairs and which
+    placement length.  Yields (contig ordinal, name, array, n_pairs, l_eff)."""
+    lib = lib or load()
+    tot_len = sum(len(a) for _, a in contigs)
+    want_reads = params.output_type != 2
+    have_regions = bool(getattr(params, "_regions", None))
+    if have_regions:
+        tot_len = ctx.set_regions(params._regions, contigs)          # dwgsim.c:499-506
+    n_sim = 0
+    n_ref = len(contigs)
+    for ci, (name, arr) in enumerate(contigs):
+        n_ref -= 1
+        n_pairs = 0
+        l_eff = len(arr)
+        if want_reads:
+            last_takes_rest = n_ref == 0 and params.C < 0               # dwgsim.c:535-537: no region bookkeeping on this path
+            if have_regions and not last_takes_rest:
+                l_eff = ctx.region_length(ci, arr)                      # dwgsim.c:539-581
+                if l_eff < 0:
+                    continue                                            # skip #0 / #1
+            n_pairs = pairs_for_contig(params, l_eff, tot_len, n_ref == 0, n_sim, lib)
+            if n_pairs < 0:
+                continue                      # skip rules #2-#5: no mutations either (dwgsim.c:596-623)
+        n_sim += n_pairs
+        yield ci, name, arr, n_pairs, l_eff
+
+
+def split_ranges(ranges, batch_pairs):
+    """[(contig, first, n)] in file order -> batches of at most batch_pairs pairs (a batch may hold several ranges and end inside a contig)"""
+    batch, room = [], batch_pairs
+    for cid, first, n in ranges:
+        while n > 0:
+            take = min(n, room)
+            batch.append((cid, first, take))
+            first += take; n -= take; room -= take
+            if room == 0:
+                yield batch
+                batch, room = [], batch_pairs
+    if batch:
+        yield batch
+
+
+def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None, debug_options=None, group_bp: int = 0) -> JobResult:
+    """dwgsim_core (dwgsim.c:419-1121) over the C-ABI: header pass, then schedule -> mutate -> mutations text -> simulate in
+    read-index batches.  group_bp = 0: contig after contig, as the reference walks them.  group_bp > 0: consecutive contigs are resident
+    together in groups of up to group_bp bases (dwgsim_hip_add_contigs): one walk per group, batches that run across contig boundaries."""
     lib = lib or load()
     res = JobResult(streams={0: bytearray(), 1: bytearray(), 2: bytearray()})
-    tot_len = sum(len(a) for _, a in contigs)
     want_mut = params.output_type != 1
     want_reads = params.output_type != 2
     vcf = bytearray()
@@ -392,40 +486,34 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
         vcf += VCF_HEADER_POST
     n_sim = 0
     rand_ii = 0
-    n_ref = len(contigs)
     with Context(params, device, lib) as ctx:
         for k, v in (debug_options or {}).items():
             ctx.debug_option(k, v)
         if getattr(params, "_mut_input", None):
             ctx.set_mutation_input(params._mut_input[0], params._mut_input[1], contigs)
         have_regions = bool(getattr(params, "_regions", None))
-        if have_regions:
-            tot_len = ctx.set_regions(params._regions, contigs)          # dwgsim.c:499-506
-        for ci, (name, arr) in enumerate(contigs):
-            n_ref -= 1
-            n_pairs = 0
-            l_eff = len(arr)
-            if want_reads:
-                last_takes_rest = n_ref == 0 and params.C < 0               # dwgsim.c:535-537: no region bookkeeping on this path
-                if have_regions and not last_takes_rest:
-                    l_eff = ctx.region_length(ci, arr)                      # dwgsim.c:539-581
-                    if l_eff < 0:
-                        continue                                            # skip #0 / #1
-                n_pairs = pairs_for_contig(params, l_eff, tot_len, n_ref == 0, n_sim, lib)
-                if n_pairs < 0:
-                    continue                      # skip rules #2-#5: no mutations either (dwgsim.c:596-623)
-            cid = ctx.add_contig(name, arr, ci)
+        sched = list(schedule_contigs(params, contigs, ctx, lib))
+        groups, cur, cur_bp = [], [], 0
+        for ent in sched:
+            if cur and (group_bp <= 0 or cur_bp + len(ent[2]) > group_bp):
+                groups.append(cur); cur, cur_bp = [], 0
+            cur.append(ent); cur_bp += len(ent[2])
+        if cur:
+            groups.append(cur)
+        for grp in groups:
+            h0 = ctx.add_contigs([(name, arr) for _, name, arr, _, _ in grp], indices=[ci for ci, _, _, _, _ in grp])
             if have_regions:
-                ctx.set_placement_length(cid, l_eff)
-            ctx.mutate(cid)
+                for k, ent in enumerate(grp):
+                    ctx.set_placement_length(h0 + k, ent[4])
+            ctx.mutate(h0)
             if want_mut:
-                t, v = ctx.mutations_text(cid)
-                txt += t
-                vcf += v
-            first = 0
-            while want_reads and first < n_pairs:
-                n = min(batch_pairs, n_pairs - first)
-                b = ctx.simulate(cid, first, n, rand_ii, 0)
+                for k in range(len(grp)):
+                    t, v = ctx.mutations_text(h0 + k)
+                    txt += t
+                    vcf += v
+            ranges = [(h0 + k, 0, ent[3]) for k, ent in enumerate(grp) if want_reads and ent[3] > 0]
+            for batch in split_ranges(ranges, batch_pairs):
+                b = ctx.simulate_ranges(batch, rand_ii, 0)
                 res.kernel_ms += b.kernel_ms
                 res.sim_kernel_ms += b.sim_kernel_ms
                 res.n_retries += b.n_retries
@@ -434,9 +522,8 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
                         if b.bytes[s]:
                             res.streams[s] += ctx.fetch(0, s, b.bytes[s])
                 rand_ii += b.n_random
-                first += n
-                n_sim += n
-            ctx.drop_contig(cid)
+                n_sim += b.n_pairs
+            ctx.drop_contig(h0)
     res.n_pairs = n_sim
     res.n_random = rand_ii
     res.mutations_txt = bytes(txt)

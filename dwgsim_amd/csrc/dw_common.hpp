@@ -62,6 +62,26 @@ DW_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
+// a value that is the same in every lane of the wave, moved to a scalar register (what depends on it -- table lookups, loop bounds -- stays scalar)
+DW_DEV uint32_t uniform_u32(uint32_t v)
+{
+#ifndef DW_EMU
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+
+// A pointer into memory that nothing writes while the kernel runs (tables the host uploaded before the launch), in the constant address space:
+// loads through it at a wave-uniform address are SCALAR loads (s_load), their results live in scalar registers.  Through a plain global pointer
+// the compiler must assume that the kernel's own stores and atomics could have clobbered the table and falls back to vector loads.
+#ifndef DW_EMU
+#define DW_CONST_AS __attribute__((address_space(4)))
+#else
+#define DW_CONST_AS
+#endif
+template <class T> DW_DEV const DW_CONST_AS T *as_constant(const T *p) { return (const DW_CONST_AS T *)p; }
+
 // byte-wise table lookup: byte i of the result = byte sel.byte[i] (0..7) of the eight-byte table {hi, lo}; one v_perm_b32
 DW_DEV uint32_t lut8(uint32_t hi, uint32_t lo, uint32_t sel)
 {
@@ -82,12 +102,15 @@ DW_DEV uint32_t spread4(uint32_t v)
     return (v | (v << 4)) & 0x0F0F0F0Fu;
 }
 
+// UNIFORM_KEY: the key is the same in every lane of the wave (scalar registers); the read kernels' keys are, the walk kernels' per-candidate keys
+// (a contig of a group per thread) are not
+template <bool UNIFORM_KEY = true>
 DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
 #ifndef DW_EMU
-        asm volatile("" : "+s"(k0), "+s"(k1));      // keep the round keys out of 20 hoisted SGPRs: two SALU adds per round instead
+        if (UNIFORM_KEY) asm volatile("" : "+s"(k0), "+s"(k1));      // keep the round keys out of 20 hoisted SGPRs: two SALU adds per round instead
 #endif
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -101,9 +124,10 @@ DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 
 struct RngKey { uint32_t seed, contig; };
 
+template <bool UNIFORM_KEY = true>
 DW_DEV U4 rng_block(RngKey k, uint32_t dom, uint64_t idx, uint32_t att, uint32_t retry, uint32_t block)
 {
-    return philox4x32_10((uint32_t)idx, (uint32_t)((idx >> 32) & 0xFFFFu) | (retry << 16), (dom << 24) | (att & 0xFFFFFFu), block, k.seed, k.contig);
+    return philox4x32_10<UNIFORM_KEY>((uint32_t)idx, (uint32_t)((idx >> 32) & 0xFFFFu) | (retry << 16), (dom << 24) | (att & 0xFFFFFFu), block, k.seed, k.contig);
 }
 
 DW_DEV double u53(uint32_t hi, uint32_t lo)
@@ -113,9 +137,10 @@ DW_DEV double u53(uint32_t hi, uint32_t lo)
 DW_DEV double u_lo(const U4 &b) { return u53(b.x, b.y); }   // even slot of the block
 DW_DEV double u_hi(const U4 &b) { return u53(b.z, b.w); }   // odd slot of the block
 
+template <bool UNIFORM_KEY = true>
 DW_DEV double rng_slot(RngKey k, uint32_t dom, uint64_t idx, uint32_t att, uint32_t slot)
 {
-    const U4 b = rng_block(k, dom, idx, att, 0, slot >> 1);
+    const U4 b = rng_block<UNIFORM_KEY>(k, dom, idx, att, 0, slot >> 1);
     return (slot & 1) ? u_hi(b) : u_lo(b);
 }
 

@@ -52,8 +52,17 @@ DW_DEV void block_excl_scan_n(const uint32_t (&v)[N], uint32_t (*sm)[16], uint32
 
 DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
 {
+    pos += h.pos_off;                      // the table holds group coordinates
     uint32_t lo = 0, hi = h.n_ins;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)h.ins_pos[mid] < pos) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// which contig of the group holds group coordinate g (the last k with start[k] <= g; a position in the padding behind a contig belongs to it)
+DW_DEV uint32_t seg_of(const SegTab &t, int64_t g)
+{
+    uint32_t lo = 0, hi = (uint32_t)t.n;   // invariant: start[lo] <= g < start[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)t.start[mid] <= g) lo = mid; else hi = mid; }
     return lo;
 }
 

@@ -6,6 +6,12 @@
 //   * device residency of contigs and mutated haplotypes (replaces seq_t / mutseq_t, mut.h:12-47)
 //   * mutations.txt / .vcf text from the sparse list of mutated cells (mut.c:781-893)
 // There is no CPU implementation of the hot path here: without a HIP device create() fails.
+//
+// Contigs are resident in GROUPS: the contigs of one dwgsim_hip_add_contigs call share one coordinate space (contig k at a multiple of
+// GROUP_ALIGN cells, unmutated N between them), one chain of walk kernels mutates all of them, and one k_simulate launch can cover read-index
+// ranges of several of them -- so a job of thousands of small contigs (the reference's contig loop, dwgsim.c:519-625, has no fixed cost per
+// contig) pays the walk chain, the launches and the host synchronisations once per group instead of once per contig.  A group of one contig
+// is the plain case.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -25,24 +31,43 @@ using namespace dw;
 
 namespace {
 
-struct Contig {
+struct HostIns { std::vector<int32_t> pos; std::vector<uint32_t> len, off; std::vector<uint8_t> bases; };
+
+struct Member {                      // one contig of a group
     std::string name;
-    std::vector<uint8_t> ascii;        // host copy (reference bases for the txt/vcf writer)
-    int64_t l = 0;
-    uint32_t contig_index = 0;
-    bool alive = false, mutated = false;
+    int64_t l = 0, l_place = 0;      // length; fragment-placement length (region length with -x)
+    uint32_t contig_index = 0;       // ordinal in the FASTA (RNG key)
+    int32_t start = 0;               // first cell in the group's coordinate space
+    int32_t reg_off = 0, n_reg = 0;  // -x: [starts | ends] of this contig in the group's region pool
+    uint32_t name_off = 0; int32_t name_fixed_len = 0;      // "@[prefix_]name" in the group's name pool
+    ResolvedContig rc;               // -m / -b / -v: the file's entries for this contig, resolved when the contig was added
+};
+
+struct Group {
+    bool alive = false, mutated = false, walk_pending = false;
+    int first_handle = -1;
+    std::vector<Member> m;
+    int64_t total = 0;               // cells of the coordinate space (a multiple of 16; allocations add CELL_PAD)
     uint8_t *d_ref = nullptr, *d_cells[2] = {nullptr, nullptr}, *d_view[2] = {nullptr, nullptr};      // reference codes, byte cells, 4-bit read views
     int32_t *d_ins_pos[2] = {nullptr, nullptr};
     uint32_t *d_ins_len[2] = {nullptr, nullptr}, *d_ins_off[2] = {nullptr, nullptr};
     uint8_t *d_ins_bases[2] = {nullptr, nullptr};
     uint32_t n_ins[2] = {0, 0}, n_ins_bases[2] = {0, 0};
     size_t cap_ins[2] = {0, 0}, cap_bases[2] = {0, 0};
-    uint8_t *d_name_fixed = nullptr; int32_t name_fixed_len = 0;
+    uint8_t *d_names = nullptr; int32_t *d_reg = nullptr; int32_t *d_seg = nullptr;      // name pool, region pool, segment table (start[n + 1] | len[n] | cindex[n])
+    std::vector<uint8_t> h_names; std::vector<int32_t> h_reg, h_seg;                     // their host sources (alive while asynchronous copies may read them)
+    int fixed_max = 0;               // longest "[prefix_]name"
     uint32_t n_cand = 0;
     uint16_t *d_summ[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries for count_random (built on demand)
-    int64_t l_place = 0;                // fragment-placement length (region length with -x)
-    int32_t *d_reg = nullptr; int32_t n_reg = 0;   // -x: [start[0..n), end[0..n)] of this contig
+    // a walk that was enqueued and not yet waited for
+    int walk_attempt = 0; uint32_t walk_cap = 0; size_t walk_cap_bases = 0; bool walk_reset = false;
+    uint32_t n_patch = 0, n_patch_ev = 0;       // file-driven mutations: patched cells / indel events
+    hipEvent_t ev_walk = nullptr;
+    // the mutated cells of the finished walk, fetched once for mutations_text
+    bool list_valid = false; std::vector<int32_t> pos; std::vector<uint32_t> cells; HostIns ins[2];
 };
+
+struct HandleRef { int group = -1, k = 0; };
 
 struct DevBuf {                     // grow-only device buffer
     void *p = nullptr; size_t cap = 0;
@@ -52,10 +77,12 @@ constexpr int N_COUNTERS = 32;      // u64 words of a counter block (SimArgs::co
 
 struct Slot {                       // one of the two batches a context can have in flight
     uint64_t *d_counters = nullptr, *h_counters = nullptr;      // device block + pinned mirror
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_fetched = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr, ev_done = nullptr, ev_fetched = nullptr;
     bool pending = false, empty = true, fetch_in_flight = false;
+    int group = -1;                 // the group the batch in flight reads
     uint64_t n_pairs = 0, out_bytes[3] = {0, 0, 0}, gz_bytes[3] = {0, 0, 0};
-    DevBuf gz_out[3], gz_status;        // GPU gzip: the members of each stream, look-back words
+    DevBuf gz_out[3], gz_status, segs;        // GPU gzip: the members of each stream, look-back words; the range table of the launch
+    SimSeg *h_segs = nullptr; size_t h_segs_cap = 0;      // ... and its page-locked source
 };
 
 } // namespace
@@ -66,25 +93,31 @@ struct dwgsim_hip_ctx {
     std::vector<uint8_t> flow;            // Ion Torrent flow order as base codes
     uint8_t *d_flow = nullptr;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // simulate: kernels of the batches
+    hipStream_t copy_stream = nullptr;       // device -> host copies of finished text
+    hipStream_t walk_stream = nullptr;       // uploads, the mutation walk, the mutated-cell list: a group can be prepared while another one is being simulated
     std::string err;
     double e_by[2] = {0, 0};
     uint64_t *d_thr[2] = {nullptr, nullptr};
     uint32_t *d_thr32[2] = {nullptr, nullptr}; int e_full = 0;
     uint32_t *d_qbase[2] = {nullptr, nullptr}; int32_t qb_words = 1;
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
-    std::vector<Contig> contigs;
+    std::vector<Group> groups;
+    std::vector<HandleRef> handles;          // contig handle -> (group, member); handles are never reused
     // simulate() working set
-    DevBuf meta, fail_summ, block_rand, status_all, out[2][3], scratch_mask, scratch_cnt;
-    DevBuf w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound;     // mutation-walk scratch (grow-only)
+    DevBuf meta, fail_summ, block_rand, status_all, out[2][3], place_segs;
+    // walk-stream working set (grow-only)
+    DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells;
+    uint8_t *h_up = nullptr; size_t h_up_cap = 0; hipEvent_t ev_up = nullptr; bool up_in_flight = false;      // page-locked staging of a group's sequence
+    SimSeg *h_place_segs = nullptr; size_t h_place_segs_cap = 0;
+    std::vector<int32_t> h_ppos; std::vector<uint16_t> h_pcells; std::vector<Event> h_pev;      // file-driven mutations of the group being walked
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
-    DevBuf w_ppos, w_pcells, flow_scratch;
-    uint64_t *d_counters = nullptr;          // N_COUNTERS x u64: walk / calibrate / count_random (synchronous calls)
-    uint64_t *h_counters = nullptr;          // pinned mirror
+    DevBuf flow_scratch;
+    uint64_t *d_counters = nullptr, *h_counters = nullptr;          // N_COUNTERS x u64 + pinned mirror: calibrate / count_random / debug hooks (compute stream)
+    uint64_t *d_wcounters = nullptr, *h_wcounters = nullptr;        // 16 x u64 + pinned mirror: the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
     Slot slot[2];                            // simulate(): two batches in flight (kernels of one overlap the copy-out of the other)
-    hipStream_t copy_stream = nullptr;       // device -> host copies of finished text
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
@@ -138,25 +171,54 @@ WalkParams walk_params(const dwgsim_hip_ctx *c)
     return w;
 }
 
-ContigDev contig_dev(const Contig &k)
+size_t padded_cells(const Group &g) { return (size_t)g.total + CELL_PAD; }
+
+SegTab seg_tab(const Group &g)
+{
+    const int n = (int)g.m.size();
+    SegTab t; t.start = g.d_seg; t.len = g.d_seg + (n + 1); t.cindex = reinterpret_cast<const uint32_t *>(g.d_seg + (2 * n + 1)); t.n = n;
+    return t;
+}
+
+void fill_haps(const Group &g, HapDev (&hap)[2])
+{
+    for (int h = 0; h < 2; ++h) {
+        hap[h].cells = g.d_cells[h]; hap[h].view = g.d_view[h]; hap[h].ins_pos = g.d_ins_pos[h]; hap[h].ins_len = g.d_ins_len[h];
+        hap[h].ins_off = g.d_ins_off[h]; hap[h].ins_bases = g.d_ins_bases[h]; hap[h].n_ins = g.n_ins[h]; hap[h].pos_off = 0;
+    }
+}
+
+ContigDev group_dev(const Group &g)
 {
     ContigDev d;
-    for (int h = 0; h < 2; ++h) {
-        d.hap[h].cells = k.d_cells[h]; d.hap[h].view = k.d_view[h]; d.hap[h].ins_pos = k.d_ins_pos[h]; d.hap[h].ins_len = k.d_ins_len[h];
-        d.hap[h].ins_off = k.d_ins_off[h]; d.hap[h].ins_bases = k.d_ins_bases[h]; d.hap[h].n_ins = k.n_ins[h];
-    }
-    d.ref = k.d_ref; d.l = k.l; d.contig_index = k.contig_index;
+    fill_haps(g, d.hap);
+    d.ref = g.d_ref; d.l = g.total; d.seg = seg_tab(g);
     d.tot4 = nullptr; d.cap_bases[0] = d.cap_bases[1] = 0;
     return d;
 }
 
-void free_contig(Contig &k)
+void free_group(Group &g)
 {
-    hipFree(k.d_ref);
-    for (int h = 0; h < 2; ++h) { hipFree(k.d_cells[h]); hipFree(k.d_view[h]); hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]); hipFree(k.d_ins_bases[h]); }
-    hipFree(k.d_name_fixed); hipFree(k.d_reg); hipFree(k.d_summ[0]); hipFree(k.d_summ[1]);
-    k = Contig();
+    hipFree(g.d_ref);
+    for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]); hipFree(g.d_ins_bases[h]); hipFree(g.d_summ[h]); }
+    hipFree(g.d_names); hipFree(g.d_reg); hipFree(g.d_seg);
+    if (g.ev_walk) hipEventDestroy(g.ev_walk);
+    g = Group();
 }
+
+// contig handle -> its group and member (nullptr + error text for a handle that is unknown or was dropped)
+Group *get_group(dwgsim_hip_ctx_t *c, int contig, int *k = nullptr)
+{
+    if (!c) return nullptr;
+    if (contig < 0 || (size_t)contig >= c->handles.size() || c->handles[(size_t)contig].group < 0) { c->err = "unknown contig handle"; return nullptr; }
+    const HandleRef r = c->handles[(size_t)contig];
+    Group &g = c->groups[(size_t)r.group];
+    if (!g.alive) { c->err = "unknown contig handle"; return nullptr; }
+    if (k) *k = r.k;
+    return &g;
+}
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 } // namespace
 
@@ -231,6 +293,13 @@ int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t
     return DWGSIM_HIP_ABI_VERSION;
 }
 
+int dwgsim_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 int dwgsim_hip_failseg_join(uint64_t acc[4], const uint64_t next[4])      // the same monoid as failseg_join in dw_simulate.hip
 {
     const uint64_t aP = acc[0], aS = acc[1], aR = acc[2], aB = acc[3], bP = next[0], bS = next[1], bR = next[2], bB = next[3];
@@ -250,6 +319,18 @@ void dwgsim_hip_shard_range(uint64_t n_pairs, int rank, int world, uint64_t *fir
     if (n) *n = base + (r < rem ? 1 : 0);
 }
 
+int64_t dwgsim_hip_group_layout(const int64_t *lens, int n, int64_t *starts)
+{
+    int64_t at = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!lens || lens[k] < 0) return -1;
+        at = align_up(at, GROUP_ALIGN);
+        if (starts) starts[k] = at;
+        at += lens[k];
+    }
+    return align_up(at, 16);
+}
+
 // Ion Torrent: room for a read after the flow model.  Every empty flow (about three per base) inserts Geometric(e) bases, inserted bases
 // are examined again: the mean growth is ~3 e / (1 - e) per base; four times that plus slack keeps overflow (reported as an error, never
 // written out of bounds) out of reach for realistic error rates and far away even for e = 0.3.
@@ -267,7 +348,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     int rc = dwgsim_hip_params_check(p, msg, sizeof msg);
     if (rc != DWGSIM_HIP_OK) { fprintf(stderr, "%s", msg); set_err(err, rc); return nullptr; }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev) {
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         fprintf(stderr, "dwgsim-hip: no usable HIP device (requested %d of %d); the hot path has no CPU fallback\n", device, ndev);
         set_err(err, DWGSIM_HIP_ERR_DEVICE); return nullptr;
     }
@@ -282,14 +363,18 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         HIPC(c, hipSetDevice(device));
         HIPC(c, hipStreamCreate(&c->stream));
         HIPC(c, hipStreamCreate(&c->copy_stream));
+        HIPC(c, hipStreamCreate(&c->walk_stream));
+        HIPC(c, hipEventCreate(&c->ev_up));
         HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
+        HIPC(c, hipMalloc((void **)&c->d_wcounters, 16 * sizeof(uint64_t)));
+        HIPC(c, hipHostMalloc((void **)&c->h_wcounters, 16 * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_chain, 4 * sizeof(uint64_t)));
         HIPC(c, hipMemset(c->d_chain, 0, 4 * sizeof(uint64_t)));
         for (Slot &sl : c->slot) {
             HIPC(c, hipMalloc((void **)&sl.d_counters, N_COUNTERS * sizeof(uint64_t)));
             HIPC(c, hipHostMalloc((void **)&sl.h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
-            HIPC(c, hipEventCreate(&sl.ev_k0)); HIPC(c, hipEventCreate(&sl.ev_k1)); HIPC(c, hipEventCreate(&sl.ev_done)); HIPC(c, hipEventCreate(&sl.ev_fetched));
+            HIPC(c, hipEventCreate(&sl.ev_k0)); HIPC(c, hipEventCreate(&sl.ev_k1)); HIPC(c, hipEventCreate(&sl.ev_end)); HIPC(c, hipEventCreate(&sl.ev_done)); HIPC(c, hipEventCreate(&sl.ev_fetched));
         }
         { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
           HIPC(c, hipMalloc((void **)&c->d_flow, 64)); HIPC(c, hipMemcpy(c->d_flow, fl.data(), 64, hipMemcpyHostToDevice)); }
@@ -357,7 +442,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             HIPC(c, hipMalloc((void **)&c->d_thr32[j], sizeof(uint32_t) * t32.size()));
             HIPC(c, hipMemcpy(c->d_thr32[j], t32.data(), sizeof(uint32_t) * t32.size(), hipMemcpyHostToDevice));
         }
-        // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 256 bytes in LDS)
+        // device copy: '@' + "[prefix_]rand", zero padded to >= 256 + 16 bytes (the kernel stages 128 bytes in LDS)
         std::string rf = c->read_prefix.empty() ? std::string("rand") : c->read_prefix + "_rand";
         c->rand_fixed_len = (int32_t)rf.size();
         std::string rbuf = "@" + rf; rbuf.resize(rbuf.size() < 256 ? 272 : rbuf.size() + 16, '\0');
@@ -413,89 +498,155 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
-    for (auto &k : c->contigs) if (k.alive) free_contig(k);
+    if (c->walk_stream) hipStreamSynchronize(c->walk_stream);
+    for (auto &g : c->groups) if (g.alive) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
-    hipFree(c->status_all.p);
-    hipFree(c->w_ppos.p); hipFree(c->w_pcells.p); hipFree(c->flow_scratch.p); hipFree(c->w_cand.p); hipFree(c->w_ev.p); hipFree(c->w_flags.p); hipFree(c->w_lo.p); hipFree(c->w_sufmin.p); hipFree(c->w_bound.p);
-    hipFree(c->d_rand_fixed); hipFree(c->meta.p); hipFree(c->fail_summ.p); hipFree(c->block_rand.p); hipFree(c->scratch_mask.p); hipFree(c->scratch_cnt.p);
+    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->place_segs, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
+                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch}) hipFree(b->p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
-    hipFree(c->d_counters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
+    hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->h_wcounters) hipHostFree(c->h_wcounters);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_up) hipHostFree(c->h_up);
+    if (c->h_place_segs) hipHostFree(c->h_place_segs);
+    if (c->ev_up) hipEventDestroy(c->ev_up);
     for (Slot &sl : c->slot) {
-        hipFree(sl.d_counters); hipFree(sl.gz_status.p);
+        hipFree(sl.d_counters); hipFree(sl.gz_status.p); hipFree(sl.segs.p);
         for (int t = 0; t < 3; ++t) hipFree(sl.gz_out[t].p);
         if (sl.h_counters) hipHostFree(sl.h_counters);
-        for (hipEvent_t e : {sl.ev_k0, sl.ev_k1, sl.ev_done, sl.ev_fetched}) if (e) hipEventDestroy(e);
+        if (sl.h_segs) hipHostFree(sl.h_segs);
+        for (hipEvent_t e : {sl.ev_k0, sl.ev_k1, sl.ev_end, sl.ev_done, sl.ev_fetched}) if (e) hipEventDestroy(e);
     }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->walk_stream) hipStreamDestroy(c->walk_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
 const char *dwgsim_hip_last_error(const dwgsim_hip_ctx_t *c) { return c ? c->err.c_str() : "no context"; }
 
-int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *ascii, int64_t len, uint32_t contig_index)
+static bool is_page_locked(const void *p)
 {
-    if (!c || !name || (!ascii && len > 0) || len < 0 || len > INT32_MAX) { if (c) c->err = "bad contig arguments"; return DWGSIM_HIP_ERR_ARG; }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return true;
+    (void)hipGetLastError();      // pageable memory: the query reports an error that must not stick
+    return false;
+}
+
+int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names, const uint8_t *const *ascii, const int64_t *lens, const uint32_t *contig_index)
+{
+    if (!c || n < 1 || !names || !ascii || !lens || !contig_index) { if (c) c->err = "bad contig arguments"; return DWGSIM_HIP_ERR_ARG; }
+    for (int k = 0; k < n; ++k) if (!names[k] || (!ascii[k] && lens[k] > 0) || lens[k] < 0 || lens[k] > INT32_MAX) { c->err = "bad contig arguments"; return DWGSIM_HIP_ERR_ARG; }
+    std::vector<int64_t> starts((size_t)n);
+    const int64_t total = dwgsim_hip_group_layout(lens, n, starts.data());
+    if (total < 0 || total > (int64_t)INT32_MAX - 2 * GROUP_ALIGN) { c->err = "dwgsim-hip: the contigs of one group must stay below 2^31 cells in all (add them in smaller groups)\n"; return DWGSIM_HIP_ERR_ARG; }
     HIPC(c, hipSetDevice(c->device));
-    int id = -1;
-    for (size_t i = 0; i < c->contigs.size(); ++i) if (!c->contigs[i].alive) { id = (int)i; break; }
-    if (id < 0) { c->contigs.emplace_back(); id = (int)c->contigs.size() - 1; }
-    Contig &k = c->contigs[(size_t)id];
-    k.name = name; k.l = len; k.contig_index = contig_index; k.ascii.assign(ascii, ascii + len); k.alive = true; k.mutated = false;
-    const size_t padded = (size_t)((len + 15) & ~(int64_t)15) + CELL_PAD;
-    uint8_t *d_ascii = nullptr;
+    int gid = -1;
+    for (size_t i = 0; i < c->groups.size(); ++i) if (!c->groups[i].alive) { gid = (int)i; break; }
+    if (gid < 0) { c->groups.emplace_back(); gid = (int)c->groups.size() - 1; }
+    Group &g = c->groups[(size_t)gid];
+    g = Group();
+    g.alive = true; g.total = total; g.first_handle = (int)c->handles.size();
+    g.m.resize((size_t)n);
+    for (int k = 0; k < n; ++k) { Member &m = g.m[(size_t)k]; m.name = names[k]; m.l = m.l_place = lens[k]; m.contig_index = contig_index[k]; m.start = (int32_t)starts[(size_t)k]; }
+    const size_t padded = padded_cells(g);
+    bool synced = true;
     auto fill = [&]() -> int {
-        HIPC(c, hipMalloc((void **)&d_ascii, padded));
-        HIPC(c, hipMalloc((void **)&k.d_ref, padded));
-        for (int h = 0; h < 2; ++h) { HIPC(c, hipMalloc((void **)&k.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&k.d_view[h], padded / 2 + 32)); }
-        HIPC(c, hipMemcpyAsync(d_ascii, ascii, (size_t)len, hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipMemsetAsync(k.d_ref, 4, padded, c->stream));
-        for (int h = 0; h < 2; ++h) HIPC(c, hipMemsetAsync(k.d_cells[h], 4, padded, c->stream));
-        if (len > 0) launch_pack(c->stream, d_ascii, k.d_ref, k.d_cells[0], k.d_cells[1], len);
-        HIPC(c, hipGetLastError());
-        k.l_place = len;
-        if (c->has_regions) {
-            std::vector<int32_t> st, en; int64_t tot = 0;
-            for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == contig_index) { st.push_back((int32_t)c->regions.start[q]); en.push_back((int32_t)c->regions.end[q]); tot += c->regions.end[q] - c->regions.start[q]; }
-            k.n_reg = (int32_t)st.size(); k.l_place = tot;
-            HIPC(c, hipMalloc((void **)&k.d_reg, sizeof(int32_t) * (2 * st.size() + 2)));
-            if (!st.empty()) {
-                HIPC(c, hipMemcpy(k.d_reg, st.data(), sizeof(int32_t) * st.size(), hipMemcpyHostToDevice));
-                HIPC(c, hipMemcpy(k.d_reg + st.size(), en.data(), sizeof(int32_t) * en.size(), hipMemcpyHostToDevice));
+        HIPC(c, hipEventCreate(&g.ev_walk));
+        HIPC(c, hipMalloc((void **)&g.d_ref, padded));
+        for (int h = 0; h < 2; ++h) { HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32)); }
+        if (ensure(c, c->up_ascii, padded)) return DWGSIM_HIP_ERR_DEVICE;
+        uint8_t *d_ascii = (uint8_t *)c->up_ascii.p;
+        // The sequence goes up on the walk stream.  One copy when the caller's buffers already are the group layout inside ONE page-locked
+        // allocation (ascii[k] = ascii[0] + start[k], zero bytes between the contigs): nothing is staged and the call does not wait -- the
+        // buffers must then stay as they are until dwgsim_hip_mutate_wait returned.  A few contigs: one copy each into a zeroed device buffer.
+        // Many: packed into page-locked staging first (one copy instead of thousands).
+        bool laid_out = true;
+        for (int k = 0; k < n && laid_out; ++k) if (lens[k] > 0 && ascii[k] != ascii[0] + starts[(size_t)k]) laid_out = false;
+        if (laid_out && n > 0 && ascii[0] && is_page_locked(ascii[0])) {
+            HIPC(c, hipMemcpyAsync(d_ascii, ascii[0], (size_t)total, hipMemcpyHostToDevice, c->walk_stream));
+            HIPC(c, hipMemsetAsync(d_ascii + total, 0, padded - (size_t)total, c->walk_stream));
+            synced = false;
+        } else if (n <= 8) {
+            HIPC(c, hipMemsetAsync(d_ascii, 0, padded, c->walk_stream));
+            for (int k = 0; k < n; ++k) if (lens[k] > 0) HIPC(c, hipMemcpyAsync(d_ascii + starts[(size_t)k], ascii[k], (size_t)lens[k], hipMemcpyHostToDevice, c->walk_stream));
+        } else {
+            if (c->up_in_flight) { HIPC(c, hipEventSynchronize(c->ev_up)); c->up_in_flight = false; }
+            if ((size_t)total > c->h_up_cap) {
+                if (c->h_up) HIPC(c, hipHostFree(c->h_up));
+                c->h_up = nullptr; c->h_up_cap = 0;
+                const size_t want = (size_t)total + (size_t)total / 4 + 4096;
+                HIPC(c, hipHostMalloc((void **)&c->h_up, want, hipHostMallocDefault));
+                c->h_up_cap = want;
             }
+            for (int k = 0; k < n; ++k) {
+                const int64_t end = starts[(size_t)k] + lens[k], next = k + 1 < n ? starts[(size_t)k + 1] : total;
+                if (lens[k] > 0) memcpy(c->h_up + starts[(size_t)k], ascii[k], (size_t)lens[k]);
+                memset(c->h_up + end, 0, (size_t)(next - end));
+            }
+            HIPC(c, hipMemcpyAsync(d_ascii, c->h_up, (size_t)total, hipMemcpyHostToDevice, c->walk_stream));
+            HIPC(c, hipMemsetAsync(d_ascii + total, 0, padded - (size_t)total, c->walk_stream));
+            HIPC(c, hipEventRecord(c->ev_up, c->walk_stream)); c->up_in_flight = true;
         }
-        std::string nf = c->read_prefix.empty() ? k.name : c->read_prefix + "_" + k.name;
-        k.name_fixed_len = (int32_t)nf.size();
-        std::string nbuf = "@" + nf; nbuf.resize(nbuf.size() < 256 ? 272 : nbuf.size() + 16, '\0');
-        HIPC(c, hipMalloc((void **)&k.d_name_fixed, nbuf.size()));
-        HIPC(c, hipMemcpyAsync(k.d_name_fixed, nbuf.data(), nbuf.size(), hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        launch_pack(c->walk_stream, d_ascii, g.d_ref, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15);
+        HIPC(c, hipGetLastError());
+        // segment table, name pool, target regions
+        g.h_seg.resize((size_t)(3 * n + 1));
+        for (int k = 0; k < n; ++k) { g.h_seg[(size_t)k] = g.m[(size_t)k].start; g.h_seg[(size_t)(n + 1 + k)] = (int32_t)g.m[(size_t)k].l; g.h_seg[(size_t)(2 * n + 1 + k)] = (int32_t)g.m[(size_t)k].contig_index; }
+        g.h_seg[(size_t)n] = (int32_t)total;
+        HIPC(c, hipMalloc((void **)&g.d_seg, sizeof(int32_t) * g.h_seg.size()));
+        HIPC(c, hipMemcpyAsync(g.d_seg, g.h_seg.data(), sizeof(int32_t) * g.h_seg.size(), hipMemcpyHostToDevice, c->walk_stream));
+        for (int k = 0; k < n; ++k) {      // '@' + "[prefix_]name", zero padded to >= 256 + 16 bytes (the kernel stages 128 bytes in LDS), entries 16-byte aligned
+            Member &m = g.m[(size_t)k];
+            const std::string nf = c->read_prefix.empty() ? m.name : c->read_prefix + "_" + m.name;
+            m.name_fixed_len = (int32_t)nf.size(); m.name_off = (uint32_t)g.h_names.size();
+            if (m.name_fixed_len > g.fixed_max) g.fixed_max = m.name_fixed_len;
+            const size_t room = ((nf.size() + 1 < 256 ? 272 : nf.size() + 1 + 16) + 15) & ~(size_t)15;
+            g.h_names.resize(g.h_names.size() + room, 0);
+            g.h_names[m.name_off] = '@'; memcpy(&g.h_names[m.name_off + 1], nf.data(), nf.size());
+        }
+        HIPC(c, hipMalloc((void **)&g.d_names, g.h_names.size()));
+        HIPC(c, hipMemcpyAsync(g.d_names, g.h_names.data(), g.h_names.size(), hipMemcpyHostToDevice, c->walk_stream));
+        if (c->has_regions) {
+            for (int k = 0; k < n; ++k) {
+                Member &m = g.m[(size_t)k];
+                std::vector<int32_t> st, en; int64_t tot = 0;
+                for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == m.contig_index) { st.push_back((int32_t)c->regions.start[q]); en.push_back((int32_t)c->regions.end[q]); tot += c->regions.end[q] - c->regions.start[q]; }
+                m.reg_off = (int32_t)g.h_reg.size(); m.n_reg = (int32_t)st.size(); m.l_place = tot;
+                g.h_reg.insert(g.h_reg.end(), st.begin(), st.end()); g.h_reg.insert(g.h_reg.end(), en.begin(), en.end());
+            }
+            g.h_reg.push_back(0);
+            HIPC(c, hipMalloc((void **)&g.d_reg, sizeof(int32_t) * g.h_reg.size()));
+            HIPC(c, hipMemcpyAsync(g.d_reg, g.h_reg.data(), sizeof(int32_t) * g.h_reg.size(), hipMemcpyHostToDevice, c->walk_stream));
+        }
+        // -m / -b / -v: the file's entries for these contigs are resolved now, while the sequence is at hand (mut.c:644-745)
+        if (c->has_mutin) for (int k = 0; k < n; ++k) resolve_mutation_input(c->mutin, g.m[(size_t)k].contig_index, ascii[k], lens[k], (uint32_t)c->prm.seed, c->prm.is_hap != 0, g.m[(size_t)k].rc);
+        if (synced) HIPC(c, hipStreamSynchronize(c->walk_stream));
         return 0;
     };
     const int rc = fill();
-    (void)hipFree(d_ascii);
-    if (rc != 0) { (void)hipStreamSynchronize(c->stream); free_contig(k); return rc; }      // no half-built contig stays behind a failed call
-    if (c->chain_contig == id) c->chain_contig = -1;      // a recycled handle does not continue its predecessor's failure counter
-    return id;
+    if (rc != 0) { (void)hipStreamSynchronize(c->walk_stream); free_group(g); return rc; }      // no half-built group stays behind a failed call
+    for (int k = 0; k < n; ++k) c->handles.push_back(HandleRef{gid, k});
+    return g.first_handle;
+}
+
+int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *c, const char *name, const uint8_t *ascii, int64_t len, uint32_t contig_index)
+{
+    return dwgsim_hip_add_contigs(c, 1, &name, &ascii, &len, &contig_index);
 }
 
 int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *c, int contig)
 {
-    if (!c || contig < 0 || (size_t)contig >= c->contigs.size() || !c->contigs[(size_t)contig].alive) return DWGSIM_HIP_ERR_ARG;
+    Group *g = get_group(c, contig);
+    if (!g) return DWGSIM_HIP_ERR_ARG;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->copy_stream);
-    free_contig(c->contigs[(size_t)contig]);
-    if (c->chain_contig == contig) c->chain_contig = -1;
+    hipStreamSynchronize(c->walk_stream);
+    for (size_t k = 0; k < g->m.size(); ++k) { if (c->chain_contig == g->first_handle + (int)k) c->chain_contig = -1; c->handles[(size_t)g->first_handle + k].group = -1; }
+    free_group(*g);
     return DWGSIM_HIP_OK;
-}
-
-static Contig *get_contig(dwgsim_hip_ctx_t *c, int contig)
-{
-    if (!c || contig < 0 || (size_t)contig >= c->contigs.size() || !c->contigs[(size_t)contig].alive) { if (c) c->err = "unknown contig handle"; return nullptr; }
-    return &c->contigs[(size_t)contig];
 }
 
 int dwgsim_hip_set_regions(dwgsim_hip_ctx_t *c, const char *path, const char *const *names, const int64_t *lens, int n_contigs, uint64_t *total_len)
@@ -530,9 +681,10 @@ int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *c, uint32_t contig_ind
 
 int dwgsim_hip_contig_set_placement_length(dwgsim_hip_ctx_t *c, int contig, int64_t l)
 {
-    Contig *kp = (c && contig >= 0 && (size_t)contig < c->contigs.size() && c->contigs[(size_t)contig].alive) ? &c->contigs[(size_t)contig] : nullptr;
-    if (!kp || l < 0) { if (c) c->err = "bad placement-length arguments"; return DWGSIM_HIP_ERR_ARG; }
-    kp->l_place = l;
+    int k = 0;
+    Group *g = get_group(c, contig, &k);
+    if (!g || l < 0) { if (c) c->err = "bad placement-length arguments"; return DWGSIM_HIP_ERR_ARG; }
+    g->m[(size_t)k].l_place = l;
     return DWGSIM_HIP_OK;
 }
 
@@ -547,167 +699,217 @@ int dwgsim_hip_set_mutation_input(dwgsim_hip_ctx_t *c, int type, const char *pat
     return DWGSIM_HIP_OK;
 }
 
-// mut_debug (mut.c:379-425): where the reference's asserts end the run (SIGABRT) the call returns DWGSIM_HIP_ERR_FAILED with the assert's text
-static int mut_debug_verdict(dwgsim_hip_ctx_t *c, const Contig &k, uint64_t v)
+// mut_debug (mut.c:379-425): where the reference's asserts end the run (SIGABRT) the call returns DWGSIM_HIP_ERR_FAILED with the assert's text.
+// The reference checks contig after contig, each before (mut.c:753) and after (:757) its justification: of the two verdicts of the group
+// (smallest failing position of each pass) the one in the earlier contig -- the pre-justification one on a tie -- is the one it would have hit.
+static int mut_debug_verdict(dwgsim_hip_ctx_t *c, const Group &g, uint64_t pre, uint64_t post)
 {
+    auto member_of = [&](uint64_t v) -> int { const int64_t p = (int64_t)(v >> 8); int k = 0; while (k + 1 < (int)g.m.size() && (int64_t)g.m[(size_t)k + 1].start <= p) ++k; return k; };
+    uint64_t v = ~0ull;
+    if (pre != ~0ull && post != ~0ull) v = member_of(post) < member_of(pre) ? post : pre;
+    else v = pre != ~0ull ? pre : post;
     if (v == ~0ull) return DWGSIM_HIP_OK;
     static const char *what[4] = {"", "(c[0]&0x3) != (c[1]&0x3)", "(c[1]&0x3) != (c[2]&0x3)", "(c[0]&0x3) == (c[1]&0x3) || (c[0]&0x3) == (c[2]&0x3)"};
-    char b[256]; snprintf(b, sizeof b, "dwgsim: src/mut.c: mut_debug: Assertion `%s' failed. [%s:%lld]\n", what[v & 3], k.name.c_str(), (long long)(v >> 8) + 1);
+    const Member &m = g.m[(size_t)member_of(v)];
+    char b[256]; snprintf(b, sizeof b, "dwgsim: src/mut.c: mut_debug: Assertion `%s' failed. [%s:%lld]\n", what[v & 3], m.name.c_str(), (long long)(v >> 8) - m.start + 1);
     c->err = b;
     return DWGSIM_HIP_ERR_FAILED;
 }
 
-int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
+// One attempt of the walk of a whole group, enqueued on the walk stream without any host read-back in between: buffers are sized for a
+// capacity (candidate sites are a Binomial(l, mut_rate) draw: mean + 8 sigma), the kernels take their element counts from device memory, and
+// the read-back at the end (dwgsim_hip_mutate_wait) also tells whether a capacity was exceeded -- then the walk is simply run again with
+// exact sizes.
+static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
 {
-    Contig *kp = get_contig(c, contig);
-    if (!kp) return DWGSIM_HIP_ERR_ARG;
-    Contig &k = *kp;
-    HIPC(c, hipSetDevice(c->device));
     const WalkParams wp = walk_params(c);
-    const int64_t l = k.l;
-    const bool again = k.mutated;      // walked before: the cells start again from the resident packed reference
-    if (again) for (int h = 0; h < 2; ++h) k.n_ins[h] = k.n_ins_bases[h] = 0;
-    if (again && c->has_mutin) {
-        const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
-        for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
-    }
-    k.mutated = true; k.n_cand = 0; k.summ_valid = false;
-    const size_t padded_cells = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
-    if (l == 0) return DWGSIM_HIP_OK;
-    if (c->has_mutin) {      // file-driven mutations (mut.c:644-745): host resolves the entries, the GPU scatters and left-justifies
-        ResolvedContig rc;
-        resolve_mutation_input(c->mutin, k.contig_index, k.ascii.data(), l, (uint32_t)c->prm.seed, c->prm.is_hap != 0, rc);
-        const uint32_t np = (uint32_t)rc.pos.size();
-        std::vector<Event> evs;
-        for (uint32_t q = 0; q < np; ++q) if (rc.cells[q] & 0x3030) { Event e; e.pos = rc.pos[q]; e.type = 4; e.hap = 3; e.base = 0; e.live = 1; e.len = 1; evs.push_back(e); }
-        const uint32_t nev = (uint32_t)evs.size();
-        k.n_cand = nev;
-        if (np == 0) {      // nothing listed for this contig: both haplotypes are the reference
-            launch_make_view(c->stream, k.d_cells[0], k.d_cells[1], (int64_t)padded_cells, k.d_view[0], k.d_view[1]);
-            HIPC(c, hipGetLastError()); HIPC(c, hipStreamSynchronize(c->stream));
-            return DWGSIM_HIP_OK;
-        }
-        if (ensure(c, c->w_ppos, sizeof(int32_t) * np) || ensure(c, c->w_pcells, sizeof(uint16_t) * np) || ensure(c, c->w_ev, sizeof(Event) * (nev ? nev : 1)) ||
-            ensure(c, c->w_lo, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_sufmin, sizeof(int32_t) * ((nev ? nev : 1) + 64)) || ensure(c, c->w_bound, nev ? nev : 1)) return DWGSIM_HIP_ERR_DEVICE;      // (+ 64: segment minima of k_sufmin)
-        HIPC(c, hipMemcpyAsync(c->w_ppos.p, rc.pos.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(c->w_pcells.p, rc.cells.data(), sizeof(uint16_t) * np, hipMemcpyHostToDevice, c->stream));
-        if (nev) HIPC(c, hipMemcpyAsync(c->w_ev.p, evs.data(), sizeof(Event) * nev, hipMemcpyHostToDevice, c->stream));
-        for (int h = 0; h < 2; ++h) {
-            const size_t n = rc.ins[h].size();
-            std::vector<int32_t> ip(n); std::vector<uint32_t> il(n), io(n); std::vector<uint8_t> ib;
-            for (size_t q = 0; q < n; ++q) { ip[q] = rc.ins[h][q].pos; il[q] = (uint32_t)rc.ins[h][q].bases.size(); io[q] = (uint32_t)ib.size(); ib.insert(ib.end(), rc.ins[h][q].bases.begin(), rc.ins[h][q].bases.end()); }
-            k.n_ins[h] = (uint32_t)n; k.n_ins_bases[h] = (uint32_t)ib.size();
-            const size_t nn = n ? n : 1, nb = ib.size() ? ib.size() : 1;
-            if (nn > k.cap_ins[h]) {
-                hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]);
-                k.cap_ins[h] = nn + nn / 4 + 64;
-                HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * k.cap_ins[h]));
-                HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * k.cap_ins[h]));
-                HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * k.cap_ins[h]));
+    const int64_t total = g.total;
+    const size_t padded = padded_cells(g);
+    hipStream_t st = c->walk_stream;
+    const SegTab seg = seg_tab(g);
+    if (c->has_mutin) {      // file-driven mutations (mut.c:644-745): the host resolved the entries, the GPU scatters and left-justifies
+        const uint32_t np = g.n_patch, nev = g.n_patch_ev;
+        if (g.walk_reset) for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(g.d_cells[h], g.d_ref, padded, hipMemcpyDeviceToDevice, st));
+        HIPC(c, hipMemsetAsync(&c->d_wcounters[12], 0xff, 2 * sizeof(uint64_t), st));
+        if (np) {
+            if (ensure(c, c->w_ppos, sizeof(int32_t) * np) || ensure(c, c->w_pcells, sizeof(uint16_t) * np) || ensure(c, c->w_ev, sizeof(Event) * (nev ? nev : 1)) ||
+                ensure(c, c->w_lo, sizeof(int32_t) * (nev ? nev : 1)) || ensure(c, c->w_sufmin, sizeof(int32_t) * ((nev ? nev : 1) + 64)) || ensure(c, c->w_bound, nev ? nev : 1)) return DWGSIM_HIP_ERR_DEVICE;      // (+ 64: segment minima of k_sufmin)
+            HIPC(c, hipMemcpyAsync(c->w_ppos.p, c->h_ppos.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, st));
+            HIPC(c, hipMemcpyAsync(c->w_pcells.p, c->h_pcells.data(), sizeof(uint16_t) * np, hipMemcpyHostToDevice, st));
+            if (nev) HIPC(c, hipMemcpyAsync(c->w_ev.p, c->h_pev.data(), sizeof(Event) * nev, hipMemcpyHostToDevice, st));
+            launch_apply_patches(st, (const int32_t *)c->w_ppos.p, (const uint16_t *)c->w_pcells.p, np, g.d_cells[0], g.d_cells[1]);
+            const ContigDev cd = group_dev(g);
+            launch_mut_debug(st, g.d_ref, g.d_cells[0], g.d_cells[1], total, &c->d_wcounters[12]);      // mut.c:753
+            if (nev) {
+                if (c->seq_justify) launch_justify_seq(st, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd);
+                else launch_justify(st, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
             }
-            if (nb > k.cap_bases[h]) { hipFree(k.d_ins_bases[h]); k.cap_bases[h] = nb + nb / 4 + 256; HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], k.cap_bases[h] + 16)); }
-            if (n) {
-                HIPC(c, hipMemcpy(k.d_ins_pos[h], ip.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-                HIPC(c, hipMemcpy(k.d_ins_len[h], il.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-                HIPC(c, hipMemcpy(k.d_ins_off[h], io.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
-                HIPC(c, hipMemcpy(k.d_ins_bases[h], ib.data(), ib.size(), hipMemcpyHostToDevice));
-            }
+            launch_mut_debug(st, g.d_ref, g.d_cells[0], g.d_cells[1], total, &c->d_wcounters[13]);      // mut.c:757
         }
-        launch_apply_patches(c->stream, (const int32_t *)c->w_ppos.p, (const uint16_t *)c->w_pcells.p, np, k.d_cells[0], k.d_cells[1]);
-        const ContigDev cd = contig_dev(k);
-        HIPC(c, hipMemsetAsync(&c->d_counters[12], 0xff, 2 * sizeof(uint64_t), c->stream));
-        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[12]);      // mut.c:753
-        if (nev) {
-            if (c->seq_justify) launch_justify_seq(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd);
-            else launch_justify(c->stream, (const Event *)c->w_ev.p, Count{nullptr, nev}, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
-        }
-        launch_mut_debug(c->stream, k.d_ref, k.d_cells[0], k.d_cells[1], l, &c->d_counters[13]);      // mut.c:757
-        launch_make_view(c->stream, k.d_cells[0], k.d_cells[1], (int64_t)padded_cells, k.d_view[0], k.d_view[1]);
+        launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.d_view[0], g.d_view[1]);
         HIPC(c, hipGetLastError());
-        HIPC(c, hipMemcpyAsync(&c->h_counters[12], &c->d_counters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
-        if (const int rc = mut_debug_verdict(c, k, c->h_counters[12])) return rc;
-        return mut_debug_verdict(c, k, c->h_counters[13]);
+        HIPC(c, hipMemcpyAsync(&c->h_wcounters[12], &c->d_wcounters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPC(c, hipEventRecord(g.ev_walk, st));
+        return DWGSIM_HIP_OK;
     }
-    const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
+    const uint32_t nblk = (uint32_t)((total + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
     if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
     uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
-    // The whole walk is enqueued without an intermediate host read-back: buffers are sized for a capacity (candidate sites are a
-    // Binomial(l, mut_rate) draw: mean + 8 sigma), the kernels take their element counts from device memory, and the one
-    // synchronisation at the end also tells whether a capacity was exceeded -- then the walk is simply run again with exact sizes.
-    const double mean = (double)l * c->prm.mut_rate;
-    uint32_t cap = (uint32_t)std::min<double>((double)l, mean + 8.0 * sqrt(mean + 1.0) + 256.0);
-    size_t cap_bases = (size_t)cap * 8 + 4096;
-    if (c->walk_cap >= 0) { cap = (uint32_t)c->walk_cap; cap_bases = 1; }      // dwgsim_hip_debug_option("walk_cap"): start too small, exercise the re-run
-    for (int attempt = 0; ; ++attempt) {
-        if (attempt > 0) {      // start again from the resident packed reference
-            const size_t padded = (size_t)((l + 15) & ~(int64_t)15) + CELL_PAD;
-            for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(k.d_cells[h], k.d_ref, padded, hipMemcpyDeviceToDevice, c->stream));
+    if (g.walk_attempt > 0)      // a capacity re-run starts again from the resident packed reference
+        for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(g.d_cells[h], g.d_ref, padded, hipMemcpyDeviceToDevice, st));
+    const uint32_t cap = g.walk_cap; const size_t cap_bases = g.walk_cap_bases;
+    const size_t ncap = cap ? cap : 1;
+    if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
+        ensure(c, c->w_flags, sizeof(uint4) * (ncap + 64)) ||      // (+ 64 rows / entries: the segment totals of k_scan4, the segment minima of k_sufmin)
+        ensure(c, c->w_lo, sizeof(int32_t) * ncap) || ensure(c, c->w_sufmin, sizeof(int32_t) * (ncap + 64)) ||
+        ensure(c, c->w_bound, ncap)) return DWGSIM_HIP_ERR_DEVICE;
+    for (int h = 0; h < 2; ++h) {      // insertion tables: at most one entry per candidate; the base pools are checked on the device
+        if (ncap > g.cap_ins[h]) {
+            hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]);
+            g.d_ins_pos[h] = nullptr; g.d_ins_len[h] = g.d_ins_off[h] = nullptr;
+            g.cap_ins[h] = ncap + ncap / 4 + 64;
+            HIPC(c, hipMalloc((void **)&g.d_ins_pos[h], sizeof(int32_t) * g.cap_ins[h]));
+            HIPC(c, hipMalloc((void **)&g.d_ins_len[h], sizeof(uint32_t) * g.cap_ins[h]));
+            HIPC(c, hipMalloc((void **)&g.d_ins_off[h], sizeof(uint32_t) * g.cap_ins[h]));
         }
-        const size_t ncap = cap ? cap : 1;
-        if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
-            ensure(c, c->w_flags, sizeof(uint4) * (ncap + 64)) ||      // (+ 64 rows / entries: the segment totals of k_scan4, the segment minima of k_sufmin)
-            ensure(c, c->w_lo, sizeof(int32_t) * ncap) || ensure(c, c->w_sufmin, sizeof(int32_t) * (ncap + 64)) ||
-            ensure(c, c->w_bound, ncap)) return DWGSIM_HIP_ERR_DEVICE;
-        for (int h = 0; h < 2; ++h) {      // insertion tables: at most one entry per candidate; the base pools are checked on the device
-            if (ncap > k.cap_ins[h]) {
-                hipFree(k.d_ins_pos[h]); hipFree(k.d_ins_len[h]); hipFree(k.d_ins_off[h]);
-                k.cap_ins[h] = ncap + ncap / 4 + 64;
-                HIPC(c, hipMalloc((void **)&k.d_ins_pos[h], sizeof(int32_t) * k.cap_ins[h]));
-                HIPC(c, hipMalloc((void **)&k.d_ins_len[h], sizeof(uint32_t) * k.cap_ins[h]));
-                HIPC(c, hipMalloc((void **)&k.d_ins_off[h], sizeof(uint32_t) * k.cap_ins[h]));
+        if (cap_bases > g.cap_bases[h]) {
+            hipFree(g.d_ins_bases[h]); g.d_ins_bases[h] = nullptr;
+            g.cap_bases[h] = cap_bases + cap_bases / 4 + 256;
+            HIPC(c, hipMalloc((void **)&g.d_ins_bases[h], g.cap_bases[h] + 16));
+        }
+    }
+    int32_t *d_cand = (int32_t *)c->w_cand.p; Event *d_ev = (Event *)c->w_ev.p; uint4 *d_flags = (uint4 *)c->w_flags.p;
+    uint32_t *d_small = reinterpret_cast<uint32_t *>(&c->d_wcounters[8]);   // [0] max_del, [1..4] tot4: eight words in counters[8..11], so that one copy brings counters[7..11] back
+    const Count nc{&c->d_wcounters[7], cap};
+    HIPC(c, hipMemsetAsync(&c->d_wcounters[7], 0, 5 * sizeof(uint64_t), st));
+    // K1: candidate sites -> ordered list
+    const bool reset = g.walk_reset && g.walk_attempt == 0;      // (a capacity re-run has just copied the cells back; a first walk finds them fresh from k_pack)
+    launch_site_scan(st, g.d_ref, total, seg, wp, d_mask, d_cnt, reset ? g.d_cells[0] : nullptr, reset ? g.d_cells[1] : nullptr);
+    launch_scan_excl(st, d_cnt, nblk, &c->d_wcounters[7]);
+    launch_compact(st, d_mask, d_cnt, d_cand, total, cap);
+    // K2: events, liveness, insertion-table allocation
+    launch_events(st, d_cand, nc, g.d_ref, seg, wp, d_ev, &d_small[0]);
+    launch_resolve(st, d_ev, nc, &d_small[0], d_flags, &d_small[1]);
+    // K3 + K4
+    ContigDev cd = group_dev(g);
+    cd.tot4 = &d_small[1]; cd.cap_bases[0] = (uint32_t)std::min<size_t>(g.cap_bases[0], 0xFFFFFFFFu); cd.cap_bases[1] = (uint32_t)std::min<size_t>(g.cap_bases[1], 0xFFFFFFFFu);
+    launch_apply(st, d_ev, nc, d_flags, cd, wp);
+    // mut_debug (mut.c:753, :757) cannot fire on randomly drawn mutations and is not run here: a substitution always changes the base
+    // ((c + 1..3) & 3, mut.c:621), a homozygous one writes the same cell to both haplotypes and a heterozygous one leaves the other
+    // haplotype's cell as it was -- the reference base, also under a deletion or an insertion, before and after left-justification
+    // (which only moves an indel over bases equal to its own).  File-driven mutations (-m / -b / -v, above) can violate all three.
+    if (c->seq_justify) launch_justify_seq(st, d_ev, nc, cd);
+    else launch_justify(st, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+    launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.d_view[0], g.d_view[1]);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(&c->h_wcounters[7], &c->d_wcounters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));      // [7] candidates, [8..11] the eight words
+    HIPC(c, hipEventRecord(g.ev_walk, st));
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_mutate_async(dwgsim_hip_ctx_t *c, int contig)
+{
+    Group *gp = get_group(c, contig);
+    if (!gp) return DWGSIM_HIP_ERR_ARG;
+    Group &g = *gp;
+    if (g.walk_pending) { c->err = "mutate: the group's previous walk was not waited for"; return DWGSIM_HIP_ERR_STATE; }
+    for (const Slot &sl : c->slot) if (sl.pending && sl.group == c->handles[(size_t)contig].group) { c->err = "mutate: a batch that reads this group is still in flight (wait for it first)"; return DWGSIM_HIP_ERR_STATE; }
+    HIPC(c, hipSetDevice(c->device));
+    g.walk_reset = g.mutated;      // walked before: the cells start again from the resident packed reference
+    for (int h = 0; h < 2; ++h) g.n_ins[h] = g.n_ins_bases[h] = 0;
+    g.mutated = true; g.n_cand = 0; g.summ_valid = false; g.list_valid = false;
+    g.walk_attempt = 0;
+    if (g.total == 0) return DWGSIM_HIP_OK;
+    if (c->has_mutin) {      // patches, indel events and insertion tables of the whole group, in group coordinates
+        c->h_ppos.clear(); c->h_pcells.clear(); c->h_pev.clear();
+        HostIns hi[2];
+        for (size_t k = 0; k < g.m.size(); ++k) {
+            const Member &m = g.m[k];
+            for (size_t q = 0; q < m.rc.pos.size(); ++q) {
+                c->h_ppos.push_back(m.rc.pos[q] + m.start); c->h_pcells.push_back(m.rc.cells[q]);
+                if (m.rc.cells[q] & 0x3030) { Event e; e.pos = m.rc.pos[q] + m.start; e.type = 4; e.hap = 3; e.base = 0; e.live = 1; e.len = 1; e.seg = (uint32_t)k; c->h_pev.push_back(e); }
             }
-            if (cap_bases > k.cap_bases[h]) {
-                hipFree(k.d_ins_bases[h]);
-                k.cap_bases[h] = cap_bases + cap_bases / 4 + 256;
-                HIPC(c, hipMalloc((void **)&k.d_ins_bases[h], k.cap_bases[h] + 16));
+            for (int h = 0; h < 2; ++h) for (const InsPayload &ip : m.rc.ins[h]) {
+                hi[h].pos.push_back(ip.pos + m.start); hi[h].len.push_back((uint32_t)ip.bases.size()); hi[h].off.push_back((uint32_t)hi[h].bases.size());
+                hi[h].bases.insert(hi[h].bases.end(), ip.bases.begin(), ip.bases.end());
             }
         }
-        int32_t *d_cand = (int32_t *)c->w_cand.p; Event *d_ev = (Event *)c->w_ev.p; uint4 *d_flags = (uint4 *)c->w_flags.p;
-        uint32_t *d_small = reinterpret_cast<uint32_t *>(&c->d_counters[8]);   // [0] max_del, [1..4] tot4: eight words in counters[8..11], so that one copy brings counters[7..11] back
-        const Count nc{&c->d_counters[7], cap};
-        HIPC(c, hipMemsetAsync(&c->d_counters[7], 0, 5 * sizeof(uint64_t), c->stream));
-        // K1: candidate sites -> ordered list
-        const bool reset = again && attempt == 0;      // (a capacity re-run has just copied the cells back; a first walk finds them fresh from k_pack)
-        launch_site_scan(c->stream, k.d_ref, l, wp, k.contig_index, d_mask, d_cnt, reset ? k.d_cells[0] : nullptr, reset ? k.d_cells[1] : nullptr);
-        launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
-        launch_compact(c->stream, d_mask, d_cnt, d_cand, l, cap);
-        // K2: events, liveness, insertion-table allocation
-        launch_events(c->stream, d_cand, nc, k.d_ref, l, wp, k.contig_index, d_ev, &d_small[0]);
-        launch_resolve(c->stream, d_ev, nc, &d_small[0], d_flags, &d_small[1]);
-        // K3 + K4
-        ContigDev cd = contig_dev(k);
-        cd.tot4 = &d_small[1]; cd.cap_bases[0] = (uint32_t)std::min<size_t>(k.cap_bases[0], 0xFFFFFFFFu); cd.cap_bases[1] = (uint32_t)std::min<size_t>(k.cap_bases[1], 0xFFFFFFFFu);
-        launch_apply(c->stream, d_ev, nc, d_flags, cd, wp);
-        // mut_debug (mut.c:753, :757) cannot fire on randomly drawn mutations and is not run here: a substitution always changes the base
-        // ((c + 1..3) & 3, mut.c:621), a homozygous one writes the same cell to both haplotypes and a heterozygous one leaves the other
-        // haplotype's cell as it was -- the reference base, also under a deletion or an insertion, before and after left-justification
-        // (which only moves an indel over bases equal to its own).  File-driven mutations (-m / -b / -v, above) can violate all three.
-        if (c->seq_justify) launch_justify_seq(c->stream, d_ev, nc, cd);
-        else launch_justify(c->stream, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
-        launch_make_view(c->stream, k.d_cells[0], k.d_cells[1], (int64_t)padded_cells, k.d_view[0], k.d_view[1]);
-        HIPC(c, hipGetLastError());
-        HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));      // [7] candidates, [8..11] the eight words
-        HIPC(c, hipStreamSynchronize(c->stream));
-        const uint64_t n_cand = c->h_counters[7];
-        const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&c->h_counters[8]);
-        const bool fits = n_cand <= cap && h_small[2] <= k.cap_bases[0] && h_small[4] <= k.cap_bases[1];
-        if (fits || attempt >= 2) {
+        g.n_patch = (uint32_t)c->h_ppos.size(); g.n_patch_ev = (uint32_t)c->h_pev.size();
+        g.n_cand = g.n_patch_ev;
+        HIPC(c, hipStreamSynchronize(c->walk_stream));      // (the tables below are copied from short-lived host vectors)
+        for (int h = 0; h < 2; ++h) {
+            const size_t n = hi[h].pos.size(), nb = hi[h].bases.size();
+            g.n_ins[h] = (uint32_t)n; g.n_ins_bases[h] = (uint32_t)nb;
+            const size_t nn = n ? n : 1, nbb = nb ? nb : 1;
+            if (nn > g.cap_ins[h]) {
+                hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]);
+                g.d_ins_pos[h] = nullptr; g.d_ins_len[h] = g.d_ins_off[h] = nullptr;
+                g.cap_ins[h] = nn + nn / 4 + 64;
+                HIPC(c, hipMalloc((void **)&g.d_ins_pos[h], sizeof(int32_t) * g.cap_ins[h]));
+                HIPC(c, hipMalloc((void **)&g.d_ins_len[h], sizeof(uint32_t) * g.cap_ins[h]));
+                HIPC(c, hipMalloc((void **)&g.d_ins_off[h], sizeof(uint32_t) * g.cap_ins[h]));
+            }
+            if (nbb > g.cap_bases[h]) { hipFree(g.d_ins_bases[h]); g.d_ins_bases[h] = nullptr; g.cap_bases[h] = nbb + nbb / 4 + 256; HIPC(c, hipMalloc((void **)&g.d_ins_bases[h], g.cap_bases[h] + 16)); }
+            if (n) {
+                HIPC(c, hipMemcpy(g.d_ins_pos[h], hi[h].pos.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(g.d_ins_len[h], hi[h].len.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(g.d_ins_off[h], hi[h].off.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+                HIPC(c, hipMemcpy(g.d_ins_bases[h], hi[h].bases.data(), nb, hipMemcpyHostToDevice));
+            }
+        }
+    } else {
+        double mean = 0;
+        for (const Member &m : g.m) mean += (double)m.l * c->prm.mut_rate;
+        g.walk_cap = (uint32_t)std::min<double>((double)g.total, mean + 8.0 * sqrt(mean + 1.0) + 256.0);
+        g.walk_cap_bases = (size_t)g.walk_cap * 8 + 4096;
+        if (c->walk_cap >= 0) { g.walk_cap = (uint32_t)c->walk_cap; g.walk_cap_bases = 1; }      // dwgsim_hip_debug_option("walk_cap"): start too small, exercise the re-run
+    }
+    if (const int rc = enqueue_walk(c, g)) return rc;
+    g.walk_pending = true;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *c, int contig)
+{
+    Group *gp = get_group(c, contig);
+    if (!gp) return DWGSIM_HIP_ERR_ARG;
+    Group &g = *gp;
+    if (!g.walk_pending) return g.mutated ? DWGSIM_HIP_OK : (c->err = "mutate_wait: no walk was enqueued for this group", DWGSIM_HIP_ERR_STATE);
+    HIPC(c, hipSetDevice(c->device));
+    for (;;) {
+        HIPC(c, hipEventSynchronize(g.ev_walk));
+        if (c->has_mutin) {
+            g.walk_pending = false;
+            return g.n_patch ? mut_debug_verdict(c, g, c->h_wcounters[12], c->h_wcounters[13]) : DWGSIM_HIP_OK;
+        }
+        const uint64_t n_cand = c->h_wcounters[7];
+        const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&c->h_wcounters[8]);
+        const bool fits = n_cand <= g.walk_cap && h_small[2] <= g.cap_bases[0] && h_small[4] <= g.cap_bases[1];
+        if (fits || g.walk_attempt >= 2) {
+            g.walk_pending = false;
             if (!fits) { c->err = "mutation walk: capacities still exceeded after an exact re-run"; return DWGSIM_HIP_ERR_FAILED; }
-            k.n_cand = (uint32_t)n_cand;
-            for (int h = 0; h < 2; ++h) { k.n_ins[h] = h_small[1 + 2 * h]; k.n_ins_bases[h] = h_small[2 + 2 * h]; }
+            g.n_cand = (uint32_t)n_cand;
+            for (int h = 0; h < 2; ++h) { g.n_ins[h] = h_small[1 + 2 * h]; g.n_ins_bases[h] = h_small[2 + 2 * h]; }
             return DWGSIM_HIP_OK;
         }
         // exact sizes (the counts read back are those of the complete candidate list unless it was truncated: take generous ones then)
-        cap = (uint32_t)std::min<uint64_t>((uint64_t)l, n_cand + 16);
-        cap_bases = std::max<size_t>(cap_bases, (size_t)std::max(h_small[2], h_small[4]) * 2 + (size_t)cap * 8 + 4096);
+        g.walk_cap = (uint32_t)std::min<uint64_t>((uint64_t)g.total, n_cand + 16);
+        g.walk_cap_bases = std::max<size_t>(g.walk_cap_bases, (size_t)std::max(h_small[2], h_small[4]) * 2 + (size_t)g.walk_cap * 8 + 4096);
+        ++g.walk_attempt;
+        if (const int rc = enqueue_walk(c, g)) { g.walk_pending = false; return rc; }
     }
+}
+
+int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
+{
+    const int rc = dwgsim_hip_mutate_async(c, contig);
+    if (rc != DWGSIM_HIP_OK) return rc;
+    return dwgsim_hip_mutate_wait(c, contig);
 }
 
 // ---- mutations.txt / mutations.vcf from the sparse list of mutated cells (mut.c:781-893) ----
 namespace {
-struct HostIns { std::vector<int32_t> pos; std::vector<uint32_t> len, off; std::vector<uint8_t> bases; };
 const char *ins_text(const HostIns &t, int32_t pos, std::string &tmp)
 {
     tmp.clear();
@@ -724,60 +926,74 @@ void appendf(std::string &s, const char *fmt, ...)
     if (n < (int)sizeof buf) { s.append(buf, (size_t)n); return; }
     std::vector<char> big((size_t)n + 1); va_start(ap, fmt); vsnprintf(big.data(), big.size(), fmt, ap); va_end(ap); s.append(big.data(), (size_t)n);
 }
+
+// the mutated cells of a walked group (positions in group coordinates, cells + reference codes) and its insertion tables, fetched once
+int fetch_mutated_list(dwgsim_hip_ctx_t *c, Group &g)
+{
+    if (g.list_valid) return DWGSIM_HIP_OK;
+    g.pos.clear(); g.cells.clear();
+    for (int h = 0; h < 2; ++h) g.ins[h] = HostIns();
+    hipStream_t st = c->walk_stream;
+    if (g.total > 0 && g.n_cand > 0) {
+        const uint32_t nblk = (uint32_t)((g.total + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
+        if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
+        if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
+        uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
+        launch_collect_mask(st, g.d_cells[0], g.d_cells[1], g.total, d_mask, d_cnt);
+        launch_scan_excl(st, d_cnt, nblk, &c->d_wcounters[14]);
+        HIPC(c, hipMemcpyAsync(&c->h_wcounters[14], &c->d_wcounters[14], sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPC(c, hipStreamSynchronize(st));
+        const uint32_t n = (uint32_t)c->h_wcounters[14];
+        if (n) {
+            if (ensure(c, c->l_pos, sizeof(int32_t) * (size_t)n) || ensure(c, c->l_cells, sizeof(uint32_t) * (size_t)n)) return DWGSIM_HIP_ERR_DEVICE;
+            launch_compact(st, d_mask, d_cnt, (int32_t *)c->l_pos.p, g.total, n);
+            launch_gather(st, (const int32_t *)c->l_pos.p, n, g.d_ref, g.d_cells[0], g.d_cells[1], (uint32_t *)c->l_cells.p);
+            g.pos.resize(n); g.cells.resize(n);
+            HIPC(c, hipMemcpyAsync(g.pos.data(), c->l_pos.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(g.cells.data(), c->l_cells.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        }
+        for (int h = 0; h < 2; ++h) if (g.n_ins[h]) {
+            g.ins[h].pos.resize(g.n_ins[h]); g.ins[h].len.resize(g.n_ins[h]); g.ins[h].off.resize(g.n_ins[h]); g.ins[h].bases.resize(g.n_ins_bases[h]);
+            HIPC(c, hipMemcpyAsync(g.ins[h].pos.data(), g.d_ins_pos[h], sizeof(int32_t) * g.n_ins[h], hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(g.ins[h].len.data(), g.d_ins_len[h], sizeof(uint32_t) * g.n_ins[h], hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(g.ins[h].off.data(), g.d_ins_off[h], sizeof(uint32_t) * g.n_ins[h], hipMemcpyDeviceToHost, st));
+            HIPC(c, hipMemcpyAsync(g.ins[h].bases.data(), g.d_ins_bases[h], g.n_ins_bases[h], hipMemcpyDeviceToHost, st));
+        }
+        HIPC(c, hipStreamSynchronize(st));
+    }
+    g.list_valid = true;
+    return DWGSIM_HIP_OK;
+}
 } // namespace
 
 int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt, size_t *txt_len, const char **vcf, size_t *vcf_len)
 {
-    Contig *kp = get_contig(c, contig);
-    if (!kp) return DWGSIM_HIP_ERR_ARG;
-    Contig &k = *kp;
-    if (!k.mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    int km = 0;
+    Group *gp = get_group(c, contig, &km);
+    if (!gp) return DWGSIM_HIP_ERR_ARG;
+    Group &g = *gp;
+    if (!g.mutated || g.walk_pending) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
     c->txt.clear(); c->vcf.clear();
-    const int64_t l = k.l;
-    std::vector<int32_t> pos; std::vector<uint16_t> cells;
-    HostIns ins[2];
-    if (l > 0 && k.n_cand > 0) {
-        const uint32_t nblk = (uint32_t)((l + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
-        if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
-        if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
-        uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
-        launch_collect_mask(c->stream, k.d_cells[0], k.d_cells[1], l, d_mask, d_cnt);
-        launch_scan_excl(c->stream, d_cnt, nblk, &c->d_counters[7]);
-        HIPC(c, hipMemcpyAsync(&c->h_counters[7], &c->d_counters[7], sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
-        const uint32_t n = (uint32_t)c->h_counters[7];
-        if (n) {
-            int32_t *d_pos = nullptr; uint16_t *d_cells = nullptr;
-            HIPC(c, hipMalloc((void **)&d_pos, sizeof(int32_t) * (size_t)n));
-            HIPC(c, hipMalloc((void **)&d_cells, sizeof(uint16_t) * (size_t)n));
-            launch_compact(c->stream, d_mask, d_cnt, d_pos, l, n);
-            launch_gather(c->stream, d_pos, n, k.d_cells[0], k.d_cells[1], d_cells);
-            pos.resize(n); cells.resize(n);
-            HIPC(c, hipMemcpyAsync(pos.data(), d_pos, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipMemcpyAsync(cells.data(), d_cells, sizeof(uint16_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-            HIPC(c, hipStreamSynchronize(c->stream));
-            HIPC(c, hipFree(d_pos)); HIPC(c, hipFree(d_cells));
-        }
-        for (int h = 0; h < 2; ++h) if (k.n_ins[h]) {
-            ins[h].pos.resize(k.n_ins[h]); ins[h].len.resize(k.n_ins[h]); ins[h].off.resize(k.n_ins[h]); ins[h].bases.resize(k.n_ins_bases[h]);
-            HIPC(c, hipMemcpy(ins[h].pos.data(), k.d_ins_pos[h], sizeof(int32_t) * k.n_ins[h], hipMemcpyDeviceToHost));
-            HIPC(c, hipMemcpy(ins[h].len.data(), k.d_ins_len[h], sizeof(uint32_t) * k.n_ins[h], hipMemcpyDeviceToHost));
-            HIPC(c, hipMemcpy(ins[h].off.data(), k.d_ins_off[h], sizeof(uint32_t) * k.n_ins[h], hipMemcpyDeviceToHost));
-            HIPC(c, hipMemcpy(ins[h].bases.data(), k.d_ins_bases[h], k.n_ins_bases[h], hipMemcpyDeviceToHost));
-        }
-    }
+    if (const int rc = fetch_mutated_list(c, g)) return rc;
+    const Member &m = g.m[(size_t)km];
+    const int64_t l = m.l, s0 = m.start;
+    // this contig's slice of the list, positions inside the contig
+    const size_t e0 = (size_t)(std::lower_bound(g.pos.begin(), g.pos.end(), (int32_t)s0) - g.pos.begin());
+    const size_t e1 = (size_t)(std::lower_bound(g.pos.begin(), g.pos.end(), (int32_t)(s0 + l)) - g.pos.begin());
     // sparse restatement of the per-position loop: only listed positions can print; "previous position
     // mutated" (mut_prev, mut.c:890-891) is "position i-1 is listed with a mutated cell on that haplotype"
     static const char B5[] = "ACGTN";       // B5[5] is the terminating NUL, as in the reference for code 5 ('-')
-    const char *nm = k.name.c_str();
+    const char *nm = m.name.c_str();
     std::string tmp;
-    auto cell = [&](size_t e, int h) -> uint8_t { return (uint8_t)(h ? cells[e] >> 8 : cells[e] & 0xff); };
-    for (size_t e = 0; e < pos.size(); ++e) {
-        const int64_t i = pos[e];
-        const uint8_t r0 = nt4(k.ascii[(size_t)i]), c1 = cell(e, 0), c2 = cell(e, 1);
+    auto cell = [&](size_t e, int h) -> uint8_t { return (uint8_t)(h ? g.cells[e] >> 8 : g.cells[e]); };
+    auto refc = [&](size_t e) -> uint8_t { return (uint8_t)(g.cells[e] >> 16); };          // nst_nt4_table code of the reference base
+    auto prevc = [&](size_t e) -> uint8_t { return (uint8_t)(g.cells[e] >> 24); };         // ... of the base in front of it
+    for (size_t e = e0; e < e1; ++e) {
+        const int64_t i = g.pos[e] - s0;
+        const uint8_t r0 = refc(e), c1 = cell(e, 0), c2 = cell(e, 1);
         if (r0 >= 4) continue;
-        const bool adj = e > 0 && pos[e - 1] == i - 1;
+        const bool adj = e > e0 && g.pos[e - 1] == g.pos[e] - 1;
         const bool prev0 = adj && (cell(e - 1, 0) & TMASK) != T_NONE, prev1 = adj && (cell(e - 1, 1) & TMASK) != T_NONE;
         appendf(c->txt, "%s\t%lld\t", nm, (long long)i + 1);
         const bool hom = (c1 & BTMASK) == (c2 & BTMASK);
@@ -797,25 +1013,25 @@ int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt,
             const bool open = hom ? (!prev0 || !prev1) : !(pl == 1 ? prev0 : prev1);
             if (open) {      // one VCF record for the run, anchored at the previous reference base (mut.c:801-815)
                 appendf(c->vcf, "%s\t%lld\t.\t", nm, (long long)i);
-                if (i > 0) c->vcf.push_back(B5[nt4(k.ascii[(size_t)i - 1])]);
+                if (i > 0) c->vcf.push_back(B5[prevc(e)]);
                 size_t ee = e; int64_t j = i;
                 for (;;) {
-                    c->vcf.push_back(B5[nt4(k.ascii[(size_t)j])]);
+                    c->vcf.push_back(B5[refc(ee)]);
                     if (j + 1 >= l) break;
                     // cell at j+1: listed -> its cells, else unmutated
-                    if (ee + 1 < pos.size() && pos[ee + 1] == j + 1) {
+                    if (ee + 1 < e1 && g.pos[ee + 1] - s0 == j + 1) {
                         ++ee; ++j;
                         const uint8_t a1 = cell(ee, 0), a2 = cell(ee, 1);
                         const bool h2 = (a1 & BTMASK) == (a2 & BTMASK);
                         if (!(h2 == hom && ((pl == 2 ? a2 : a1) & TMASK) == T_DEL)) break;
                     } else break;
                 }
-                if (i > 0) appendf(c->vcf, "\t%c", B5[nt4(k.ascii[(size_t)i - 1])]); else c->vcf.append("\t.");
+                if (i > 0) appendf(c->vcf, "\t%c", B5[prevc(e)]); else c->vcf.append("\t.");
                 appendf(c->vcf, "\t100\tPASS\tAF=%s;pl=%d;mt=DELETE\n", hom ? "1.0" : "0.5", pl);
             }
         } else {
             const int pl = hom ? 3 : (t1 == T_INS ? 1 : 2);
-            const char *seq = ins_text(ins[pl == 2 ? 1 : 0], (int32_t)i, tmp);
+            const char *seq = ins_text(g.ins[pl == 2 ? 1 : 0], g.pos[e], tmp);
             appendf(c->txt, "-\t%s\t%d\n", seq, pl);
             appendf(c->vcf, "%s\t%lld\t.\t%c\t%c%s\t100\tPASS\tAF=%s;pl=%d;mt=INSERT\n", nm, (long long)i + 1, B5[r0], B5[r0], seq, hom ? "1.0" : "0.5", pl);
         }
@@ -828,7 +1044,38 @@ int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt,
 }
 
 // ---- read simulation ----
-static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uint64_t n_pairs, SimArgs &a)
+// The ranges of one launch: all of one walked group, in file order.  ppb = pairs per block of the kernel that will run.
+static int build_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t ppb, Group **gout, std::vector<SimSeg> &segs, uint64_t *n_pairs, uint32_t *n_blocks, int *fixed_max)
+{
+    if (!r || n < 1) { c->err = "bad range arguments"; return DWGSIM_HIP_ERR_ARG; }
+    Group *g = nullptr;
+    uint64_t pairs = 0, blocks = 0; int fmax = 0;
+    segs.clear();
+    for (int q = 0; q < n; ++q) {
+        int k = 0;
+        Group *gq = get_group(c, r[q].contig, &k);
+        if (!gq) return DWGSIM_HIP_ERR_ARG;
+        if (g && gq != g) { c->err = "the ranges of one call must belong to contigs that were added together (dwgsim_hip_add_contigs)"; return DWGSIM_HIP_ERR_ARG; }
+        g = gq;
+        if (r[q].n_pairs == 0) continue;
+        const Member &m = g->m[(size_t)k];
+        if (c->has_regions && m.n_reg == 0 && c->prm.rand_read < 1.0) { c->err = "dwgsim-hip: this contig has no target region (-x): the reference's placement loop would not terminate\n"; return DWGSIM_HIP_ERR_ARG; }
+        SimSeg s; memset(&s, 0, sizeof s);
+        s.first_block = (uint32_t)blocks; s.contig_index = m.contig_index; s.start = m.start; s.l = (int32_t)m.l;
+        s.first_ii = r[q].first_ii; s.n_pairs = r[q].n_pairs; s.pair_off = pairs; s.l_place = m.l_place;
+        s.reg_off = m.reg_off; s.n_reg = m.n_reg; s.name_off = m.name_off; s.name_fixed_len = m.name_fixed_len;
+        s.contig_start = r[q].first_ii == 0 ? 1u : 0u;
+        segs.push_back(s);
+        pairs += r[q].n_pairs; blocks += (r[q].n_pairs + ppb - 1) / ppb;
+        if (m.name_fixed_len > fmax) fmax = m.name_fixed_len;
+        if (blocks > 0x7fffffffull) { c->err = "too many pairs in one call"; return DWGSIM_HIP_ERR_ARG; }
+    }
+    if (!g->mutated || g->walk_pending) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    *gout = g; *n_pairs = pairs; *n_blocks = (uint32_t)blocks; *fixed_max = fmax;
+    return DWGSIM_HIP_OK;
+}
+
+static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
 {
     const dwgsim_hip_params_t &p = c->prm;
     memset(&a, 0, sizeof a);
@@ -839,14 +1086,14 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.p.has_bfast = p.reads_output_type != 1; a.p.has_bwa = p.reads_output_type != 2;
     a.p.seed = (uint32_t)p.seed;
     lazy_quality_params(p.quality_std, &a.p.q_k, &a.p.q_eps, &a.p.q_lmin, &a.p.q_near1);
-    a.c = contig_dev(k);
-    a.first_ii = first_ii; a.n_pairs = n_pairs; a.chain = c->d_chain;
-    a.l_place = k.l_place; a.have_regions = c->has_regions ? 1 : 0; a.n_reg = k.n_reg; a.reg_start = k.d_reg; a.reg_end = k.d_reg ? k.d_reg + k.n_reg : nullptr;
+    fill_haps(g, a.hap);
+    a.chain = c->d_chain;
+    a.have_regions = c->has_regions ? 1 : 0; a.reg = g.d_reg;
     for (int j = 0; j < 2; ++j) { a.e_thr[j] = c->d_thr[j]; a.e_thr32[j] = c->d_thr32[j]; a.qbase[j] = c->d_qbase[j] ? c->d_qbase[j] : c->d_qbase[0]; }
     a.qb_words = c->qb_words;
     a.e_full = c->e_full;
-    a.name_fixed = k.d_name_fixed; a.name_fixed_len = k.name_fixed_len;
-    a.summ[0] = k.d_summ[0]; a.summ[1] = k.d_summ[1];      // null unless count_random built them
+    a.names = g.d_names;
+    a.summ[0] = g.d_summ[0]; a.summ[1] = g.d_summ[1];      // null unless count_random built them
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
     // lanes per k_simulate block: the staged read (lds_words per lane) must fit LDS; long Illumina / SOLiD reads get one-wave blocks
     const int lmax0 = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
@@ -867,16 +1114,6 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
             c->err = b; return DWGSIM_HIP_ERR_UNSUP;
         }
     }
-    const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block
-    const uint64_t nblk = (n_pairs + sim_ppb - 1) / sim_ppb;
-    const uint64_t nblk_place = (n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;       // k_place (count_random) writes one entry per ITS block
-    const uint64_t nblk_rand = nblk > nblk_place ? nblk : nblk_place;
-    if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)(nblk_rand ? nblk_rand : 1))) return DWGSIM_HIP_ERR_DEVICE;
-    if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)(nblk ? nblk : 1))) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
-    if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
-    a.meta = (uint32_t *)c->meta.p;
-    a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
-    for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)(nblk ? nblk : 1);
     const int lmax = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
@@ -886,42 +1123,55 @@ static int build_sim_args(dwgsim_hip_ctx_t *c, Contig &k, uint64_t first_ii, uin
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
     a.flow_scratch = nullptr;
-    if (p.data_type == 2) {
-        const size_t nthr = (size_t)SIM_THREADS;
-        const size_t words = (size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr * (size_t)(nblk ? nblk : 1);
-        if (ensure(c, c->flow_scratch, words * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
-        a.flow_scratch = (uint32_t *)c->flow_scratch.p;
-    }
     return 0;
 }
 
-int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t *n_random)
+int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t *n_random)
 {
-    Contig *kp = get_contig(c, contig);
-    if (!kp) return DWGSIM_HIP_ERR_ARG;
-    if (!kp->mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
-    HIPC(c, hipSetDevice(c->device));
+    if (!c) return DWGSIM_HIP_ERR_ARG;
     if (n_random) *n_random = 0;
+    Group *gp = nullptr; std::vector<SimSeg> segs; uint64_t n_pairs = 0; uint32_t n_blocks = 0; int fixed_max = 0;
+    if (const int rc = build_ranges(c, r, n, PAIRS_PER_BLOCK, &gp, segs, &n_pairs, &n_blocks, &fixed_max)) return rc;
     if (n_pairs == 0) return DWGSIM_HIP_OK;
-    if (!kp->summ_valid) {         // per-64-cell summaries of the two haplotypes: let k_place accept clean windows without walking them
-        const size_t nb = (size_t)((kp->l + SUMM_CELLS - 1) / SUMM_CELLS);
+    Group &g = *gp;
+    HIPC(c, hipSetDevice(c->device));
+    if (!g.summ_valid) {         // per-64-cell summaries of the two haplotypes: let k_place accept clean windows without walking them
+        const size_t nb = (size_t)((g.total + SUMM_CELLS - 1) / SUMM_CELLS);
         for (int h = 0; h < 2; ++h) {
-            if (!kp->d_summ[h]) HIPC(c, hipMalloc((void **)&kp->d_summ[h], sizeof(uint16_t) * (nb ? nb : 1)));
-            launch_summarize(c->stream, kp->d_cells[h], kp->l, kp->d_summ[h]);
+            if (!g.d_summ[h]) HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (nb ? nb : 1)));
+            launch_summarize(c->stream, g.d_cells[h], g.total, g.d_summ[h]);
         }
-        kp->summ_valid = true;
+        g.summ_valid = true;
     }
     SimArgs a;
-    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, a)) return rc;
+    if (const int rc = fill_sim_args(c, g, a)) return rc;
+    if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)n_blocks)) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->place_segs, sizeof(SimSeg) * segs.size())) return DWGSIM_HIP_ERR_DEVICE;
+    if (segs.size() > c->h_place_segs_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->h_place_segs) HIPC(c, hipHostFree(c->h_place_segs));
+        c->h_place_segs = nullptr; c->h_place_segs_cap = 0;
+        HIPC(c, hipHostMalloc((void **)&c->h_place_segs, sizeof(SimSeg) * (segs.size() + 64), hipHostMallocDefault));
+        c->h_place_segs_cap = segs.size() + 64;
+    }
+    memcpy(c->h_place_segs, segs.data(), sizeof(SimSeg) * segs.size());
+    HIPC(c, hipMemcpyAsync(c->place_segs.p, c->h_place_segs, sizeof(SimSeg) * segs.size(), hipMemcpyHostToDevice, c->stream));
+    a.segs = (const SimSeg *)c->place_segs.p; a.n_seg = (int32_t)segs.size(); a.n_blocks = n_blocks; a.n_pairs = n_pairs;
+    a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
     HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
     launch_place(c->stream, a);
-    const uint32_t nblk = (uint32_t)((n_pairs + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-    launch_scan_excl(c->stream, a.block_rand, nblk, &c->d_counters[3]);
+    launch_scan_excl(c->stream, a.block_rand, n_blocks, &c->d_counters[3]);
     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     if (n_random) *n_random = c->h_counters[3];
     return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t *n_random)
+{
+    dwgsim_hip_range_t r; memset(&r, 0, sizeof r); r.contig = contig; r.first_ii = first_ii; r.n_pairs = n_pairs;
+    return dwgsim_hip_count_random_ranges(c, &r, 1, n_random);
 }
 
 int dwgsim_hip_set_fail_carry(dwgsim_hip_ctx_t *c, uint64_t carry)
@@ -931,72 +1181,116 @@ int dwgsim_hip_set_fail_carry(dwgsim_hip_ctx_t *c, uint64_t carry)
     return DWGSIM_HIP_OK;
 }
 
-// Enqueue one batch on the compute stream: [chain set] -> memsets -> k_simulate -> abort-rule epilogue -> counters to the slot's pinned
-// mirror -> event.  Nothing here waits for the GPU (buffers only grow between batches of different shapes, and hipFree synchronises).
-int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, int slot)
+// Enqueue one batch on the compute stream: [chain set] -> memsets -> k_simulate -> abort-rule epilogue -> [k_gzip] -> counters to the slot's
+// pinned mirror -> event.  Every buffer the batch needs is in place before anything is enqueued or the chain state moves, so a failing call
+// leaves the context as it found it.
+int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t rand_base, int slot)
 {
-    Contig *kp = get_contig(c, contig);
-    if (!kp || slot < 0 || slot > 1) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
-    if (!kp->mutated) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
+    if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "simulate: the slot still holds a batch that was not waited for"; return DWGSIM_HIP_ERR_STATE; }
-    HIPC(c, hipSetDevice(c->device));
-    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = sl.gz_bytes[t] = 0;
-    sl.n_pairs = n_pairs; sl.empty = n_pairs == 0;
-    // the reference's failure counter (dwgsim.c:635) runs over the pairs of ONE contig in index order: it is carried from the previous
-    // batch only when this one continues it; any other range starts from zero unless the caller supplied the carry (sharded jobs)
-    const bool continues = c->chain_contig == contig && c->chain_next_ii == first_ii && first_ii != 0;
-    const bool set_carry = c->has_carry_override || !continues;
-    const uint64_t carry = c->has_carry_override ? c->carry_override : 0;
-    c->has_carry_override = false;
-    const bool set_rand = rand_base != DWGSIM_HIP_RAND_CHAIN;
-    if (set_rand || set_carry) launch_chain_set(c->stream, c->d_chain, rand_base, set_rand ? 1 : 0, carry, set_carry ? 1 : 0);
-    c->chain_contig = contig; c->chain_next_ii = first_ii + n_pairs;
-    if (n_pairs == 0) return DWGSIM_HIP_OK;
-    SimArgs a;
-    if (const int rc = build_sim_args(c, *kp, first_ii, n_pairs, a)) return rc;
-    if (c->has_regions && kp->n_reg == 0 && c->prm.rand_read < 1.0) { c->err = "dwgsim-hip: this contig has no target region (-x): the reference's placement loop would not terminate\n"; return DWGSIM_HIP_ERR_ARG; }
-    // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     const dwgsim_hip_params_t &p = c->prm;
-    const int fixed_max = kp->name_fixed_len > c->rand_fixed_len ? kp->name_fixed_len : c->rand_fixed_len;
+    // lanes per block are a property of the options, so the range table can be laid out before the arguments are complete
+    Group *gp = nullptr; std::vector<SimSeg> segs; uint64_t n_pairs = 0; uint32_t nblk = 0; int fixed_max = 0;
+    SimArgs a;
+    {
+        // (fill_sim_args needs a group: take it from the first range)
+        Group *g0 = (r && n >= 1) ? get_group(c, r[0].contig) : nullptr;
+        if (!g0) { if (r && n >= 1) return DWGSIM_HIP_ERR_ARG; c->err = "bad range arguments"; return DWGSIM_HIP_ERR_ARG; }
+        if (const int rc = fill_sim_args(c, *g0, a)) return rc;
+    }
+    const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));      // pairs per k_simulate block
+    if (const int rc = build_ranges(c, r, n, sim_ppb, &gp, segs, &n_pairs, &nblk, &fixed_max)) return rc;
+    Group &g = *gp;
+    HIPC(c, hipSetDevice(c->device));
+    if (c->rand_fixed_len > fixed_max) fixed_max = c->rand_fixed_len;
+    // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     size_t cap[3] = {0, 0, 0};
     for (int j = 0; j < 2; ++j) if (p.length[j] > 0) cap[j] = (size_t)n_pairs * (size_t)(1 + fixed_max + 120 + 3 + 2 * (p.data_type == 2 ? a.cap : p.length[j]) + 4);
     cap[2] = cap[0] + cap[1];
     if (!a.p.has_bwa) cap[0] = cap[1] = 0;
     if (!a.p.has_bfast) cap[2] = 0;
-    for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
-    a.counters = sl.d_counters;
-    const uint64_t sim_ppb = (uint64_t)(a.sim_threads / (p.length[1] > 0 ? 2 : 1));
-    const uint32_t nblk = (uint32_t)((n_pairs + sim_ppb - 1) / sim_ppb);
-    const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
-    if (ensure(c, c->fail_summ, (nfb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
-    if (sl.fetch_in_flight) { HIPC(c, hipStreamWaitEvent(c->stream, sl.ev_fetched, 0)); sl.fetch_in_flight = false; }      // the slot's text is still being copied out
+    if (n_pairs) {
+        // the slot's text may still be on its way to the host: wait for that before a buffer could be replaced
+        if (sl.fetch_in_flight) { HIPC(c, hipStreamWaitEvent(c->stream, sl.ev_fetched, 0)); bool grows = false; for (int t = 0; t < 3; ++t) if (cap[t] + 64 > c->out[slot][t].cap) grows = true; if (grows) HIPC(c, hipEventSynchronize(sl.ev_fetched)); sl.fetch_in_flight = false; }
+        for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
+        if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)nblk)) return DWGSIM_HIP_ERR_DEVICE;
+        if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)nblk)) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
+        if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
+        const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
+        if (ensure(c, c->fail_summ, (nfb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
+        if (p.data_type == 2) {
+            const size_t words = (size_t)flow_words_per_lane(a.lds_words, a.cap) * (size_t)SIM_THREADS * (size_t)nblk;
+            if (ensure(c, c->flow_scratch, words * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
+            a.flow_scratch = (uint32_t *)c->flow_scratch.p;
+        }
+        if (ensure(c, sl.segs, sizeof(SimSeg) * segs.size())) return DWGSIM_HIP_ERR_DEVICE;
+        if (segs.size() > sl.h_segs_cap) {
+            if (sl.h_segs) HIPC(c, hipHostFree(sl.h_segs));
+            sl.h_segs = nullptr; sl.h_segs_cap = 0;
+            HIPC(c, hipHostMalloc((void **)&sl.h_segs, sizeof(SimSeg) * (segs.size() + 64), hipHostMallocDefault));
+            sl.h_segs_cap = segs.size() + 64;
+        }
+        if (c->gzip_on) {
+            size_t off = 0;
+            for (int t = 0; t < 3; ++t) { off += (size_t)gz_chunks(cap[t]); if (cap[t] && ensure(c, sl.gz_out[t], (size_t)gz_capacity(cap[t]) + 64)) return DWGSIM_HIP_ERR_DEVICE; }
+            if (ensure(c, sl.gz_status, sizeof(uint64_t) * (off ? off : 1))) return DWGSIM_HIP_ERR_DEVICE;
+        }
+    }
+    // ---- nothing below fails for want of memory ----
+    for (int t = 0; t < 3; ++t) sl.out_bytes[t] = sl.gz_bytes[t] = 0;
+    sl.n_pairs = n_pairs; sl.empty = n_pairs == 0;
+    // the reference's failure counter (dwgsim.c:635) runs over the pairs of ONE contig in index order: it is carried from the previous
+    // batch only when this one continues it; any other range starts from zero unless the caller supplied the carry (sharded jobs)
+    const dwgsim_hip_range_t *r_first = nullptr, *r_last = nullptr;
+    for (int q = 0; q < n; ++q) if (r[q].n_pairs) { if (!r_first) r_first = &r[q]; r_last = &r[q]; }
+    if (!r_first) { r_first = &r[0]; r_last = &r[n - 1]; }
+    const bool continues = c->chain_contig == r_first->contig && c->chain_next_ii == r_first->first_ii && r_first->first_ii != 0;
+    const bool set_carry = c->has_carry_override || !continues;
+    const uint64_t carry = c->has_carry_override ? c->carry_override : 0;
+    c->has_carry_override = false;
+    const bool set_rand = rand_base != DWGSIM_HIP_RAND_CHAIN;
+    if (set_rand || set_carry) launch_chain_set(c->stream, c->d_chain, rand_base, set_rand ? 1 : 0, carry, set_carry ? 1 : 0);
+    c->chain_contig = r_last->contig; c->chain_next_ii = r_last->first_ii + r_last->n_pairs;
+    if (n_pairs == 0) return DWGSIM_HIP_OK;
+    uint32_t opens = 0;
+    for (const SimSeg &s : segs) opens |= s.contig_start;
+    memcpy(sl.h_segs, segs.data(), sizeof(SimSeg) * segs.size());
+    HIPC(c, hipMemcpyAsync(sl.segs.p, sl.h_segs, sizeof(SimSeg) * segs.size(), hipMemcpyHostToDevice, c->stream));
+    a.segs = (const SimSeg *)sl.segs.p; a.n_seg = (int32_t)segs.size(); a.n_blocks = nblk; a.n_pairs = n_pairs;
+    a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = sl.d_counters;
+    for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)nblk;
+    sl.group = c->handles[(size_t)g.first_handle].group;
     HIPC(c, hipMemsetAsync(sl.d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
     HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(sl.ev_k0, c->stream));
     launch_simulate(c->stream, a);
     HIPC(c, hipEventRecord(sl.ev_k1, c->stream));
-    launch_failrule(c->stream, a.meta, n_pairs, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
+    launch_failrule(c->stream, a.meta, n_pairs, opens, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
     if (c->gzip_on) {      // the .gz form of every stream, enqueued behind the text (lengths are read on the device: counters[4 + t])
         size_t nch[3], off = 0;
         for (int t = 0; t < 3; ++t) { nch[t] = (size_t)gz_chunks(cap[t]); off += nch[t]; }
-        if (ensure(c, sl.gz_status, sizeof(uint64_t) * (off ? off : 1))) return DWGSIM_HIP_ERR_DEVICE;
         HIPC(c, hipMemsetAsync(sl.gz_status.p, 0, sizeof(uint64_t) * (off ? off : 1), c->stream));
         off = 0;
         for (int t = 0; t < 3; ++t) {
             if (cap[t] == 0) continue;
-            const size_t gcap = (size_t)gz_capacity(cap[t]);
-            if (ensure(c, sl.gz_out[t], gcap + 64)) return DWGSIM_HIP_ERR_DEVICE;
-            launch_gzip(c->stream, a.out[t], &sl.d_counters[4 + t], cap[t], (uint8_t *)sl.gz_out[t].p, gcap, (uint64_t *)sl.gz_status.p + off, &sl.d_counters[28 + t], &sl.d_counters[24 + t], &sl.d_counters[2],
+            launch_gzip(c->stream, a.out[t], &sl.d_counters[4 + t], cap[t], (uint8_t *)sl.gz_out[t].p, (size_t)gz_capacity(cap[t]), (uint64_t *)sl.gz_status.p + off, &sl.d_counters[28 + t], &sl.d_counters[24 + t], &sl.d_counters[2],
                         c->d_crc_table, c->d_crc_shift);
             off += nch[t];
         }
     }
+    HIPC(c, hipEventRecord(sl.ev_end, c->stream));
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(sl.h_counters, sl.d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipEventRecord(sl.ev_done, c->stream));
     sl.pending = true;
     return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t rand_base, int slot)
+{
+    dwgsim_hip_range_t r; memset(&r, 0, sizeof r); r.contig = contig; r.first_ii = first_ii; r.n_pairs = n_pairs;
+    return dwgsim_hip_simulate_ranges_async(c, &r, 1, rand_base, slot);
 }
 
 int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
@@ -1030,7 +1324,7 @@ int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
         for (int t = 0; t < 4; ++t) out->fail_seg[t] = h[16 + t];
         out->fail_carry = h[21];
         HIPC(c, hipEventElapsedTime(&out->sim_kernel_ms, sl.ev_k0, sl.ev_k1));
-        out->kernel_ms = out->sim_kernel_ms;
+        HIPC(c, hipEventElapsedTime(&out->kernel_ms, sl.ev_k0, sl.ev_end));       // ... with the abort-rule epilogue and the gzip kernels
     }
     return DWGSIM_HIP_OK;
 }
@@ -1117,14 +1411,10 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, 
     const size_t n = (size_t)sl.out_bytes[stream];
     if (n > cap) { c->err = "fetch: destination too small"; return DWGSIM_HIP_ERR_ARG; }
     if (n == 0) return DWGSIM_HIP_OK;
-    {   // a pinned (page-locked / registered) destination takes one direct copy at link speed
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, host_dst) == hipSuccess && at.type == hipMemoryTypeHost) {
-            HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->copy_stream));
-            HIPC(c, hipStreamSynchronize(c->copy_stream));
-            return DWGSIM_HIP_OK;
-        }
-        (void)hipGetLastError();      // pageable memory: the query reports an error that must not stick
+    if (is_page_locked(host_dst)) {   // a pinned (page-locked / registered) destination takes one direct copy at link speed
+        HIPC(c, hipMemcpyAsync(host_dst, c->out[slot][stream].p, n, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPC(c, hipStreamSynchronize(c->copy_stream));
+        return DWGSIM_HIP_OK;
     }
     // double-buffered pinned staging: D2H of chunk k+1 overlaps the host copy of chunk k
     const size_t CH = (size_t)16 << 20;

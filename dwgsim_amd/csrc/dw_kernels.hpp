@@ -21,7 +21,9 @@ constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_POS_PER_BLOCK = SCAN_POS_PER_THREAD * SCAN_THREADS;   // 4096
-constexpr int CELL_PAD = 32;             // cells are allocated with 32 readable pad bytes after the contig
+constexpr int CELL_PAD = 32;             // cells are allocated with 32 readable pad bytes after the last contig
+constexpr int GROUP_ALIGN = SCAN_POS_PER_BLOCK;   // contigs that are resident together share ONE coordinate space ("group"): contig k starts at a multiple of this many cells,
+                                         // so that a block of the position-parallel walk kernels, a 32-cell chunk of the read view and a 64-cell summary all lie inside one contig
 constexpr int MAX_ATTEMPTS = 10000;      // dwgsim.c:837
 
 // mutation type bits of a cell (low byte of the reference's mut_t, mut.h:25-30)
@@ -29,13 +31,18 @@ constexpr uint8_t T_NONE = 0x00, T_INS = 0x10, T_SUB = 0x20, T_DEL = 0x30, TMASK
 
 // a candidate mutation site resolved speculatively (k_events) and then marked live/dead (k_resolve)
 struct Event {
-    int32_t  pos;
-    uint8_t  type;      // 0 dead, 1 substitution, 2 deletion, 3 insertion
+    int32_t  pos;       // group coordinate
+    uint8_t  type;      // 0 dead, 1 substitution, 2 deletion, 3 insertion, 4 patched from a mutation-input file
     uint8_t  hap;       // haplotype mask 1|2
     uint8_t  base;      // substitution: new base; else reference code at pos
     uint8_t  live;
     uint32_t len;       // deletion run length / insertion length
+    uint32_t seg;       // which contig of the group
 };
+
+// The contigs of a group: contig k occupies group coordinates [start[k], start[k] + len[k]); start[] is ascending, multiples of GROUP_ALIGN,
+// start[n] = the padded total.  Cells between two contigs are unmutated N.
+struct SegTab { const int32_t *start; const int32_t *len; const uint32_t *cindex; int32_t n; };
 
 // one haplotype of one contig, resident in HBM
 struct HapDev {
@@ -48,13 +55,15 @@ struct HapDev {
     uint32_t *ins_off;      // offset of the inserted bases P[0..n) (printed order) in ins_bases
     uint8_t *ins_bases;
     uint32_t n_ins;
+    int32_t pos_off;        // added to a position before it is looked up in ins_pos (which holds group coordinates): 0 in the walk kernels, the contig's start
+                            // in the read kernels, whose cells / view pointers are those of the contig
 };
 
-struct ContigDev {
+struct ContigDev {             // a group of contigs in its coordinate space (a single contig: one segment starting at 0)
     HapDev hap[2];
-    const uint8_t *ref;     // [l + CELL_PAD] reference base codes
-    int64_t l;
-    uint32_t contig_index;  // RNG key
+    const uint8_t *ref;     // [total + CELL_PAD] reference base codes
+    int64_t l;              // padded total of the group
+    SegTab seg;
     const uint32_t *tot4;   // walk kernels only (else null): device copy of {n_ins[0], n_ins_bases[0], n_ins[1], n_ins_bases[1]} still being produced
     uint32_t cap_bases[2];  // ... and the capacity of the inserted-base pools
 };
@@ -98,22 +107,36 @@ constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_s
 inline constexpr int flow_hit_bits(int cap) { return (2 * cap + 256 + 31) & ~31; }
 inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_words + ((cap + 15) >> 4) + (flow_hit_bits(cap) >> 5)) | 1; }
 
+// One read-index range of one contig inside a k_simulate / k_place launch.  A launch covers n_seg of them, in file order; a block never spans two.
+struct SimSeg {
+    uint32_t first_block;          // logical block of the range's first pair (exclusive prefix of ceil(n_pairs / pairs per block))
+    uint32_t contig_index;         // RNG key
+    int32_t  start, l;             // the contig inside its group
+    uint64_t first_ii, n_pairs;    // the range
+    uint64_t pair_off;             // pairs of the launch in front of this range (index into meta)
+    int64_t  l_place;              // the `l` that sizes fragment placement: contig length, or the contig's region length with -x (dwgsim.c:552)
+    int32_t  reg_off, n_reg;       // -x: this contig's merged target regions, reg[reg_off .. +n_reg) = starts, the next n_reg = ends (regions_bed.c)
+    uint32_t name_off; int32_t name_fixed_len;     // "@[prefix_]contig" in the group's name pool (zero padded to >= 272 bytes)
+    uint32_t contig_start;         // 1: the range begins its contig (first_ii == 0): the abort rule's counter starts from zero there (dwgsim.c:635)
+    uint32_t pad_;
+};
+
 struct SimArgs {
     SimParams p;
-    ContigDev c;
-    uint64_t first_ii, n_pairs;
+    HapDev hap[2];                 // the group (pointers at group coordinate 0)
+    const SimSeg *segs; int32_t n_seg; uint32_t n_blocks;     // the ranges of this launch (device memory) and its logical blocks
+    uint64_t n_pairs;              // pairs of the launch
     const uint64_t *chain;         // device words chained from batch to batch on the context's stream: [0] random reads emitted before this batch (rand_ii, dwgsim.c:1042,1096), [1] the abort rule's carry
-    int64_t l_place;               // the `l` that sizes fragment placement: contig length, or the contig's region length with -x (dwgsim.c:552)
-    const int32_t *reg_start, *reg_end; int32_t n_reg, have_regions;   // -x: this contig's merged target regions (regions_bed.c)
+    const int32_t *reg; int32_t have_regions;       // -x: region pool of the group
     const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
     const uint16_t *summ[2];       // k_place only (else null): per SUMM_CELLS cells of a haplotype, bits 0-7 = INSERT / DELETE cells, bit 15 = a base code >= 4
     const uint32_t *e_thr32[2];    // the same as 32-bit words, zero padded to a multiple of 8 entries; a threshold of 2^32 (e = 1) is stored as
     int32_t e_full;                // 0xFFFFFFFF and flagged here: those positions always err
     const uint32_t *qbase[2];      // per-position base quality characters (dwgsim.c:907; signed-char semantics) packed four to a word: len entries, then the last one
     int32_t qb_words;              // repeated up to qb_words words (>= len + 4 entries, the same for both read ends); the kernel stages both tables in LDS
-    const uint8_t *name_fixed; int32_t name_fixed_len;   // "[prefix_]contig"
+    const uint8_t *names;          // name pool of the group
     const uint8_t *rand_fixed; int32_t rand_fixed_len;   // "[prefix_]rand"
-    uint32_t *meta;                // per pair: failed attempts | random read << 31 (input of the abort rule, k_failrule)
+    uint32_t *meta;                // per pair: failed attempts | contig start << 30 | random read << 31 (input of the abort rule, k_failrule)
     uint32_t *block_rand;          // per 128-pair block: random pairs (k_place), then exclusive prefix (k_scan)
     uint64_t *counters;            // this batch's slot: [0] ticket, [1] retries, [2] fail flags, [3] total random, [4..6] stream bytes, [16..19] abort-rule segment of the batch, [20] abort, [21] carry out
     uint64_t *status[4];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count, (SOLiD) BFAST bytes

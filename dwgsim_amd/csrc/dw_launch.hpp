@@ -5,10 +5,10 @@
 
 namespace dw {
 void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l);
-void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1);
+void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg, WalkParams wp, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1);
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out);
 void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_base, int32_t *out, int64_t l, uint32_t cap);
-void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del);
+void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, SegTab seg, WalkParams wp, Event *ev, uint32_t *max_del);
 void walk_debug_seg_min(uint32_t rows);      // test hook: candidate capacity from which k_scan4 / k_sufmin run segmented (0 = default)
 void launch_resolve(hipStream_t st, Event *ev, Count n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4);
 void launch_apply(hipStream_t st, Event *ev, Count n, const uint4 *flags, ContigDev c, WalkParams wp);
@@ -18,12 +18,12 @@ void launch_mut_debug(hipStream_t st, const uint8_t *ref, const uint8_t *h0, con
 void launch_make_view(hipStream_t st, const uint8_t *cells0, const uint8_t *cells1, int64_t n_cells, uint8_t *view0, uint8_t *view1);
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1);
 void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count);
-void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells);
+void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *ref, const uint8_t *h0, const uint8_t *h1, uint32_t *cells);
 void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ);
 void launch_place(hipStream_t st, const SimArgs &a);
 void launch_simulate(hipStream_t st, const SimArgs &a);
 void launch_calibrate(hipStream_t st, const CalibArgs &a);
-void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t *summ, uint64_t *counters, uint64_t *chain);
+void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint32_t opens_contig, uint64_t *summ, uint64_t *counters, uint64_t *chain);
 void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry);
 void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out);
 uint64_t gz_chunks(uint64_t n);

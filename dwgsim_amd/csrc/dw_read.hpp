@@ -119,29 +119,52 @@ struct PairDraw { bool is_rand; int32_t pos, d; int hap, strand0, strand1; };
 
 // select-by-value accessors: dynamic indexing into the by-value kernel argument block would force a
 // private copy of the whole struct (promoted to LDS by the backend)
-DW_DEV HapDev sel_hap(const SimArgs &a, int h)
+// The block's range of the launch: the fields of its SimSeg (block-uniform, scalar registers) in the form the read code uses
+struct SegCtx {
+    int64_t l, l_place;            // contig length; the `l` of fragment placement (region length with -x)
+    int32_t start;                 // the contig's first cell in the group's coordinate space (a multiple of GROUP_ALIGN)
+    const int32_t *reg_start, *reg_end; int32_t n_reg;
+};
+// haplotype h of the block's contig: cells / view pointers moved to the contig's first cell (start is a multiple of 32 cells: view chunks stay 16-byte
+// aligned), the insertion tables stay those of the group (ins_find adds pos_off)
+DW_DEV HapDev sel_hap(const SimArgs &a, const SegCtx &sc, int h)
 {
     HapDev r;
-    r.cells = h ? a.c.hap[1].cells : a.c.hap[0].cells;
-    r.view = h ? a.c.hap[1].view : a.c.hap[0].view;
-    r.ins_pos = h ? a.c.hap[1].ins_pos : a.c.hap[0].ins_pos;
-    r.ins_len = h ? a.c.hap[1].ins_len : a.c.hap[0].ins_len;
-    r.ins_off = h ? a.c.hap[1].ins_off : a.c.hap[0].ins_off;
-    r.ins_bases = h ? a.c.hap[1].ins_bases : a.c.hap[0].ins_bases;
-    r.n_ins = h ? a.c.hap[1].n_ins : a.c.hap[0].n_ins;
+    r.cells = (h ? a.hap[1].cells : a.hap[0].cells) + sc.start;
+    r.view = (h ? a.hap[1].view : a.hap[0].view) + (sc.start >> 1);
+    r.ins_pos = h ? a.hap[1].ins_pos : a.hap[0].ins_pos;
+    r.ins_len = h ? a.hap[1].ins_len : a.hap[0].ins_len;
+    r.ins_off = h ? a.hap[1].ins_off : a.hap[0].ins_off;
+    r.ins_bases = h ? a.hap[1].ins_bases : a.hap[0].ins_bases;
+    r.n_ins = h ? a.hap[1].n_ins : a.hap[0].n_ins;
+    r.pos_off = sc.start;
     return r;
+}
+// The range (SimSeg) that logical block t of the launch belongs to: the last one whose first_block <= t.  t is block-uniform.
+typedef const DW_CONST_AS SimSeg *SegPtr;       // the range table of a launch: uploaded before it, read with scalar loads
+DW_DEV uint32_t seg_of_block(SegPtr segs, int32_t n_seg, uint32_t t)
+{
+    uint32_t lo = 0, hi = (uint32_t)n_seg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (segs[mid].first_block <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+DW_DEV SegCtx seg_ctx(const SimArgs &a, SegPtr sg)
+{
+    SegCtx sc; sc.l = sg->l; sc.l_place = sg->l_place; sc.start = sg->start;
+    sc.reg_start = a.reg ? a.reg + sg->reg_off : nullptr; sc.reg_end = a.reg ? a.reg + sg->reg_off + sg->n_reg : nullptr; sc.n_reg = sg->n_reg;
+    return sc;
 }
 DW_DEV int sel_len(const SimArgs &a, int j) { return j ? a.p.len[1] : a.p.len[0]; }
 
 // dwgsim.c:649-742: random-read test, fragment size + position, haplotype, strands
-DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t att)
+DW_DEV PairDraw draw_pair(const SimArgs &a, const SegCtx &sc, RngKey key, uint64_t ii, uint32_t att)
 {
     PairDraw pd; pd.pos = 0; pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
     const U4 b0 = rng_block(key, D_PAIR, ii, att, 0, 0);
     pd.is_rand = !(a.p.rand_read < u_lo(b0));
     if (pd.is_rand) return pd;
     const int s0 = a.p.len[0], s1 = a.p.len[1];
-    const int64_t l = a.l_place, sl = a.c.l;          // placement length (region length with -x) vs contig length
+    const int64_t l = sc.l_place, sl = sc.l;          // placement length (region length with -x) vs contig length
     if (a.p.amplicons) { pd.pos = 0; pd.d = (int32_t)sl; }
     else {
         uint32_t t = 0; int32_t pos, d; bool continue_flag = false;
@@ -165,18 +188,18 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t at
             pos = (int32_t)((double)range * rng_slot(key, D_PLACE, ii, att, t));
             bool inside = true;
             if (a.have_regions) {                         // dwgsim.c:696-707: region coordinate -> contig coordinate, then regions_bed_query (:712)
-                for (int q = 0; q < a.n_reg; ++q) {
-                    const int32_t jl = a.reg_end[q] - a.reg_start[q];
-                    if (pos < jl) { pos = a.reg_start[q] + pos - 1; break; }
+                for (int q = 0; q < sc.n_reg; ++q) {
+                    const int32_t jl = sc.reg_end[q] - sc.reg_start[q];
+                    if (pos < jl) { pos = sc.reg_start[q] + pos - 1; break; }
                     pos -= jl;
                 }
                 inside = false;                           // regions are sorted and disjoint: "some region contains [pos, pos + d)" (regions_bed.c:130-156)
-                int lo = 0, hi = a.n_reg - 1;
+                int lo = 0, hi = sc.n_reg - 1;
                 const uint32_t qs = (uint32_t)pos, qe = (uint32_t)(pos + d);
                 while (lo <= hi) {
                     const int mid = lo + (hi - lo) / 2;
-                    if (qs < (uint32_t)a.reg_start[mid]) hi = mid - 1;
-                    else if ((uint32_t)a.reg_end[mid] < qe) lo = mid + 1;
+                    if (qs < (uint32_t)sc.reg_start[mid]) hi = mid - 1;
+                    else if ((uint32_t)sc.reg_end[mid] < qe) lo = mid + 1;
                     else { inside = true; break; }
                 }
             }
@@ -207,9 +230,9 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, RngKey key, uint64_t ii, uint32_t at
 }
 
 // dwgsim.c:745-821: first cell and direction of read end j
-DW_DEV void read_geom(const SimArgs &a, const PairDraw &pd, int j, int64_t *start, int *step)
+DW_DEV void read_geom(const SimArgs &a, const SegCtx &sc, const PairDraw &pd, int j, int64_t *start, int *step)
 {
-    const int64_t pos = pd.pos, d = pd.d, s0 = a.p.len[0], s1 = a.p.len[1], sl = a.c.l;
+    const int64_t pos = pd.pos, d = pd.d, s0 = a.p.len[0], s1 = a.p.len[1], sl = sc.l;
     const bool amp = a.p.amplicons != 0, inner = a.p.is_inner != 0;
     if (s1 > 0) {
         const int64_t far_outer = pos + d - 1;

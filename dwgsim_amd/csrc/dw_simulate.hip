@@ -83,22 +83,24 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
 {
     __shared__ uint32_t sm[17];
     const int tid = (int)threadIdx.x, j = (LPP == 2) ? (tid & 1) : 0;
-    const uint64_t pair = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);
-    const bool valid = pair < a.n_pairs;
-    const uint64_t ii = a.first_ii + pair;
-    const RngKey key{a.p.seed, a.c.contig_index};
+    const SegPtr sg = as_constant(a.segs) + seg_of_block(as_constant(a.segs), a.n_seg, blockIdx.x);          // the read-index range this block works on
+    const SegCtx sc = seg_ctx(a, sg);
+    const uint64_t pair = (uint64_t)(blockIdx.x - sg->first_block) * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);      // inside the range
+    const bool valid = pair < sg->n_pairs;
+    const uint64_t ii = sg->first_ii + pair;
+    const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
     const int sj = sel_len(a, j);
     uint32_t att = 0; bool is_rand = false, failed = false, done = !valid;
     while (__ballot(!done)) {                      // wave-uniform loop: the two lanes of a pair always agree on `done`
         bool ok = true;
         if (!done) {
-            const PairDraw pd = draw_pair(a, key, ii, att);
+            const PairDraw pd = draw_pair(a, sc, key, ii, att);
             if (pd.is_rand) { is_rand = true; done = true; }
             else if (sj > 0) {
                 int64_t start; int step;
-                read_geom(a, pd, j, &start, &step);
-                if (!attempt_surely_accepted(pd.hap ? a.summ[1] : a.summ[0], a.c.l, start, step, sj)) {     // rare: N, dense indels, contig ends
-                    const ReadRes r = gen_read<false>(sel_hap(a, pd.hap), a.c.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                read_geom(a, sc, pd, j, &start, &step);
+                if (!attempt_surely_accepted((pd.hap ? a.summ[1] : a.summ[0]) + sc.start / SUMM_CELLS, sc.l, start, step, sj)) {     // rare: N, dense indels, contig ends
+                    const ReadRes r = gen_read<false>(sel_hap(a, sc, pd.hap), sc.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
                     ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
                 }
             }
@@ -302,8 +304,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const int wave = tid >> 6, lane = tid & 63;
     PH_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
-    for (int q = tid; q < 64; q += nthr)                                                           // buffers are padded to 256 + 16 bytes
-        (&s_fixed[0][0])[q] = q < 32 ? reinterpret_cast<const uint32_t *>(a.name_fixed)[q] : reinterpret_cast<const uint32_t *>(a.rand_fixed)[q - 32];
+    for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
     uint32_t *const s_qb = dyn_lds + (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr;
@@ -311,13 +312,19 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // this lane's text FIFO (record writer), behind the tables
     uint8_t *const s_fifo = reinterpret_cast<uint8_t *>(dyn_lds + ((((size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) + 3) & ~(size_t)3)) + (size_t)tid * SIM_FIFO_BYTES;
     __syncthreads();
+    const uint32_t t = uniform_u32(s_ticket);                     // logical block: predecessors have started
+    // the read-index range (contig, first index, count) this block belongs to: block-uniform, its fields live in scalar registers
+    const SegPtr sg = as_constant(a.segs) + seg_of_block(as_constant(a.segs), a.n_seg, t);
+    const SegCtx sc = seg_ctx(a, sg);
+    const uint8_t *name_fixed = a.names + sg->name_off;
+    for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
     if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
-    const uint32_t t = s_ticket;                                  // logical block: predecessors have started
     const int j = (LPP == 2) ? (tid & 1) : 0;
-    const uint64_t pair = (uint64_t)t * PPB + (uint64_t)(tid / LPP);
-    const bool valid = pair < a.n_pairs;
-    const uint64_t ii = a.first_ii + pair;
-    const RngKey key{a.p.seed, a.c.contig_index};
+    const uint64_t pair_in = (uint64_t)(t - sg->first_block) * PPB + (uint64_t)(tid / LPP);      // inside the range
+    const bool valid = pair_in < sg->n_pairs;
+    const uint64_t ii = sg->first_ii + pair_in;
+    const uint64_t pair = sg->pair_off + pair_in;                 // inside the launch
+    const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
     const int s = sel_len(a, j);
     // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
     // read buffers live in a global scratch so that LDS does not cap residency; only the run stack of pass 2 stays in LDS
@@ -332,15 +339,15 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     while (__ballot(!done)) {
         bool ok = true;
         if (!done) {
-            pd = draw_pair(a, key, ii, att);
+            pd = draw_pair(a, sc, key, ii, att);
             if (pd.is_rand) { is_rand = true; done = true; rr = ReadRes{0, 0, 0, 0, 0}; }
             else if (s > 0) {
                 int64_t start; int step;
-                read_geom(a, pd, j, &start, &step);
+                read_geom(a, sc, pd, j, &start, &step);
                 PH_MARK(7);     // placement draws (phase 1 below is then the base extraction alone)
                 if (DW_KNOCK & 8) { rr = ReadRes{(int32_t)start, 0, 0, 0, 0}; for (int w = 0; w * 8 < s; ++w) lds[w * nthr] = 0x32103210u; }
                 else
-                rr = gen_read<true>(sel_hap(a, pd.hap), a.c.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
+                rr = gen_read<true>(sel_hap(a, sc, pd.hap), sc.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
                 ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
             }
         }
@@ -350,14 +357,15 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             else if (++att > (uint32_t)MAX_ATTEMPTS) { atomicOr((unsigned long long *)&a.counters[2], 1ull); done = true; }
         }
     }
-    if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u);      // failed attempts and outcome: input of the abort rule (k_failrule)
+    // failed attempts and outcome of the pair, and whether it opens its contig: input of the abort rule (k_failrule)
+    if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u) | ((sg->contig_start && pair_in == 0) ? 0x40000000u : 0u);
     { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
     // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
     uint32_t rrank, rtot;
     { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     if (wave == 0) {
         const uint64_t g = lookback_excl(a.status[2], t, rtot, 0);
-        if (lane == 0) { s_rbase = g; if ((uint64_t)t + 1 == (a.n_pairs + PPB - 1) / PPB) a.counters[3] = g + rtot; }
+        if (lane == 0) { s_rbase = g; if (t + 1 == a.n_blocks) a.counters[3] = g + rtot; }
     }
     // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
     // overlaps with that work instead of idling three waves)
@@ -477,7 +485,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     uint32_t tail_len, tail_len_w, fixed_len;
     if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
     else {
-        fixed_len = (uint32_t)a.name_fixed_len;
+        fixed_len = (uint32_t)sg->name_fixed_len;
         tail_len = pair_tail_len(x0, x1, nc, ii);
         tail_len_w = (DT == 1) ? pair_tail_len(x0, x1, ncw, ii) : tail_len;
     }
@@ -508,14 +516,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
     const uint64_t G1 = s_base[0], G2 = s_base[1];
-    const uint64_t reads_before_block = (uint64_t)t * PPB * (uint64_t)LPP;
+    const uint64_t reads_before_block = (sg->pair_off + (uint64_t)(t - sg->first_block) * PPB) * (uint64_t)LPP;      // (every block in front of a range's last is full)
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
     // Illumina: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
     const uint64_t off_bf = BF_SCAN ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
     if (tid == nthr - 1) {
-        const uint64_t nblocks = (a.n_pairs + PPB - 1) / PPB;
-        if ((uint64_t)t + 1 == nblocks) {
+        if (t + 1 == a.n_blocks) {
             const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
             a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
             a.counters[5] = a.p.has_bwa ? G2 + T2 : 0;
@@ -531,7 +538,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                 if (!(OUT & (1 << which))) continue;
                 Out2<1, WR> o;
                 o.init(s_fifo, which ? a.out[2] + off_bf : (j ? a.out[1] : a.out[0]) + off_bwa, nullptr);
-                put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
+                put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : name_fixed, fixed_len);
                 if (is_rand) put_rand_tail(o, rand_ii);
                 else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1,           // (value selects: a struct select would go through memory)
                                    NameCounts{which ? e0 : e0w, u0, which ? i0 : i0w, which ? e1c : e1w, u1, which ? i1 : i1w}, ii);
@@ -561,7 +568,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         if (rec) {
         o.init(s_fifo, (OUT & 1) ? (j ? a.out[1] : a.out[0]) + off_bwa : nullptr, (OUT & 2) ? a.out[2] + off_bf : nullptr);
         if (!(DW_KNOCK & 16)) {
-        put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : a.name_fixed, fixed_len);
+        put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : name_fixed, fixed_len);
         if (is_rand) put_rand_tail(o, rand_ii);
         else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
         }
@@ -746,7 +753,9 @@ void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *m
 // ---- the reference's abort rule (dwgsim.c:635, :833-843): one counter of failed attempts runs over the pairs of a contig in index order,
 // a pair that ends as a genomic read resets it, a pair that ends as a random read does not, and the job dies as soon as the counter
 // passes 10 000.  Pairs are simulated independently here, so the rule is evaluated afterwards from the per-pair record
-// meta[pair] = failed attempts | random << 31 -- only for batches that had a failed attempt at all.
+// meta[pair] = failed attempts | opens its contig << 30 | random << 31 -- only for batches that had a failed attempt at all.  A launch can cover
+// several contigs; the counter is per contig (`int num_failed = 0`, dwgsim.c:635), so a pair that opens its contig first puts a reset in front
+// of itself: MARK = {0, 0, 1, 0} (joining it after a run that already passed the limit still flags that run: the monoid's `bad` rule).
 // A run of pairs is summarised as {P: fails before its first reset (all of them if it has none), S: fails after its last reset,
 // R: has a reset, bad: a run between two of its resets passed the limit}.
 struct FailSeg { uint64_t P, S; uint32_t R, bad; };
@@ -781,7 +790,7 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
     __shared__ FailSeg seg[4];
     if (counters[1] == 0) return;
     const uint64_t first = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * FAIL_PAIRS_PER_THREAD;
-    FailSeg s{0, 0, 0, 0};                                          // (a thread past the end holds the neutral element: nothing failed, no reset)
+    FailSeg s{0, 0, 0, 0};                                          // the neutral element: nothing failed, no reset (also what a thread past the end holds)
     for (int q4 = 0; q4 < FAIL_PAIRS_PER_THREAD && first + q4 < n_pairs; q4 += 4) {       // 16-byte loads (meta is padded to a multiple of four entries)
         const uint4 v = *reinterpret_cast<const uint4 *>(meta + first + q4);
         const uint32_t mm[4] = {v.x, v.y, v.z, v.w};
@@ -789,9 +798,10 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
         for (int u = 0; u < 4; ++u) {
             if (first + q4 + u >= n_pairs) break;
             const uint32_t m = mm[u];
-            FailSeg one{m & 0x7fffffffu, 0, (m >> 31) ? 0u : 1u, 0};           // the pair's fails come before its outcome; a genomic read resets
+            if (m & 0x40000000u) s = failseg_join(s, FailSeg{0, 0, 1, 0});      // the pair opens its contig: the counter starts from zero
+            FailSeg one{m & 0x3fffffffu, 0, (m >> 31) ? 0u : 1u, 0};           // the pair's fails come before its outcome; a genomic read resets
             if (!one.R) one.S = one.P;                                          // no reset: everything is both prefix and suffix
-            s = (q4 + u == 0) ? one : failseg_join(s, one);
+            s = failseg_join(s, one);
         }
     }
     s = failseg_wave_join(s, 64);
@@ -807,9 +817,9 @@ __global__ void __launch_bounds__(256) k_failrule_a(const uint32_t *__restrict__
 // B, the batch epilogue (one wave): the block summaries are joined in order (64 lanes stage them through LDS, lane 0 joins) into the
 // segment of this batch alone -> counters[16..19]; behind the carry of the earlier batches (chain[1]) that gives the verdict
 // counters[20] = abort? and the carry out counters[21] = chain[1]; the running random-read count chain[0] moves on by counters[3].
-__global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t n_pairs, uint64_t *__restrict__ counters, uint64_t *__restrict__ chain)
+__global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ summ, uint32_t n_blocks, uint64_t n_pairs, uint32_t opens_contig, uint64_t *__restrict__ counters, uint64_t *__restrict__ chain)
 {
-    FailSeg t{0, 0, counters[3] < n_pairs ? 1u : 0u, 0};          // no failed attempt at all: any genomic read resets the counter
+    FailSeg t{0, 0, (counters[3] < n_pairs || opens_contig) ? 1u : 0u, 0};          // no failed attempt at all: any genomic read -- or the start of a contig inside the batch -- resets the counter
     if (counters[1] != 0) {                                       // lane k joins its slice of the block summaries, the wave joins the slices in order
         const uint32_t per = (n_blocks + 63) / 64, b0 = threadIdx.x * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
         FailSeg x{0, 0, 0, 0};
@@ -829,11 +839,11 @@ __global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ 
         chain[0] += counters[3];
     }
 }
-void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint64_t *summ, uint64_t *counters, uint64_t *chain)
+void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint32_t opens_contig, uint64_t *summ, uint64_t *counters, uint64_t *chain)
 {
     const uint32_t nb = cdiv(n_pairs, 256ull * FAIL_PAIRS_PER_THREAD);
     hipLaunchKernelGGL(k_failrule_a, dim3(nb), dim3(256), 0, st, meta, n_pairs, counters, summ);
-    hipLaunchKernelGGL(k_failrule_b, dim3(1), dim3(64), 0, st, summ, nb, n_pairs, counters, chain);
+    hipLaunchKernelGGL(k_failrule_b, dim3(1), dim3(64), 0, st, summ, nb, n_pairs, opens_contig, counters, chain);
 }
 // chain[0] (random reads before the next batch) and / or chain[1] (the abort rule's carry) set in stream order
 __global__ void __launch_bounds__(64) k_chain_set(uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry)
@@ -871,10 +881,10 @@ void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t 
     const uint64_t nb = (uint64_t)(l + SUMM_CELLS - 1) / SUMM_CELLS;
     if (nb) hipLaunchKernelGGL(k_summarize, dim3(cdiv(nb, 256)), dim3(256), 0, st, cells, l, summ);
 }
-void launch_place(hipStream_t st, const SimArgs &a)
+void launch_place(hipStream_t st, const SimArgs &a)      // a.segs / a.n_blocks laid out for PAIRS_PER_BLOCK pairs per block
 {
-    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_place<2>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK * 2), 0, st, a);
-    else hipLaunchKernelGGL(k_place<1>, dim3(cdiv(a.n_pairs, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), 0, st, a);
+    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_place<2>, dim3(a.n_blocks), dim3(PAIRS_PER_BLOCK * 2), 0, st, a);
+    else hipLaunchKernelGGL(k_place<1>, dim3(a.n_blocks), dim3(PAIRS_PER_BLOCK), 0, st, a);
 }
 // one launcher per (LPP, DT) family, each defined in its own part
 void launch_sim_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
@@ -891,7 +901,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
 {
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = (uint32_t)a.sim_threads;
-    const uint32_t nb = cdiv(a.n_pairs, nthr / (pe ? 2 : 1));
+    const uint32_t nb = a.n_blocks;                                  // a.segs is laid out for nthr / (pe ? 2 : 1) pairs per block
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
     const size_t lds = sim_lds_bytes((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables + the text FIFOs
     const bool solid = a.p.data_type == 1;

@@ -70,16 +70,19 @@ DW_DEV uint32_t site_hits8(RngKey key, uint32_t blk, uint64_t thr)      // bit k
     return lt;
 }
 // reset0 / reset1 (a contig that is walked AGAIN): the 16 cells of both haplotypes are set back to the reference on the way.
-__global__ void k_site_scan(const uint8_t *__restrict__ ref, int64_t l, WalkParams wp, uint32_t contig_index,
+__global__ void k_site_scan(const uint8_t *__restrict__ ref, SegTab seg, WalkParams wp,
                             uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count, uint8_t *__restrict__ reset0, uint8_t *__restrict__ reset1)
 {
     __shared__ uint32_t sm[17];
-    const RngKey key{wp.seed, contig_index};
-    const int64_t p0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    // a block's SCAN_POS_PER_BLOCK positions lie inside one contig of the group (contigs start at multiples of GROUP_ALIGN)
+    const uint32_t sk = seg_of(seg, (int64_t)blockIdx.x * SCAN_POS_PER_BLOCK);
+    const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
+    const int64_t g0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
+    const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];               // position inside the contig: what the draws are indexed by
     uint32_t bits = 0;
     if (p0 < l) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(ref + p0);      // ref is padded: reading past l is safe
-        if (reset0) { *reinterpret_cast<uint4 *>(reset0 + p0) = v; *reinterpret_cast<uint4 *>(reset1 + p0) = v; }
+        const uint4 v = *reinterpret_cast<const uint4 *>(ref + g0);      // ref is padded: reading past l is safe
+        if (reset0) { *reinterpret_cast<uint4 *>(reset0 + g0) = v; *reinterpret_cast<uint4 *>(reset1 + g0) = v; }
         const uint32_t in[4] = {v.x, v.y, v.z, v.w};
         uint32_t acgt = 0;                                               // positions that hold A, C, G or T (and lie inside the contig)
 #pragma unroll
@@ -123,18 +126,20 @@ __global__ void k_compact(const uint16_t *__restrict__ mask, const uint32_t *__r
 // ------------------------------------------------------------------------------------------------
 // K2a: one thread per candidate site: the event it would be if it is live.  mut.c:619-640, 287-308.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_events(const int32_t *__restrict__ cand, Count nc, const uint8_t *__restrict__ ref, int64_t l,
-                         WalkParams wp, uint32_t contig_index, Event *__restrict__ ev, uint32_t *__restrict__ max_del)
+__global__ void k_events(const int32_t *__restrict__ cand, Count nc, const uint8_t *__restrict__ ref, SegTab seg,
+                         WalkParams wp, Event *__restrict__ ev, uint32_t *__restrict__ max_del)
 {
     const uint32_t n_cand = count_of(nc);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_cand) {
-        const RngKey key{wp.seed, contig_index};
-        const int64_t p = cand[k];
-        const uint32_t c = ref[p];
-        const U4 b1 = rng_block(key, D_WALK, (uint64_t)p, 0, 0, 1);   // slots 2,3
-        const U4 b2 = rng_block(key, D_WALK, (uint64_t)p, 0, 0, 2);   // slots 4,5
-        Event e; e.pos = (int32_t)p; e.live = 1; e.len = 1; e.base = (uint8_t)c;
+        const int64_t g = cand[k];
+        const uint32_t sk = seg_of(seg, g);
+        const RngKey key{wp.seed, seg.cindex[sk]};
+        const int64_t p = g - seg.start[sk], l = seg.len[sk];          // position inside its contig
+        const uint32_t c = ref[g];
+        const U4 b1 = rng_block<false>(key, D_WALK, (uint64_t)p, 0, 0, 1);   // slots 2,3
+        const U4 b2 = rng_block<false>(key, D_WALK, (uint64_t)p, 0, 0, 2);   // slots 4,5
+        Event e; e.pos = (int32_t)g; e.live = 1; e.len = 1; e.base = (uint8_t)c; e.seg = sk;
         if (u_lo(b1) >= wp.indel_frac) {                 // substitution (mut.c:619-626)
             e.type = 1;
             e.base = (uint8_t)((c + (uint32_t)(uint64_t)(u_hi(b1) * 3.0 + 1)) & 3);
@@ -144,14 +149,14 @@ __global__ void k_events(const int32_t *__restrict__ cand, Count nc, const uint8
             e.hap = (wp.is_hap || u_lo(b2) < 0.3333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
             uint32_t len = 1;
             for (int64_t q = p + 1; q < l; ++q) {
-                if ((int64_t)len < wp.indel_min || rng_slot(key, D_WALK, (uint64_t)q, 0, 0) < wp.indel_extend) ++len; else break;
+                if ((int64_t)len < wp.indel_min || rng_slot<false>(key, D_WALK, (uint64_t)q, 0, 0) < wp.indel_extend) ++len; else break;
             }
             e.len = len;
             atomicMax(max_del, len);
         } else {                                         // insertion (mut.c:637-639 -> :287-308)
             e.type = 3;
             uint64_t num = 0; uint32_t kk = 0;
-            do { ++num; } while (num < 0xFFFFFFFFull && ((int64_t)num < wp.indel_min || rng_slot(key, D_WALK_INSLEN, (uint64_t)p, 0, kk++) < wp.indel_extend));
+            do { ++num; } while (num < 0xFFFFFFFFull && ((int64_t)num < wp.indel_min || rng_slot<false>(key, D_WALK_INSLEN, (uint64_t)p, 0, kk++) < wp.indel_extend));
             e.len = (uint32_t)num;
             e.hap = (wp.is_hap || u_lo(b2) < 0.333333) ? 3 : (u_hi(b2) < 0.5 ? 1 : 2);
         }
@@ -267,7 +272,8 @@ __global__ void k_apply(Event *ev, Count nc, const uint4 *flags, ContigDev c, Wa
             if (e.hap & 2) c.hap[1].cells[p + q] = v;
         }
     } else {
-        const RngKey key{wp.seed, c.contig_index};
+        const RngKey key{wp.seed, c.seg.cindex[e.seg]};
+        const uint64_t pl = (uint64_t)(p - c.seg.start[e.seg]);                  // position inside the contig: index of the draws
         const uint32_t idx[2] = {f.x & 0x7fffffffu, f.z}, off[2] = {f.y, f.w};
         for (int h = 0; h < 2; ++h) if (e.hap & (1 << h)) {
             c.hap[h].cells[p] = T_INS | e.base;
@@ -276,7 +282,7 @@ __global__ void k_apply(Event *ev, Count nc, const uint4 *flags, ContigDev c, Wa
             c.hap[h].ins_off[idx[h]] = off[h];
         }
         for (uint32_t j = 0; j < e.len; ++j) {      // draw j lands at printed index len-1-j (mut.c:313-315, :347-365 read by :249-279)
-            const uint8_t b = (uint8_t)(uint64_t)(rng_slot(key, D_WALK_INSBASE, (uint64_t)p, 0, j) * 4.0);
+            const uint8_t b = (uint8_t)(uint64_t)(rng_slot<false>(key, D_WALK_INSBASE, pl, 0, j) * 4.0);
             if (e.hap & 1) c.hap[0].ins_bases[off[0] + e.len - 1 - j] = b;
             if (e.hap & 2) c.hap[1].ins_bases[off[1] + e.len - 1 - j] = b;
         }
@@ -288,13 +294,14 @@ __global__ void k_apply(Event *ev, Count nc, const uint4 *flags, ContigDev c, Wa
 // and unmutated (non-N) positions merely reset prev_del, so the walk visits the live events'
 // original footprints in order and treats the gaps between them in O(1).
 // ------------------------------------------------------------------------------------------------
-DW_DEV void justify_ins(HapDev &h, int64_t i)          // mut.c:427-478
+// [lo, hi): the group coordinates of the contig the position belongs to (the reference's 0 and seq->l)
+DW_DEV void justify_ins(HapDev &h, int64_t i, int64_t lo)          // mut.c:427-478
 {
     const uint32_t idx = ins_find(h, i);
     const uint32_t n = h.ins_len[idx];
     uint8_t *P = h.ins_bases + h.ins_off[idx];
     int64_t j = i;
-    while (j > 0 && (h.cells[j - 1] & TMASK) == T_NONE && P[n - 1] == (h.cells[j - 1] & 3)) {
+    while (j > lo && (h.cells[j - 1] & TMASK) == T_NONE && P[n - 1] == (h.cells[j - 1] & 3)) {
         for (uint32_t t = n - 1; t > 0; --t) P[t] = P[t - 1];
         P[0] = h.cells[j - 1] & 3;
         h.cells[j] = h.cells[j] & 3;
@@ -313,7 +320,7 @@ DW_DEV int64_t del_run(const HapDev &h, int64_t i, int64_t l)
     for (int64_t j = i + 1; j < l && (h.cells[j] & TMASK) == T_DEL; ++j) ++dl;
     return dl;
 }
-DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
+DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del, int64_t lo, int64_t hi)
 {
     if (c.ref[i] >= 4) return;
     HapDev &h0 = c.hap[0], &h1 = c.hap[1];
@@ -324,16 +331,16 @@ DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
         else if ((c1 & TMASK) == T_DEL) {
             if (prev_del[0] == 1 || prev_del[1] == 1) return;
             prev_del[0] = prev_del[1] = 1;
-            const int64_t dl = del_run(h0, i, c.l);
-            if (c.l <= i + dl) return;
-            if (i > 0) for (int64_t j = i - 1;; --j) {
+            const int64_t dl = del_run(h0, i, hi);
+            if (hi <= i + dl) return;
+            if (i > lo) for (int64_t j = i - 1;; --j) {
                 const uint8_t a = h0.cells[j], b = h1.cells[j];
                 if ((a & TMASK) != T_INS && (b & TMASK) != T_INS && (a & TMASK) != T_DEL && (b & TMASK) != T_DEL
                     && (a & 3) == (h0.cells[j + dl] & 3) && (b & 3) == (h1.cells[j + dl] & 3)) { del_swap(h0, j, dl); del_swap(h1, j, dl); }
                 else break;
-                if (j == 0) break;
+                if (j == lo) break;
             }
-        } else { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); justify_ins(h1, i); }
+        } else { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i, lo); justify_ins(h1, i, lo); }
     } else {
         if ((c1 & TMASK) == T_SUB || (c2 & TMASK) == T_SUB) { prev_del[0] = prev_del[1] = 0; }
         else if ((c1 & TMASK) == T_DEL || (c2 & TMASK) == T_DEL) {
@@ -341,15 +348,15 @@ DW_DEV void justify_visit(ContigDev &c, int64_t i, int *prev_del)
             if (prev_del[x] == 1) return;
             prev_del[x] = 1;
             HapDev &h = c.hap[x];
-            const int64_t dl = del_run(h, i, c.l);
-            if (c.l <= i + dl) return;
-            if (i > 0) for (int64_t j = i - 1;; --j) {
+            const int64_t dl = del_run(h, i, hi);
+            if (hi <= i + dl) return;
+            if (i > lo) for (int64_t j = i - 1;; --j) {
                 const uint8_t a = h.cells[j];
                 if ((a & TMASK) == T_NONE && (a & 3) == (h.cells[j + dl] & 3)) del_swap(h, j, dl); else break;
-                if (j == 0) break;
+                if (j == lo) break;
             }
-        } else if ((c1 & TMASK) == T_INS) { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i); }
-        else { prev_del[0] = prev_del[1] = 0; justify_ins(h1, i); }
+        } else if ((c1 & TMASK) == T_INS) { prev_del[0] = prev_del[1] = 0; justify_ins(h0, i, lo); }
+        else { prev_del[0] = prev_del[1] = 0; justify_ins(h1, i, lo); }
     }
 }
 // sequential cross-check (DWGSIM_HIP_JUSTIFY=seq): one thread walks every live event of the contig
@@ -359,14 +366,16 @@ __global__ void k_justify_seq(const Event *ev, Count nc, ContigDev c)
     adopt_device_sizes(c);
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int prev_del[2] = {0, 0};
-    int64_t last = -1;
+    int64_t last = -1; uint32_t cur = 0xFFFFFFFFu;
     for (uint32_t k = 0; k < n_cand; ++k) {
         const Event e = ev[k];
         if (!e.live) continue;
+        const int64_t lo = c.seg.start[e.seg], hi = lo + c.seg.len[e.seg];
+        if (e.seg != cur) { cur = e.seg; prev_del[0] = prev_del[1] = 0; last = lo - 1; }      // every contig is justified on its own (mut.c:481-489)
         const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
         if (prev_del[0] | prev_del[1])
             for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
-        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
+        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del, lo, hi);
         last = right;
     }
 }
@@ -381,19 +390,19 @@ __global__ void k_justify_seq(const Event *ev, Count nc, ContigDev c)
 // can reach the previous live event's footprint and an unmutated non-N position separates them
 // (prev_del is then 0, mut.c:585-587).  (4) k_jrun: one thread per cluster replays the exact
 // sequential semantics (justify_visit) over its events; clusters touch disjoint cells.
-DW_DEV int64_t reach_del(const ContigDev &c, int h, int64_t p)
+DW_DEV int64_t reach_del(const ContigDev &c, int h, int64_t p, int64_t lo, int64_t hi)
 {
     // period = the run of DELETE cells the sequential pass would measure at p (adjacent runs merge,
     // mut.c:503 / :535 / :557) on haplotype h
-    const int64_t L = del_run(c.hap[h], p, c.l);
+    const int64_t L = del_run(c.hap[h], p, hi);
     int64_t j = p - 1;
-    for (; j >= 0; --j) {
+    for (; j >= lo; --j) {
         const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
-        if (!(mutated || (p + L < c.l && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
+        if (!(mutated || (p + L < hi && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
     }
-    return j < 0 ? 0 : j;                              // last cell read
+    return j < lo ? lo : j;                            // last cell read
 }
-DW_DEV int64_t reach_ins(const ContigDev &c, int h, int64_t p)
+DW_DEV int64_t reach_ins(const ContigDev &c, int h, int64_t p, int64_t lo)
 {
     const uint32_t idx = ins_find(c.hap[h], p);
     const uint32_t n = c.hap[h].ins_len[idx];
@@ -401,12 +410,12 @@ DW_DEV int64_t reach_ins(const ContigDev &c, int h, int64_t p)
     // rotating left by one makes the cell's base the new first base: after r rotations the last
     // inserted base is P[n-1-r] while r < n, then ref[p-1-(r-n)] & 3 (bases rotated in earlier)
     int64_t j = p - 1; int64_t r = 0;
-    for (; j >= 0; --j, ++r) {
+    for (; j >= lo; --j, ++r) {
         const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
         const uint32_t last = r < (int64_t)n ? (uint32_t)P[n - 1 - r] : (uint32_t)(c.ref[p - 1 - (r - n)] & 3);
         if (!(mutated || last == (uint32_t)(c.ref[j] & 3))) break;
     }
-    return j < 0 ? 0 : j;
+    return j < lo ? lo : j;
 }
 __global__ void k_jreach(const Event *__restrict__ ev, Count nc, ContigDev c, int32_t *__restrict__ lo)
 {
@@ -417,15 +426,15 @@ __global__ void k_jreach(const Event *__restrict__ ev, Count nc, ContigDev c, in
     const Event e = ev[k];
     int64_t reach = 0x7fffffff;
     if (e.live) {
-        const int64_t p = e.pos;
+        const int64_t p = e.pos, lo = c.seg.start[e.seg], hi = lo + c.seg.len[e.seg];
         reach = p;                                      // substitution: no scan; it only matters as a neighbour (prev_del)
-        if (e.type == 2) reach = reach_del(c, (e.hap & 1) ? 0 : 1, p);         // haplotype 1 for hom and hap-1 events
-        else if (e.type == 3) reach = reach_ins(c, (e.hap & 1) ? 0 : 1, p);    // both copies carry the same bases before justification
+        if (e.type == 2) reach = reach_del(c, (e.hap & 1) ? 0 : 1, p, lo, hi);         // haplotype 1 for hom and hap-1 events
+        else if (e.type == 3) reach = reach_ins(c, (e.hap & 1) ? 0 : 1, p, lo);        // both copies carry the same bases before justification
         else if (e.type == 4) {                         // cell patched from a mutation-input file: whatever the two cells hold
             for (int h = 0; h < 2; ++h) {
                 const uint8_t t = c.hap[h].cells[p] & TMASK;
                 int64_t r = p;
-                if (t == T_DEL) r = reach_del(c, h, p); else if (t == T_INS) r = reach_ins(c, h, p);
+                if (t == T_DEL) r = reach_del(c, h, p, lo, hi); else if (t == T_INS) r = reach_ins(c, h, p, lo);
                 if (r < reach) reach = r;
             }
         }
@@ -475,7 +484,7 @@ __global__ void k_jbound(const Event *__restrict__ ev, Count nc, ContigDev c, co
     if (ev[k].live) {
         int64_t a = (int64_t)k - 1;
         while (a >= 0 && !ev[a].live) --a;
-        if (a < 0) b = 1;
+        if (a < 0 || ev[a].seg != ev[k].seg) b = 1;       // the first live event of a contig: every contig is justified on its own
         else {
             const int64_t right_a = (int64_t)ev[a].pos + (ev[a].type == 2 ? (int64_t)ev[a].len - 1 : 0);
             if ((int64_t)sufmin[k] > right_a) {
@@ -498,9 +507,10 @@ __global__ void k_jrun(const Event *__restrict__ ev, Count nc, ContigDev c, cons
         if (!e.live) continue;
         if (k > k0 && bound[k]) break;
         const int64_t p = e.pos, right = p + (e.type == 2 ? (int64_t)e.len - 1 : 0);
+        const int64_t lo = c.seg.start[e.seg], hi = lo + c.seg.len[e.seg];      // (a cluster never spans two contigs: k_jbound)
         if (k > k0 && (prev_del[0] | prev_del[1]))      // an unmutated non-N position in the gap resets prev_del (mut.c:585-587)
             for (int64_t q = last + 1; q < p; ++q) if (c.ref[q] < 4) { prev_del[0] = prev_del[1] = 0; break; }
-        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del);
+        for (int64_t i = p; i <= right; ++i) justify_visit(c, i, prev_del, lo, hi);
         last = right;
     }
 }
@@ -530,10 +540,12 @@ __global__ void k_collect_mask(const uint8_t *__restrict__ h0, const uint8_t *__
     (void)block_excl_scan((uint32_t)__popc(bits), sm, &total);
     if (threadIdx.x == 0) block_count[blockIdx.x] = total;
 }
-__global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, uint16_t *__restrict__ cells)
+// per listed position: haplotype-1 cell | haplotype-2 cell << 8 | reference code << 16 | reference code of the position in front << 24 (the text writer
+// needs no host copy of the sequence; a position that opens its contig finds the N of the padding in front of it and never prints it)
+__global__ void k_gather(const int32_t *__restrict__ pos, uint32_t n, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ h0, const uint8_t *__restrict__ h1, uint32_t *__restrict__ cells)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) cells[k] = (uint16_t)(h0[pos[k]] | (h1[pos[k]] << 8));
+    if (k < n) { const int32_t p = pos[k]; cells[k] = (uint32_t)h0[p] | ((uint32_t)h1[p] << 8) | ((uint32_t)ref[p] << 16) | ((uint32_t)(p > 0 ? ref[p - 1] : 4) << 24); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,9 +557,9 @@ void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0
     uint32_t nb = cdiv(nchunk, 256); if (nb > (1u << 16)) nb = 1u << 16; if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, ascii, ref, h0, h1, l);
 }
-void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1)
+void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg, WalkParams wp, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1)
 {
-    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, l, wp, contig_index, mask, block_count, reset0, reset1);
+    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, seg, wp, mask, block_count, reset0, reset1);
 }
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out)
 {
@@ -558,9 +570,9 @@ void launch_compact(hipStream_t st, const uint16_t *mask, const uint32_t *block_
     hipLaunchKernelGGL(k_compact, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, mask, block_base, out, cap);
 }
 // The launchers below size their grids for n.host elements (an exact count or a capacity); the kernels work on min(*n.dev, n.host).
-void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, int64_t l, WalkParams wp, uint32_t contig_index, Event *ev, uint32_t *max_del)
+void launch_events(hipStream_t st, const int32_t *cand, Count n, const uint8_t *ref, SegTab seg, WalkParams wp, Event *ev, uint32_t *max_del)
 {
-    if (n.host) hipLaunchKernelGGL(k_events, dim3(cdiv(n.host, 256)), dim3(256), 0, st, cand, n, ref, l, wp, contig_index, ev, max_del);
+    if (n.host) hipLaunchKernelGGL(k_events, dim3(cdiv(n.host, 256)), dim3(256), 0, st, cand, n, ref, seg, wp, ev, max_del);
 }
 void launch_resolve(hipStream_t st, Event *ev, Count n, const uint32_t *max_del, uint4 *flags, uint32_t *tot4)
 {
@@ -657,9 +669,9 @@ void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, i
 {
     hipLaunchKernelGGL(k_collect_mask, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, h0, h1, l, mask, block_count);
 }
-void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *h0, const uint8_t *h1, uint16_t *cells)
+void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *ref, const uint8_t *h0, const uint8_t *h1, uint32_t *cells)
 {
-    if (n) hipLaunchKernelGGL(k_gather, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, n, h0, h1, cells);
+    if (n) hipLaunchKernelGGL(k_gather, dim3(cdiv(n, 256)), dim3(256), 0, st, pos, n, ref, h0, h1, cells);
 }
 
 } // namespace dw

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DWGSIM_HIP_ABI_VERSION 2
+#define DWGSIM_HIP_ABI_VERSION 3
 
 /* error codes (negative) */
 #define DWGSIM_HIP_OK            0
@@ -78,7 +78,7 @@ typedef struct dwgsim_hip_batch {
     uint64_t n_retries;        /* rejected attempts (N filter / walk off the contig, dwgsim.c:833-842) */
     uint64_t bytes[3];         /* finished FASTQ text bytes per stream (0 if the stream is disabled) */
     const void *dev_ptr[3];    /* device addresses of the packed text (valid until the slot is reused) */
-    float    kernel_ms;        /* HIP-event time of the batch's kernels on the context's stream */
+    float    kernel_ms;        /* HIP-event time of the batch's kernels on the context's stream (simulate_pairs, the abort-rule epilogue, the gzip kernels) */
     float    sim_kernel_ms;    /* ... of the dominant kernel (simulate_pairs) alone */
     /* The reference's abort rule (one counter of failed attempts over the pairs of a contig, reset by every genomic read, fatal above
      * 10 000: dwgsim.c:635, :833-843) as a mergeable summary of THIS batch alone: {fails before its first reset (all of them if it has
@@ -121,6 +121,19 @@ int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *ctx, const char *name, const uint8_t
                           uint32_t contig_index);
 int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *ctx, int contig);
 
+/* Several contigs at once -- a GROUP.  The reference's contig loop (dwgsim.c:519-625) costs nothing per contig beyond a calloc; here a contig
+ * that is added alone costs a chain of walk kernels, a launch and a host synchronisation of its own, which a scaffold-level assembly (10^3-10^5
+ * contigs) cannot afford.  The contigs of one call are resident together: dwgsim_hip_mutate_contig on any of them walks all of them with ONE
+ * chain of kernels, and read-index ranges of several of them can be simulated by ONE launch (dwgsim_hip_simulate_ranges_async).  Returns the
+ * handle of the first contig; contig k of the call has handle + k.  dwgsim_hip_drop_contig on any of them releases the whole group.
+ * Upload: if the n buffers already are the group layout inside one page-locked allocation (dwgsim_hip_host_alloc; ascii[k] == ascii[0] +
+ * starts[k] of dwgsim_hip_group_layout, zero bytes between the contigs) the copy is asynchronous and the buffers must stay unchanged until
+ * dwgsim_hip_mutate_wait returned for the group; any other buffers may be released when the call returns. */
+int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *ctx, int n, const char *const *names, const uint8_t *const *ascii, const int64_t *lens,
+                           const uint32_t *contig_index);
+/* Where the contigs of a group lie in its coordinate space: starts[k] (optional) = first byte of contig k; returns the total size. */
+int64_t dwgsim_hip_group_layout(const int64_t *lens, int n, int64_t *starts);
+
 /* Replaces regions_bed_init() (src/regions_bed.c:38-125, dwgsim.c:499-506): target regions (-x).  names/lens as for
  * dwgsim_hip_set_mutation_input.  *total_len receives the summed region length (the reference's tot_len, dwgsim.c:502-505).
  * Call before add_contig. */
@@ -145,6 +158,11 @@ int dwgsim_hip_set_mutation_input(dwgsim_hip_ctx_t *ctx, int type, const char *p
 /* Replaces mut_diref() random branch + mut_left_justify() (mut.c:591-643, :481-589): builds the
  * two mutated haplotypes of the contig in HBM. */
 int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *ctx, int contig);
+/* The same in two halves (the walk runs on a stream of its own: a group can be uploaded and walked while batches of another group are being
+ * simulated): mutate_async enqueues, mutate_wait blocks until the haplotypes are finished and reports the walk's errors.  `contig` = any
+ * contig of the group; the whole group is walked. */
+int dwgsim_hip_mutate_async(dwgsim_hip_ctx_t *ctx, int contig);
+int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *ctx, int contig);
 
 /* Replaces mut_print() (mut.c:781-893): the mutations.txt and mutations.vcf BODY lines of this
  * contig.  Buffers are owned by the context and valid until the next call for any contig. */
@@ -155,6 +173,11 @@ int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *ctx, int contig, const char **tx
  * rand_ii is a running count over all earlier pairs, dwgsim.c:1042,1096). */
 int dwgsim_hip_count_random(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
                             uint64_t *n_random);
+
+/* A read-index range of one contig.  A call that takes several of them covers them in the order given (= file order); they must belong to
+ * contigs of one group. */
+typedef struct dwgsim_hip_range { int32_t contig; int32_t reserved; uint64_t first_ii, n_pairs; } dwgsim_hip_range_t;
+int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *ctx, const dwgsim_hip_range_t *ranges, int n_ranges, uint64_t *n_random);
 
 /* Replaces the loop body dwgsim.c:636-1099 for the read-index range [first_ii, first_ii+n_pairs)
  * of one contig.  rand_base = number of random reads emitted before first_ii (over all contigs).
@@ -171,6 +194,10 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, ui
 int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
                               uint64_t rand_base, int slot);
 int dwgsim_hip_wait(dwgsim_hip_ctx_t *ctx, int slot, dwgsim_hip_batch_t *out);
+/* ... for several ranges at once: one launch, one contiguous piece of every output stream (the loop dwgsim.c:519-1099 over several
+ * contigs).  The abort rule's counter starts from zero wherever a range begins its contig (first_ii == 0), as `int num_failed = 0` does at
+ * dwgsim.c:635; rand_base counts the random reads in front of the first range. */
+int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *ctx, const dwgsim_hip_range_t *ranges, int n_ranges, uint64_t rand_base, int slot);
 
 /* The failure counter carried into the next simulate call (default: the previous batch's counter when the call continues the
  * same contig at the next read index, else 0).  For sharded jobs: the carry out of the preceding shard. */
@@ -212,6 +239,8 @@ int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int
 
 /* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);
+/* HIP devices visible to the process (0 without a GPU). */
+int dwgsim_hip_device_count(void);
 
 #ifdef __cplusplus
 }

@@ -31,14 +31,14 @@ def first_diff(a: bytes, b: bytes):
 IN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs")
 
 
-def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22, debug_options=None):
+def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22, debug_options=None, group_bp=0):
     """Returns the JobResult; raises AssertionError with a readable diff on any mismatch."""
     flags = flags.replace("{IN}", IN_DIR)
     with tempfile.TemporaryDirectory() as t:
         want = run_oracle(oracle_bin, fasta, flags, t)
     params = api.parse_flags(flags, lib)
     contigs = api.read_fasta(fasta)
-    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib, debug_options=debug_options)
+    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib, debug_options=debug_options, group_bp=group_bp)
     assert res.mutations_txt == want["txt"], "mutations.txt: " + first_diff(res.mutations_txt, want["txt"])
     assert res.mutations_vcf == want["vcf"], "mutations.vcf: " + first_diff(res.mutations_vcf, want["vcf"])
     for k in STREAMS:
@@ -181,14 +181,14 @@ def check_count_random_matches_simulate(lib, fasta, flags, ranges=((0, None), (1
     assert checked > 0
 
 
-def check_both_abort(lib, oracle_bin, fasta, flags):
+def check_both_abort(lib, oracle_bin, fasta, flags, group_bp=0):
     """Jobs the reference gives up on ("failed to generate a read after 10001 trials", dwgsim.c:833-843: one counter of failed attempts
     over the pairs of a contig, reset only by a genomic read): the oracle exits non-zero and the HIP path must return the same error."""
     with tempfile.TemporaryDirectory() as t:
         r = subprocess.run([oracle_bin, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, text=True)
     assert r.returncode != 0 and "failed to generate a read" in r.stderr, r.stderr[-300:]
     try:
-        api.run_job(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib)
+        api.run_job(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib, group_bp=group_bp)
     except api.DwgsimError as e:
         assert "failed to generate a read after 10001 trials" in str(e), str(e)
         return

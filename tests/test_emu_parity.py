@@ -40,6 +40,67 @@ def test_kernel_logic_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, f
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=700)
 
 
+GROUPED_CASES = [      # the same jobs with all contigs resident together (one walk chain, batches that run across contig boundaries)
+    ("ex1.fa", "-z 13 -N 1500"),
+    ("tiny.fa", "-z 4 -N 1200 -r 0.02 -R 0.5 -I 30 -X 0.6"),
+    ("odd.fa", "-z 3 -N 1200 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50"),
+    ("tiny.fa", "-z 9 -C 4 -2 0 -n 2 -y 0.3 -P pfx"),
+    ("tiny.fa", "-z 9 -N 400 -c 2 -f TACG -1 100 -2 60 -e 0.2 -E 0.1 -d 300 -o 1"),
+    ("tiny.fa", "-z 8 -N 700 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1"),
+    ("tiny.fa", "-z 5 -N 600 -m {IN}/muts_edge.txt"),
+    ("tiny.fa", "-z 5 -N 600 -b {IN}/muts_edge.bed"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 700"),
+    ("tiny.fa", "-z 5 -x {IN}/regions_b.bed -C 4 -d 200 -s 10 -1 50 -2 50 -n 5"),
+]
+
+
+@pytest.mark.parametrize("fasta,flags", GROUPED_CASES, ids=[f"{f}:{fl}" for f, fl in GROUPED_CASES])
+def test_contigs_resident_together_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags):
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=333, group_bp=1 << 30)
+
+
+def write_many_contigs(path, n, seed, repeats=True):
+    """n short contigs: random bases with homopolymers / tandem repeats (left-justification runs into contig ends) and N runs; some are
+    too short to be simulated at all (skip rules), lengths are not multiples of anything"""
+    import random
+    rnd = random.Random(seed)
+    with open(path, "w") as f:
+        for k in range(n):
+            l = rnd.choice([60, 150, 333, 700, 1024, 1500, 2100, 4096, 4097])
+            seq = [rnd.choice("ACGT") for _ in range(l)]
+            pos = 0
+            while repeats and pos < l - 40:
+                pos += rnd.randrange(10, 200)
+                unit = rnd.choice(["A", "T", "CA", "GGC", "N"])
+                reps = rnd.randrange(3, 25)
+                for q, ch in enumerate((unit * reps)[: max(0, l - pos)]):
+                    seq[pos + q] = ch
+                pos += len(unit) * reps
+            if k % 7 == 3:
+                seq[:9] = "AAAAAAAAA"          # a homopolymer at the very start: shifts that would run off the contig
+            if k % 5 == 2:
+                seq[-7:] = "TTTTTTT"
+            f.write(f">ctg{k}_{l}\n")
+            for q in range(0, l, 61):
+                f.write("".join(seq[q:q + 61]) + "\n")
+
+
+@pytest.mark.parametrize("flags,group_bp", [
+    ("-z 11 -C 6 -1 50 -2 50 -d 200 -s 15 -r 0.03 -R 0.6 -X 0.6 -n 8 -y 0.1", 1 << 30),
+    ("-z 12 -N 4000 -1 60 -2 40 -d 220 -s 10 -r 0.05 -R 0.9 -X 0.7 -I 2 -n 20", 9000),         # several groups, -N remainder on the last contig
+    ("-z 13 -C 3 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 80 -2 0 -e 0.02 -n 5 -r 0.02 -R 0.5", 1 << 30),
+    ("-z 14 -C 3 -c 1 -1 40 -2 40 -d 150 -s 10 -r 0.04 -R 0.5 -n 10 -o 0", 20000),
+])
+def test_many_small_contigs_on_cpu_emulation(emu_lib, oracle_bin, tmp_path, flags, group_bp):
+    """A scaffold-like job (dwgsim.c:519-625 loops over any number of contigs): 60 short contigs in groups -- one walk chain per group, the
+    justification clusters, deletion runs and read windows must stop at every contig's own ends, read names, rand_ii and the abort rule's
+    per-contig counter run on across the batch."""
+    fa = str(tmp_path / "many.fa")
+    write_many_contigs(fa, 60, seed=len(flags))
+    compare_case(emu_lib, oracle_bin, fa, flags, batch_pairs=500, group_bp=group_bp)
+    compare_case(emu_lib, oracle_bin, fa, flags, batch_pairs=1 << 20, group_bp=group_bp, debug_options={"justify_seq": 1})
+
+
 def test_read_names_tell_the_truth_on_cpu_emulation(emu_lib, golden_dir):
     """Oracle-independent check of the name contract (see parity_common.check_read_names_tell_the_truth)."""
     from parity_common import check_read_names_tell_the_truth
@@ -85,6 +146,25 @@ def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):
     check_both_abort(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 1200 -r 0 -e 0.0-0.1 -Q 0 -a")
     # ... while the same job with fewer pairs stays under the limit and must match byte for byte
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 600 -r 0 -e 0.0-0.1 -Q 0 -a", batch_pairs=100)
+
+
+def test_abort_rule_counts_per_contig_inside_a_group(emu_lib, oracle_bin, golden_dir, tmp_path):
+    """`int num_failed = 0` sits inside the contig loop (dwgsim.c:635): a job whose failures add up to more than 10 000 over TWO contigs, but
+    not inside either, runs to the end.  With both contigs in one group -- one launch across the boundary -- the counter must still start
+    again at the second contig; and it must still abort when one contig alone passes the limit."""
+    from parity_common import check_both_abort
+    src = api.read_fasta(os.path.join(golden_dir, "odd.fa"))
+    fa = str(tmp_path / "twice.fa")
+    with open(fa, "w") as f:
+        for tag in ("a", "b"):
+            for name, arr in src:
+                if name != "tiny":
+                    f.write(f">{name}{tag}\n{bytes(arr).decode()}\n")
+    flags = "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 1600 -r 0 -e 0.0-0.1 -Q 0 -a"
+    res = compare_case(emu_lib, oracle_bin, fa, flags, batch_pairs=1 << 20, group_bp=1 << 30)
+    assert res.n_retries > 10000
+    compare_case(emu_lib, oracle_bin, fa, flags, batch_pairs=250, group_bp=1 << 30)
+    check_both_abort(emu_lib, oracle_bin, fa, flags.replace("-N 1600", "-N 2400"), group_bp=1 << 30)
 
 
 def test_hopeless_target_regions_end_with_an_error(emu_lib, golden_dir, tmp_path):

@@ -20,6 +20,43 @@ def test_bit_exact_vs_oracle(lib, oracle_bin, golden_dir, fasta, flags):
     compare_case(lib, oracle_bin, os.path.join(golden_dir, fasta), flags)
 
 
+GROUPABLE = [c for c in CASES if " -B" not in c[1] and "-1 1500" not in c[1] and "-1 1300" not in c[1] and "-1 1400" not in c[1]]
+
+
+@pytest.mark.parametrize("fasta,flags", GROUPABLE, ids=[f"{f}:{fl}" for f, fl in GROUPABLE])
+def test_bit_exact_vs_oracle_with_the_contigs_resident_together(lib, oracle_bin, golden_dir, fasta, flags):
+    """The same option surface with all contigs of the FASTA in ONE group (dwgsim_hip_add_contigs): one chain of walk kernels for all of
+    them, batches of 777 pairs that run across the contig boundaries (dwgsim_hip_simulate_ranges_async)."""
+    compare_case(lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=777, group_bp=1 << 30)
+
+
+@pytest.fixture(scope="module")
+def many_fa(tmp_path_factory):
+    from test_emu_parity import write_many_contigs
+    p = str(tmp_path_factory.mktemp("many") / "many.fa")
+    write_many_contigs(p, 200, seed=77)
+    return p
+
+
+@pytest.mark.parametrize("flags,group_bp,batch", [
+    ("-z 11 -C 20 -1 50 -2 50 -d 200 -s 15 -r 0.03 -R 0.6 -X 0.6 -n 8 -y 0.1", 1 << 30, 1 << 22),
+    ("-z 12 -N 60000 -1 60 -2 40 -d 220 -s 10 -r 0.05 -R 0.9 -X 0.7 -I 2 -n 20", 50000, 4099),      # several groups, -N remainder on the last contig
+    ("-z 13 -C 10 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 80 -2 0 -e 0.02 -n 5 -r 0.02 -R 0.5", 1 << 30, 1 << 22),
+    ("-z 14 -C 10 -c 1 -1 40 -2 40 -d 150 -s 10 -r 0.04 -R 0.5 -n 10 -o 0", 100000, 1 << 22),
+    ("-z 15 -C 15 -1 150 -2 150 -o 1", 1 << 30, 1 << 22),
+])
+def test_two_hundred_small_contigs(lib, oracle_bin, many_fa, flags, group_bp, batch):
+    """A scaffold-like job (dwgsim.c:519-625 loops over any number of contigs at no fixed cost): 200 short contigs in groups, every byte as
+    the oracle writes it -- left-justification, deletion runs and read windows stop at every contig's own ends; read names, rand_ii and the
+    abort rule's per-contig counter run on across a launch."""
+    compare_case(lib, oracle_bin, many_fa, flags, batch_pairs=batch, group_bp=group_bp)
+
+
+def test_abort_rule_counts_per_contig_inside_a_group(lib, oracle_bin, golden_dir, tmp_path):
+    from test_emu_parity import test_abort_rule_counts_per_contig_inside_a_group as body
+    body(lib, oracle_bin, golden_dir, tmp_path)
+
+
 def test_batches_and_shards_are_order_independent(lib, oracle_bin, golden_dir):
     """Read-index ranges are independent: tiny batches (many simulate() calls, rand_base chained by the
     host) give the same bytes as one call -- the property multi-GPU sharding relies on."""
