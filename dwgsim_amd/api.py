@@ -42,6 +42,21 @@ class Range(C.Structure):
     _fields_ = [("contig", C.c_int32), ("reserved", C.c_int32), ("first_ii", C.c_uint64), ("n_pairs", C.c_uint64)]
 
 
+MUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
+READS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int)
+MSG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+
+
+class JobSink(C.Structure):
+    """dwgsim_hip_job_sink_t"""
+    _fields_ = [("user", C.c_void_p), ("mutations", MUT_CB), ("reads", READS_CB), ("message", MSG_CB)]
+
+
+class JobOptions(C.Structure):
+    """dwgsim_hip_job_options_t"""
+    _fields_ = [("gzip", C.c_int32), ("quiet", C.c_int32), ("batch_pairs", C.c_uint64), ("group_bp", C.c_uint64), ("min_share", C.c_uint64)]
+
+
 RAND_CHAIN = (1 << 64) - 1        # DWGSIM_HIP_RAND_CHAIN
 
 
@@ -53,6 +68,8 @@ EXPORTS = [
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
     "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
+    "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig",
+    "dwgsim_hip_job_finish", "dwgsim_hip_job_last_error", "dwgsim_hip_job_destroy",
     "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
 ]
 
@@ -85,9 +102,21 @@ def load(path: str | None = None):
     lib.dwgsim_hip_group_layout.argtypes = [P(C.c_int64), C.c_int, P(C.c_int64)]
     lib.dwgsim_hip_mutate_async.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_mutate_wait.argtypes = [C.c_void_p, C.c_int]
-    lib.dwgsim_hip_count_random_ranges.argtypes = [C.c_void_p, P(Range), C.c_int, P(C.c_uint64)]
+    lib.dwgsim_hip_count_random_ranges.argtypes = [C.c_void_p, P(Range), C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.dwgsim_hip_simulate_ranges_async.argtypes = [C.c_void_p, P(Range), C.c_int, C.c_uint64, C.c_int]
     lib.dwgsim_hip_device_count.argtypes = []
+    lib.dwgsim_hip_job_create.restype = C.c_void_p
+    lib.dwgsim_hip_job_create.argtypes = [P(Params), P(C.c_int), C.c_int, P(JobSink), P(JobOptions), P(C.c_int)]
+    lib.dwgsim_hip_job_set_contig_table.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_int64), C.c_int]
+    lib.dwgsim_hip_job_set_regions.argtypes = [C.c_void_p, C.c_char_p]
+    lib.dwgsim_hip_job_set_mutation_input.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    lib.dwgsim_hip_job_prepare.argtypes = [C.c_void_p, P(C.c_uint64)]
+    lib.dwgsim_hip_job_add_contig.restype = C.c_int64
+    lib.dwgsim_hip_job_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.dwgsim_hip_job_finish.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_job_last_error.restype = C.c_char_p
+    lib.dwgsim_hip_job_last_error.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_job_destroy.argtypes = [C.c_void_p]
     lib.dwgsim_hip_set_regions.argtypes = [C.c_void_p, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int, P(C.c_uint64)]
     lib.dwgsim_hip_contig_region_length.restype = C.c_int64
     lib.dwgsim_hip_contig_region_length.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
@@ -298,11 +327,12 @@ class Context:
             arr[k].contig, arr[k].first_ii, arr[k].n_pairs = cid, first, n
         return arr
 
-    def count_random_ranges(self, ranges) -> int:
+    def count_random_ranges(self, ranges, per_range: bool = False):
         """ranges: [(contig handle, first read index, pairs)] in file order, contigs of one group"""
         n = C.c_uint64(0)
-        self._chk(self.lib.dwgsim_hip_count_random_ranges(self.h, self._ranges(ranges), len(ranges), C.byref(n)))
-        return n.value
+        per = (C.c_uint64 * len(ranges))() if per_range else None
+        self._chk(self.lib.dwgsim_hip_count_random_ranges(self.h, self._ranges(ranges), len(ranges), C.byref(n), per))
+        return list(per) if per_range else n.value
 
     def simulate_ranges_async(self, ranges, rand_base: int = RAND_CHAIN, slot: int = 0):
         self._chk(self.lib.dwgsim_hip_simulate_ranges_async(self.h, self._ranges(ranges), len(ranges), rand_base, slot))
@@ -529,4 +559,75 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
     res.mutations_txt = bytes(txt)
     res.mutations_vcf = bytes(vcf)
     res.streams = {k: bytes(v) for k, v in res.streams.items()}
+    return res
+
+
+def run_job_api(params: Params, contigs, devices=None, gzip_on_gpu: bool = True, batch_pairs: int = 0, group_bp: int = 0, min_share: int = 0,
+                lib=None, keep_output: bool = True) -> JobResult:
+    """The same job through the JOB level of the C-ABI (dwgsim_hip_job_*): the library schedules, groups, shards over `devices`
+    (default: all) and delivers in file order; the sink below only collects.  Streams are returned as text (gzip members are
+    decompressed here)."""
+    import gzip as _gz
+    import numpy as np
+    lib = lib or load()
+    res = JobResult(streams={0: bytearray(), 1: bytearray(), 2: bytearray()})
+    raw = {0: [], 1: [], 2: []}
+    txt, vcf = bytearray(), bytearray()
+    if params.output_type != 1:
+        vcf += b"##fileformat=VCFv4.1\n"
+        for name, arr in contigs:
+            vcf += f"##contig=<ID={name},length={len(arr)}>\n".encode()
+        vcf += VCF_HEADER_POST
+    order = {"mut": [], "text_n": {0: 0, 1: 0, 2: 0}}
+
+    def on_mut(user, name, t, tl, v, vl):
+        order["mut"].append(name.decode())
+        txt.extend(C.string_at(t, tl) if tl else b"")
+        vcf.extend(C.string_at(v, vl) if vl else b"")
+        return 0
+
+    def on_reads(user, stream, data, n, text_n, gz):
+        order["text_n"][stream] += text_n
+        if keep_output:
+            raw[stream].append((bool(gz), C.string_at(data, n), text_n))
+        return 0
+
+    sink = JobSink(None, MUT_CB(on_mut), READS_CB(on_reads), MSG_CB(lambda u, m: None))
+    opt = JobOptions(1 if gzip_on_gpu else 0, 1, batch_pairs, group_bp, min_share)
+    err = C.c_int(0)
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    job = lib.dwgsim_hip_job_create(C.byref(params), devs, len(devices) if devices else 0, C.byref(sink), C.byref(opt), C.byref(err))
+    if not job:
+        raise DwgsimError(f"dwgsim_hip_job_create failed with code {err.value}")
+    try:
+        def chk(rc):
+            if rc < 0:
+                raise DwgsimError(f"error {rc}: {lib.dwgsim_hip_job_last_error(job).decode(errors='replace')}")
+        n = len(contigs)
+        names = (C.c_char_p * n)(*[nm.encode() for nm, _ in contigs])
+        lens = (C.c_int64 * n)(*[len(a) for _, a in contigs])
+        chk(lib.dwgsim_hip_job_set_contig_table(job, names, lens, n))
+        if getattr(params, "_regions", None):
+            chk(lib.dwgsim_hip_job_set_regions(job, params._regions.encode()))
+        if getattr(params, "_mut_input", None):
+            chk(lib.dwgsim_hip_job_set_mutation_input(job, params._mut_input[0], params._mut_input[1].encode()))
+        chk(lib.dwgsim_hip_job_prepare(job, None))
+        for name, arr in contigs:
+            a = np.ascontiguousarray(arr, dtype=np.uint8)
+            r = lib.dwgsim_hip_job_add_contig(job, name.encode(), a.ctypes.data_as(C.c_void_p), len(a))
+            if r < 0 and r not in (-2, -3, -4, -5, -10, -11):
+                chk(r)
+            if r > 0:
+                res.n_pairs += r
+        chk(lib.dwgsim_hip_job_finish(job))
+    finally:
+        lib.dwgsim_hip_job_destroy(job)
+    for s_ in range(3):
+        for gz, blob, text_n in raw[s_]:
+            piece = _gz.decompress(blob) if gz else blob
+            assert len(piece) == text_n
+            res.streams[s_] += piece
+    res.mutations_txt, res.mutations_vcf = bytes(txt), bytes(vcf)
+    res.streams = {k: bytes(v) for k, v in res.streams.items()}
+    res.delivered_text_bytes = dict(order["text_n"])
     return res

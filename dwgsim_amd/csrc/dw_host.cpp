@@ -1126,10 +1126,11 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     return 0;
 }
 
-int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t *n_random)
+int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t *n_random, uint64_t *per_range)
 {
     if (!c) return DWGSIM_HIP_ERR_ARG;
     if (n_random) *n_random = 0;
+    if (per_range) for (int q = 0; q < n; ++q) per_range[q] = 0;
     Group *gp = nullptr; std::vector<SimSeg> segs; uint64_t n_pairs = 0; uint32_t n_blocks = 0; int fixed_max = 0;
     if (const int rc = build_ranges(c, r, n, PAIRS_PER_BLOCK, &gp, segs, &n_pairs, &n_blocks, &fixed_max)) return rc;
     if (n_pairs == 0) return DWGSIM_HIP_OK;
@@ -1165,13 +1166,24 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
     if (n_random) *n_random = c->h_counters[3];
+    if (per_range) {      // the scanned per-block counts hold every range's share: prefix at its first block .. prefix at the next range's
+        std::vector<uint32_t> pre((size_t)n_blocks);
+        HIPC(c, hipMemcpyAsync(pre.data(), a.block_rand, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        size_t si = 0;
+        for (int q = 0; q < n; ++q) {
+            if (r[q].n_pairs == 0) continue;
+            const uint64_t lo = pre[segs[si].first_block], hi = si + 1 < segs.size() ? pre[segs[si + 1].first_block] : c->h_counters[3];
+            per_range[q] = hi - lo; ++si;
+        }
+    }
     return DWGSIM_HIP_OK;
 }
 
 int dwgsim_hip_count_random(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint64_t n_pairs, uint64_t *n_random)
 {
     dwgsim_hip_range_t r; memset(&r, 0, sizeof r); r.contig = contig; r.first_ii = first_ii; r.n_pairs = n_pairs;
-    return dwgsim_hip_count_random_ranges(c, &r, 1, n_random);
+    return dwgsim_hip_count_random_ranges(c, &r, 1, n_random, nullptr);
 }
 
 int dwgsim_hip_set_fail_carry(dwgsim_hip_ctx_t *c, uint64_t carry)

@@ -1,0 +1,554 @@
+// dw_job.cpp -- the job level of the C-ABI (include/dwgsim_hip.h, dwgsim_hip_job_*): the whole of dwgsim_core() (src/dwgsim.c:419-1121) on any
+// number of GPUs, behind five calls.  It is written on top of the context-level entry points of the same header (one context per device) and
+// owns what a caller of those would otherwise have to choreograph:
+//   * the scheduling arithmetic of the contig loop (dwgsim.c:519-625): pairs per contig, skip rules, region lengths, -N remainders;
+//   * GROUPS: consecutive contigs up to a size are resident, walked and simulated together (a scaffold-level assembly costs one walk chain
+//     and a few launches per group, not per contig); their sequence is staged once in page-locked memory and uploaded asynchronously;
+//   * the pipeline of every device: upload + walk of group k+1 on the walk stream while the batches of group k run; two batches in flight;
+//     finished text (or the gzip members made on the GPU) copied into page-locked buffers behind the kernels;
+//   * SHARDING: the pairs of a group, in file order, are cut into batches of read-index ranges; batch b belongs to device b mod n.  Every
+//     device walks every group itself (deterministic, cheap: no broadcast).  What crosses devices is two integers per batch -- the random-read
+//     count in front of it (rand_ii, dwgsim.c:1042,1096: every device counts the random reads of its batches with k_place before it simulates,
+//     one host-side prefix sum per group) and the abort rule's summary (dwgsim.c:635, :833-843; joined in order at the end of the group).
+//     No collective, no RCCL, no device-to-device traffic;
+//   * ORDER: one delivery thread per output stream hands the batches to the caller's sink in file order.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <string>
+#include <vector>
+#include <deque>
+#include <array>
+#include <memory>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include "../../include/dwgsim_hip.h"
+
+namespace {
+
+struct PinBuf { char *p[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}; };      // the output of one batch in page-locked memory
+
+struct BatchOut {             // one batch on its way to the sink
+    PinBuf *buf = nullptr; int lane = -1;
+    size_t n[3] = {0, 0, 0}, text_n[3] = {0, 0, 0};
+    bool ready = false; int left = 0;       // streams that still have to deliver it
+    uint64_t pairs = 0;
+};
+
+struct GroupJob {
+    int id = 0;
+    std::vector<std::string> names; std::vector<int64_t> lens, l_eff, n_pairs; std::vector<uint32_t> cindex;
+    int stage_slot = -1; std::vector<const uint8_t *> ptrs;      // the sequence in page-locked staging, group layout
+    int stage_users = 0;
+    uint64_t pairs = 0;
+    int nd = 1;                                                   // devices that share the group's batches
+    std::vector<std::vector<dwgsim_hip_range_t>> batches;         // ranges with contig = member ordinal (each device adds its own handle base)
+    std::vector<uint64_t> batch_pairs, batch_rand;                // pairs / counted random reads per batch
+    int counted = 0;                                              // devices that have published their batches' counts
+    bool base_known = false; uint64_t rand_base = 0;              // random reads in front of the group
+    std::vector<std::array<uint64_t, 4>> fail_seg; std::vector<uint64_t> got_rand;
+    std::vector<BatchOut> out;
+    int batches_done = 0; bool closed = false;
+    int mut_done = 0;                                             // (device 0) mutation text delivered
+};
+
+} // namespace
+
+struct dwgsim_hip_job {
+    dwgsim_hip_params_t prm; std::string prefix, flow;
+    dwgsim_hip_job_sink_t sink; dwgsim_hip_job_options_t opt;
+    std::vector<int> devices; std::vector<dwgsim_hip_ctx_t *> ctx;
+    int ND = 0;
+    bool want_mut = true, want_reads = true, gzip = true;
+    uint64_t batch_pairs = 1u << 20, group_bp = 32u << 20, min_share = 65536;
+    // contig table, scheduling state (dwgsim.c:465-478, :519-625)
+    std::vector<std::string> tab_names; std::vector<int64_t> tab_lens; bool have_table = false;
+    uint64_t tot_len = 0; int n_ref = 0; int64_t n_sim = 0; int prev_skip = 0; uint32_t next_index = 0;
+    std::string regions_path, mutin_path; int mutin_type = -1;
+    // staging of the sequence: page-locked buffers handed from the adding thread to the device workers
+    static constexpr int N_STAGE = 3;
+    uint8_t *stage[N_STAGE] = {nullptr, nullptr, nullptr}; size_t stage_cap[N_STAGE] = {0, 0, 0}; bool stage_busy[N_STAGE] = {false, false, false};
+    std::shared_ptr<GroupJob> pending; size_t pending_bytes = 0;           // the group being filled
+    // shared state
+    std::mutex m; std::condition_variable cv;
+    std::deque<std::shared_ptr<GroupJob>> groups;      // dispatched, not yet retired (front = oldest)
+    int n_dispatched = 0; bool no_more = false;
+    std::vector<int> next_group;                       // per device: id of the group it takes next
+    std::atomic<bool> failed{false}; std::string err;
+    std::vector<std::thread> workers; std::thread deliver[3];
+    bool started = false, finished = false;
+    uint64_t delivered_pairs = 0; uint64_t total_rand = 0;
+    // page-locked output buffers per device
+    std::vector<std::vector<std::unique_ptr<PinBuf>>> bufs; std::vector<std::vector<PinBuf *>> free_bufs;
+    int max_bufs = 4;
+};
+
+namespace {
+
+void job_fail(dwgsim_hip_job *j, const std::string &what)
+{
+    std::lock_guard<std::mutex> g(j->m);
+    if (!j->failed.exchange(true)) j->err = what;
+    j->cv.notify_all();
+}
+
+void say(dwgsim_hip_job *j, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void say(dwgsim_hip_job *j, const char *fmt, ...)
+{
+    char b[4608]; va_list ap; va_start(ap, fmt); vsnprintf(b, sizeof b, fmt, ap); va_end(ap);
+    if (j->sink.message) j->sink.message(j->sink.user, b); else if (!j->opt.quiet) fputs(b, stderr);
+}
+
+std::shared_ptr<GroupJob> group_by_id(dwgsim_hip_job *j, int id)      // j->m held
+{
+    for (auto &g : j->groups) if (g->id == id) return g;
+    return nullptr;
+}
+
+// ---- one device ----
+struct Worker {
+    dwgsim_hip_job *j; int d; dwgsim_hip_ctx_t *x;
+    std::shared_ptr<GroupJob> prepped; int prepped_handle = -1;      // the group whose upload + walk is already enqueued
+    bool first_batch_of_job = true;
+
+    bool ok() const { return !j->failed.load(); }
+    void fail_ctx() { job_fail(j, std::string("dwgsim-hip: ") + dwgsim_hip_last_error(x)); }
+
+    int prep(const std::shared_ptr<GroupJob> &g)      // upload (asynchronous: the staging is page-locked and in group layout) and enqueue the walk
+    {
+        const int n = (int)g->names.size();
+        std::vector<const char *> nm((size_t)n);
+        for (int k = 0; k < n; ++k) nm[(size_t)k] = g->names[(size_t)k].c_str();
+        const int h = dwgsim_hip_add_contigs(x, n, nm.data(), g->ptrs.data(), g->lens.data(), g->cindex.data());
+        if (h < 0) { fail_ctx(); return -1; }
+        if (!j->regions_path.empty())      // the `l` of fragment placement: the region length -- or the full length for the last contig of an -N run (dwgsim.c:535-537)
+            for (int k = 0; k < n; ++k) if (dwgsim_hip_contig_set_placement_length(x, h + k, g->l_eff[(size_t)k]) < 0) { fail_ctx(); return -1; }
+        if (dwgsim_hip_mutate_async(x, h) < 0) { fail_ctx(); return -1; }
+        return h;
+    }
+
+    PinBuf *acquire(const uint64_t need[3])
+    {
+        PinBuf *b = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(j->m);
+            auto &fr = j->free_bufs[(size_t)d]; auto &all = j->bufs[(size_t)d];
+            j->cv.wait(lk, [&]() { return !fr.empty() || (int)all.size() < j->max_bufs || j->failed.load(); });
+            if (j->failed.load()) return nullptr;
+            if (!fr.empty()) { b = fr.back(); fr.pop_back(); }
+            else { all.push_back(std::make_unique<PinBuf>()); b = all.back().get(); }
+        }
+        for (int s = 0; s < 3; ++s) if (need[s] > b->cap[s]) {
+            dwgsim_hip_host_free(b->p[s]);
+            b->cap[s] = (size_t)need[s] + (size_t)need[s] / 8 + 4096;
+            b->p[s] = (char *)dwgsim_hip_host_alloc(b->cap[s]);
+            if (!b->p[s]) { b->cap[s] = 0; job_fail(j, "dwgsim-hip: cannot allocate page-locked host memory for the output"); return nullptr; }
+        }
+        return b;
+    }
+
+    void run()
+    {
+        for (;;) {
+            std::shared_ptr<GroupJob> g;
+            {
+                std::unique_lock<std::mutex> lk(j->m);
+                const int want = j->next_group[(size_t)d];
+                j->cv.wait(lk, [&]() { return j->failed.load() || group_by_id(j, want) || (j->no_more && want >= j->n_dispatched); });
+                if (j->failed.load()) break;
+                g = group_by_id(j, want);
+                if (!g) break;
+                j->next_group[(size_t)d] = want + 1;
+            }
+            if (!process(g)) break;
+        }
+        if (prepped) { (void)dwgsim_hip_mutate_wait(x, prepped_handle); prepped.reset(); }
+    }
+
+    bool takes_part(const GroupJob &g) const { return d == 0 || (j->want_reads && d < g.nd); }      // device 0 also writes the mutation text
+
+    bool process(const std::shared_ptr<GroupJob> &g)
+    {
+        if (!takes_part(*g)) {      // a small group is not worth a copy on every device
+            std::lock_guard<std::mutex> lk(j->m);
+            if (--g->stage_users == 0) { j->stage_busy[g->stage_slot] = false; }
+            j->cv.notify_all();
+            return true;
+        }
+        int h;
+        if (prepped && prepped->id == g->id) { h = prepped_handle; prepped.reset(); }
+        else if ((h = prep(g)) < 0) return false;
+        if (dwgsim_hip_mutate_wait(x, h) < 0) { fail_ctx(); return false; }
+        {   // the upload has finished: this device is done with the staging
+            std::lock_guard<std::mutex> lk(j->m);
+            if (--g->stage_users == 0) { j->stage_busy[g->stage_slot] = false; j->cv.notify_all(); }
+        }
+        if (d == 0 && j->want_mut && j->sink.mutations) {      // mut_print (mut.c:781-893), contigs in order
+            for (size_t k = 0; k < g->names.size() && ok(); ++k) {
+                const char *t, *v; size_t tl, vl;
+                if (dwgsim_hip_mutations_text(x, h + (int)k, &t, &tl, &v, &vl) < 0) { fail_ctx(); return false; }
+                if (j->sink.mutations(j->sink.user, g->names[k].c_str(), t, tl, v, vl) != 0) { job_fail(j, "dwgsim-hip: the sink refused the mutation text"); return false; }
+            }
+        }
+        const int nb = (int)g->batches.size();
+        std::vector<int> mine;
+        if (j->want_reads && d < g->nd) for (int b = d; b < nb; b += g->nd) mine.push_back(b);
+        auto ranges_of = [&](int b) { std::vector<dwgsim_hip_range_t> r = g->batches[(size_t)b]; for (auto &q : r) q.contig += h; return r; };
+        if (j->ND > 1 && j->want_reads) {
+            // random reads of my batches, counted without producing them (k_place): one launch, one count per batch
+            if (!mine.empty()) {
+                std::vector<dwgsim_hip_range_t> all; std::vector<int> owner;
+                for (int b : mine) for (const auto &q : ranges_of(b)) { all.push_back(q); owner.push_back(b); }
+                std::vector<uint64_t> per(all.size(), 0); uint64_t tot = 0;
+                if (dwgsim_hip_count_random_ranges(x, all.data(), (int)all.size(), &tot, per.data()) < 0) { fail_ctx(); return false; }
+                std::lock_guard<std::mutex> lk(j->m);
+                for (size_t q = 0; q < all.size(); ++q) g->batch_rand[(size_t)owner[q]] += per[q];
+            }
+            std::unique_lock<std::mutex> lk(j->m);
+            if (d < g->nd) { ++g->counted; j->cv.notify_all(); }
+            j->cv.wait(lk, [&]() { return j->failed.load() || (g->counted >= g->nd && g->base_known); });
+            if (j->failed.load()) return false;
+            if (g->counted == g->nd) {      // (every device computes the same thing; the first one publishes it for the next group)
+                uint64_t tot = g->rand_base;
+                for (uint64_t c : g->batch_rand) tot += c;
+                auto nx = group_by_id(j, g->id + 1);
+                if (nx && !nx->base_known) { nx->rand_base = tot; nx->base_known = true; j->cv.notify_all(); }
+                j->total_rand = tot;
+            }
+        }
+        // the next group, if it is already here, is uploaded and walked on the walk stream while this one's batches run
+        if (!prepped) {
+            std::shared_ptr<GroupJob> nx;
+            { std::lock_guard<std::mutex> lk(j->m); nx = group_by_id(j, g->id + 1); }
+            if (nx && takes_part(*nx)) { const int nh = prep(nx); if (nh < 0) return false; prepped = nx; prepped_handle = nh; }
+        }
+        // batches: two in flight; batch k-1 is copied out while batch k runs
+        struct Pending { bool live = false; int slot = 0, b = 0; } prev;
+        auto finish_batch = [&](Pending &pb) -> bool {
+            if (!pb.live) return true;
+            pb.live = false;
+            dwgsim_hip_batch_t bt;
+            if (dwgsim_hip_wait(x, pb.slot, &bt) < 0) { fail_ctx(); return false; }
+            BatchOut bo; bo.lane = d; bo.pairs = bt.n_pairs;
+            if (j->sink.reads) {
+                PinBuf *tb = acquire(j->gzip ? bt.gz_bytes : bt.bytes);
+                if (!tb) return false;
+                bo.buf = tb;
+                for (int s = 0; s < 3; ++s) {
+                    bo.n[s] = j->gzip ? bt.gz_bytes[s] : bt.bytes[s]; bo.text_n[s] = bt.bytes[s];
+                    if (bo.n[s] && (j->gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail_ctx(); return false; }
+                    if (bo.n[s]) ++bo.left;
+                }
+                if (dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
+            }
+            std::lock_guard<std::mutex> lk(j->m);
+            for (int q = 0; q < 4; ++q) g->fail_seg[(size_t)pb.b][(size_t)q] = bt.fail_seg[q];
+            g->got_rand[(size_t)pb.b] = bt.n_random;
+            bo.ready = true;
+            if (bo.left == 0 && bo.buf) { j->free_bufs[(size_t)d].push_back(bo.buf); bo.buf = nullptr; }
+            g->out[(size_t)pb.b] = bo;
+            ++g->batches_done;
+            j->delivered_pairs += bt.n_pairs;
+            if (!j->opt.quiet) { char t[64]; snprintf(t, sizeof t, "\r[dwgsim_core] %llu", (unsigned long long)j->delivered_pairs); if (j->sink.message) j->sink.message(j->sink.user, t); else fputs(t, stderr); }
+            j->cv.notify_all();
+            return true;
+        };
+        int kk = 0;
+        for (int b : mine) {
+            if (!ok()) break;
+            uint64_t rbase;
+            if (j->ND > 1) { rbase = g->rand_base; for (int q = 0; q < b; ++q) rbase += g->batch_rand[(size_t)q]; }      // (batch_rand is final: all devices have published)
+            else { rbase = first_batch_of_job ? 0 : DWGSIM_HIP_RAND_CHAIN; first_batch_of_job = false; }
+            const auto r = ranges_of(b);
+            const int slot = kk & 1;
+            if (dwgsim_hip_simulate_ranges_async(x, r.data(), (int)r.size(), rbase, slot) < 0) { fail_ctx(); break; }
+            if (!finish_batch(prev)) { prev.live = true; prev.slot = slot; prev.b = b; break; }
+            prev.live = true; prev.slot = slot; prev.b = b;
+            ++kk;
+        }
+        if (ok()) { if (!finish_batch(prev)) return false; }
+        else if (prev.live) { dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, prev.slot, &bt); }
+        if (!ok()) return false;
+        if (dwgsim_hip_drop_contig(x, h) < 0) { fail_ctx(); return false; }
+        return true;
+    }
+};
+
+// one output stream: the batches of every group, in order
+void deliver_loop(dwgsim_hip_job *j, int s)
+{
+    int gid = 0;
+    for (;;) {
+        std::shared_ptr<GroupJob> g;
+        {
+            std::unique_lock<std::mutex> lk(j->m);
+            j->cv.wait(lk, [&]() { return j->failed.load() || gid < j->n_dispatched || j->no_more; });
+            if (j->failed.load()) return;
+            if (gid >= j->n_dispatched) return;
+            g = group_by_id(j, gid);
+            if (!g) { ++gid; continue; }      // retired already: it had nothing for this stream
+        }
+        const int nb = j->want_reads ? (int)g->batches.size() : 0;
+        for (int b = 0; b < nb; ++b) {
+            BatchOut bo;
+            {
+                std::unique_lock<std::mutex> lk(j->m);
+                j->cv.wait(lk, [&]() { return j->failed.load() || g->out[(size_t)b].ready; });
+                if (j->failed.load()) return;
+                bo = g->out[(size_t)b];
+            }
+            if (bo.n[s] && j->sink.reads) {
+                if (j->sink.reads(j->sink.user, s, bo.buf->p[s], bo.n[s], bo.text_n[s], j->gzip ? 1 : 0) != 0) { job_fail(j, "dwgsim-hip: writing FASTQ failed"); return; }
+                std::lock_guard<std::mutex> lk(j->m);
+                BatchOut &ref = g->out[(size_t)b];
+                if (--ref.left == 0) { j->free_bufs[(size_t)ref.lane].push_back(ref.buf); ref.buf = nullptr; j->cv.notify_all(); }
+            }
+        }
+        ++gid;
+    }
+}
+
+// the group is complete when every batch was simulated: join the abort rule's summaries in read-index order (dwgsim.c:635, :833-843) and retire it
+void retire_loop_step(dwgsim_hip_job *j)      // j->m held
+{
+    while (!j->groups.empty()) {
+        auto &g = j->groups.front();
+        const int nb = j->want_reads ? (int)g->batches.size() : 0;
+        bool delivered = g->batches_done >= nb;
+        for (int b = 0; b < nb && delivered; ++b) if (!g->out[(size_t)b].ready || g->out[(size_t)b].left > 0) delivered = false;
+        bool all_taken = true;
+        for (int d = 0; d < j->ND; ++d) if (j->next_group[(size_t)d] <= g->id) all_taken = false;
+        if (!delivered || !all_taken || g->stage_users > 0) break;
+        uint64_t acc[4] = {0, 0, 0, 0}; bool aborted = false;
+        for (int b = 0; b < nb && !aborted; ++b) if (dwgsim_hip_failseg_join(acc, g->fail_seg[(size_t)b].data())) aborted = true;
+        if (aborted && !j->failed.exchange(true)) j->err = "\r[dwgsim_core] failed to generate a read after 10001 trials\n";
+        if (j->ND == 1) for (uint64_t r : g->got_rand) j->total_rand += r;
+        j->groups.pop_front();
+    }
+}
+
+int dispatch_pending(dwgsim_hip_job *j)
+{
+    if (!j->pending) return DWGSIM_HIP_OK;
+    auto g = j->pending; j->pending.reset(); j->pending_bytes = 0;
+    // the group's pairs in file order, cut into batches; batch b belongs to device b mod nd
+    g->pairs = 0; for (int64_t n : g->n_pairs) g->pairs += (uint64_t)n;
+    g->nd = j->ND;
+    while (g->nd > 1 && g->pairs / (uint64_t)g->nd < j->min_share) --g->nd;
+    if (j->want_reads) {
+        std::vector<dwgsim_hip_range_t> cur; uint64_t room = j->batch_pairs, cur_pairs = 0;
+        for (size_t k = 0; k < g->n_pairs.size(); ++k) {
+            uint64_t first = 0, n = (uint64_t)g->n_pairs[k];
+            while (n > 0) {
+                const uint64_t take = n < room ? n : room;
+                dwgsim_hip_range_t r; memset(&r, 0, sizeof r); r.contig = (int32_t)k; r.first_ii = first; r.n_pairs = take;
+                cur.push_back(r); first += take; n -= take; room -= take; cur_pairs += take;
+                if (room == 0) { g->batches.push_back(cur); g->batch_pairs.push_back(cur_pairs); cur.clear(); room = j->batch_pairs; cur_pairs = 0; }
+            }
+        }
+        if (!cur.empty()) { g->batches.push_back(cur); g->batch_pairs.push_back(cur_pairs); }
+    }
+    const size_t nb = g->batches.size();
+    g->batch_rand.assign(nb, 0); g->fail_seg.assign(nb, std::array<uint64_t, 4>{0, 0, 0, 0}); g->got_rand.assign(nb, 0); g->out.assign(nb, BatchOut());
+    g->stage_users = j->ND;
+    std::unique_lock<std::mutex> lk(j->m);
+    // at most two groups in front of the devices: the staging of a third one is being filled meanwhile
+    j->cv.wait(lk, [&]() { retire_loop_step(j); return j->failed.load() || j->groups.size() < 2; });
+    if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
+    g->id = j->n_dispatched++;
+    if (g->id == 0) { g->base_known = true; g->rand_base = 0; }
+    else if (auto pv = group_by_id(j, g->id - 1)) { if (pv->counted >= pv->nd && pv->base_known && j->ND > 1) { uint64_t t = pv->rand_base; for (uint64_t c : pv->batch_rand) t += c; g->rand_base = t; g->base_known = true; } }
+    else { g->rand_base = j->total_rand; g->base_known = true; }      // the group in front has been retired already: its total is final
+    j->groups.push_back(g);
+    j->cv.notify_all();
+    return DWGSIM_HIP_OK;
+}
+
+int start_threads(dwgsim_hip_job *j)
+{
+    if (j->started) return DWGSIM_HIP_OK;
+    j->started = true;
+    for (int d = 0; d < j->ND; ++d) {
+        if (!j->regions_path.empty()) {      // dwgsim.c:499-506
+            std::vector<const char *> nm; for (auto &s : j->tab_names) nm.push_back(s.c_str());
+            uint64_t tl = 0;
+            if (dwgsim_hip_set_regions(j->ctx[(size_t)d], j->regions_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size(), &tl) < 0) { j->err = dwgsim_hip_last_error(j->ctx[(size_t)d]); j->failed = true; return DWGSIM_HIP_ERR_ARG; }
+            j->tot_len = tl;
+        }
+        if (j->mutin_type >= 0) {            // dwgsim.c:494-497
+            std::vector<const char *> nm; for (auto &s : j->tab_names) nm.push_back(s.c_str());
+            if (dwgsim_hip_set_mutation_input(j->ctx[(size_t)d], j->mutin_type, j->mutin_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size()) < 0) { j->err = dwgsim_hip_last_error(j->ctx[(size_t)d]); j->failed = true; return DWGSIM_HIP_ERR_ARG; }
+        }
+        if (j->gzip && j->want_reads && j->sink.reads && dwgsim_hip_set_gzip(j->ctx[(size_t)d], 1) < 0) { j->err = dwgsim_hip_last_error(j->ctx[(size_t)d]); j->failed = true; return DWGSIM_HIP_ERR_DEVICE; }
+    }
+    for (int d = 0; d < j->ND; ++d) j->workers.emplace_back([j, d]() { Worker w{j, d, j->ctx[(size_t)d]}; w.run(); });
+    if (j->want_reads && j->sink.reads) for (int s = 0; s < 3; ++s) j->deliver[s] = std::thread([j, s]() { deliver_loop(j, s); });
+    return DWGSIM_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int *devices, int n_devices, const dwgsim_hip_job_sink_t *sink,
+                                        const dwgsim_hip_job_options_t *opt, int *err)
+{
+    auto bad = [&](int e) { if (err) *err = e; return (dwgsim_hip_job_t *)nullptr; };
+    if (!p) return bad(DWGSIM_HIP_ERR_ARG);
+    std::vector<int> devs;
+    if (n_devices <= 0 || !devices) { const int n = dwgsim_hip_device_count(); for (int d = 0; d < n; ++d) devs.push_back(d); }      // every device the process sees
+    else devs.assign(devices, devices + n_devices);
+    if (devs.empty()) { fprintf(stderr, "dwgsim-hip: no usable HIP device; the hot path has no CPU fallback\n"); return bad(DWGSIM_HIP_ERR_DEVICE); }
+    auto *j = new dwgsim_hip_job();
+    j->prm = *p;
+    if (p->read_prefix) { j->prefix = p->read_prefix; j->prm.read_prefix = j->prefix.c_str(); }
+    if (p->flow_order) { j->flow = p->flow_order; j->prm.flow_order = j->flow.c_str(); }
+    memset(&j->sink, 0, sizeof j->sink); if (sink) j->sink = *sink;
+    memset(&j->opt, 0, sizeof j->opt); if (opt) j->opt = *opt; else j->opt.gzip = 1;
+    j->gzip = j->opt.gzip != 0;
+    if (j->opt.batch_pairs) j->batch_pairs = j->opt.batch_pairs;
+    if (j->opt.group_bp) j->group_bp = j->opt.group_bp;
+    if (j->opt.min_share) j->min_share = j->opt.min_share;
+    j->want_mut = p->output_type != 1; j->want_reads = p->output_type != 2;
+    j->devices = devs; j->ND = (int)devs.size();
+    j->ctx.assign((size_t)j->ND, nullptr);
+    for (int d = 0; d < j->ND; ++d) {
+        int e = 0;
+        j->ctx[(size_t)d] = dwgsim_hip_create(&j->prm, devs[(size_t)d], &e);
+        if (!j->ctx[(size_t)d]) { fprintf(stderr, "dwgsim-hip: cannot create a GPU context on device %d (error %d)\n", devs[(size_t)d], e); for (auto *x : j->ctx) if (x) dwgsim_hip_destroy(x); delete j; return bad(e ? e : DWGSIM_HIP_ERR_DEVICE); }
+    }
+    j->next_group.assign((size_t)j->ND, 0);
+    j->bufs.resize((size_t)j->ND); j->free_bufs.resize((size_t)j->ND);
+    if (err) *err = DWGSIM_HIP_OK;
+    return j;
+}
+
+int dwgsim_hip_job_set_contig_table(dwgsim_hip_job_t *j, const char *const *names, const int64_t *lens, int n)
+{
+    if (!j || n < 0 || (n && (!names || !lens)) || j->started) { if (j) j->err = "job: the contig table must be set once, before the first contig"; return DWGSIM_HIP_ERR_ARG; }
+    j->tab_names.clear(); j->tab_lens.clear(); j->tot_len = 0;
+    for (int i = 0; i < n; ++i) { j->tab_names.push_back(names[i]); j->tab_lens.push_back(lens[i]); j->tot_len += (uint64_t)lens[i]; }
+    j->n_ref = n; j->have_table = true;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_job_set_regions(dwgsim_hip_job_t *j, const char *path)
+{
+    if (!j || !path || j->started) { if (j) j->err = "job: regions must be set before the first contig"; return DWGSIM_HIP_ERR_ARG; }
+    j->regions_path = path;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_job_set_mutation_input(dwgsim_hip_job_t *j, int type, const char *path)
+{
+    if (!j || !path || type < 0 || type > 2 || j->started) { if (j) j->err = "job: the mutation input must be set before the first contig"; return DWGSIM_HIP_ERR_ARG; }
+    j->mutin_type = type; j->mutin_path = path;
+    return DWGSIM_HIP_OK;
+}
+
+int dwgsim_hip_job_prepare(dwgsim_hip_job_t *j, uint64_t *total_len)
+{
+    if (!j || !j->have_table) { if (j) j->err = "job: set the contig table first"; return DWGSIM_HIP_ERR_STATE; }
+    const int rc = start_threads(j);
+    if (total_len) *total_len = j->tot_len;
+    return rc;
+}
+
+int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *j, const char *name, const uint8_t *ascii, int64_t l)
+{
+    if (!j || !name || (!ascii && l > 0) || l < 0) { if (j) j->err = "job: bad contig arguments"; return DWGSIM_HIP_ERR_ARG; }
+    if (!j->have_table) { j->err = "job: set the contig table first (the reference reads it before the first contig: dwgsim.c:465-478)"; return DWGSIM_HIP_ERR_STATE; }
+    if (j->finished) { j->err = "job: already finished"; return DWGSIM_HIP_ERR_STATE; }
+    if (start_threads(j) < 0) return DWGSIM_HIP_ERR_FAILED;
+    if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
+    const dwgsim_hip_params_t &o = j->prm;
+    const uint32_t ci = j->next_index++;
+    --j->n_ref;
+    int64_t n_pairs = 0, l_eff = l;
+    if (j->want_reads) {      // dwgsim.c:535-625
+        const bool last_takes_rest = j->n_ref == 0 && o.C < 0;     // dwgsim.c:535-537
+        if (!j->regions_path.empty() && !last_takes_rest) {
+            l_eff = dwgsim_hip_contig_region_length(j->ctx[0], ci, ascii, l);
+            if (l_eff == -10) { say(j, "[dwgsim_core] #0 skip sequence '%s' as it is not in the targeted region\n", name); return -10; }
+            if (l_eff == -11) { say(j, "[dwgsim_core] #1 skip sequence '%s' as more than 95%% of its targeted bases are non-ACGT\n", name); return -11; }
+        }
+        n_pairs = dwgsim_hip_pairs_for_contig(&o, l_eff, j->tot_len, j->n_ref == 0, j->n_sim);
+        if (n_pairs < 0) {
+            if (!j->prev_skip) say(j, "\n");
+            j->prev_skip = 1;
+            if (n_pairs == -2) say(j, "[dwgsim_core] #2 skip sequence '%s' as it is shorter than the read length %d < %d!\n", name, (int)l, o.length[0] > o.length[1] ? o.length[0] : o.length[1]);
+            else if (n_pairs == -3) say(j, "[dwgsim_core] #3 skip sequence '%s' as it is shorter than %f!\n", name, o.dist + 3 * o.std_dev);
+            else if (n_pairs == -4) say(j, "[dwgsim_core] #4 skip sequence '%s' as it is shorter than %d!\n", name, (l < o.length[0]) ? o.length[0] : o.length[1]);
+            else say(j, "[dwgsim_core] #5 skip sequence '%s' as not enough pairs found\n", name);
+            return n_pairs;
+        }
+        j->prev_skip = 0;
+        j->n_sim += n_pairs;
+    }
+    // into the group being filled; a contig that would take it past the group size closes it first
+    const int64_t aligned_len = (l + 4095) / 4096 * 4096;
+    if (j->pending && j->pending_bytes + (size_t)aligned_len > (size_t)j->group_bp) { if (dispatch_pending(j) < 0) return DWGSIM_HIP_ERR_FAILED; }
+    if (!j->pending) {
+        auto g = std::make_shared<GroupJob>();
+        std::unique_lock<std::mutex> lk(j->m);
+        j->cv.wait(lk, [&]() { retire_loop_step(j); if (j->failed.load()) return true; for (int s = 0; s < dwgsim_hip_job::N_STAGE; ++s) if (!j->stage_busy[s]) return true; return false; });
+        if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
+        for (int s = 0; s < dwgsim_hip_job::N_STAGE; ++s) if (!j->stage_busy[s]) { g->stage_slot = s; j->stage_busy[s] = true; break; }
+        j->pending = g; j->pending_bytes = 0;
+    }
+    GroupJob &g = *j->pending;
+    // the contig's place in the group layout (dwgsim_hip_group_layout): the next multiple of 4096
+    std::vector<int64_t> lens = g.lens; lens.push_back(l);
+    std::vector<int64_t> starts(lens.size());
+    const int64_t total = dwgsim_hip_group_layout(lens.data(), (int)lens.size(), starts.data());
+    const int s = g.stage_slot;
+    if ((size_t)total > j->stage_cap[s]) {      // grow, keeping what the group already holds
+        const size_t want = std::max<size_t>((size_t)total + (size_t)total / 4, (size_t)std::min<uint64_t>(j->group_bp, 256u << 20) + 8192);
+        uint8_t *nb = (uint8_t *)dwgsim_hip_host_alloc(want);
+        if (!nb) { j->err = "dwgsim-hip: cannot allocate page-locked host memory for the sequence"; j->failed = true; return DWGSIM_HIP_ERR_NOMEM; }
+        if (j->stage[s] && j->pending_bytes) memcpy(nb, j->stage[s], j->pending_bytes);
+        dwgsim_hip_host_free(j->stage[s]);
+        j->stage[s] = nb; j->stage_cap[s] = want;
+    }
+    const int64_t st = starts.back();
+    if ((size_t)st > j->pending_bytes) memset(j->stage[s] + j->pending_bytes, 0, (size_t)st - j->pending_bytes);      // zero bytes between the contigs
+    if (l > 0) memcpy(j->stage[s] + st, ascii, (size_t)l);
+    if ((size_t)total > (size_t)(st + l)) memset(j->stage[s] + st + l, 0, (size_t)total - (size_t)(st + l));
+    j->pending_bytes = (size_t)total;
+    g.names.push_back(name); g.lens.push_back(l); g.l_eff.push_back(l_eff); g.n_pairs.push_back(n_pairs); g.cindex.push_back(ci);
+    g.ptrs.clear();
+    for (size_t k = 0; k < g.lens.size(); ++k) g.ptrs.push_back(j->stage[s] + starts[k]);
+    if (j->pending_bytes >= (size_t)j->group_bp) { if (dispatch_pending(j) < 0) return DWGSIM_HIP_ERR_FAILED; }
+    return n_pairs;
+}
+
+int dwgsim_hip_job_finish(dwgsim_hip_job_t *j)
+{
+    if (!j) return DWGSIM_HIP_ERR_ARG;
+    if (j->finished) return j->failed.load() ? DWGSIM_HIP_ERR_FAILED : DWGSIM_HIP_OK;
+    j->finished = true;
+    if (!j->failed.load()) (void)dispatch_pending(j);
+    { std::lock_guard<std::mutex> lk(j->m); j->no_more = true; j->cv.notify_all(); }
+    for (auto &t : j->workers) if (t.joinable()) t.join();
+    for (auto &t : j->deliver) if (t.joinable()) t.join();
+    { std::lock_guard<std::mutex> lk(j->m); if (!j->failed.load()) retire_loop_step(j); }
+    return j->failed.load() ? DWGSIM_HIP_ERR_FAILED : DWGSIM_HIP_OK;
+}
+
+const char *dwgsim_hip_job_last_error(const dwgsim_hip_job_t *j) { return j ? j->err.c_str() : "no job"; }
+
+void dwgsim_hip_job_destroy(dwgsim_hip_job_t *j)
+{
+    if (!j) return;
+    if (!j->finished) { job_fail(j, "job destroyed before it was finished"); (void)dwgsim_hip_job_finish(j); }
+    for (auto *x : j->ctx) if (x) dwgsim_hip_destroy(x);
+    for (int s = 0; s < dwgsim_hip_job::N_STAGE; ++s) dwgsim_hip_host_free(j->stage[s]);
+    for (auto &lane : j->bufs) for (auto &b : lane) for (int s = 0; s < 3; ++s) dwgsim_hip_host_free(b->p[s]);
+    delete j;
+}
+
+} // extern "C"

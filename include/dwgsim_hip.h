@@ -177,7 +177,8 @@ int dwgsim_hip_count_random(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii
 /* A read-index range of one contig.  A call that takes several of them covers them in the order given (= file order); they must belong to
  * contigs of one group. */
 typedef struct dwgsim_hip_range { int32_t contig; int32_t reserved; uint64_t first_ii, n_pairs; } dwgsim_hip_range_t;
-int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *ctx, const dwgsim_hip_range_t *ranges, int n_ranges, uint64_t *n_random);
+/* random reads among the pairs of the ranges: their total, and (per_range != NULL) one count per range */
+int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *ctx, const dwgsim_hip_range_t *ranges, int n_ranges, uint64_t *n_random, uint64_t *per_range);
 
 /* Replaces the loop body dwgsim.c:636-1099 for the read-index range [first_ii, first_ii+n_pairs)
  * of one contig.  rand_base = number of random reads emitted before first_ii (over all contigs).
@@ -241,6 +242,57 @@ int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);
 /* HIP devices visible to the process (0 without a GPU). */
 int dwgsim_hip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * Job level: dwgsim_core() (dwgsim.c:419-1121) as a whole, on any number of GPUs.  The calls above drive ONE device and leave the
+ * choreography to the caller; these own it: contig scheduling (dwgsim.c:519-625), grouping of small contigs, upload / walk / simulate /
+ * copy-out pipelines of every device, read-index sharding (batch b of a group's pairs belongs to device b mod n; every device walks the
+ * group itself; the random-read count in front of a batch and the abort rule's summaries are the only things that cross devices, as host
+ * integers -- no collective), and delivery of the output in file order.  A binding at the reference's seam (dwgsim.c:1163) is: create, set the
+ * contig table, add every contig of the FASTA in order, finish.
+ * ------------------------------------------------------------------------------------------------------------------------------------ */
+typedef struct dwgsim_hip_job dwgsim_hip_job_t;
+
+typedef struct dwgsim_hip_job_sink {
+    void *user;
+    /* mut_print() (mut.c:781-893): the mutations.txt / mutations.vcf body lines of the next contig, contigs in FASTA order.  One call at a
+     * time, from a thread of the job.  Non-zero return stops the job. */
+    int (*mutations)(void *user, const char *contig, const char *txt, size_t txt_len, const char *vcf, size_t vcf_len);
+    /* The gzprintf / gzputc stream of dwgsim.c:919-981: the next piece of output stream `stream` (DWGSIM_HIP_STREAM_*), pieces in file
+     * order.  gz != 0: `len` bytes of complete gzip members that hold text_len bytes of text; gz == 0: len == text_len bytes of text.
+     * One thread per stream, so the three files can be written side by side; `data` is page-locked memory of the job, reused once the call
+     * has returned.  NULL: the reads are simulated and left on the device (benchmarks).  Non-zero return stops the job. */
+    int (*reads)(void *user, int stream, const void *data, size_t len, size_t text_len, int gz);
+    /* dwgsim_core's stderr lines (skip notes, the running pair count); NULL: written to stderr unless options.quiet */
+    void (*message)(void *user, const char *text);
+} dwgsim_hip_job_sink_t;
+
+typedef struct dwgsim_hip_job_options {
+    int32_t  gzip;           /* 1: reads() gets gzip members made on the GPU (dwgsim_hip_set_gzip), 0: text */
+    int32_t  quiet;
+    uint64_t batch_pairs;    /* pairs per launch (0: 2^20) */
+    uint64_t group_bp;       /* consecutive contigs are resident, walked and simulated together up to this many bases (0: 32 Mi) */
+    uint64_t min_share;      /* a group is spread over fewer devices while a device's share would stay below this many pairs (0: 65536) */
+} dwgsim_hip_job_options_t;
+
+/* devices == NULL or n_devices <= 0: every HIP device the process sees.  options == NULL: GPU gzip, defaults. */
+dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int *devices, int n_devices, const dwgsim_hip_job_sink_t *sink,
+                                        const dwgsim_hip_job_options_t *options, int *err);
+/* contigs_add() (dwgsim.c:465-478): every contig of the FASTA (or of its .fai) -- fixes tot_len and n_ref, and is what -m/-b/-v/-x files are
+ * checked against.  Then, optionally, regions_bed_init() / muts_input_init() (dwgsim.c:494-506). */
+int dwgsim_hip_job_set_contig_table(dwgsim_hip_job_t *job, const char *const *names, const int64_t *lens, int n);
+int dwgsim_hip_job_set_regions(dwgsim_hip_job_t *job, const char *path);
+int dwgsim_hip_job_set_mutation_input(dwgsim_hip_job_t *job, int type, const char *path);
+/* optional: parse the files above and start the device threads now (errors of -x / -m / -b / -v surface here instead of at the first contig) */
+int dwgsim_hip_job_prepare(dwgsim_hip_job_t *job, uint64_t *total_len);
+/* The body of the contig loop (dwgsim.c:519-625 and everything below it) for the next contig of the FASTA.  Returns the pairs scheduled for
+ * it (>= 0) or why it is skipped (-2 .. -5 as dwgsim_hip_pairs_for_contig, -10 / -11 as dwgsim_hip_contig_region_length) or an error code.
+ * The sequence is copied: `ascii` is the caller's again when the call returns.  Blocks only when the devices are two groups behind. */
+int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *job, const char *name, const uint8_t *ascii, int64_t len);
+/* no more contigs: returns when everything has been delivered to the sink (DWGSIM_HIP_OK) or the job failed */
+int dwgsim_hip_job_finish(dwgsim_hip_job_t *job);
+const char *dwgsim_hip_job_last_error(const dwgsim_hip_job_t *job);
+void dwgsim_hip_job_destroy(dwgsim_hip_job_t *job);
 
 #ifdef __cplusplus
 }

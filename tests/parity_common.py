@@ -46,6 +46,19 @@ def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22, debug_optio
     return res
 
 
+def compare_job_api(lib, oracle_bin, fasta, flags, **kw):
+    """The job level of the C-ABI (dwgsim_hip_job_*: the library schedules, groups, shards over the devices and orders) against the oracle."""
+    flags = flags.replace("{IN}", IN_DIR)
+    with tempfile.TemporaryDirectory() as t:
+        want = run_oracle(oracle_bin, fasta, flags, t)
+    res = api.run_job_api(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib, **kw)
+    assert res.mutations_txt == want["txt"], "mutations.txt: " + first_diff(res.mutations_txt, want["txt"])
+    assert res.mutations_vcf == want["vcf"], "mutations.vcf: " + first_diff(res.mutations_vcf, want["vcf"])
+    for k in STREAMS:
+        assert res.streams[k] == want[k], f"{STREAMS[k]}: " + first_diff(res.streams[k], want[k])
+    return res
+
+
 FLOW = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
 
 # (fasta under tests/golden, flags): the option surface of the accelerated path (Illumina, SOLiD and Ion Torrent)

@@ -148,6 +148,39 @@ def test_abort_rule_matches_the_reference(emu_lib, oracle_bin, golden_dir):
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 600 -r 0 -e 0.0-0.1 -Q 0 -a", batch_pairs=100)
 
 
+@pytest.mark.parametrize("fasta,flags,kw", [
+    ("tiny.fa", "-z 9 -N 900 -P pfx -r 0.01 -R 0.3 -y 0.2", dict(devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=100, min_share=40)),
+    ("tiny.fa", "-z 9 -N 300 -y 0.2 -o 1", dict(devices=[0, 0], gzip_on_gpu=True, batch_pairs=100, min_share=40)),
+    ("tiny.fa", "-z 9 -C 3 -y 0.1", dict(devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=64, min_share=1, group_bp=5000)),      # contig by contig (groups of one)
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 700 -m {IN}/muts_edge.txt", dict(devices=[0, 0], gzip_on_gpu=False, batch_pairs=90, min_share=1)),
+    ("odd.fa", "-z 6 -N 700 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2", dict(devices=[0, 0, 0, 0], gzip_on_gpu=False, batch_pairs=77, min_share=1)),
+    ("ex1.fa", "-z 13 -N 800 -M 2", dict(devices=[0, 0], gzip_on_gpu=False)),
+    ("ex1.fa", "-z 13 -N 800 -M 1", dict(devices=[0], gzip_on_gpu=False, batch_pairs=300)),
+])
+def test_job_level_of_the_abi_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags, kw):
+    """dwgsim_hip_job_* through ctypes: several contexts (here all on the one emulated device), batches dealt round-robin, counted random
+    reads as rand_ii bases, ordered delivery -- every byte as the oracle's single-process run."""
+    from parity_common import compare_job_api
+    compare_job_api(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, **kw)
+
+
+def test_job_level_many_small_contigs_on_cpu_emulation(emu_lib, oracle_bin, tmp_path):
+    from parity_common import compare_job_api
+    fa = str(tmp_path / "many.fa")
+    write_many_contigs(fa, 60, seed=5)
+    compare_job_api(emu_lib, oracle_bin, fa, "-z 11 -C 6 -1 50 -2 50 -d 200 -s 15 -r 0.03 -R 0.6 -X 0.6 -n 8 -y 0.1", devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=256, min_share=100, group_bp=30000)
+
+
+def test_job_level_abort_rule_across_devices_on_cpu_emulation(emu_lib, oracle_bin, golden_dir):
+    """The failure counter over the pairs of a contig (dwgsim.c:635) when its batches are dealt to three contexts: the joined summaries give the
+    reference's verdict -- no abort at 600 pairs, abort at 1200."""
+    from parity_common import compare_job_api
+    fa = os.path.join(golden_dir, "odd.fa")
+    compare_job_api(emu_lib, oracle_bin, fa, "-z 6466 -1 33 -2 150 -d 900 -s 50 -N 600 -r 0 -e 0.0-0.1 -Q 0 -a", devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=50, min_share=1)
+    with pytest.raises(api.DwgsimError, match="failed to generate a read after 10001 trials"):
+        api.run_job_api(api.parse_flags("-z 6466 -1 33 -2 150 -d 900 -s 50 -N 1200 -r 0 -e 0.0-0.1 -Q 0 -a", emu_lib), api.read_fasta(fa), devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=50, min_share=1, lib=emu_lib)
+
+
 def test_abort_rule_counts_per_contig_inside_a_group(emu_lib, oracle_bin, golden_dir, tmp_path):
     """`int num_failed = 0` sits inside the contig loop (dwgsim.c:635): a job whose failures add up to more than 10 000 over TWO contigs, but
     not inside either, runs to the end.  With both contigs in one group -- one launch across the boundary -- the counter must still start
