@@ -2,29 +2,34 @@
 """bench.py -- throughput of the MI355X dwgsim hot path on BASELINE.json's metric
 ("M read-pairs/sec, 2x150 bp PE").
 
-A step = one pass of the hot path over one job held resident in HBM: the mutation walk of the
-contig (replaces mut_diref) followed by the per-pair loop over the job's whole read-index range
-(replaces dwgsim.c:636-1099), FASTQ text left packed in HBM.
+A step = one pass of the hot path over one job held resident in HBM: the mutation walk of every contig
+(replaces mut_diref) followed by the per-pair loop over this rank's read-index ranges (replaces
+dwgsim.c:636-1099), FASTQ text left packed in HBM.  Contigs are resident in groups of up to --group-bp
+bases (dwgsim_hip_add_contigs): one chain of walk kernels and a few launches per group, however many contigs.
 
 Workload at N=1 (default): BASELINE configs[2], the largest single-GPU configuration -- S3, a chr20-sized
 synthetic contig (64 444 167 bp with telomere / centromere N blocks), `-z 13 -1 150 -2 150 -C 30 -o 1`
 (-r 0.001 -R 0.1 are dwgsim's defaults) => 6 783 597 pairs and 4.9 GB of FASTQ text per step.
-`--workload ecoli` is configs[1] (S2, 488 595 pairs), `--workload grch38` the whole-genome S4 job.
+`--workload ecoli` is configs[1] (S2, 488 595 pairs), `--workload grch38` the whole-genome S4 job,
+`--workload assembly5k` a scaffold-level assembly (5000 contigs, N50 ~ 50 kb).
 
-N>1 (one process per GPU, launched by torch.distributed.run): no data-path collective and no RCCL -- the ranks
-own disjoint read-index ranges and exchange ONE integer each per step (the random-read count that offsets
-rand_ii, dwgsim.c:1042,1096) through a host-side (gloo) all-gather.
-  --mode weak   (default) every rank simulates a full job's worth of pairs: rank r owns [r n, (r+1) n) of an N-times deeper job
-  --mode strong one fixed job (e.g. the S4 genome at 30x) split over the ranks per contig
+N>1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run) when no launcher did.
+Sharding is the product's (dw_job.cpp): the pairs of every group of contigs, in file order, are cut into batches of read-index ranges and
+batch b belongs to rank b mod N; every rank walks every contig itself.  No data-path collective and no RCCL: what crosses ranks is ONE
+host-side (gloo) all-gather of integers per step -- the random reads of every batch, counted (k_place) before anything is simulated, whose
+running sum offsets rand_ii (dwgsim.c:1042,1096); a job of many groups takes a second one, so that the walks of the later groups run
+behind the kernels of the first.
+  --mode weak   (default) per-GPU work is fixed: the job's coverage is N times the workload's (-C 30 N), i.e. N times the pairs
+  --mode strong one fixed job (e.g. --workload grch38: the 325 M-pair S4 genome) split over the ranks
 
-`value` = pairs of all ranks / max-over-ranks wall time of the timed steps, text left in HBM (the contract).  Two more
-legs are measured at N=1 and reported beside it (never as `value`): `host_landed` (text copied into page-locked host
-memory through the asynchronous two-slot pipeline, copies overlapped with kernels) and `end_to_end` (the dwgsim-hip
-executable: FASTA in, five output files out, gzip included).
+`value` = pairs of all ranks / max-over-ranks wall time of the timed steps, text left in HBM (the contract).  More legs are measured at
+N=1 and reported beside it (never as `value`): `host_landed` (text copied into page-locked host memory through the asynchronous
+two-slot pipeline), `host_landed_gz` (the same with the gzip members made on the GPU -- what the product moves), `end_to_end` (the
+dwgsim-hip executable: FASTA in, five output files out) and `end_to_end_genome` (dwgsim-hip on the whole S4 genome, counting sink).
 
 Prints ONE JSON line on rank 0.
 """
-import argparse, json, os, subprocess, sys, tempfile, time
+import argparse, hashlib, json, os, subprocess, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,7 +38,17 @@ FLAGS = "-z 13 -1 150 -2 150 -C 30 -o 1"
 ION_FLAGS = "-z 13 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 400 -2 0 -C 50 -e 0.01 -o 1"
 ALGO_BYTES_PER_PAIR_2x150 = 863.0  # 713 B FASTQ written + 150 B haplotype bases read at 4 bit/base
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
-WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3)}
+WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3), "assembly5k": ("5000 scaffolds, N50 ~ 50 kb", 3)}
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
+MAX_LAUNCH_PAIRS = 1 << 23         # pairs per launch at most (a launch's text buffers are sized for it: 6 GB at 2 x 150 bp)
+
+
+def file_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def _tmpdir():
@@ -108,12 +123,12 @@ def cpu_baseline(contigs, flags, sample_pairs=250000):
     return out
 
 
-def host_landed_leg(api, ctx, cid, n_pairs, params, steps=2, batch=1 << 20):
-    """Text of every batch copied into page-locked host memory while the next batch is being computed (two slots, copy stream)."""
-    import ctypes as C
+def host_landed_leg(api, ctx, cid, n_pairs, gz=False, steps=2, batch=1 << 20):
+    """Output of every batch copied into page-locked host memory while the next batch is being computed (two slots, copy stream):
+    the text, or (gz) the gzip members k_gzip made of it -- what dwgsim-hip moves and writes."""
     lib = ctx.lib
-    nstreams = [s for s in range(3)]
     bufs = {}
+    ctx.set_gzip(gz)
 
     def ensure(slot, s, n):
         cap, p = bufs.get((slot, s), (0, None))
@@ -128,38 +143,49 @@ def host_landed_leg(api, ctx, cid, n_pairs, params, steps=2, batch=1 << 20):
 
     def finish(slot):
         b = ctx.wait(slot)
-        for s in nstreams:
-            if b.bytes[s]:
-                cap, p = ensure(slot, s, b.bytes[s])
-                ctx.fetch_async(slot, s, p, cap)
-        return b
+        sizes = b.gz_bytes if gz else b.bytes
+        for s in range(3):
+            if sizes[s]:
+                cap, p = ensure(slot, s, sizes[s])
+                if gz:
+                    ctx._chk(lib.dwgsim_hip_fetch_gz_async(ctx.h, slot, s, p, cap))
+                else:
+                    ctx.fetch_async(slot, s, p, cap)
+        return sum(sizes), sum(b.bytes)
 
     def one_pass():
-        tot = 0
+        moved = text = 0
         k = 0
         for off in range(0, n_pairs, batch):
             n = min(batch, n_pairs - off)
             slot = k & 1
+            ctx.fetch_wait(slot)
             ctx.simulate_async(cid, off, n, 0 if off == 0 else api.RAND_CHAIN, slot)
             if k > 0:
-                b = finish((k - 1) & 1); tot += sum(b.bytes)
+                a, b = finish((k - 1) & 1); moved += a; text += b
             k += 1
-        b = finish((k - 1) & 1); tot += sum(b.bytes)
+        a, b = finish((k - 1) & 1); moved += a; text += b
         ctx.fetch_wait(0); ctx.fetch_wait(1)
-        return tot
+        return moved, text
     one_pass()                                                # warm-up: allocations, page-locking
     t0 = time.perf_counter()
-    tot = 0
+    moved = text = 0
     for _ in range(steps):
-        tot += one_pass()
+        a, b = one_pass(); moved += a; text += b
     dt = time.perf_counter() - t0
     for cap, p in bufs.values():
         lib.dwgsim_hip_host_free(p)
-    return {"value": round(n_pairs * steps / dt / 1e6, 3), "unit": "M read-pairs/s", "gb_per_s": round(tot / dt / 1e9, 2), "steps": steps, "batch_pairs": batch,
-            "note": "FASTQ text landed in page-locked host memory: simulate_async / wait / fetch_async on two slots, copies on a second stream overlapped with the kernels of the next batch"}
+    ctx.set_gzip(False)
+    out = {"value": round(n_pairs * steps / dt / 1e6, 3), "unit": "M read-pairs/s", "gb_per_s": round(moved / dt / 1e9, 2), "steps": steps, "batch_pairs": batch}
+    if gz:
+        out["text_gb_per_s"] = round(text / dt / 1e9, 2); out["gz_ratio"] = round(moved / max(text, 1), 4)
+        out["note"] = "gzip members made on the GPU (k_gzip behind k_simulate) landed in page-locked host memory: what dwgsim-hip writes to its .gz files"
+    else:
+        out["note"] = "FASTQ text landed in page-locked host memory: simulate_async / wait / fetch_async on two slots, copies on a second stream overlapped with the kernels of the next batch"
+    return out
 
 
-def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu"):
+def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu", fai=False, null_sink=False):
     """The dwgsim-hip executable on the same job: FASTA parse, upload, walk, mutation files, reads, gzip (members made on the GPU, or
     zlib on the host cores with DWGSIM_HIP_GZIP=cpu), page-locked copies, the five output files written (to tmpfs when there is one)."""
     from dwgsim_amd import synth
@@ -169,9 +195,18 @@ def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu"):
     with tempfile.TemporaryDirectory(dir=_tmpdir()) as t:
         fa = os.path.join(t, "ref.fa")
         synth.write_fasta(fa, contigs)
+        if fai:      # the index the reference reads its contig table from (dwgsim.c:465-478): with it the FASTA is streamed, contig by contig
+            with open(fa + ".fai", "w") as f:
+                off = 0
+                for name, arr in contigs:
+                    off += len(name) + 2
+                    f.write(f"{name}\t{len(arr)}\t{off}\t60\t61\n")
+                    off += len(arr) + (len(arr) + 59) // 60
+        env = dict(os.environ, DWGSIM_HIP_GZIP=gzip_mode, DWGSIM_HIP_TIMING="1", DWGSIM_HIP_DEVICES="1")
+        if null_sink:
+            env["DWGSIM_HIP_SINK"] = "null"
         t0 = time.time()
-        r = subprocess.run([exe] + flags.split() + [fa, os.path.join(t, "out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                           env=dict(os.environ, DWGSIM_HIP_GZIP=gzip_mode, DWGSIM_HIP_TIMING="1"))
+        r = subprocess.run([exe] + flags.split() + [fa, os.path.join(t, "out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.time() - t0
         if r.returncode != 0:
             return {"error": r.stderr.decode(errors="replace")[-300:]}
@@ -181,7 +216,30 @@ def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu"):
               {"where": "cpu", "threads": effective_cores(), "zlib_level": int(os.environ.get("DWGSIM_HIP_GZIP_LEVEL", "1")), "members": "independent 1 MiB gzip members"})
     return {"seconds": round(dt, 2), "value": round(n_pairs / dt / 1e6, 3), "unit": "M read-pairs/s", "gz_bytes": gz, "gzip": gzinfo,
             "stages": stages[-1][13:] if stages else None,
-            "note": "wall time of `dwgsim-hip <flags> ref.fa out` (process start to exit), outputs on " + ("tmpfs" if _tmpdir() else "the temp dir")}
+            "note": "wall time of `dwgsim-hip <flags> ref.fa out` (process start to exit, one GPU), " +
+                    ("FASTQ deliveries counted, not written (DWGSIM_HIP_SINK=null)" if null_sink else "outputs on " + ("tmpfs" if _tmpdir() else "the temp dir"))}
+
+
+def make_groups(job, group_bp):
+    """consecutive contigs, up to group_bp bases together (a contig that is longer stands alone)"""
+    groups, cur, cur_bp = [], [], 0
+    for ent in job:
+        l = (len(ent[1]) + 4095) // 4096 * 4096
+        if cur and cur_bp + l > group_bp:
+            groups.append(cur); cur, cur_bp = [], 0
+        cur.append(ent); cur_bp += l
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def balanced_batches(api, ranges, world, max_pairs):
+    """the pairs of a group, in file order, in a multiple of `world` near-equal batches of at most max_pairs (batch b: rank b mod world)"""
+    pairs = sum(n for _, _, n in ranges)
+    if pairs == 0:
+        return []
+    nb = world * -(-pairs // (world * max_pairs))
+    return list(api.split_ranges(ranges, -(-pairs // nb)))
 
 
 def main():
@@ -191,9 +249,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="chr20", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--group-bp", type=int, default=32 << 20, help="contigs are resident together (one walk chain, launches across contigs) up to this many bases")
     ap.add_argument("--ion", action="store_true", help="BASELINE configs[4] flags (Ion Torrent flow model, 400 bp SE, 50x) instead of 2x150 Illumina")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the host_landed / end_to_end legs")
+    ap.add_argument("--no-genome-leg", action="store_true", help="skip the end_to_end_genome leg (dwgsim-hip on the whole S4 genome: about a minute, most of it making the synthetic FASTA)")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
@@ -225,38 +285,51 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo")          # host-side exchange of one integer per rank and step; no RCCL on this path
+        dist.init_process_group("gloo")          # host-side exchange of integers; no RCCL on this path
 
     lib = api.load()
     flags = args.flags or (ION_FLAGS if args.ion else FLAGS)
-    params = api.parse_flags(flags, lib)
+    params = api.parse_flags(flags, lib)                  # the workload's own configuration (the legs and baselines run it)
+    job_flags = flags
+    if args.mode == "weak" and world > 1:                 # per-GPU work fixed: world times the coverage
+        toks = flags.split(); i = toks.index("-C"); toks[i + 1] = repr(float(toks[i + 1]) * world); job_flags = " ".join(toks)
+    job_params = api.parse_flags(job_flags, lib)
     contigs = synth.workload_contigs(args.workload)
     tot_len = sum(len(a) for _, a in contigs)
     paired = params.length[1] > 0
 
-    ctx = api.Context(params, dev, lib)
+    ctx = api.Context(job_params, dev, lib)
     if args.phases:
         ctx.debug_option("phases", 1)
-    # the job: pairs per contig exactly as dwgsim_core schedules them (dwgsim.c:582-590); every contig stays resident
+    # the job: pairs per contig exactly as dwgsim_core schedules them (dwgsim.c:582-590); every contig stays resident, in groups
     job = []
     n_sim = 0
     for ci, (name, arr) in enumerate(contigs):
-        n = api.pairs_for_contig(params, len(arr), tot_len, ci == len(contigs) - 1, n_sim, lib)
+        n = api.pairs_for_contig(job_params, len(arr), tot_len, ci == len(contigs) - 1, n_sim, lib)
         if n < 0:
             continue
-        cid = ctx.add_contig(name, arr, ci)
-        job.append((cid, n))
+        job.append((name, arr, ci, n))
         n_sim += n
-    job_pairs = sum(n for _, n in job)
-    if args.mode == "weak":
-        my_pairs = job_pairs
-        ranges = [(cid, rank * n, n) for cid, n in job]                   # rank r: [r n, (r+1) n) of the N-times deeper job
-    else:
-        ranges = []
-        for cid, n in job:
-            first, cnt = api.shard_range(n, rank, world, lib)
-            ranges.append((cid, first, cnt))
-        my_pairs = sum(c for _, _, c in ranges)
+    job_pairs = sum(e[3] for e in job)
+    groups = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
+    for grp in make_groups(job, args.group_bp):
+        h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
+        launches = balanced_batches(api, [(h0 + k, 0, n) for k, (_, _, _, n) in enumerate(grp) if n > 0], world, MAX_LAUNCH_PAIRS)
+        groups.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)], "launches": launches, "mine": [b for b in range(len(launches)) if b % world == rank], "pairs": sum(n for l in launches for _, _, n in l)})
+    my_pairs = sum(n for g in groups for b in g["mine"] for _, _, n in g["launches"][b])
+    n_my_launches = sum(len(g["mine"]) for g in groups)
+
+    # groups whose random reads are exchanged together: the first ~1/8 of the job's pairs alone (so that the walks and counts of the
+    # rest run behind its kernels), then everything else
+    chunks = [list(range(len(groups)))]
+    if world > 1 and len(groups) > 2:
+        acc, cut = 0, 0
+        for gi, g in enumerate(groups):
+            acc += g["pairs"]; cut = gi + 1
+            if acc * 8 >= job_pairs:
+                break
+        if 0 < cut < len(groups):
+            chunks = [list(range(cut)), list(range(cut, len(groups)))]
 
     def barrier():
         torch.cuda.synchronize()
@@ -264,35 +337,70 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stats = {"walk_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
+    stats = {"prep_ms": 0.0, "count_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
 
     def step(record):
+        for g in groups:
+            ctx.mutate_async(g["h0"])                              # every rank walks every group itself (deterministic, cheap): all enqueued on the walk stream
         rand_before = 0
-        nbytes = 0; nrand = 0
-        for cid, first, cnt in ranges:
-            t0 = time.perf_counter()
-            ctx.mutate(cid)                                        # mutation walk on the GPU (every rank re-walks: deterministic, cheap)
-            t1 = time.perf_counter()
-            rand_base = rand_before
-            if world > 1:
-                # one integer per rank (no data-path collective): random reads in the ranges of lower ranks, host-side all-gather
-                mine = torch.tensor([ctx.count_random(cid, first, cnt) if cnt else 0], dtype=torch.int64)
-                allc = torch.empty(world, dtype=torch.int64)
-                dist.all_gather_into_tensor(allc, mine)
-                rand_base += int(allc[:rank].sum())
-                rand_before += int(allc.sum())
-            t2 = time.perf_counter()
-            if cnt:
-                b = ctx.simulate(cid, first, cnt, rand_base, 0)
-                nbytes += int(b.bytes[0] + b.bytes[1] + b.bytes[2]); nrand += int(b.n_random)
-                if world == 1:
-                    rand_before += int(b.n_random)
+        acc = {"bytes": 0, "rand": 0}
+        slot = 0
+        pending = []
+
+        def drain(keep):
+            while len(pending) > keep:
+                b = ctx.wait(pending.pop(0))
+                acc["bytes"] += int(b.bytes[0] + b.bytes[1] + b.bytes[2]); acc["rand"] += int(b.n_random)
                 if record:
                     stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
+        first_launch = True
+        for chunk in chunks:
+            t0 = time.perf_counter()
+            tc = 0.0
+            counts = []
+            for gi in chunk:
+                g = groups[gi]
+                ctx.mutate_wait(g["h0"])
+                if world > 1:
+                    t1 = time.perf_counter()
+                    flat = [r for b in g["mine"] for r in g["launches"][b]]
+                    per = ctx.count_random_ranges(flat, per_range=True) if flat else []      # (on the walk stream: behind the walks, beside the kernels)
+                    it = iter(per)
+                    counts.append([sum(next(it) for _ in g["launches"][b]) for b in g["mine"]])
+                    tc += time.perf_counter() - t1
+            t2 = time.perf_counter()
+            bases = {}
+            if world > 1:
+                # ONE all-gather for the chunk: per rank, the counts of its launches in (group, launch) order, padded to a common width
+                width = max(1, max(-(-len(groups[gi]["launches"]) // world) for gi in chunk))
+                mine_vec = torch.zeros(len(chunk) * width, dtype=torch.int64)
+                for q, gi in enumerate(chunk):
+                    for k, cval in enumerate(counts[q]):
+                        mine_vec[q * width + k] = cval
+                allv = torch.empty(world * mine_vec.numel(), dtype=torch.int64)
+                dist.all_gather_into_tensor(allv, mine_vec)
+                allv = allv.view(world, len(chunk), width)
+                for q, gi in enumerate(chunk):      # launch b belongs to rank b mod world; its count sits at that rank's position b // world
+                    run = rand_before
+                    for b in range(len(groups[gi]["launches"])):
+                        if b % world == rank:
+                            bases[(gi, b)] = run
+                        run += int(allv[b % world, q, b // world])
+                    rand_before = run
+            t3 = time.perf_counter()
             if record:
-                stats["walk_ms"] += (t1 - t0) * 1e3; stats["exch_ms"] += (t2 - t1) * 1e3
+                stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
+            for gi in chunk:
+                g = groups[gi]
+                for b in g["mine"]:
+                    drain(1)
+                    base = bases[(gi, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
+                    first_launch = False
+                    ctx.simulate_ranges_async(g["launches"][b], base, slot)
+                    pending.append(slot); slot ^= 1
+        drain(0)
         if record:
-            stats["bytes"] = nbytes; stats["n_random"] = nrand
+            stats["bytes"] = acc["bytes"]; stats["n_random"] = acc["rand"]
 
     for _ in range(args.warmup):
         step(False)
@@ -316,7 +424,7 @@ def main():
         ms_per_step = elapsed / K * 1e3
         value = total_pairs * K / elapsed / 1e6
         sim_ms_launch = stats["sim_kernel_ms"] / max(stats["launches"], 1)          # average duration of one k_simulate launch
-        pairs_per_launch = my_pairs / max(len([1 for _, _, c in ranges if c]), 1)
+        pairs_per_launch = my_pairs / max(n_my_launches, 1)
         text_per_pair = stats["bytes"] / max(my_pairs, 1)
         if not args.ion and args.flags is None:
             algo_per_pair = ALGO_BYTES_PER_PAIR_2x150
@@ -325,42 +433,67 @@ def main():
             algo_per_pair = text_per_pair + (params.length[0] + params.length[1]) / 2.0
             algo_note = f"{algo_per_pair:.0f} algorithmic B per pair/read = {text_per_pair:.1f} B of FASTQ written (measured) + {(params.length[0] + params.length[1]) / 2:.0f} B of haplotype bases read at 4 bit/base"
         achieved = algo_per_pair * pairs_per_launch / (sim_ms_launch * 1e-3) / 1e9 if sim_ms_launch > 0 else 0.0
-        prof = {}
+        # counter evidence (profiles/r03_counters.json, made by tools/make_counters_json.py from rocprofv3 PMC passes) is quoted only when it was
+        # taken on exactly the library that is being timed now
+        lib_sha = file_sha256(api.LIB_PATH)
+        prof, prof_note = {}, None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json"))).get(f"{args.workload}{'_ion' if args.ion else ''}", {})
+            ent = json.load(open(COUNTERS_JSON)).get(f"{args.workload}{'_ion' if args.ion else ''}", {})
+            if ent and ent.get("lib_sha256") == lib_sha and ent.get("pairs_per_launch") == int(pairs_per_launch):
+                prof = ent
+            elif ent:
+                prof_note = (f"{os.path.relpath(COUNTERS_JSON, ROOT)} holds counters of another build (library sha256 {str(ent.get('lib_sha256'))[:12]}..., "
+                             f"this one {lib_sha[:12]}...) or launch size: not quoted")
         except Exception:
-            pass
+            prof_note = "no counter file for this round"
         sname, cfg_i = WORKLOADS[args.workload]
         out = {
             "metric": "M read-pairs/sec (2x150 bp PE)" if not args.ion else "M reads/sec (Ion Torrent 400 bp SE)", "value": round(value, 3), "unit": "M read-pairs/s" if paired else "M reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{sname} ({args.workload}): {len(job)} uniform-random contig(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {flags}, "
+            "config": {"workload": f"{sname} ({args.workload}): {len(job)} uniform-random contig(s) in {len(groups)} resident group(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {job_flags}, "
                                    f"{job_pairs} pairs per job; step = mutation walk of every contig + all pairs of this rank's read-index ranges, FASTQ text left in HBM",
-                       "pairs_per_gpu_per_step": my_pairs, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
-                       "random_pairs": stats["n_random"], "parallelism": f"read-index shards x{world} ({args.mode}), host-side exchange of one integer per rank"},
-            "breakdown_ms": {"walk": round(stats["walk_ms"] / K, 4), "rand_count_exchange": round(stats["exch_ms"] / K, 4), "simulate_kernels": round(stats["sim_kernel_ms"] / K, 4)},
+                       "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
+                       "random_pairs": stats["n_random"],
+                       "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), {len(chunks)} host-side all-gather(s) of integers per step" if world > 1 else "one GPU")},
+            "breakdown_ms": {"wait_for_walks": round(stats["prep_ms"] / K, 4), "count_random": round(stats["count_ms"] / K, 4), "exchange": round(stats["exch_ms"] / K, 4), "simulate_kernels": round(stats["sim_kernel_ms"] / K, 4),
+                             "note": "host time before this rank's launches of each exchange chunk (walks and counts run on their own stream, those of later groups behind the kernels of earlier ones), and the HIP-event time of the k_simulate launches"},
             "roofline": {"bound": "valu", "kernel": f"k_simulate<{2 if paired else 1},{[3, 1, 2][params.reads_output_type]},{params.data_type}>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": prof.get("traffic_bytes_per_launch") if prof.get("pairs_per_launch") == int(pairs_per_launch) else None,
-                         "algorithmic_bytes_per_launch": int(algo_per_pair * pairs_per_launch), "launch_ms": round(sim_ms_launch, 4),
-                         "valu": {k: prof[k] for k in ("valu_instr_per_pair", "valu_instr_per_wave", "salu_instr_per_wave", "valu_issue_active_pct", "source") if k in prof},
+                         "traffic": prof.get("traffic_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": int(algo_per_pair * pairs_per_launch), "launch_ms": round(sim_ms_launch, 4), "library_sha256": lib_sha,
+                         "valu": {k: prof[k] for k in ("valu_instr_per_pair", "valu_instr_per_wave", "salu_instr_per_wave", "valu_issue_active_pct", "source", "git_head") if k in prof},
                          "note": algo_note + " x pairs per launch / HIP-event time of the launch (events on the library's own stream); the kernel is bound by VALU issue "
                                  "(Philox rounds, fp32 / fp64 quality normals, text formatting), not by HBM: the fraction of the HBM roof says how far the ALU work has been squeezed"},
         }
+        if prof_note:
+            out["roofline"]["counters_note"] = prof_note
         if world == 1 and not args.no_legs:
-            cid0, n0 = max(job, key=lambda x: x[1])
+            g0 = max(groups, key=lambda g: g["pairs"])
+            cid0, n0 = max(g0["members"], key=lambda m: m[1])          # the contig with the most pairs
             ctx.mutate(cid0)
-            out["host_landed"] = host_landed_leg(api, ctx, cid0, n0, params)
+            out["host_landed"] = host_landed_leg(api, ctx, cid0, n0)
+            out["host_landed_gz"] = host_landed_leg(api, ctx, cid0, n0, gz=True)
         ctx.close(); ctx = None
+        small = [(name, arr) for name, arr, _, _ in job]
         if world == 1 and not args.no_legs and args.workload in ("ecoli", "chr20"):
-            out["end_to_end"] = end_to_end_leg(contigs, flags, job_pairs)
-            cpu_gz = end_to_end_leg(contigs, flags, job_pairs, "cpu")
+            out["end_to_end"] = end_to_end_leg(small, flags, job_pairs)
+            cpu_gz = end_to_end_leg(small, flags, job_pairs, "cpu")
             if cpu_gz and "seconds" in cpu_gz:
                 out["end_to_end"]["with_zlib_on_host"] = {k: cpu_gz[k] for k in ("seconds", "value", "gz_bytes", "gzip")}
         if world == 1 and not args.no_cpu_baseline:
-            base_contigs = contigs[:1] if len(contigs) == 1 else [c for c in contigs if c[0] == "chr20"] or contigs[:1]      # (whole-genome jobs: the chr20-sized contig)
+            base_contigs = small[:1] if len(small) == 1 else [c for c in small if c[0] == "chr20"] or small[:1]      # (whole-genome jobs: the chr20-sized contig)
             out["cpu_baseline"] = cpu_baseline(base_contigs, flags)
+        if world == 1 and not args.no_legs and not args.no_genome_leg and not args.ion and args.flags is None:
+            # steady state of the product: dwgsim-hip on the whole S4 genome (BASELINE configs[3] on one GPU), FASTA streamed through its .fai,
+            # 325 M pairs, 232 GB of text -> 115 GB of gzip members landed in host memory and counted (they would not fit a tmpfs)
+            g38 = small if args.workload == "grch38" else synth.workload_contigs("grch38")
+            job = groups = small = contigs = None
+            tl = sum(len(a) for _, a in g38)
+            npairs = 0
+            for ci, (name, arr) in enumerate(g38):
+                npairs += max(api.pairs_for_contig(params, len(arr), tl, ci == len(g38) - 1, npairs, lib), 0)
+            out["end_to_end_genome"] = end_to_end_leg(g38, flags, npairs, fai=True, null_sink=True)
         print(json.dumps(out), flush=True)
     if ctx is not None:
         ctx.close()

@@ -105,9 +105,9 @@ struct dwgsim_hip_ctx {
     std::vector<Group> groups;
     std::vector<HandleRef> handles;          // contig handle -> (group, member); handles are never reused
     // simulate() working set
-    DevBuf meta, fail_summ, block_rand, status_all, out[2][3], place_segs;
+    DevBuf meta, fail_summ, block_rand, status_all, out[2][3];
     // walk-stream working set (grow-only)
-    DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells;
+    DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand;
     uint8_t *h_up = nullptr; size_t h_up_cap = 0; hipEvent_t ev_up = nullptr; bool up_in_flight = false;      // page-locked staging of a group's sequence
     SimSeg *h_place_segs = nullptr; size_t h_place_segs_cap = 0;
     std::vector<int32_t> h_ppos; std::vector<uint16_t> h_pcells; std::vector<Event> h_pev;      // file-driven mutations of the group being walked
@@ -117,6 +117,7 @@ struct dwgsim_hip_ctx {
     DevBuf flow_scratch;
     uint64_t *d_counters = nullptr, *h_counters = nullptr;          // N_COUNTERS x u64 + pinned mirror: calibrate / count_random / debug hooks (compute stream)
     uint64_t *d_wcounters = nullptr, *h_wcounters = nullptr;        // 16 x u64 + pinned mirror: the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
+    uint64_t *d_pcounters = nullptr, *h_pcounters = nullptr;        // N_COUNTERS x u64 + pinned mirror: count_random (walk stream)
     Slot slot[2];                            // simulate(): two batches in flight (kernels of one overlap the copy-out of the other)
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
@@ -369,6 +370,8 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_wcounters, 16 * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_wcounters, 16 * sizeof(uint64_t), hipHostMallocDefault));
+        HIPC(c, hipMalloc((void **)&c->d_pcounters, N_COUNTERS * sizeof(uint64_t)));
+        HIPC(c, hipHostMalloc((void **)&c->h_pcounters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_chain, 4 * sizeof(uint64_t)));
         HIPC(c, hipMemset(c->d_chain, 0, 4 * sizeof(uint64_t)));
         for (Slot &sl : c->slot) {
@@ -501,12 +504,13 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->walk_stream) hipStreamSynchronize(c->walk_stream);
     for (auto &g : c->groups) if (g.alive) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
-    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->place_segs, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
+    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->place_segs, &c->place_rand, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
                       &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch}) hipFree(b->p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
-    hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
+    hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->h_wcounters) hipHostFree(c->h_wcounters);
+    if (c->h_pcounters) hipHostFree(c->h_pcounters);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_up) hipHostFree(c->h_up);
     if (c->h_place_segs) hipHostFree(c->h_place_segs);
@@ -1136,44 +1140,45 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     Group &g = *gp;
     HIPC(c, hipSetDevice(c->device));
+    // (on the walk stream: the count of one group can run while batches of another -- or of this one -- are being simulated)
     if (!g.summ_valid) {         // per-64-cell summaries of the two haplotypes: let k_place accept clean windows without walking them
         const size_t nb = (size_t)((g.total + SUMM_CELLS - 1) / SUMM_CELLS);
         for (int h = 0; h < 2; ++h) {
             if (!g.d_summ[h]) HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (nb ? nb : 1)));
-            launch_summarize(c->stream, g.d_cells[h], g.total, g.d_summ[h]);
+            launch_summarize(c->walk_stream, g.d_cells[h], g.total, g.d_summ[h]);
         }
         g.summ_valid = true;
     }
     SimArgs a;
     if (const int rc = fill_sim_args(c, g, a)) return rc;
-    if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)n_blocks)) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->place_rand, sizeof(uint32_t) * (size_t)n_blocks)) return DWGSIM_HIP_ERR_DEVICE;
     if (ensure(c, c->place_segs, sizeof(SimSeg) * segs.size())) return DWGSIM_HIP_ERR_DEVICE;
     if (segs.size() > c->h_place_segs_cap) {
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipStreamSynchronize(c->walk_stream));
         if (c->h_place_segs) HIPC(c, hipHostFree(c->h_place_segs));
         c->h_place_segs = nullptr; c->h_place_segs_cap = 0;
         HIPC(c, hipHostMalloc((void **)&c->h_place_segs, sizeof(SimSeg) * (segs.size() + 64), hipHostMallocDefault));
         c->h_place_segs_cap = segs.size() + 64;
     }
     memcpy(c->h_place_segs, segs.data(), sizeof(SimSeg) * segs.size());
-    HIPC(c, hipMemcpyAsync(c->place_segs.p, c->h_place_segs, sizeof(SimSeg) * segs.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->place_segs.p, c->h_place_segs, sizeof(SimSeg) * segs.size(), hipMemcpyHostToDevice, c->walk_stream));
     a.segs = (const SimSeg *)c->place_segs.p; a.n_seg = (int32_t)segs.size(); a.n_blocks = n_blocks; a.n_pairs = n_pairs;
-    a.block_rand = (uint32_t *)c->block_rand.p; a.counters = c->d_counters;
-    HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
-    launch_place(c->stream, a);
-    launch_scan_excl(c->stream, a.block_rand, n_blocks, &c->d_counters[3]);
-    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
-    if (c->h_counters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
-    if (n_random) *n_random = c->h_counters[3];
+    a.block_rand = (uint32_t *)c->place_rand.p; a.counters = c->d_pcounters;
+    HIPC(c, hipMemsetAsync(c->d_pcounters, 0, N_COUNTERS * sizeof(uint64_t), c->walk_stream));
+    launch_place(c->walk_stream, a);
+    launch_scan_excl(c->walk_stream, a.block_rand, n_blocks, &c->d_pcounters[3]);
+    HIPC(c, hipMemcpyAsync(c->h_pcounters, c->d_pcounters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->walk_stream));
+    HIPC(c, hipStreamSynchronize(c->walk_stream));
+    if (c->h_pcounters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
+    if (n_random) *n_random = c->h_pcounters[3];
     if (per_range) {      // the scanned per-block counts hold every range's share: prefix at its first block .. prefix at the next range's
         std::vector<uint32_t> pre((size_t)n_blocks);
-        HIPC(c, hipMemcpyAsync(pre.data(), a.block_rand, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, c->stream));
-        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipMemcpyAsync(pre.data(), a.block_rand, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, c->walk_stream));
+        HIPC(c, hipStreamSynchronize(c->walk_stream));
         size_t si = 0;
         for (int q = 0; q < n; ++q) {
             if (r[q].n_pairs == 0) continue;
-            const uint64_t lo = pre[segs[si].first_block], hi = si + 1 < segs.size() ? pre[segs[si + 1].first_block] : c->h_counters[3];
+            const uint64_t lo = pre[segs[si].first_block], hi = si + 1 < segs.size() ? pre[segs[si + 1].first_block] : c->h_pcounters[3];
             per_range[q] = hi - lo; ++si;
         }
     }

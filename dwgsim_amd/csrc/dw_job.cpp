@@ -339,15 +339,18 @@ int dispatch_pending(dwgsim_hip_job *j)
     g->pairs = 0; for (int64_t n : g->n_pairs) g->pairs += (uint64_t)n;
     g->nd = j->ND;
     while (g->nd > 1 && g->pairs / (uint64_t)g->nd < j->min_share) --g->nd;
-    if (j->want_reads) {
-        std::vector<dwgsim_hip_range_t> cur; uint64_t room = j->batch_pairs, cur_pairs = 0;
+    if (j->want_reads && g->pairs) {
+        // a multiple of nd near-equal batches of at most batch_pairs pairs: every device gets the same number of them, of the same size
+        const uint64_t nbt = (uint64_t)g->nd * ((g->pairs + (uint64_t)g->nd * j->batch_pairs - 1) / ((uint64_t)g->nd * j->batch_pairs));
+        const uint64_t per = (g->pairs + nbt - 1) / nbt;
+        std::vector<dwgsim_hip_range_t> cur; uint64_t room = per, cur_pairs = 0;
         for (size_t k = 0; k < g->n_pairs.size(); ++k) {
             uint64_t first = 0, n = (uint64_t)g->n_pairs[k];
             while (n > 0) {
                 const uint64_t take = n < room ? n : room;
                 dwgsim_hip_range_t r; memset(&r, 0, sizeof r); r.contig = (int32_t)k; r.first_ii = first; r.n_pairs = take;
                 cur.push_back(r); first += take; n -= take; room -= take; cur_pairs += take;
-                if (room == 0) { g->batches.push_back(cur); g->batch_pairs.push_back(cur_pairs); cur.clear(); room = j->batch_pairs; cur_pairs = 0; }
+                if (room == 0) { g->batches.push_back(cur); g->batch_pairs.push_back(cur_pairs); cur.clear(); room = per; cur_pairs = 0; }
             }
         }
         if (!cur.empty()) { g->batches.push_back(cur); g->batch_pairs.push_back(cur_pairs); }

@@ -15,6 +15,7 @@
 //     DWGSIM_HIP_GROUP_BP  consecutive contigs are resident together up to this many bases (default 32 Mi)
 //     DWGSIM_HIP_MIN_SHARE a group is spread over fewer devices while a device's share would be below this many pairs (default 65536)
 //     DWGSIM_HIP_TIMING    print the stage times
+//     DWGSIM_HIP_SINK      "null": measurement aid -- the FASTQ deliveries are counted, not written (the .gz files stay empty)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -202,7 +203,7 @@ static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return
 // what the job delivers, written as the reference writes it (dwgsim.c:919-981 -> the three .gz files, mut.c:781-893 -> the two mutation files)
 struct FileSink {
     FILE *fp_txt = nullptr, *fp_vcf = nullptr, *fgz[3] = {nullptr, nullptr, nullptr};
-    DeflatePool *pool = nullptr;
+    DeflatePool *pool = nullptr; bool null_sink = false;
     std::atomic<uint64_t> bytes_in{0}, bytes_out{0};
     static int mutations(void *u, const char *, const char *txt, size_t tl, const char *vcf, size_t vl)
     {
@@ -217,6 +218,7 @@ struct FileSink {
         FILE *f = s->fgz[stream];
         if (!f) return 1;
         s->bytes_in += text_len;
+        if (s->null_sink) { s->bytes_out += len; return 0; }
         if (gz) { s->bytes_out += len; return fwrite(data, 1, len, f) == len ? 0 : 1; }
         const long before = ftell(f);
         if (!s->pool->write(f, (const char *)data, len)) return 1;
@@ -325,6 +327,7 @@ int main(int argc, char **argv)
 
     const bool has_bfast = want_reads && o.reads_output_type != 1, has_bwa = want_reads && o.reads_output_type != 2;
     FileSink fs;
+    if (const char *e = getenv("DWGSIM_HIP_SINK")) fs.null_sink = !strcmp(e, "null");
     std::string p = out_prefix;
     if (want_mut) {
         fs.fp_txt = fopen((p + ".mutations.txt").c_str(), "w"); fs.fp_vcf = fopen((p + ".mutations.vcf").c_str(), "w");

@@ -107,6 +107,14 @@ def workload_contigs(name: str):
         return [("ecoli_synth", random_contig(4_641_652, 1))]
     if name == "chr20":           # S3: chr20-length with telomere / internal N blocks
         return [("chr20_synth", random_contig(64_444_167, 2, [(0, 60_000), (26_400_000, 26_900_000), (64_334_167, 64_444_167)]))]
+    if name == "assembly5k":      # a scaffold-level assembly: 5000 contigs, exponential lengths with a mean of 30 kb (N50 ~ 50 kb), 150 Mb in all
+        u = (_splitmix64(5000, 77) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        lens = np.maximum(1000, (-30000.0 * np.log(1.0 - u)).astype(np.int64))
+        out = []
+        for i, l in enumerate(lens.tolist()):
+            runs = [(l // 3, l // 3 + 200)] if i % 9 == 4 and l > 3000 else []          # a gap of Ns in some scaffolds
+            out.append((f"scaffold{i + 1}", random_contig(int(l), 5000 + i, runs)))
+        return out
     if name in ("grch38", "grch38_mini"):      # S4 (and S5 with the Ion Torrent flags): 24 contigs with the GRCh38 primary-assembly lengths
         scale = 1 if name == "grch38" else 64   # grch38_mini: every length / 64 (48 Mb), same layout -- for CPU-side checks of the multi-contig plumbing
         return [(nm, random_contig(l // scale, 1000 + i, [(a // scale, b // scale) for a, b in grch38_n_runs(nm, l)])) for i, (nm, l) in enumerate(GRCH38_PRIMARY)]

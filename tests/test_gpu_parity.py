@@ -170,6 +170,63 @@ def test_gzip_kernel_on_hard_inputs(lib):
     check_gzip_kernel_on_hard_inputs(lib, scale=8)
 
 
+JOB_CASES = [
+    ("tiny.fa", "-z 9 -N 9000 -P pfx -r 0.01 -R 0.3 -y 0.2", dict(devices=[0, 0, 0], batch_pairs=700, min_share=40)),
+    ("tiny.fa", "-z 9 -N 9000 -y 0.2 -o 1", dict(devices=[0, 0], gzip_on_gpu=False, batch_pairs=1000, min_share=40)),
+    ("tiny.fa", "-z 9 -C 30 -y 0.1", dict(devices=[0, 0, 0], batch_pairs=64, min_share=1, group_bp=5000)),       # contig by contig (groups of one)
+    ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 7000 -m {IN}/muts_edge.txt", dict(devices=[0, 0], batch_pairs=900, min_share=1)),
+    ("odd.fa", "-z 6 -N 7000 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2", dict(devices=[0, 0, 0, 0], batch_pairs=777, min_share=1)),
+    ("tiny.fa", "-z 8 -N 4000 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1", dict(devices=[0, 0, 0], batch_pairs=500, min_share=1)),
+    ("ex1.fa", "-z 13 -N 10000 -1 100 -2 100", dict(devices=None)),                                                    # every device the process sees, defaults
+    ("ex1.fa", "-z 13 -N 8000 -M 2", dict(devices=[0, 0])),
+    ("ex1.fa", "-z 13 -N 8000 -M 1", dict(devices=[0], batch_pairs=3000)),
+]
+
+
+@pytest.mark.parametrize("fasta,flags,kw", JOB_CASES, ids=[f"{f}:{fl}" for f, fl, _ in JOB_CASES])
+def test_job_level_of_the_abi(lib, oracle_bin, golden_dir, fasta, flags, kw):
+    """dwgsim_hip_job_* through ctypes (what a binding at the reference's seam calls): several contexts on the one GPU of the
+    box, batches dealt round-robin, counted random reads as rand_ii bases, gzip members made on the GPU, ordered delivery -- every byte as
+    the oracle's single-process run."""
+    from parity_common import compare_job_api
+    compare_job_api(lib, oracle_bin, os.path.join(golden_dir, fasta), flags, **kw)
+
+
+def test_job_level_two_hundred_small_contigs(lib, oracle_bin, many_fa):
+    from parity_common import compare_job_api
+    compare_job_api(lib, oracle_bin, many_fa, "-z 11 -C 20 -1 50 -2 50 -d 200 -s 15 -r 0.03 -R 0.6 -X 0.6 -n 8 -y 0.1", devices=[0, 0, 0], batch_pairs=4096, min_share=100, group_bp=100000)
+    compare_job_api(lib, oracle_bin, many_fa, "-z 15 -C 15 -1 150 -2 150 -o 1", devices=[0])
+
+
+def test_job_level_abort_rule_across_devices(lib, oracle_bin, golden_dir):
+    from test_emu_parity import test_job_level_abort_rule_across_devices_on_cpu_emulation as body
+    body(lib, oracle_bin, golden_dir)
+
+
+def test_two_ranks_over_gloo_on_the_real_library(oracle_bin, golden_dir, tmp_path):
+    """The N>1 flow of bench.py / dw_job.cpp with two PROCESSES that share the box's one GPU: each rank walks every contig itself, counts the
+    random reads of its batches (k_place), one gloo all-gather per group, batches dealt round-robin; the rank-ordered interleaving of the
+    batches equals the oracle's single-process output.  (tests/test_sharding_gloo.py runs the same flow on the CPU emulation.)"""
+    import pickle, subprocess, sys
+    from parity_common import run_oracle, STREAMS, first_diff
+    from test_sharding_gloo import WORKER_BATCHES
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = "-z 9 -N 20000 -y 0.25 -1 50 -2 50 -d 200 -s 20 -r 0.01 -R 0.3"
+    fasta = os.path.join(golden_dir, "tiny.fa")
+    want = run_oracle(oracle_bin, fasta, flags, str(tmp_path))
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER_BATCHES)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(w), root, flags, fasta, str(tmp_path), os.path.join(root, "dwgsim_amd", "libdwgsim_hip.so"), "1500"], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p_ in procs:
+        assert p_.wait(timeout=600) == 0
+    parts = [pickle.load(open(str(tmp_path / f"rank{r}.pkl"), "rb")) for r in range(2)]
+    merged = sorted(parts[0] + parts[1], key=lambda m: (m[0], m[1]))          # (group, batch, {stream: bytes})
+    for s_ in STREAMS:
+        got = b"".join(m[2][s_] for m in merged)
+        assert got == want[s_], f"{STREAMS[s_]}: " + first_diff(got, want[s_])
+
+
 def test_cli_abort_rule_across_contexts(oracle_bin, golden_dir, tmp_path):
     """The failure counter of dwgsim.c:635 runs over the pairs of a contig in index order; with the contig split over contexts no single
     range reaches 10 000 failures in this job, the joined summaries do: dwgsim-hip must die as the reference does -- and must not when
