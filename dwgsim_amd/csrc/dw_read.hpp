@@ -12,106 +12,97 @@ namespace dw {
 struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n, n_ins; };   // n_ins: INSERT cells crossed (the reference's n_indel_first, dwgsim.c:98)
 
 // dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
-// The haplotype is read through its 4-bit view (HapDev::view) in 16-byte chunks = 32 cells, the next chunk prefetched; up to 16 cells in
-// travel order are handled at once with nibble-parallel arithmetic as long as none of them is an escape (an INSERT / DELETE cell or a '-':
-// nibble >= 9); an escape cell goes through the reference's per-cell logic on the byte cells.
+// The haplotype is read through its 4-bit view (HapDev::view).  The read is produced one staged WORD (8 bases) at a time: the next 8 cells in
+// travel order are one unaligned 8-byte load and a funnel shift; when none of them is an escape (an INSERT / DELETE cell or a '-': nibble >= 9)
+// the word is finished with nibble-parallel arithmetic (substitution / N counts, nibble reversal and complement for the reverse strand).  A
+// word that holds an escape, or that reaches over a contig end, is produced by an EPISODE of the reference's per-cell logic on the byte cells
+// instead, which runs on until the output stands at a word boundary again (insertions can carry it over several words); then the word loop
+// resumes from the cell the episode stopped at.  Indel cells are rare (one word in a thousand at dwgsim's default rates), so a wave runs an
+// episode about once per read and the word loop -- ~30 instructions per 8 bases -- is what the extraction costs.
 DW_DEV uint64_t reverse_nibbles(uint64_t x)
 {
     x = __builtin_bswap64(x);
     return ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
 }
+DW_DEV uint32_t reverse_nibbles32(uint32_t x)
+{
+    x = __builtin_bswap32(x);
+    return ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+}
+struct __attribute__((packed, aligned(4))) ViewPair { uint32_t lo, hi; };      // two consecutive words of the view at a 4-byte aligned address: one dwordx2 load
 template <bool STORE>
 DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
 {
     ReadRes r{-10, 0, 0, 0, 0};
-    int k = 0, kw = 0; uint64_t acc = 0; uint32_t nacc = 0;       // nacc (< 8) nibbles pending in acc
-    auto push8 = [&](uint32_t nibs, uint32_t cnt) {                // append cnt (<= 8) packed nibbles
-        if (STORE) {
-            acc |= (uint64_t)nibs << (4 * nacc); nacc += cnt;
-            if (nacc >= 8) { lds[kw * stride] = (uint32_t)acc; acc >>= 32; nacc -= 8; ++kw; }
-        }
+    const bool fwd = step > 0;
+    const int32_t li = (int32_t)l;                     // (contigs are shorter than 2^31)
+    int k = 0;                                         // bases produced; a multiple of 8 whenever the word loop looks at it
+    int32_t i = (start < -0x7fffffffll || start > 0x7fffffffll) ? -1 : (int32_t)start;      // next cell in travel order
+    uint32_t accw = 0; int na = 0;                     // (episodes) the word being filled
+    auto emit = [&](uint32_t v) {                      // one base from the per-cell logic
+        if (strand) v = v < 4 ? 3 - v : 4;             // dwgsim.c:150-152
+        r.num_n += (v == 4);                            // dwgsim.c:824-831
+        accw |= v << (4 * na); ++k;
+        if (++na == 8) { if (STORE) lds[((k >> 3) - 1) * stride] = accw; accw = 0; na = 0; }
     };
-    auto emit = [&](uint32_t v) {
-        if (strand) v = v < 4 ? 3 - v : 4;                 // dwgsim.c:150-152
-        r.num_n += (v == 4);                                // dwgsim.c:824-831
-        push8(v, 1); ++k;
-    };
-    const int64_t last_chunk = (l - 1) >> 5;
-    const int dirc = step > 0 ? 1 : -1;
-    int64_t cb = -1, pb = -1; uint64_t clo = 0, chi = 0, plo = 0, phi = 0;
-    if (start >= 0 && start < l) {
-        cb = start >> 5;
-        const uint4 v = *reinterpret_cast<const uint4 *>(h.view + (cb << 4));
-        clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-        pb = cb + dirc;
-        if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.view + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
-#if !defined(DW_EMU) && !defined(DW_NO_TOUCH)
-        // touch the following 128-byte lines (256 cells each) of the read's window now (results unused): their HBM latency overlaps with
-        // the first chunks instead of being met one line at a time by the chunk loop
-        for (int t = 1; t <= 3 && t * 256 < s; ++t) {                    // only addresses the read is sure to reach: no over-fetch
-            const int64_t pa = start + (int64_t)dirc * 256 * t;
-            if (pa >= 0 && pa < l) (void)*reinterpret_cast<const volatile uint32_t *>(h.view + ((pa >> 1) & ~(int64_t)3));
+    while (k < s) {
+        // ---- the word: the next `want` cells in travel order are the ascending cells [a, a + want)
+        const int want = s - k < 8 ? s - k : 8;
+        const int32_t a = fwd ? i : i - (want - 1);
+        bool fast = a >= 0 && a <= li - want && i >= 0 && i < li;
+        uint32_t x = 0;
+        if (fast) {
+            const ViewPair d = *reinterpret_cast<const ViewPair *>(h.view + (size_t)((uint32_t)a >> 3) * 4);
+            x = __builtin_amdgcn_alignbit(d.hi, d.lo, 4u * ((uint32_t)a & 7u));
+            if (want < 8) x &= (1u << (4 * want)) - 1u;
+            const uint32_t n8 = x & 0x88888888u;                                            // nibble >= 8
+            fast = (n8 & ((x & 0x77777777u) + 0x77777777u)) == 0;                           // ... and not >= 9: no escape among them
         }
-#endif
-    }
-    int64_t i = start;
-    while (i >= 0 && i < l && k < s) {
-        if ((i >> 5) != cb) {
-            cb = i >> 5;
-            if (cb == pb) { clo = plo; chi = phi; }
-            else { const uint4 v = *reinterpret_cast<const uint4 *>(h.view + (cb << 4)); clo = (uint64_t)v.x | ((uint64_t)v.y << 32); chi = (uint64_t)v.z | ((uint64_t)v.w << 32); }
-            pb = cb + dirc;
-            if (pb >= 0 && pb <= last_chunk) { const uint4 w = *reinterpret_cast<const uint4 *>(h.view + (pb << 4)); plo = (uint64_t)w.x | ((uint64_t)w.y << 32); phi = (uint64_t)w.z | ((uint64_t)w.w << 32); }
-        }
-        const uint64_t half = (i & 16) ? chi : clo;
-        const uint32_t off = (uint32_t)(i & 15);
-        // cells of this 16-cell half in travel order, limited by the half, the read and the contig end
-        uint32_t want = step > 0 ? 16 - off : off + 1;
-        const uint32_t left = (uint32_t)(s - k);
-        if (want > left) want = left;
-        if (step > 0) { const int64_t room = l - i; if ((int64_t)want > room) want = (uint32_t)room; }
-        uint64_t x = step > 0 ? half >> (4 * off) : reverse_nibbles(half << (4 * (15 - off)));
-        const uint64_t live = want < 16 ? (1ull << (4 * want)) - 1 : ~0ull;
-        x &= live;
-        const uint64_t isn = (x >> 3) & 0x1111111111111111ull;                                 // nibble >= 8
-        if ((isn & (x | (x >> 1) | (x >> 2))) == 0) {         // no escape (nibble >= 9) among them: one base per cell
-            if (r.ext_coor < 0) { r.ext_coor = (int32_t)i; if (strand) r.ext_coor -= s - 1; }
-            r.n_sub += __popcll(x & 0x4444444444444444ull);                                    // nibbles 4-7: substituted cells
-            r.num_n += __popcll(isn);                                                          // nibble 8: an N
-            uint64_t codes = x & 0x3333333333333333ull;
-            if (strand) codes = (codes ^ 0x3333333333333333ull) & ~(isn * 3) & live;           // complement, dwgsim.c:150-152 (N stays N)
-            codes |= isn << 2;                                                                  // N = code 4
-            push8((uint32_t)codes, want < 8 ? want : 8);
-            if (want > 8) push8((uint32_t)(codes >> 32), want - 8);
-            k += (int)want;
-            i += (int64_t)step * want;
+        if (fast) {
+            if (r.ext_coor < 0) { r.ext_coor = i; if (strand) r.ext_coor -= s - 1; }
+            uint32_t n8 = x & 0x88888888u;
+            r.n_sub += __popc(x & 0x44444444u);                                             // nibbles 4-7: substituted cells
+            r.num_n += __popc(n8);                                                          // nibble 8: an N
+            uint32_t codes = x & 0x33333333u;
+            if (!fwd) { const uint32_t sh = 4u * (uint32_t)(8 - want); codes = reverse_nibbles32(codes) >> sh; n8 = reverse_nibbles32(n8) >> sh; }   // travel order
+            if (strand) codes = (codes ^ 0x33333333u) & ~((n8 >> 3) * 3u);                  // complement, dwgsim.c:150-152 (N stays N)
+            if (want < 8) codes &= (1u << (4 * want)) - 1u;
+            codes |= n8 >> 1;                                                                // N = code 4
+            if (STORE) lds[(k >> 3) * stride] = codes;
+            k += want; i += fwd ? want : -want;
             continue;
         }
-        const uint32_t c = h.cells[i], mt = c & TMASK;          // an escape in the stretch: this cell by the reference's per-cell logic
-        if (r.ext_coor < 0) {
-            if (mt != T_NONE && mt != T_SUB) { i += step; continue; }
-            r.ext_coor = (int32_t)i;
-            if (strand) r.ext_coor -= s - 1;
-        }
-        if (mt == T_DEL) { ++r.n_indel; if (strand) r.ext_coor--; }
-        else if (mt == T_NONE || mt == T_SUB) { emit(c & 0xf); if (mt == T_SUB) ++r.n_sub; }
-        else {
-            ++r.n_indel; ++r.n_ins;
-            const uint32_t idx = ins_find(h, i);
-            uint32_t n = h.ins_len[idx];
-            const uint8_t *P = h.ins_bases + h.ins_off[idx];
-            if (!strand) {
-                if (k < s) emit(c & 0xf);
-                for (uint32_t t = 0; t < n && k < s; ++t) emit(P[t] & 3u);
-            } else {
-                while (n > 0 && k < s) { r.ext_coor++; emit(P[n - 1] & 3u); --n; }
-                if (k < s) emit(c & 0xf);
+        // ---- an episode of the reference's per-cell logic, until the output stands at a word boundary again
+        for (;;) {
+            if (i < 0 || i >= li) { k = -1; break; }                 // walked off the contig before the read was complete
+            const uint32_t c = h.cells[i], mt = c & TMASK;
+            if (r.ext_coor < 0) {
+                if (mt != T_NONE && mt != T_SUB) { i += step; continue; }
+                r.ext_coor = i;
+                if (strand) r.ext_coor -= s - 1;
             }
+            if (mt == T_DEL) { ++r.n_indel; if (strand) r.ext_coor--; }
+            else if (mt == T_NONE || mt == T_SUB) { emit(c & 0xf); if (mt == T_SUB) ++r.n_sub; }
+            else {
+                ++r.n_indel; ++r.n_ins;
+                const uint32_t idx = ins_find(h, i);
+                uint32_t n = h.ins_len[idx];
+                const uint8_t *P = h.ins_bases + h.ins_off[idx];
+                if (!strand) {
+                    if (k < s) emit(c & 0xf);
+                    for (uint32_t t = 0; t < n && k < s; ++t) emit(P[t] & 3u);
+                } else {
+                    while (n > 0 && k < s) { r.ext_coor++; emit(P[n - 1] & 3u); --n; }
+                    if (k < s) emit(c & 0xf);
+                }
+            }
+            i += step;
+            if (k >= s || na == 0) break;
         }
-        i += step;
+        if (k < 0) break;
     }
-    if (STORE && nacc) lds[kw * stride] = (uint32_t)acc;
-    if (k != s) r.ext_coor = -10;
+    if (k != s) { r.ext_coor = -10; return r; }
+    if (STORE && na) lds[(k >> 3) * stride] = accw;      // the ragged last word of an episode
     return r;
 }
 
