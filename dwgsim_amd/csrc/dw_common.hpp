@@ -36,8 +36,9 @@ enum : uint32_t {
     // NARROW domains: a draw is one 32-bit word w of a block, u = w * 2^-32, four draws per Philox block
     D_BASE0 = 8,        // +read end.  16-bit draws, eight per block: halfword i (block i>>3, word (i&7)>>1, low half first) = the HIGH half of the 32-bit
                         // uniform of base i: error test (dwgsim.c:237) or random-read base (:1000); the low half is halfword i of D_BASE_REF0
-    D_QUAL0 = 10,       // +read end.  the sequential stream of polar tries of the read's quality normals (dwgsim.c:912, :156-175): try t = words
-                        // 2 (t&1), 2 (t&1) + 1 of block t>>1; every accepted try delivers two normals (v2*fac, then the cached v1*fac)
+    D_QUAL0 = 10,       // +read end.  the sequential stream of polar tries of the read's quality normals (dwgsim.c:912, :156-175), 16-BIT uniforms: try t =
+                        // the two halves of word t & 3 of block t >> 2 (low half v1, high half v2); every accepted try delivers two normals (v2*fac,
+                        // then the cached v1*fac)
     D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): 16-bit draws, eight per block -- halfword h is the HIGH half of the FIRST
                         // uniform of event h: the homopolymer start at position h of the evolving read (pass 1), the h-th empty flow of the read
                         // (pass 2, + D_FLOW_PASS2); low halves: + D_FLOW_REF (lazy); every further draw of an event: its private stream + D_FLOW_EV

@@ -160,7 +160,7 @@ void lazy_quality_params(double sigma, float *k, float *eps, float *lmin, int32_
     if (lm < 0x1p-10) lm = 0x1p-10;
     *lmin = (float)lm;
     lm = (double)*lmin * (1.0 - 0x1p-20);         // (what the budget may assume after the rounding to float)
-    *k = (float)(sqrt(two_ln2) * 0x1p-31 * sigma);
+    *k = (float)(sqrt(two_ln2) * sigma);
     *eps = (float)(1.5 * sigma * (3.4e-7 / sqrt(lm) + 7.2e-6) + 0x1p-18);       // (+inf for an absurd -Q: every value then takes the exact path)
 }
 
@@ -427,9 +427,9 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 qb[(size_t)i] = (int8_t)q;
             }
             HIPC(c, hipMalloc((void **)&c->d_thr[j], sizeof(uint64_t) * (size_t)n));
-            {   // packed table: n entries, then the last one repeated (>= 4 copies), the same word count for both read ends
+            {   // packed table: n entries, then the last one repeated (>= 8 copies), the same word count for both read ends
                 const int lmax = c->prm.length[0] > c->prm.length[1] ? c->prm.length[0] : c->prm.length[1];
-                c->qb_words = (lmax + 4 + 3) / 4 + 1;
+                c->qb_words = (lmax + 4 + 3) / 4 + 2;      // (a block of the quality stream looks at eight positions: three words from any position <= lmax)
                 std::vector<int8_t> padded((size_t)c->qb_words * 4, qb[(size_t)n - 1]);
                 memcpy(padded.data(), qb.data(), (size_t)n);
                 HIPC(c, hipMalloc((void **)&c->d_qbase[j], padded.size()));
@@ -474,9 +474,10 @@ extern "C" int dwgsim_hip_selftest_fp64(int device, uint32_t seed, uint64_t n, u
 }
 
 // Not part of the drop-in ABI either: self-test of the lazy quality normals (dw_simulate.hip k_selftest_lazy).  out[0..4] = counters of the
-// comparison with the exact form on n random blocks at quality_std = sigma, out[5] = max |estimate - exact| / eps, out[6..8] = worst error of
-// v_log_f32 / v_rcp_f32 / v_sqrt_f32 over EVERY float of their operand ranges, in units of the bounds the error budget assumes (doubles).
-extern "C" int dwgsim_hip_selftest_lazy(int device, uint32_t seed, uint64_t n, double sigma, int exhaustive, uint64_t *out)
+// comparison with the exact form on the n tries w = first, first + 1, ... (n = 2^32: EVERY try) at quality_std = sigma, out[5] = max
+// |estimate - exact| / eps, out[6..8] = worst error of v_log_f32 / v_rcp_f32 / v_sqrt_f32 over EVERY float of their operand ranges, in units of
+// the bounds the error budget assumes (doubles).
+extern "C" int dwgsim_hip_selftest_lazy(int device, uint32_t first, uint64_t n, double sigma, int exhaustive, uint64_t *out)
 {
     if (!out || hipSetDevice(device) != hipSuccess) return DWGSIM_HIP_ERR_DEVICE;
     uint64_t *d = nullptr;
@@ -484,11 +485,11 @@ extern "C" int dwgsim_hip_selftest_lazy(int device, uint32_t seed, uint64_t n, d
     hipMemset(d, 0, 12 * sizeof(uint64_t));
     float qk, qeps, qlmin; int32_t qnear1;
     lazy_quality_params(sigma, &qk, &qeps, &qlmin, &qnear1);
-    launch_selftest_lazy(nullptr, 0, seed, n, sigma, qk, qeps, qlmin, qnear1, d);
+    launch_selftest_lazy(nullptr, 0, first, n, sigma, qk, qeps, qlmin, qnear1, d);
     if (exhaustive) {
-        launch_selftest_lazy(nullptr, 1, 0, 0x3F800000u - 0x20800000u, 0, 0, 0, 0, 0, d);
-        launch_selftest_lazy(nullptr, 2, 0, 0x3F800000u - 0x20800000u, 0, 0, 0, 0, 0, d);
-        launch_selftest_lazy(nullptr, 3, 0, 0x62800000u - 0x3A000000u, 0, 0, 0, 0, 0, d);
+        launch_selftest_lazy(nullptr, 1, 0, 0x3F800000u - 0x30800000u, 0, 0, 0, 0, 0, d);           // [2^-30, 1)
+        launch_selftest_lazy(nullptr, 2, 0, 0x4E800000u - 0x3F800000u + 1u, 0, 0, 0, 0, 0, d);      // [1, 2^30]
+        launch_selftest_lazy(nullptr, 3, 0, 0x42000000u - 0x2B000000u, 0, 0, 0, 0, 0, d);           // [2^-41, 2^5)
     }
     const hipError_t e = hipMemcpy(out, d, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost);
     hipFree(d);

@@ -84,7 +84,7 @@ struct SimParams {
     int32_t dist, is_inner, len[2], max_n, strandedness, read_one_strand, amplicons, fixed_quality, data_type;
     int32_t has_bwa, has_bfast;
     uint32_t seed;
-    // lazy quality normals (dw_simulate.hip quality_try_lazy, host: lazy_quality_params): k = sqrt(2 ln 2) * 2^-31 * quality_std as a float,
+    // lazy quality normals (dw_simulate.hip quality_try_lazy, host: lazy_quality_params): k = sqrt(2 ln 2) * quality_std as a float,
     // eps = the proven error bound of the fp32 estimate, lmin / near1 = the treatment of polar radii next to 1
     float q_k, q_eps, q_lmin; int32_t q_near1;
 };

@@ -12,13 +12,15 @@ namespace dw {
 struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n, n_ins; };   // n_ins: INSERT cells crossed (the reference's n_indel_first, dwgsim.c:98)
 
 // dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
-// The haplotype is read through its 4-bit view (HapDev::view).  The read is produced one staged WORD (8 bases) at a time: the next 8 cells in
-// travel order are one unaligned 8-byte load and a funnel shift; when none of them is an escape (an INSERT / DELETE cell or a '-': nibble >= 9)
-// the word is finished with nibble-parallel arithmetic (substitution / N counts, nibble reversal and complement for the reverse strand).  A
-// word that holds an escape, or that reaches over a contig end, is produced by an EPISODE of the reference's per-cell logic on the byte cells
-// instead, which runs on until the output stands at a word boundary again (insertions can carry it over several words); then the word loop
-// resumes from the cell the episode stopped at.  Indel cells are rare (one word in a thousand at dwgsim's default rates), so a wave runs an
-// episode about once per read and the word loop -- ~30 instructions per 8 bases -- is what the extraction costs.
+// The haplotype is read through its 4-bit view (HapDev::view).  A read's window of the view sits at a random place of a contig that no cache
+// of the chip holds for the ~10^5 lanes in flight: what the extraction costs is the memory round trips it takes one after the other, not
+// its arithmetic.  So the window of the next 23 staged words (184 cells) is fetched by up to six 16-byte loads issued TOGETHER -- one round
+// trip -- into 24 registers, in travel order (a reverse-strand lane loads downwards and turns each block around), and the words are then cut
+// out of neighbouring registers with a funnel shift at compile-time register indices: nibble-parallel substitution / N counts, nibble
+// reversal and complement for the reverse strand.  A word that holds an escape (an INSERT / DELETE cell or a '-': nibble >= 9), and any word
+// too close to a contig end for the window to be loaded, goes through an EPISODE of the reference's per-cell logic on the byte cells, which
+// runs on until the output stands at a word boundary again (insertions can carry it over several words); then a new window is loaded from
+// the cell the episode stopped at.  Indel cells are rare (one word in a thousand at dwgsim's default rates).
 DW_DEV uint64_t reverse_nibbles(uint64_t x)
 {
     x = __builtin_bswap64(x);
@@ -29,14 +31,15 @@ DW_DEV uint32_t reverse_nibbles32(uint32_t x)
     x = __builtin_bswap32(x);
     return ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
 }
-struct __attribute__((packed, aligned(4))) ViewPair { uint32_t lo, hi; };      // two consecutive words of the view at a 4-byte aligned address: one dwordx2 load
+struct __attribute__((packed, aligned(4))) ViewQuad { uint32_t a, b, c, d; };      // four consecutive words of the view at a 4-byte aligned address: one dwordx4 load
+constexpr int WIN_CHUNKS = 6, WIN_WORDS = 4 * WIN_CHUNKS - 1;                    // 16-byte blocks per window; staged words it serves
 template <bool STORE>
 DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
 {
     ReadRes r{-10, 0, 0, 0, 0};
     const bool fwd = step > 0;
     const int32_t li = (int32_t)l;                     // (contigs are shorter than 2^31)
-    int k = 0;                                         // bases produced; a multiple of 8 whenever the word loop looks at it
+    int k = 0;                                         // bases produced; a multiple of 8 whenever a window or an episode starts
     int32_t i = (start < -0x7fffffffll || start > 0x7fffffffll) ? -1 : (int32_t)start;      // next cell in travel order
     uint32_t accw = 0; int na = 0;                     // (episodes) the word being filled
     auto emit = [&](uint32_t v) {                      // one base from the per-cell logic
@@ -45,33 +48,53 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         accw |= v << (4 * na); ++k;
         if (++na == 8) { if (STORE) lds[((k >> 3) - 1) * stride] = accw; accw = 0; na = 0; }
     };
+    const uint32_t *const vw = reinterpret_cast<const uint32_t *>(h.view);
     while (k < s) {
-        // ---- the word: the next `want` cells in travel order are the ascending cells [a, a + want)
-        const int want = s - k < 8 ? s - k : 8;
-        const int32_t a = fwd ? i : i - (want - 1);
-        bool fast = a >= 0 && a <= li - want && i >= 0 && i < li;
-        uint32_t x = 0;
-        if (fast) {
-            const ViewPair d = *reinterpret_cast<const ViewPair *>(h.view + (size_t)((uint32_t)a >> 3) * 4);
-            x = __builtin_amdgcn_alignbit(d.hi, d.lo, 4u * ((uint32_t)a & 7u));
-            if (want < 8) x &= (1u << (4 * want)) - 1u;
-            const uint32_t n8 = x & 0x88888888u;                                            // nibble >= 8
-            fast = (n8 & ((x & 0x77777777u) + 0x77777777u)) == 0;                           // ... and not >= 9: no escape among them
+        // ---- a window: the next nw words = the next `cells` cells in travel order, all inside the contig
+        const int words_left = (s - k + 7) >> 3, nw = words_left < WIN_WORDS ? words_left : WIN_WORDS;
+        const int cells = (s - k) < 8 * nw ? (s - k) : 8 * nw;
+        const int nch = (nw + 4) >> 2;                                   // 16-byte blocks that hold the nw + 1 words a window of nw staged words is cut from
+        // forward: words b0, b0 + 1, ... of the view; reverse: words eb, eb - 1, ... (eb holds cell i)
+        const int32_t b0 = i >> 3, eb = i >> 3;
+        const bool win = i >= 0 && i < li && (fwd ? i <= li - cells : (i - cells + 1 >= 0 && eb - 4 * nch + 1 >= 0));
+        bool esc = !win;
+        if (win) {
+            uint32_t X[4 * WIN_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < WIN_CHUNKS; ++c) {
+                ViewQuad q{0, 0, 0, 0};
+                if (c < nch) q = *reinterpret_cast<const ViewQuad *>(vw + (fwd ? b0 + 4 * c : eb - 4 * c - 3));
+                X[4 * c] = fwd ? q.a : q.d; X[4 * c + 1] = fwd ? q.b : q.c; X[4 * c + 2] = fwd ? q.c : q.b; X[4 * c + 3] = fwd ? q.d : q.a;      // travel order
+            }
+            // forward: word w = cells from nibble (i & 7) of X[w], continued in X[w + 1].  Reverse: the eight cells ending at cell i - 8 w start at
+            // nibble ((i + 1) & 7) of view word eb - w - d (d = 1 unless cell i is the last nibble of its word): X[w + d], continued in X[w + d - 1]
+            const bool d1 = !fwd && ((uint32_t)i & 7u) != 7u;
+            const uint32_t sh = 4u * ((fwd ? (uint32_t)i : (uint32_t)i + 1u) & 7u);
+            bool go = true;
+#pragma unroll
+            for (int w = 0; w < WIN_WORDS; ++w) {
+                if (!(go && w < nw)) continue;                                             // (no early exit: the loop unrolls into straight-line code on fixed registers)
+                const int want = s - k < 8 ? s - k : 8;
+                const uint32_t lo = d1 ? X[w + 1] : X[w], hi = d1 ? X[w] : X[w + 1];
+                uint32_t x = __builtin_amdgcn_alignbit(hi, lo, sh);
+                if (!fwd) x = reverse_nibbles32(x);                                        // travel order: base 0 of the word in nibble 0
+                if (want < 8) x &= (1u << (4 * want)) - 1u;
+                const uint32_t n8 = x & 0x88888888u;                                        // nibble >= 8
+                if (n8 & ((x & 0x77777777u) + 0x77777777u)) { esc = true; go = false; }     // ... and >= 9: an escape among them
+                else {
+                    if (r.ext_coor < 0) { r.ext_coor = i; if (strand) r.ext_coor -= s - 1; }
+                    r.n_sub += __popc(x & 0x44444444u);                                     // nibbles 4-7: substituted cells
+                    r.num_n += __popc(n8);                                                  // nibble 8: an N
+                    uint32_t codes = x & 0x33333333u;
+                    if (strand) codes = (codes ^ 0x33333333u) & ~((n8 >> 3) * 3u);          // complement, dwgsim.c:150-152 (N stays N)
+                    if (want < 8) codes &= (1u << (4 * want)) - 1u;
+                    codes |= n8 >> 1;                                                        // N = code 4
+                    if (STORE) lds[(k >> 3) * stride] = codes;
+                    k += want; i += fwd ? want : -want;
+                }
+            }
         }
-        if (fast) {
-            if (r.ext_coor < 0) { r.ext_coor = i; if (strand) r.ext_coor -= s - 1; }
-            uint32_t n8 = x & 0x88888888u;
-            r.n_sub += __popc(x & 0x44444444u);                                             // nibbles 4-7: substituted cells
-            r.num_n += __popc(n8);                                                          // nibble 8: an N
-            uint32_t codes = x & 0x33333333u;
-            if (!fwd) { const uint32_t sh = 4u * (uint32_t)(8 - want); codes = reverse_nibbles32(codes) >> sh; n8 = reverse_nibbles32(n8) >> sh; }   // travel order
-            if (strand) codes = (codes ^ 0x33333333u) & ~((n8 >> 3) * 3u);                  // complement, dwgsim.c:150-152 (N stays N)
-            if (want < 8) codes &= (1u << (4 * want)) - 1u;
-            codes |= n8 >> 1;                                                                // N = code 4
-            if (STORE) lds[(k >> 3) * stride] = codes;
-            k += want; i += fwd ? want : -want;
-            continue;
-        }
+        if (!esc) continue;
         // ---- an episode of the reference's per-cell logic, until the output stands at a word boundary again
         for (;;) {
             if (i < 0 || i >= li) { k = -1; break; }                 // walked off the contig before the read was complete

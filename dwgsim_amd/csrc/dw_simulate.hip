@@ -173,116 +173,121 @@ DW_DEV uint32_t pair_tail_len(int32_t x0, int32_t x1, const NameCounts &n, uint6
          + ndigits10((uint32_t)n.e1) + 1 + ndigits10((uint32_t)n.u1) + 1 + ndigits10((uint32_t)n.i1) + 1 + ndigits16(ii);
 }
 // ---- quality normals (dwgsim.c:156-175 ran_normal, :912): the integer offsets (int)(nrm * sigma + 0.5) that one Philox block delivers.
-// The polar tries of a read's quality string form one sequential stream: try t = words 2 (t & 1), 2 (t & 1) + 1 of block t >> 1 (narrow
-// uniforms); an accepted try delivers two normals, v2 * fac first and the cached v1 * fac second (dwgsim.c:170-174).  A block = tries a, b.
-// EXACT form: fp64 arithmetic in the reference's evaluation order.  acc bit 0 / 1: try a / b accepted; k[0], k[1] = offsets of try a,
-// k[2], k[3] of try b. ----
-DW_DEV void quality_try_exact(uint32_t w1, uint32_t w2, double sigma, bool &ok, int32_t &k0, int32_t &k1)
+// The polar tries of a read's quality string form one sequential stream of 16-BIT uniforms: try t = the two halves of word t & 3 of block
+// t >> 2 (low half v1, high half v2; u = h * 2^-16, v = 2u - 1 = (h - 32768) * 2^-15) -- four tries per Philox block.  An accepted try delivers
+// two normals, v2 * fac first and the cached v1 * fac second (dwgsim.c:170-174).  The only consumer of a normal is the truncation
+// (int)(nrm * sigma + 0.5), which 2^32 distinct tries resolve far beyond what a quality character can show.
+// EXACT form: fp64 arithmetic in the reference's evaluation order. ----
+DW_DEV void quality_try_exact(uint32_t w, double sigma, bool &ok, int32_t &k0, int32_t &k1)
 {
-    const double v1 = (double)w1 * 0x1p-31 - 1.0, v2 = (double)w2 * 0x1p-31 - 1.0;          // v = 2 * (w * 2^-32) - 1 = w * 2^-31 - 1, exact
+    const double v1 = (double)((int32_t)(w & 0xFFFFu) - 32768) * 0x1p-15, v2 = (double)((int32_t)(w >> 16) - 32768) * 0x1p-15;      // exact
     const double rsq = v1 * v1 + v2 * v2;
     ok = !(rsq >= 1.0 || rsq == 0.0);
     if (!ok) return;
-    // rsq is a multiple of 2^-62 in (0, 1): -2 log(rsq) in [2^-52, 86], the quotient in [2^-52, 2^69] -- the range-restricted forms apply
+    // rsq is a multiple of 2^-30 in (0, 1): -2 log(rsq) in [2^-30, 42], the quotient in [2^-30, 2^36] -- the range-restricted forms apply
     const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
     k0 = (int32_t)(((v2 * fac) * sigma) + 0.5);
     k1 = (int32_t)(((v1 * fac) * sigma) + 0.5);
 }
-DW_DEV uint32_t quality_block_exact(const U4 &blk, double sigma, int32_t (&k)[4])
-{
-    bool oka, okb;
-    quality_try_exact(blk.x, blk.y, sigma, oka, k[0], k[1]);
-    quality_try_exact(blk.z, blk.w, sigma, okb, k[2], k[3]);
-    return (oka ? 1u : 0u) | (okb ? 2u : 0u);
-}
-// LAZY form -- same results, a fraction of the work.  The only consumer of a quality normal is the truncation (int)(nrm * sigma + 0.5), so
-// an estimate y of x = nrm * sigma + 0.5 with a PROVEN bound |y - x| < eps decides the integer whenever y is further than eps from every
-// integer; only the rest (about 2 * eps of all values) takes the exact path.  The estimate is fp32: correctly rounded IEEE operations plus
-// v_log_f32 / v_rcp_f32 / v_sqrt_f32, whose errors on the operand ranges used here are established exhaustively on the device
-// (k_selftest_lazy: every float of the range).  Error budget (DESIGN.md "Lazy quality normals"): with s = w ^ 2^31 as int32 (v = s * 2^-31),
-//   R = fl(s1)^2 + fl(s2)^2 in fp32 has relative error <= 2^-22  =>  accept / reject is certain unless R lies within 2^-20 of 2^62;
-//   L' = -log2(R * 2^-62) has absolute error a <= 1.44 * 2^-22 (from R) + 2^-23 (1 + L') (v_log_f32, measured on every float), <= 1.22 * 2^-21 for L' <= 1;
-//   for L' >= Lmin that moves sqrt(L') by at most a / (2 sqrt Lmin), i.e. nrm = v sqrt(2 ln 2 L' / r) by <= 3.4e-7 / sqrt(Lmin) (|v| <= sqrt r);
+// LAZY form -- same results, a fraction of the work.  An estimate y of x = nrm * sigma + 0.5 with a PROVEN bound |y - x| < eps decides the
+// integer whenever y is further than eps from every integer; only the rest (about 2 * eps of all values) takes the exact path.  The estimate is
+// fp32: correctly rounded IEEE operations plus v_log_f32 / v_rcp_f32 / v_sqrt_f32, whose errors on the operand ranges used here are
+// established exhaustively on the device (k_selftest_lazy: every float of the range) -- and since a try is one 32-bit word, k_selftest_lazy
+// also compares the decision of EVERY possible try with the exact form (2^32 words per quality_std tested).  Error budget (DESIGN.md "Lazy
+// quality normals"); with s = h - 32768 (v = s * 2^-15):
+//   R = s1^2 + s2^2 is an exact integer <= 2^31: accept / reject (0 < R < 2^30) is exact;
+//   Rf = fl(R) has relative error <= 2^-24; rt = Rf * 2^-30 (exact scaling, in [2^-30, 1));
+//   L' = -log2(rt) has absolute error a <= 1.44 * 2^-24 (from Rf) + 2^-23 (1 + L') (v_log_f32, measured on every float), <= 1.1 * 2^-22 for L' <= 1;
+//   for L' >= Lmin that moves sqrt(L') by at most a / (2 sqrt Lmin), i.e. nrm = s sqrt(2 ln 2 L' / R) by <= 3.4e-7 / sqrt(Lmin) (|s| <= sqrt R);
 //   everything else is relative: v_rcp_f32 and v_sqrt_f32 (each measured < 2^-23), three multiplies, the conversions, the constant, the
-//   relative error of L' above 1: < 2^-20.3 in all, times |nrm| <= 9.3: 7.2e-6.  So |y - x| <= sigma (3.4e-7 / sqrt(Lmin) + 7.2e-6) + the rounding of
-//   the last fma; eps = 1.5 x that + 2^-18 (host: lazy_quality_params), and k_selftest_lazy measures the largest |y - x| / eps on the device;
+//   relative error of L' above 1: < 2^-20.3 in all, times |nrm| <= 6.5: 5.0e-6.  So |y - x| <= sigma (3.4e-7 / sqrt(Lmin) + 5.0e-6) + the rounding
+//   of the last fma; eps = 1.5 x (sigma (3.4e-7 / sqrt(Lmin) + 7.2e-6)) + 2^-18 (host: lazy_quality_params -- the budget of the 32-bit layout, kept:
+//   it is the larger one), and k_selftest_lazy measures the largest |y - x| / eps on the device;
 //   L' < Lmin means |nrm| < sqrt(2 ln 2 Lmin): Lmin is chosen by the host so that |nrm * sigma| < 0.45 there -- the offset is 0 without
 //   further work (near1_zero) -- or, for a large sigma, Lmin = 2^-10 and the exact path runs.
-struct QualLazy { float k, eps, lmin; int32_t near1_zero; };
-DW_DEV int quality_try_lazy(float x1, float x2, float R, const QualLazy &ql, int32_t &k0, int32_t &k1)      // 0: rejected, 1: accepted + decided, 2: take the exact path
+struct QualLazy { float k, eps, lmin; int32_t near1_zero; };      // k = sqrt(2 ln 2) * quality_std
+// Branch-free.  Returns bit 0: the try is accepted, bit 1: its offsets must come from the exact form (k0 / k1 hold the estimate's otherwise).
+DW_DEV uint32_t quality_try_lazy(uint32_t w, const QualLazy &ql, int32_t &k0, int32_t &k1)
 {
-    const float LO = 0x1p62f * (1.0f - 0x1p-20f), HI = 0x1p62f * (1.0f + 0x1p-20f);
-    if (R >= HI || R == 0.0f) return 0;                                               // R == 0 only for s1 = s2 = 0, which converts exactly
-    if (!(R < LO)) return 2;                                                          // the band around 1
-    const float rt = R * 0x1p-62f;                                                    // exact scaling, in [2^-62, 1)
+    const uint32_t wx = w ^ 0x80008000u;                                              // h - 32768 as a signed 16-bit value
+    const int32_t s1 = (int32_t)(int16_t)(wx & 0xFFFFu), s2 = (int32_t)wx >> 16;
+    const uint32_t R = (uint32_t)(s1 * s1) + (uint32_t)(s2 * s2);                     // exact, <= 2^31
+    const bool acc = R - 1u < 0x3FFFFFFFu;                                            // 0 < R < 2^30  <=>  0 < rsq < 1
+    const float Rf = (float)R, rt = Rf * 0x1p-30f;
     const float Lp = -__builtin_amdgcn_logf(rt);                                      // v_log_f32 (log2)
-    if (Lp < ql.lmin) { if (!ql.near1_zero) return 2; k0 = k1 = 0; return 1; }
-    const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
-    const float y0 = __builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = __builtin_fmaf(x1 * f, ql.k, 0.5f);
+    const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(Rf));
+    const float y0 = __builtin_fmaf((float)s2 * f, ql.k, 0.5f), y1 = __builtin_fmaf((float)s1 * f, ql.k, 0.5f);
     const float d0 = __builtin_fabsf(y0 - __builtin_rintf(y0)), d1 = __builtin_fabsf(y1 - __builtin_rintf(y1));
-    if (!(d0 >= ql.eps && d1 >= ql.eps)) return 2;                                    // (also catches an infinite eps: sigma out of the fp32 path's range)
-    k0 = (int32_t)y0; k1 = (int32_t)y1;
-    return 1;
+    const bool near1 = Lp < ql.lmin;
+    const bool sure = near1 ? ql.near1_zero != 0 : (d0 >= ql.eps && d1 >= ql.eps);     // (also false for an infinite eps: sigma out of the fp32 path's range)
+    k0 = near1 ? 0 : (int32_t)y0; k1 = near1 ? 0 : (int32_t)y1;
+    return (acc ? 1u : 0u) | ((acc && !sure) ? 2u : 0u);
 }
-DW_DEV bool quality_block_lazy(const U4 &blk, const QualLazy &ql, int32_t (&k)[4], uint32_t &acc)      // false: take the exact path for the block
+// The quality characters one Philox block of a read end's try stream delivers -- at most eight, in order, little-endian in `blk`; returns how many.
+// pos = position of the first of them.  qbw = the base quality characters per position, staged in LDS as packed bytes: nq entries followed by
+// at least eight copies of the last one (positions >= nq reuse the last entry: Ion Torrent reads can outgrow the table, their error rate is
+// uniform, dwgsim_opt.c:338-343).  (dwgsim.c:899-918: q = (char)(base quality + offset), clamped to '!' .. 'I'.)
+DW_DEV uint32_t quality_block(const U4 &b, const QualLazy &ql, double sigma, const uint32_t *qbw, int nq, int pos, uint64_t &blk)
 {
-    const float xa1 = (float)(int32_t)(blk.x ^ 0x80000000u), xa2 = (float)(int32_t)(blk.y ^ 0x80000000u);
-    const float xb1 = (float)(int32_t)(blk.z ^ 0x80000000u), xb2 = (float)(int32_t)(blk.w ^ 0x80000000u);
-    const float Ra = __builtin_fmaf(xa1, xa1, xa2 * xa2), Rb = __builtin_fmaf(xb1, xb1, xb2 * xb2);     // r * 2^62
-    const int sa = quality_try_lazy(xa1, xa2, Ra, ql, k[0], k[1]), sb = quality_try_lazy(xb1, xb2, Rb, ql, k[2], k[3]);
-    acc = (sa == 1 ? 1u : 0u) | (sb == 1 ? 2u : 0u);
-    return sa != 2 && sb != 2;
-}
-// Quality characters of one read end, in order (dwgsim.c:899-918): emit(i, q) for i = 0 .. n - 1.  qbw = the base quality characters per
-// position, staged in LDS as packed bytes: nq entries followed by at least four copies of the last one (positions >= nq reuse the last
-// entry: Ion Torrent reads can outgrow the table, their error rate is uniform, dwgsim_opt.c:338-343).
-DW_DEV uint32_t qbase4(const uint32_t *qbw, int nq, int pos)          // the four entries from pos on, as bytes
-{
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+    int32_t k[8]; uint32_t acc = 0, need = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const uint32_t r = quality_try_lazy(w[t], ql, k[2 * t], k[2 * t + 1]); acc |= (r & 1u) << t; need |= (r >> 1) << t; }
+    if (need) {                              // rare (about 2 eps of the values; the branch is skipped when no lane of the wave takes it): the reference's own arithmetic decides
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if ((need >> t) & 1u) { bool ok; quality_try_exact(w[t], sigma, ok, k[2 * t], k[2 * t + 1]); }
+    }
+    // the base qualities of the (up to eight) positions this block can fill
     const int pc = pos < nq ? pos : nq;
-    return __builtin_amdgcn_alignbyte(qbw[(pc >> 2) + 1], qbw[pc >> 2], (uint32_t)pc & 3u);
+    const uint32_t q0 = qbw[pc >> 2], q1 = qbw[(pc >> 2) + 1], q2 = qbw[(pc >> 2) + 2];
+    const uint64_t qb8 = (uint64_t)__builtin_amdgcn_alignbyte(q1, q0, (uint32_t)pc & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(q2, q1, (uint32_t)pc & 3u) << 32);
+    blk = 0; uint32_t nb = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t qb2 = (uint32_t)(qb8 >> (8 * nb));                         // the base qualities of this try's two positions
+        int32_t qa = (int8_t)((int32_t)(int8_t)(qb2 & 0xffu) + k[2 * t]), qc = (int8_t)((int32_t)(int8_t)((qb2 >> 8) & 0xffu) + k[2 * t + 1]);
+        qa = qa < 33 ? 33 : qa > 73 ? 73 : qa; qc = qc < 33 ? 33 : qc > 73 ? 73 : qc;
+        const bool on = (acc >> t) & 1u;
+        blk |= (uint64_t)(on ? ((uint32_t)qa | ((uint32_t)qc << 8)) : 0u) << (8 * nb);
+        nb += on ? 2u : 0u;
+    }
+    return nb;
 }
-struct NoTick { static constexpr bool sync = false; DW_DEV void operator()() const {} };
-template <class L> struct WaveTick { static constexpr bool sync = true; L f; DW_DEV void operator()() { f(); } };
-template <class L> DW_DEV WaveTick<L> wave_tick(L f) { return WaveTick<L>{f}; }
-// emit(i, q): quality character q of position i, in order.  With a wave_tick(...) EVERY lane of the wave must call (n = 0 for a lane without
-// a read): the blocks are then drawn in a wave-uniform loop and tick() runs once per block in all lanes together.
-template <class F, class T = NoTick>
-DW_DEV void for_each_quality(const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const uint32_t *qbw, int nq, int n, F &&emit, T tick = T())
+// The quality line of one read end, block by block (dwgsim.c:899-918): put(blk, n) receives the next n (1 .. 8) characters, little-endian in blk,
+// upper bytes zero.  n_chars characters in all; skip_first: the first one is drawn but not written (SOLiD BWA records drop the first colour's
+// quality, dwgsim.c:950-955).
+template <class F>
+DW_DEV void for_each_quality_block(const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const uint32_t *qbw, int nq, int n_chars, bool skip_first, F &&put)
 {
-    if (p.fixed_quality >= 0) { for (int i = 0; i < n; ++i) emit(i, (uint32_t)p.fixed_quality); return; }
-    if (!(0 < p.quality_std)) {
-        for (int i = 0; i < n; ++i) { int32_t q = (int8_t)(qbase4(qbw, nq, i) & 0xffu); if (q < 33) q = 33; if (q > 73) q = 73; emit(i, (uint32_t)q); }
+    auto deliver = [&](uint64_t blk, uint32_t nb, int pos) {       // clip to the line's length, drop the first character if asked to
+        if ((int)nb > n_chars - pos) { nb = (uint32_t)(n_chars - pos); blk &= (1ull << (8 * nb)) - 1ull; }
+        if (skip_first && pos == 0 && nb) { blk >>= 8; --nb; }
+        if (nb) put(blk, nb);
+    };
+    if (p.fixed_quality >= 0 || !(0 < p.quality_std)) {           // -q: one character; -Q 0: the base quality as it is
+        for (int pos = 0; pos < n_chars; pos += 8) {
+            uint64_t blk;
+            if (p.fixed_quality >= 0) blk = 0x0101010101010101ull * (uint64_t)(uint32_t)p.fixed_quality;
+            else {
+                const int pc = pos < nq ? pos : nq;
+                const uint32_t q0 = qbw[pc >> 2], q1 = qbw[(pc >> 2) + 1], q2 = qbw[(pc >> 2) + 2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)pc & 3u), hi = __builtin_amdgcn_alignbyte(q2, q1, (uint32_t)pc & 3u);
+                blk = 0;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) { int32_t q = (int8_t)(((b < 4 ? lo : hi) >> (8 * (b & 3))) & 0xffu); q = q < 33 ? 33 : q > 73 ? 73 : q; blk |= (uint64_t)(uint32_t)q << (8 * b); }
+            }
+            deliver(blk, 8, pos);
+        }
         return;
     }
     const QualLazy ql{p.q_k, p.q_eps, p.q_lmin, p.q_near1};
     int pos = 0; uint32_t t = 0;
-    for (;;) {
-        if (T::sync) { if (__ballot(pos < n) == 0) break; } else if (!(pos < n)) break;
-        if (pos < n) {
-        const uint32_t qb4 = qbase4(qbw, nq, pos);           // the base qualities of the (up to four) positions this block can fill
-        const U4 blk = rng_block(key, dom, ii, att, 0, t++);
-        int32_t k[4] = {0, 0, 0, 0}; uint32_t acc;
-        if (!quality_block_lazy(blk, ql, k, acc)) acc = quality_block_exact(blk, p.quality_std, k);
-        // try a, then try b: two offsets each, in order
-        int used = 0;
-#pragma unroll
-        for (int tr = 0; tr < 2; ++tr) {
-            if (!(acc & (1u << tr))) continue;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = pos + used;
-                if (i < n) {
-                    int32_t q = (int8_t)((int32_t)(int8_t)((qb4 >> (8 * used)) & 0xffu) + k[2 * tr + h]);
-                    if (q < 33) q = 33;
-                    if (q > 73) q = 73;
-                    emit(i, (uint32_t)q);
-                }
-                ++used;
-            }
-        }
-        pos += used;
-        }
-        tick();
+    while (pos < n_chars) {
+        const U4 b = rng_block(key, dom, ii, att, 0, t++);
+        uint64_t blk;
+        const uint32_t nb = quality_block(b, ql, p.quality_std, qbw, nq, pos, blk);
+        deliver(blk, nb, pos);
+        pos += (int)nb;
     }
 }
 
@@ -553,8 +558,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                     else for (int b = lo; b < hi; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
                 }
                 o.put('\n'); o.put('+'); o.put('\n');
-                for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out,
-                                 [&](int i, uint32_t q) { if (i >= first) o.put(q); });       // same draws for both outputs
+                for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, first != 0,
+                                       [&](uint64_t blk, uint32_t nb) { o.putn(blk, nb); });       // same draws for both outputs
                 o.put('\n');
                 o.flush();
             }
@@ -604,38 +609,9 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         o.rebase();
         }
         PH_MARK(5); // sequence line
-        // qualities (dwgsim.c:899-918), sixteen characters per store.  The lanes of a wave fill their groups of sixteen at different
-        // Philox blocks (the polar method rejects at random).  FIFO writer: a finished group waits in r0..r3 and the wave appends its
-        // waiting groups together -- when some lane could not hold another one -- instead of running the append + drain code for one
-        // lane's group in almost every block (measured: 8.62 -> 8.38 ms on chr20; the register writer's single store is better left alone)
-        {
-            uint32_t q0 = 0, q1 = 0, q2 = 0, qacc = 0, nq = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0; bool waiting = false;
-            auto emit = [&](int, uint32_t q) {
-                qacc |= q << (8 * (nq & 3));
-                if ((++nq & 3) == 0) {
-                    const uint32_t k = nq >> 2;
-                    if (k == 4) {
-                        if (WR == 0) o.put16(q0, q1, q2, qacc);     // the register writer: one store, as the group completes
-                        else {
-                            if (waiting) o.put16(r0, r1, r2, r3);   // (does not happen: the tick below writes first)
-                            r0 = q0; r1 = q1; r2 = q2; r3 = qacc; waiting = true;
-                        }
-                        nq = 0;
-                    } else { q0 = k == 1 ? qacc : q0; q1 = k == 2 ? qacc : q1; q2 = k == 3 ? qacc : q2; }
-                    qacc = 0;
-                }
-            };
-            if (WR == 0) for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, rec ? s_out : 0, emit);
-            else for_each_quality(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, rec ? s_out : 0, emit, wave_tick([&]() {
-                if (__ballot(waiting && nq >= 12u)) { if (waiting) { o.put16(r0, r1, r2, r3); waiting = false; } }      // a block adds at most four characters
-            }));
-            if (waiting) o.put16(r0, r1, r2, r3);
-            const uint32_t k = nq >> 2;
-            if (k > 0) o.put4(q0);
-            if (k > 1) o.put4(q1);
-            if (k > 2) o.put4(q2);
-            for (uint32_t q = 0; q < (nq & 3); ++q) o.put((qacc >> (8 * q)) & 0xff);
-        }
+        // qualities (dwgsim.c:899-918): up to eight characters per Philox block of the read end's try stream, appended as they come
+        if (rec) for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false,
+                                        [&](uint64_t blk, uint32_t nb) { o.putn(blk, nb); });
         if (rec) { o.put('\n'); o.flush(); }
     }
     PH_MARK(6);     // quality line
@@ -679,57 +655,53 @@ __global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n
         atomicAdd((unsigned long long *)&mism[3], (unsigned long long)s3);
     }
 }
-// Self-test of the lazy quality normals.  mode 0: n blocks drawn as the quality path draws them -- every decision of quality_block_lazy is
-// compared with quality_block_exact; out[0] = offsets that differ, out[1] = accept / reject verdicts that differ, out[2] = blocks the lazy form
-// decided, out[3] = blocks it handed to the exact path, out[4] = blocks, out[5] = max |y - x| / eps (double bits; estimate against the exact
-// fp64 value, over decided values).  mode 1 / 2 / 3: EVERY float of the operand range of v_log_f32 ([2^-62, 1)), v_rcp_f32 (same) and
-// v_sqrt_f32 ([2^-11, 2^70)) against fp64: out[6] = max |log2_hw - log2| / (2^-23 (1 + |log2|)), out[7], out[8] = max relative error / 2^-23.
+// Self-test of the lazy quality normals.  mode 0: n tries w = first, first + 1, ... (a try is one 32-bit word: n = 2^32 covers EVERY try) -- the
+// decision of quality_try_lazy is compared with quality_try_exact; out[0] = offsets that differ, out[1] = accept / reject verdicts that differ,
+// out[2] = tries the lazy form decided, out[3] = tries it handed to the exact path, out[4] = tries, out[5] = max |y - x| / eps (double bits;
+// estimate against the exact fp64 value, over decided values).  mode 1 / 2 / 3: EVERY float of the operand range of v_log_f32 ([2^-30, 1)),
+// v_rcp_f32 ([1, 2^30]) and v_sqrt_f32 ([2^-41, 2^5)) against fp64: out[6] = max |log2_hw - log2| / (2^-23 (1 + |log2|)), out[7], out[8] = max
+// relative error / 2^-23.
 DW_DEV void atomic_max_pos_double(uint64_t *p, double v) { atomicMax((unsigned long long *)p, (unsigned long long)dbl_bits(v)); }
-__global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out)
+__global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t first, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t bad_k = 0, bad_acc = 0, n_fast = 0, n_slow = 0, n_all = 0; double worst = 0.0;
-    if (i < n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         if (mode == 0) {
-            const RngKey key{seed, 0u};
-            const U4 blk = rng_block(key, 30, i, 0, 0, 0);
+            const uint32_t w = first + (uint32_t)i;
             const QualLazy ql{qk, qeps, qlmin, qnear1};
-            int32_t k[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}; uint32_t acc = 0;
-            const bool decided = quality_block_lazy(blk, ql, k, acc);
-            const uint32_t eacc = quality_block_exact(blk, sigma, e);
-            n_all = 1;
-            if (!decided) n_slow = 1;
-            else {
-                n_fast = 1;
-                if (acc != eacc) bad_acc = 1;
+            int32_t k0 = 0, k1 = 0, e0 = 0, e1 = 0; bool eok = false;
+            const uint32_t r = quality_try_lazy(w, ql, k0, k1);
+            quality_try_exact(w, sigma, eok, e0, e1);
+            ++n_all;
+            if ((r & 1u) != (eok ? 1u : 0u)) ++bad_acc;
+            else if (eok) {
+                if (r & 2u) ++n_slow;
                 else {
-                    const uint32_t w[4] = {blk.x, blk.y, blk.z, blk.w};
-                    for (int tr = 0; tr < 2; ++tr) if (acc & (1u << tr)) {
-                        bad_k += (k[2 * tr] != e[2 * tr]) + (k[2 * tr + 1] != e[2 * tr + 1]);
-                        // the estimate itself against the exact fp64 value (recomputed here as the lazy form computes it)
-                        const double v1 = (double)w[2 * tr] * 0x1p-31 - 1.0, v2 = (double)w[2 * tr + 1] * 0x1p-31 - 1.0, rsq = v1 * v1 + v2 * v2;
-                        const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
-                        const float x1 = (float)(int32_t)(w[2 * tr] ^ 0x80000000u), x2 = (float)(int32_t)(w[2 * tr + 1] ^ 0x80000000u);
-                        const float R = __builtin_fmaf(x1, x1, x2 * x2), rt = R * 0x1p-62f, Lp = -__builtin_amdgcn_logf(rt);
-                        if (!(Lp < ql.lmin)) {
-                            const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(rt));
-                            const double y0 = (double)__builtin_fmaf(x2 * f, ql.k, 0.5f), y1 = (double)__builtin_fmaf(x1 * f, ql.k, 0.5f);
-                            const double d0 = fabs(y0 - ((v2 * fac) * sigma + 0.5)), d1 = fabs(y1 - ((v1 * fac) * sigma + 0.5));
-                            const double wv = (d0 > d1 ? d0 : d1) / (double)ql.eps;
-                            worst = wv > worst ? wv : worst;
-                        } else {     // "offset 0 without further work": the exact value must really truncate to 0
-                            bad_k += (e[2 * tr] != 0) + (e[2 * tr + 1] != 0);
-                        }
-                    }
+                    ++n_fast;
+                    bad_k += (k0 != e0) + (k1 != e1);
+                    // the estimate itself against the exact fp64 value (recomputed here as the lazy form computes it)
+                    const int32_t s1 = (int32_t)(w & 0xFFFFu) - 32768, s2 = (int32_t)(w >> 16) - 32768;
+                    const double v1 = (double)s1 * 0x1p-15, v2 = (double)s2 * 0x1p-15, rsq = v1 * v1 + v2 * v2;
+                    const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+                    const float Rf = (float)((uint32_t)(s1 * s1) + (uint32_t)(s2 * s2)), Lp = -__builtin_amdgcn_logf(Rf * 0x1p-30f);
+                    if (!(Lp < ql.lmin)) {
+                        const float f = __builtin_amdgcn_sqrtf(Lp * __builtin_amdgcn_rcpf(Rf));
+                        const double y0 = (double)__builtin_fmaf((float)s2 * f, ql.k, 0.5f), y1 = (double)__builtin_fmaf((float)s1 * f, ql.k, 0.5f);
+                        const double d0 = fabs(y0 - ((v2 * fac) * sigma + 0.5)), d1 = fabs(y1 - ((v1 * fac) * sigma + 0.5));
+                        const double wv = (d0 > d1 ? d0 : d1) / (double)ql.eps;
+                        worst = wv > worst ? wv : worst;
+                    }      // (else "offset 0 without further work": covered by bad_k above -- the exact value must really truncate to 0)
                 }
             }
         } else {
-            const uint32_t first = mode == 3 ? 0x3A000000u : 0x20800000u;       // 2^-11 : 2^-62
-            union { uint32_t u; float f; } c; c.u = first + (uint32_t)i;
+            const uint32_t base = mode == 1 ? 0x30800000u : mode == 2 ? 0x3F800000u : 0x2B000000u;       // 2^-30 : 1 : 2^-41
+            union { uint32_t u; float f; } c; c.u = base + (uint32_t)i;
             const double x = (double)c.f;
-            if (mode == 1) { const double t = det_log(x) * 1.44269504088896340736; worst = fabs((double)__builtin_amdgcn_logf(c.f) - t) / (0x1p-23 * (1.0 + fabs(t))); }
-            else if (mode == 2) { const double t = 1.0 / x; worst = fabs((double)__builtin_amdgcn_rcpf(c.f) - t) / t / 0x1p-23; }
-            else { const double t = sqrt(x); worst = fabs((double)__builtin_amdgcn_sqrtf(c.f) - t) / t / 0x1p-23; }
+            double e;
+            if (mode == 1) { const double t = det_log(x) * 1.44269504088896340736; e = fabs((double)__builtin_amdgcn_logf(c.f) - t) / (0x1p-23 * (1.0 + fabs(t))); }
+            else if (mode == 2) { const double t = 1.0 / x; e = fabs((double)__builtin_amdgcn_rcpf(c.f) - t) / t / 0x1p-23; }
+            else { const double t = sqrt(x); e = fabs((double)__builtin_amdgcn_sqrtf(c.f) - t) / t / 0x1p-23; }
+            worst = e > worst ? e : worst;
         }
     }
     const uint32_t s0 = wave_sum_u32(bad_k), s1 = wave_sum_u32(bad_acc), s2 = wave_sum_u32(n_fast), s3 = wave_sum_u32(n_slow), s4 = wave_sum_u32(n_all);
@@ -742,9 +714,10 @@ __global__ void __launch_bounds__(256) k_selftest_lazy(int mode, uint32_t seed, 
     }
     if (worst > 0.0) atomic_max_pos_double(&out[mode == 0 ? 5 : 5 + mode], worst);
 }
-void launch_selftest_lazy(hipStream_t st, int mode, uint32_t seed, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out)
+void launch_selftest_lazy(hipStream_t st, int mode, uint32_t first, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out)
 {
-    hipLaunchKernelGGL(k_selftest_lazy, dim3(cdiv(n, 256)), dim3(256), 0, st, mode, seed, n, sigma, qk, qeps, qlmin, qnear1, out);
+    const uint64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_selftest_lazy, dim3((uint32_t)(nb < (1u << 20) ? (nb ? nb : 1) : (1u << 20))), dim3(256), 0, st, mode, first, n, sigma, qk, qeps, qlmin, qnear1, out);
 }
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
 {

@@ -62,8 +62,8 @@ enum {
     D_PLACE_NORM = 6,  /* index = ii; block t = polar tries of placement try t */
     D_BASE0 = 8,       /* +j; index = ii; 16-bit draws, eight per block: halfword i (block i >> 3, word (i & 7) >> 1, low half first) = the HIGH half of
                           the 32-bit uniform of base i (error test / random-read base); the low half is halfword i of D_BASE_REF0 + j */
-    D_QUAL0 = 10,      /* +j; index = ii; NARROW: the sequential stream of polar tries of the read's quality normals -- try t = words
-                          2 (t & 1), 2 (t & 1) + 1 of block t >> 1; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
+    D_QUAL0 = 10,      /* +j; index = ii; 16-BIT: the sequential stream of polar tries of the read's quality normals -- try t = the low (v1) and the high
+                          (v2) half of word t & 3 of block t >> 2; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
     D_FLOW0 = 12,      /* +j; index = ii; generate_errors_flows: 16-bit draws, eight per block -- halfword h is the HIGH half of the FIRST uniform of
                           the homopolymer event examined at position h of the evolving read (pass 1; + D_FLOW_PASS2: of the h-th empty flow of
                           pass 2); low halves in + D_FLOW_REF, every further draw of an event in its private stream + D_FLOW_EV (see flow_first) */
@@ -182,6 +182,13 @@ static inline uint32_t philox_halfword(rng_t *r, uint32_t dom, uint64_t idx, uin
     oracle_philox4x32_10(ctr, key, w);
     return (w[(i & 7) >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
 }
+/* a 16-bit uniform of a narrow stream: mode B takes halfword i of the stream (eight per Philox block, low half of a word first), u = h * 2^-16 */
+static inline double rng_u16(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t i)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
+    return (double)philox_halfword(r, dom, idx, att, i) * 0x1p-16;
+}
 static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
 {
     r->n_draws++;
@@ -241,8 +248,9 @@ double oracle_det_log(double x)
 /* A stream of normals.  Mode A ignores it (global cache + sequential draws).  Mode B, wide (placement): polar
  * tries r = 0,1,.. of block p; the accepted try gives normal 2p (= v2*fac) and, if `cache`,
  * normal 2p+1 (= v1*fac); p advances after every accepted try.  Mode B, narrow (quality strings): the tries form ONE sequential
- * stream t = 0,1,2,.. (field p counts tries): try t = words 2 (t & 1), 2 (t & 1) + 1 of block t >> 1 -- the reference's own
- * consumption pattern (a rejected try costs two uniforms, an accepted one delivers two normals) with Philox words as the uniforms. */
+ * stream t = 0,1,2,.. (field p counts tries) of 16-bit uniforms: try t = halfwords 2t, 2t + 1 of the stream = the low and the high half of
+ * word t & 3 of block t >> 2 -- the reference's own consumption pattern (a rejected try costs two uniforms, an accepted one delivers two
+ * normals) with Philox halfwords as the uniforms: 2^32 distinct tries, far more than the truncation (int)(nrm * sigma + 0.5) can resolve. */
 typedef struct { uint32_t dom; uint64_t idx; uint32_t att; uint32_t p; int cache; int has; double g; int narrow; } nstream_t;
 
 /* dwgsim.c:156-175 ran_normal(): Marsaglia polar method */
@@ -255,8 +263,8 @@ static double ran_normal(rng_t *r, nstream_t *ns)
         uint32_t retry = 0;
         do {
             if (ns->narrow) {
-                v1 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, 0, 2 * ns->p) - 1.0;
-                v2 = 2.0 * rng_u32(r, ns->dom, ns->idx, ns->att, 0, 2 * ns->p + 1) - 1.0;
+                v1 = 2.0 * rng_u16(r, ns->dom, ns->idx, ns->att, 2 * ns->p) - 1.0;
+                v2 = 2.0 * rng_u16(r, ns->dom, ns->idx, ns->att, 2 * ns->p + 1) - 1.0;
                 ns->p++;
             } else {
                 v1 = 2.0 * rng_u(r, ns->dom, ns->idx, ns->att, retry, 2 * ns->p) - 1.0;

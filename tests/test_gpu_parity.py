@@ -296,24 +296,25 @@ def test_range_restricted_fp64_forms_equal_the_general_ones(lib):
 
 
 def test_lazy_quality_normals_decide_exactly_what_the_exact_form_decides(lib):
-    """quality_pair_lazy (fp32 estimate + proven error bound, exact fp64 path only near a rounding boundary) against quality_pair_exact on
-    2^28 blocks per quality_std, and the hardware operations the bound rests on (v_log_f32, v_rcp_f32, v_sqrt_f32) against fp64 on EVERY
-    float of their operand ranges."""
+    """quality_try_lazy (fp32 estimate + proven error bound, exact fp64 path only near a rounding boundary) against quality_try_exact on EVERY
+    possible try -- a try of the quality stream is one 32-bit word, so 2^32 of them per quality_std is all there is -- and the hardware
+    operations the bound rests on (v_log_f32, v_rcp_f32, v_sqrt_f32) against fp64 on EVERY float of their operand ranges."""
     import ctypes as C, struct
     out = (C.c_uint64 * 12)()
     lib.dwgsim_hip_selftest_lazy.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.c_double, C.c_int, C.POINTER(C.c_uint64)]
     lib.dwgsim_hip_selftest_lazy.restype = C.c_int
     dbl = lambda u: struct.unpack("<d", struct.pack("<Q", u))[0]
-    for k, sigma in enumerate((2.0, 0.3, 10.0, 40.0, 5000.0, 1e7)):
-        assert lib.dwgsim_hip_selftest_lazy(0, 100 + k, 1 << 28, sigma, 1 if k == 0 else 0, out) == 0
-        assert out[4] == 1 << 28 and out[2] + out[3] == out[4], list(out)
+    for k, sigma in enumerate((2.0, 0.3, 1.0, 3.7, 10.0, 40.0, 5000.0, 1e7)):
+        assert lib.dwgsim_hip_selftest_lazy(0, 0, 1 << 32, sigma, 1 if k == 0 else 0, out) == 0
+        assert out[4] == 1 << 32, list(out)
         assert out[0] == 0 and out[1] == 0, (sigma, list(out))                  # not one offset, not one accept / reject verdict differs
+        assert 3.3e9 < out[2] + out[3] < 3.4e9                                   # pi / 4 of the tries are accepted
         assert dbl(out[5]) < 0.5, (sigma, dbl(out[5]))                           # the estimate stays well inside its proven bound
         if sigma <= 10:
             assert out[3] < 0.01 * out[4], (sigma, out[3] / out[4])              # ... and the exact path is rare at realistic -Q
         if k == 0:
             assert 0 < dbl(out[6]) <= 1.0 and 0 < dbl(out[7]) <= 1.0 and 0 < dbl(out[8]) <= 1.0, [dbl(out[q]) for q in (6, 7, 8)]
-        print(f"sigma {sigma}: exact-path share {out[3] / out[4]:.5f}, max |y - x| / eps {dbl(out[5]):.3f}", [round(dbl(out[q]), 3) for q in (6, 7, 8)] if k == 0 else "")
+        print(f"sigma {sigma}: exact-path share {out[3] / max(out[2] + out[3], 1):.5f}, max |y - x| / eps {dbl(out[5]):.3f}", [round(dbl(out[q]), 3) for q in (6, 7, 8)] if k == 0 else "")
 
 
 @pytest.mark.parametrize("which,flags", [
