@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""tools/make_counters_json.py <workload-key> <gpurun_out/tag> [profiles/r02_counters.json] -- analysis only: fold the PMC passes of
+"""tools/make_counters_json.py <workload-key> <gpurun_out/tag> [profiles/r03_counters.json] -- analysis only: fold the PMC passes of
 tools/profile_round.sh into the JSON that bench.py quotes (roofline.traffic, roofline.valu).  Units and corrections as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as
 64 bytes, so it is doubled; separate --pmc passes."""
-import json, os, re, sys
+import hashlib, json, os, re, subprocess, sys
 
 key, d = sys.argv[1], sys.argv[2]
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_counters.json")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_counters.json")
 vals = {}
 for line in open(os.path.join(d, "pmc.txt")):
     m = re.match(r"^.*k_simulate.*?\s([A-Z][A-Z0-9_]+)\s+([0-9.]+)\s+n=", line)
@@ -15,8 +15,15 @@ for line in open(os.path.join(d, "pmc.txt")):
 bench = json.load(open(os.path.join(d, "bench_line.json")))
 pairs = bench["config"]["pairs_per_gpu_per_step"]
 waves = vals.get("SQ_WAVES")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sha = hashlib.sha256(open(os.path.join(root, "dwgsim_amd", "libdwgsim_hip.so"), "rb").read()).hexdigest()      # the build the counters were taken on: bench.py quotes them for this library only
+try:
+    head = open(os.path.join(d, "git_head.txt")).read().strip()
+except Exception:
+    head = None
+pairs = int(pairs / max(bench["config"].get("launches_per_gpu_per_step", 1), 1))
 out = {"source": f"profiles/{os.path.basename(d)}_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
-       "kernel": bench["roofline"]["kernel"], "pairs_per_launch": pairs}
+       "kernel": bench["roofline"]["kernel"], "pairs_per_launch": pairs, "lib_sha256": sha, "git_head": head}
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.update({"fetch_size_kib": vals["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kib": vals["WRITE_SIZE"],
                 "traffic_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)})
