@@ -12,12 +12,9 @@
 #include <stdint.h>
 
 #define DW_DEV __device__ __forceinline__
-// dynamic LDS of a kernel (the test-only CPU emulation in tests/emu substitutes a heap buffer)
-#ifndef DW_EMU
-#define DW_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
-#else
-#define DW_DYN_SHARED(type, name) type *name = (type *)hipemu::dyn_shared()
-#endif
+// the gfx950 instructions and address spaces this code is written for -- the only header with a stand-in elsewhere (tests/emu/dw_intrin.hpp, found
+// first by the include path of the test-only CPU emulation build: test infrastructure, never part of the product)
+#include <dw_intrin.hpp>
 
 namespace dw {
 
@@ -53,48 +50,8 @@ enum : uint32_t {
 
 struct U4 { uint32_t x, y, z, w; };
 
-// a ^ b ^ c in one instruction: gfx950's v_bitop3_b32 (truth table 0x96)
-DW_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
-{
-#ifndef DW_EMU
-    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-#else
-    return a ^ b ^ c;
-#endif
-}
+template <class T> DW_DEV const DW_CONST_AS T *as_constant(const T *p) { return (const DW_CONST_AS T *)p; }      // (DW_CONST_AS: dw_intrin.hpp)
 
-// a value that is the same in every lane of the wave, moved to a scalar register (what depends on it -- table lookups, loop bounds -- stays scalar)
-DW_DEV uint32_t uniform_u32(uint32_t v)
-{
-#ifndef DW_EMU
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-#else
-    return v;
-#endif
-}
-
-// A pointer into memory that nothing writes while the kernel runs (tables the host uploaded before the launch), in the constant address space:
-// loads through it at a wave-uniform address are SCALAR loads (s_load), their results live in scalar registers.  Through a plain global pointer
-// the compiler must assume that the kernel's own stores and atomics could have clobbered the table and falls back to vector loads.
-#ifndef DW_EMU
-#define DW_CONST_AS __attribute__((address_space(4)))
-#else
-#define DW_CONST_AS
-#endif
-template <class T> DW_DEV const DW_CONST_AS T *as_constant(const T *p) { return (const DW_CONST_AS T *)p; }
-
-// byte-wise table lookup: byte i of the result = byte sel.byte[i] (0..7) of the eight-byte table {hi, lo}; one v_perm_b32
-DW_DEV uint32_t lut8(uint32_t hi, uint32_t lo, uint32_t sel)
-{
-#ifndef DW_EMU
-    return __builtin_amdgcn_perm(hi, lo, sel);
-#else
-    const uint64_t t = ((uint64_t)hi << 32) | lo;
-    uint32_t r = 0;
-    for (int i = 0; i < 4; ++i) r |= (uint32_t)((t >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
-    return r;
-#endif
-}
 // the four nibbles of v[15:0] spread into the four bytes of the result
 DW_DEV uint32_t spread4(uint32_t v)
 {
@@ -110,9 +67,7 @@ DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-#ifndef DW_EMU
-        if (UNIFORM_KEY) asm volatile("" : "+s"(k0), "+s"(k1));      // keep the round keys out of 20 hoisted SGPRs: two SALU adds per round instead
-#endif
+        if (UNIFORM_KEY) keep_scalar(k0, k1);      // keep the round keys out of 20 hoisted SGPRs: two SALU adds per round instead
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -153,31 +108,7 @@ DW_DEV double bits_dbl(uint64_t u) { union { double d; uint64_t u; } c; c.u = u;
 // lowerFSQRTF64) minus their v_div_scale / v_div_fixup / ldexp / class-test range handling, which is the identity on such
 // operands.  Used where the operand range is known (quality normals: y, x in [2^-62, 2^70]); dwgsim_hip_selftest_fp64 compares
 // them bit for bit with the compiler's own `/` and sqrt() (tests/test_gpu_parity.py).
-DW_DEV double div_mid(double x, double y)
-{
-#ifndef DW_EMU
-    const double r0 = __builtin_amdgcn_rcp(y);
-    const double r1 = __builtin_fma(r0, __builtin_fma(-y, r0, 1.0), r0);
-    const double r2 = __builtin_fma(r1, __builtin_fma(-y, r1, 1.0), r1);
-    const double q0 = x * r2;
-    return __builtin_fma(__builtin_fma(-y, q0, x), r2, q0);
-#else
-    return x / y;
-#endif
-}
-DW_DEV double sqrt_mid(double x)
-{
-#ifndef DW_EMU
-    const double y = __builtin_amdgcn_rsq(x);
-    const double g0 = x * y, h0 = y * 0.5;
-    const double r0 = __builtin_fma(-h0, g0, 0.5);
-    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
-    const double g2 = __builtin_fma(__builtin_fma(-g1, g1, x), h1, g1);
-    return __builtin_fma(__builtin_fma(-g2, g2, x), h1, g2);
-#else
-    return sqrt(x);
-#endif
-}
+// (div_mid, sqrt_mid: dw_intrin.hpp)
 
 // Natural log for finite x > 0 with only IEEE-754 fp64 + - * / (compile with -ffp-contract=off):
 // argument reduction x = 2^k (1+f), s = f/(2+f), even polynomial in s -- the classic fdlibm

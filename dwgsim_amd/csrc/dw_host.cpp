@@ -332,13 +332,25 @@ int64_t dwgsim_hip_group_layout(const int64_t *lens, int n, int64_t *starts)
     return align_up(at, 16);
 }
 
-// Ion Torrent: room for a read after the flow model.  Every empty flow (about three per base) inserts Geometric(e) bases, inserted bases
-// are examined again: the mean growth is ~3 e / (1 - e) per base; four times that plus slack keeps overflow (reported as an error, never
+// Ion Torrent: room for a read after the flow model.  Every empty flow in front of a base inserts Geometric(e) bases, and inserted bases are
+// examined again.  How many empty flows a base has in front of it is a property of the flow order: m = the mean distance from a flow to the next
+// flow of a given base (about 2.5 for the usual 32-flow orders, 1.5 for TACG, but 15 for an order that keeps three bases away for 37 flows).  The
+// mean growth is g = m e / (1 - e) per base, with the cascade 1 / (1 - g); four times that plus slack keeps overflow (reported as an error, never
 // written out of bounds) out of reach for realistic error rates and far away even for e = 0.3.
-static int flow_read_capacity(int len, double e)
+static int flow_read_capacity(int len, double e, const std::vector<uint8_t> &flow)
 {
     const double ec = !(e > 0) ? 0 : e > 0.9 ? 0.9 : e;       // (NaN, e.g. -B with -e 0: no flow errors at all)
-    return len + 64 + (int)(len * 12.0 * ec / (1.0 - ec));
+    double m = 3.0;
+    const int F = (int)flow.size();
+    if (F > 0) {
+        double sum = 0;
+        for (int f = 0; f < F; ++f) for (uint8_t b = 0; b < 4; ++b) { int k = 0, g = f; while (flow[(size_t)g] != b && k < F) { ++k; g = g + 1 == F ? 0 : g + 1; } sum += k; }
+        m = sum / (4.0 * F);
+        if (m < 3.0) m = 3.0;
+    }
+    double g = m * ec / (1.0 - ec);
+    g = g / (1.0 - (g < 0.75 ? g : 0.75));
+    return len + 64 + (int)(len * 4.0 * g);
 }
 
 static int set_err(int *err, int v) { if (err) *err = v; return v; }
@@ -398,7 +410,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
                 ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
-                ca.cap = flow_read_capacity(len, e); ca.lds_words = (ca.cap + 7) / 8;
+                ca.cap = flow_read_capacity(len, e, c->flow); ca.lds_words = (ca.cap + 7) / 8;
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
                 if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
                 ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
@@ -1123,7 +1135,7 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
         const double emax = p.e_start[0] > p.e_start[1] ? p.e_start[0] : p.e_start[1];
-        a.cap = flow_read_capacity(lmax, emax);
+        a.cap = flow_read_capacity(lmax, emax, c->flow);
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();

@@ -336,7 +336,8 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
     // leaves this loop; 2^14 errors in one flow already overflow every buffer, so the caller reports the read as outgrown.
     DW_DEV int more_errors(uint64_t thr) { int n = 1; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
 };
-// Sequential reader of a lane's hit bitmap (word w at base[w * stride]): up to 31 bits at a non-decreasing bit position
+// Sequential reader of a lane's hit bitmap (word w at base[w * stride]): up to 31 bits (k <= 31: the mask is built with a 32-bit shift) at a
+// non-decreasing bit position; callers with more flows to look at (a flow order may keep a base away for up to 63 flows) take them in pieces
 struct BitWindow {
     const uint32_t *base; int stride, cw, nw; uint32_t lo, hi;
     DW_DEV void init(const uint32_t *b, int st, int nwords) { base = b; stride = st; nw = nwords; cw = 0; lo = nw > 0 ? base[0] : 0u; hi = nw > 1 ? base[stride] : 0u; }
@@ -469,7 +470,8 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
             if (!done && o2.n >= cap) { failed = true; done = true; }
             if (!done) {
                 const uint32_t k_empty = dist[4 * flow_i + (int)x];
-                if (g + k_empty <= (uint32_t)G0 && bw.peek(g, k_empty) == 0) { flow_i += (int)k_empty; if (flow_i >= F) flow_i -= F; g += k_empty; settle(x, t2, sp); }
+                // (more than 31 empty flows in front of a base -- only flow orders with such gaps have them -- go through the parked path, which takes them in pieces)
+                if (k_empty <= 31u && g + k_empty <= (uint32_t)G0 && bw.peek(g, k_empty) == 0) { flow_i += (int)k_empty; if (flow_i >= F) flow_i -= F; g += k_empty; settle(x, t2, sp); }
                 else parked = true;
             }
         }
@@ -481,7 +483,13 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
                 uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
                 while (!failed && left > 0) {
                     uint32_t skip;                              // quiet flows before the next scoring one
-                    if (g + left <= (uint32_t)G0) { const uint32_t bits = bw.peek(g, left); skip = bits ? (uint32_t)__ffs((int)bits) - 1u : left; }
+                    bool quiet_piece = false;                   // the piece looked at (at most 31 flows) held no scoring flow and is not the last one
+                    if (g + left <= (uint32_t)G0) {
+                        const uint32_t piece = left < 31u ? left : 31u;
+                        const uint32_t bits = bw.peek(g, piece);
+                        skip = bits ? (uint32_t)__ffs((int)bits) - 1u : piece;
+                        quiet_piece = !bits && piece < left;
+                    }
                     else {                                      // beyond the bitmap (a long cascade): flow by flow
                         skip = 0;
                         while (skip < left && !((flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, (g + skip) >> 3, thr) >> ((g + skip) & 7u)) & 1u)) ++skip;
@@ -489,6 +497,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
                     flow_i += (int)skip; if (flow_i >= F) flow_i -= F;
                     g += skip; left -= skip;
                     if (left == 0) break;
+                    if (quiet_piece) continue;
                     rg.open(g);                                 // flow g scores: while (drand48() < e) n_err++ goes on in its private stream
                     const int n_err = rg.more_errors(thr);
                     if (flow_i != marked_flow) {

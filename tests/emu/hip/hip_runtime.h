@@ -20,7 +20,7 @@
 #include <thread>
 #include <vector>
 
-#define DW_EMU 1
+#define DW_EMU 1      // (nothing under dwgsim_amd/ looks at it: the emulation enters through tests/emu/dw_intrin.hpp)
 #define __global__
 #define __device__
 #define __host__

@@ -12,7 +12,7 @@ DRIVER = r'''
 import os, re, sys
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from dwgsim_amd import api
-from parity_common import compare_case, check_gpu_gzip, check_record_writers, WRITER_CASES
+from parity_common import compare_case, compare_job_api, check_gpu_gzip, check_record_writers, WRITER_CASES
 lib = api.load(LIB)
 oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
 g = os.path.join(ROOT, "tests", "golden")
@@ -21,6 +21,9 @@ for fasta, flags in [("ex1.fa", "-z 13 -N 160"), ("odd.fa", "-z 3 -N 200 -1 50 -
                      ("tiny.fa", "-z 9 -N 200 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
                      ("tiny.fa", "-z 3 -N 40 -1 1300 -2 1400 -d 3600 -s 40 -n 60")]:
     compare_case(lib, oracle, os.path.join(g, fasta), flags, batch_pairs=128)
+# contigs resident together (one coordinate space, launches across contig boundaries), and the job level on three contexts
+compare_case(lib, oracle, os.path.join(g, "odd.fa"), "-z 3 -N 300 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50 -y 0.1", batch_pairs=90, group_bp=1 << 30)
+compare_job_api(lib, oracle, os.path.join(g, "tiny.fa"), "-z 9 -N 300 -y 0.2 -r 0.02 -R 0.5", devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=64, min_share=20)
 # reads the flow model gives up on (absurd per-flow error): the call must fail cleanly, with every write in bounds
 compare_case(lib, oracle, os.path.join(g, "ex1.fa"), "-z 8397 -1 100 -2 0 -N 64 -e 0.3 -o 0 -c 2 -f GATC", batch_pairs=128)      # deep insertion cascades
 for flags in ["-z 4246 -1 9 -2 0 -N 300 -e 1.0 -y 0.3 -n 20 -c 2 -f TACG", "-z 4246 -1 9 -2 9 -d 40 -N 300 -e 1.0 -o 0 -c 2 -f TACG"]:
@@ -46,7 +49,7 @@ def test_kernel_sources_are_asan_clean_on_the_emulator(oracle_bin, tmp_path):
     lib = str(tmp_path / "libdwgsim_emu_asan.so")
     subprocess.run(["g++", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
                     "-I" + os.path.join(HERE, "emu"), "-x", "c++", os.path.join(SRC, "dw_walk.hip"), os.path.join(SRC, "dw_gzip.hip"), os.path.join(SRC, "dw_simulate.hip"),
-                    os.path.join(SRC, "dw_host.cpp"), os.path.join(SRC, "dw_mutin.cpp"), os.path.join(HERE, "emu", "hip_emu.cpp"), "-o", lib], check=True)
+                    os.path.join(SRC, "dw_host.cpp"), os.path.join(SRC, "dw_mutin.cpp"), os.path.join(SRC, "dw_job.cpp"), os.path.join(HERE, "emu", "hip_emu.cpp"), "-o", lib], check=True)
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\nLIB = {lib!r}\n" + DRIVER], capture_output=True, text=True, env=env, timeout=1200)
     assert r.returncode == 0 and "ASAN-CLEAN" in r.stdout, (r.stdout[-800:], r.stderr[-3000:])

@@ -17,6 +17,7 @@ EMU_CASES = [
     ("tiny.fa", "-z 9 -N 700 -o 1 -y 0.3 -P pfx -A 2"),
     ("tiny.fa", "-z 9 -N 600 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 400 -2 0 -e 0.01"),
     ("tiny.fa", "-z 9 -N 400 -c 2 -f TACG -1 100 -2 60 -e 0.2 -E 0.1 -d 300 -o 1"),
+    ("tiny.fa", "-z 9 -N 300 -c 2 -f TCG" + "A" * 37 + " -1 120 -2 0 -e 0.03"),                      # 39 empty flows in front of a T: more than one 31-bit piece of the hit bitmap
     ("tiny.fa", "-z 8 -N 700 -c 1 -1 50 -2 35 -d 300 -r 0.02 -R 0.5 -e 0.05 -E 0.03 -y 0.1"),
     ("odd.fa", "-z 6 -N 500 -c 1 -2 0 -1 40 -r 0.08 -R 0.8 -n 20"),
     ("tiny.fa", "-z 3 -N 200 -1 1300 -2 1400 -d 3600 -s 40 -n 60 -y 0.1"),
