@@ -31,7 +31,7 @@
 #define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0)
 #endif
 #ifndef DW_ION_WAVES
-#define DW_ION_WAVES 1       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants
+#define DW_ION_WAVES 5       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants: without the hint the window registers of the extraction push them to 104 VGPRs = 4 waves (measured 165 -> 187 M reads/s at 5; 6 brings nothing)
 #endif
 
 namespace dw {
