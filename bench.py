@@ -17,8 +17,9 @@ N>1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself 
 Sharding is the product's (dw_job.cpp): the pairs of every group of contigs, in file order, are cut into batches of read-index ranges and
 batch b belongs to rank b mod N; every rank walks every contig itself.  No data-path collective and no RCCL: what crosses ranks is ONE
 host-side (gloo) all-gather of integers per step -- the random reads of every batch, counted (k_place) before anything is simulated, whose
-running sum offsets rand_ii (dwgsim.c:1042,1096); a job of many groups takes a second one, so that the walks of the later groups run
-behind the kernels of the first.
+running sum offsets rand_ii (dwgsim.c:1042,1096).
+Steps are pipelined as the groups of a long job are (dw_job.cpp): every contig is resident twice, and the preparation of step k+1 -- walk,
+random-read count, exchange: walk stream and host -- runs beside the kernels of step k.  `--no-pipeline`: every step prepares itself first.
   --mode weak   (default) per-GPU work is fixed: the job's coverage is N times the workload's (-C 30 N), i.e. N times the pairs
   --mode strong one fixed job (e.g. --workload grch38: the 325 M-pair S4 genome) split over the ranks
 
@@ -256,6 +257,7 @@ def main():
     ap.add_argument("--no-genome-leg", action="store_true", help="skip the end_to_end_genome leg (dwgsim-hip on the whole S4 genome: about a minute, most of it making the synthetic FASTA)")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
+    ap.add_argument("--no-pipeline", action="store_true", help="every step prepares itself (walk, random-read count, exchange) before its first launch, on one resident copy of the contigs")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
     args = ap.parse_args()
 
@@ -311,25 +313,20 @@ def main():
         job.append((name, arr, ci, n))
         n_sim += n
     job_pairs = sum(e[3] for e in job)
-    groups = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
-    for grp in make_groups(job, args.group_bp):
-        h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
-        launches = balanced_batches(api, [(h0 + k, 0, n) for k, (_, _, _, n) in enumerate(grp) if n > 0], world, MAX_LAUNCH_PAIRS)
-        groups.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)], "launches": launches, "mine": [b for b in range(len(launches)) if b % world == rank], "pairs": sum(n for l in launches for _, _, n in l)})
+    # Every group is resident TWICE (copies A / B, used by alternate steps): the walk rewrites the haplotypes in place, so the walk + random-read
+    # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
+    # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
+    copies = []
+    for _copy in range(1 if args.no_pipeline else 2):
+        gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
+        for grp in make_groups(job, args.group_bp):
+            h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
+            launches = balanced_batches(api, [(h0 + k, 0, n) for k, (_, _, _, n) in enumerate(grp) if n > 0], world, MAX_LAUNCH_PAIRS)
+            gl.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)], "launches": launches, "mine": [b for b in range(len(launches)) if b % world == rank], "pairs": sum(n for l in launches for _, _, n in l)})
+        copies.append(gl)
+    groups = copies[0]
     my_pairs = sum(n for g in groups for b in g["mine"] for _, _, n in g["launches"][b])
     n_my_launches = sum(len(g["mine"]) for g in groups)
-
-    # groups whose random reads are exchanged together: the first ~1/8 of the job's pairs alone (so that the walks and counts of the
-    # rest run behind its kernels), then everything else
-    chunks = [list(range(len(groups)))]
-    if world > 1 and len(groups) > 2:
-        acc, cut = 0, 0
-        for gi, g in enumerate(groups):
-            acc += g["pairs"]; cut = gi + 1
-            if acc * 8 >= job_pairs:
-                break
-        if 0 < cut < len(groups):
-            chunks = [list(range(cut)), list(range(cut, len(groups)))]
 
     def barrier():
         torch.cuda.synchronize()
@@ -339,10 +336,47 @@ def main():
 
     stats = {"prep_ms": 0.0, "count_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
 
-    def step(record):
-        for g in groups:
-            ctx.mutate_async(g["h0"])                              # every rank walks every group itself (deterministic, cheap): all enqueued on the walk stream
-        rand_before = 0
+    def prepare(gl, record):
+        """What a step needs before its first launch: the walk of every group (every rank walks every group itself: deterministic, no broadcast),
+        this rank's random-read counts (k_place, one launch per group, one count per batch) and ONE all-gather of them; -> the rand_ii base of
+        every launch of this rank.  All of it on the walk stream / the host: it runs beside whatever the compute stream is doing."""
+        t0 = time.perf_counter()
+        for g in gl:
+            ctx.mutate_async(g["h0"])
+        counts = []
+        tc = 0.0
+        for g in gl:
+            ctx.mutate_wait(g["h0"])
+            if world > 1:
+                t1 = time.perf_counter()
+                flat = [r for b in g["mine"] for r in g["launches"][b]]
+                per = iter(ctx.count_random_ranges(flat, per_range=True) if flat else [])
+                counts.append([sum(next(per) for _ in g["launches"][b]) for b in g["mine"]])
+                tc += time.perf_counter() - t1
+        t2 = time.perf_counter()
+        bases = {}
+        if world > 1:
+            width = max(1, max(-(-len(g["launches"]) // world) for g in gl))
+            mine_vec = torch.zeros(len(gl) * width, dtype=torch.int64)
+            for q in range(len(gl)):
+                for k, cval in enumerate(counts[q]):
+                    mine_vec[q * width + k] = cval
+            allv = torch.empty(world * mine_vec.numel(), dtype=torch.int64)
+            dist.all_gather_into_tensor(allv, mine_vec)          # one integer per launch: the only thing that crosses ranks
+            allv = allv.view(world, len(gl), width)
+            run = 0
+            for q, g in enumerate(gl):      # launch b belongs to rank b mod world; its count sits at that rank's position b // world
+                for b in range(len(g["launches"])):
+                    if b % world == rank:
+                        bases[(q, b)] = run
+                    run += int(allv[b % world, q, b // world])
+        t3 = time.perf_counter()
+        if record:
+            stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
+        return bases
+
+    def run(gl, bases, record, then=None):
+        """all launches of this rank for one step, two in flight; `then` (the preparation of the next step) runs once the last one is enqueued"""
         acc = {"bytes": 0, "rand": 0}
         slot = 0
         pending = []
@@ -354,60 +388,36 @@ def main():
                 if record:
                     stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
         first_launch = True
-        for chunk in chunks:
-            t0 = time.perf_counter()
-            tc = 0.0
-            counts = []
-            for gi in chunk:
-                g = groups[gi]
-                ctx.mutate_wait(g["h0"])
-                if world > 1:
-                    t1 = time.perf_counter()
-                    flat = [r for b in g["mine"] for r in g["launches"][b]]
-                    per = ctx.count_random_ranges(flat, per_range=True) if flat else []      # (on the walk stream: behind the walks, beside the kernels)
-                    it = iter(per)
-                    counts.append([sum(next(it) for _ in g["launches"][b]) for b in g["mine"]])
-                    tc += time.perf_counter() - t1
-            t2 = time.perf_counter()
-            bases = {}
-            if world > 1:
-                # ONE all-gather for the chunk: per rank, the counts of its launches in (group, launch) order, padded to a common width
-                width = max(1, max(-(-len(groups[gi]["launches"]) // world) for gi in chunk))
-                mine_vec = torch.zeros(len(chunk) * width, dtype=torch.int64)
-                for q, gi in enumerate(chunk):
-                    for k, cval in enumerate(counts[q]):
-                        mine_vec[q * width + k] = cval
-                allv = torch.empty(world * mine_vec.numel(), dtype=torch.int64)
-                dist.all_gather_into_tensor(allv, mine_vec)
-                allv = allv.view(world, len(chunk), width)
-                for q, gi in enumerate(chunk):      # launch b belongs to rank b mod world; its count sits at that rank's position b // world
-                    run = rand_before
-                    for b in range(len(groups[gi]["launches"])):
-                        if b % world == rank:
-                            bases[(gi, b)] = run
-                        run += int(allv[b % world, q, b // world])
-                    rand_before = run
-            t3 = time.perf_counter()
-            if record:
-                stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
-            for gi in chunk:
-                g = groups[gi]
-                for b in g["mine"]:
-                    drain(1)
-                    base = bases[(gi, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
-                    first_launch = False
-                    ctx.simulate_ranges_async(g["launches"][b], base, slot)
-                    pending.append(slot); slot ^= 1
+        for q, g in enumerate(gl):
+            for b in g["mine"]:
+                drain(1)
+                base = bases[(q, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
+                first_launch = False
+                ctx.simulate_ranges_async(g["launches"][b], base, slot)
+                pending.append(slot); slot ^= 1
+        nxt = then() if then else None
         drain(0)
         if record:
             stats["bytes"] = acc["bytes"]; stats["n_random"] = acc["rand"]
+        return nxt
 
-    for _ in range(args.warmup):
-        step(False)
+    def steps(n, record):
+        if args.no_pipeline:
+            for _ in range(n):
+                run(copies[0], prepare(copies[0], record), record)
+            return
+        bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares its successor)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n):
+            nx = copies[(k + 1) & 1]
+            bases = run(copies[k & 1], bases, record, then=lambda: prepare(nx, record))
+        return t0
+
+    steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    t0 = steps(args.steps, True) or t0
     barrier()
     elapsed = time.perf_counter() - t0
     total_pairs = my_pairs
@@ -452,12 +462,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{sname} ({args.workload}): {len(job)} uniform-random contig(s) in {len(groups)} resident group(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {job_flags}, "
-                                   f"{job_pairs} pairs per job; step = mutation walk of every contig + all pairs of this rank's read-index ranges, FASTQ text left in HBM",
+                                   f"{job_pairs} pairs per job; step = mutation walk of every contig + all pairs of this rank's read-index ranges, FASTQ text left in HBM; " +
+                                   ("every step prepares itself before its first launch" if args.no_pipeline else "the walk, random-read count and exchange of step k+1 run on the walk stream beside the kernels of step k (contigs resident twice)"),
                        "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
                        "random_pairs": stats["n_random"],
-                       "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), {len(chunks)} host-side all-gather(s) of integers per step" if world > 1 else "one GPU")},
+                       "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), one host-side all-gather of integers per step" if world > 1 else "one GPU")},
             "breakdown_ms": {"wait_for_walks": round(stats["prep_ms"] / K, 4), "count_random": round(stats["count_ms"] / K, 4), "exchange": round(stats["exch_ms"] / K, 4), "simulate_kernels": round(stats["sim_kernel_ms"] / K, 4),
-                             "note": "host time before this rank's launches of each exchange chunk (walks and counts run on their own stream, those of later groups behind the kernels of earlier ones), and the HIP-event time of the k_simulate launches"},
+                             "note": "host time of a step's preparation (walks and counts run on their own stream" + ("" if args.no_pipeline else ", beside the previous step's kernels") + ") and the HIP-event time of its k_simulate launches"},
             "roofline": {"bound": "valu", "kernel": f"k_simulate<{2 if paired else 1},{[3, 1, 2][params.reads_output_type]},{params.data_type}>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": prof.get("traffic_bytes_per_launch"),
