@@ -190,7 +190,9 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, const SegCtx &sc, RngKey key, uint64
                     v1 = 2.0 * u_lo(b) - 1.0; v2 = 2.0 * u_hi(b) - 1.0;
                     rsq = v1 * v1 + v2 * v2; ++r;
                 } while (rsq >= 1.0 || rsq == 0.0);
-                const double fac = sqrt(-2.0 * det_log(rsq) / rsq);
+                // (the range-restricted forms give the same bits on their operand range -- dwgsim_hip_selftest_fp64; a radius below 2^-60 never
+                // occurs in practice and takes the general ones)
+                const double fac = rsq >= 0x1p-60 ? sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq)) : sqrt(-2.0 * det_log(rsq) / rsq);
                 double ran = v2 * fac;
                 ran = ran * a.p.std_dev + a.p.dist;
                 d = (int32_t)(ran + 0.5);

@@ -76,45 +76,40 @@ DW_DEV bool attempt_surely_accepted(const uint16_t *summ, int64_t l, int64_t sta
     return !(flags & 0x8000u) && indel <= (uint32_t)s;
 }
 
-// K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.
-// One lane per read end (LPP = 2: lanes 2q / 2q+1 test the two ends of pair q and exchange the verdict).
-template <int LPP>
-__global__ void __launch_bounds__(PAIRS_PER_BLOCK *LPP) k_place(SimArgs a)
+// K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.  One lane per PAIR: the pair's draws are
+// made once, then both read ends are tested (a window the summaries clear is accepted without being read).
+__global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_place(SimArgs a)
 {
     __shared__ uint32_t sm[17];
-    const int tid = (int)threadIdx.x, j = (LPP == 2) ? (tid & 1) : 0;
+    const int tid = (int)threadIdx.x;
     const SegPtr sg = as_constant(a.segs) + seg_of_block(as_constant(a.segs), a.n_seg, blockIdx.x);          // the read-index range this block works on
     const SegCtx sc = seg_ctx(a, sg);
-    const uint64_t pair = (uint64_t)(blockIdx.x - sg->first_block) * PAIRS_PER_BLOCK + (uint64_t)(tid / LPP);      // inside the range
+    const uint64_t pair = (uint64_t)(blockIdx.x - sg->first_block) * PAIRS_PER_BLOCK + (uint64_t)tid;      // inside the range
     const bool valid = pair < sg->n_pairs;
     const uint64_t ii = sg->first_ii + pair;
     const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
-    const int sj = sel_len(a, j);
     uint32_t att = 0; bool is_rand = false, failed = false, done = !valid;
-    while (__ballot(!done)) {                      // wave-uniform loop: the two lanes of a pair always agree on `done`
+    while (!done) {
+        const PairDraw pd = draw_pair(a, sc, key, ii, att);
+        if (pd.is_rand) { is_rand = true; break; }
         bool ok = true;
-        if (!done) {
-            const PairDraw pd = draw_pair(a, sc, key, ii, att);
-            if (pd.is_rand) { is_rand = true; done = true; }
-            else if (sj > 0) {
-                int64_t start; int step;
-                read_geom(a, sc, pd, j, &start, &step);
-                if (!attempt_surely_accepted((pd.hap ? a.summ[1] : a.summ[0]) + sc.start / SUMM_CELLS, sc.l, start, step, sj)) {     // rare: N, dense indels, contig ends
-                    const ReadRes r = gen_read<false>(sel_hap(a, sc, pd.hap), sc.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
-                    ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
-                }
+        for (int j = 0; j < 2 && ok; ++j) {
+            const int sj = sel_len(a, j);
+            if (sj <= 0) continue;
+            int64_t start; int step;
+            read_geom(a, sc, pd, j, &start, &step);
+            if (!attempt_surely_accepted((pd.hap ? a.summ[1] : a.summ[0]) + sc.start / SUMM_CELLS, sc.l, start, step, sj)) {     // rare: N, dense indels, contig ends
+                const ReadRes r = gen_read<false>(sel_hap(a, sc, pd.hap), sc.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
             }
         }
-        if (LPP == 2) { const int other = __shfl_xor((int)ok, 1); ok = ok && (other != 0); }   // every lane shuffles (no short-circuit)
-        if (!done) {
-            if (ok) done = true;
-            else if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; done = true; }
-        }
+        if (ok) done = true;
+        else if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; done = true; }
     }
     uint32_t total;
-    (void)block_excl_scan((is_rand && j == 0) ? 1u : 0u, sm, &total);
+    (void)block_excl_scan(is_rand ? 1u : 0u, sm, &total);
     if (threadIdx.x == 0) a.block_rand[blockIdx.x] = total;
-    const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u);
+    const uint32_t retries = wave_sum_u32(valid ? att : 0u);
     if (lane_id() == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries);
     if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
 }
@@ -642,6 +637,17 @@ __global__ void __launch_bounds__(256) k_selftest_fp64(uint32_t seed, uint64_t n
             bad_div += dbl_bits(f / (2.0 + f)) != dbl_bits(div_mid(f, 2.0 + f));
             done += 4;
         }
+        {   // the placement's insert-size normal (draw_pair): radii with full 53-bit operands
+            const double p1 = 2.0 * u53(c.x, c.y) - 1.0, p2 = 2.0 * u53(c.z, c.w) - 1.0, pr = p1 * p1 + p2 * p2;
+            if (pr < 1.0 && pr >= 0x1p-60) {
+                const double l1 = det_log(pr), l2 = det_log<true>(pr);
+                bad_log += dbl_bits(l1) != dbl_bits(l2);
+                const double q1 = (-2.0 * l1) / pr;
+                bad_div += dbl_bits(q1) != dbl_bits(div_mid(-2.0 * l1, pr));
+                bad_sqrt += dbl_bits(sqrt(q1)) != dbl_bits(sqrt_mid(q1));
+                done += 3;
+            }
+        }
         const double x = ldexp(1.0 + u53(c.x, c.y), (int)(b.z % 141u) - 70), y = ldexp(1.0 + u53(c.z, c.w), (int)(b.w % 141u) - 70);
         bad_div += dbl_bits(x / y) != dbl_bits(div_mid(x, y));
         bad_sqrt += dbl_bits(sqrt(x)) != dbl_bits(sqrt_mid(x));
@@ -856,8 +862,7 @@ void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t 
 }
 void launch_place(hipStream_t st, const SimArgs &a)      // a.segs / a.n_blocks laid out for PAIRS_PER_BLOCK pairs per block
 {
-    if (a.p.len[1] > 0) hipLaunchKernelGGL(k_place<2>, dim3(a.n_blocks), dim3(PAIRS_PER_BLOCK * 2), 0, st, a);
-    else hipLaunchKernelGGL(k_place<1>, dim3(a.n_blocks), dim3(PAIRS_PER_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_place, dim3(a.n_blocks), dim3(PAIRS_PER_BLOCK), 0, st, a);
 }
 // one launcher per (LPP, DT) family, each defined in its own part
 void launch_sim_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
