@@ -67,7 +67,7 @@ EXPORTS = [
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
-    "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
+    "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_mutate_poll", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
     "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig",
     "dwgsim_hip_job_finish", "dwgsim_hip_job_last_error", "dwgsim_hip_job_destroy",
     "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
@@ -102,6 +102,7 @@ def load(path: str | None = None):
     lib.dwgsim_hip_group_layout.argtypes = [P(C.c_int64), C.c_int, P(C.c_int64)]
     lib.dwgsim_hip_mutate_async.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_mutate_wait.argtypes = [C.c_void_p, C.c_int]
+    lib.dwgsim_hip_mutate_poll.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_count_random_ranges.argtypes = [C.c_void_p, P(Range), C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.dwgsim_hip_simulate_ranges_async.argtypes = [C.c_void_p, P(Range), C.c_int, C.c_uint64, C.c_int]
     lib.dwgsim_hip_device_count.argtypes = []

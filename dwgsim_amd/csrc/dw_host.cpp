@@ -918,6 +918,18 @@ int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *c, int contig)
     }
 }
 
+int dwgsim_hip_mutate_poll(dwgsim_hip_ctx_t *c, int contig)
+{
+    Group *gp = get_group(c, contig);
+    if (!gp) return DWGSIM_HIP_ERR_ARG;
+    if (!gp->walk_pending) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    const hipError_t e = hipEventQuery(gp->ev_walk);
+    if (e == hipSuccess) return 1;
+    (void)hipGetLastError();
+    return e == hipErrorNotReady ? 0 : (c->err = "mutate_poll: device error", DWGSIM_HIP_ERR_DEVICE);
+}
+
 int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
 {
     const int rc = dwgsim_hip_mutate_async(c, contig);

@@ -113,6 +113,7 @@ std::shared_ptr<GroupJob> group_by_id(dwgsim_hip_job *j, int id)      // j->m he
 struct Worker {
     dwgsim_hip_job *j; int d; dwgsim_hip_ctx_t *x;
     std::shared_ptr<GroupJob> prepped; int prepped_handle = -1;      // the group whose upload + walk is already enqueued
+    bool prepped_waited = false, prepped_counted = false;           // ... whose walk has been waited for / whose random reads this device has counted already
     bool first_batch_of_job = true;
 
     bool ok() const { return !j->failed.load(); }
@@ -129,6 +130,45 @@ struct Worker {
             for (int k = 0; k < n; ++k) if (dwgsim_hip_contig_set_placement_length(x, h + k, g->l_eff[(size_t)k]) < 0) { fail_ctx(); return -1; }
         if (dwgsim_hip_mutate_async(x, h) < 0) { fail_ctx(); return -1; }
         return h;
+    }
+
+    // the walk has finished: the staging is no longer needed by this device
+    bool walked(const std::shared_ptr<GroupJob> &g, int h)
+    {
+        if (dwgsim_hip_mutate_wait(x, h) < 0) { fail_ctx(); return false; }
+        std::lock_guard<std::mutex> lk(j->m);
+        if (--g->stage_users == 0) { j->stage_busy[g->stage_slot] = false; j->cv.notify_all(); }
+        return true;
+    }
+
+    // random reads of my batches of the group, counted without producing them (k_place on the walk stream): one launch, one count per batch
+    bool count_mine(const std::shared_ptr<GroupJob> &g, int h)
+    {
+        if (d < g->nd) {
+            std::vector<dwgsim_hip_range_t> all; std::vector<int> owner;
+            for (int b = d; b < (int)g->batches.size(); b += g->nd) for (auto q : g->batches[(size_t)b]) { q.contig += h; all.push_back(q); owner.push_back(b); }
+            std::vector<uint64_t> per(all.size(), 0); uint64_t tot = 0;
+            if (!all.empty() && dwgsim_hip_count_random_ranges(x, all.data(), (int)all.size(), &tot, per.data()) < 0) { fail_ctx(); return false; }
+            std::lock_guard<std::mutex> lk(j->m);
+            for (size_t q = 0; q < all.size(); ++q) g->batch_rand[(size_t)owner[q]] += per[q];
+            ++g->counted;
+            j->cv.notify_all();
+        }
+        return true;
+    }
+
+    // between two batches: whatever can be done for the NEXT group without waiting -- upload + walk as soon as it has been handed over, the count
+    // of its random reads as soon as its walk has finished -- so that its first batch follows this group's last one at once
+    bool look_ahead(const std::shared_ptr<GroupJob> &g)
+    {
+        if (!prepped) {
+            std::shared_ptr<GroupJob> nx;
+            { std::lock_guard<std::mutex> lk(j->m); nx = group_by_id(j, g->id + 1); }
+            if (nx && takes_part(*nx)) { const int nh = prep(nx); if (nh < 0) return false; prepped = nx; prepped_handle = nh; prepped_waited = prepped_counted = false; }
+        }
+        if (prepped && !prepped_waited && dwgsim_hip_mutate_poll(x, prepped_handle) == 1) { if (!walked(prepped, prepped_handle)) return false; prepped_waited = true; }
+        if (prepped && prepped_waited && !prepped_counted && j->ND > 1 && j->want_reads) { if (!count_mine(prepped, prepped_handle)) return false; prepped_counted = true; }
+        return true;
     }
 
     PinBuf *acquire(const uint64_t need[3])
@@ -166,7 +206,7 @@ struct Worker {
             }
             if (!process(g)) break;
         }
-        if (prepped) { (void)dwgsim_hip_mutate_wait(x, prepped_handle); prepped.reset(); }
+        if (prepped) { if (!prepped_waited) (void)dwgsim_hip_mutate_wait(x, prepped_handle); prepped.reset(); }
     }
 
     bool takes_part(const GroupJob &g) const { return d == 0 || (j->want_reads && d < g.nd); }      // device 0 also writes the mutation text
@@ -179,14 +219,10 @@ struct Worker {
             j->cv.notify_all();
             return true;
         }
-        int h;
-        if (prepped && prepped->id == g->id) { h = prepped_handle; prepped.reset(); }
+        int h; bool waited = false, counted = false;
+        if (prepped && prepped->id == g->id) { h = prepped_handle; waited = prepped_waited; counted = prepped_counted; prepped.reset(); }
         else if ((h = prep(g)) < 0) return false;
-        if (dwgsim_hip_mutate_wait(x, h) < 0) { fail_ctx(); return false; }
-        {   // the upload has finished: this device is done with the staging
-            std::lock_guard<std::mutex> lk(j->m);
-            if (--g->stage_users == 0) { j->stage_busy[g->stage_slot] = false; j->cv.notify_all(); }
-        }
+        if (!waited && !walked(g, h)) return false;
         if (d == 0 && j->want_mut && j->sink.mutations) {      // mut_print (mut.c:781-893), contigs in order
             for (size_t k = 0; k < g->names.size() && ok(); ++k) {
                 const char *t, *v; size_t tl, vl;
@@ -199,17 +235,8 @@ struct Worker {
         if (j->want_reads && d < g->nd) for (int b = d; b < nb; b += g->nd) mine.push_back(b);
         auto ranges_of = [&](int b) { std::vector<dwgsim_hip_range_t> r = g->batches[(size_t)b]; for (auto &q : r) q.contig += h; return r; };
         if (j->ND > 1 && j->want_reads) {
-            // random reads of my batches, counted without producing them (k_place): one launch, one count per batch
-            if (!mine.empty()) {
-                std::vector<dwgsim_hip_range_t> all; std::vector<int> owner;
-                for (int b : mine) for (const auto &q : ranges_of(b)) { all.push_back(q); owner.push_back(b); }
-                std::vector<uint64_t> per(all.size(), 0); uint64_t tot = 0;
-                if (dwgsim_hip_count_random_ranges(x, all.data(), (int)all.size(), &tot, per.data()) < 0) { fail_ctx(); return false; }
-                std::lock_guard<std::mutex> lk(j->m);
-                for (size_t q = 0; q < all.size(); ++q) g->batch_rand[(size_t)owner[q]] += per[q];
-            }
+            if (!counted && !count_mine(g, h)) return false;
             std::unique_lock<std::mutex> lk(j->m);
-            if (d < g->nd) { ++g->counted; j->cv.notify_all(); }
             j->cv.wait(lk, [&]() { return j->failed.load() || (g->counted >= g->nd && g->base_known); });
             if (j->failed.load()) return false;
             if (g->counted == g->nd) {      // (every device computes the same thing; the first one publishes it for the next group)
@@ -221,11 +248,7 @@ struct Worker {
             }
         }
         // the next group, if it is already here, is uploaded and walked on the walk stream while this one's batches run
-        if (!prepped) {
-            std::shared_ptr<GroupJob> nx;
-            { std::lock_guard<std::mutex> lk(j->m); nx = group_by_id(j, g->id + 1); }
-            if (nx && takes_part(*nx)) { const int nh = prep(nx); if (nh < 0) return false; prepped = nx; prepped_handle = nh; }
-        }
+        if (!look_ahead(g)) return false;
         // batches: two in flight; batch k-1 is copied out while batch k runs
         struct Pending { bool live = false; int slot = 0, b = 0; } prev;
         auto finish_batch = [&](Pending &pb) -> bool {
@@ -269,6 +292,7 @@ struct Worker {
             if (!finish_batch(prev)) { prev.live = true; prev.slot = slot; prev.b = b; break; }
             prev.live = true; prev.slot = slot; prev.b = b;
             ++kk;
+            if (!look_ahead(g)) break;
         }
         if (ok()) { if (!finish_batch(prev)) return false; }
         else if (prev.live) { dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, prev.slot, &bt); }

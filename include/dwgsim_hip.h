@@ -163,6 +163,8 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *ctx, int contig);
  * contig of the group; the whole group is walked. */
 int dwgsim_hip_mutate_async(dwgsim_hip_ctx_t *ctx, int contig);
 int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *ctx, int contig);
+/* 1: the enqueued walk has finished on the device (mutate_wait will not block; a capacity re-run, rare, may still follow inside it), 0: not yet */
+int dwgsim_hip_mutate_poll(dwgsim_hip_ctx_t *ctx, int contig);
 
 /* Replaces mut_print() (mut.c:781-893): the mutations.txt and mutations.vcf BODY lines of this
  * contig.  Buffers are owned by the context and valid until the next call for any contig. */

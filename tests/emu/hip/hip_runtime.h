@@ -134,6 +134,8 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
+#define hipErrorNotReady 600
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
