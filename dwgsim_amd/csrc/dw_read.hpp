@@ -338,21 +338,49 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
     // leaves this loop; 2^14 errors in one flow already overflow every buffer, so the caller reports the read as outgrown.
     DW_DEV int more_errors(uint64_t thr) { int n = 1; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
 };
-// Sequential reader of a lane's hit bitmap (word w at base[w * stride]): up to 31 bits (k <= 31: the mask is built with a 32-bit shift) at a
-// non-decreasing bit position; callers with more flows to look at (a flow order may keep a base away for up to 63 flows) take them in pieces
-struct BitWindow {
-    const uint32_t *base; int stride, cw, nw; uint32_t lo, hi;
-    DW_DEV void init(const uint32_t *b, int st, int nwords) { base = b; stride = st; nw = nwords; cw = 0; lo = nw > 0 ? base[0] : 0u; hi = nw > 1 ? base[stride] : 0u; }
-    DW_DEV uint32_t peek(uint32_t g, uint32_t k)
+// A lane's packed array with word-wide access (word w at base[w * stride], nw words; indices outside read as zero):
+// get8(p): the eight 4-bit codes at nibble positions p .. p + 7 (p may be negative), get8x2(p): eight 2-bit bases at positions p .. p + 7
+struct WordView {
+    const uint32_t *base; int stride, nw;
+    DW_DEV uint32_t word(int w) const { return (w >= 0 && w < nw) ? base[(size_t)w * stride] : 0u; }
+    DW_DEV uint32_t get8(int p) const { const int w = p >> 3; return __builtin_amdgcn_alignbit(word(w + 1), word(w), ((uint32_t)p & 7u) * 4u); }
+    DW_DEV uint32_t get8x2(int p) const { const int w = p >> 4; return __builtin_amdgcn_alignbit(word(w + 1), word(w), ((uint32_t)p & 15u) * 2u) & 0xFFFFu; }
+};
+// Appends BITS-bit elements, one or up to 32 / BITS at a time (v: cnt elements, nothing above them), a word is stored whenever one is full
+template <int BITS>
+struct BitAppender {
+    uint32_t *base; int stride, n, wi; uint32_t fill; uint64_t acc;
+    DW_DEV void init(uint32_t *b, int st) { base = b; stride = st; n = 0; wi = 0; fill = 0; acc = 0; }
+    DW_DEV void push_many(uint32_t v, int cnt)
     {
-        const int w = (int)(g >> 5);
-        while (cw < w) { ++cw; lo = hi; hi = (cw + 1 < nw) ? base[(size_t)(cw + 1) * stride] : 0u; }
-        return __builtin_amdgcn_alignbit(hi, lo, g & 31u) & ((1u << k) - 1u);
+        acc |= (uint64_t)v << fill; fill += (uint32_t)cnt * BITS; n += cnt;
+        if (fill >= 32u) { base[(size_t)wi * stride] = (uint32_t)acc; ++wi; acc >>= 32; fill -= 32u; }
+    }
+    DW_DEV void push(uint32_t v) { push_many(v, 1); }
+    DW_DEV void flush() { if (fill) base[(size_t)wi * stride] = (uint32_t)acc; }
+};
+// A lane's bitmap of scoring first draws (word w at base[w * stride], nbits a multiple of 32): the first set bit at or after p, nbits if none
+struct HitMap {
+    const uint32_t *base; int stride; uint32_t nbits;
+    DW_DEV uint32_t next(uint32_t p) const
+    {
+        while (p < nbits) {
+            const uint32_t w = base[(size_t)(p >> 5) * stride] >> (p & 31u);
+            if (w) return p + (uint32_t)__ffs((int)w) - 1u;
+            p = (p | 31u) + 1u;
+        }
+        return nbits;
     }
 };
-// Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.  The final read is left in
-// bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is read
-// (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: FLOW_STACK_RUNS (base, count) runs, two per word.
+DW_DEV uint32_t nibbles_reversed(uint32_t v) { v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); return __builtin_bswap32(v); }
+DW_DEV uint32_t nibbles_to_pairs(uint32_t v)      // eight nibbles holding 0 .. 3 -> sixteen bits
+{
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; return (v | (v >> 8)) & 0xFFFFu;
+}
+DW_DEV uint32_t pairs_to_nibbles(uint32_t v)      // sixteen bits -> eight nibbles holding 0 .. 3
+{
+    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; return (v | (v << 2)) & 0x33333333u;
+}
 // dist[4 * f + b]: flows from flow f (inclusive) to the first flow of base b, 0 .. F-1 (filled by fill_flow_dist, every base occurs in the order)
 DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, int nthr)
 {
@@ -363,99 +391,145 @@ DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, i
         dist[q] = (uint8_t)k;
     }
 }
-// Pass 1 of generate_errors_flows (dwgsim.c:253-364) for one lane: bufA (len bases) -> bufB (2 bits per base).  Returns the new length or
-// -1; leaves the flow mask, the flow position and the number of erroneous bases for pass 2.
-// The reference's flow mask (dwgsim.c:283-333) never has more than one bit set: a deletion marks the flow the pointer stands on, and the mark is
-// cleared as soon as the pointer moves (the range of skipped flows starts at the pointer) or a new homopolymer starts on that flow.  So the
-// mask is one flag -- "the flow under the pointer is marked" -- and what pass 2 sees is that flag together with the final pointer.
-DW_DEV int flow_pass1(FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, int stride,
-                      int len, int strand, int cap, bool &marked, int &flow_i, int &total)
+// a batch of parked lanes runs once eight have gathered, or as many as are still running (measured on pass 2: 1 / 2 / 4 / 8 / 16 / 24 / 32 lanes ->
+// 5.66 / 5.36 / 5.17 / 5.06 / 5.15 / 5.37 / 5.55 ms for 848 k reads of 400 bp at e = 0.01; waiting for the last runners alone costs 5 %)
+DW_DEV bool flow_batch_due(bool parked, bool running)
 {
-    // input = bufA (len bases, read back-to-front when strand == 1, N -> A: dwgsim.c:253-265), pass 1 -> bufB, pass 2 -> bufA
-    PackReader<4> rd, la; rd.init(bufA, stride); la.init(bufA, stride);
-    auto in = [&](PackReader<4> &r, int t) -> uint32_t { const uint32_t v = r.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
-    { const uint32_t c0 = in(rd, 0); while (flow_i < F && c0 != flow[flow_i]) ++flow_i; if (flow_i == F) return -1; }
-    // ---- pass 1 (dwgsim.c:281-364): one error event per homopolymer start ----
-    PackAppender<2> o1; o1.init(bufB, stride);
-    int t = 0; uint32_t prev_c = 4, pend_c = 0, hits8 = 0; int pend_n = 0;
-    for (;;) {
-        uint32_t c; bool from_pend = false;
-        if (pend_n > 0) { c = pend_c; from_pend = true; } else if (t < len) c = in(rd, t); else break;
-        if (o1.n >= cap) return -1;
-        // every iteration appends exactly one base, so o1.n is the reference's loop index i (dwgsim.c:281) and the same in every lane of the
-        // wave: the first draws of positions 8 m .. 8 m + 7 come from one block, generated by all lanes together.  (The event code below runs
-        // for whichever lanes score in this iteration -- some lane in four iterations out of ten at e = 0.01; collecting the scoring lanes
-        // into batches as pass 2 does was measured and loses: the event is too short to pay for the waiting.)
-        if ((o1.n & 7) == 0) hits8 = flow_hits8(RngKey{rg.seed, rg.contig}, rg.dom, rg.ii, rg.att, (uint32_t)o1.n >> 3, thr);
-        {   // skip the flows in front of this base (dwgsim.c:285-288), clearing their mask bits: a cyclic range [flow_i, flow_i + k)
-            const int k = dist[4 * flow_i + (int)c];
-            if (k) { marked = false; flow_i += k; if (flow_i >= F) flow_i -= F; }
-        }
-        if (prev_c != c) {
-            marked = false;
-            if ((hits8 >> (o1.n & 7)) & 1u) {
-                rg.open((uint32_t)o1.n);
-                int n_err = rg.more_errors(thr);
-                if (n_err >= (1 << 14)) return -1;
-                if (rg.next() < 0x80000000u) {                  // insert n_err copies in front of the homopolymer
-                    o1.push(c); pend_c = c; pend_n = n_err - 1;
-                    total += n_err; prev_c = c;
-                    continue;
-                }
-                int hp_l = 0; uint32_t next_c = c;              // delete: bounded by the homopolymer length
-                while (t + hp_l < len) { next_c = in(la, t + hp_l); if (next_c != c) break; ++hp_l; }
-                if (n_err > hp_l) n_err = hp_l;
-                t += n_err; marked = true; total += n_err;
-                if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
-                    if (next_c == c) return -1;                // the whole read was one deleted homopolymer (the reference asserts)
-                    int jj = 0; while (next_c != flow[(flow_i + jj) % F]) ++jj;
-                    const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
-                    o1.push(flow[(flow_i + kk) % F]);
-                } else if (t < len) { o1.push(in(rd, t)); ++t; }   // the base now at this position is not examined
-                prev_c = c;
-                continue;
-            }
-            prev_c = c;
-        }
-        o1.push(c);
-        if (from_pend) --pend_n; else ++t;
-    }
-    o1.flush();
-    return o1.n;
+    const uint64_t p = __ballot(parked), r = __ballot(running);
+    return p && (__popcll(p) >= 8 || __popcll(p) >= __popcll(r));
 }
-// Every lane of the wave must call this (pass 2 regroups lanes with wave ballots); lanes without a read pass active = false.
-// bm: this lane's hit bitmap of pass 2 (flow_hit_bits(cap) bits, word w at bm[w * stride]), filled here.
+// generate_errors_flows (dwgsim.c:246-417).  Every lane of the wave must call this (both passes regroup the lanes of a wave with ballots);
+// lanes without a read pass active = false.  Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.
+// The final read is left in bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is
+// read (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: FLOW_STACK_RUNS (base, count) runs, two per word; bm: this lane's
+// bitmap of scoring first draws (flow_hit_bits(cap) bits), of pass 1 first and then of pass 2.
+//
+// Both passes are sequential per read and almost always quiet: the first draw of a position (pass 1) or of an empty flow (pass 2) scores with
+// probability e.  All first draws are made up front, in step, as a bitmap; a lane then knows where its next scoring draw is and moves EIGHT
+// bases per iteration up to it -- one word of the packed read, the flow pointer's chain of eight table look-ups, one append -- and only a lane
+// standing on a scoring draw runs the event code.  With 64 lanes some lane scores in almost every iteration, and the event code (a Philox
+// block of its own, homopolymer scans, the run stack) is long: such lanes park, the others run on, and the events are handled for a batch
+// of parked lanes at once.  Each lane still performs exactly its own sequence of operations; only their interleaving changes.
 DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *bm, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
-    int n1 = 0, total = 0, flow_i = 0; bool marked = false; bool failed = !active;
-    // the first draws of the first G0 empty flows of pass 2 as a bitmap: 32 flows per word, four Philox blocks each, every lane in step
-    const int G0 = flow_hit_bits(cap), nbw = G0 >> 5;
-    const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
-    if (active)
-        for (int w = 0; w < nbw; ++w) {
-            uint32_t bits = 0;
+    int total = 0, flow_i = 0; bool marked = false; bool failed = !active;
+    const int G0 = flow_hit_bits(cap);
+    auto draw_bitmap = [&](uint32_t dom, int nwords) {         // 32 first draws per word, four Philox blocks each, every lane in step
+        if (active)
+            for (int w = 0; w < nwords; ++w) {
+                uint32_t bits = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, 4u * (uint32_t)w + q, thr) << (8 * q);
-            bm[(size_t)w * stride] = bits;
+                for (uint32_t q = 0; q < 4; ++q) { if (DW_KNOCK & 256) break; bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom, rg.ii, rg.att, 4u * (uint32_t)w + q, thr) << (8 * q); }
+                if (DW_KNOCK & 4096) { asm volatile("" :: "v"(bits)); bits = 0; }     // (analysis builds: 256 no draws, 4096 drawn but nothing scores)
+                bm[(size_t)w * stride] = bits;
+            }
+    };
+    auto step_flow = [&](uint32_t k) { flow_i += (int)k; if (flow_i >= F) flow_i -= F; };
+
+    // ---- pass 1 (dwgsim.c:253-364): one error event per homopolymer start whose first draw scores.  Input = bufA (len bases, read
+    // back-to-front when strand == 1, N -> A: dwgsim.c:253-265), output -> bufB.  The output index is the reference's loop index i
+    // (dwgsim.c:281): position i's first draw is bit i of the bitmap. ----
+    // The reference's flow mask (dwgsim.c:283-333) never has more than one bit set: a deletion marks the flow the pointer stands on, and the
+    // mark is cleared as soon as the pointer moves (the range of skipped flows starts at the pointer) or a new homopolymer starts on that flow --
+    // and the pointer stands on the previous base's flow, so both mean "this base differs from the one before".  So the mask is one flag, and
+    // what pass 2 sees is that flag together with the final pointer.
+    const int nb1 = (cap + 31) >> 5;
+    draw_bitmap(rg.dom, nb1);
+    const WordView inA{bufA, stride, (cap + 7) >> 3};
+    PackReader<4> la; la.init(bufA, stride);
+    auto in1 = [&](int t) -> uint32_t { const uint32_t v = la.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
+    auto in8 = [&](int t) -> uint32_t {                       // bases t .. t + 7 of the input as nibbles, N -> A
+        uint32_t v = strand ? nibbles_reversed(inA.get8(len - 8 - t)) : inA.get8(t);
+        return v & 0x33333333u & ~(((v >> 2) & 0x11111111u) * 3u);
+    };
+    const HitMap hm1{bm, stride, (uint32_t)nb1 << 5};
+    BitAppender<2> o1; o1.init(bufB, stride);
+    int t = 0; uint32_t prev_c = 4, nh = 0;
+    if (active) {
+        const uint32_t c0 = in1(0);
+        while (flow_i < F && c0 != flow[flow_i]) ++flow_i;
+        if (flow_i == F) failed = true; else nh = hm1.next(0);
+    }
+    {
+        bool done = failed, parked = false;
+        for (;;) {
+            if (!done && !parked) {
+                if (t >= len) done = true;
+                else if (o1.n >= cap) { failed = true; done = true; }
+                else {
+                    const uint32_t v = in8(t);
+                    int n = len - t < 8 ? len - t : 8;
+                    if (cap - o1.n < n) n = cap - o1.n;
+                    if ((int)(nh - (uint32_t)o1.n) < n) n = (int)(nh - (uint32_t)o1.n);
+                    uint32_t pc = prev_c; bool differs = false;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t c = (v >> (4 * i)) & 3u;
+                        if (i < n) { step_flow(dist[4 * flow_i + (int)c]); differs = differs || c != pc; pc = c; }
+                    }
+                    if (differs) marked = false;
+                    o1.push_many(nibbles_to_pairs(v) & ((1u << (2 * n)) - 1u), n);
+                    t += n; prev_c = pc;
+                    if (n < 8 && (uint32_t)o1.n == nh && t < len && o1.n < cap) {       // standing on a position whose first draw scored
+                        if (((v >> (4 * n)) & 3u) != prev_c) parked = true;            // a homopolymer starts here: the event happens
+                        else nh = hm1.next(nh + 1u);
+                    }
+                }
+            }
+            if (flow_batch_due(parked, !done && !parked)) {
+                if (parked) {
+                    const uint32_t c = in1(t);
+                    step_flow(dist[4 * flow_i + (int)c]); marked = false;
+                    rg.open((uint32_t)o1.n);
+                    int n_err = rg.more_errors(thr);
+                    if (n_err >= (1 << 14)) failed = true;
+                    else if (rg.next() < 0x80000000u) {              // insert n_err copies in front of the homopolymer (whose own bases follow unexamined: prev_c == c)
+                        if (o1.n + n_err > cap) failed = true;       // (the reference runs out of room at the latest when it reaches the homopolymer itself)
+                        else { for (int q = 0; q < n_err; ++q) o1.push(c); total += n_err; prev_c = c; }
+                    }
+                    else {                                          // delete: bounded by the homopolymer length
+                        int hp_l = 0; uint32_t next_c = c;
+                        while (t + hp_l < len) { next_c = in1(t + hp_l); if (next_c != c) break; ++hp_l; }
+                        if (n_err > hp_l) n_err = hp_l;
+                        t += n_err; marked = true; total += n_err;
+                        if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
+                            if (next_c == c) failed = true;         // the whole read was one deleted homopolymer (the reference asserts)
+                            else {
+                                const int jj = dist[4 * flow_i + (int)next_c];
+                                const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
+                                int f = flow_i + kk; if (f >= F) f -= F;
+                                o1.push(flow[f]);
+                            }
+                        } else if (t < len) { o1.push(in1(t)); ++t; }   // the base now at this position is not examined
+                        prev_c = c;
+                    }
+                    if (failed) done = true; else nh = hm1.next((uint32_t)o1.n);
+                    parked = false;
+                }
+            }
+            if (__ballot(!done) == 0) break;
         }
-    if (active) n1 = flow_pass1(rg, flow, dist, F, thr, bufA, bufB, stride, len, strand, cap, marked, flow_i, total);
-    if (n1 < 0) failed = true;
+    }
+    o1.flush();
+    const int n1 = o1.n;
+    if (DW_KNOCK & 1024) { *n_err_out += total; return failed ? -1 : n1; }
     const int marked_flow = marked ? flow_i : -1;      // the one flow of the (persistent) mask that pass 2 finds set
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
-    // g counts the empty flows examined so far: flow g's first draw is bit g of the bitmap, so "nothing happens in the k empty flows in
-    // front of this base" is one bit-field test.  With e = 0.01 some lane of a wave has a scoring flow at almost every position, so the
-    // lanes are regrouped: a lane whose examined base has a scoring flow parks, the others run on through quiet positions, and the
-    // scoring flows are handled for a batch of parked lanes (each lane still performs exactly its own sequence of operations, only
-    // their interleaving changes); there the quiet flows between two scoring ones are skipped with a find-first-set. ----
-    PackReader<2> r2; r2.init(bufB, stride);
-    PackAppender<4> o2; o2.init(bufA, stride);
-    BitWindow bw; bw.init(bm, stride, active ? nbw : 0);
+    // g counts the empty flows examined so far: flow g's first draw is bit g of the bitmap (flows beyond the bitmap -- long cascades -- are
+    // drawn one by one), nh is the next scoring flow: a base whose empty flows end at or before nh is quiet.  Lanes with an empty stack
+    // move up to eight quiet bases per iteration, lanes with pending runs one; a base with a scoring flow in front of it parks. ----
+    const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
+    draw_bitmap(dom2, G0 >> 5);
+    const HitMap hm2{bm, stride, (uint32_t)G0};
+    const WordView inB{bufB, stride, (cap + 15) >> 4};
+    BitAppender<4> o2; o2.init(bufA, stride);
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
     auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
-    auto settle = [&](uint32_t x, int &t2, int &sp) {      // the position's final base: the examined base, or the first base of the top run
+    int t2 = 0, sp = 0;
+    auto settle = [&](uint32_t x) {                        // the position's final base: the examined base, or the first base of the top run
         if (sp == 0) { o2.push(x); ++t2; }
         else {
             const uint32_t top = stk_get(sp - 1);
@@ -463,57 +537,65 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
             if ((top & 0x3fffu) <= 1) --sp; else stk_set(sp - 1, top - 1);
         }
     };
-    int t2 = 0, sp = 0;
     rg.dom = dom2;
-    bool done = failed, parked = false; uint32_t g = 0, x = 0;
-    for (;;) {
-        if (!done && !parked) {
-            if (sp > 0) x = stk_get(sp - 1) >> 14; else if (t2 < n1) x = r2.get(t2); else done = true;
-            if (!done && o2.n >= cap) { failed = true; done = true; }
-            if (!done) {
-                const uint32_t k_empty = dist[4 * flow_i + (int)x];
-                // (more than 31 empty flows in front of a base -- only flow orders with such gaps have them -- go through the parked path, which takes them in pieces)
-                if (k_empty <= 31u && g + k_empty <= (uint32_t)G0 && bw.peek(g, k_empty) == 0) { flow_i += (int)k_empty; if (flow_i >= F) flow_i -= F; g += k_empty; settle(x, t2, sp); }
-                else parked = true;
-            }
-        }
-        const uint64_t parked_lanes = __ballot(parked), running_lanes = __ballot(!done && !parked);
-        // a batch of parked lanes runs once eight have gathered, or as many as are still running (measured: 1 / 2 / 4 / 8 / 16 / 24 / 32 lanes ->
-        // 5.66 / 5.36 / 5.17 / 5.06 / 5.15 / 5.37 / 5.55 ms for 848 k reads of 400 bp at e = 0.01; waiting for the last runners alone costs 5 %)
-        if (parked_lanes && (__popcll(parked_lanes) >= 8 || __popcll(parked_lanes) >= __popcll(running_lanes))) {
-            if (parked) {
-                uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
-                while (!failed && left > 0) {
-                    uint32_t skip;                              // quiet flows before the next scoring one
-                    bool quiet_piece = false;                   // the piece looked at (at most 31 flows) held no scoring flow and is not the last one
-                    if (g + left <= (uint32_t)G0) {
-                        const uint32_t piece = left < 31u ? left : 31u;
-                        const uint32_t bits = bw.peek(g, piece);
-                        skip = bits ? (uint32_t)__ffs((int)bits) - 1u : piece;
-                        quiet_piece = !bits && piece < left;
-                    }
-                    else {                                      // beyond the bitmap (a long cascade): flow by flow
-                        skip = 0;
-                        while (skip < left && !((flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, (g + skip) >> 3, thr) >> ((g + skip) & 7u)) & 1u)) ++skip;
-                    }
-                    flow_i += (int)skip; if (flow_i >= F) flow_i -= F;
-                    g += skip; left -= skip;
-                    if (left == 0) break;
-                    if (quiet_piece) continue;
-                    rg.open(g);                                 // flow g scores: while (drand48() < e) n_err++ goes on in its private stream
-                    const int n_err = rg.more_errors(thr);
-                    if (flow_i != marked_flow) {
-                        if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
-                        else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
-                    }
-                    flow_i = flow_i + 1 == F ? 0 : flow_i + 1;
-                    ++g; --left;
+    {
+        bool done = failed, parked = false; uint32_t g = 0, x = 0;
+        nh = done ? 0u : hm2.next(0);
+        for (;;) {
+            if (!done && !parked) {
+                if (sp == 0 && t2 >= n1) done = true;
+                else if (o2.n >= cap) { failed = true; done = true; }
+                else if (sp > 0) {                                  // runs pending: one base
+                    x = stk_get(sp - 1) >> 14;
+                    const uint32_t k = dist[4 * flow_i + (int)x];
+                    if (g + k <= nh) { step_flow(k); g += k; settle(x); } else parked = true;
                 }
-                if (failed) done = true; else settle(x, t2, sp);
-                parked = false;
+                else {
+                    const uint32_t v = inB.get8x2(t2);
+                    int n = n1 - t2 < 8 ? n1 - t2 : 8;
+                    if (cap - o2.n < n) n = cap - o2.n;
+                    int m = 0; bool quiet = true;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = dist[4 * flow_i + (int)((v >> (2 * i)) & 3u)];
+                        quiet = quiet && i < n && g + k <= nh;
+                        if (quiet) { step_flow(k); g += k; ++m; }
+                    }
+                    o2.push_many(pairs_to_nibbles(v) & (m == 8 ? 0xFFFFFFFFu : (1u << (4 * m)) - 1u), m);
+                    t2 += m;
+                    if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }
+                }
             }
+            if (flow_batch_due(parked, !done && !parked)) {
+                if (parked) {
+                    uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
+                    while (!failed && left > 0) {
+                        uint32_t skip; bool scores;                 // quiet flows before the next scoring one
+                        if (g < (uint32_t)G0) { const uint32_t q = nh - g; skip = q < left ? q : left; scores = q < left && nh < (uint32_t)G0; }
+                        else {                                      // beyond the bitmap (a long cascade): flow by flow
+                            skip = 0;
+                            while (skip < left && !((flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, (g + skip) >> 3, thr) >> ((g + skip) & 7u)) & 1u)) ++skip;
+                            scores = skip < left;
+                        }
+                        step_flow(skip);
+                        g += skip; left -= skip;
+                        if (!scores) continue;                      // (all of them looked at, or the bitmap ended: on beyond it)
+                        rg.open(g);                                 // flow g scores: while (drand48() < e) n_err++ goes on in its private stream
+                        const int n_err = rg.more_errors(thr);
+                        if (flow_i != marked_flow) {
+                            if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
+                            else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
+                        }
+                        step_flow(1);
+                        ++g; --left;
+                        if (g <= (uint32_t)G0) nh = hm2.next(g);
+                    }
+                    if (failed) done = true; else settle(x);
+                    parked = false;
+                }
+            }
+            if (__ballot(!done) == 0) break;
         }
-        if (__ballot(!done) == 0) break;
     }
     if (failed) return -1;
     o2.flush();
