@@ -353,6 +353,14 @@ static int flow_read_capacity(int len, double e, const std::vector<uint8_t> &flo
     return len + 64 + (int)(len * 4.0 * g);
 }
 
+// the largest entry of the kernels' flow-distance table: flows from a flow (inclusive) to the next flow of a base
+static int flow_max_gap(const std::vector<uint8_t> &flow)
+{
+    const int F = (int)flow.size(); int mx = 0;
+    for (int f = 0; f < F; ++f) for (uint8_t b = 0; b < 4; ++b) { int k = 0, g = f; while (flow[(size_t)g] != b && k < F) { ++k; g = g + 1 == F ? 0 : g + 1; } if (k > mx) mx = k; }
+    return mx;
+}
+
 static int set_err(int *err, int v) { if (err) *err = v; return v; }
 
 dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, int *err)
@@ -409,7 +417,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 CalibArgs ca;
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
-                ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
+                ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size(); ca.flow_maxk = flow_max_gap(c->flow);
                 ca.cap = flow_read_capacity(len, e, c->flow); ca.lds_words = (ca.cap + 7) / 8;
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
                 if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
@@ -1150,7 +1158,7 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
         a.cap = flow_read_capacity(lmax, emax, c->flow);
     }
     a.lds_words = (a.cap + 7) / 8;
-    a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
+    a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size(); a.flow_maxk = flow_max_gap(c->flow);
     a.flow_scratch = nullptr;
     return 0;
 }

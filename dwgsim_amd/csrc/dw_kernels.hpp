@@ -93,7 +93,7 @@ struct SimParams {
 struct CalibArgs {
     uint32_t seed; int32_t end, len; uint64_t n_reads;
     uint64_t thr;                   // ceil(e * 2^32) of the uncalibrated -e
-    const uint8_t *flow; int32_t flow_len, cap, lds_words;
+    const uint8_t *flow; int32_t flow_len, cap, lds_words, flow_maxk;
     uint32_t *scratch;              // per block [lds_words + (cap + 15) / 16][PAIRS_PER_BLOCK] words
     uint64_t *counters;             // [8] += errors, [9] += read lengths after errors, [2] |= 2 on a buffer overflow
 };
@@ -146,6 +146,7 @@ struct SimArgs {
     int32_t fifo;                 // 1: the records leave through the per-lane LDS FIFO (32-byte aligned bursts); 0: 16-byte pieces straight from registers (when the FIFO would cost a block per CU)
     int32_t sim_threads;          // lanes per k_simulate block chosen by the host: SIM_THREADS, or SIM_THREADS_LONG for long reads
     int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
+    int32_t flow_maxk;             // ... and the largest number of flows between a flow and the next flow of some base (flow_max_gap)
     uint32_t *flow_scratch;        // Ion Torrent: per-block read buffers in HBM, (lds_words + ceil(cap/16)) words per lane, word w of lane t at [w * nthr + t]
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes
 };

@@ -360,6 +360,7 @@ struct BitAppender {
     DW_DEV void flush() { if (fill) base[(size_t)wi * stride] = (uint32_t)acc; }
 };
 // A lane's bitmap of scoring first draws (word w at base[w * stride], nbits a multiple of 32): the first set bit at or after p, nbits if none
+// (nbits: how far the bitmap has been drawn so far; a search that runs into that frontier returns it, or p when p is already beyond it)
 struct HitMap {
     const uint32_t *base; int stride; uint32_t nbits;
     DW_DEV uint32_t next(uint32_t p) const
@@ -369,7 +370,7 @@ struct HitMap {
             if (w) return p + (uint32_t)__ffs((int)w) - 1u;
             p = (p | 31u) + 1u;
         }
-        return nbits;
+        return p > nbits ? p : nbits;
     }
 };
 DW_DEV uint32_t nibbles_reversed(uint32_t v) { v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); return __builtin_bswap32(v); }
@@ -405,25 +406,26 @@ DW_DEV bool flow_batch_due(bool parked, bool running)
 // bitmap of scoring first draws (flow_hit_bits(cap) bits), of pass 1 first and then of pass 2.
 //
 // Both passes are sequential per read and almost always quiet: the first draw of a position (pass 1) or of an empty flow (pass 2) scores with
-// probability e.  All first draws are made up front, in step, as a bitmap; a lane then knows where its next scoring draw is and moves EIGHT
+// probability e.  The first draws are made in step, as a bitmap, a word of 32 at a time just ahead of the lane that is furthest along
+// (a read needs about len of pass 1's and 1.6 len of pass 2's; the capacity they are sized for is twice that, and a Philox block per
+// eight draws is the largest single cost of the model); a lane then knows where its next scoring draw is and moves EIGHT
 // bases per iteration up to it -- one word of the packed read, the flow pointer's chain of eight table look-ups, one append -- and only a lane
 // standing on a scoring draw runs the event code.  With 64 lanes some lane scores in almost every iteration, and the event code (a Philox
 // block of its own, homopolymer scans, the run stack) is long: such lanes park, the others run on, and the events are handled for a batch
 // of parked lanes at once.  Each lane still performs exactly its own sequence of operations; only their interleaving changes.
-DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *bm, uint32_t *stk, int stride,
+DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, int maxk, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *bm, uint32_t *stk, int stride,
                        int len, int strand, int cap, int32_t *n_err_out)
 {
     int total = 0, flow_i = 0; bool marked = false; bool failed = !active;
     const int G0 = flow_hit_bits(cap);
-    auto draw_bitmap = [&](uint32_t dom, int nwords) {         // 32 first draws per word, four Philox blocks each, every lane in step
-        if (active)
-            for (int w = 0; w < nwords; ++w) {
-                uint32_t bits = 0;
+    auto draw_word = [&](uint32_t dom, uint32_t w) {           // 32 first draws, four Philox blocks, every lane in step
+        if (active) {
+            uint32_t bits = 0;
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) { if (DW_KNOCK & 256) break; bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom, rg.ii, rg.att, 4u * (uint32_t)w + q, thr) << (8 * q); }
-                if (DW_KNOCK & 4096) { asm volatile("" :: "v"(bits)); bits = 0; }     // (analysis builds: 256 no draws, 4096 drawn but nothing scores)
-                bm[(size_t)w * stride] = bits;
-            }
+            for (uint32_t q = 0; q < 4; ++q) { if (DW_KNOCK & 256) break; bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom, rg.ii, rg.att, 4u * w + q, thr) << (8 * q); }
+            if (DW_KNOCK & 4096) { asm volatile("" :: "v"(bits)); bits = 0; }     // (analysis builds: 256 no draws, 4096 drawn but nothing scores)
+            bm[(size_t)w * stride] = bits;
+        }
     };
     auto step_flow = [&](uint32_t k) { flow_i += (int)k; if (flow_i >= F) flow_i -= F; };
 
@@ -434,8 +436,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     // mark is cleared as soon as the pointer moves (the range of skipped flows starts at the pointer) or a new homopolymer starts on that flow --
     // and the pointer stands on the previous base's flow, so both mean "this base differs from the one before".  So the mask is one flag, and
     // what pass 2 sees is that flag together with the final pointer.
-    const int nb1 = (cap + 31) >> 5;
-    draw_bitmap(rg.dom, nb1);
+    const uint32_t D1_MAX = (uint32_t)((cap + 31) >> 5) << 5;
     const WordView inA{bufA, stride, (cap + 7) >> 3};
     PackReader<4> la; la.init(bufA, stride);
     auto in1 = [&](int t) -> uint32_t { const uint32_t v = la.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
@@ -443,17 +444,24 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
         uint32_t v = strand ? nibbles_reversed(inA.get8(len - 8 - t)) : inA.get8(t);
         return v & 0x33333333u & ~(((v >> 2) & 0x11111111u) * 3u);
     };
-    const HitMap hm1{bm, stride, (uint32_t)nb1 << 5};
+    HitMap hm1{bm, stride, 0u};
     BitAppender<2> o1; o1.init(bufB, stride);
     int t = 0; uint32_t prev_c = 4, nh = 0;
     if (active) {
         const uint32_t c0 = in1(0);
         while (flow_i < F && c0 != flow[flow_i]) ++flow_i;
-        if (flow_i == F) failed = true; else nh = hm1.next(0);
+        if (flow_i == F) failed = true;
     }
     {
         bool done = failed, parked = false;
         for (;;) {
+            // the bitmap stays ahead of every lane: a step looks at up to nine positions (an event that inserts more than that is waited for here)
+            while (__ballot(!done && hm1.nbits < D1_MAX && (uint32_t)o1.n + 16u > hm1.nbits)) {
+                const uint32_t old = hm1.nbits;
+                draw_word(rg.dom, old >> 5);
+                hm1.nbits = old + 32u;
+                if (!done && nh >= old) nh = hm1.next((uint32_t)o1.n > old ? (uint32_t)o1.n : old);
+            }
             if (!done && !parked) {
                 if (t >= len) done = true;
                 else if (o1.n >= cap) { failed = true; done = true; }
@@ -522,8 +530,8 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     // drawn one by one), nh is the next scoring flow: a base whose empty flows end at or before nh is quiet.  Lanes with an empty stack
     // move up to eight quiet bases per iteration, lanes with pending runs one; a base with a scoring flow in front of it parks. ----
     const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
-    draw_bitmap(dom2, G0 >> 5);
-    const HitMap hm2{bm, stride, (uint32_t)G0};
+    HitMap hm2{bm, stride, 0u};
+    const uint32_t margin2 = 8u * (uint32_t)maxk + 64u;      // a step moves g by at most eight bases' worth of flows
     const WordView inB{bufB, stride, (cap + 15) >> 4};
     BitAppender<4> o2; o2.init(bufA, stride);
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
@@ -540,8 +548,14 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     rg.dom = dom2;
     {
         bool done = failed, parked = false; uint32_t g = 0, x = 0;
-        nh = done ? 0u : hm2.next(0);
+        nh = 0;
         for (;;) {
+            while (__ballot(!done && hm2.nbits < (uint32_t)G0 && g + margin2 > hm2.nbits)) {
+                const uint32_t old = hm2.nbits;
+                draw_word(dom2, old >> 5);
+                hm2.nbits = old + 32u;
+                if (!done && nh >= old) nh = hm2.next(old);
+            }
             if (!done && !parked) {
                 if (sp == 0 && t2 >= n1) done = true;
                 else if (o2.n >= cap) { failed = true; done = true; }
@@ -571,7 +585,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
                     uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
                     while (!failed && left > 0) {
                         uint32_t skip; bool scores;                 // quiet flows before the next scoring one
-                        if (g < (uint32_t)G0) { const uint32_t q = nh - g; skip = q < left ? q : left; scores = q < left && nh < (uint32_t)G0; }
+                        if (g < (uint32_t)G0) { const uint32_t q = nh - g; skip = q < left ? q : left; scores = q < left && nh < hm2.nbits; }
                         else {                                      // beyond the bitmap (a long cascade): flow by flow
                             skip = 0;
                             while (skip < left && !((flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, (g + skip) >> 3, thr) >> ((g + skip) & 7u)) & 1u)) ++skip;

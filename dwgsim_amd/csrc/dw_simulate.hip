@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     if (DT == 2) {                              // dwgsim.c:861-864; every lane calls (the second pass regroups the lanes of a wave)
         const bool flows = valid && !is_rand && s > 0;
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(flows, rg, s_flow, s_dist, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr, dyn_lds + tid,
+        const int so = flow_errors(flows, rg, s_flow, s_dist, a.flow_len, a.flow_maxk, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr, dyn_lds + tid,
                                    nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
         if (flows) {
             s_out = so;
@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     }
     {   // every lane calls (the second pass regroups the lanes of a wave)
         FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(live, rg, s_flow, s_dist, a.flow_len, a.thr, buf, buf + (size_t)a.lds_words * nthr, buf + (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
+        const int so = flow_errors(live, rg, s_flow, s_dist, a.flow_len, a.flow_maxk, a.thr, buf, buf + (size_t)a.lds_words * nthr, buf + (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
         if (live) { s_out = so; if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; } }
     }
     const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);
