@@ -64,7 +64,7 @@ struct dwgsim_hip_job {
     std::vector<int> devices; std::vector<dwgsim_hip_ctx_t *> ctx;
     int ND = 0;
     bool want_mut = true, want_reads = true, gzip = true;
-    uint64_t batch_pairs = 1u << 20, group_bp = 32u << 20, min_share = 65536;
+    uint64_t batch_pairs = 1u << 18, group_bp = 32u << 20, min_share = 65536;      // (batches of 2^18 pairs: 190 MB of text, 94 MB of members -- measured against 2^17 .. 2^20: the smaller the batch, the shorter a job's fill and drain and the less page-locked memory there is to hand back; below 2^18 the whole-genome rate stops improving)
     // contig table, scheduling state (dwgsim.c:465-478, :519-625)
     std::vector<std::string> tab_names; std::vector<int64_t> tab_lens; bool have_table = false;
     uint64_t tot_len = 0; int n_ref = 0; int64_t n_sim = 0; int prev_skip = 0; uint32_t next_index = 0;
@@ -443,10 +443,20 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
     j->want_mut = p->output_type != 1; j->want_reads = p->output_type != 2;
     j->devices = devs; j->ND = (int)devs.size();
     j->ctx.assign((size_t)j->ND, nullptr);
-    for (int d = 0; d < j->ND; ++d) {
-        int e = 0;
-        j->ctx[(size_t)d] = dwgsim_hip_create(&j->prm, devs[(size_t)d], &e);
-        if (!j->ctx[(size_t)d]) { fprintf(stderr, "dwgsim-hip: cannot create a GPU context on device %d (error %d)\n", devs[(size_t)d], e); for (auto *x : j->ctx) if (x) dwgsim_hip_destroy(x); delete j; return bad(e ? e : DWGSIM_HIP_ERR_DEVICE); }
+    {   // one context per device, made side by side (a context costs about 0.1 s of runtime set-up, code objects and buffers)
+        std::vector<int> errs((size_t)j->ND, 0);
+        std::vector<std::thread> th;
+        for (int d = 1; d < j->ND; ++d) th.emplace_back([&, d]() { j->ctx[(size_t)d] = dwgsim_hip_create(&j->prm, devs[(size_t)d], &errs[(size_t)d]); });
+        j->ctx[0] = dwgsim_hip_create(&j->prm, devs[0], &errs[0]);
+        for (auto &t : th) t.join();
+        for (int d = 0; d < j->ND; ++d)
+            if (!j->ctx[(size_t)d]) {
+                const int e = errs[(size_t)d];
+                fprintf(stderr, "dwgsim-hip: cannot create a GPU context on device %d (error %d)\n", devs[(size_t)d], e);
+                for (auto *x : j->ctx) if (x) dwgsim_hip_destroy(x);
+                delete j;
+                return bad(e ? e : DWGSIM_HIP_ERR_DEVICE);
+            }
     }
     j->next_group.assign((size_t)j->ND, 0);
     j->bufs.resize((size_t)j->ND); j->free_bufs.resize((size_t)j->ND);

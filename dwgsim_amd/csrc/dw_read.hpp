@@ -394,10 +394,13 @@ DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, i
 }
 // a batch of parked lanes runs once eight have gathered, or as many as are still running (measured on pass 2: 1 / 2 / 4 / 8 / 16 / 24 / 32 lanes ->
 // 5.66 / 5.36 / 5.17 / 5.06 / 5.15 / 5.37 / 5.55 ms for 848 k reads of 400 bp at e = 0.01; waiting for the last runners alone costs 5 %)
+#ifndef DW_FLOW_BATCH
+#define DW_FLOW_BATCH 8
+#endif
 DW_DEV bool flow_batch_due(bool parked, bool running)
 {
     const uint64_t p = __ballot(parked), r = __ballot(running);
-    return p && (__popcll(p) >= 8 || __popcll(p) >= __popcll(r));
+    return p && (__popcll(p) >= DW_FLOW_BATCH || __popcll(p) >= __popcll(r));
 }
 // generate_errors_flows (dwgsim.c:246-417).  Every lane of the wave must call this (both passes regroup the lanes of a wave with ballots);
 // lanes without a read pass active = false.  Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.

@@ -15,6 +15,7 @@
 //     DWGSIM_HIP_GROUP_BP  consecutive contigs are resident together up to this many bases (default 32 Mi)
 //     DWGSIM_HIP_MIN_SHARE a group is spread over fewer devices while a device's share would be below this many pairs (default 65536)
 //     DWGSIM_HIP_TIMING    print the stage times
+//     DWGSIM_HIP_TEARDOWN  free every buffer and context before returning from main (by default the process ends as soon as the files are closed)
 //     DWGSIM_HIP_SINK      "null": measurement aid -- the FASTQ deliveries are counted, not written (the .gz files stay empty)
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,13 +24,18 @@
 #include <ctype.h>
 #include <time.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sched.h>
 #include <limits.h>
 #include <zlib.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <deque>
 #include <thread>
+#include <future>
 #include <mutex>
 #include <condition_variable>
 #include <atomic>
@@ -87,40 +93,91 @@ static int xatoi(const char *a, char flag, int neg_ok)                     // dw
 }
 
 // mut.c:49-87 seq_read_fasta: the name is the header up to the first blank, the sequence keeps isalpha, '-' and '.'; a '>' opens a new
-// record wherever it stands.  Whole lines of plain letters (the usual case) are appended with one copy.  Every finished record goes to
-// `on_record` at once, so the first contigs are on the GPU while the rest of the file is still being read.
-static bool read_fasta(const char *fn, const std::function<bool(const std::string &, std::vector<uint8_t> &)> &on_record)
-{
-    FILE *fp = strcmp(fn, "-") ? fopen(fn, "r") : stdin;
-    if (!fp) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn); return false; }
-    std::vector<char> buf((size_t)1 << 24);
+// record wherever it stands.  Every finished record goes to `on_record` at once, so the first contigs are on the GPU while the rest of
+// the file is still being read.  The reader is what a whole-genome run waits for (3.1 GB of text): a regular file is mapped instead of
+// copied through stdio, lines are found with memchr, and a line of plain letters -- all but the headers of a usual FASTA -- is verified
+// eight bytes at a time and appended with one copy; anything else goes character by character as the reference does.
+// `expect(k)`: the length of the k-th record when the caller knows it (the .fai), so that its bases are stored without re-allocations.
+struct FastaParser {
+    const std::function<bool(const std::string &, std::vector<uint8_t> &)> &on_record;
+    const std::function<int64_t(size_t)> &expect;
     std::string name; std::vector<uint8_t> seq; int state = 0;   // 0 before first '>', 1 in name, 2 rest of header line, 3 sequence
-    bool have = false, go = true;
-    static bool keep[256], init = false;
-    if (!init) { for (int c = 0; c < 256; ++c) keep[c] = isalpha(c) || c == '-' || c == '.'; init = true; }
-    size_t n;
-    while (go && (n = fread(buf.data(), 1, buf.size(), fp)) > 0) {
+    bool have = false, go = true; size_t n_rec = 0;
+    bool keep[256];
+    FastaParser(const std::function<bool(const std::string &, std::vector<uint8_t> &)> &f, const std::function<int64_t(size_t)> &e) : on_record(f), expect(e)
+    {
+        for (int c = 0; c < 256; ++c) keep[c] = isalpha(c) || c == '-' || c == '.';
+    }
+    static bool all_letters(const char *p, size_t n)
+    {
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t x; memcpy(&x, p + i, 8);
+            if (x & 0x8080808080808080ull) return false;
+            const uint64_t y = x | 0x2020202020202020ull;                                  // 7-bit values, lower case
+            const uint64_t ge_a = y + 0x1F1F1F1F1F1F1F1Full, gt_z = y + 0x0505050505050505ull;   // bit 7 of a byte: y >= 'a', y > 'z' (no carries: y <= 0x7F)
+            if ((ge_a & ~gt_z & 0x8080808080808080ull) != 0x8080808080808080ull) return false;
+        }
+        for (; i < n; ++i) if (!isalpha((unsigned char)p[i])) return false;
+        return true;
+    }
+    void open_record() { state = 1; name.clear(); seq.clear(); const int64_t e = expect ? expect(n_rec) : 0; if (e > 0) seq.reserve((size_t)e); ++n_rec; }
+    void feed(const char *buf, size_t n)
+    {
         size_t i = 0;
         while (i < n && go) {
             const int c = (unsigned char)buf[i];
             if (state == 3) {
-                // the run of sequence characters from here
-                size_t j = i;
-                while (j < n && keep[(unsigned char)buf[j]]) ++j;
-                if (j > i) { seq.insert(seq.end(), (const uint8_t *)buf.data() + i, (const uint8_t *)buf.data() + j); i = j; continue; }
-                if (c == '>') { go = on_record(name, seq); seq.clear(); state = 1; name.clear(); }
+                if (c != '>' ) {
+                    const char *nl = (const char *)memchr(buf + i, '\n', n - i);
+                    const size_t e = nl ? (size_t)(nl - buf) : n;
+                    if (all_letters(buf + i, e - i)) { seq.insert(seq.end(), (const uint8_t *)buf + i, (const uint8_t *)buf + e); i = nl ? e + 1 : e; continue; }
+                    // the run of sequence characters from here, then whatever stops it
+                    size_t j = i;
+                    while (j < n && keep[(unsigned char)buf[j]]) ++j;
+                    if (j > i) { seq.insert(seq.end(), (const uint8_t *)buf + i, (const uint8_t *)buf + j); i = j; continue; }
+                    ++i;
+                    continue;
+                }
+                go = on_record(name, seq); open_record();
                 ++i;
                 continue;
             }
-            if (state == 0) { if (c == '>') { state = 1; name.clear(); seq.clear(); have = true; } }
+            if (state == 0) { if (c == '>') { open_record(); have = true; } }
             else if (state == 1) { if (c == ' ' || c == '\t') state = 2; else if (c == '\n') state = 3; else if (c != '\r') name.push_back((char)c); }
             else if (state == 2) { if (c == '\n') state = 3; }
             ++i;
         }
     }
-    if (have && go) go = on_record(name, seq);
-    if (fp != stdin) fclose(fp);
-    return go;
+    bool finish() { if (have && go) go = on_record(name, seq); return go; }
+};
+static bool read_fasta(const char *fn, const std::function<bool(const std::string &, std::vector<uint8_t> &)> &on_record, const std::function<int64_t(size_t)> &expect = nullptr)
+{
+    FastaParser ps(on_record, expect);
+    if (strcmp(fn, "-")) {
+        const int fd = open(fn, O_RDONLY);
+        if (fd < 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn); return false; }
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                const size_t piece = (size_t)1 << 26;
+                for (size_t off = 0; off < (size_t)st.st_size && ps.go; off += piece) ps.feed((const char *)m + off, std::min(piece, (size_t)st.st_size - off));
+                munmap(m, (size_t)st.st_size); close(fd);
+                return ps.finish();
+            }
+        }
+        std::vector<char> buf((size_t)1 << 24);
+        ssize_t n;
+        while (ps.go && (n = read(fd, buf.data(), buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
+        close(fd);
+        return ps.finish();
+    }
+    std::vector<char> buf((size_t)1 << 24);
+    size_t n;
+    while (ps.go && (n = fread(buf.data(), 1, buf.size(), stdin)) > 0) ps.feed(buf.data(), n);
+    return ps.finish();
 }
 
 static bool deflate_member(const char *src, size_t n, int level, std::vector<unsigned char> &out)
@@ -305,6 +362,13 @@ int main(int argc, char **argv)
     if (const char *e = getenv("DWGSIM_HIP_GROUP_BP")) { const long long v = atoll(e); if (v > 0) jo.group_bp = (uint64_t)v; }
 
     const char *fn_fa = argv[optind], *out_prefix = argv[optind + 1];
+    // the job (runtime set-up, one context per device: about 0.1 s) is made on a thread of its own while this one reads the contig table
+    FileSink fs;
+    dwgsim_hip_job_sink_t sink; memset(&sink, 0, sizeof sink);
+    sink.user = &fs; sink.mutations = want_mut ? FileSink::mutations : nullptr; sink.reads = want_reads ? FileSink::reads : nullptr;
+    int job_err = 0;
+    std::future<dwgsim_hip_job_t *> job_made = std::async(std::launch::async, [&]() { return dwgsim_hip_job_create(&o, devs.empty() ? nullptr : devs.data(), (int)devs.size(), &sink, &jo, &job_err); });
+    auto give_up = [&](int code) { if (dwgsim_hip_job_t *jb = job_made.get()) dwgsim_hip_job_destroy(jb); return code; };
     // the contig table -- names, lengths, their number and sum -- comes from <in.ref.fa>.fai when that file exists (dwgsim.c:465-478:
     // the VCF header, tot_len, n_ref and the table the mutation / region files are checked against): the FASTA is then read once, contig
     // after contig, each one handed to the GPUs as soon as it is complete.  Without an index the reference reads the FASTA twice; here it
@@ -317,7 +381,7 @@ int main(int argc, char **argv)
         fclose(fai);
         streaming = true;
     } else {
-        if (!read_fasta(fn_fa, [&](const std::string &nm, std::vector<uint8_t> &seq) { held.emplace_back(nm, std::move(seq)); seq = std::vector<uint8_t>(); return true; })) return 1;
+        if (!read_fasta(fn_fa, [&](const std::string &nm, std::vector<uint8_t> &seq) { held.emplace_back(nm, std::move(seq)); seq = std::vector<uint8_t>(); return true; })) return give_up(1);
         for (auto &r : held) { tab_names.push_back(r.first); tab_lens.push_back((int64_t)r.second.size()); }
     }
     const double t_fasta = now_s();
@@ -326,12 +390,11 @@ int main(int argc, char **argv)
     fprintf(stderr, "[dwgsim_core] %d sequences, total length: %llu\n", (int)tab_names.size(), (unsigned long long)tot_len);
 
     const bool has_bfast = want_reads && o.reads_output_type != 1, has_bwa = want_reads && o.reads_output_type != 2;
-    FileSink fs;
     if (const char *e = getenv("DWGSIM_HIP_SINK")) fs.null_sink = !strcmp(e, "null");
     std::string p = out_prefix;
     if (want_mut) {
         fs.fp_txt = fopen((p + ".mutations.txt").c_str(), "w"); fs.fp_vcf = fopen((p + ".mutations.vcf").c_str(), "w");
-        if (!fs.fp_txt || !fs.fp_vcf) { fprintf(stderr, "[main] fail to open mutation files for '%s'. Abort!\n", out_prefix); return 1; }
+        if (!fs.fp_txt || !fs.fp_vcf) { fprintf(stderr, "[main] fail to open mutation files for '%s'. Abort!\n", out_prefix); return give_up(1); }
         fprintf(fs.fp_vcf, "##fileformat=VCFv4.1\n");
         for (size_t i = 0; i < tab_names.size(); ++i) fprintf(fs.fp_vcf, "##contig=<ID=%s,length=%d>\n", tab_names[i].c_str(), (int)tab_lens[i]);
         fprintf(fs.fp_vcf, "##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency\">\n"
@@ -339,17 +402,14 @@ int main(int argc, char **argv)
                            "##INFO=<ID=mt,Number=1,Type=String,Description=\"Variant Type: SUBSTITUTE/INSERT/DELETE\">\n"
                            "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
     }
-    if (has_bwa) { fs.fgz[0] = fopen((p + ".bwa.read1.fastq.gz").c_str(), "wb"); fs.fgz[1] = fopen((p + ".bwa.read2.fastq.gz").c_str(), "wb"); if (!fs.fgz[0] || !fs.fgz[1]) { fprintf(stderr, "fail to open FASTQ outputs\n"); return 1; } }
-    if (has_bfast) { fs.fgz[2] = fopen((p + ".bfast.fastq.gz").c_str(), "wb"); if (!fs.fgz[2]) { fprintf(stderr, "fail to open FASTQ outputs\n"); return 1; } }
+    if (has_bwa) { fs.fgz[0] = fopen((p + ".bwa.read1.fastq.gz").c_str(), "wb"); fs.fgz[1] = fopen((p + ".bwa.read2.fastq.gz").c_str(), "wb"); if (!fs.fgz[0] || !fs.fgz[1]) { fprintf(stderr, "fail to open FASTQ outputs\n"); return give_up(1); } }
+    if (has_bfast) { fs.fgz[2] = fopen((p + ".bfast.fastq.gz").c_str(), "wb"); if (!fs.fgz[2]) { fprintf(stderr, "fail to open FASTQ outputs\n"); return give_up(1); } }
     for (int s = 0; s < 3; ++s) if (fs.fgz[s]) setvbuf(fs.fgz[s], nullptr, _IONBF, 0);      // deliveries are megabytes: no second copy through stdio
     std::unique_ptr<DeflatePool> pool;
     if (!gpu_gzip && want_reads) { pool = std::make_unique<DeflatePool>(nthreads, gz_level); fs.pool = pool.get(); }
 
-    dwgsim_hip_job_sink_t sink; memset(&sink, 0, sizeof sink);
-    sink.user = &fs; sink.mutations = want_mut ? FileSink::mutations : nullptr; sink.reads = want_reads ? FileSink::reads : nullptr;
-    int err = 0;
-    dwgsim_hip_job_t *job = dwgsim_hip_job_create(&o, devs.empty() ? nullptr : devs.data(), (int)devs.size(), &sink, &jo, &err);
-    if (!job) { fprintf(stderr, "dwgsim-hip: cannot set the job up (error %d)\n", err); return 1; }
+    dwgsim_hip_job_t *job = job_made.get();
+    if (!job) { fprintf(stderr, "dwgsim-hip: cannot set the job up (error %d)\n", job_err); return 1; }
     int rc = 0;
     auto job_error = [&]() { const char *e = dwgsim_hip_job_last_error(job); if (rc == 0) fprintf(stderr, "%s%s", e, (e[0] && e[strlen(e) - 1] != '\n') ? "\n" : ""); rc = 1; };
     {
@@ -366,7 +426,7 @@ int main(int argc, char **argv)
         return true;
     };
     if (rc == 0) {
-        if (streaming) { if (!read_fasta(fn_fa, feed) && rc == 0) rc = 1; }
+        if (streaming) { if (!read_fasta(fn_fa, feed, [&](size_t k) -> int64_t { return k < tab_lens.size() ? tab_lens[k] : 0; }) && rc == 0) rc = 1; }
         else for (auto &r : held) { if (!feed(r.first, r.second)) break; std::vector<uint8_t>().swap(r.second); }
     }
     const double t_fed = now_s();
@@ -378,9 +438,12 @@ int main(int argc, char **argv)
                         streaming ? " (.fai)" : " (FASTA read into memory)", t_fasta - t_start, t_ctx - t_fasta, streaming ? "FASTA read, " : "", t_fed - t_ctx, t_out_done - t_fed, t_out_done - t_start,
                         fs.bytes_in.load() / 1e9, fs.bytes_out.load() / 1e9,
                         gpu_gzip ? "gzip members made on the GPU" : (std::string("zlib level ") + std::to_string(gz_level) + " on " + std::to_string(nthreads) + " host threads").c_str());
-    dwgsim_hip_job_destroy(job);
     if (fs.fp_txt) fclose(fs.fp_txt);
     if (fs.fp_vcf) fclose(fs.fp_vcf);
     for (int s = 0; s < 3; ++s) close_gz(fs.fgz[s], gz_level);
-    return rc;
+    if (getenv("DWGSIM_HIP_TEARDOWN")) { dwgsim_hip_job_destroy(job); return rc; }
+    // everything has been delivered and the files are closed: the process ends here.  Handing back device memory, page-locked buffers and the
+    // runtime piece by piece costs 0.2 s after a chromosome-sized job; the driver reclaims them with the process.
+    fflush(nullptr);
+    _exit(rc);
 }

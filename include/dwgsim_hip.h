@@ -272,7 +272,7 @@ typedef struct dwgsim_hip_job_sink {
 typedef struct dwgsim_hip_job_options {
     int32_t  gzip;           /* 1: reads() gets gzip members made on the GPU (dwgsim_hip_set_gzip), 0: text */
     int32_t  quiet;
-    uint64_t batch_pairs;    /* pairs per launch (0: 2^20) */
+    uint64_t batch_pairs;    /* pairs per launch (0: 2^18) */
     uint64_t group_bp;       /* consecutive contigs are resident, walked and simulated together up to this many bases (0: 32 Mi) */
     uint64_t min_share;      /* a group is spread over fewer devices while a device's share would stay below this many pairs (0: 65536) */
 } dwgsim_hip_job_options_t;

@@ -269,3 +269,34 @@ def test_command_line_honours_a_fai_index_as_the_reference_does(emu_lib, oracle_
         assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k], suf
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"] and b"phantom" in want["vcf"]
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
+
+
+def test_command_line_reads_an_awkward_fasta_as_the_reference_does(emu_lib, oracle_bin, tmp_path):
+    """mut.c:49-87 seq_read_fasta: text before the first '>', CR LF, blank lines, lower case, '-' and '.', digits and blanks inside the
+    sequence, a '>' in the middle of a line, lines of every length around the reader's eight-byte steps, bytes with the high bit set, no
+    newline at the end.  The command line's reader (mapped file, memchr, eight letters verified at a time) against the oracle's."""
+    import gzip, random
+    from parity_common import run_oracle
+    rng = random.Random(5)
+    def seq(n): return "".join(rng.choice("ACGT") for _ in range(n))
+    body = ["junk before the first record", ">c1 first comment\r"]
+    for L in list(range(1, 20)) + [60, 61, 64, 65]:
+        body.append(seq(L) + ("\r" if L % 3 == 0 else ""))
+    body += ["", seq(30).lower(), seq(10) + "-." + seq(7), seq(9) + " 12 " + seq(9), seq(8) + "\xe9" + seq(8), seq(40)]
+    body += [">c2\tsecond", seq(700), seq(33) + ">c3 opens mid-line", seq(900)]
+    body += [">c4"] + [seq(61) for _ in range(30)]
+    fa = str(tmp_path / "awkward.fa")
+    open(fa, "w", encoding="latin-1").write("\n".join(body) + "\n" + seq(50))      # (no newline at the end)
+    flags = "-z 21 -N 1200 -1 50 -2 50 -d 200 -s 10 -o 1 -n 50"
+    want = run_oracle(oracle_bin, fa, flags, str(tmp_path))
+    subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + [fa, str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL,
+                   env=dict(os.environ, DWGSIM_HIP_THREADS="2", DWGSIM_HIP_GZIP="cpu"))
+    for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz")]:
+        assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k], suf
+    assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"] and b"c3" in want["vcf"]
+    assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
+    # the same file through a pipe (no mapping: the chunked path of the reader)
+    with open(fa, "rb") as f:
+        subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + ["-", str(tmp_path / "pipe")], check=True, stdin=f, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, DWGSIM_HIP_THREADS="2", DWGSIM_HIP_GZIP="cpu"))
+    assert gzip.open(str(tmp_path / "pipe.bwa.read1.fastq.gz"), "rb").read() == want[0]
