@@ -37,6 +37,7 @@ struct Idx { unsigned x, y, z; };
 extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 void sync_block();
 void sync_wave();
+void yield();                     // the calling lane lets the other lanes of the block run (s_sleep in a polling loop)
 uint64_t *wave_buf();             // 64 x u64 exchange slots of the calling thread's wave
 void *dyn_shared();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn);
@@ -87,7 +88,7 @@ static inline uint32_t atomicMax(uint32_t *p, uint32_t v) { uint32_t o = __atomi
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
-static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
+static inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); }
 
 // hardware transcendentals used only inside estimates with a guard band (quality_pair_lazy): libm stand-ins are at least as accurate
 #ifndef __clang__
