@@ -40,6 +40,7 @@ def random_flags(rng):
     return " ".join(f)
 
 
+ORACLE_TIMEOUT = float(os.environ.get("DWGSIM_FUZZ_ORACLE_TIMEOUT", "20"))      # option sets on which the oracle (like the reference) never ends: e = 1 in the flow model
 IN = os.path.join(ROOT, "tests", "golden", "inputs")
 def random_flags_tiny_inputs(rng):
     """tiny.fa only: mutation-input files, target regions, -B"""
@@ -47,17 +48,17 @@ def random_flags_tiny_inputs(rng):
     c = rng.random()
     if c < 0.5: f += " " + rng.choice([f"-m {IN}/muts_generated.txt", f"-m {IN}/muts_edge.txt", f"-v {IN}/muts_generated.vcf", f"-v {IN}/muts_edge.vcf", f"-b {IN}/muts_edge.bed"])
     if rng.random() < 0.5: f += " " + rng.choice([f"-x {IN}/regions_a.bed", f"-x {IN}/regions_b.bed"])
-    if "-c 2" in f and rng.random() < 0.3: f += " -B"
+    if "-c 2" in f and rng.random() < 0.3 and not os.environ.get("DWGSIM_FUZZ_NO_B"): f += " -B"      # (the draw is made either way: the same option sets with and without the knob)
     return f
 
 def one_case_cli(flags, fasta):
     """child process, CLI flavour: dwgsim-hip <flags> ref.fa prefix against the oracle's five files (gunzipped)"""
     import gzip, subprocess
     oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
-    cli = os.path.join(ROOT, "dwgsim_amd", "dwgsim-hip")
+    cli = os.environ.get("DWGSIM_HIP_CLI") or os.path.join(ROOT, "dwgsim_amd", "dwgsim-hip")      # (the CPU suite points this at tests/emu/dwgsim-emu)
     with tempfile.TemporaryDirectory() as t:
         try:
-            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=20)
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=ORACLE_TIMEOUT)
         except subprocess.TimeoutExpired:
             print("ORACLE-TIMEOUT", flush=True); return 3
         c = subprocess.run([cli] + flags.split() + [fasta, os.path.join(t, "c")], capture_output=True, text=True, timeout=100)
@@ -131,7 +132,7 @@ def one_case_shards(flags, fasta, seed):
     oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
     with tempfile.TemporaryDirectory() as t:
         try:
-            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=20)
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=ORACLE_TIMEOUT)
         except subprocess.TimeoutExpired:
             print("ORACLE-TIMEOUT", flush=True); return 3
         if r.returncode != 0:
@@ -154,7 +155,7 @@ def one_case(flags, fasta):
     oracle = os.path.join(ROOT, "oracle", "build", "dwgsim_oracle")
     with tempfile.TemporaryDirectory() as t:
         try:
-            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=20)
+            r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=ORACLE_TIMEOUT)
         except subprocess.TimeoutExpired:
             print("ORACLE-TIMEOUT", flush=True); return 3
     if r.returncode != 0:

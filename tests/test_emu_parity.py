@@ -2,7 +2,7 @@
 the SIMT emulation shim in tests/emu (one OS thread per GPU thread) must match the oracle in Philox
 mode byte for byte.  This is test infrastructure -- the product library has no CPU path -- and only
 a subset of the GPU parity cases is run (the emulation is slow)."""
-import os, subprocess
+import os, subprocess, sys
 import pytest
 
 from dwgsim_amd import api
@@ -300,3 +300,16 @@ def test_command_line_reads_an_awkward_fasta_as_the_reference_does(emu_lib, orac
         subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + ["-", str(tmp_path / "pipe")], check=True, stdin=f, stderr=subprocess.DEVNULL,
                        env=dict(os.environ, DWGSIM_HIP_THREADS="2", DWGSIM_HIP_GZIP="cpu"))
     assert gzip.open(str(tmp_path / "pipe.bwa.read1.fastq.gz"), "rb").read() == want[0]
+
+
+@pytest.mark.parametrize("seed,count,mode", [(201, 160, ""), (202, 100, "inputs"), (203, 60, "cli"), (204, 30, "inputs cli"), (205, 100, "shards"), (206, 60, "inputs shards")])
+def test_random_option_sets_on_cpu_emulation(emu_lib, oracle_bin, seed, count, mode):
+    """tests/fuzz_flags.py (what test_gpu_fuzz.py runs on the GPU) through the emulated library and command line: random option combinations --
+    all three technologies, every length from 1, ramps, mutation inputs, regions, read-index ranges simulated out of order -- against the
+    oracle, byte for byte; option sets the oracle itself rejects are skipped.  (-B is left to its own cases above: its calibration runs 10^5 reads
+    through the flow model, minutes under emulation.)"""
+    env = dict(os.environ, DWGSIM_HIP_LIB=os.path.join(HERE, "emu", "libdwgsim_emu.so"), DWGSIM_HIP_CLI=os.path.join(HERE, "emu", "dwgsim-emu"), DWGSIM_HIP_GZIP="cpu",
+               DWGSIM_FUZZ_ORACLE_TIMEOUT="3", DWGSIM_FUZZ_NO_B="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_flags.py"), str(seed), str(count)] + mode.split(), capture_output=True, text=True, timeout=1400, env=env)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-3000:]
