@@ -384,7 +384,7 @@ __global__ void k_justify_seq(const Event *ev, Count nc, ContigDev c)
 // The reference's pass is sequential, but an indel only interacts with what its leftward scan can
 // touch.  (1) k_jreach: per live event, a conservative lower bound `lo` of every cell its scan can
 // read or write: continue while the cell is mutated on either haplotype (pre-justify state) or the
-// reference is periodic there (deletion: ref[j]&3 == ref[j+L]&3, insertion: the rotated copy keeps
+// bases are periodic there (deletion: cell[j]&3 == cell[j+L]&3, insertion: the rotated copy keeps
 // matching).  Shifts preserve (cell & 3) at every position, so the true scan never goes further.
 // (2) k_sufmin: suffix minimum of lo.  (3) k_jbound: event b starts a new cluster iff no event >= b
 // can reach the previous live event's footprint and an unmutated non-N position separates them
@@ -395,10 +395,14 @@ DW_DEV int64_t reach_del(const ContigDev &c, int h, int64_t p, int64_t lo, int64
     // period = the run of DELETE cells the sequential pass would measure at p (adjacent runs merge,
     // mut.c:503 / :535 / :557) on haplotype h
     const int64_t L = del_run(c.hap[h], p, hi);
+    const uint8_t *cl = c.hap[h].cells;
     int64_t j = p - 1;
     for (; j >= lo; --j) {
         const bool mutated = ((c.hap[0].cells[j] | c.hap[1].cells[j]) & TMASK) != 0;
-        if (!(mutated || (p + L < hi && (c.ref[j] & 3) == (c.ref[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
+        // the scan compares the bases the CELLS hold (a substituted cell L further right holds its new base, and the homozygous scan walks
+        // through substituted cells: mut.c:515-516), not the reference's: with the reference here, a deletion that crosses a substitution
+        // was given too short a reach, its cluster ran beside the one it reaches into, and the result depended on which thread came first
+        if (!(mutated || (p + L < hi && (cl[j] & 3) == (cl[j + L] & 3)))) break;   // run at the contig end never moves (mut.c:506)
     }
     return j < lo ? lo : j;                            // last cell read
 }

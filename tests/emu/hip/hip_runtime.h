@@ -40,7 +40,7 @@ void sync_wave();
 void yield();                     // the calling lane lets the other lanes of the block run (s_sleep in a polling loop)
 uint64_t *wave_buf();             // 64 x u64 exchange slots of the calling thread's wave
 void *dyn_shared();
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn, const char *kernel_name = nullptr);
 }
 #define threadIdx hipemu::t_threadIdx
 #define blockIdx hipemu::t_blockIdx
@@ -140,4 +140,4 @@ static inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); }, #kernel)

@@ -101,7 +101,7 @@ void yield() { to_scheduler(); }
 uint64_t *wave_buf() { return g.wave_buf[t_threadIdx.x >> 6]; }
 void *dyn_shared() { return g.dyn.data(); }
 
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn)
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn, const char *kernel_name)
 {
     const unsigned nt = block.x;
     if (nt == 0 || grid.x == 0) return;
@@ -115,11 +115,23 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
     }
     g.dyn.assign(shmem + 64, 0);
     g.nt = nt; g.fn = &fn;
+    // HIPEMU_REVERSE=<kernel name>[,<kernel name>...]: the blocks of those kernels run from the last to the first, and so do the lanes of a
+    // block.  Threads that are meant to be independent (one cluster of the left-justification each) must not care; run in index order only,
+    // an overlap between two of them looks like the sequential algorithm and stays hidden (it did: dw_walk.hip reach_del, found on the GPU).
+    // Not for kernels whose blocks wait for their predecessors (look-backs).
+    bool reverse_lanes = false;
+    if (const char *e = getenv("HIPEMU_REVERSE")) {
+        const char *nm = kernel_name ? kernel_name : "";
+        const char *colon = strrchr(nm, ':'); if (colon) nm = colon + 1;                  // dw::k_jrun -> k_jrun
+        const size_t n = strcspn(nm, "<( ");
+        for (const char *q = e; *q;) { const size_t m = strcspn(q, ","); if (m == n && !strncmp(q, nm, n)) reverse_lanes = true; q += m; if (*q == ',') ++q; }
+    }
     const unsigned gy = grid.y ? grid.y : 1;
     const Idx saved[4] = {t_threadIdx, t_blockIdx, t_blockDim, t_gridDim};
     t_blockDim = Idx{nt, 1, 1}; t_gridDim = Idx{grid.x, gy, 1};
     for (unsigned y = 0; y < gy; ++y)
-        for (unsigned b = 0; b < grid.x; ++b) {      // blocks run one after the other (static __shared__ storage)
+        for (unsigned bb = 0; bb < grid.x; ++bb) {      // blocks run one after the other (static __shared__ storage)
+            const unsigned b = reverse_lanes ? grid.x - 1 - bb : bb;
             t_blockIdx = Idx{b, y, 0};
             g.block_bar = Barrier();
             for (unsigned w = 0; w < nt / 64; ++w) g.wave_bar[w] = Barrier();
@@ -132,7 +144,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
             unsigned left = nt, idle_rounds = 0;
             while (left) {
                 g.progress = false;
-                for (unsigned t = 0; t < nt; ++t) {
+                for (unsigned tt = 0; tt < nt; ++tt) {
+                    const unsigned t = reverse_lanes ? nt - 1 - tt : tt;
                     if (g.fib[t].done) continue;
                     g.cur = t; t_threadIdx = Idx{t, 0, 0};
 #if EMU_ASAN

@@ -16,7 +16,8 @@ def random_flags(rng):
         d = rng.choice([l1 + l2, l1 + l2 + 5, 200, 500, 900]); f += [f"-d {max(d, l1 + l2)}", f"-s {rng.choice([0, 1, 10, 50])}"]
         if rng.random() < 0.2: f.append("-i")
     f.append(rng.choice([f"-N {rng.choice([1, 2, 63, 64, 65, 257, 1000, 3000])}", f"-C {rng.choice([0.01, 0.5, 2, 7])}"]))
-    if rng.random() < 0.6: f.append(f"-r {rng.choice([0, 0.0001, 0.001, 0.01, 0.05, 0.3])}")
+    if os.environ.get("DWGSIM_FUZZ_MUT"): f.append(f"-r {rng.choice([0.05, 0.1, 0.2, 0.3, 0.5])}")      # (the walk under stress: dense events)
+    elif rng.random() < 0.6: f.append(f"-r {rng.choice([0, 0.0001, 0.001, 0.01, 0.05, 0.3])}")
     if rng.random() < 0.5: f.append(f"-R {rng.choice([0, 0.1, 0.5, 1.0])}")
     if rng.random() < 0.4: f.append(f"-X {rng.choice([0, 0.3, 0.8, 0.95])}")
     if rng.random() < 0.3: f.append(f"-I {rng.choice([1, 2, 10, 40])}")

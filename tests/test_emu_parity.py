@@ -313,3 +313,23 @@ def test_random_option_sets_on_cpu_emulation(emu_lib, oracle_bin, seed, count, m
     r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_flags.py"), str(seed), str(count)] + mode.split(), capture_output=True, text=True, timeout=1400, env=env)
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-3000:]
+
+
+INDEPENDENT_THREADS = "k_jrun,k_apply,k_resolve,k_jreach,k_jbound,k_events,k_apply_patches,k_gather,k_pack,k_compact,k_make_view,k_collect_mask"
+
+
+def test_independent_threads_in_reverse_order_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, tmp_path, monkeypatch):
+    """Kernels whose threads are meant to be independent -- above all k_jrun, one cluster of the left-justification per thread -- with their
+    blocks and lanes run from the last to the first (HIPEMU_REVERSE, tests/emu/hip_emu.cpp).  In index order an overlap between two clusters
+    looks like the sequential algorithm and stays hidden; this order shows it, as the GPU does.  The case the GPU found, dense indels in
+    homopolymers and tandem repeats, and 150 of the fuzzer's option sets at high mutation rates."""
+    monkeypatch.setenv("HIPEMU_REVERSE", INDEPENDENT_THREADS)
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 8384 -1 7 -2 1 -d 900 -s 1 -C 0.5 -r 0.3 -y 0.3 -n 1000 -S 1 -H -o 1")
+    fa = str(tmp_path / "many.fa")
+    write_many_contigs(fa, 40, 77)
+    for flags in ("-z 21 -N 3000 -1 40 -2 40 -d 150 -s 10 -r 0.2 -R 0.7 -X 0.6 -n 40", "-z 22 -N 3000 -1 40 -2 40 -d 150 -s 10 -r 0.3 -R 0.3 -X 0.3 -n 40 -H",
+                  "-z 23 -N 2000 -1 30 -2 30 -d 120 -s 5 -r 0.1 -R 1.0 -X 0.9 -I 3 -n 40"):
+        compare_case(emu_lib, oracle_bin, fa, flags, group_bp=1 << 30)
+    env = dict(os.environ, DWGSIM_HIP_LIB=os.path.join(HERE, "emu", "libdwgsim_emu.so"), DWGSIM_FUZZ_ORACLE_TIMEOUT="3", DWGSIM_FUZZ_NO_B="1", DWGSIM_FUZZ_MUT="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_flags.py"), "207", "150"], capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].endswith(" 0 bad"), r.stdout[-3000:]
