@@ -119,19 +119,25 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
     // block.  Threads that are meant to be independent (one cluster of the left-justification each) must not care; run in index order only,
     // an overlap between two of them looks like the sequential algorithm and stays hidden (it did: dw_walk.hip reach_del, found on the GPU).
     // Not for kernels whose blocks wait for their predecessors (look-backs).
-    bool reverse_lanes = false;
-    if (const char *e = getenv("HIPEMU_REVERSE")) {
+    // HIPEMU_REVERSE_LANES=<kernel names>: only the lanes (blocks stay in order): for kernels with look-backs; shows code that counts on the
+    // lock step of a wave where no wave operation enforces it.
+    auto named_in = [&](const char *var) {
+        const char *e = getenv(var);
+        if (!e) return false;
         const char *nm = kernel_name ? kernel_name : "";
         const char *colon = strrchr(nm, ':'); if (colon) nm = colon + 1;                  // dw::k_jrun -> k_jrun
         const size_t n = strcspn(nm, "<( ");
-        for (const char *q = e; *q;) { const size_t m = strcspn(q, ","); if (m == n && !strncmp(q, nm, n)) reverse_lanes = true; q += m; if (*q == ',') ++q; }
-    }
+        for (const char *q = e; *q;) { const size_t m = strcspn(q, ","); if ((m == n && !strncmp(q, nm, n)) || (m == 3 && !strncmp(q, "all", 3))) return true; q += m; if (*q == ',') ++q; }
+        return false;
+    };
+    const bool reverse_blocks = named_in("HIPEMU_REVERSE");
+    const bool reverse_lanes = reverse_blocks || named_in("HIPEMU_REVERSE_LANES");
     const unsigned gy = grid.y ? grid.y : 1;
     const Idx saved[4] = {t_threadIdx, t_blockIdx, t_blockDim, t_gridDim};
     t_blockDim = Idx{nt, 1, 1}; t_gridDim = Idx{grid.x, gy, 1};
     for (unsigned y = 0; y < gy; ++y)
         for (unsigned bb = 0; bb < grid.x; ++bb) {      // blocks run one after the other (static __shared__ storage)
-            const unsigned b = reverse_lanes ? grid.x - 1 - bb : bb;
+            const unsigned b = reverse_blocks ? grid.x - 1 - bb : bb;
             t_blockIdx = Idx{b, y, 0};
             g.block_bar = Barrier();
             for (unsigned w = 0; w < nt / 64; ++w) g.wave_bar[w] = Barrier();

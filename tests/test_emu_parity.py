@@ -333,3 +333,14 @@ def test_independent_threads_in_reverse_order_on_cpu_emulation(emu_lib, oracle_b
     env = dict(os.environ, DWGSIM_HIP_LIB=os.path.join(HERE, "emu", "libdwgsim_emu.so"), DWGSIM_FUZZ_ORACLE_TIMEOUT="3", DWGSIM_FUZZ_NO_B="1", DWGSIM_FUZZ_MUT="1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_flags.py"), "207", "150"], capture_output=True, text=True, timeout=1400, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].endswith(" 0 bad"), r.stdout[-3000:]
+
+
+def test_lanes_in_reverse_order_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, monkeypatch):
+    """Every kernel with the lanes of a block run from the last to the first (HIPEMU_REVERSE_LANES=all; blocks stay in order for the look-backs):
+    nothing may count on the lock step of a wave where no wave operation enforces it."""
+    from parity_common import CASES
+    monkeypatch.setenv("HIPEMU_REVERSE_LANES", "all")
+    picked = [c for c in CASES if any(t in c[1] for t in ("-z 13 -N 10000 -1 100", "-I 30", "-c 1 -1 40", "-e 0.05 -n 10", "-o 2 -q 5", "-B -o 1", "-z 8384"))]
+    assert len(picked) >= 5
+    for fasta, flags in picked:
+        compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags.replace("-N 10000", "-N 3000"))
