@@ -278,7 +278,7 @@ class Context:
         err = C.c_int(0)
         self.h = self.lib.dwgsim_hip_create(C.byref(params), device, C.byref(err))
         if not self.h:
-            raise DwgsimError(f"dwgsim_hip_create failed with code {err.value} (no HIP device? there is no CPU fallback)")
+            raise DwgsimError(f"dwgsim_hip_create failed with code {err.value}" + (" (no HIP device? there is no CPU fallback)" if err.value == -2 else " (the library said why on stderr)"))
 
     def close(self):
         if self.h:

@@ -379,7 +379,8 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     if (p->data_type == 2) for (const char *q = p->flow_order; *q; ++q) c->flow.push_back(nt4((unsigned char)*q));
     c->prm.read_prefix = nullptr; c->prm.flow_order = nullptr;
     c->device = device;
-    auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, DWGSIM_HIP_ERR_DEVICE); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
+    int fail_code = DWGSIM_HIP_ERR_DEVICE;       // (the -B calibration reports reads that outgrow their buffers as DWGSIM_HIP_ERR_FAILED: an option set, not the device)
+    auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, fail_code); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
     auto init = [&]() -> int {
         HIPC(c, hipSetDevice(device));
         HIPC(c, hipStreamCreate(&c->stream));
@@ -426,7 +427,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 launch_calibrate(c->stream, ca);
                 HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
                 HIPC(c, hipStreamSynchronize(c->stream));
-                if (c->h_counters[2]) { c->err = "-B calibration: a read outgrew its flow-space buffer"; return -1; }
+                if (c->h_counters[2]) { c->err = "-B calibration: a read outgrew its flow-space buffer (the flow model's growth at this error rate and flow order: INTEGRATION.md)"; fail_code = DWGSIM_HIP_ERR_FAILED; return -1; }
                 const int32_t n_err = (int32_t)c->h_counters[8], counts = (int32_t)c->h_counters[9];       // int32 accumulators as in the reference
                 sf = e / (n_err / (1.0 * counts));
                 c->prm.e_end[i] *= sf; c->prm.e_start[i] = c->prm.e_end[i];

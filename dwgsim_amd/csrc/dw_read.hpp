@@ -444,7 +444,8 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     PackReader<4> la; la.init(bufA, stride);
     auto in1 = [&](int t) -> uint32_t { const uint32_t v = la.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
     auto in8 = [&](int t) -> uint32_t {                       // bases t .. t + 7 of the input as nibbles, N -> A
-        uint32_t v = strand ? nibbles_reversed(inA.get8(len - 8 - t)) : inA.get8(t);
+        uint32_t v = inA.get8(strand ? len - 8 - t : t);
+        v = strand ? nibbles_reversed(v) : v;
         return v & 0x33333333u & ~(((v >> 2) & 0x11111111u) * 3u);
     };
     HitMap hm1{bm, stride, 0u};
