@@ -22,7 +22,7 @@ try:
 except Exception:
     head = None
 pairs = int(pairs / max(bench["config"].get("launches_per_gpu_per_step", 1), 1))
-out = {"source": f"profiles/{os.path.basename(d)}_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
+out = {"source": f"profiles/r03_{os.path.basename(d).replace('final_', '')}_kernel_stats_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
        "kernel": bench["roofline"]["kernel"], "pairs_per_launch": pairs, "lib_sha256": sha, "git_head": head}
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.update({"fetch_size_kib": vals["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kib": vals["WRITE_SIZE"],
