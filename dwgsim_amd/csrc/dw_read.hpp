@@ -278,26 +278,16 @@ DW_DEV void read_geom(const SimArgs &a, const SegCtx &sc, const PairDraw &pd, in
 
 // ---- Ion Torrent flow-space errors: dwgsim.c:246-417 generate_errors_flows ----
 // The reference edits the read in place; both passes only ever insert/delete at the position being
-// examined, so they are replayed as transducers over packed 4-bit arrays in LDS (word w of a lane
-// at base[w * stride]).  Draws: narrow uniforms of domain D_FLOW0 + read end, one sequential slot
-// counter per read end.  The flow mask is per read (the reference's persistent mask is fully
-// rewritten by every read's pass 1).
-// word-cached access to a lane's packed array (BITS = 4: codes 0-5, BITS = 2: bases 0-3): the flow model reads and
-// appends sequentially, so one LDS access serves 8 / 16 bases
+// examined, so they are replayed as transducers over packed arrays in the block's global scratch (word w of a
+// lane at base[w * stride]; flow_errors below says how).  Draws: narrow uniforms of domain D_FLOW0 + read end.  The
+// flow mask is per read (the reference's persistent mask is fully rewritten by every read's pass 1).
+// word-cached access to a lane's packed array (BITS = 4: codes 0-5): the event code looks at single bases
 template <int BITS>
 struct PackReader {
     static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4; static constexpr uint32_t M = (1u << BITS) - 1;
     const uint32_t *base; int stride, cw; uint32_t word;
     DW_DEV void init(const uint32_t *b, int st) { base = b; stride = st; cw = -1; word = 0; }
     DW_DEV uint32_t get(int i) { const int w = i >> SH; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & (PER - 1)) * BITS)) & M; }
-};
-template <int BITS>
-struct PackAppender {
-    static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4;
-    uint32_t *base; int stride, n; uint32_t acc;
-    DW_DEV void init(uint32_t *b, int st) { base = b; stride = st; n = 0; acc = 0; }
-    DW_DEV void push(uint32_t v) { acc |= v << ((n & (PER - 1)) * BITS); if ((++n & (PER - 1)) == 0) { base[((n >> SH) - 1) * stride] = acc; acc = 0; } }
-    DW_DEV void flush() { if (n & (PER - 1)) base[(n >> SH) * stride] = acc; }
 };
 #ifndef DW_KNOCK
 #define DW_KNOCK 0
