@@ -345,3 +345,11 @@ def test_lanes_in_reverse_order_on_cpu_emulation(emu_lib, oracle_bin, golden_dir
     import re
     for fasta, flags in picked:
         compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), re.sub(r"-N \d+", "-N 1200", flags))
+
+
+def test_ion_torrent_random_flow_orders_on_cpu_emulation(emu_lib, oracle_bin):
+    """tests/fuzz_ion_flows.py (the GPU suite runs it too): the flow model under flow orders of 4 .. 64 flows with long gaps, read lengths 1 .. 400,
+    per-flow error rates up to 0.2; reads that outgrow their buffer (the documented limit) are counted, not failed."""
+    env = dict(os.environ, DWGSIM_HIP_LIB=os.path.join(HERE, "emu", "libdwgsim_emu.so"), DWGSIM_FUZZ_ORACLE_TIMEOUT="3", DWGSIM_FUZZ_NO_B="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_ion_flows.py"), "32", "80"], capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].endswith(" 0 bad"), r.stdout[-3000:]
