@@ -171,6 +171,8 @@ def one_case(flags, fasta):
     except AssertionError as e:
         print("MISMATCH ::", str(e)[:300], flush=True); return 4
     except Exception as e:
+        if "-B" in flags.split() and "failed with code -5" in repr(e):      # the documented limit of the flow model, met by the calibration
+            print("LIMIT :: -B calibration: a read outgrew its buffer", flush=True); return 3
         print("ERROR ::", repr(e)[:300], flush=True); return 4
     return 0
 
