@@ -58,6 +58,12 @@ class JobOptions(C.Structure):
 
 
 RAND_CHAIN = (1 << 64) - 1        # DWGSIM_HIP_RAND_CHAIN
+SKIP_NO_REGION, SKIP_NON_ACGT, SKIP_AMPLICON, SKIP_SHORT_INSERT, SKIP_SHORT_READ, SKIP_NO_PAIRS = -100, -101, -102, -103, -104, -105      # DWGSIM_HIP_SKIP_*
+
+
+def is_skip(r: int) -> bool:
+    """DWGSIM_HIP_IS_SKIP: the value says why dwgsim_core passes over a contig (a range disjoint from the error codes)"""
+    return -105 <= r <= -100
 
 
 EXPORTS = [
@@ -68,7 +74,7 @@ EXPORTS = [
     "dwgsim_hip_fetch", "dwgsim_hip_device_info",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
     "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_mutate_poll", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
-    "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig",
+    "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig", "dwgsim_hip_job_begin_contig", "dwgsim_hip_job_commit_contig", "dwgsim_hip_job_cancel_contig", "dwgsim_hip_get_params",
     "dwgsim_hip_job_finish", "dwgsim_hip_job_last_error", "dwgsim_hip_job_destroy",
     "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
 ]
@@ -114,13 +120,19 @@ def load(path: str | None = None):
     lib.dwgsim_hip_job_prepare.argtypes = [C.c_void_p, P(C.c_uint64)]
     lib.dwgsim_hip_job_add_contig.restype = C.c_int64
     lib.dwgsim_hip_job_add_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.dwgsim_hip_job_begin_contig.restype = C.c_void_p
+    lib.dwgsim_hip_job_begin_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, P(C.c_int64)]
+    lib.dwgsim_hip_job_commit_contig.restype = C.c_int64
+    lib.dwgsim_hip_job_commit_contig.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_job_cancel_contig.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_get_params.argtypes = [C.c_void_p, P(Params)]
     lib.dwgsim_hip_job_finish.argtypes = [C.c_void_p]
     lib.dwgsim_hip_job_last_error.restype = C.c_char_p
     lib.dwgsim_hip_job_last_error.argtypes = [C.c_void_p]
     lib.dwgsim_hip_job_destroy.argtypes = [C.c_void_p]
     lib.dwgsim_hip_set_regions.argtypes = [C.c_void_p, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int, P(C.c_uint64)]
     lib.dwgsim_hip_contig_region_length.restype = C.c_int64
-    lib.dwgsim_hip_contig_region_length.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
+    lib.dwgsim_hip_contig_region_length.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, P(C.c_int64), P(C.c_int64)]
     lib.dwgsim_hip_contig_set_placement_length.argtypes = [C.c_void_p, C.c_int, C.c_int64]
     lib.dwgsim_hip_set_mutation_input.argtypes = [C.c_void_p, C.c_int, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int]
     lib.dwgsim_hip_mutate_contig.argtypes = [C.c_void_p, C.c_int]
@@ -353,7 +365,7 @@ class Context:
     def region_length(self, contig_index: int, ascii_arr) -> int:
         import numpy as np
         arr = np.ascontiguousarray(ascii_arr, dtype=np.uint8)
-        return self.lib.dwgsim_hip_contig_region_length(self.h, contig_index, arr.ctypes.data_as(C.c_void_p), len(arr))
+        return self.lib.dwgsim_hip_contig_region_length(self.h, contig_index, arr.ctypes.data_as(C.c_void_p), len(arr), None, None)
 
     def set_placement_length(self, cid: int, l: int):
         self._chk(self.lib.dwgsim_hip_contig_set_placement_length(self.h, cid, l))
@@ -616,7 +628,7 @@ def run_job_api(params: Params, contigs, devices=None, gzip_on_gpu: bool = True,
         for name, arr in contigs:
             a = np.ascontiguousarray(arr, dtype=np.uint8)
             r = lib.dwgsim_hip_job_add_contig(job, name.encode(), a.ctypes.data_as(C.c_void_p), len(a))
-            if r < 0 and r not in (-2, -3, -4, -5, -10, -11):
+            if r < 0 and not is_skip(r):      # a real error: stop feeding the job
                 chk(r)
             if r > 0:
                 res.n_pairs += r

@@ -63,6 +63,7 @@ struct Group {
     int walk_attempt = 0; uint32_t walk_cap = 0; size_t walk_cap_bases = 0; bool walk_reset = false;
     uint32_t n_patch = 0, n_patch_ev = 0;       // file-driven mutations: patched cells / indel events
     hipEvent_t ev_walk = nullptr;
+    uint64_t *h_wc = nullptr;        // page-locked mirror of the walk's counters (the context's d_wcounters) at the end of THIS group's walk: several groups' walks can be in flight
     // the mutated cells of the finished walk, fetched once for mutations_text
     bool list_valid = false; std::vector<int32_t> pos; std::vector<uint32_t> cells; HostIns ins[2];
 };
@@ -116,7 +117,7 @@ struct dwgsim_hip_ctx {
     Regions regions; bool has_regions = false;                           // -x
     DevBuf flow_scratch;
     uint64_t *d_counters = nullptr, *h_counters = nullptr;          // N_COUNTERS x u64 + pinned mirror: calibrate / count_random / debug hooks (compute stream)
-    uint64_t *d_wcounters = nullptr, *h_wcounters = nullptr;        // 16 x u64 + pinned mirror: the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
+    uint64_t *d_wcounters = nullptr;                                // 16 x u64 (mirrored per group: Group::h_wc): the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
     uint64_t *d_pcounters = nullptr, *h_pcounters = nullptr;        // N_COUNTERS x u64 + pinned mirror: count_random (walk stream)
     Slot slot[2];                            // simulate(): two batches in flight (kernels of one overlap the copy-out of the other)
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
@@ -204,6 +205,7 @@ void free_group(Group &g)
     for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]); hipFree(g.d_ins_bases[h]); hipFree(g.d_summ[h]); }
     hipFree(g.d_names); hipFree(g.d_reg); hipFree(g.d_seg);
     if (g.ev_walk) hipEventDestroy(g.ev_walk);
+    if (g.h_wc) hipHostFree(g.h_wc);
     g = Group();
 }
 
@@ -278,10 +280,10 @@ int64_t dwgsim_hip_pairs_for_contig(const dwgsim_hip_params_t *p, int64_t l, uin
         if (p->N - n_sim_so_far < n_pairs) n_pairs = p->N - n_sim_so_far;
     } else n_pairs = (int64_t)(uint64_t)(l * p->C / ((long double)(size0 + size1)) / (1.0 - p->rand_read) + 0.5);   // :589
     const int max_len = size0 > size1 ? size0 : size1;
-    if (p->amplicons == 1) { if (l < max_len) return -2; }                                          // #2 :596-603
-    else if (0 < size1 && l < p->dist + 3 * p->std_dev) return -3;                                 // #3 :605-611
-    else if (l < size0 || (0 < size1 && l < size1)) return -4;                                     // #4 :612-618
-    return n_pairs < 0 ? -5 : n_pairs;
+    if (p->amplicons == 1) { if (l < max_len) return DWGSIM_HIP_SKIP_AMPLICON; }                                          // #2 :596-603
+    else if (0 < size1 && l < p->dist + 3 * p->std_dev) return DWGSIM_HIP_SKIP_SHORT_INSERT;                                 // #3 :605-611
+    else if (l < size0 || (0 < size1 && l < size1)) return DWGSIM_HIP_SKIP_SHORT_READ;                                     // #4 :612-618
+    return n_pairs < 0 ? DWGSIM_HIP_SKIP_NO_PAIRS : n_pairs;
 }
 
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes)
@@ -390,7 +392,6 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_wcounters, 16 * sizeof(uint64_t)));
-        HIPC(c, hipHostMalloc((void **)&c->h_wcounters, 16 * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_pcounters, N_COUNTERS * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_pcounters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_chain, 4 * sizeof(uint64_t)));
@@ -531,7 +532,6 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
-    if (c->h_wcounters) hipHostFree(c->h_wcounters);
     if (c->h_pcounters) hipHostFree(c->h_pcounters);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_up) hipHostFree(c->h_up);
@@ -551,6 +551,13 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
 }
 
 const char *dwgsim_hip_last_error(const dwgsim_hip_ctx_t *c) { return c ? c->err.c_str() : "no context"; }
+
+int dwgsim_hip_get_params(const dwgsim_hip_ctx_t *c, dwgsim_hip_params_t *out)
+{
+    if (!c || !out) return DWGSIM_HIP_ERR_ARG;
+    *out = c->prm;      // (read_prefix / flow_order were cleared when the context took its copies)
+    return DWGSIM_HIP_OK;
+}
 
 static bool is_page_locked(const void *p)
 {
@@ -580,6 +587,7 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
     bool synced = true;
     auto fill = [&]() -> int {
         HIPC(c, hipEventCreate(&g.ev_walk));
+        HIPC(c, hipHostMalloc((void **)&g.h_wc, 16 * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&g.d_ref, padded));
         for (int h = 0; h < 2; ++h) { HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32)); }
         if (ensure(c, c->up_ascii, padded)) return DWGSIM_HIP_ERR_DEVICE;
@@ -690,8 +698,10 @@ int dwgsim_hip_set_regions(dwgsim_hip_ctx_t *c, const char *path, const char *co
     return DWGSIM_HIP_OK;
 }
 
-int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *c, uint32_t contig_index, const uint8_t *ascii, int64_t len)
+int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *c, uint32_t contig_index, const uint8_t *ascii, int64_t len, int64_t *non_acgt, int64_t *region_bases)
 {
+    if (non_acgt) *non_acgt = 0;
+    if (region_bases) *region_bases = len;
     if (!c || !c->has_regions) return len;
     int64_t m = 0, num_n = 0;
     for (size_t q = 0; q < c->regions.contig.size(); ++q) if (c->regions.contig[q] == contig_index) {
@@ -700,8 +710,10 @@ int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *c, uint32_t contig_ind
         // s[-1] for start == 0 is out of bounds there and is counted as non-ACGT here
         for (int64_t p = c->regions.start[q]; p <= (int64_t)c->regions.end[q]; ++p) { const int ch = (p >= 1 && p - 1 < len) ? ascii[p - 1] : 'N'; if (nt4(ch) >= 4) ++num_n; }
     }
-    if (m == 0) return -10;
-    if (0.95 < num_n / (double)m) return -11;
+    if (non_acgt) *non_acgt = num_n;
+    if (region_bases) *region_bases = m;
+    if (m == 0) return DWGSIM_HIP_SKIP_NO_REGION;
+    if (0.95 < num_n / (double)m) return DWGSIM_HIP_SKIP_NON_ACGT;
     return m;
 }
 
@@ -774,7 +786,7 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
         }
         launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.d_view[0], g.d_view[1]);
         HIPC(c, hipGetLastError());
-        HIPC(c, hipMemcpyAsync(&c->h_wcounters[12], &c->d_wcounters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(&g.h_wc[12], &c->d_wcounters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIPC(c, hipEventRecord(g.ev_walk, st));
         return DWGSIM_HIP_OK;
     }
@@ -829,7 +841,7 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
     else launch_justify(st, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
     launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.d_view[0], g.d_view[1]);
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(&c->h_wcounters[7], &c->d_wcounters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));      // [7] candidates, [8..11] the eight words
+    HIPC(c, hipMemcpyAsync(&g.h_wc[7], &c->d_wcounters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));      // [7] candidates, [8..11] the eight words
     HIPC(c, hipEventRecord(g.ev_walk, st));
     return DWGSIM_HIP_OK;
 }
@@ -840,6 +852,8 @@ int dwgsim_hip_mutate_async(dwgsim_hip_ctx_t *c, int contig)
     if (!gp) return DWGSIM_HIP_ERR_ARG;
     Group &g = *gp;
     if (g.walk_pending) { c->err = "mutate: the group's previous walk was not waited for"; return DWGSIM_HIP_ERR_STATE; }
+    // (walks of several groups may be in flight: they run one after the other on the walk stream and share its device scratch in stream order;
+    // what the host reads back afterwards -- counts, mut_debug verdicts -- lands in the group's own page-locked mirror g.h_wc)
     for (const Slot &sl : c->slot) if (sl.pending && sl.group == c->handles[(size_t)contig].group) { c->err = "mutate: a batch that reads this group is still in flight (wait for it first)"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
     g.walk_reset = g.mutated;      // walked before: the cells start again from the resident packed reference
@@ -848,6 +862,7 @@ int dwgsim_hip_mutate_async(dwgsim_hip_ctx_t *c, int contig)
     g.walk_attempt = 0;
     if (g.total == 0) return DWGSIM_HIP_OK;
     if (c->has_mutin) {      // patches, indel events and insertion tables of the whole group, in group coordinates
+        HIPC(c, hipStreamSynchronize(c->walk_stream));      // (an earlier group's walk may still be copying from the host lists below)
         c->h_ppos.clear(); c->h_pcells.clear(); c->h_pev.clear();
         HostIns hi[2];
         for (size_t k = 0; k < g.m.size(); ++k) {
@@ -907,10 +922,10 @@ int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *c, int contig)
         HIPC(c, hipEventSynchronize(g.ev_walk));
         if (c->has_mutin) {
             g.walk_pending = false;
-            return g.n_patch ? mut_debug_verdict(c, g, c->h_wcounters[12], c->h_wcounters[13]) : DWGSIM_HIP_OK;
+            return g.n_patch ? mut_debug_verdict(c, g, g.h_wc[12], g.h_wc[13]) : DWGSIM_HIP_OK;
         }
-        const uint64_t n_cand = c->h_wcounters[7];
-        const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&c->h_wcounters[8]);
+        const uint64_t n_cand = g.h_wc[7];
+        const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&g.h_wc[8]);
         const bool fits = n_cand <= g.walk_cap && h_small[2] <= g.cap_bases[0] && h_small[4] <= g.cap_bases[1];
         if (fits || g.walk_attempt >= 2) {
             g.walk_pending = false;
@@ -979,9 +994,9 @@ int fetch_mutated_list(dwgsim_hip_ctx_t *c, Group &g)
         uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
         launch_collect_mask(st, g.d_cells[0], g.d_cells[1], g.total, d_mask, d_cnt);
         launch_scan_excl(st, d_cnt, nblk, &c->d_wcounters[14]);
-        HIPC(c, hipMemcpyAsync(&c->h_wcounters[14], &c->d_wcounters[14], sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(&g.h_wc[14], &c->d_wcounters[14], sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIPC(c, hipStreamSynchronize(st));
-        const uint32_t n = (uint32_t)c->h_wcounters[14];
+        const uint32_t n = (uint32_t)g.h_wc[14];
         if (n) {
             if (ensure(c, c->l_pos, sizeof(int32_t) * (size_t)n) || ensure(c, c->l_cells, sizeof(uint32_t) * (size_t)n)) return DWGSIM_HIP_ERR_DEVICE;
             launch_compact(st, d_mask, d_cnt, (int32_t *)c->l_pos.p, g.total, n);

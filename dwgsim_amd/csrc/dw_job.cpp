@@ -17,6 +17,8 @@
 #include <string.h>
 #include <stdint.h>
 #include <stdarg.h>
+#include <limits.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <deque>
@@ -53,6 +55,7 @@ struct GroupJob {
     std::vector<std::array<uint64_t, 4>> fail_seg; std::vector<uint64_t> got_rand;
     std::vector<BatchOut> out;
     int batches_done = 0; bool closed = false;
+    int joined = 0; uint64_t fail_acc[4] = {0, 0, 0, 0};          // abort rule: batches 0 .. joined-1 are simulated and their summaries joined, in order
     int mut_done = 0;                                             // (device 0) mutation text delivered
 };
 
@@ -72,7 +75,9 @@ struct dwgsim_hip_job {
     // staging of the sequence: page-locked buffers handed from the adding thread to the device workers
     static constexpr int N_STAGE = 3;
     uint8_t *stage[N_STAGE] = {nullptr, nullptr, nullptr}; size_t stage_cap[N_STAGE] = {0, 0, 0}; bool stage_busy[N_STAGE] = {false, false, false};
+    size_t stage_want = 0;        // from the contig table: room for the largest group, so that a staging buffer is page-locked once
     std::shared_ptr<GroupJob> pending; size_t pending_bytes = 0;           // the group being filled
+    struct Open { bool open = false; std::string name; int64_t l = 0, st = 0, total = 0; uint32_t ci = 0; } open;      // the contig between begin_contig and commit_contig
     // shared state
     std::mutex m; std::condition_variable cv;
     std::deque<std::shared_ptr<GroupJob>> groups;      // dispatched, not yet retired (front = oldest)
@@ -94,6 +99,12 @@ void job_fail(dwgsim_hip_job *j, const std::string &what)
     std::lock_guard<std::mutex> g(j->m);
     if (!j->failed.exchange(true)) j->err = what;
     j->cv.notify_all();
+}
+
+int arg_error(dwgsim_hip_job *j, int code, const char *what)      // a call that is refused: the text for last_error, the job itself goes on
+{
+    if (j) { std::lock_guard<std::mutex> g(j->m); if (!j->failed.load()) j->err = what; }
+    return code;
 }
 
 void say(dwgsim_hip_job *j, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -268,16 +279,25 @@ struct Worker {
                 }
                 if (dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
             }
-            std::lock_guard<std::mutex> lk(j->m);
-            for (int q = 0; q < 4; ++q) g->fail_seg[(size_t)pb.b][(size_t)q] = bt.fail_seg[q];
-            g->got_rand[(size_t)pb.b] = bt.n_random;
-            bo.ready = true;
-            if (bo.left == 0 && bo.buf) { j->free_bufs[(size_t)d].push_back(bo.buf); bo.buf = nullptr; }
-            g->out[(size_t)pb.b] = bo;
-            ++g->batches_done;
-            j->delivered_pairs += bt.n_pairs;
-            if (!j->opt.quiet) { char t[64]; snprintf(t, sizeof t, "\r[dwgsim_core] %llu", (unsigned long long)j->delivered_pairs); if (j->sink.message) j->sink.message(j->sink.user, t); else fputs(t, stderr); }
-            j->cv.notify_all();
+            uint64_t shown = 0; bool aborted = false;
+            {
+                std::lock_guard<std::mutex> lk(j->m);
+                for (int q = 0; q < 4; ++q) g->fail_seg[(size_t)pb.b][(size_t)q] = bt.fail_seg[q];
+                g->got_rand[(size_t)pb.b] = bt.n_random;
+                bo.ready = true;
+                if (bo.left == 0 && bo.buf) { j->free_bufs[(size_t)d].push_back(bo.buf); bo.buf = nullptr; }
+                g->out[(size_t)pb.b] = bo;
+                ++g->batches_done;
+                // the abort rule (dwgsim.c:635, :833-843) over the batches of several devices: the summaries are joined in read-index order as soon
+                // as the batches in front are complete -- a batch goes to the sink only behind its verdict (deliver_loop waits for `joined`)
+                while (!aborted && g->joined < (int)g->out.size() && g->out[(size_t)g->joined].ready) {
+                    if (dwgsim_hip_failseg_join(g->fail_acc, g->fail_seg[(size_t)g->joined].data())) aborted = true; else ++g->joined;
+                }
+                shown = (j->delivered_pairs += bt.n_pairs);
+                j->cv.notify_all();
+            }
+            if (aborted) { job_fail(j, "\r[dwgsim_core] failed to generate a read after 10001 trials\n"); return false; }
+            if (!j->opt.quiet) { char t[64]; snprintf(t, sizeof t, "\r[dwgsim_core] %llu", (unsigned long long)shown); if (j->sink.message) j->sink.message(j->sink.user, t); else fputs(t, stderr); }      // (outside the lock: a sink may call back into the job)
             return true;
         };
         int kk = 0;
@@ -321,7 +341,7 @@ void deliver_loop(dwgsim_hip_job *j, int s)
             BatchOut bo;
             {
                 std::unique_lock<std::mutex> lk(j->m);
-                j->cv.wait(lk, [&]() { return j->failed.load() || g->out[(size_t)b].ready; });
+                j->cv.wait(lk, [&]() { return j->failed.load() || g->joined > b; });      // simulated, and the abort rule's verdict over everything up to it is in
                 if (j->failed.load()) return;
                 bo = g->out[(size_t)b];
             }
@@ -336,20 +356,17 @@ void deliver_loop(dwgsim_hip_job *j, int s)
     }
 }
 
-// the group is complete when every batch was simulated: join the abort rule's summaries in read-index order (dwgsim.c:635, :833-843) and retire it
+// the group is complete when every batch was simulated (finish_batch has joined the abort rule's summaries by then) and delivered: retire it
 void retire_loop_step(dwgsim_hip_job *j)      // j->m held
 {
     while (!j->groups.empty()) {
         auto &g = j->groups.front();
         const int nb = j->want_reads ? (int)g->batches.size() : 0;
-        bool delivered = g->batches_done >= nb;
+        bool delivered = g->batches_done >= nb && g->joined >= nb;
         for (int b = 0; b < nb && delivered; ++b) if (!g->out[(size_t)b].ready || g->out[(size_t)b].left > 0) delivered = false;
         bool all_taken = true;
         for (int d = 0; d < j->ND; ++d) if (j->next_group[(size_t)d] <= g->id) all_taken = false;
         if (!delivered || !all_taken || g->stage_users > 0) break;
-        uint64_t acc[4] = {0, 0, 0, 0}; bool aborted = false;
-        for (int b = 0; b < nb && !aborted; ++b) if (dwgsim_hip_failseg_join(acc, g->fail_seg[(size_t)b].data())) aborted = true;
-        if (aborted && !j->failed.exchange(true)) j->err = "\r[dwgsim_core] failed to generate a read after 10001 trials\n";
         if (j->ND == 1) for (uint64_t r : g->got_rand) j->total_rand += r;
         j->groups.pop_front();
     }
@@ -359,6 +376,11 @@ int dispatch_pending(dwgsim_hip_job *j)
 {
     if (!j->pending) return DWGSIM_HIP_OK;
     auto g = j->pending; j->pending.reset(); j->pending_bytes = 0;
+    if (g->names.empty()) {      // every contig that was begun for it was skipped: only the staging goes back
+        std::lock_guard<std::mutex> lk(j->m);
+        j->stage_busy[g->stage_slot] = false; j->cv.notify_all();
+        return DWGSIM_HIP_OK;
+    }
     // the group's pairs in file order, cut into batches; batch b belongs to device b mod nd
     g->pairs = 0; for (int64_t n : g->n_pairs) g->pairs += (uint64_t)n;
     g->nd = j->ND;
@@ -403,14 +425,14 @@ int start_threads(dwgsim_hip_job *j)
         if (!j->regions_path.empty()) {      // dwgsim.c:499-506
             std::vector<const char *> nm; for (auto &s : j->tab_names) nm.push_back(s.c_str());
             uint64_t tl = 0;
-            if (dwgsim_hip_set_regions(j->ctx[(size_t)d], j->regions_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size(), &tl) < 0) { j->err = dwgsim_hip_last_error(j->ctx[(size_t)d]); j->failed = true; return DWGSIM_HIP_ERR_ARG; }
+            if (dwgsim_hip_set_regions(j->ctx[(size_t)d], j->regions_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size(), &tl) < 0) { job_fail(j, dwgsim_hip_last_error(j->ctx[(size_t)d])); return DWGSIM_HIP_ERR_ARG; }
             j->tot_len = tl;
         }
         if (j->mutin_type >= 0) {            // dwgsim.c:494-497
             std::vector<const char *> nm; for (auto &s : j->tab_names) nm.push_back(s.c_str());
-            if (dwgsim_hip_set_mutation_input(j->ctx[(size_t)d], j->mutin_type, j->mutin_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size()) < 0) { j->err = dwgsim_hip_last_error(j->ctx[(size_t)d]); j->failed = true; return DWGSIM_HIP_ERR_ARG; }
+            if (dwgsim_hip_set_mutation_input(j->ctx[(size_t)d], j->mutin_type, j->mutin_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size()) < 0) { job_fail(j, dwgsim_hip_last_error(j->ctx[(size_t)d])); return DWGSIM_HIP_ERR_ARG; }
         }
-        if (j->gzip && j->want_reads && j->sink.reads && dwgsim_hip_set_gzip(j->ctx[(size_t)d], 1) < 0) { j->err = dwgsim_hip_last_error(j->ctx[(size_t)d]); j->failed = true; return DWGSIM_HIP_ERR_DEVICE; }
+        if (j->gzip && j->want_reads && j->sink.reads && dwgsim_hip_set_gzip(j->ctx[(size_t)d], 1) < 0) { job_fail(j, dwgsim_hip_last_error(j->ctx[(size_t)d])); return DWGSIM_HIP_ERR_DEVICE; }
     }
     for (int d = 0; d < j->ND; ++d) j->workers.emplace_back([j, d]() { Worker w{j, d, j->ctx[(size_t)d]}; w.run(); });
     if (j->want_reads && j->sink.reads) for (int s = 0; s < 3; ++s) j->deliver[s] = std::thread([j, s]() { deliver_loop(j, s); });
@@ -446,8 +468,14 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
     {   // one context per device, made side by side (a context costs about 0.1 s of runtime set-up, code objects and buffers)
         std::vector<int> errs((size_t)j->ND, 0);
         std::vector<std::thread> th;
-        for (int d = 1; d < j->ND; ++d) th.emplace_back([&, d]() { j->ctx[(size_t)d] = dwgsim_hip_create(&j->prm, devs[(size_t)d], &errs[(size_t)d]); });
-        j->ctx[0] = dwgsim_hip_create(&j->prm, devs[0], &errs[0]);
+        dwgsim_hip_params_t rest = j->prm;
+        const bool calibrates = j->prm.data_type == 2 && j->prm.use_base_error;      // -B (dwgsim_opt.c:415-457): once, on the first device; the others take its result
+        if (calibrates) {
+            j->ctx[0] = dwgsim_hip_create(&j->prm, devs[0], &errs[0]);
+            if (j->ctx[0] && dwgsim_hip_get_params(j->ctx[0], &rest) == DWGSIM_HIP_OK) { rest.use_base_error = 0; rest.read_prefix = j->prm.read_prefix; rest.flow_order = j->prm.flow_order; }
+        }
+        for (int d = 1; d < j->ND; ++d) th.emplace_back([&, d]() { j->ctx[(size_t)d] = dwgsim_hip_create(&rest, devs[(size_t)d], &errs[(size_t)d]); });
+        if (!calibrates) j->ctx[0] = dwgsim_hip_create(&j->prm, devs[0], &errs[0]);
         for (auto &t : th) t.join();
         for (int d = 0; d < j->ND; ++d)
             if (!j->ctx[(size_t)d]) {
@@ -466,74 +494,57 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
 
 int dwgsim_hip_job_set_contig_table(dwgsim_hip_job_t *j, const char *const *names, const int64_t *lens, int n)
 {
-    if (!j || n < 0 || (n && (!names || !lens)) || j->started) { if (j) j->err = "job: the contig table must be set once, before the first contig"; return DWGSIM_HIP_ERR_ARG; }
+    if (!j || n < 0 || (n && (!names || !lens)) || j->started) return arg_error(j, DWGSIM_HIP_ERR_ARG, "job: the contig table must be set once, before the first contig");
     j->tab_names.clear(); j->tab_lens.clear(); j->tot_len = 0;
     for (int i = 0; i < n; ++i) { j->tab_names.push_back(names[i]); j->tab_lens.push_back(lens[i]); j->tot_len += (uint64_t)lens[i]; }
     j->n_ref = n; j->have_table = true;
+    // room for the largest group (consecutive contigs up to group_bp, or one longer contig alone), so that each staging buffer is page-locked once
+    int64_t longest = 0; for (int i = 0; i < n; ++i) longest = std::max<int64_t>(longest, (lens[i] + 4095) / 4096 * 4096);
+    j->stage_want = (size_t)std::max<int64_t>(longest, (int64_t)std::min<uint64_t>(j->group_bp, (uint64_t)j->tot_len + 4096 * (uint64_t)n)) + 8192;
     return DWGSIM_HIP_OK;
 }
 
 int dwgsim_hip_job_set_regions(dwgsim_hip_job_t *j, const char *path)
 {
-    if (!j || !path || j->started) { if (j) j->err = "job: regions must be set before the first contig"; return DWGSIM_HIP_ERR_ARG; }
+    if (!j || !path || j->started) return arg_error(j, DWGSIM_HIP_ERR_ARG, "job: regions must be set before the first contig");
     j->regions_path = path;
     return DWGSIM_HIP_OK;
 }
 
 int dwgsim_hip_job_set_mutation_input(dwgsim_hip_job_t *j, int type, const char *path)
 {
-    if (!j || !path || type < 0 || type > 2 || j->started) { if (j) j->err = "job: the mutation input must be set before the first contig"; return DWGSIM_HIP_ERR_ARG; }
+    if (!j || !path || type < 0 || type > 2 || j->started) return arg_error(j, DWGSIM_HIP_ERR_ARG, "job: the mutation input must be set before the first contig");
     j->mutin_type = type; j->mutin_path = path;
     return DWGSIM_HIP_OK;
 }
 
 int dwgsim_hip_job_prepare(dwgsim_hip_job_t *j, uint64_t *total_len)
 {
-    if (!j || !j->have_table) { if (j) j->err = "job: set the contig table first"; return DWGSIM_HIP_ERR_STATE; }
+    if (!j || !j->have_table) return arg_error(j, DWGSIM_HIP_ERR_STATE, "job: set the contig table first");
     const int rc = start_threads(j);
     if (total_len) *total_len = j->tot_len;
     return rc;
 }
 
-int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *j, const char *name, const uint8_t *ascii, int64_t l)
+// The contig loop's body (dwgsim.c:519-625) in two halves, so that the caller can produce the sequence in place -- and with as many threads as it
+// likes: begin reserves the contig's bytes in the page-locked staging of the group being filled (group layout), commit schedules it.
+uint8_t *dwgsim_hip_job_begin_contig(dwgsim_hip_job_t *j, const char *name, int64_t l, int64_t *status)
 {
-    if (!j || !name || (!ascii && l > 0) || l < 0) { if (j) j->err = "job: bad contig arguments"; return DWGSIM_HIP_ERR_ARG; }
-    if (!j->have_table) { j->err = "job: set the contig table first (the reference reads it before the first contig: dwgsim.c:465-478)"; return DWGSIM_HIP_ERR_STATE; }
-    if (j->finished) { j->err = "job: already finished"; return DWGSIM_HIP_ERR_STATE; }
-    if (start_threads(j) < 0) return DWGSIM_HIP_ERR_FAILED;
-    if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
-    const dwgsim_hip_params_t &o = j->prm;
-    const uint32_t ci = j->next_index++;
-    --j->n_ref;
-    int64_t n_pairs = 0, l_eff = l;
-    if (j->want_reads) {      // dwgsim.c:535-625
-        const bool last_takes_rest = j->n_ref == 0 && o.C < 0;     // dwgsim.c:535-537
-        if (!j->regions_path.empty() && !last_takes_rest) {
-            l_eff = dwgsim_hip_contig_region_length(j->ctx[0], ci, ascii, l);
-            if (l_eff == -10) { say(j, "[dwgsim_core] #0 skip sequence '%s' as it is not in the targeted region\n", name); return -10; }
-            if (l_eff == -11) { say(j, "[dwgsim_core] #1 skip sequence '%s' as more than 95%% of its targeted bases are non-ACGT\n", name); return -11; }
-        }
-        n_pairs = dwgsim_hip_pairs_for_contig(&o, l_eff, j->tot_len, j->n_ref == 0, j->n_sim);
-        if (n_pairs < 0) {
-            if (!j->prev_skip) say(j, "\n");
-            j->prev_skip = 1;
-            if (n_pairs == -2) say(j, "[dwgsim_core] #2 skip sequence '%s' as it is shorter than the read length %d < %d!\n", name, (int)l, o.length[0] > o.length[1] ? o.length[0] : o.length[1]);
-            else if (n_pairs == -3) say(j, "[dwgsim_core] #3 skip sequence '%s' as it is shorter than %f!\n", name, o.dist + 3 * o.std_dev);
-            else if (n_pairs == -4) say(j, "[dwgsim_core] #4 skip sequence '%s' as it is shorter than %d!\n", name, (l < o.length[0]) ? o.length[0] : o.length[1]);
-            else say(j, "[dwgsim_core] #5 skip sequence '%s' as not enough pairs found\n", name);
-            return n_pairs;
-        }
-        j->prev_skip = 0;
-        j->n_sim += n_pairs;
-    }
+    auto out = [&](int64_t st) { if (status) *status = st; return (uint8_t *)nullptr; };
+    if (!j || !name || l < 0 || l > INT32_MAX) return out(arg_error(j, DWGSIM_HIP_ERR_ARG, "job: bad contig arguments"));
+    if (!j->have_table) return out(arg_error(j, DWGSIM_HIP_ERR_STATE, "job: set the contig table first (the reference reads it before the first contig: dwgsim.c:465-478)"));
+    if (j->finished) return out(arg_error(j, DWGSIM_HIP_ERR_STATE, "job: already finished"));
+    if (j->open.open) return out(arg_error(j, DWGSIM_HIP_ERR_STATE, "job: the previous contig was neither committed nor cancelled"));
+    if (start_threads(j) < 0) return out(DWGSIM_HIP_ERR_FAILED);
+    if (j->failed.load()) return out(DWGSIM_HIP_ERR_FAILED);
     // into the group being filled; a contig that would take it past the group size closes it first
     const int64_t aligned_len = (l + 4095) / 4096 * 4096;
-    if (j->pending && j->pending_bytes + (size_t)aligned_len > (size_t)j->group_bp) { if (dispatch_pending(j) < 0) return DWGSIM_HIP_ERR_FAILED; }
+    if (j->pending && j->pending_bytes + (size_t)aligned_len > (size_t)j->group_bp) { if (dispatch_pending(j) < 0) return out(DWGSIM_HIP_ERR_FAILED); }
     if (!j->pending) {
         auto g = std::make_shared<GroupJob>();
         std::unique_lock<std::mutex> lk(j->m);
         j->cv.wait(lk, [&]() { retire_loop_step(j); if (j->failed.load()) return true; for (int s = 0; s < dwgsim_hip_job::N_STAGE; ++s) if (!j->stage_busy[s]) return true; return false; });
-        if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
+        if (j->failed.load()) return out(DWGSIM_HIP_ERR_FAILED);
         for (int s = 0; s < dwgsim_hip_job::N_STAGE; ++s) if (!j->stage_busy[s]) { g->stage_slot = s; j->stage_busy[s] = true; break; }
         j->pending = g; j->pending_bytes = 0;
     }
@@ -544,23 +555,81 @@ int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *j, const char *name, const u
     const int64_t total = dwgsim_hip_group_layout(lens.data(), (int)lens.size(), starts.data());
     const int s = g.stage_slot;
     if ((size_t)total > j->stage_cap[s]) {      // grow, keeping what the group already holds
-        const size_t want = std::max<size_t>((size_t)total + (size_t)total / 4, (size_t)std::min<uint64_t>(j->group_bp, 256u << 20) + 8192);
+        const size_t want = std::max<size_t>((size_t)total + (size_t)total / 4, std::max<size_t>(j->stage_want, (size_t)std::min<uint64_t>(j->group_bp, 256u << 20) + 8192));
         uint8_t *nb = (uint8_t *)dwgsim_hip_host_alloc(want);
-        if (!nb) { j->err = "dwgsim-hip: cannot allocate page-locked host memory for the sequence"; j->failed = true; return DWGSIM_HIP_ERR_NOMEM; }
+        if (!nb) { job_fail(j, "dwgsim-hip: cannot allocate page-locked host memory for the sequence"); return out(DWGSIM_HIP_ERR_NOMEM); }
         if (j->stage[s] && j->pending_bytes) memcpy(nb, j->stage[s], j->pending_bytes);
         dwgsim_hip_host_free(j->stage[s]);
         j->stage[s] = nb; j->stage_cap[s] = want;
     }
     const int64_t st = starts.back();
     if ((size_t)st > j->pending_bytes) memset(j->stage[s] + j->pending_bytes, 0, (size_t)st - j->pending_bytes);      // zero bytes between the contigs
-    if (l > 0) memcpy(j->stage[s] + st, ascii, (size_t)l);
     if ((size_t)total > (size_t)(st + l)) memset(j->stage[s] + st + l, 0, (size_t)total - (size_t)(st + l));
-    j->pending_bytes = (size_t)total;
+    j->open.open = true; j->open.name = name; j->open.l = l; j->open.st = st; j->open.total = total; j->open.ci = j->next_index;
+    if (status) *status = DWGSIM_HIP_OK;
+    return j->stage[s] + st;
+}
+
+int dwgsim_hip_job_cancel_contig(dwgsim_hip_job_t *j)
+{
+    if (!j || !j->open.open) return arg_error(j, DWGSIM_HIP_ERR_STATE, "job: no contig is open");
+    j->open.open = false;      // (the reserved bytes are simply handed out again)
+    return DWGSIM_HIP_OK;
+}
+
+int64_t dwgsim_hip_job_commit_contig(dwgsim_hip_job_t *j)
+{
+    if (!j || !j->open.open) return arg_error(j, DWGSIM_HIP_ERR_STATE, "job: no contig is open");
+    j->open.open = false;
+    if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
+    GroupJob &g = *j->pending;
+    const int s = g.stage_slot;
+    const char *name = j->open.name.c_str(); const int64_t l = j->open.l;
+    const uint8_t *ascii = j->stage[s] + j->open.st;
+    const dwgsim_hip_params_t &o = j->prm;
+    const uint32_t ci = j->next_index++;
+    --j->n_ref;
+    int64_t n_pairs = 0, l_eff = l;
+    if (j->want_reads) {      // dwgsim.c:535-625
+        const bool last_takes_rest = j->n_ref == 0 && o.C < 0;     // dwgsim.c:535-537
+        if (!j->regions_path.empty() && !last_takes_rest) {
+            int64_t num_n = 0, m = 0;
+            l_eff = dwgsim_hip_contig_region_length(j->ctx[0], ci, ascii, l, &num_n, &m);
+            if (l_eff == DWGSIM_HIP_SKIP_NO_REGION) { say(j, "[dwgsim_core] #0 skip sequence '%s' as it is not in the targeted region\n", name); return l_eff; }
+            if (l_eff == DWGSIM_HIP_SKIP_NON_ACGT) { say(j, "[dwgsim_core] #1 skip sequence '%s' as %d out of %d bases are non-ACGT\n", name, (int)num_n, (int)m); return l_eff; }      // dwgsim.c:575
+        }
+        n_pairs = dwgsim_hip_pairs_for_contig(&o, l_eff, j->tot_len, j->n_ref == 0, j->n_sim);
+        if (n_pairs < 0) {
+            if (!j->prev_skip) say(j, "\n");
+            j->prev_skip = 1;
+            // (the reference prints its `l`, which is the region length once -x is in force: dwgsim.c:552, :601, :615)
+            if (n_pairs == DWGSIM_HIP_SKIP_AMPLICON) say(j, "[dwgsim_core] #2 skip sequence '%s' as it is shorter than the read length %d < %d!\n", name, (int)l_eff, o.length[0] > o.length[1] ? o.length[0] : o.length[1]);
+            else if (n_pairs == DWGSIM_HIP_SKIP_SHORT_INSERT) say(j, "[dwgsim_core] #3 skip sequence '%s' as it is shorter than %f!\n", name, o.dist + 3 * o.std_dev);
+            else if (n_pairs == DWGSIM_HIP_SKIP_SHORT_READ) say(j, "[dwgsim_core] #4 skip sequence '%s' as it is shorter than %d!\n", name, (l_eff < o.length[0]) ? o.length[0] : o.length[1]);
+            else say(j, "[dwgsim_core] #5 skip sequence '%s' as not enough pairs found\n", name);
+            return n_pairs;
+        }
+        j->prev_skip = 0;
+        j->n_sim += n_pairs;
+    }
+    j->pending_bytes = (size_t)j->open.total;
     g.names.push_back(name); g.lens.push_back(l); g.l_eff.push_back(l_eff); g.n_pairs.push_back(n_pairs); g.cindex.push_back(ci);
+    std::vector<int64_t> starts(g.lens.size());
+    (void)dwgsim_hip_group_layout(g.lens.data(), (int)g.lens.size(), starts.data());
     g.ptrs.clear();
     for (size_t k = 0; k < g.lens.size(); ++k) g.ptrs.push_back(j->stage[s] + starts[k]);
     if (j->pending_bytes >= (size_t)j->group_bp) { if (dispatch_pending(j) < 0) return DWGSIM_HIP_ERR_FAILED; }
     return n_pairs;
+}
+
+int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *j, const char *name, const uint8_t *ascii, int64_t l)
+{
+    if (j && !ascii && l > 0) return arg_error(j, DWGSIM_HIP_ERR_ARG, "job: bad contig arguments");
+    int64_t st = 0;
+    uint8_t *dst = dwgsim_hip_job_begin_contig(j, name, l, &st);
+    if (!dst) return st;
+    if (l > 0) memcpy(dst, ascii, (size_t)l);
+    return dwgsim_hip_job_commit_contig(j);
 }
 
 int dwgsim_hip_job_finish(dwgsim_hip_job_t *j)

@@ -154,30 +154,161 @@ struct FastaParser {
 static bool read_fasta(const char *fn, const std::function<bool(const std::string &, std::vector<uint8_t> &)> &on_record, const std::function<int64_t(size_t)> &expect = nullptr)
 {
     FastaParser ps(on_record, expect);
+    std::vector<char> buf((size_t)1 << 24);
     if (strcmp(fn, "-")) {
         const int fd = open(fn, O_RDONLY);
         if (fd < 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn); return false; }
-        struct stat st;
-        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) {
-                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-                const size_t piece = (size_t)1 << 26;
-                for (size_t off = 0; off < (size_t)st.st_size && ps.go; off += piece) ps.feed((const char *)m + off, std::min(piece, (size_t)st.st_size - off));
-                munmap(m, (size_t)st.st_size); close(fd);
-                return ps.finish();
-            }
-        }
-        std::vector<char> buf((size_t)1 << 24);
         ssize_t n;
         while (ps.go && (n = read(fd, buf.data(), buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
         close(fd);
         return ps.finish();
     }
-    std::vector<char> buf((size_t)1 << 24);
     size_t n;
     while (ps.go && (n = fread(buf.data(), 1, buf.size(), stdin)) > 0) ps.feed(buf.data(), n);
     return ps.finish();
+}
+
+// ---- the reader of a regular file: mapped, indexed, and parsed by all host cores ----
+// The reference reads the FASTA with one fgetc per character on one thread (mut.c:49-87) in front of a loop that needs minutes per chromosome;
+// here the GPUs take a chromosome in a tenth of a second, and one thread parsing 3 GB of text was what a whole-genome run waited for.  So:
+//   1. every '>' of the mapped file is found by memchr, all cores side by side; a '>' opens a record unless it stands in a header line
+//      (FastaParser above: state 1 / 2), which a sequential pass over the (few) candidates settles -> records [header | body);
+//   2. a body is REGULAR when every line holds the same number L of letters followed by '\n' and the last one 1 .. L letters with or without
+//      '\n' -- what every FASTA writer produces.  Then the sequence length and the place of every base follow from the byte count, and the lines
+//      are verified (letters only, '\n' where it must be) and copied by all cores straight into the job's page-locked staging
+//      (dwgsim_hip_job_begin_contig / commit_contig): the sequence is touched once;
+//   3. a body that is not (blank lines, '\r', '-' or '.', ragged lines: the verification says so) goes through FastaParser, the
+//      reference's own state machine -- same bytes as before, on one thread.
+class Pool {
+public:
+    explicit Pool(unsigned n) { for (unsigned t = 1; t < (n ? n : 1); ++t) th_.emplace_back([this]() { work(); }); }
+    ~Pool() { { std::lock_guard<std::mutex> g(m_); stop_ = true; } cv_.notify_all(); for (auto &t : th_) t.join(); }
+    unsigned size() const { return (unsigned)th_.size() + 1; }
+    void run(size_t n_tasks, const std::function<void(size_t)> &fn)      // fn(0 .. n_tasks-1), the caller works too; returns when all are done
+    {
+        if (n_tasks == 0) return;
+        { std::lock_guard<std::mutex> g(m_); fn_ = &fn; next_ = 0; n_ = n_tasks; left_ = n_tasks; ++gen_; }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&]() { return left_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void drain()
+    {
+        for (;;) {
+            size_t i; const std::function<void(size_t)> *f;
+            { std::lock_guard<std::mutex> g(m_); if (!fn_ || next_ >= n_) return; i = next_++; f = fn_; }
+            (*f)(i);
+            { std::lock_guard<std::mutex> g(m_); if (--left_ == 0) done_.notify_all(); }
+        }
+    }
+    void work()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&]() { return stop_ || gen_ != seen; }); if (stop_) return; seen = gen_; }
+            drain();
+        }
+    }
+    std::mutex m_; std::condition_variable cv_, done_; std::vector<std::thread> th_;
+    const std::function<void(size_t)> *fn_ = nullptr; size_t next_ = 0, n_ = 0, left_ = 0; uint64_t gen_ = 0; bool stop_ = false;
+};
+
+struct FastaRecord { size_t gt = 0, body = 0, end = 0; std::string name; };      // '>' | first byte behind the header line | one past the record
+
+struct MappedFasta {
+    const char *p = nullptr; size_t n = 0; int fd = -1;
+    std::vector<FastaRecord> rec;
+    ~MappedFasta() { if (p) munmap((void *)p, n); if (fd >= 0) close(fd); }
+    bool open_file(const char *fn)
+    {
+        fd = open(fn, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return false;
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const char *)m; n = (size_t)st.st_size;
+        return true;
+    }
+    void index(Pool &pool)
+    {
+        const size_t piece = (size_t)8 << 20, np = (n + piece - 1) / piece;
+        std::vector<std::vector<size_t>> found(np);
+        pool.run(np, [&](size_t k) {
+            const size_t lo = k * piece, hi = std::min(n, lo + piece);
+            for (const char *q = p + lo; q < p + hi;) { const char *g = (const char *)memchr(q, '>', (size_t)(p + hi - q)); if (!g) break; found[k].push_back((size_t)(g - p)); q = g + 1; }
+        });
+        size_t header_end = 0;      // one past the header line of the record that is open
+        for (const auto &v : found) for (size_t g : v) {
+            if (!rec.empty() && g < header_end) continue;      // inside a header line: part of the name, or ignored (FastaParser states 1 / 2)
+            if (!rec.empty()) rec.back().end = g;
+            FastaRecord r; r.gt = g;
+            const char *nl = (const char *)memchr(p + g, '\n', n - g);
+            header_end = nl ? (size_t)(nl - p) + 1 : n;
+            r.body = header_end; r.end = n;
+            for (size_t q = g + 1; q < header_end; ++q) { const char c = p[q]; if (c == ' ' || c == '\t' || c == '\n') break; if (c != '\r') r.name.push_back(c); }
+            rec.push_back(std::move(r));
+        }
+    }
+    // a regular body: L letters per line, `len` letters in all; false: not of that shape on the face of it (the lines themselves are verified by fill)
+    bool geometry(const FastaRecord &r, size_t *L, int64_t *len) const
+    {
+        const size_t nb = r.end - r.body;
+        if (nb == 0) { *L = 1; *len = 0; return true; }
+        const char *b = p + r.body;
+        const char *nl = (const char *)memchr(b, '\n', nb);
+        const size_t l0 = nl ? (size_t)(nl - b) : nb;
+        if (l0 == 0) return false;
+        const size_t q = nb / (l0 + 1), rem = nb % (l0 + 1);
+        size_t last = rem;                                      // bytes of a last, shorter line
+        if (rem && b[nb - 1] == '\n') { if (rem == 1) return false; last = rem - 1; }
+        *L = l0; *len = (int64_t)(q * l0 + last);
+        return true;
+    }
+    // verifies and copies a regular body into dst[0 .. len); false: some line is not what the geometry says (dst is then garbage)
+    bool fill(const FastaRecord &r, size_t L, int64_t len, uint8_t *dst, Pool &pool) const
+    {
+        if (len == 0) return true;
+        const char *b = p + r.body;
+        const size_t nb = r.end - r.body, full = nb / (L + 1), rem = nb % (L + 1), last = (size_t)len - full * L;
+        const size_t per = std::max<size_t>(1, ((size_t)4 << 20) / (L + 1)), nt = (full + per - 1) / per;
+        std::atomic<bool> ok{true};
+        pool.run(nt, [&](size_t k) {
+            const size_t i0 = k * per, i1 = std::min(full, i0 + per);
+            for (size_t i = i0; i < i1 && ok.load(std::memory_order_relaxed); ++i) {
+                const char *ln = b + i * (L + 1);
+                if (ln[L] != '\n' || !FastaParser::all_letters(ln, L)) { ok = false; return; }
+                memcpy(dst + i * L, ln, L);
+            }
+        });
+        if (!ok) return false;
+        if (last) {
+            const char *ln = b + full * (L + 1);
+            if (!FastaParser::all_letters(ln, last) || (rem == last + 1 && ln[last] != '\n')) return false;
+            memcpy(dst + full * L, ln, last);
+        }
+        return true;
+    }
+    // the reference's state machine over one record (irregular bodies)
+    void parse_generic(const FastaRecord &r, std::vector<uint8_t> &seq) const
+    {
+        std::string nm;
+        const std::function<bool(const std::string &, std::vector<uint8_t> &)> take = [&](const std::string &, std::vector<uint8_t> &s) { seq.swap(s); return true; };
+        const std::function<int64_t(size_t)> none;
+        FastaParser ps(take, none);
+        ps.feed(p + r.gt, r.end - r.gt);
+        ps.finish();
+    }
+};
+
+static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t n, Pool &pool)
+{
+    const size_t piece = (size_t)8 << 20, np = (n + piece - 1) / piece;
+    if (np <= 1) { if (n) memcpy(dst, src, n); return; }
+    pool.run(np, [&](size_t k) { const size_t lo = k * piece; memcpy(dst + lo, src + lo, std::min(piece, n - lo)); });
 }
 
 static bool deflate_member(const char *src, size_t n, int level, std::vector<unsigned char> &out)
@@ -373,13 +504,31 @@ int main(int argc, char **argv)
     // the VCF header, tot_len, n_ref and the table the mutation / region files are checked against): the FASTA is then read once, contig
     // after contig, each one handed to the GPUs as soon as it is complete.  Without an index the reference reads the FASTA twice; here it
     // is read once into memory and handed over from there.
+    // A regular file is mapped, its records are found by all cores, and their lines are verified and copied by all cores (MappedFasta);
+    // anything else (stdin, a pipe) goes through the sequential parser.
     std::vector<std::string> tab_names; std::vector<int64_t> tab_lens;
     std::vector<std::pair<std::string, std::vector<uint8_t>>> held; bool streaming = false;
+    unsigned read_threads = nthreads;
+    if (const char *e = getenv("DWGSIM_HIP_READ_THREADS")) { const int v = atoi(e); if (v >= 1) read_threads = (unsigned)v; }
+    Pool rpool(read_threads);
+    MappedFasta mf;
+    const bool mapped = strcmp(fn_fa, "-") != 0 && mf.open_file(fn_fa);
+    if (mapped) mf.index(rpool);
+    else if (strcmp(fn_fa, "-") != 0 && access(fn_fa, R_OK) != 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn_fa); return give_up(1); }
     if (FILE *fai = fopen((std::string(fn_fa) + ".fai").c_str(), "r")) {
         char nmbuf[4096]; int ll, d0, d1, d2;
         while (0 < fscanf(fai, "%4095s\t%d\t%d\t%d\t%d", nmbuf, &ll, &d0, &d1, &d2)) { tab_names.push_back(nmbuf); tab_lens.push_back(ll); }
         fclose(fai);
         streaming = true;
+    } else if (mapped) {
+        for (const FastaRecord &r : mf.rec) {
+            std::vector<uint8_t> seq; size_t L = 0; int64_t len = 0;
+            bool done = false;
+            if (mf.geometry(r, &L, &len)) { seq.resize((size_t)len); done = mf.fill(r, L, len, seq.data(), rpool); }
+            if (!done) mf.parse_generic(r, seq);
+            held.emplace_back(r.name, std::move(seq));
+        }
+        for (auto &r : held) { tab_names.push_back(r.first); tab_lens.push_back((int64_t)r.second.size()); }
     } else {
         if (!read_fasta(fn_fa, [&](const std::string &nm, std::vector<uint8_t> &seq) { held.emplace_back(nm, std::move(seq)); seq = std::vector<uint8_t>(); return true; })) return give_up(1);
         for (auto &r : held) { tab_names.push_back(r.first); tab_lens.push_back((int64_t)r.second.size()); }
@@ -420,13 +569,30 @@ int main(int argc, char **argv)
         if (rc == 0 && dwgsim_hip_job_prepare(job, nullptr) < 0) job_error();
     }
     const double t_ctx = now_s();
-    auto feed = [&](const std::string &nm, std::vector<uint8_t> &seq) -> bool {
-        const int64_t r = dwgsim_hip_job_add_contig(job, nm.c_str(), seq.data(), (int64_t)seq.size());
-        if (r < 0 && !(r <= -2 && r >= -5) && r != -10 && r != -11) { job_error(); return false; }
-        return true;
+    auto taken = [&](int64_t r) -> bool { if (r < 0 && !DWGSIM_HIP_IS_SKIP(r)) { job_error(); return false; } return true; };      // scheduled or skipped (a note was printed): go on; an error: stop feeding
+    auto feed = [&](const std::string &nm, std::vector<uint8_t> &seq) -> bool {      // a sequence that sits in memory: into the staging with all cores
+        int64_t st = 0;
+        uint8_t *dst = dwgsim_hip_job_begin_contig(job, nm.c_str(), (int64_t)seq.size(), &st);
+        if (!dst) return taken(st);
+        parallel_copy(dst, seq.data(), seq.size(), rpool);
+        return taken(dwgsim_hip_job_commit_contig(job));
     };
     if (rc == 0) {
-        if (streaming) { if (!read_fasta(fn_fa, feed, [&](size_t k) -> int64_t { return k < tab_lens.size() ? tab_lens[k] : 0; }) && rc == 0) rc = 1; }
+        if (streaming && mapped) {
+            for (const FastaRecord &r : mf.rec) {      // every record parsed where the upload will read it
+                size_t L = 0; int64_t len = 0; bool done = false, go = true;
+                if (mf.geometry(r, &L, &len)) {
+                    int64_t st = 0;
+                    uint8_t *dst = dwgsim_hip_job_begin_contig(job, r.name.c_str(), len, &st);
+                    if (!dst) { taken(st); break; }
+                    if (mf.fill(r, L, len, dst, rpool)) { done = true; go = taken(dwgsim_hip_job_commit_contig(job)); }
+                    else (void)dwgsim_hip_job_cancel_contig(job);
+                }
+                if (!done) { std::vector<uint8_t> seq; mf.parse_generic(r, seq); go = feed(r.name, seq); }
+                if (!go) break;
+            }
+        }
+        else if (streaming) { if (!read_fasta(fn_fa, feed, [&](size_t k) -> int64_t { return k < tab_lens.size() ? tab_lens[k] : 0; }) && rc == 0) rc = 1; }
         else for (auto &r : held) { if (!feed(r.first, r.second)) break; std::vector<uint8_t>().swap(r.second); }
     }
     const double t_fed = now_s();

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DWGSIM_HIP_ABI_VERSION 3
+#define DWGSIM_HIP_ABI_VERSION 4
 
 /* error codes (negative) */
 #define DWGSIM_HIP_OK            0
@@ -34,6 +34,17 @@ extern "C" {
 #define DWGSIM_HIP_ERR_UNSUP    -4   /* option outside the accelerated path (see DESIGN.md "out of scope") */
 #define DWGSIM_HIP_ERR_FAILED   -5   /* "failed to generate a read after %d trials" (dwgsim.c:837-840) */
 #define DWGSIM_HIP_ERR_STATE    -6   /* call order violated (e.g. simulate before mutate) */
+
+/* Why dwgsim_core() passes over a contig (dwgsim.c:539-625, the "[dwgsim_core] #k skip sequence" notes): returned in place of a pair count by
+ * dwgsim_hip_pairs_for_contig, dwgsim_hip_contig_region_length and dwgsim_hip_job_add_contig.  A range of their own, disjoint from the error
+ * codes above: a skipped contig is not a failure, and a failure must never be mistaken for a skipped contig. */
+#define DWGSIM_HIP_SKIP_NO_REGION    -100  /* #0: the contig is not in the targeted region (-x) */
+#define DWGSIM_HIP_SKIP_NON_ACGT     -101  /* #1: more than 95 % of its targeted bases are non-ACGT */
+#define DWGSIM_HIP_SKIP_AMPLICON     -102  /* #2: shorter than the read length (-a) */
+#define DWGSIM_HIP_SKIP_SHORT_INSERT -103  /* #3: shorter than dist + 3 std_dev */
+#define DWGSIM_HIP_SKIP_SHORT_READ   -104  /* #4: shorter than a read */
+#define DWGSIM_HIP_SKIP_NO_PAIRS     -105  /* #5: a negative pair count */
+#define DWGSIM_HIP_IS_SKIP(r) ((r) <= -100 && (r) >= -105)
 
 /* POD mirror of the dwgsim_opt_t fields read on the path (src/dwgsim_opt.h:21-60);
  * defaults are those of dwgsim_opt_init() (src/dwgsim_opt.c:40-80). */
@@ -102,7 +113,7 @@ void dwgsim_hip_params_default(dwgsim_hip_params_t *p);
 int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap);
 
 /* Pairs to simulate on a contig of length l: dwgsim.c:535-537, :582-590 and the skip rules
- * #2-#4 (:595-618).  Returns n_pairs (>= 0), or -2/-3/-4 for skip rule #2/#3/#4
+ * #2-#5 (:595-623).  Returns n_pairs (>= 0), or DWGSIM_HIP_SKIP_AMPLICON / _SHORT_INSERT / _SHORT_READ / _NO_PAIRS for skip rule #2 .. #5
  * (skipped contigs get no mutations either, dwgsim.c:605-611). */
 int64_t dwgsim_hip_pairs_for_contig(const dwgsim_hip_params_t *p, int64_t l, uint64_t tot_len,
                                     int is_last_contig, int64_t n_sim_so_far);
@@ -111,6 +122,9 @@ int64_t dwgsim_hip_pairs_for_contig(const dwgsim_hip_params_t *p, int64_t l, uin
  * device = HIP device ordinal.  Fails (NULL, *err set) when no GPU is present. */
 dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, int *err);
 void dwgsim_hip_destroy(dwgsim_hip_ctx_t *ctx);
+/* The parameters the context works with: those it was created from, with the error rates -B calibrated (dwgsim_opt.c:452-454: e.start = e.end =
+ * the scaled rate).  read_prefix / flow_order come back NULL (the context keeps its own copies). */
+int dwgsim_hip_get_params(const dwgsim_hip_ctx_t *ctx, dwgsim_hip_params_t *out);
 const char *dwgsim_hip_last_error(const dwgsim_hip_ctx_t *ctx);
 
 /* Replaces seq_read_fasta()'s result + nst_nt4_table lookup (mut.c:49-87, dwgsim.c:56-73):
@@ -141,8 +155,9 @@ int dwgsim_hip_set_regions(dwgsim_hip_ctx_t *ctx, const char *path, const char *
                            int n_contigs, uint64_t *total_len);
 
 /* dwgsim.c:539-581: the region length of a contig -- the `l` the reference then uses for pairs-per-contig, the skip rules
- * and fragment placement -- or -10 (skip #0: not in the targeted region) / -11 (skip #1: > 95 % non-ACGT). */
-int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *ctx, uint32_t contig_index, const uint8_t *ascii, int64_t len);
+ * and fragment placement -- or DWGSIM_HIP_SKIP_NO_REGION (skip #0) / DWGSIM_HIP_SKIP_NON_ACGT (skip #1: > 95 % non-ACGT).  non_acgt / region_bases
+ * (optional) receive the two numbers the reference prints with skip #1 (num_n and the region length, dwgsim.c:574-576). */
+int64_t dwgsim_hip_contig_region_length(dwgsim_hip_ctx_t *ctx, uint32_t contig_index, const uint8_t *ascii, int64_t len, int64_t *non_acgt, int64_t *region_bases);
 
 /* The `l` that sizes fragment placement on this contig (dwgsim.c:659-671): defaults to the contig length, or to its region
  * length once regions are set.  The reference's last contig in -N mode keeps the full length (dwgsim.c:535-537 bypasses the
@@ -288,9 +303,18 @@ int dwgsim_hip_job_set_mutation_input(dwgsim_hip_job_t *job, int type, const cha
 /* optional: parse the files above and start the device threads now (errors of -x / -m / -b / -v surface here instead of at the first contig) */
 int dwgsim_hip_job_prepare(dwgsim_hip_job_t *job, uint64_t *total_len);
 /* The body of the contig loop (dwgsim.c:519-625 and everything below it) for the next contig of the FASTA.  Returns the pairs scheduled for
- * it (>= 0) or why it is skipped (-2 .. -5 as dwgsim_hip_pairs_for_contig, -10 / -11 as dwgsim_hip_contig_region_length) or an error code.
+ * it (>= 0), or why it is skipped (DWGSIM_HIP_SKIP_*: test with DWGSIM_HIP_IS_SKIP), or an error code (DWGSIM_HIP_ERR_*: the job has failed, stop
+ * feeding it and call finish / last_error).
  * The sequence is copied: `ascii` is the caller's again when the call returns.  Blocks only when the devices are two groups behind. */
 int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *job, const char *name, const uint8_t *ascii, int64_t len);
+/* The same in two halves, for a caller that produces the sequence itself (seq_read_fasta, mut.c:49-87, with as many threads as it likes):
+ * begin returns where the contig's `len` sequence characters go -- page-locked staging of the job, already in the layout the upload needs, so
+ * nothing is copied again -- or NULL with *status = an error code; any threads of the caller fill [p, p + len); commit schedules the contig and
+ * returns what dwgsim_hip_job_add_contig returns; cancel hands the reservation back (e.g. the record turned out to have another length).  One
+ * contig can be open at a time; the pointer is valid until commit / cancel.  begin blocks only when the devices are two groups behind. */
+uint8_t *dwgsim_hip_job_begin_contig(dwgsim_hip_job_t *job, const char *name, int64_t len, int64_t *status);
+int64_t dwgsim_hip_job_commit_contig(dwgsim_hip_job_t *job);
+int dwgsim_hip_job_cancel_contig(dwgsim_hip_job_t *job);
 /* no more contigs: returns when everything has been delivered to the sink (DWGSIM_HIP_OK) or the job failed */
 int dwgsim_hip_job_finish(dwgsim_hip_job_t *job);
 const char *dwgsim_hip_job_last_error(const dwgsim_hip_job_t *job);

@@ -56,11 +56,11 @@ def test_pairs_per_contig_matches_reference_arithmetic(lib):
     assert api.pairs_for_contig(p, 4641652, 4641652, True, 0, lib) == 464165
     assert api.pairs_for_contig(p, 64444167, 64444167, True, 0, lib) == 6444417
     # skip rules #3 (shorter than d + 3 sigma), #4 (shorter than a read), #2 (amplicon shorter than read)
-    assert api.pairs_for_contig(p, 600, 10000, False, 0, lib) == -3
+    assert api.pairs_for_contig(p, 600, 10000, False, 0, lib) == api.SKIP_SHORT_INSERT
     q = api.parse_flags("-z 1 -N 100 -2 0 -1 70", lib)
-    assert api.pairs_for_contig(q, 50, 1000, False, 0, lib) == -4
+    assert api.pairs_for_contig(q, 50, 1000, False, 0, lib) == api.SKIP_SHORT_READ
     q = api.parse_flags("-z 1 -N 100 -a", lib)
-    assert api.pairs_for_contig(q, 50, 1000, False, 0, lib) == -2
+    assert api.pairs_for_contig(q, 50, 1000, False, 0, lib) == api.SKIP_AMPLICON
 
 
 def test_no_cpu_fallback(lib):
