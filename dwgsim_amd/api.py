@@ -76,7 +76,7 @@ EXPORTS = [
     "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_mutate_poll", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
     "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig", "dwgsim_hip_job_begin_contig", "dwgsim_hip_job_commit_contig", "dwgsim_hip_job_cancel_contig", "dwgsim_hip_get_params",
     "dwgsim_hip_job_finish", "dwgsim_hip_job_last_error", "dwgsim_hip_job_destroy",
-    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
+    "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_get", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
 ]
 
 _lib = None
@@ -153,6 +153,7 @@ def load(path: str | None = None):
     lib.dwgsim_hip_shard_range.restype = None
     lib.dwgsim_hip_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.dwgsim_hip_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.dwgsim_hip_debug_get.argtypes = [C.c_void_p, C.c_char_p, P(C.c_int64)]
     lib.dwgsim_hip_debug_count_byte.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_uint64)]
     lib.dwgsim_hip_debug_gzip.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, P(C.c_size_t)]
     lib.dwgsim_hip_set_gzip.argtypes = [C.c_void_p, C.c_int]
@@ -249,15 +250,19 @@ def read_fasta(path: str):
     name, chunks = None, []
     with open(path, "rb") as f:
         data = f.read()
-    # split on '>' at any position, as the reference's fgetc loop does
-    for rec in data.split(b">")[1:]:
-        nl = rec.find(b"\n")
-        header, body = (rec, b"") if nl < 0 else (rec[:nl], rec[nl + 1:])
+    # a '>' opens a record wherever it stands in the sequence, as in the reference's fgetc loop -- but not inside a header line
+    at = data.find(b">")
+    while at >= 0:
+        nl = data.find(b"\n", at)
+        header = data[at + 1:] if nl < 0 else data[at + 1:nl]
+        nxt = -1 if nl < 0 else data.find(b">", nl + 1)
+        body = b"" if nl < 0 else (data[nl + 1:] if nxt < 0 else data[nl + 1:nxt])
         header = header.replace(b"\r", b"")
-        name = header.split(b" ")[0].split(b"\t")[0].decode()
+        name = header.split(b" ")[0].split(b"\t")[0].decode("latin-1")
         arr = np.frombuffer(body, dtype=np.uint8)
         keep = ((arr >= 65) & (arr <= 90)) | ((arr >= 97) & (arr <= 122)) | (arr == 45) | (arr == 46)
         out.append((name, np.ascontiguousarray(arr[keep])))
+        at = nxt
     return out
 
 
@@ -447,6 +452,11 @@ class Context:
         out = np.empty(int(nbytes), dtype=np.uint8)
         self._chk(self.lib.dwgsim_hip_fetch(self.h, slot, stream, out.ctypes.data_as(C.c_void_p), int(nbytes)))
         return out
+
+    def debug_get(self, key: str) -> int:
+        v = C.c_int64(0)
+        self._chk(self.lib.dwgsim_hip_debug_get(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def debug_option(self, key: str, value: int):
         self._chk(self.lib.dwgsim_hip_debug_option(self.h, key.encode(), value))

@@ -58,7 +58,7 @@ struct Group {
     std::vector<uint8_t> h_names; std::vector<int32_t> h_reg, h_seg;                     // their host sources (alive while asynchronous copies may read them)
     int fixed_max = 0;               // longest "[prefix_]name"
     uint32_t n_cand = 0;
-    uint16_t *d_summ[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries for count_random (built on demand)
+    uint16_t *d_summ[2] = {nullptr, nullptr}, *d_summ2[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries (per 64 and per 1024 cells) for count_random (built on demand)
     // a walk that was enqueued and not yet waited for
     int walk_attempt = 0; uint32_t walk_cap = 0; size_t walk_cap_bases = 0; bool walk_reset = false;
     uint32_t n_patch = 0, n_patch_ev = 0;       // file-driven mutations: patched cells / indel events
@@ -108,9 +108,10 @@ struct dwgsim_hip_ctx {
     // simulate() working set
     DevBuf meta, fail_summ, block_rand, status_all, out[2][3];
     // walk-stream working set (grow-only)
-    DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand;
+    DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand, place_list, place_aux;
     uint8_t *h_up = nullptr; size_t h_up_cap = 0; hipEvent_t ev_up = nullptr; bool up_in_flight = false;      // page-locked staging of a group's sequence
     SimSeg *h_place_segs = nullptr; size_t h_place_segs_cap = 0;
+    uint64_t *h_range_rand = nullptr; size_t h_range_rand_cap = 0;      // page-locked: count_random's result per range
     std::vector<int32_t> h_ppos; std::vector<uint16_t> h_pcells; std::vector<Event> h_pev;      // file-driven mutations of the group being walked
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
@@ -123,7 +124,7 @@ struct dwgsim_hip_ctx {
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
-    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0;      // dwgsim_hip_debug_option
+    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0;      // dwgsim_hip_debug_option / _debug_get
     bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
     std::string txt, vcf;
@@ -202,7 +203,7 @@ ContigDev group_dev(const Group &g)
 void free_group(Group &g)
 {
     hipFree(g.d_ref);
-    for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]); hipFree(g.d_ins_bases[h]); hipFree(g.d_summ[h]); }
+    for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]); hipFree(g.d_ins_bases[h]); hipFree(g.d_summ[h]); hipFree(g.d_summ2[h]); }
     hipFree(g.d_names); hipFree(g.d_reg); hipFree(g.d_seg);
     if (g.ev_walk) hipEventDestroy(g.ev_walk);
     if (g.h_wc) hipHostFree(g.h_wc);
@@ -527,7 +528,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->walk_stream) hipStreamSynchronize(c->walk_stream);
     for (auto &g : c->groups) if (g.alive) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
-    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->place_segs, &c->place_rand, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
+    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
                       &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch}) hipFree(b->p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
@@ -536,6 +537,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_up) hipHostFree(c->h_up);
     if (c->h_place_segs) hipHostFree(c->h_place_segs);
+    if (c->h_range_rand) hipHostFree(c->h_range_rand);
     if (c->ev_up) hipEventDestroy(c->ev_up);
     for (Slot &sl : c->slot) {
         hipFree(sl.d_counters); hipFree(sl.gz_status.p); hipFree(sl.segs.p);
@@ -1146,7 +1148,10 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     a.qb_words = c->qb_words;
     a.e_full = c->e_full;
     a.names = g.d_names;
-    a.summ[0] = g.d_summ[0]; a.summ[1] = g.d_summ[1];      // null unless count_random built them
+    a.summ[0] = g.d_summ[0]; a.summ[1] = g.d_summ[1]; a.summ2[0] = g.d_summ2[0]; a.summ2[1] = g.d_summ2[1];      // null unless count_random built them
+    // k_place decides most pairs without their insert size: |normal| <= sqrt(-2 ln 2^-104) < 12.01 for the polar method on 53-bit uniforms (dw_simulate.hip pair_surely_accepted)
+    a.place_fast = (!c->has_regions && !p.amplicons && p.std_dev * 12.1 + 2.0 < 1e9) ? 1 : 0;
+    a.place_k = a.place_fast ? (int32_t)ceil(p.std_dev * 12.1) + 2 : 0;
     a.rand_fixed = c->d_rand_fixed; a.rand_fixed_len = c->rand_fixed_len;
     // lanes per k_simulate block: the staged read (lds_words per lane) must fit LDS; long Illumina / SOLiD reads get one-wave blocks
     const int lmax0 = p.length[0] > p.length[1] ? p.length[0] : p.length[1];
@@ -1185,52 +1190,70 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t
     if (n_random) *n_random = 0;
     if (per_range) for (int q = 0; q < n; ++q) per_range[q] = 0;
     Group *gp = nullptr; std::vector<SimSeg> segs; uint64_t n_pairs = 0; uint32_t n_blocks = 0; int fixed_max = 0;
-    if (const int rc = build_ranges(c, r, n, PAIRS_PER_BLOCK, &gp, segs, &n_pairs, &n_blocks, &fixed_max)) return rc;
+    if (const int rc = build_ranges(c, r, n, PLACE_PAIRS, &gp, segs, &n_pairs, &n_blocks, &fixed_max)) return rc;
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     Group &g = *gp;
     HIPC(c, hipSetDevice(c->device));
-    // (on the walk stream: the count of one group can run while batches of another -- or of this one -- are being simulated)
-    if (!g.summ_valid) {         // per-64-cell summaries of the two haplotypes: let k_place accept clean windows without walking them
-        const size_t nb = (size_t)((g.total + SUMM_CELLS - 1) / SUMM_CELLS);
+    hipStream_t st = c->walk_stream;      // (the count of one group can run while batches of another -- or of this one -- are being simulated)
+    if (!g.summ_valid) {         // summaries of the two haplotypes, per 64 and per 1024 cells: k_place accepts clean windows without walking them
+        const size_t nb = (size_t)((g.total + SUMM_CELLS - 1) / SUMM_CELLS), nb2 = (size_t)((g.total + SUMM2_CELLS - 1) / SUMM2_CELLS);
         for (int h = 0; h < 2; ++h) {
             if (!g.d_summ[h]) HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (nb ? nb : 1)));
-            launch_summarize(c->walk_stream, g.d_cells[h], g.total, g.d_summ[h]);
+            if (!g.d_summ2[h]) HIPC(c, hipMalloc((void **)&g.d_summ2[h], sizeof(uint16_t) * (nb2 + 16)));
+            launch_summarize(st, g.d_cells[h], g.total, g.d_summ[h], g.d_summ2[h]);
         }
         g.summ_valid = true;
     }
     SimArgs a;
     if (const int rc = fill_sim_args(c, g, a)) return rc;
-    if (ensure(c, c->place_rand, sizeof(uint32_t) * (size_t)n_blocks)) return DWGSIM_HIP_ERR_DEVICE;
-    if (ensure(c, c->place_segs, sizeof(SimSeg) * segs.size())) return DWGSIM_HIP_ERR_DEVICE;
-    if (segs.size() > c->h_place_segs_cap) {
-        HIPC(c, hipStreamSynchronize(c->walk_stream));
+    const size_t ns = segs.size();
+    if (ensure(c, c->place_rand, sizeof(uint32_t) * ((size_t)n_blocks + 1))) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->place_segs, sizeof(SimSeg) * ns)) return DWGSIM_HIP_ERR_DEVICE;
+    if (ensure(c, c->place_aux, PLACE_LISTS * 16 * sizeof(uint32_t) + sizeof(uint64_t) * ns)) return DWGSIM_HIP_ERR_DEVICE;
+    if (ns > c->h_place_segs_cap || ns > c->h_range_rand_cap) {
+        HIPC(c, hipStreamSynchronize(st));
         if (c->h_place_segs) HIPC(c, hipHostFree(c->h_place_segs));
-        c->h_place_segs = nullptr; c->h_place_segs_cap = 0;
-        HIPC(c, hipHostMalloc((void **)&c->h_place_segs, sizeof(SimSeg) * (segs.size() + 64), hipHostMallocDefault));
-        c->h_place_segs_cap = segs.size() + 64;
+        if (c->h_range_rand) HIPC(c, hipHostFree(c->h_range_rand));
+        c->h_place_segs = nullptr; c->h_range_rand = nullptr; c->h_place_segs_cap = c->h_range_rand_cap = 0;
+        HIPC(c, hipHostMalloc((void **)&c->h_place_segs, sizeof(SimSeg) * (ns + 64), hipHostMallocDefault));
+        HIPC(c, hipHostMalloc((void **)&c->h_range_rand, sizeof(uint64_t) * (ns + 64), hipHostMallocDefault));
+        c->h_place_segs_cap = c->h_range_rand_cap = ns + 64;
     }
-    memcpy(c->h_place_segs, segs.data(), sizeof(SimSeg) * segs.size());
-    HIPC(c, hipMemcpyAsync(c->place_segs.p, c->h_place_segs, sizeof(SimSeg) * segs.size(), hipMemcpyHostToDevice, c->walk_stream));
-    a.segs = (const SimSeg *)c->place_segs.p; a.n_seg = (int32_t)segs.size(); a.n_blocks = n_blocks; a.n_pairs = n_pairs;
+    memcpy(c->h_place_segs, segs.data(), sizeof(SimSeg) * ns);
+    HIPC(c, hipMemcpyAsync(c->place_segs.p, c->h_place_segs, sizeof(SimSeg) * ns, hipMemcpyHostToDevice, st));
+    a.segs = (const SimSeg *)c->place_segs.p; a.n_seg = (int32_t)ns; a.n_blocks = n_blocks; a.n_pairs = n_pairs;
     a.block_rand = (uint32_t *)c->place_rand.p; a.counters = c->d_pcounters;
-    HIPC(c, hipMemsetAsync(c->d_pcounters, 0, N_COUNTERS * sizeof(uint64_t), c->walk_stream));
-    launch_place(c->walk_stream, a);
-    launch_scan_excl(c->walk_stream, a.block_rand, n_blocks, &c->d_pcounters[3]);
-    HIPC(c, hipMemcpyAsync(c->h_pcounters, c->d_pcounters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->walk_stream));
-    HIPC(c, hipStreamSynchronize(c->walk_stream));
-    if (c->h_pcounters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
-    if (n_random) *n_random = c->h_pcounters[3];
-    if (per_range) {      // the scanned per-block counts hold every range's share: prefix at its first block .. prefix at the next range's
-        std::vector<uint32_t> pre((size_t)n_blocks);
-        HIPC(c, hipMemcpyAsync(pre.data(), a.block_rand, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, c->walk_stream));
-        HIPC(c, hipStreamSynchronize(c->walk_stream));
-        size_t si = 0;
-        for (int q = 0; q < n; ++q) {
-            if (r[q].n_pairs == 0) continue;
-            const uint64_t lo = pre[segs[si].first_block], hi = si + 1 < segs.size() ? pre[segs[si + 1].first_block] : c->h_pcounters[3];
-            per_range[q] = hi - lo; ++si;
-        }
+    // the lists of pairs k_place leaves open: room for an eighth of the pairs (the usual share is a per cent); if that does not do -- contigs
+    // made of N runs, a read length close to the contig's -- the count is run once more with room for every pair
+    const uint64_t waves = (uint64_t)n_blocks * (PLACE_PAIRS / 64);
+    const uint32_t cap_full = (uint32_t)((waves + PLACE_LISTS - 1) / PLACE_LISTS) * 64u;
+    uint32_t cap = (uint32_t)std::min<uint64_t>(cap_full, 1024 + n_pairs / PLACE_LISTS / 8);
+    if (c->place_cap >= 0 && (uint64_t)c->place_cap < cap) cap = (uint32_t)c->place_cap;      // dwgsim_hip_debug_option("place_cap"): start too small, exercise the second run
+    for (int attempt = 0;; ++attempt) {
+        if (ensure(c, c->place_list, sizeof(uint32_t) * (size_t)cap * PLACE_LISTS)) return DWGSIM_HIP_ERR_DEVICE;
+        a.place_list = (uint32_t *)c->place_list.p; a.place_list_cap = cap;
+        a.place_list_n = (uint32_t *)c->place_aux.p; a.range_rand = reinterpret_cast<uint64_t *>((uint8_t *)c->place_aux.p + PLACE_LISTS * 16 * sizeof(uint32_t));
+        HIPC(c, hipMemsetAsync(c->d_pcounters, 0, N_COUNTERS * sizeof(uint64_t), st));
+        HIPC(c, hipMemsetAsync(c->place_aux.p, 0, PLACE_LISTS * 16 * sizeof(uint32_t) + sizeof(uint64_t) * ns, st));
+        launch_place(st, a);
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipMemcpyAsync(c->h_pcounters, c->d_pcounters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPC(c, hipMemcpyAsync(c->h_range_rand, a.range_rand, sizeof(uint64_t) * ns, hipMemcpyDeviceToHost, st));
+        HIPC(c, hipStreamSynchronize(st));
+        if (!(c->h_pcounters[2] & 16) || attempt > 0) break;
+        cap = cap_full;
     }
+    if (c->h_pcounters[2] & 16) { c->err = "count_random: the list of undecided pairs overflowed twice"; return DWGSIM_HIP_ERR_FAILED; }
+    if (c->h_pcounters[2]) { char b[128]; snprintf(b, sizeof b, "\r[dwgsim_core] failed to generate a read after %d trials\n", MAX_ATTEMPTS + 1); c->err = b; return DWGSIM_HIP_ERR_FAILED; }
+    c->place_open = c->h_pcounters[5];
+    uint64_t total = 0; size_t si = 0;
+    for (int q = 0; q < n; ++q) {
+        if (r[q].n_pairs == 0) continue;
+        total += c->h_range_rand[si];
+        if (per_range) per_range[q] = c->h_range_rand[si];
+        ++si;
+    }
+    if (n_random) *n_random = total;
     return DWGSIM_HIP_OK;
 }
 
@@ -1550,7 +1573,8 @@ int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *c, const void *text, size_t n, void 
 // "phases" = 1 prints the phase split of the -DDW_PHASE_TIMING analysis build,
 // "writer" = 0 / 1 forces the register / FIFO record writer of the Illumina kernels (-1: chosen by LDS occupancy),
 // "sim_threads" = 64 forces the one-wave blocks of the long-read variant (measured: 25 % slower on 2 x 150 bp, small jobs included),
-// "walk_seg_min" = n runs the walk's two serial scans in their segmented form from a capacity of n candidates on (default 16384; 0 restores it).
+// "walk_seg_min" = n runs the walk's two serial scans in their segmented form from a capacity of n candidates on (default 16384; 0 restores it),
+// "place_cap" = n gives the lists of pairs that k_place leaves open room for n entries each (exercises the second, full-size run).
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
 {
     if (!c || !key) return DWGSIM_HIP_ERR_ARG;
@@ -1560,7 +1584,17 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "writer")) c->writer = (int)value;
     else if (!strcmp(key, "sim_threads")) c->force_threads = (int)value;
     else if (!strcmp(key, "walk_seg_min")) walk_debug_seg_min((uint32_t)value);      // (process-wide)
+    else if (!strcmp(key, "place_cap")) c->place_cap = value;
     else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
+    return DWGSIM_HIP_OK;
+}
+
+// ... and values to read back: "place_open" = pairs the last dwgsim_hip_count_random* call could not settle from the coarse summaries
+int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *c, const char *key, int64_t *value)
+{
+    if (!c || !key || !value) return DWGSIM_HIP_ERR_ARG;
+    if (!strcmp(key, "place_open")) *value = (int64_t)c->place_open;
+    else { c->err = "unknown debug value"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }
 

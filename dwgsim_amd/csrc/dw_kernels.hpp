@@ -5,7 +5,9 @@
 
 namespace dw {
 
-constexpr int PAIRS_PER_BLOCK = 128;     // k_place / k_calibrate: pairs (reads) per block
+constexpr int PAIRS_PER_BLOCK = 128;     // k_calibrate: reads per block
+constexpr int PLACE_PAIRS = 256;         // k_place: pairs per block (one lane per pair)
+constexpr int PLACE_LISTS = 64;          // k_place hands the pairs it cannot decide to k_place_rest through this many lists (one counter each: no hot word)
 #ifndef DW_SIM_THREADS
 #define DW_SIM_THREADS 256
 #endif
@@ -99,6 +101,7 @@ struct CalibArgs {
 };
 
 constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_summarize / k_place)
+constexpr int SUMM2_CELLS = 1024;       // ... of the coarse level: bits 0-14 INSERT / DELETE cells, bit 15 a base code >= 4 (16 fine words each)
 
 // Ion Torrent scratch: words per lane of one block's read buffers (4-bit buffer + 2-bit pass-1 buffer), forced odd so that the
 // blocks' areas do not all start on the same HBM channels (a 96 KB stride cost 14 % against 89 KB)
@@ -130,6 +133,10 @@ struct SimArgs {
     const int32_t *reg; int32_t have_regions;       // -x: region pool of the group
     const uint64_t *e_thr[2];      // per-position error thresholds ceil((e.start + e.by*i) * 2^32) (dwgsim.c:237): u < e  <=>  w < thr
     const uint16_t *summ[2];       // k_place only (else null): per SUMM_CELLS cells of a haplotype, bits 0-7 = INSERT / DELETE cells, bit 15 = a base code >= 4
+    const uint16_t *summ2[2];      // ... and per SUMM2_CELLS cells
+    int32_t place_fast, place_k;   // k_place: 1 = a pair can be decided from the coarse summaries under any insert size within dist +- place_k (no -x, no -a); place_k bounds |normal| * std_dev
+    uint32_t *place_list, *place_list_n; uint32_t place_list_cap;      // k_place -> k_place_rest: PLACE_LISTS lists of place_list_cap pair numbers, their lengths (16 words apart)
+    uint64_t *range_rand;          // k_place: random reads per range of the launch
     const uint32_t *e_thr32[2];    // the same as 32-bit words, zero padded to a multiple of 8 entries; a threshold of 2^32 (e = 1) is stored as
     int32_t e_full;                // 0xFFFFFFFF and flagged here: those positions always err
     const uint32_t *qbase[2];      // per-position base quality characters (dwgsim.c:907; signed-char semantics) packed four to a word: len entries, then the last one

@@ -16,6 +16,7 @@
 //   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
 //   DW_PART 7, 8: the one-wave-per-block variants for long Illumina / SOLiD reads
 //   DW_PART -1 (default): everything in one translation unit
+#include <algorithm>
 #include "dw_read.hpp"
 #include "dw_launch.hpp"
 
@@ -37,12 +38,11 @@
 namespace dw {
 
 #if DW_HAS(0)
-// Haplotype summary for k_place: one word per SUMM_CELLS cells -- how many of them are INSERT / DELETE cells (bit 4 of the cell),
-// and whether any holds a base code >= 4 (N, '-').
-__global__ void __launch_bounds__(256) k_summarize(const uint8_t *cells, int64_t l, uint16_t *summ)
+// Haplotype summaries for k_place, two levels: one word per SUMM_CELLS (64) cells and one per SUMM2_CELLS (1024) -- how many of them are
+// INSERT / DELETE cells (bit 4 of the cell), and whether any holds a base code >= 4 (N, '-').  256 threads = sixteen coarse words per block.
+__global__ void __launch_bounds__(256) k_summarize(const uint8_t *cells, int64_t l, uint16_t *summ, uint16_t *summ2)
 {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, first = b * SUMM_CELLS;
-    if (first >= l) return;
     uint32_t indel = 0, non_acgt = 0;
 #pragma unroll
     for (int q = 0; q < SUMM_CELLS / 16; ++q) {
@@ -52,13 +52,18 @@ __global__ void __launch_bounds__(256) k_summarize(const uint8_t *cells, int64_t
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t rem = l - (at + 4 * k);                              // cells of this word that belong to the contig
+            const int64_t rem = l - (at + 4 * k);                              // cells of this word that belong to the group
             const uint32_t live = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ((1u << (8 * (int)rem)) - 1u);
             indel += (uint32_t)__popc(w[k] & live & 0x10101010u);
             non_acgt |= w[k] & live & 0x0C0C0C0Cu;
         }
     }
-    summ[b] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
+    if (first < l) summ[b] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
+    // the coarse word of these sixteen threads (every lane takes part in the shuffles)
+    uint32_t i2 = indel, f2 = non_acgt ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < SUMM2_CELLS / SUMM_CELLS; d <<= 1) { i2 += (uint32_t)__shfl_xor((int)i2, d); f2 |= (uint32_t)__shfl_xor((int)f2, d); }
+    if ((threadIdx.x & (SUMM2_CELLS / SUMM_CELLS - 1)) == 0 && first < l) summ2[b / (SUMM2_CELLS / SUMM_CELLS)] = (uint16_t)(i2 | (f2 ? 0x8000u : 0u));
 }
 
 // A sufficient condition for an attempt to be accepted (dwgsim.c:824-843) without walking the read: take the 2s+3 cells from
@@ -76,22 +81,47 @@ DW_DEV bool attempt_surely_accepted(const uint16_t *summ, int64_t l, int64_t sta
     return !(flags & 0x8000u) && indel <= (uint32_t)s;
 }
 
-// K5: per pair, the attempt that is accepted (dwgsim.c:833-843 retry rule) and the random-read flag.  One lane per PAIR: the pair's draws are
-// made once, then both read ends are tested (a window the summaries clear is accepted without being read).
-__global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_place(SimArgs a)
+// The same for a PAIR whose insert size is not known yet -- from two Philox blocks, the random-read test and the position uniform of the first
+// placement try, instead of four plus the fp64 polar normal.  Without -x and -a the first try always stands (dwgsim.c:672-675: pos <= l - d and
+// d >= s0 + s1), pos = (int)((l - d + 1) u) falls as d grows, and d = (int)(normal * std_dev + dist + 0.5) clamped to [s0 + s1, l] lies within
+// dist +- place_k: the polar method delivers |normal| <= sqrt(-2 ln rsq) with rsq >= 2^-104 (v = 2u - 1 is a multiple of 2^-52), i.e. below
+// 12.01; the host takes 12.1 std_dev + 2.  Whatever the strands, both reads start inside [pos, pos + d + s0 + s1) (read_geom) and walk at most
+// 2s + 2 cells from there.  If the coarse summaries of that whole span show no base code >= 4 and at most min(s0, s1) indel cells, both reads
+// satisfy attempt_surely_accepted for every insert size and strand the pair can still draw.  (hap: from the same block as the random-read test.)
+DW_DEV bool pair_surely_accepted(const SimArgs &a, const SegCtx &sc, RngKey key, uint64_t ii, uint32_t att, const U4 &b0)
 {
-    __shared__ uint32_t sm[17];
-    const int tid = (int)threadIdx.x;
-    const SegPtr sg = as_constant(a.segs) + seg_of_block(as_constant(a.segs), a.n_seg, blockIdx.x);          // the read-index range this block works on
-    const SegCtx sc = seg_ctx(a, sg);
-    const uint64_t pair = (uint64_t)(blockIdx.x - sg->first_block) * PAIRS_PER_BLOCK + (uint64_t)tid;      // inside the range
-    const bool valid = pair < sg->n_pairs;
-    const uint64_t ii = sg->first_ii + pair;
-    const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
-    uint32_t att = 0; bool is_rand = false, failed = false, done = !valid;
-    while (!done) {
+    const int32_t s0 = a.p.len[0], s1 = a.p.len[1], smax = s0 > s1 ? s0 : s1, smin = s1 > 0 && s1 < s0 ? s1 : s0;
+    const int64_t l = sc.l;
+    if (l < (int64_t)s0 + s1 + 1) return false;
+    int64_t dlo = 0, dhi = 0;
+    if (s1 > 0) {
+        dlo = (int64_t)a.p.dist - a.place_k; dhi = (int64_t)a.p.dist + a.place_k;
+        if (dlo < s0 + s1) dlo = s0 + s1;
+        if (dhi < s0 + s1) dhi = s0 + s1;
+        if (dlo > l) dlo = l;
+        if (dhi > l) dhi = l;
+    }
+    const double u = u_lo(rng_block(key, D_PLACE, ii, att, 0, 0));                                 // slot 0: the position uniform of try 0 (dwgsim.c:671)
+    const int64_t pos_lo = (int64_t)(int32_t)((double)(l - dhi + 1) * u), pos_hi = (int64_t)(int32_t)((double)(l - dlo + 1) * u);
+    const int64_t lo = pos_lo - (2 * (int64_t)smax + 2), hi = pos_hi + dhi + s0 + s1 + 2 * (int64_t)smax + 2;
+    if (lo < 0 || hi >= l) return false;
+    const int hap = u_hi(b0) < a.p.mut_freq ? 0 : 1;
+    const uint16_t *summ2 = (hap ? a.summ2[1] : a.summ2[0]) + sc.start / SUMM2_CELLS;
+    uint32_t indel = 0, flags = 0;
+    for (int64_t b = lo / SUMM2_CELLS; b <= hi / SUMM2_CELLS; ++b) { const uint32_t v = summ2[b]; indel += v & 0x7fffu; flags |= v; }
+    return !(flags & 0x8000u) && indel <= (uint32_t)smin;
+}
+
+// one pair, exactly: the attempt that is accepted (dwgsim.c:833-843 retry rule) and whether it ends as a random read
+DW_DEV void place_pair_exact(const SimArgs &a, const SegCtx &sc, RngKey key, uint64_t ii, bool &is_rand, bool &failed, uint32_t &att)
+{
+    att = 0; is_rand = false; failed = false;
+    for (;;) {
+        const U4 b0 = rng_block(key, D_PAIR, ii, att, 0, 0);
+        if (!(a.p.rand_read < u_lo(b0))) { is_rand = true; return; }
+        if (a.place_fast && pair_surely_accepted(a, sc, key, ii, att, b0)) return;
         const PairDraw pd = draw_pair(a, sc, key, ii, att);
-        if (pd.is_rand) { is_rand = true; break; }
+        if (pd.is_rand) { is_rand = true; return; }      // (a placement that gave up on the target regions ends as a discarded random read: draw_pair)
         bool ok = true;
         for (int j = 0; j < 2 && ok; ++j) {
             const int sj = sel_len(a, j);
@@ -103,15 +133,93 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_place(SimArgs a)
                 ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
             }
         }
-        if (ok) done = true;
-        else if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; done = true; }
+        if (ok) return;
+        if (++att > (uint32_t)MAX_ATTEMPTS) { failed = true; return; }
     }
-    uint32_t total;
-    (void)block_excl_scan(is_rand ? 1u : 0u, sm, &total);
-    if (threadIdx.x == 0) a.block_rand[blockIdx.x] = total;
-    const uint32_t retries = wave_sum_u32(valid ? att : 0u);
-    if (lane_id() == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries);
-    if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
+}
+
+// K5 (dwgsim_hip_count_random: sharding): how many pairs of every range end as random reads.  One lane per PAIR.  k_place settles what two
+// Philox blocks can settle -- a random read at the first attempt, or a genomic pair whose whole neighbourhood is clean -- and hands the rest
+// (windows near N runs, contig ends or dense indels: a per cent or so) to k_place_rest, packed, so that no wave drags 63 settled lanes through
+// the long path.
+__global__ void __launch_bounds__(PLACE_PAIRS) k_place(SimArgs a)
+{
+    __shared__ uint32_t s_cnt[PLACE_PAIRS / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SegPtr sg = as_constant(a.segs) + seg_of_block(as_constant(a.segs), a.n_seg, blockIdx.x);          // the read-index range this block works on
+    const SegCtx sc = seg_ctx(a, sg);
+    const uint64_t pair = (uint64_t)(blockIdx.x - sg->first_block) * PLACE_PAIRS + (uint64_t)tid;      // inside the range
+    const bool valid = pair < sg->n_pairs;
+    const uint64_t ii = sg->first_ii + pair;
+    const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
+    bool is_rand = false, open = false;
+    if (valid) {
+        const U4 b0 = rng_block(key, D_PAIR, ii, 0, 0, 0);
+        is_rand = !(a.p.rand_read < u_lo(b0));                                                      // dwgsim.c:649
+        open = !is_rand && !(a.place_fast && pair_surely_accepted(a, sc, key, ii, 0, b0));
+    }
+    const uint64_t rm = __ballot(is_rand), om = __ballot(open);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(rm);
+    if (om) {      // the wave's open pairs go to one of the lists, in one piece
+        const uint32_t li = (blockIdx.x * (PLACE_PAIRS / 64) + (uint32_t)wave) % PLACE_LISTS;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.place_list_n[16 * li], (uint32_t)__popcll(om));
+        base = (uint32_t)__shfl((int)base, 0);
+        const uint32_t at = base + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
+        if (open) {
+            if (at < a.place_list_cap) a.place_list[(size_t)li * a.place_list_cap + at] = blockIdx.x * (uint32_t)PLACE_PAIRS + (uint32_t)tid;
+            else atomicOr((unsigned long long *)&a.counters[2], 16ull);                             // (a list overflowed: the host runs the count again with room for every pair)
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t t = 0; for (int w = 0; w < PLACE_PAIRS / 64; ++w) t += s_cnt[w]; a.block_rand[blockIdx.x] = t; }
+}
+
+// ... the pairs k_place left open, one lane each.  A wave may hold pairs of several ranges (contigs): they are worked off range by range, so that
+// the range's fields and the RNG key stay wave-uniform.
+__global__ void __launch_bounds__(128) k_place_rest(SimArgs a)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t li = blockIdx.x % PLACE_LISTS, sub = blockIdx.x / PLACE_LISTS, nsub = gridDim.x / PLACE_LISTS;
+    uint32_t n = a.place_list_n[16 * li];
+    if (n > a.place_list_cap) n = a.place_list_cap;
+    for (uint32_t base = sub * 128u; base < n; base += nsub * 128u) {                               // (base is block-uniform: every lane of a wave runs the same iterations)
+        const uint32_t q = base + threadIdx.x;
+        bool todo = q < n;
+        uint32_t e = 0, myseg = 0;
+        if (todo) { e = a.place_list[(size_t)li * a.place_list_cap + q]; myseg = seg_of_block(as_constant(a.segs), a.n_seg, e / PLACE_PAIRS); }
+        uint32_t retries = 0;
+        for (;;) {
+            const uint64_t m = __ballot(todo);
+            if (!m) break;
+            const uint32_t s = uniform_u32((uint32_t)__shfl((int)myseg, __ffsll((unsigned long long)m) - 1));
+            if (todo && myseg == s) {
+                const SegPtr sg = as_constant(a.segs) + s;
+                const SegCtx sc = seg_ctx(a, sg);
+                const uint64_t pair = (uint64_t)(e / PLACE_PAIRS - sg->first_block) * PLACE_PAIRS + (uint64_t)(e % PLACE_PAIRS);
+                const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
+                bool is_rand, failed; uint32_t att;
+                place_pair_exact(a, sc, key, sg->first_ii + pair, is_rand, failed, att);
+                if (is_rand) atomicAdd((unsigned long long *)&a.range_rand[s], 1ull);
+                if (failed) atomicOr((unsigned long long *)&a.counters[2], 1ull);
+                retries = att;
+                todo = false;
+            }
+        }
+        const uint32_t rs = wave_sum_u32(retries);
+        if (lane == 0 && rs) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)rs);
+    }
+}
+
+// random reads per range: what k_place counted per block (block_rand, scanned: exclusive prefix; total in counters[3]) + what k_place_rest added
+__global__ void __launch_bounds__(256) k_range_counts(SimArgs a)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= (uint32_t)a.n_seg) return;
+    const SegPtr sg = as_constant(a.segs);
+    const uint64_t lo = a.block_rand[sg[q].first_block], hi = q + 1 < (uint32_t)a.n_seg ? (uint64_t)a.block_rand[sg[q + 1].first_block] : a.counters[3];
+    a.range_rand[q] += hi - lo;
+    if (q == 0) { uint64_t open = 0; for (int li = 0; li < PLACE_LISTS; ++li) open += a.place_list_n[16 * li]; a.counters[5] = open; }      // (how many pairs took the long path: analysis)
 }
 #endif // DW_HAS(0): k_summarize, k_place
 
@@ -855,14 +963,20 @@ void launch_count_byte(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t
 {
     hipLaunchKernelGGL(k_count_byte, dim3(4096), dim3(256), 0, st, text, n, byte, out);
 }
-void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ)
+void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ, uint16_t *summ2)
 {
     const uint64_t nb = (uint64_t)(l + SUMM_CELLS - 1) / SUMM_CELLS;
-    if (nb) hipLaunchKernelGGL(k_summarize, dim3(cdiv(nb, 256)), dim3(256), 0, st, cells, l, summ);
+    if (nb) hipLaunchKernelGGL(k_summarize, dim3(cdiv(nb, 256)), dim3(256), 0, st, cells, l, summ, summ2);
 }
-void launch_place(hipStream_t st, const SimArgs &a)      // a.segs / a.n_blocks laid out for PAIRS_PER_BLOCK pairs per block
+// a.segs / a.n_blocks laid out for PLACE_PAIRS pairs per block; a.block_rand[n_blocks], a.range_rand[n_seg] (zeroed), a.place_list_n (zeroed).
+// Behind it: a.block_rand scanned (exclusive) with its total in a.counters[3], a.range_rand[q] = random reads of range q.
+void launch_place(hipStream_t st, const SimArgs &a)
 {
-    hipLaunchKernelGGL(k_place, dim3(a.n_blocks), dim3(PAIRS_PER_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_place, dim3(a.n_blocks), dim3(PLACE_PAIRS), 0, st, a);
+    const uint32_t per_list = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)a.place_list_cap + 1023) / 1024));      // blocks of 128 lanes per list, sized for a tenth of the capacity in one sweep
+    hipLaunchKernelGGL(k_place_rest, dim3(PLACE_LISTS * per_list), dim3(128), 0, st, a);
+    launch_scan_excl(st, a.block_rand, a.n_blocks, &a.counters[3]);
+    hipLaunchKernelGGL(k_range_counts, dim3(cdiv((uint64_t)a.n_seg, 256)), dim3(256), 0, st, a);
 }
 // one launcher per (LPP, DT) family, each defined in its own part
 void launch_sim_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);

@@ -14,6 +14,7 @@
 //     DWGSIM_HIP_BATCH     read pairs per GPU launch (default 2^20)
 //     DWGSIM_HIP_GROUP_BP  consecutive contigs are resident together up to this many bases (default 32 Mi)
 //     DWGSIM_HIP_MIN_SHARE a group is spread over fewer devices while a device's share would be below this many pairs (default 65536)
+//     DWGSIM_HIP_READ_THREADS threads that index, verify and copy the mapped FASTA (default: all cores); DWGSIM_HIP_READ_CHUNK bytes of text per task (4 Mi)
 //     DWGSIM_HIP_TIMING    print the stage times
 //     DWGSIM_HIP_TEARDOWN  free every buffer and context before returning from main (by default the process ends as soon as the files are closed)
 //     DWGSIM_HIP_SINK      "null": measurement aid -- the FASTQ deliveries are counted, not written (the .gz files stay empty)
@@ -220,6 +221,7 @@ struct FastaRecord { size_t gt = 0, body = 0, end = 0; std::string name; };     
 
 struct MappedFasta {
     const char *p = nullptr; size_t n = 0; int fd = -1;
+    size_t chunk_bytes = (size_t)4 << 20;      // text a thread verifies and copies at a time (DWGSIM_HIP_READ_CHUNK: tests make it tiny)
     std::vector<FastaRecord> rec;
     ~MappedFasta() { if (p) munmap((void *)p, n); if (fd >= 0) close(fd); }
     bool open_file(const char *fn)
@@ -235,7 +237,7 @@ struct MappedFasta {
     }
     void index(Pool &pool)
     {
-        const size_t piece = (size_t)8 << 20, np = (n + piece - 1) / piece;
+        const size_t piece = 2 * chunk_bytes, np = (n + piece - 1) / piece;
         std::vector<std::vector<size_t>> found(np);
         pool.run(np, [&](size_t k) {
             const size_t lo = k * piece, hi = std::min(n, lo + piece);
@@ -274,7 +276,7 @@ struct MappedFasta {
         if (len == 0) return true;
         const char *b = p + r.body;
         const size_t nb = r.end - r.body, full = nb / (L + 1), rem = nb % (L + 1), last = (size_t)len - full * L;
-        const size_t per = std::max<size_t>(1, ((size_t)4 << 20) / (L + 1)), nt = (full + per - 1) / per;
+        const size_t per = std::max<size_t>(1, chunk_bytes / (L + 1)), nt = (full + per - 1) / per;
         std::atomic<bool> ok{true};
         pool.run(nt, [&](size_t k) {
             const size_t i0 = k * per, i1 = std::min(full, i0 + per);
@@ -512,6 +514,7 @@ int main(int argc, char **argv)
     if (const char *e = getenv("DWGSIM_HIP_READ_THREADS")) { const int v = atoi(e); if (v >= 1) read_threads = (unsigned)v; }
     Pool rpool(read_threads);
     MappedFasta mf;
+    if (const char *e = getenv("DWGSIM_HIP_READ_CHUNK")) { const long long v = atoll(e); if (v >= 1) mf.chunk_bytes = (size_t)v; }
     const bool mapped = strcmp(fn_fa, "-") != 0 && mf.open_file(fn_fa);
     if (mapped) mf.index(rpool);
     else if (strcmp(fn_fa, "-") != 0 && access(fn_fa, R_OK) != 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn_fa); return give_up(1); }

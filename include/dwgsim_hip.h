@@ -248,13 +248,6 @@ int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void 
  * hipMemcpyAsync at link speed; pageable memory goes through double-buffered pinned staging inside. */
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
-/* Test / analysis hooks, not part of the drop-in surface: "justify_seq", "walk_cap", "phases", "writer", "sim_threads", "walk_seg_min" (see dw_host.cpp). */
-int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
-/* ... and: the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text). */
-int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *ctx, const void *text, size_t n, void *out, size_t cap, size_t *out_n);
-/* ... and: occurrences of `byte` in one finished stream of a slot, counted on the device (whole-output checks without a copy-out). */
-int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int byte, uint64_t *count);
-
 /* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);
 /* HIP devices visible to the process (0 without a GPU). */
@@ -319,6 +312,29 @@ int dwgsim_hip_job_cancel_contig(dwgsim_hip_job_t *job);
 int dwgsim_hip_job_finish(dwgsim_hip_job_t *job);
 const char *dwgsim_hip_job_last_error(const dwgsim_hip_job_t *job);
 void dwgsim_hip_job_destroy(dwgsim_hip_job_t *job);
+
+/* ====================================================================================================================================
+ * TEST / ANALYSIS HOOKS -- everything below this line is NOT part of the drop-in surface.  A binding of the reference needs none of it; the
+ * parity tests and the profiling scripts do.  (All of it is read-only with respect to what the product computes: the options select between
+ * code paths that produce the same bytes, the self-tests and counters only report.)
+ * ==================================================================================================================================== */
+/* "justify_seq" = 1: left-justification from one thread (cross-check of the cluster-parallel form); "walk_cap" = n: start the mutation walk with
+ * room for n candidates (exercises the exact re-run); "walk_seg_min" = n: segmented form of the walk's serial scans from n candidates on;
+ * "writer" = 0 / 1: force the register / LDS-FIFO record writer; "sim_threads" = 64: force the one-wave blocks of the long-read variant;
+ * "place_cap" = n: room for n undecided pairs per list in dwgsim_hip_count_random* (exercises its second run); "phases" = 1: print the phase
+ * split of the -DDW_PHASE_TIMING analysis build. */
+int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
+/* "place_open": pairs the last dwgsim_hip_count_random* call could not settle from the coarse haplotype summaries */
+int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *ctx, const char *key, int64_t *value);
+/* the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text) */
+int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *ctx, const void *text, size_t n, void *out, size_t cap, size_t *out_n);
+/* occurrences of `byte` in one finished stream of a slot, counted on the device (whole-output checks without a copy-out) */
+int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int byte, uint64_t *count);
+/* device self-tests of the arithmetic shortcuts (dw_common.hpp / dw_simulate.hip): the range-restricted fp64 division / sqrt / log against the
+ * compiler's general forms on n operand sets; the lazy fp32 quality normals against the exact fp64 form on n tries from `first` (n = 2^32: every
+ * try) and, with exhaustive != 0, the hardware log2 / rcp / sqrt on every float of their operand ranges.  out: see dw_host.cpp. */
+int dwgsim_hip_selftest_fp64(int device, uint32_t seed, uint64_t n, uint64_t *out);
+int dwgsim_hip_selftest_lazy(int device, uint32_t first, uint64_t n, double sigma, int exhaustive, uint64_t *out);
 
 #ifdef __cplusplus
 }

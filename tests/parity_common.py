@@ -200,6 +200,37 @@ def check_count_random_matches_simulate(lib, fasta, flags, ranges=((0, None), (1
     assert checked > 0
 
 
+def check_count_random_fast_path(lib, length=60000, n=2500, flags="-z 17 -1 50 -2 50 -d 300 -s 20 -C 10 -y 0.1 -r 0.01 -R 0.5 -n 1", ranges=((0, None), (333, 1111))):
+    """dwgsim_hip_count_random on contigs where BOTH of its paths matter: most pairs are settled by k_place from two Philox blocks and the
+    coarse (1024-cell) haplotype summaries under any insert size the pair can still draw, the pairs near the N runs, the contig ends and dense
+    indels go through k_place_rest.  The counts must equal the random reads k_simulate itself produces for the same ranges; with the lists of
+    open pairs made too small ("place_cap") the second, full-size run must give the same answer."""
+    from dwgsim_amd import synth
+    params = api.parse_flags(flags, lib)
+    contigs = [("f1", synth.random_contig(length, 5, n_runs=[(0, 700), (length // 3, length // 3 + 2500), (length - 300, length)])),
+               ("f2", synth.random_contig(length // 2, 6, n_runs=[(9000, 9040)]))]
+    tot = sum(len(a) for _, a in contigs)
+    with api.Context(params, 0, lib) as ctx:
+        h0 = ctx.add_contigs(contigs, indices=[0, 1])
+        ctx.mutate(h0)
+        for k, (name, arr) in enumerate(contigs):
+            n_pairs = min(n, api.pairs_for_contig(params, len(arr), tot, False, 0, lib))
+            for first, cnt in ranges:
+                first = min(first, n_pairs - 1)
+                cnt = n_pairs - first if cnt is None else min(cnt, n_pairs - first)
+                want = int(ctx.simulate(h0 + k, first, cnt, 0, 0).n_random)
+                for cap in (-1, 0, 3):
+                    ctx.debug_option("place_cap", cap)
+                    assert ctx.count_random(h0 + k, first, cnt) == want, (name, first, cnt, cap)
+                    opened = ctx.debug_get("place_open")
+                    assert 0 < opened < cnt // 2, (name, first, cnt, opened)      # both paths were taken
+        # several ranges of both contigs in one call
+        ctx.debug_option("place_cap", -1)
+        rr = [(h0, 0, 700), (h0, 700, 300), (h0 + 1, 5, 900)]
+        per = ctx.count_random_ranges(rr, per_range=True)
+        assert list(per) == [int(ctx.simulate(c, f, m, 0, 0).n_random) for c, f, m in rr]
+
+
 def check_both_abort(lib, oracle_bin, fasta, flags, group_bp=0):
     """Jobs the reference gives up on ("failed to generate a read after 10001 trials", dwgsim.c:833-843: one counter of failed attempts
     over the pairs of a contig, reset only by a genomic read): the oracle exits non-zero and the HIP path must return the same error."""

@@ -84,6 +84,6 @@ def test_product_does_not_link_or_import_the_oracle():
 
 def test_fasta_reader_follows_seq_read_fasta(tmp_path):
     p = tmp_path / "x.fa"
-    p.write_bytes(b"garbage\n>c1 comment here\r\nACGT\r\nac-g.t1 2\n>c2\tdesc\nNNNN>c3\nAC\n")
+    p.write_bytes(b"garbage\n>c1 comment > here\r\nACGT\r\nac-g.t1 2\n>c2\tdesc\nNNNN>c3\nAC\n")
     got = api.read_fasta(str(p))
     assert [(n, bytes(a)) for n, a in got] == [("c1", b"ACGTac-g.t"), ("c2", b"NNNN"), ("c3", b"AC")]

@@ -120,6 +120,11 @@ def test_count_random_matches_simulate_on_cpu_emulation(emu_lib, golden_dir, fas
     check_count_random_matches_simulate(emu_lib, os.path.join(golden_dir, fasta), flags, ranges=((0, None), (17, 300)))
 
 
+def test_count_random_fast_and_long_path_on_cpu_emulation(emu_lib):
+    from parity_common import check_count_random_fast_path
+    check_count_random_fast_path(emu_lib, n=1200)
+
+
 def test_walk_reruns_when_a_capacity_is_exceeded(emu_lib, oracle_bin, golden_dir):
     """The walk is enqueued with estimated capacities and checked once at the end; too small a candidate list or inserted-base
     pool must lead to an exact re-run with the same result."""
@@ -271,7 +276,8 @@ def test_command_line_honours_a_fai_index_as_the_reference_does(emu_lib, oracle_
     assert open(str(tmp_path / "cli.mutations.txt"), "rb").read() == want["txt"]
 
 
-def test_command_line_reads_an_awkward_fasta_as_the_reference_does(emu_lib, oracle_bin, tmp_path):
+@pytest.mark.parametrize("threads,chunk,fai", [(1, 0, False), (3, 64, False), (16, 7, False), (3, 100, True), (16, 1, True)])
+def test_command_line_reads_an_awkward_fasta_as_the_reference_does(emu_lib, oracle_bin, tmp_path, threads, chunk, fai):
     """mut.c:49-87 seq_read_fasta: text before the first '>', CR LF, blank lines, lower case, '-' and '.', digits and blanks inside the
     sequence, a '>' in the middle of a line, lines of every length around the reader's eight-byte steps, bytes with the high bit set, no
     newline at the end.  The command line's reader (mapped file, memchr, eight letters verified at a time) against the oracle's."""
@@ -283,14 +289,27 @@ def test_command_line_reads_an_awkward_fasta_as_the_reference_does(emu_lib, orac
     for L in list(range(1, 20)) + [60, 61, 64, 65]:
         body.append(seq(L) + ("\r" if L % 3 == 0 else ""))
     body += ["", seq(30).lower(), seq(10) + "-." + seq(7), seq(9) + " 12 " + seq(9), seq(8) + "\xe9" + seq(8), seq(40)]
-    body += [">c2\tsecond", seq(700), seq(33) + ">c3 opens mid-line", seq(900)]
+    body += [">c2\tsecond", seq(700), seq(33) + ">c3 opens mid-line", seq(900), ">c5 with a > in its header >x", seq(450)]
     body += [">c4"] + [seq(61) for _ in range(30)]
+    # regular records (what every FASTA writer produces: the path that is verified and copied by all cores), ending in every way they can
+    body += [">r1 regular, last line shorter"] + [seq(60) for _ in range(40)] + [seq(17)]
+    body += [">r2 regular, all lines full"] + [seq(70) for _ in range(25)]
+    body += [">r3 one line", seq(333)]
+    body += [">r4 a ragged line in the middle"] + [seq(50) for _ in range(20)] + [seq(49)] + [seq(50) for _ in range(20)]
+    body += [">r5 a digit among the letters"] + [seq(50) for _ in range(10)] + [seq(25) + "7" + seq(24)] + [seq(50) for _ in range(10)]
+    body += [">r6 empty", ">r7"] + [seq(80) for _ in range(12)]
     fa = str(tmp_path / "awkward.fa")
     open(fa, "w", encoding="latin-1").write("\n".join(body) + "\n" + seq(50))      # (no newline at the end)
     flags = "-z 21 -N 1200 -1 50 -2 50 -d 200 -s 10 -o 1 -n 50"
+    if fai:      # with an index the records are parsed straight into the job's staging, one after the other (the index's own numbers are the reference's
+                 # contig table, dwgsim.c:465-478: here they are the true ones)
+        from dwgsim_amd import api as _api
+        open(fa + ".fai", "w").write("".join(f"{n}\t{len(a)}\t0\t60\t61\n" for n, a in _api.read_fasta(fa)))
+    env = dict(os.environ, DWGSIM_HIP_THREADS="2", DWGSIM_HIP_GZIP="cpu", DWGSIM_HIP_READ_THREADS=str(threads))
+    if chunk:
+        env["DWGSIM_HIP_READ_CHUNK"] = str(chunk)
     want = run_oracle(oracle_bin, fa, flags, str(tmp_path))
-    subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + [fa, str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL,
-                   env=dict(os.environ, DWGSIM_HIP_THREADS="2", DWGSIM_HIP_GZIP="cpu"))
+    subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + [fa, str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL, env=env)
     for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz")]:
         assert gzip.open(str(tmp_path / ("cli." + suf)), "rb").read() == want[k], suf
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"] and b"c3" in want["vcf"]

@@ -332,6 +332,15 @@ def test_count_random_matches_simulate(lib, golden_dir, repeats_fa, which, flags
     check_count_random_matches_simulate(lib, fasta, flags)
 
 
+@pytest.mark.parametrize("flags", ["-z 17 -1 50 -2 50 -d 300 -s 20 -C 10 -y 0.1 -r 0.01 -R 0.5 -n 1", "-z 18 -1 150 -2 150 -C 8 -n 0", "-z 19 -1 100 -2 0 -C 4 -y 0.02 -r 0.003",
+                                   "-z 20 -1 100 -2 100 -i -d 100 -s 30 -C 6 -S 1", "-z 21 -1 120 -2 80 -d 5000 -s 700 -C 6 -S 2 -A 2"])
+def test_count_random_fast_and_long_path(lib, flags):
+    """k_place's two-Philox-block decision (coarse summaries, any insert size within dist +- 12.1 sigma) + k_place_rest against k_simulate's own
+    count: 3 Mb contigs with N runs at the ends and inside, paired / single-end / inner-distance / mate-pair geometries, forced list overflow."""
+    from parity_common import check_count_random_fast_path
+    check_count_random_fast_path(lib, length=3000000, n=150000, flags=flags, ranges=((0, None), (33333, 55555)))
+
+
 def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa):
     """See tests/test_emu_parity.py: forced tiny capacities on the repeat-rich 1.8 Mb contigs."""
     compare_case(lib, oracle_bin, repeats_fa, "-z 32 -M 2 -r 0.2 -R 0.9 -X 0.3 -I 2", debug_options={"walk_cap": 100})
