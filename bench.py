@@ -416,10 +416,13 @@ def main():
 
     steps(args.warmup, False)
     barrier()
+    gpu_us0 = (ctx.debug_get("walk_us"), ctx.debug_get("count_us"))
     t0 = time.perf_counter()
     t0 = steps(args.steps, True) or t0
     barrier()
     elapsed = time.perf_counter() - t0
+    stats["walk_gpu_ms"] = (ctx.debug_get("walk_us") - gpu_us0[0]) / 1e3
+    stats["count_gpu_ms"] = (ctx.debug_get("count_us") - gpu_us0[1]) / 1e3
     total_pairs = my_pairs
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -467,8 +470,11 @@ def main():
                        "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
                        "random_pairs": stats["n_random"],
                        "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), one host-side all-gather of integers per step" if world > 1 else "one GPU")},
-            "breakdown_ms": {"wait_for_walks": round(stats["prep_ms"] / K, 4), "count_random": round(stats["count_ms"] / K, 4), "exchange": round(stats["exch_ms"] / K, 4), "simulate_kernels": round(stats["sim_kernel_ms"] / K, 4),
-                             "note": "host time of a step's preparation (walks and counts run on their own stream" + ("" if args.no_pipeline else ", beside the previous step's kernels") + ") and the HIP-event time of its k_simulate launches"},
+            "breakdown_ms": {"walk_gpu": round(stats["walk_gpu_ms"] / K, 4), "count_random_gpu": round(stats["count_gpu_ms"] / K, 4), "simulate_kernels": round(stats["sim_kernel_ms"] / K, 4),
+                             "host_wait_for_walks": round(stats["prep_ms"] / K, 4), "host_count_random": round(stats["count_ms"] / K, 4), "host_exchange": round(stats["exch_ms"] / K, 4),
+                             "note": "per step, rank 0.  walk_gpu / count_random_gpu: HIP-event time, first kernel to last, of the walk chains of all groups and of the random-read counts "
+                                     "(k_place .. k_range_counts; only N > 1 counts) on the low-priority walk stream" + ("" if args.no_pipeline else " -- they run beside the previous step's k_simulate, so the time includes what that kernel makes them wait") +
+                                     "; simulate_kernels: HIP-event time of the k_simulate launches; host_*: wall time the host spent waiting for / calling them"},
             "roofline": {"bound": "valu", "kernel": f"k_simulate<{2 if paired else 1},{[3, 1, 2][params.reads_output_type]},{params.data_type}>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": prof.get("traffic_bytes_per_launch"),

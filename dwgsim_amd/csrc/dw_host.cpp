@@ -58,11 +58,11 @@ struct Group {
     std::vector<uint8_t> h_names; std::vector<int32_t> h_reg, h_seg;                     // their host sources (alive while asynchronous copies may read them)
     int fixed_max = 0;               // longest "[prefix_]name"
     uint32_t n_cand = 0;
-    uint16_t *d_summ[2] = {nullptr, nullptr}, *d_summ2[2] = {nullptr, nullptr}; bool summ_valid = false;      // haplotype summaries (per 64 and per 1024 cells) for count_random (built on demand)
+    uint16_t *d_summ[2] = {nullptr, nullptr}, *d_summ2[2] = {nullptr, nullptr};      // haplotype summaries (per 64 and per 1024 cells) for count_random: written with the read views at the end of the walk
     // a walk that was enqueued and not yet waited for
     int walk_attempt = 0; uint32_t walk_cap = 0; size_t walk_cap_bases = 0; bool walk_reset = false;
     uint32_t n_patch = 0, n_patch_ev = 0;       // file-driven mutations: patched cells / indel events
-    hipEvent_t ev_walk = nullptr;
+    hipEvent_t ev_walk = nullptr, ev_walk0 = nullptr;      // end / start of the walk chain on the walk stream
     uint64_t *h_wc = nullptr;        // page-locked mirror of the walk's counters (the context's d_wcounters) at the end of THIS group's walk: several groups' walks can be in flight
     // the mutated cells of the finished walk, fetched once for mutations_text
     bool list_valid = false; std::vector<int32_t> pos; std::vector<uint32_t> cells; HostIns ins[2];
@@ -124,7 +124,8 @@ struct dwgsim_hip_ctx {
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
-    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0;      // dwgsim_hip_debug_option / _debug_get
+    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0;      // dwgsim_hip_debug_option / _debug_get
+    hipEvent_t ev_cnt0 = nullptr, ev_cnt1 = nullptr;
     bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
     std::string txt, vcf;
@@ -206,6 +207,7 @@ void free_group(Group &g)
     for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]); hipFree(g.d_ins_bases[h]); hipFree(g.d_summ[h]); hipFree(g.d_summ2[h]); }
     hipFree(g.d_names); hipFree(g.d_reg); hipFree(g.d_seg);
     if (g.ev_walk) hipEventDestroy(g.ev_walk);
+    if (g.ev_walk0) hipEventDestroy(g.ev_walk0);
     if (g.h_wc) hipHostFree(g.h_wc);
     g = Group();
 }
@@ -386,10 +388,14 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, fail_code); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
     auto init = [&]() -> int {
         HIPC(c, hipSetDevice(device));
-        HIPC(c, hipStreamCreate(&c->stream));
-        HIPC(c, hipStreamCreate(&c->copy_stream));
-        HIPC(c, hipStreamCreate(&c->walk_stream));
-        HIPC(c, hipEventCreate(&c->ev_up));
+        // the batches' kernels get the compute units first; what prepares the NEXT group (upload, walk, random-read count: walk stream) fills what
+        // they leave -- the thinning tail of every launch -- instead of taking slots from them
+        int prio_least = 0, prio_greatest = 0;
+        HIPC(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        HIPC(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest));
+        HIPC(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamDefault, prio_greatest));
+        HIPC(c, hipStreamCreateWithPriority(&c->walk_stream, hipStreamDefault, prio_least));
+        HIPC(c, hipEventCreate(&c->ev_up)); HIPC(c, hipEventCreate(&c->ev_cnt0)); HIPC(c, hipEventCreate(&c->ev_cnt1));
         HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&c->d_wcounters, 16 * sizeof(uint64_t)));
@@ -539,6 +545,8 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->h_place_segs) hipHostFree(c->h_place_segs);
     if (c->h_range_rand) hipHostFree(c->h_range_rand);
     if (c->ev_up) hipEventDestroy(c->ev_up);
+    if (c->ev_cnt0) hipEventDestroy(c->ev_cnt0);
+    if (c->ev_cnt1) hipEventDestroy(c->ev_cnt1);
     for (Slot &sl : c->slot) {
         hipFree(sl.d_counters); hipFree(sl.gz_status.p); hipFree(sl.segs.p);
         for (int t = 0; t < 3; ++t) hipFree(sl.gz_out[t].p);
@@ -588,10 +596,13 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
     const size_t padded = padded_cells(g);
     bool synced = true;
     auto fill = [&]() -> int {
-        HIPC(c, hipEventCreate(&g.ev_walk));
+        HIPC(c, hipEventCreate(&g.ev_walk)); HIPC(c, hipEventCreate(&g.ev_walk0));
         HIPC(c, hipHostMalloc((void **)&g.h_wc, 16 * sizeof(uint64_t), hipHostMallocDefault));
         HIPC(c, hipMalloc((void **)&g.d_ref, padded));
-        for (int h = 0; h < 2; ++h) { HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32)); }
+        for (int h = 0; h < 2; ++h) {
+            HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32));
+            HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, hipMalloc((void **)&g.d_summ2[h], sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
+        }
         if (ensure(c, c->up_ascii, padded)) return DWGSIM_HIP_ERR_DEVICE;
         uint8_t *d_ascii = (uint8_t *)c->up_ascii.p;
         // The sequence goes up on the walk stream.  One copy when the caller's buffers already are the group layout inside ONE page-locked
@@ -767,6 +778,7 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
     const size_t padded = padded_cells(g);
     hipStream_t st = c->walk_stream;
     const SegTab seg = seg_tab(g);
+    HIPC(c, hipEventRecord(g.ev_walk0, st));
     if (c->has_mutin) {      // file-driven mutations (mut.c:644-745): the host resolved the entries, the GPU scatters and left-justifies
         const uint32_t np = g.n_patch, nev = g.n_patch_ev;
         if (g.walk_reset) for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(g.d_cells[h], g.d_ref, padded, hipMemcpyDeviceToDevice, st));
@@ -786,7 +798,7 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
             }
             launch_mut_debug(st, g.d_ref, g.d_cells[0], g.d_cells[1], total, &c->d_wcounters[13]);      // mut.c:757
         }
-        launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.d_view[0], g.d_view[1]);
+        launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.total, g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
         HIPC(c, hipGetLastError());
         HIPC(c, hipMemcpyAsync(&g.h_wc[12], &c->d_wcounters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIPC(c, hipEventRecord(g.ev_walk, st));
@@ -841,7 +853,7 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
     // (which only moves an indel over bases equal to its own).  File-driven mutations (-m / -b / -v, above) can violate all three.
     if (c->seq_justify) launch_justify_seq(st, d_ev, nc, cd);
     else launch_justify(st, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
-    launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.d_view[0], g.d_view[1]);
+    launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.total, g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(&g.h_wc[7], &c->d_wcounters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));      // [7] candidates, [8..11] the eight words
     HIPC(c, hipEventRecord(g.ev_walk, st));
@@ -860,7 +872,7 @@ int dwgsim_hip_mutate_async(dwgsim_hip_ctx_t *c, int contig)
     HIPC(c, hipSetDevice(c->device));
     g.walk_reset = g.mutated;      // walked before: the cells start again from the resident packed reference
     for (int h = 0; h < 2; ++h) g.n_ins[h] = g.n_ins_bases[h] = 0;
-    g.mutated = true; g.n_cand = 0; g.summ_valid = false; g.list_valid = false;
+    g.mutated = true; g.n_cand = 0; g.list_valid = false;
     g.walk_attempt = 0;
     if (g.total == 0) return DWGSIM_HIP_OK;
     if (c->has_mutin) {      // patches, indel events and insertion tables of the whole group, in group coordinates
@@ -922,6 +934,7 @@ int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *c, int contig)
     HIPC(c, hipSetDevice(c->device));
     for (;;) {
         HIPC(c, hipEventSynchronize(g.ev_walk));
+        { float ms = 0; if (hipEventElapsedTime(&ms, g.ev_walk0, g.ev_walk) == hipSuccess) c->walk_us += 1e3 * ms; else (void)hipGetLastError(); }      // (analysis: dwgsim_hip_debug_get "walk_us")
         if (c->has_mutin) {
             g.walk_pending = false;
             return g.n_patch ? mut_debug_verdict(c, g, g.h_wc[12], g.h_wc[13]) : DWGSIM_HIP_OK;
@@ -1148,7 +1161,7 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     a.qb_words = c->qb_words;
     a.e_full = c->e_full;
     a.names = g.d_names;
-    a.summ[0] = g.d_summ[0]; a.summ[1] = g.d_summ[1]; a.summ2[0] = g.d_summ2[0]; a.summ2[1] = g.d_summ2[1];      // null unless count_random built them
+    a.summ[0] = g.d_summ[0]; a.summ[1] = g.d_summ[1]; a.summ2[0] = g.d_summ2[0]; a.summ2[1] = g.d_summ2[1];
     // k_place decides most pairs without their insert size: |normal| <= sqrt(-2 ln 2^-104) < 12.01 for the polar method on 53-bit uniforms (dw_simulate.hip pair_surely_accepted)
     a.place_fast = (!c->has_regions && !p.amplicons && p.std_dev * 12.1 + 2.0 < 1e9) ? 1 : 0;
     a.place_k = a.place_fast ? (int32_t)ceil(p.std_dev * 12.1) + 2 : 0;
@@ -1195,15 +1208,7 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t
     Group &g = *gp;
     HIPC(c, hipSetDevice(c->device));
     hipStream_t st = c->walk_stream;      // (the count of one group can run while batches of another -- or of this one -- are being simulated)
-    if (!g.summ_valid) {         // summaries of the two haplotypes, per 64 and per 1024 cells: k_place accepts clean windows without walking them
-        const size_t nb = (size_t)((g.total + SUMM_CELLS - 1) / SUMM_CELLS), nb2 = (size_t)((g.total + SUMM2_CELLS - 1) / SUMM2_CELLS);
-        for (int h = 0; h < 2; ++h) {
-            if (!g.d_summ[h]) HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (nb ? nb : 1)));
-            if (!g.d_summ2[h]) HIPC(c, hipMalloc((void **)&g.d_summ2[h], sizeof(uint16_t) * (nb2 + 16)));
-            launch_summarize(st, g.d_cells[h], g.total, g.d_summ[h], g.d_summ2[h]);
-        }
-        g.summ_valid = true;
-    }
+    // (the haplotype summaries k_place reads -- per 64 and per 1024 cells -- were written with the read views at the end of the walk)
     SimArgs a;
     if (const int rc = fill_sim_args(c, g, a)) return rc;
     const size_t ns = segs.size();
@@ -1235,11 +1240,14 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t
         a.place_list_n = (uint32_t *)c->place_aux.p; a.range_rand = reinterpret_cast<uint64_t *>((uint8_t *)c->place_aux.p + PLACE_LISTS * 16 * sizeof(uint32_t));
         HIPC(c, hipMemsetAsync(c->d_pcounters, 0, N_COUNTERS * sizeof(uint64_t), st));
         HIPC(c, hipMemsetAsync(c->place_aux.p, 0, PLACE_LISTS * 16 * sizeof(uint32_t) + sizeof(uint64_t) * ns, st));
+        HIPC(c, hipEventRecord(c->ev_cnt0, st));
         launch_place(st, a);
+        HIPC(c, hipEventRecord(c->ev_cnt1, st));
         HIPC(c, hipGetLastError());
         HIPC(c, hipMemcpyAsync(c->h_pcounters, c->d_pcounters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIPC(c, hipMemcpyAsync(c->h_range_rand, a.range_rand, sizeof(uint64_t) * ns, hipMemcpyDeviceToHost, st));
         HIPC(c, hipStreamSynchronize(st));
+        { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_cnt0, c->ev_cnt1) == hipSuccess) c->count_us += 1e3 * ms; else (void)hipGetLastError(); }
         if (!(c->h_pcounters[2] & 16) || attempt > 0) break;
         cap = cap_full;
     }
@@ -1589,11 +1597,14 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     return DWGSIM_HIP_OK;
 }
 
-// ... and values to read back: "place_open" = pairs the last dwgsim_hip_count_random* call could not settle from the coarse summaries
+// ... and values to read back: "place_open" = pairs the last dwgsim_hip_count_random* call could not settle from the coarse summaries;
+// "walk_us" / "count_us" = accumulated HIP-event time (microseconds) of the walk chains / random-read counts of this context
 int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *c, const char *key, int64_t *value)
 {
     if (!c || !key || !value) return DWGSIM_HIP_ERR_ARG;
     if (!strcmp(key, "place_open")) *value = (int64_t)c->place_open;
+    else if (!strcmp(key, "walk_us")) *value = (int64_t)c->walk_us;           // HIP-event time of the walk chains waited for so far (start of the chain to its end, on the walk stream)
+    else if (!strcmp(key, "count_us")) *value = (int64_t)c->count_us;         // ... of the random-read counts (k_place .. k_range_counts)
     else { c->err = "unknown debug value"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }

@@ -15,11 +15,10 @@ void launch_apply(hipStream_t st, Event *ev, Count n, const uint4 *flags, Contig
 void launch_justify_seq(hipStream_t st, const Event *ev, Count n, ContigDev c);
 void launch_justify(hipStream_t st, const Event *ev, Count n, ContigDev c, int32_t *lo, int32_t *sufmin, uint8_t *bound);
 void launch_mut_debug(hipStream_t st, const uint8_t *ref, const uint8_t *h0, const uint8_t *h1, int64_t l, uint64_t *verdict);
-void launch_make_view(hipStream_t st, const uint8_t *cells0, const uint8_t *cells1, int64_t n_cells, uint8_t *view0, uint8_t *view1);
+void launch_make_view(hipStream_t st, const uint8_t *cells0, const uint8_t *cells1, int64_t n_cells, int64_t l_live, uint8_t *view0, uint8_t *view1, uint16_t *summ0, uint16_t *summ1, uint16_t *summ2_0, uint16_t *summ2_1);
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1);
 void launch_collect_mask(hipStream_t st, const uint8_t *h0, const uint8_t *h1, int64_t l, uint16_t *mask, uint32_t *block_count);
 void launch_gather(hipStream_t st, const int32_t *pos, uint32_t n, const uint8_t *ref, const uint8_t *h0, const uint8_t *h1, uint32_t *cells);
-void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ, uint16_t *summ2);
 void launch_place(hipStream_t st, const SimArgs &a);
 void launch_simulate(hipStream_t st, const SimArgs &a);
 void launch_calibrate(hipStream_t st, const CalibArgs &a);

@@ -4,7 +4,7 @@
 //     k_simulate      per read end: attempt loop (placement, haplotype, strands, base extraction through indels, N filter),
 //                     errors (Illumina base space / SOLiD colour space / Ion Torrent flow space), qualities, FASTQ formatting,
 //                     decoupled look-back for record offsets, 64-byte burst stores
-//     k_summarize, k_place   dwgsim_hip_count_random (sharding): random reads in a read-index range without producing them
+//     k_place, k_place_rest  dwgsim_hip_count_random (sharding): random reads in a read-index range without producing them
 //     k_calibrate     -B: per-base calibration of the Ion Torrent flow error (dwgsim_opt.c:415-457)
 //     k_selftest_fp64 device self-test of the range-restricted fp64 forms (dw_common.hpp)
 //
@@ -12,7 +12,7 @@
 // with -ffp-contract=off.
 //
 // The file is compiled in parts so the k_simulate variants build in parallel (csrc/Makefile):
-//   DW_PART 0: k_summarize, k_place, k_selftest_fp64, host launchers and the k_simulate dispatcher
+//   DW_PART 0: k_place, k_place_rest, k_selftest_fp64, host launchers and the k_simulate dispatcher
 //   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
 //   DW_PART 7, 8: the one-wave-per-block variants for long Illumina / SOLiD reads
 //   DW_PART -1 (default): everything in one translation unit
@@ -38,34 +38,8 @@
 namespace dw {
 
 #if DW_HAS(0)
-// Haplotype summaries for k_place, two levels: one word per SUMM_CELLS (64) cells and one per SUMM2_CELLS (1024) -- how many of them are
-// INSERT / DELETE cells (bit 4 of the cell), and whether any holds a base code >= 4 (N, '-').  256 threads = sixteen coarse words per block.
-__global__ void __launch_bounds__(256) k_summarize(const uint8_t *cells, int64_t l, uint16_t *summ, uint16_t *summ2)
-{
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, first = b * SUMM_CELLS;
-    uint32_t indel = 0, non_acgt = 0;
-#pragma unroll
-    for (int q = 0; q < SUMM_CELLS / 16; ++q) {
-        const int64_t at = first + 16 * q;
-        if (at >= l) break;
-        const uint4 v = *reinterpret_cast<const uint4 *>(cells + at);          // cells are readable (padded) up to a multiple of 16 past l
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t rem = l - (at + 4 * k);                              // cells of this word that belong to the group
-            const uint32_t live = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ((1u << (8 * (int)rem)) - 1u);
-            indel += (uint32_t)__popc(w[k] & live & 0x10101010u);
-            non_acgt |= w[k] & live & 0x0C0C0C0Cu;
-        }
-    }
-    if (first < l) summ[b] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
-    // the coarse word of these sixteen threads (every lane takes part in the shuffles)
-    uint32_t i2 = indel, f2 = non_acgt ? 1u : 0u;
-#pragma unroll
-    for (int d = 1; d < SUMM2_CELLS / SUMM_CELLS; d <<= 1) { i2 += (uint32_t)__shfl_xor((int)i2, d); f2 |= (uint32_t)__shfl_xor((int)f2, d); }
-    if ((threadIdx.x & (SUMM2_CELLS / SUMM_CELLS - 1)) == 0 && first < l) summ2[b / (SUMM2_CELLS / SUMM_CELLS)] = (uint16_t)(i2 | (f2 ? 0x8000u : 0u));
-}
-
+// (the haplotype summaries k_place reads are written by k_make_view at the end of the walk, dw_walk.hip: one word per SUMM_CELLS (64) cells and one
+// per SUMM2_CELLS (1024) -- how many of them are INSERT / DELETE cells, and whether any holds a base code >= 4)
 // A sufficient condition for an attempt to be accepted (dwgsim.c:824-843) without walking the read: take the 2s+3 cells from
 // `start` in travel direction.  If they all lie inside the contig, none holds a base code >= 4 and at most s of them are
 // INSERT / DELETE cells, then the walk of __gen_read (one base per NOCHANGE / SUBSTITUTE cell, inserted bases are never N)
@@ -221,7 +195,7 @@ __global__ void __launch_bounds__(256) k_range_counts(SimArgs a)
     a.range_rand[q] += hi - lo;
     if (q == 0) { uint64_t open = 0; for (int li = 0; li < PLACE_LISTS; ++li) open += a.place_list_n[16 * li]; a.counters[5] = open; }      // (how many pairs took the long path: analysis)
 }
-#endif // DW_HAS(0): k_summarize, k_place
+#endif // DW_HAS(0): k_place
 
 // K6: one lane per read end (LPP = 2: lanes 2q / 2q+1 are the two ends of pair q; LPP = 1: single end).
 // Opt-in phase timing (tools/phase_profile.sh builds a separate library with -DDW_PHASE_TIMING; the
@@ -962,11 +936,6 @@ __global__ void __launch_bounds__(256) k_count_byte(const uint8_t *__restrict__ 
 void launch_count_byte(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t byte, uint64_t *out)
 {
     hipLaunchKernelGGL(k_count_byte, dim3(4096), dim3(256), 0, st, text, n, byte, out);
-}
-void launch_summarize(hipStream_t st, const uint8_t *cells, int64_t l, uint16_t *summ, uint16_t *summ2)
-{
-    const uint64_t nb = (uint64_t)(l + SUMM_CELLS - 1) / SUMM_CELLS;
-    if (nb) hipLaunchKernelGGL(k_summarize, dim3(cdiv(nb, 256)), dim3(256), 0, st, cells, l, summ, summ2);
 }
 // a.segs / a.n_blocks laid out for PLACE_PAIRS pairs per block; a.block_rand[n_blocks], a.range_rand[n_seg] (zeroed), a.place_list_n (zeroed).
 // Behind it: a.block_rand scanned (exclusive) with its total in a.counters[3], a.range_rand[q] = random reads of range q.

@@ -13,7 +13,7 @@
 //     k_apply_patches file-driven mutations (-m / -b / -v) resolved on the host, scattered here
 //     k_collect_mask / k_gather   list of mutated cells for the host's txt/vcf writer
 //     k_mut_debug     the reference's consistency asserts (mut.c:379-425)
-//     k_make_view     4-bit read view of a finished haplotype (what base extraction reads)
+//     k_make_view     4-bit read view of a finished haplotype (what base extraction reads) + its two levels of summaries (what the random-read count reads)
 //
 // Byte/integer work only: no MFMA.  Host-callable launchers (dw_launch.hpp) are at the end.
 #include "dw_device.hpp"
@@ -639,31 +639,54 @@ void launch_mut_debug(hipStream_t st, const uint8_t *ref, const uint8_t *h0, con
     if (l > 0) hipLaunchKernelGGL(k_mut_debug, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, h0, h1, l, verdict);
 }
 // The read view of a finished haplotype (HapDev::view): one nibble per cell, 32 cells per thread.
-__global__ void __launch_bounds__(256) k_make_view(const uint8_t *__restrict__ cells0, const uint8_t *__restrict__ cells1, int64_t n_cells, uint8_t *__restrict__ view0, uint8_t *__restrict__ view1)
+__global__ void __launch_bounds__(256) k_make_view(const uint8_t *__restrict__ cells0, const uint8_t *__restrict__ cells1, int64_t n_cells, int64_t l_live, uint8_t *__restrict__ view0, uint8_t *__restrict__ view1,
+                                                   uint16_t *__restrict__ summ0, uint16_t *__restrict__ summ1, uint16_t *__restrict__ summ2_0, uint16_t *__restrict__ summ2_1)
 {
     const uint8_t *__restrict__ cells = blockIdx.y ? cells1 : cells0;       // grid.y = haplotype
     uint8_t *__restrict__ view = blockIdx.y ? view1 : view0;
-    const int64_t first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 32;
-    if (first >= n_cells) return;                                  // n_cells (the padded length) is a multiple of 16
-    uint32_t out[4] = {0, 0, 0, 0};
+    uint16_t *__restrict__ summ = blockIdx.y ? summ1 : summ0, *__restrict__ summ2 = blockIdx.y ? summ2_1 : summ2_0;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, first = t * 32;
+    const bool live = first < n_cells;                             // n_cells (the padded length) is a multiple of 16
+    uint32_t out[4] = {0, 0, 0, 0}, indel = 0, non_acgt = 0;
+    if (live) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (first + 16 * q >= n_cells) break;
-        const uint4 v = *reinterpret_cast<const uint4 *>(cells + first + 16 * q);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int q = 0; q < 2; ++q) {
+            if (first + 16 * q >= n_cells) break;
+            const uint4 v = *reinterpret_cast<const uint4 *>(cells + first + 16 * q);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const uint32_t c = (w[b >> 2] >> (8 * (b & 3))) & 0xffu, t = c & TMASK, base = c & 0xfu;
-            const uint32_t nib = t == T_NONE ? (base < 4 ? base : base == 4 ? 8u : 9u) : (t == T_SUB && base < 4) ? 4u + base : 15u;
-            const int cell = 16 * q + b;
-            out[cell >> 3] |= nib << (4 * (cell & 7));
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t c = (w[b >> 2] >> (8 * (b & 3))) & 0xffu, ty = c & TMASK, base = c & 0xfu;
+                const uint32_t nib = ty == T_NONE ? (base < 4 ? base : base == 4 ? 8u : 9u) : (ty == T_SUB && base < 4) ? 4u + base : 15u;
+                const int cell = 16 * q + b;
+                out[cell >> 3] |= nib << (4 * (cell & 7));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t rem = l_live - (first + 16 * q + 4 * k);               // cells of this word that belong to the group (the rest is padding)
+                const uint32_t lm = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ((1u << (8 * (int)rem)) - 1u);
+                indel += (uint32_t)__popc(w[k] & lm & 0x10101010u);
+                non_acgt |= w[k] & lm & 0x0C0C0C0Cu;
+            }
         }
+        *reinterpret_cast<uint4 *>(view + (first >> 1)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
-    *reinterpret_cast<uint4 *>(view + (first >> 1)) = make_uint4(out[0], out[1], out[2], out[3]);
+    // the haplotype summaries dwgsim_hip_count_random reads (dw_simulate.hip k_place): per SUMM_CELLS and per SUMM2_CELLS cells, how many are
+    // INSERT / DELETE cells (bit 4) and whether any holds a base code >= 4.  Every lane takes part in the shuffles.
+    uint32_t i1 = indel, f1 = non_acgt ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < SUMM_CELLS / 32; d <<= 1) { i1 += (uint32_t)__shfl_xor((int)i1, d); f1 |= (uint32_t)__shfl_xor((int)f1, d); }
+    uint32_t i2 = i1, f2 = f1;
+#pragma unroll
+    for (int d = SUMM_CELLS / 32; d < SUMM2_CELLS / 32; d <<= 1) { i2 += (uint32_t)__shfl_xor((int)i2, d); f2 |= (uint32_t)__shfl_xor((int)f2, d); }
+    if (first < l_live) {
+        if ((t & (SUMM_CELLS / 32 - 1)) == 0) summ[t / (SUMM_CELLS / 32)] = (uint16_t)(i1 | (f1 ? 0x8000u : 0u));
+        if ((t & (SUMM2_CELLS / 32 - 1)) == 0) summ2[t / (SUMM2_CELLS / 32)] = (uint16_t)(i2 | (f2 ? 0x8000u : 0u));
+    }
 }
-void launch_make_view(hipStream_t st, const uint8_t *cells0, const uint8_t *cells1, int64_t n_cells, uint8_t *view0, uint8_t *view1)
+void launch_make_view(hipStream_t st, const uint8_t *cells0, const uint8_t *cells1, int64_t n_cells, int64_t l_live, uint8_t *view0, uint8_t *view1, uint16_t *summ0, uint16_t *summ1, uint16_t *summ2_0, uint16_t *summ2_1)
 {
-    if (n_cells > 0) hipLaunchKernelGGL(k_make_view, dim3(cdiv((uint64_t)n_cells, 256 * 32), 2), dim3(256), 0, st, cells0, cells1, n_cells, view0, view1);
+    if (n_cells > 0) hipLaunchKernelGGL(k_make_view, dim3(cdiv((uint64_t)n_cells, 256 * 32), 2), dim3(256), 0, st, cells0, cells1, n_cells, l_live, view0, view1, summ0, summ1, summ2_0, summ2_1);
 }
 void launch_apply_patches(hipStream_t st, const int32_t *pos, const uint16_t *cells, uint32_t n, uint8_t *h0, uint8_t *h1)
 {

@@ -324,7 +324,8 @@ void dwgsim_hip_job_destroy(dwgsim_hip_job_t *job);
  * "place_cap" = n: room for n undecided pairs per list in dwgsim_hip_count_random* (exercises its second run); "phases" = 1: print the phase
  * split of the -DDW_PHASE_TIMING analysis build. */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
-/* "place_open": pairs the last dwgsim_hip_count_random* call could not settle from the coarse haplotype summaries */
+/* "place_open": pairs the last dwgsim_hip_count_random* call could not settle from the coarse haplotype summaries; "walk_us" / "count_us":
+ * HIP-event time (microseconds, accumulated) of the context's walk chains / random-read counts on the walk stream */
 int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *ctx, const char *key, int64_t *value);
 /* the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text) */
 int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *ctx, const void *text, size_t n, void *out, size_t cap, size_t *out_n);

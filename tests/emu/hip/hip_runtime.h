@@ -129,6 +129,9 @@ enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMe
 struct hipPointerAttribute_t { hipMemoryType type; };
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeUnregistered; return 1; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(1); return 0; }
+#define hipStreamDefault 0
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = 0; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)calloc(1, sizeof(hipemu_event)); return 0; }

@@ -177,6 +177,14 @@ def test_job_level_many_small_contigs_on_cpu_emulation(emu_lib, oracle_bin, tmp_
     compare_job_api(emu_lib, oracle_bin, fa, "-z 11 -C 6 -1 50 -2 50 -d 200 -s 15 -r 0.03 -R 0.6 -X 0.6 -n 8 -y 0.1", devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=256, min_share=100, group_bp=30000)
 
 
+def test_job_level_in_the_shape_of_a_whole_node_on_cpu_emulation(emu_lib, oracle_bin, tmp_path):
+    """Eight workers, 24+ groups, tiny batches, three delivery threads: the shape of the 8-GPU node (here eight emulated contexts)."""
+    from parity_common import compare_job_api
+    fa = str(tmp_path / "many.fa")
+    write_many_contigs(fa, 60, seed=8)
+    compare_job_api(emu_lib, oracle_bin, fa, "-z 12 -C 5 -1 60 -2 40 -d 220 -s 10 -r 0.02 -R 0.5 -n 10 -y 0.15", devices=[0] * 8, batch_pairs=23, min_share=1, group_bp=3000)
+
+
 def test_job_level_abort_rule_across_devices_on_cpu_emulation(emu_lib, oracle_bin, golden_dir):
     """The failure counter over the pairs of a contig (dwgsim.c:635) when its batches are dealt to three contexts: the joined summaries give the
     reference's verdict -- no abort at 600 pairs, abort at 1200."""

@@ -192,6 +192,15 @@ def test_job_level_of_the_abi(lib, oracle_bin, golden_dir, fasta, flags, kw):
     compare_job_api(lib, oracle_bin, os.path.join(golden_dir, fasta), flags, **kw)
 
 
+def test_job_level_in_the_shape_of_a_whole_node(lib, oracle_bin, many_fa):
+    """Eight workers (here eight contexts on the one GPU of the box), 30+ groups, tiny batches, the three delivery threads: the shape of the
+    8-GPU node the scaling run uses -- every worker takes part in every group, counts its batches' random reads, waits for the other seven."""
+    from parity_common import compare_job_api
+    res = compare_job_api(lib, oracle_bin, many_fa, "-z 12 -C 25 -1 60 -2 40 -d 220 -s 10 -r 0.02 -R 0.5 -n 10 -y 0.15", devices=[0] * 8, batch_pairs=97, min_share=1, group_bp=12000)
+    assert res.n_pairs > 20000
+    compare_job_api(lib, oracle_bin, many_fa, "-z 13 -N 30000 -1 50 -2 0 -o 0 -y 0.3", devices=[0] * 8, batch_pairs=512, min_share=64, group_bp=40000, gzip_on_gpu=False)
+
+
 def test_job_level_two_hundred_small_contigs(lib, oracle_bin, many_fa):
     from parity_common import compare_job_api
     compare_job_api(lib, oracle_bin, many_fa, "-z 11 -C 20 -1 50 -2 50 -d 200 -s 15 -r 0.03 -R 0.6 -X 0.6 -n 8 -y 0.1", devices=[0, 0, 0], batch_pairs=4096, min_share=100, group_bp=100000)
