@@ -3,6 +3,7 @@
 //   model (dwgsim.c:246-417), and the FASTQ text assembly (64-byte burst writer, packed decimal / hex fields).
 #pragma once
 #include "dw_device.hpp"
+#include <dw_probe.hpp>
 
 namespace dw {
 
@@ -289,9 +290,6 @@ struct PackReader {
     DW_DEV void init(const uint32_t *b, int st) { base = b; stride = st; cw = -1; word = 0; }
     DW_DEV uint32_t get(int i) { const int w = i >> SH; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & (PER - 1)) * BITS)) & M; }
 };
-#ifndef DW_KNOCK
-#define DW_KNOCK 0
-#endif
 // First draws of the flow model's events as bits: bit k of the result = (first uniform of event 8 * blk + k) < e, e as thr = e * 2^32
 // (dw_common.hpp D_FLOW0: sixteen-bit halves, the low halves drawn only when a high half ties with thr's).
 DW_DEV uint32_t flow_hits8(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t blk, uint64_t thr)
@@ -415,8 +413,8 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
         if (active) {
             uint32_t bits = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { if (DW_KNOCK & 256) break; bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom, rg.ii, rg.att, 4u * w + q, thr) << (8 * q); }
-            if (DW_KNOCK & 4096) { asm volatile("" :: "v"(bits)); bits = 0; }     // (analysis builds: 256 no draws, 4096 drawn but nothing scores)
+            for (uint32_t q = 0; q < 4; ++q) { if (probe::off(256)) break; bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom, rg.ii, rg.att, 4u * w + q, thr) << (8 * q); }
+            if (probe::off(4096)) { probe::keep(bits); bits = 0; }
             bm[(size_t)w * stride] = bits;
         }
     };
@@ -515,7 +513,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     }
     o1.flush();
     const int n1 = o1.n;
-    if (DW_KNOCK & 1024) { *n_err_out += total; return failed ? -1 : n1; }
+    if (probe::off(1024)) { *n_err_out += total; return failed ? -1 : n1; }
     const int marked_flow = marked ? flow_i : -1;      // the one flow of the (persistent) mask that pass 2 finds set
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
@@ -612,7 +610,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
 }
 
 // ---- FASTQ text assembly ----
-// (analysis builds only, tools/knockout_build.sh: -DDW_KNOCK=<bits> switches parts of k_simulate off to weigh them; the product build has none of it)
+// (probe::off / probe::keep: dw_probe.hpp -- nothing in the product build)
 struct __attribute__((packed, aligned(1))) Unal16 { uint64_t a, b; };      // stores at any byte address: gfx950 global memory takes unaligned
 struct __attribute__((packed, aligned(1))) Unal8 { uint64_t v; };           // dword / dwordx2 / dwordx4 accesses as they are (one instruction)
 struct __attribute__((packed, aligned(1))) Unal4 { uint32_t v; };
@@ -626,22 +624,22 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
     DW_DEV void init(uint8_t *, uint8_t *q) { init(q); }
     DW_DEV void emit()
     {
-        if (DW_KNOCK & 2) asm volatile("" :: "v"(lo), "v"(hi), "v"(p));      // assembled, kept alive, not stored
+        if (probe::off(2)) probe::keep(lo, hi, p);
         else { Unal16 v; v.a = lo; v.b = hi; *reinterpret_cast<Unal16 *>(p) = v; }
         p += 16; lo = hi = 0; n = 0;
     }
     DW_DEV void put(uint32_t b)
     {
-        if (DW_KNOCK & 1) return;
-        if (DW_KNOCK & 64) { asm volatile("" :: "v"(b)); return; }       // producers kept alive, no assembly
+        if (probe::off(1)) return;
+        if (probe::off(64)) { probe::keep(b); return; }
         const uint64_t v = (uint64_t)b << (8 * (n & 7));
         if (n < 8) lo |= v; else hi |= v;
         if (++n == 16) emit();
     }
     DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes, little-endian in v, upper bytes zero
     {
-        if (DW_KNOCK & 1) return;
-        if (DW_KNOCK & 64) { asm volatile("" :: "v"(v), "v"(cnt)); return; }
+        if (probe::off(1)) return;
+        if (probe::off(64)) { probe::keep(v, cnt); return; }
         const uint32_t sh = 8 * (n & 7);
         if (n < 8) { lo |= v << sh; if (sh) hi |= v >> (64 - sh); }
         else hi |= v << sh;
@@ -656,15 +654,15 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
     DW_DEV void put4(uint32_t w) { putn((uint64_t)w, 4); }
     DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)       // sixteen bytes; one store when the section stands at a multiple of 16
     {
-        if (DW_KNOCK & 1) return;
-        if (DW_KNOCK & 64) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d)); return; }
+        if (probe::off(1)) return;
+        if (probe::off(64)) { probe::keep(a, b, c, d); return; }
         const uint64_t x = (uint64_t)a | ((uint64_t)b << 32), y = (uint64_t)c | ((uint64_t)d << 32);
         if (n == 0) { lo = x; hi = y; emit(); }
         else { putn(x, 8); putn(y, 8); }
     }
     DW_DEV void flush()                          // the n < 16 gathered bytes; the next byte starts a new section
     {
-        if (DW_KNOCK & 2) { asm volatile("" :: "v"(lo), "v"(hi), "v"(p), "v"(n)); p += n; lo = hi = 0; n = 0; return; }
+        if (probe::off(2)) { probe::keep(lo, hi, p, n); p += n; lo = hi = 0; n = 0; return; }
         if (n & 8) { Unal8 v; v.v = lo; *reinterpret_cast<Unal8 *>(p) = v; p += 8; lo = hi; }
         if (n & 4) { Unal4 v; v.v = (uint32_t)lo; *reinterpret_cast<Unal4 *>(p) = v; p += 4; lo >>= 32; }
         if (n & 2) { Unal2 v; v.v = (uint16_t)lo; *reinterpret_cast<Unal2 *>(p) = v; p += 2; lo >>= 16; }
@@ -698,7 +696,7 @@ struct FifoWriter {
     }
     DW_DEV void drain()                          // wp >= 32: one unit leaves
     {
-        if (!(DW_KNOCK & 2)) {
+        if (!(probe::off(2))) {
             if (skip == 0) { st16(0); st16(16); }
             else store_range(skip, 32);
         }
@@ -706,16 +704,16 @@ struct FifoWriter {
         *reinterpret_cast<uint64_t *>(f) = ld8(32);      // the (< 8) bytes past the unit move to the front
         dst += 32; wp -= 32;
     }
-    DW_DEV void put(uint32_t b) { if (DW_KNOCK & 1) return; f[wp] = (uint8_t)b; if (++wp >= 32u) drain(); }
+    DW_DEV void put(uint32_t b) { if (probe::off(1)) return; f[wp] = (uint8_t)b; if (++wp >= 32u) drain(); }
     DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes; the bytes above them are overwritten by the next put
     {
-        if (DW_KNOCK & 1) return;
+        if (probe::off(1)) return;
         Unal8 x; x.v = v; *reinterpret_cast<Unal8 *>(f + wp) = x;
         wp += cnt; if (wp >= 32u) drain();
     }
-    DW_DEV void put4(uint32_t w) { if (DW_KNOCK & 1) return; Unal4 x; x.v = w; *reinterpret_cast<Unal4 *>(f + wp) = x; wp += 4; if (wp >= 32u) drain(); }
+    DW_DEV void put4(uint32_t w) { if (probe::off(1)) return; Unal4 x; x.v = w; *reinterpret_cast<Unal4 *>(f + wp) = x; wp += 4; if (wp >= 32u) drain(); }
     DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { putn((uint64_t)a | ((uint64_t)b << 32), 8); putn((uint64_t)c | ((uint64_t)d << 32), 8); }
-    DW_DEV void flush() { if (wp > skip && !(DW_KNOCK & 2)) store_range(skip, wp); dst += wp; wp = skip = 0; }
+    DW_DEV void flush() { if (wp > skip && !(probe::off(2))) store_range(skip, wp); dst += wp; wp = skip = 0; }
 };
 // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream.  The (first) output goes through the FIFO writer (WR = 1)
 // or the register writer (WR = 0: the host found that the FIFO's LDS would cost a resident block per CU); with both outputs (-o 0) the

@@ -198,16 +198,7 @@ __global__ void __launch_bounds__(256) k_range_counts(SimArgs a)
 #endif // DW_HAS(0): k_place
 
 // K6: one lane per read end (LPP = 2: lanes 2q / 2q+1 are the two ends of pair q; LPP = 1: single end).
-// Opt-in phase timing (tools/phase_profile.sh builds a separate library with -DDW_PHASE_TIMING; the
-// product build compiles these macros to nothing): per wave, shader-clock ticks spent in each phase
-// are added to counters[8 + phase].
-#ifdef DW_PHASE_TIMING
-#define PH_INIT() uint64_t ph_t = __builtin_amdgcn_s_memtime()
-#define PH_MARK(k) do { const uint64_t ph_n = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&a.counters[8 + (k)], (unsigned long long)(ph_n - ph_t)); ph_t = ph_n; } while (0)
-#else
-#define PH_INIT() do { } while (0)
-#define PH_MARK(k) do { } while (0)
-#endif
+// DW_PROBE_INIT / DW_PROBE_MARK (phase clocks) and probe::off (parts switched off to weigh them): dw_probe.hpp -- nothing in the product build.
 
 // ---- pieces of a FASTQ record shared by the Illumina / Ion Torrent and the SOLiD write paths ----
 // '@' + "[prefix_]contig" (or "[prefix_]rand"): whole words from LDS (first 128 bytes), any rest from HBM
@@ -384,7 +375,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    PH_INIT();
+    DW_PROBE_INIT();
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
@@ -412,7 +403,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // read buffers live in a global scratch so that LDS does not cap residency; only the run stack of pass 2 stays in LDS
     uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid : dyn_lds + tid;
 
-    PH_MARK(0);     // ticket, fixed strings
+    DW_PROBE_MARK(a, 0);     // ticket, fixed strings
     // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
     // read end, N filter; the two lanes of a pair exchange their verdicts and retry together with attempt + 1 ----
     PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
@@ -426,8 +417,8 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             else if (s > 0) {
                 int64_t start; int step;
                 read_geom(a, sc, pd, j, &start, &step);
-                PH_MARK(7);     // placement draws (phase 1 below is then the base extraction alone)
-                if (DW_KNOCK & 8) { rr = ReadRes{(int32_t)start, 0, 0, 0, 0}; for (int w = 0; w * 8 < s; ++w) lds[w * nthr] = 0x32103210u; }
+                DW_PROBE_MARK(a, 7);     // placement draws (phase 1 below is then the base extraction alone)
+                if (probe::off(8)) { rr = ReadRes{(int32_t)start, 0, 0, 0, 0}; for (int w = 0; w * 8 < s; ++w) lds[w * nthr] = 0x32103210u; }
                 else
                 rr = gen_read<true>(sel_hap(a, sc, pd.hap), sc.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
                 ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
@@ -451,7 +442,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     }
     // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
     // overlaps with that work instead of idling three waves)
-    PH_MARK(1);     // placement + base extraction
+    DW_PROBE_MARK(a, 1);     // placement + base extraction
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // 16-bit draws: one Philox block tests eight bases (the low half of a uniform is drawn lazily, see below); an error marks bit 3 of
     // the base's nibble and its substituted base is drawn afterwards, only for the (few) marked bases
@@ -471,7 +462,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         }
     }
     int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
-    if (valid && (DT != 2 || is_rand) && !(DW_KNOCK & 4)) {
+    if (valid && (DT != 2 || is_rand) && !(probe::off(4))) {
         // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
         const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
         uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
@@ -544,7 +535,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     }
     __syncthreads();
     const uint64_t rand_ii = a.chain[0] + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
-    PH_MARK(2);     // error tests + substitutions
+    DW_PROBE_MARK(a, 2);     // error tests + substitutions
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
     int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
     int32_t e1c = 0, u1 = 0, i1 = 0, x1 = 0;                                   // read end 2 (single-end: zeros, dwgsim.c:643)
@@ -612,7 +603,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         }
     }
 
-    PH_MARK(3);     // name lengths, block scan, look-back
+    DW_PROBE_MARK(a, 3);     // name lengths, block scan, look-back
     // ---- SOLiD records (dwgsim.c:934-976, :1056-1094): the two outputs differ in name counts, suffix, alphabet and length ----
     if (DT == 1) {
         if (emits) {
@@ -649,13 +640,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         Out2<OUT, WR> o;
         if (rec) {
         o.init(s_fifo, (OUT & 1) ? (j ? a.out[1] : a.out[0]) + off_bwa : nullptr, (OUT & 2) ? a.out[2] + off_bf : nullptr);
-        if (!(DW_KNOCK & 16)) {
+        if (!(probe::off(16))) {
         put_name_fixed(o, is_rand ? s_fixed[1] : s_fixed[0], is_rand ? a.rand_fixed : name_fixed, fixed_len);
         if (is_rand) put_rand_tail(o, rand_ii);
         else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
         }
         o.put_suffix((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3, (uint64_t)'\n', 1);
-        PH_MARK(4); // header line
+        DW_PROBE_MARK(a, 4); // header line
         // bases (the second writer of -o 0 starts a new section, so that sixteen bases are one store)
         o.rebase();
         // word w of the record (bases 8w .. 8w + 7).  Ion Torrent, reverse strand: base i of the record = base s_out-1-i of the flow-model
@@ -685,13 +676,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         o.put('\n'); o.put('+'); o.put('\n');
         o.rebase();
         }
-        PH_MARK(5); // sequence line
+        DW_PROBE_MARK(a, 5); // sequence line
         // qualities (dwgsim.c:899-918): up to eight characters per Philox block of the read end's try stream, appended as they come
         if (rec) for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false,
                                         [&](uint64_t blk, uint32_t nb) { o.putn(blk, nb); });
         if (rec) { o.put('\n'); o.flush(); }
     }
-    PH_MARK(6);     // quality line
+    DW_PROBE_MARK(a, 6);     // quality line
 }
 
 // ------------------------------------------------------------------------------------------------

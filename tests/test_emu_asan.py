@@ -48,7 +48,7 @@ def test_kernel_sources_are_asan_clean_on_the_emulator(oracle_bin, tmp_path):
         pytest.skip("libasan not available")
     lib = str(tmp_path / "libdwgsim_emu_asan.so")
     subprocess.run(["g++", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-                    "-I" + os.path.join(HERE, "emu"), "-x", "c++", os.path.join(SRC, "dw_walk.hip"), os.path.join(SRC, "dw_gzip.hip"), os.path.join(SRC, "dw_simulate.hip"),
+                    "-I" + os.path.join(HERE, "emu"), "-I" + SRC, "-x", "c++", os.path.join(SRC, "dw_walk.hip"), os.path.join(SRC, "dw_gzip.hip"), os.path.join(SRC, "dw_simulate.hip"),
                     os.path.join(SRC, "dw_host.cpp"), os.path.join(SRC, "dw_mutin.cpp"), os.path.join(SRC, "dw_job.cpp"), os.path.join(HERE, "emu", "hip_emu.cpp"), "-o", lib], check=True)
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\nLIB = {lib!r}\n" + DRIVER], capture_output=True, text=True, env=env, timeout=1200)

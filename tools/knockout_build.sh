@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../dwgsim_amd/csrc"
 make -s -j12 all
 mkdir -p build/knock
-F="--offload-arch=gfx950 -I. -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-unused-result"
+F="--offload-arch=gfx950 -I../../tools/probe -I. -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -Wno-unused-result"
 bits="${@:-2 64}"
 for k in $bits; do /opt/rocm/bin/hipcc $F -DDW_PART=1 -DDW_KNOCK=$k -c dw_simulate.hip -o build/knock/s1_k$k.o & done
 wait
