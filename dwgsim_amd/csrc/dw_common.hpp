@@ -15,6 +15,7 @@
 // the gfx950 instructions and address spaces this code is written for -- the only header with a stand-in elsewhere (tests/emu/dw_intrin.hpp, found
 // first by the include path of the test-only CPU emulation build: test infrastructure, never part of the product)
 #include <dw_intrin.hpp>
+#include <dw_probe.hpp>
 
 namespace dw {
 
@@ -192,7 +193,7 @@ DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, 
     for (;;) {
         const int64_t idx = k - lane;
         uint64_t v = ST_PREFIX;             // below block 0: an empty prefix
-        if (idx >= 0) { do { v = status_load(&status[idx]); if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2); } while ((v >> 62) == 0); }
+        if (idx >= 0) { do { v = status_load(&status[idx]); if (probe::off(2048) && (v >> 62) == 0) v = ST_PREFIX; if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2); } while ((v >> 62) == 0); }      // (probe 2048: a look-back that never waits -- garbage offsets, analysis only)
         const uint64_t pm = __ballot((v >> 62) == 2);
         const int first = pm ? (__ffsll((unsigned long long)pm) - 1) : 64;
         excl += wave_sum_u64(lane <= first ? (v & ST_VAL) : 0);

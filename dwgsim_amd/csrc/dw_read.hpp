@@ -184,7 +184,8 @@ DW_DEV PairDraw draw_pair(const SimArgs &a, const SegCtx &sc, RngKey key, uint64
     else {
         uint32_t t = 0; int32_t pos, d; bool continue_flag = false;
         do {
-            if (s1 > 0) {
+            if (s1 > 0 && probe::off(32)) d = a.p.dist;      // (analysis: the pair without its insert-size normal)
+            else if (s1 > 0) {
                 double v1, v2, rsq; uint32_t r = 0;
                 do {
                     const U4 b = rng_block(key, D_PLACE_NORM, ii, att, r, t);

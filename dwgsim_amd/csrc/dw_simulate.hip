@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     uint32_t rrank, rtot;
     { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     if (wave == 0) {
-        const uint64_t g = lookback_excl(a.status[2], t, rtot, 0);
+        const uint64_t g = probe::off(128) ? (uint64_t)t * 6 : lookback_excl(a.status[2], t, rtot, 0);
         if (lane == 0) { s_rbase = g; if (t + 1 == a.n_blocks) a.counters[3] = g + rtot; }
     }
     // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
@@ -583,10 +583,10 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         e1 = ex[0]; e2 = ex[1]; T1 = tot[0]; T2 = tot[1];
     }
     if (wave == 0) {
-        const uint64_t g = lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
+        const uint64_t g = probe::off(128) ? (uint64_t)t * PPB * (uint64_t)(60 + 2 * s + a.rand_fixed_len + sg->name_fixed_len) : lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
         if (BF_SCAN) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
     }
-    if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
+    if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = probe::off(128) ? (uint64_t)t * PPB * (uint64_t)(60 + 2 * s + a.rand_fixed_len + sg->name_fixed_len) : lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
     const uint64_t G1 = s_base[0], G2 = s_base[1];
     const uint64_t reads_before_block = (sg->pair_off + (uint64_t)(t - sg->first_block) * PPB) * (uint64_t)LPP;      // (every block in front of a range's last is full)
