@@ -106,7 +106,7 @@ struct dwgsim_hip_ctx {
     std::vector<Group> groups;
     std::vector<HandleRef> handles;          // contig handle -> (group, member); handles are never reused
     // simulate() working set
-    DevBuf meta, fail_summ, block_rand, status_all, out[2][3];
+    DevBuf meta, fail_summ, block_rand, status_all, out[2][3], split_state, split_hand, split_agg, split_pre, split_chunk;
     // walk-stream working set (grow-only)
     DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand, place_list, place_aux;
     uint8_t *h_up = nullptr; size_t h_up_cap = 0; hipEvent_t ev_up = nullptr; bool up_in_flight = false;      // page-locked staging of a group's sequence
@@ -124,7 +124,7 @@ struct dwgsim_hip_ctx {
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
-    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0;      // dwgsim_hip_debug_option / _debug_get
+    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0; int split = -1;      // dwgsim_hip_debug_option / _debug_get
     hipEvent_t ev_cnt0 = nullptr, ev_cnt1 = nullptr;
     bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
@@ -534,7 +534,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->walk_stream) hipStreamSynchronize(c->walk_stream);
     for (auto &g : c->groups) if (g.alive) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
-    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
+    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->split_state, &c->split_hand, &c->split_agg, &c->split_pre, &c->split_chunk, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
                       &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch}) hipFree(b->p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
@@ -1194,6 +1194,13 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size(); a.flow_maxk = flow_max_gap(c->flow);
     a.flow_scratch = nullptr;
+    // Short Illumina reads run as two kernels with the offsets computed in between (dw_simulate.hip SPLIT): no look-backs, and the second half --
+    // no staged bases in LDS -- writes the text in 64-byte bursts.  What does not scale with the read length (placement, the look-backs, the name)
+    // is most of the work there: 2 x 36 / 2 x 50 / 2 x 75 bp and 100 bp single-end run 16 / 17 / 9 / 15 % faster than in the single kernel, 2 x 100
+    // the same, 2 x 150 2-3 % slower (the state crosses HBM, 2.5 GB per chr20-sized launch): profiles/r04_split.txt.  "split" = 0 / 1 forces either.
+    const bool split_wins = lmax0 <= 100;
+    a.split = (p.data_type == 0 && a.sim_threads == SIM_THREADS && (c->split < 0 ? split_wins : c->split != 0)) ? 1 : 0;
+    if (a.split && c->writer < 0) a.fifo = 1;      // (its LDS holds no bases: the FIFO writer always fits)
     return 0;
 }
 
@@ -1312,7 +1319,12 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
         if (sl.fetch_in_flight) { HIPC(c, hipStreamWaitEvent(c->stream, sl.ev_fetched, 0)); bool grows = false; for (int t = 0; t < 3; ++t) if (cap[t] + 64 > c->out[slot][t].cap) grows = true; if (grows) HIPC(c, hipEventSynchronize(sl.ev_fetched)); sl.fetch_in_flight = false; }
         for (int t = 0; t < 3; ++t) { if (ensure(c, c->out[slot][t], cap[t] + 64)) return DWGSIM_HIP_ERR_DEVICE; a.out[t] = (uint8_t *)c->out[slot][t].p; }
         if (ensure(c, c->block_rand, sizeof(uint32_t) * (size_t)nblk)) return DWGSIM_HIP_ERR_DEVICE;
-        if (ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)nblk)) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
+        if (!a.split && ensure(c, c->status_all, 4 * sizeof(uint64_t) * (size_t)nblk)) return DWGSIM_HIP_ERR_DEVICE;      // the four look-back arrays, contiguous: one memset per batch
+        if (a.split) {      // what the first half hands to the second
+            if (ensure(c, c->split_state, sizeof(uint32_t) * (size_t)a.lds_words * SIM_THREADS * (size_t)nblk) || ensure(c, c->split_hand, 16 * (size_t)SIM_THREADS * (size_t)nblk) ||
+                ensure(c, c->split_agg, 16 * (size_t)nblk) || ensure(c, c->split_pre, 32 * (size_t)nblk) || ensure(c, c->split_chunk, 32 * ((size_t)nblk / 1024 + 1))) return DWGSIM_HIP_ERR_DEVICE;
+            a.split_state = (uint32_t *)c->split_state.p; a.split_hand = (uint32_t *)c->split_hand.p; a.split_agg = (uint32_t *)c->split_agg.p; a.split_pre = (uint64_t *)c->split_pre.p; a.split_chunk = (uint64_t *)c->split_chunk.p;
+        }
         if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
         const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
         if (ensure(c, c->fail_summ, (nfb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
@@ -1356,10 +1368,10 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
     HIPC(c, hipMemcpyAsync(sl.segs.p, sl.h_segs, sizeof(SimSeg) * segs.size(), hipMemcpyHostToDevice, c->stream));
     a.segs = (const SimSeg *)sl.segs.p; a.n_seg = (int32_t)segs.size(); a.n_blocks = nblk; a.n_pairs = n_pairs;
     a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = sl.d_counters;
-    for (int j = 0; j < 4; ++j) a.status[j] = (uint64_t *)c->status_all.p + (size_t)j * (size_t)nblk;
+    for (int j = 0; j < 4; ++j) a.status[j] = a.split ? nullptr : (uint64_t *)c->status_all.p + (size_t)j * (size_t)nblk;
     sl.group = c->handles[(size_t)g.first_handle].group;
     HIPC(c, hipMemsetAsync(sl.d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
-    HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
+    if (!a.split) HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
     HIPC(c, hipEventRecord(sl.ev_k0, c->stream));
     launch_simulate(c->stream, a);
     HIPC(c, hipEventRecord(sl.ev_k1, c->stream));
@@ -1582,7 +1594,9 @@ int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *c, const void *text, size_t n, void 
 // "writer" = 0 / 1 forces the register / FIFO record writer of the Illumina kernels (-1: chosen by LDS occupancy),
 // "sim_threads" = 64 forces the one-wave blocks of the long-read variant (measured: 25 % slower on 2 x 150 bp, small jobs included),
 // "walk_seg_min" = n runs the walk's two serial scans in their segmented form from a capacity of n candidates on (default 16384; 0 restores it),
-// "place_cap" = n gives the lists of pairs that k_place leaves open room for n entries each (exercises the second, full-size run).
+// "place_cap" = n gives the lists of pairs that k_place leaves open room for n entries each (exercises the second, full-size run),
+// "split" = 0 / 1 runs the Illumina read kernel as one kernel with look-backs / as two kernels with the offsets computed in between (-1: two for reads of
+// up to 100 bases).
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
 {
     if (!c || !key) return DWGSIM_HIP_ERR_ARG;
@@ -1593,6 +1607,7 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "sim_threads")) c->force_threads = (int)value;
     else if (!strcmp(key, "walk_seg_min")) walk_debug_seg_min((uint32_t)value);      // (process-wide)
     else if (!strcmp(key, "place_cap")) c->place_cap = value;
+    else if (!strcmp(key, "split")) c->split = (int)value;
     else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }

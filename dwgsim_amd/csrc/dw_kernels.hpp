@@ -15,8 +15,9 @@ constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (
 constexpr int FLOW_STACK_RUNS = 32;           // Ion Torrent pass 2: (base, count) runs that can be pending in front of the examined base (two per LDS word)
 constexpr int SIM_THREADS_LONG = 64;          // ... for reads whose staged bases do not fit LDS at SIM_THREADS lanes (up to ~5 kb)
 constexpr int SIM_FIFO_BYTES = 40;            // per lane: the text FIFO of the record writer (one 32-byte burst + the overshoot of an 8-byte put)
+constexpr int SIM_FIFO_BYTES_WIDE = 72;       // ... with 64-byte bursts (second half of the two-kernel form: no staged bases compete for LDS)
 // dynamic LDS of a k_simulate block: [words_per_lane][lanes] staged bases | the two base-quality tables | [lanes] text FIFOs (16-byte aligned)
-inline size_t sim_lds_bytes(size_t words_per_lane, size_t lanes, size_t qb_words, bool fifo) { return ((words_per_lane * lanes + 2 * qb_words + 3) & ~(size_t)3) * 4 + (fifo ? lanes * (size_t)SIM_FIFO_BYTES : 0); }
+inline size_t sim_lds_bytes(size_t words_per_lane, size_t lanes, size_t qb_words, bool fifo, size_t fifo_bytes = SIM_FIFO_BYTES) { return ((words_per_lane * lanes + 2 * qb_words + 3) & ~(size_t)3) * 4 + (fifo ? lanes * fifo_bytes : 0); }
 // blocks of SIM_THREADS lanes a CU holds at this much dynamic LDS (160 KB per CU in granules of 1280 bytes, ~0.6 KB static per block), at most `cap` (the register limit)
 inline int sim_blocks_per_cu(size_t dyn_lds, int cap) { const size_t per = (dyn_lds + 640 + 1279) / 1280 * 1280; const int b = (int)(163840 / per); return b < cap ? b : cap; }
 constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for (160 KB per CU minus the static part)
@@ -154,6 +155,12 @@ struct SimArgs {
     int32_t sim_threads;          // lanes per k_simulate block chosen by the host: SIM_THREADS, or SIM_THREADS_LONG for long reads
     int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
     int32_t flow_maxk;             // ... and the largest number of flows between a flow and the next flow of some base (flow_max_gap)
+    int32_t split;                 // 1: k_simulate runs as two kernels (dw_simulate.hip SPLIT) handing their state over through the arrays below
+    uint32_t *split_state;         // per block [lds_words][lanes]: the staged bases after the error phase
+    uint32_t *split_hand;          // per lane 16 bytes: ext_coor | n_err, n_sub | n_indel, n_ins | attempt, flags
+    uint32_t *split_agg;           // per block 16 bytes: random pairs, bytes of stream 1 / 2 (without random reads' hexadecimal digits)
+    uint64_t *split_pre;           // per block 4 words: random reads / bytes of stream 1 / bytes of stream 2 in front of it inside its chunk of 1024 blocks (k_split_scan1)
+    uint64_t *split_chunk;         // per chunk 4 words: the chunk's sums (k_split_scan1), then the sums in front of the chunk (k_split_scan2)
     uint32_t *flow_scratch;        // Ion Torrent: per-block read buffers in HBM, (lds_words + ceil(cap/16)) words per lane, word w of lane t at [w * nthr + t]
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes
 };

@@ -677,9 +677,12 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
 // touched sector per burst: 16-byte pieces cost 2.5x-3.3x the text, aligned 32-byte bursts 1.1x (tools/ubench_write_bursts.hip,
 // profiles/r02_ubench_write_bursts.txt).  FIFO position 0 always stands for the 32-byte aligned address dst; a record starts at position
 // skip = its address mod 32.  40 bytes, not 48 with 16-byte appends: LDS is what limits the blocks per CU (5 at 2 x 150 bp).
+// BURST = 64 (a 72-byte FIFO): where LDS does not bound residency -- the second half of the two-kernel form, which stages no bases -- the text
+// leaves as aligned 64-byte bursts: whole pairs of sectors, 1.02x the text instead of 1.15x-1.5x.
+template <uint32_t BURST = 32u>
 struct FifoWriter {
     uint8_t *f, *dst; uint32_t wp, skip;
-    DW_DEV void init(uint8_t *fifo, uint8_t *rec) { const uint32_t h = (uint32_t)((uintptr_t)rec & 31u); f = fifo; dst = rec - h; wp = skip = h; }
+    DW_DEV void init(uint8_t *fifo, uint8_t *rec) { const uint32_t h = (uint32_t)((uintptr_t)rec & (BURST - 1u)); f = fifo; dst = rec - h; wp = skip = h; }
     DW_DEV uint64_t ld8(uint32_t b) const { return *reinterpret_cast<const uint64_t *>(f + b); }
     DW_DEV void st16(uint32_t b) const { *reinterpret_cast<uint4 *>(dst + b) = make_uint4((uint32_t)ld8(b), (uint32_t)(ld8(b) >> 32), (uint32_t)ld8(b + 8), (uint32_t)(ld8(b + 8) >> 32)); }
     DW_DEV void store_range(uint32_t from, uint32_t upto)        // bytes [from, upto) of the unit (ragged first / last unit of a record), from LDS
@@ -690,37 +693,39 @@ struct FifoWriter {
         if ((b & 4u) && b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
         if ((b & 8u) && b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
         if (b + 16 <= upto) { st16(b); b += 16; }
+        if (BURST == 64u) { if (b + 16 <= upto) { st16(b); b += 16; } if (b + 16 <= upto) { st16(b); b += 16; } }
         if (b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
         if (b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
         if (b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
         if (b + 1 <= upto) { dst[b] = f[b]; }
     }
-    DW_DEV void drain()                          // wp >= 32: one unit leaves
+    DW_DEV void drain()                          // wp >= BURST: one unit leaves
     {
         if (!(probe::off(2))) {
-            if (skip == 0) { st16(0); st16(16); }
-            else store_range(skip, 32);
+            if (skip == 0) { st16(0); st16(16); if (BURST == 64u) { st16(32); st16(48); } }
+            else store_range(skip, BURST);
         }
         skip = 0;
-        *reinterpret_cast<uint64_t *>(f) = ld8(32);      // the (< 8) bytes past the unit move to the front
-        dst += 32; wp -= 32;
+        *reinterpret_cast<uint64_t *>(f) = ld8(BURST);      // the (< 8) bytes past the unit move to the front
+        dst += BURST; wp -= BURST;
     }
-    DW_DEV void put(uint32_t b) { if (probe::off(1)) return; f[wp] = (uint8_t)b; if (++wp >= 32u) drain(); }
+    DW_DEV void put(uint32_t b) { if (probe::off(1)) return; f[wp] = (uint8_t)b; if (++wp >= BURST) drain(); }
     DW_DEV void putn(uint64_t v, uint32_t cnt)   // cnt (1..8) bytes; the bytes above them are overwritten by the next put
     {
         if (probe::off(1)) return;
         Unal8 x; x.v = v; *reinterpret_cast<Unal8 *>(f + wp) = x;
-        wp += cnt; if (wp >= 32u) drain();
+        wp += cnt; if (wp >= BURST) drain();
     }
-    DW_DEV void put4(uint32_t w) { if (probe::off(1)) return; Unal4 x; x.v = w; *reinterpret_cast<Unal4 *>(f + wp) = x; wp += 4; if (wp >= 32u) drain(); }
+    DW_DEV void put4(uint32_t w) { if (probe::off(1)) return; Unal4 x; x.v = w; *reinterpret_cast<Unal4 *>(f + wp) = x; wp += 4; if (wp >= BURST) drain(); }
     DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { putn((uint64_t)a | ((uint64_t)b << 32), 8); putn((uint64_t)c | ((uint64_t)d << 32), 8); }
     DW_DEV void flush() { if (wp > skip && !(probe::off(2))) store_range(skip, wp); dst += wp; wp = skip = 0; }
 };
 // OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream.  The (first) output goes through the FIFO writer (WR = 1)
 // or the register writer (WR = 0: the host found that the FIFO's LDS would cost a resident block per CU); with both outputs (-o 0) the
 // bfast stream always takes the register writer.
-template <int WR> struct PrimaryWriter { typedef FifoWriter type; };
+template <int WR> struct PrimaryWriter { typedef FifoWriter<32u> type; };      // WR = 1
 template <> struct PrimaryWriter<0> { typedef Writer type; };
+template <> struct PrimaryWriter<2> { typedef FifoWriter<64u> type; };
 template <int OUT, int WR = 1>
 struct Out2 {
     typename PrimaryWriter<WR>::type a; Writer b;

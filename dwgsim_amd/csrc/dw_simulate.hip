@@ -15,6 +15,7 @@
 //   DW_PART 0: k_place, k_place_rest, k_selftest_fp64, host launchers and the k_simulate dispatcher
 //   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
 //   DW_PART 7, 8: the one-wave-per-block variants for long Illumina / SOLiD reads
+//   DW_PART 9, 10: the two-kernel form (SPLIT) of the paired / single-end Illumina variants
 //   DW_PART -1 (default): everything in one translation unit
 #include <algorithm>
 #include "dw_read.hpp"
@@ -30,6 +31,9 @@
 #endif
 #ifndef DW_SIM_WAVES_BOTH
 #define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0)
+#endif
+#ifndef DW_SIMB_WAVES
+#define DW_SIMB_WAVES 6      // ... requested for the second half of the two-kernel form (text assembly)
 #endif
 #ifndef DW_ION_WAVES
 #define DW_ION_WAVES 5       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants: without the hint the window registers of the extraction push them to 104 VGPRs = 4 waves (measured 165 -> 187 M reads/s at 5; 6 brings nothing)
@@ -359,12 +363,31 @@ DW_DEV void for_each_quality_block(const SimParams &p, RngKey key, uint32_t dom,
     }
 }
 
+// sum over i < c of the hexadecimal digits of b + i: what the running index adds to the names of c consecutive random reads (dwgsim.c:1044-1048)
+DW_DEV uint64_t hex_digits_sum(uint64_t b, uint64_t c)
+{
+    uint64_t sum = 0;
+    for (int d = 1; d <= 16 && c; ++d) {                     // numbers with d digits: [16^(d-1), 16^d), from 0 for d = 1
+        const uint64_t hi = d == 16 ? ~0ull : (1ull << (4 * d)) - 1ull;      // the largest of them
+        if (b > hi) continue;
+        const uint64_t n = hi - b + 1ull < c && d < 16 ? hi - b + 1ull : c;
+        sum += n * (uint64_t)d; b += n; c -= n;
+    }
+    return sum;
+}
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 // NTHR: lanes per block.  SIM_THREADS_LONG (one wave) is the variant for reads too long to stage at SIM_THREADS lanes.
 // WR = 1: records leave through the per-lane LDS FIFO; 0: straight from registers (dw_read.hpp FifoWriter / Writer)
-template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1>
-__global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+// SPLIT: 0 = the whole path in one kernel: a block learns where its records go from a decoupled look-back over the blocks in front of it.
+// 1 / 2 = the same code cut in two at the point where the record lengths are known (Illumina, 256-lane blocks): the FIRST HALF (1) runs up to
+// there and hands its state over through HBM -- the staged, finished bases, 16 bytes of name fields per lane, three sums per block; k_split_scan
+// turns the sums into every block's offsets; the SECOND HALF (2) writes the text.  Neither half waits for another block: in the single kernel a
+// block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
+// block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
+template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
+__global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
+    static_assert(SPLIT == 0 || (DT == 0 && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants with 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
     __shared__ uint32_t s_ticket;
@@ -376,21 +399,25 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     DW_PROBE_INIT();
-    if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
-    for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
+    if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
+    if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
-    uint32_t *const s_qb = dyn_lds + (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr;
-    for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
+    const size_t stage_words = SPLIT == 2 ? 0 : (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words);      // (the second half of the two-kernel form reads its bases from HBM)
+    uint32_t *const s_qb = dyn_lds + stage_words * nthr;
+    if (SPLIT != 1) for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     // this lane's text FIFO (record writer), behind the tables
-    uint8_t *const s_fifo = reinterpret_cast<uint8_t *>(dyn_lds + ((((size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words) * nthr + 2 * (size_t)a.qb_words) + 3) & ~(size_t)3)) + (size_t)tid * SIM_FIFO_BYTES;
-    __syncthreads();
-    const uint32_t t = uniform_u32(s_ticket);                     // logical block: predecessors have started
+    uint8_t *const s_fifo = reinterpret_cast<uint8_t *>(dyn_lds + (((stage_words * nthr + 2 * (size_t)a.qb_words) + 3) & ~(size_t)3)) + (size_t)tid * (WR == 2 ? SIM_FIFO_BYTES_WIDE : SIM_FIFO_BYTES);
+    if (SPLIT == 0) __syncthreads();
+    constexpr int H = SPLIT;      // which half of the path this kernel is: 0 both (the single kernel), 1 first, 2 second
+    // logical block.  One kernel: from an atomic ticket, so that a block's predecessors have started when it looks back at them.  Two kernels:
+    // no block waits for another, the block index will do
+    const uint32_t t = SPLIT == 0 ? uniform_u32(s_ticket) : (uint32_t)blockIdx.x;
     // the read-index range (contig, first index, count) this block belongs to: block-uniform, its fields live in scalar registers
     const SegPtr sg = as_constant(a.segs) + seg_of_block(as_constant(a.segs), a.n_seg, t);
     const SegCtx sc = seg_ctx(a, sg);
     const uint8_t *name_fixed = a.names + sg->name_off;
-    for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
+    if (H != 1) for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
     if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
     const int j = (LPP == 2) ? (tid & 1) : 0;
     const uint64_t pair_in = (uint64_t)(t - sg->first_block) * PPB + (uint64_t)(tid / LPP);      // inside the range
@@ -401,7 +428,9 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const int s = sel_len(a, j);
     // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
     // read buffers live in a global scratch so that LDS does not cap residency; only the run stack of pass 2 stays in LDS
-    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid : dyn_lds + tid;
+    // (second half of the two-kernel form: the tile's staged bases where the first half left them, read once, in batches of eight words)
+    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid
+                  : SPLIT == 2 ? a.split_state + (size_t)t * ((size_t)a.lds_words * nthr) + tid : dyn_lds + tid;
 
     DW_PROBE_MARK(a, 0);     // ticket, fixed strings
     // ---- attempts until the pair is accepted (dwgsim.c:649-843): placement, haplotype, strands, base extraction of this
@@ -409,6 +438,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     PairDraw pd; pd.is_rand = true; pd.pos = pd.d = 0; pd.hap = 0; pd.strand0 = pd.strand1 = 0;
     ReadRes rr{0, 0, 0, 0, 0};
     uint32_t att = 0; bool is_rand = false, done = !valid;
+    int32_t n_err = 0;
+    int s_out = s;                              // read length after errors (changes only for Ion Torrent)
+    bool flow_reversed = false;
+    const int nw = (s + 7) >> 3;
+    int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
+    uint32_t rrank = 0, rtot = 0;
+    if (H != 2) {
     while (__ballot(!done)) {
         bool ok = true;
         if (!done) {
@@ -434,11 +470,12 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u) | ((sg->contig_start && pair_in == 0) ? 0x40000000u : 0u);
     { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
     // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
-    uint32_t rrank, rtot;
+    if (H == 0) {
     { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     if (wave == 0) {
         const uint64_t g = probe::off(128) ? (uint64_t)t * 6 : lookback_excl(a.status[2], t, rtot, 0);
         if (lane == 0) { s_rbase = g; if (t + 1 == a.n_blocks) a.counters[3] = g + rtot; }
+    }
     }
     // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
     // overlaps with that work instead of idling three waves)
@@ -446,10 +483,6 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // 16-bit draws: one Philox block tests eight bases (the low half of a uniform is drawn lazily, see below); an error marks bit 3 of
     // the base's nibble and its substituted base is drawn afterwards, only for the (few) marked bases
-    int32_t n_err = 0;
-    int s_out = s;                              // read length after errors (changes only for Ion Torrent)
-    bool flow_reversed = false;
-    const int nw = (s + 7) >> 3;
     if (DT == 2) {                              // dwgsim.c:861-864; every lane calls (the second pass regroups the lanes of a wave)
         const bool flows = valid && !is_rand && s > 0;
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
@@ -461,7 +494,6 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
         }
     }
-    int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
     if (valid && (DT != 2 || is_rand) && !(probe::off(4))) {
         // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
         const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
@@ -533,8 +565,27 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             }
         }
     }
-    __syncthreads();
-    const uint64_t rand_ii = a.chain[0] + s_rbase + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+    }      // H != 2: placement, extraction, errors
+    // ---- the second half of the two-kernel form picks up what the first half left: 16 bytes of name fields per lane and the staged bases ----
+    // the random reads and the bytes of stream 1 / 2 in front of this block: inside its chunk of 1024 blocks + in front of the chunk (k_split_scan1 / 2)
+    // + the hexadecimal digits that the random reads in front of it add to their names (one record per random pair in each stream)
+    uint64_t pre_rand = 0, pre_b1 = 0, pre_b2 = 0;
+    if (SPLIT == 2) {
+        const uint64_t *pi = a.split_pre + 4 * (size_t)t, *pc = a.split_chunk + 4 * (size_t)(t >> 10);
+        pre_rand = pi[0] + pc[0];
+        const uint64_t hexb = hex_digits_sum(a.chain[0], pre_rand);
+        pre_b1 = pi[1] + pc[1] + hexb; pre_b2 = pi[2] + pc[2] + (LPP == 2 ? hexb : 0ull);
+    }
+    if (H == 2) {
+        const uint4 hm = reinterpret_cast<const uint4 *>(a.split_hand)[(size_t)t * nthr + tid];
+        rr.ext_coor = (int32_t)hm.x; n_err = (int32_t)(hm.y & 0xffffu); rr.n_sub = (int32_t)(hm.y >> 16); rr.n_indel = (int32_t)(hm.z & 0xffffu); rr.n_ins = (int32_t)(hm.z >> 16);
+        att = hm.w & 0x3fffu; is_rand = (hm.w >> 14) & 1u; pd.strand0 = (int)((hm.w >> 15) & 1u); pd.strand1 = (int)((hm.w >> 16) & 1u);
+        __syncthreads();      // the tables of the prologue (names, base qualities)
+        { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
+    }
+    if (H == 0) __syncthreads();
+    // (the first half does not know the running index yet: its lengths leave the hexadecimal digits of random reads' names out, k_split_scan adds them)
+    const uint64_t rand_ii = H == 1 ? 0 : a.chain[0] + (SPLIT == 2 ? pre_rand : s_rbase) + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
     DW_PROBE_MARK(a, 2);     // error tests + substitutions
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
     int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
@@ -556,7 +607,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     }
     const NameCounts nc{e0, u0, i0, e1c, u1, i1}, ncw{e0w, u0, i0w, e1w, u1, i1w};
     uint32_t tail_len, tail_len_w, fixed_len;
-    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + ndigits16(rand_ii); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
+    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + (H == 1 ? 0u : ndigits16(rand_ii)); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
     else {
         fixed_len = (uint32_t)sg->name_fixed_len;
         tail_len = pair_tail_len(x0, x1, nc, ii);
@@ -577,24 +628,40 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         const uint32_t v[3] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u, Lbf};
         uint32_t ex[3], tot[3]; block_excl_scan_n<3>(v, sm_bytes, ex, tot);
         e1 = ex[0]; e2 = ex[1]; eb = ex[2]; T1 = tot[0]; T2 = tot[1]; Tb = tot[2];
-    } else {
+    } else if (H != 1) {
         const uint32_t v[2] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u};
         uint32_t ex[2], tot[2]; block_excl_scan_n<2>(v, sm_bytes, ex, tot);
         e1 = ex[0]; e2 = ex[1]; T1 = tot[0]; T2 = tot[1];
+    } else { e1 = e2 = T1 = T2 = 0; }
+    if (H == 1) {
+        // ---- end of the first half: the block's sums (random pairs, bytes of stream 1 / 2 without the random reads' hexadecimal digits), this
+        // lane's name fields and its staged bases go to HBM, each array laid out so that a wave's accesses are contiguous ----
+        const uint32_t rsum = wave_sum_u32((is_rand && j == 0) ? 1u : 0u), b1 = wave_sum_u32(j == 0 ? Lbwa : 0u), b2 = wave_sum_u32(j == 1 ? Lbwa : 0u);
+        if (lane == 0) { sm_rand[0][wave] = rsum; sm_bytes[0][wave] = b1; sm_bytes[1][wave] = b2; }
+        const uint4 hm = make_uint4((uint32_t)rr.ext_coor, (uint32_t)n_err | ((uint32_t)rr.n_sub << 16), (uint32_t)rr.n_indel | ((uint32_t)rr.n_ins << 16),
+                                    att | (is_rand ? 1u << 14 : 0u) | ((uint32_t)pd.strand0 << 15) | ((uint32_t)pd.strand1 << 16));
+        reinterpret_cast<uint4 *>(a.split_hand)[(size_t)t * nthr + tid] = hm;
+        uint32_t *gs = a.split_state + (size_t)t * ((size_t)a.lds_words * nthr) + tid;
+        if (valid) for (int w = 0; w < nw; ++w) gs[(size_t)w * nthr] = lds[w * nthr];
+        __syncthreads();
+        if (tid == 0) { uint32_t r = 0, t1 = 0, t2 = 0; for (int w = 0; w < nwaves; ++w) { r += sm_rand[0][w]; t1 += sm_bytes[0][w]; t2 += sm_bytes[1][w]; } reinterpret_cast<uint4 *>(a.split_agg)[t] = make_uint4(r, t1, t2, 0u); }
+        return;
     }
+    if (H == 0) {
     if (wave == 0) {
         const uint64_t g = probe::off(128) ? (uint64_t)t * PPB * (uint64_t)(60 + 2 * s + a.rand_fixed_len + sg->name_fixed_len) : lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
         if (BF_SCAN) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
     }
     if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = probe::off(128) ? (uint64_t)t * PPB * (uint64_t)(60 + 2 * s + a.rand_fixed_len + sg->name_fixed_len) : lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
-    const uint64_t G1 = s_base[0], G2 = s_base[1];
+    }
+    const uint64_t G1 = SPLIT == 2 ? pre_b1 : s_base[0], G2 = SPLIT == 2 ? pre_b2 : s_base[1];
     const uint64_t reads_before_block = (sg->pair_off + (uint64_t)(t - sg->first_block) * PPB) * (uint64_t)LPP;      // (every block in front of a range's last is full)
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
     // Illumina: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
     const uint64_t off_bf = BF_SCAN ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
-    if (tid == nthr - 1) {
+    if (H == 0 && tid == nthr - 1) {
         if (t + 1 == a.n_blocks) {
             const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
             a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
@@ -658,20 +725,32 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
             const uint32_t a0 = lds[(lo >> 3) * nthr], a1 = (lo & 7) ? lds[((lo >> 3) + 1) * nthr] : 0u;
             return (uint32_t)(reverse_nibbles((uint64_t)__builtin_amdgcn_alignbit(a1, a0, 4u * (uint32_t)(lo & 7))) >> 32);
         };
+        auto put_last_word = [&](uint32_t word, int rem) __attribute__((always_inline)) {      // fewer than sixteen bases left: this word's share of them
+            if (rem >= 8) { o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16)); }
+            else { const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16); for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff); }
+        };
+        if (SPLIT == 2) {      // the bases come from HBM: eight words (64 bases) fetched together, then written
+            const int full16 = s_out >> 4;                       // whole groups of sixteen bases
+            for (int g0 = 0; g0 < full16; g0 += 4) {
+                uint32_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = (g0 + (k >> 1) < full16) ? lds[(size_t)(2 * g0 + k) * nthr] : 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (g0 + q < full16) o.put16(base_chars4(r[2 * q]), base_chars4(r[2 * q] >> 16), base_chars4(r[2 * q + 1]), base_chars4(r[2 * q + 1] >> 16));
+            }
+            if (s_out & 15) {                                     // the last, shorter group
+                const int w = 2 * full16, rem = s_out - 8 * w;
+                const uint32_t wa = lds[(size_t)w * nthr], wb = rem > 8 ? lds[(size_t)(w + 1) * nthr] : 0u;
+                put_last_word(wa, rem);
+                if (rem > 8) put_last_word(wb, rem - 8);
+            }
+        } else {
         int w = 0;
         for (; (w + 2) * 8 <= s_out; w += 2) {
             const uint32_t w0 = rec_word(w), w1 = rec_word(w + 1);
             o.put16(base_chars4(w0), base_chars4(w0 >> 16), base_chars4(w1), base_chars4(w1 >> 16));
         }
-        for (; w * 8 < s_out; ++w) {
-            const uint32_t word = rec_word(w);
-            const int rem = s_out - w * 8;
-            if (rem >= 8) {
-                o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16));
-            } else {
-                const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16);
-                for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff);
-            }
+        for (; w * 8 < s_out; ++w) put_last_word(rec_word(w), s_out - w * 8);
         }
         o.put('\n'); o.put('+'); o.put('\n');
         o.rebase();
@@ -802,6 +881,53 @@ void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *m
 {
     hipLaunchKernelGGL(k_selftest_fp64, dim3(cdiv(n, 256)), dim3(256), 0, st, seed, n, mism);
 }
+// ---- the two-kernel form of k_simulate (SPLIT): every block's offsets from the sums its first half left ----
+// Exclusive sums over the logical blocks of {random pairs, bytes of stream 1, bytes of stream 2} (agg, 16 bytes per block: the byte counts
+// without the hexadecimal digits of random reads' names), in two small kernels.  k_split_scan1: a block per 1024 logical blocks -- their sums
+// scanned inside the chunk -> pre[4 t .. 4 t + 2], the chunk's totals -> chunk[4 c ..].  k_split_scan2 (one wave): the chunk totals scanned ->
+// chunk[4 c ..] = sums in front of chunk c, and the launch's totals into counters[3 .. 6] as the single kernel leaves them.  The second half
+// adds pre + chunk and the digits (split_offsets below).
+__global__ void __launch_bounds__(1024) k_split_scan1(SimArgs a)
+{
+    __shared__ uint32_t sm[3][16];
+    const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+    uint4 g = make_uint4(0, 0, 0, 0);
+    if (t < a.n_blocks) g = reinterpret_cast<const uint4 *>(a.split_agg)[t];
+    const uint32_t v[3] = {g.x, g.y, g.z};
+    uint32_t ex[3], tot[3];
+    block_excl_scan_n<3>(v, sm, ex, tot);
+    if (t < a.n_blocks) { uint64_t *o = a.split_pre + 4 * (size_t)t; o[0] = ex[0]; o[1] = ex[1]; o[2] = ex[2]; }
+    if (threadIdx.x == 0) { uint64_t *c = a.split_chunk + 4 * (size_t)blockIdx.x; c[0] = tot[0]; c[1] = tot[1]; c[2] = tot[2]; }
+}
+__global__ void __launch_bounds__(64) k_split_scan2(SimArgs a, int lpp)
+{
+    const uint32_t nch = (a.n_blocks + 1023u) / 1024u;
+    uint64_t run[3] = {0, 0, 0};
+    for (uint32_t base = 0; base < nch; base += 64u) {
+        const uint32_t c = base + threadIdx.x;
+        uint64_t v[3] = {0, 0, 0};
+        if (c < nch) for (int k = 0; k < 3; ++k) v[k] = a.split_chunk[4 * (size_t)c + k];
+        uint64_t inc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint64_t x = v[k];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t ol = (uint32_t)__shfl_up((int)(uint32_t)x, d), oh = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d); if (lane_id() >= d) x += ((uint64_t)oh << 32) | ol; }
+            inc[k] = x;
+        }
+        if (c < nch) for (int k = 0; k < 3; ++k) a.split_chunk[4 * (size_t)c + k] = run[k] + inc[k] - v[k];
+        for (int k = 0; k < 3; ++k) { const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)inc[k], 63), hi = (uint32_t)__shfl((int)(uint32_t)(inc[k] >> 32), 63); run[k] += ((uint64_t)hi << 32) | lo; }
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t H = hex_digits_sum(a.chain[0], run[0]), G1 = run[1] + H, G2 = run[2] + (lpp == 2 ? H : 0ull);
+        const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
+        a.counters[3] = run[0];
+        a.counters[4] = a.p.has_bwa ? G1 : 0;
+        a.counters[5] = a.p.has_bwa ? G2 : 0;
+        a.counters[6] = !a.p.has_bfast ? 0 : G1 + G2 - 2 * nreads;
+    }
+}
+
 // ---- the reference's abort rule (dwgsim.c:635, :833-843): one counter of failed attempts runs over the pairs of a contig in index order,
 // a pair that ends as a genomic read resets it, a pair that ends as a random read does not, and the job dies as soon as the counter
 // passes 10 000.  Pairs are simulated independently here, so the rule is evaluated afterwards from the per-pair record
@@ -949,12 +1075,24 @@ void launch_sim_long_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t l
 void launch_sim_long_1_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_long_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_long_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_split_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
+void launch_sim_split_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
+void launch_split_scan(hipStream_t st, const SimArgs &a, int lpp)
+{
+    hipLaunchKernelGGL(k_split_scan1, dim3(cdiv(a.n_blocks, 1024)), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_split_scan2, dim3(1), dim3(64), 0, st, a, lpp);
+}
 void launch_simulate(hipStream_t st, const SimArgs &a)
 {
     const bool pe = a.p.len[1] > 0, ion = a.p.data_type == 2;
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = a.n_blocks;                                  // a.segs is laid out for nthr / (pe ? 2 : 1) pairs per block
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
+    if (a.split) {      // Illumina, 256-lane blocks: first half | offsets | second half (k_simulate<.., SPLIT>)
+        const size_t lds_a = sim_lds_bytes((size_t)a.lds_words, nthr, 0, false), lds_b = sim_lds_bytes(0, nthr, (size_t)a.qb_words, a.fifo != 0, SIM_FIFO_BYTES_WIDE);      // (the second half stages no bases)
+        if (pe) launch_sim_split_2(st, a, nb, lds_a, lds_b, out); else launch_sim_split_1(st, a, nb, lds_a, lds_b, out);
+        return;
+    }
     const size_t lds = sim_lds_bytes((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables + the text FIFOs
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
@@ -989,8 +1127,31 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
         else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, DT, SIM_THREADS_LONG>), dim3(nb), dim3(nthr), lds, st, a);        \
         else hipLaunchKernelGGL((k_simulate<LPP, 3, DT, SIM_THREADS_LONG>), dim3(nb), dim3(nthr), lds, st, a);                      \
     }
+// the two-kernel form (Illumina, 256-lane blocks): first half, k_split_scan, second half
+void launch_split_scan(hipStream_t st, const SimArgs &a, int lpp);
+#define DW_SIM_SPLIT(LPP)                                                                                                                  \
+    void launch_sim_split_##LPP(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out)                        \
+    {                                                                                                                                      \
+        hipLaunchKernelGGL((k_simulate<LPP, 1, 0, SIM_THREADS, 1, 1>), dim3(nb), dim3(SIM_THREADS), lds_a, st, a);                         \
+        launch_split_scan(st, a, LPP);                                                                                                     \
+        if (a.fifo) {                                                                                                                      \
+            if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, 0, SIM_THREADS, 2, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);       \
+            else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, 0, SIM_THREADS, 2, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);  \
+            else hipLaunchKernelGGL((k_simulate<LPP, 3, 0, SIM_THREADS, 2, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);                \
+        } else {                                                                                                                           \
+            if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, 0, SIM_THREADS, 0, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);       \
+            else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, 0, SIM_THREADS, 0, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);  \
+            else hipLaunchKernelGGL((k_simulate<LPP, 3, 0, SIM_THREADS, 0, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);                \
+        }                                                                                                                                  \
+    }
 #if DW_HAS(1)
 DW_SIM_FAMILY(2, 0)
+#endif
+#if DW_HAS(9)
+DW_SIM_SPLIT(2)
+#endif
+#if DW_HAS(10)
+DW_SIM_SPLIT(1)
 #endif
 #if DW_HAS(7)
 DW_SIM_FAMILY_LONG(2, 0)

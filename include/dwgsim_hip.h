@@ -321,7 +321,8 @@ void dwgsim_hip_job_destroy(dwgsim_hip_job_t *job);
 /* "justify_seq" = 1: left-justification from one thread (cross-check of the cluster-parallel form); "walk_cap" = n: start the mutation walk with
  * room for n candidates (exercises the exact re-run); "walk_seg_min" = n: segmented form of the walk's serial scans from n candidates on;
  * "writer" = 0 / 1: force the register / LDS-FIFO record writer; "sim_threads" = 64: force the one-wave blocks of the long-read variant;
- * "place_cap" = n: room for n undecided pairs per list in dwgsim_hip_count_random* (exercises its second run); "phases" = 1: print the phase
+ * "place_cap" = n: room for n undecided pairs per list in dwgsim_hip_count_random* (exercises its second run); "split" = 0 / 1: the Illumina
+ * read kernel as one kernel with look-backs / as two kernels with the offsets computed in between (default: two for reads of up to 100 bases); "phases" = 1: print the phase
  * split of the -DDW_PHASE_TIMING analysis build. */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
 /* "place_open": pairs the last dwgsim_hip_count_random* call could not settle from the coarse haplotype summaries; "walk_us" / "count_us":

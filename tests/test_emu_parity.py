@@ -120,6 +120,13 @@ def test_count_random_matches_simulate_on_cpu_emulation(emu_lib, golden_dir, fas
     check_count_random_matches_simulate(emu_lib, os.path.join(golden_dir, fasta), flags, ranges=((0, None), (17, 300)))
 
 
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("fasta,flags", [c for c in EMU_CASES if "-c " not in c[1]][:7], ids=lambda v: str(v))
+def test_both_forms_of_the_illumina_read_kernel_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags, split):
+    """k_simulate as one kernel (look-backs) and as two (first half | offsets | second half): see tests/test_gpu_parity.py"""
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=333, debug_options={"split": split})
+
+
 def test_count_random_fast_and_long_path_on_cpu_emulation(emu_lib):
     from parity_common import check_count_random_fast_path
     check_count_random_fast_path(emu_lib, n=1200)
@@ -360,6 +367,44 @@ def test_independent_threads_in_reverse_order_on_cpu_emulation(emu_lib, oracle_b
     env = dict(os.environ, DWGSIM_HIP_LIB=os.path.join(HERE, "emu", "libdwgsim_emu.so"), DWGSIM_FUZZ_ORACLE_TIMEOUT="3", DWGSIM_FUZZ_NO_B="1", DWGSIM_FUZZ_MUT="1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_flags.py"), "207", "150"], capture_output=True, text=True, timeout=1400, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].endswith(" 0 bad"), r.stdout[-3000:]
+
+
+# every kernel whose blocks do not wait for one another: the whole mutation walk, the random-read count, the scans, the abort rule, the calibration
+# (k_simulate and k_gzip in their single-kernel forms look back at the blocks in front of them: their LANES are reversed, HIPEMU_REVERSE_LANES)
+ORDER_FREE_KERNELS = ("k_pack,k_site_scan,k_scan_excl,k_compact,k_events,k_resolve,k_scan4,k_scan4_fix,k_apply,k_jreach,k_sufmin,k_sufmin_fix,k_jbound,k_jrun,k_apply_patches,"
+                      "k_collect_mask,k_gather,k_mut_debug,k_make_view,k_place,k_place_rest,k_range_counts,k_split_scan1,k_split_scan2,k_failrule_a,k_failrule_b,k_calibrate")
+DENSE_CASES = [      # dense indels, long insertions, homopolymers and tandem repeats, N runs, file-driven mutations, regions: what makes the threads of the walk meet
+    ("odd.fa", "-z 8384 -1 7 -2 1 -d 900 -s 1 -C 0.5 -r 0.3 -y 0.3 -n 1000 -S 1 -H -o 1", 0),
+    ("odd.fa", "-z 3 -N 1200 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50", 0),
+    ("tiny.fa", "-z 4 -N 1200 -r 0.02 -R 0.5 -I 30 -X 0.6", 0),
+    ("tiny.fa", "-z 5 -N 600 -m {IN}/muts_edge.txt", 0),
+    ("tiny.fa", "-z 5 -N 600 -v {IN}/muts_edge.vcf -H", 0),
+    ("tiny.fa", "-z 5 -N 600 -b {IN}/muts_edge.bed", 0),
+    ("tiny.fa", "-z 5 -x {IN}/regions_b.bed -C 4 -d 200 -s 10 -1 50 -2 50 -n 5 -r 0.05 -R 0.5", 0),
+    ("tiny.fa", "-z 9 -N 400 -c 2 -f TACG -1 100 -2 60 -e 0.2 -E 0.1 -d 300 -o 1 -r 0.05 -R 0.6", 0),
+    ("tiny.fa", "-z 8 -N 700 -c 1 -1 50 -2 35 -d 300 -r 0.05 -R 0.5 -e 0.05 -E 0.03 -y 0.1", 0),
+    ("many", "-z 21 -N 3000 -1 40 -2 40 -d 150 -s 10 -r 0.2 -R 0.7 -X 0.6 -n 40", 1 << 30),
+    ("many", "-z 22 -N 3000 -1 40 -2 40 -d 150 -s 10 -r 0.3 -R 0.3 -X 0.3 -n 40 -H", 1 << 30),
+    ("many", "-z 23 -N 2000 -1 30 -2 30 -d 120 -s 5 -r 0.1 -R 1.0 -X 0.9 -I 3 -n 40", 9000),
+]
+
+
+@pytest.mark.parametrize("fasta,flags,group_bp", DENSE_CASES, ids=[f"{f}:{fl}" for f, fl, _ in DENSE_CASES])
+def test_every_order_free_kernel_in_reverse_order_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, tmp_path, monkeypatch, fasta, flags, group_bp):
+    """ALWAYS both orders: every dense-indel case runs in index order elsewhere in this file, and here with the blocks AND lanes of every kernel
+    that has no look-back run from the last to the first, and the lanes of the two that have one reversed too.  Threads that are meant to be
+    independent have to be: in index order an overlap between two of them looks like the sequential algorithm and stays hidden (it did for two
+    rounds: dw_walk.hip reach_del)."""
+    monkeypatch.setenv("HIPEMU_REVERSE", ORDER_FREE_KERNELS)
+    monkeypatch.setenv("HIPEMU_REVERSE_LANES", "all")
+    if fasta == "many":
+        fa = str(tmp_path / "many.fa")
+        write_many_contigs(fa, 40, 77)
+    else:
+        fa = os.path.join(golden_dir, fasta)
+    compare_case(emu_lib, oracle_bin, fa, flags, batch_pairs=700, group_bp=group_bp)
+    if "-c" not in flags:      # the Illumina read kernel also in its single-kernel form (look-backs; blocks in order, lanes reversed)
+        compare_case(emu_lib, oracle_bin, fa, flags, batch_pairs=700, group_bp=group_bp, debug_options={"split": 0})
 
 
 def test_lanes_in_reverse_order_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, monkeypatch):

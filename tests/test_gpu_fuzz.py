@@ -8,12 +8,45 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def source_seed():
+    """A seed that changes with the product: the first digits of the sha256 over the kernel and host sources and the C-ABI header (the GPU box
+    gets no .git, so `git rev-parse HEAD` is not available there; this is what a commit that touches the product changes).  Every round's GPU
+    run therefore fuzzes a sample nobody has seen before -- and anyone can reproduce it from the same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "dwgsim_amd", "csrc")
+    for name in sorted(os.listdir(src)) + ["../../include/dwgsim_hip.h"]:
+        p = os.path.join(src, name)
+        if os.path.isfile(p) and name.endswith((".hip", ".hpp", ".cpp", ".h", "Makefile")):
+            h.update(open(p, "rb").read())
+    return 300000 + int(h.hexdigest()[:8], 16) % 600000
+
+
+SRC_SEED = source_seed()
+
+
 @pytest.mark.parametrize("seed,count,mode", [(101, 40, ""), (102, 25, "inputs"), (103, 20, "cli"), (104, 10, "inputs cli"), (105, 25, "shards"), (106, 15, "inputs shards")])
 def test_random_option_sets_bit_exact(oracle_bin, seed, count, mode):
     cmd = [sys.executable, os.path.join(ROOT, "tests", "fuzz_flags.py"), str(seed), str(count)] + mode.split()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("seed,count,mode,mut", [(SRC_SEED, 40, "", 0), (SRC_SEED + 1, 20, "inputs", 0), (SRC_SEED + 2, 12, "cli", 0), (SRC_SEED + 3, 20, "shards", 0), (SRC_SEED + 4, 30, "", 1),
+                                                 (SRC_SEED + 5, 12, "inputs shards", 1)],
+                         ids=lambda v: str(v))
+def test_fresh_random_option_sets_bit_exact(oracle_bin, seed, count, mode, mut):
+    """The same fuzzer with seeds derived from the sources under test (the seed is in the test id and in the failure text): what the fixed seeds
+    above found once they can only find again.  mut = 1: mutation rates of 0.05 .. 0.5 (the walk under stress, where round 3's campaign found the
+    reach bug of the parallel left-justification)."""
+    env = dict(os.environ)
+    if mut:
+        env["DWGSIM_FUZZ_MUT"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "fuzz_flags.py"), str(seed), str(count)] + mode.split()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and last.endswith(" 0 bad"), f"seed {seed} mode '{mode}' mut {mut}: " + r.stdout[-2000:]
 
 
 def test_ion_torrent_random_flow_orders_bit_exact(oracle_bin):

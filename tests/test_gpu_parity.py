@@ -341,6 +341,17 @@ def test_count_random_matches_simulate(lib, golden_dir, repeats_fa, which, flags
     check_count_random_matches_simulate(lib, fasta, flags)
 
 
+ILLUMINA_CASES = [c for c in CASES if "-c 1" not in c[1] and "-c 2" not in c[1]]
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("fasta,flags", ILLUMINA_CASES, ids=[f"{f}:{fl}" for f, fl in ILLUMINA_CASES])
+def test_both_forms_of_the_illumina_read_kernel(lib, oracle_bin, golden_dir, fasta, flags, split):
+    """k_simulate as ONE kernel (look-backs over the blocks in front) and as TWO (first half | offsets | second half, dw_simulate.hip SPLIT): the
+    library picks one by read length; here every Illumina option set runs through both, batches of 777 pairs, byte for byte against the oracle."""
+    compare_case(lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=777, debug_options={"split": split})
+
+
 @pytest.mark.parametrize("flags", ["-z 17 -1 50 -2 50 -d 300 -s 20 -C 10 -y 0.1 -r 0.01 -R 0.5 -n 1", "-z 18 -1 150 -2 150 -C 8 -n 0", "-z 19 -1 100 -2 0 -C 4 -y 0.02 -r 0.003",
                                    "-z 20 -1 100 -2 100 -i -d 100 -s 30 -C 6 -S 1", "-z 21 -1 120 -2 80 -d 5000 -s 700 -C 6 -S 2 -A 2"])
 def test_count_random_fast_and_long_path(lib, flags):

@@ -12,6 +12,6 @@ bits="${@:-2 64}"
 for k in $bits; do /opt/rocm/bin/hipcc $F -DDW_PART=1 -DDW_KNOCK=$k -c dw_simulate.hip -o build/knock/s1_k$k.o & done
 wait
 for k in $bits; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/walk.o build/gzip.o build/host.o build/mutin.o build/job.o build/s0.o build/knock/s1_k$k.o build/s[2-8].o -lpthread -o ../libdwgsim_hip_knock$k.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/walk.o build/gzip.o build/host.o build/mutin.o build/job.o build/s0.o build/knock/s1_k$k.o build/s[2-9].o build/s10.o -lpthread -o ../libdwgsim_hip_knock$k.so
 done
 echo built knock libs: $bits
