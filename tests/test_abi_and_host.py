@@ -19,7 +19,7 @@ def lib():
 
 def test_every_declared_symbol_is_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "dwgsim_hip.h")).read()
-    declared = set(re.findall(r"\b(dwgsim_hip_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(dwgsim_hip_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(api.EXPORTS)
     for s in declared:
         assert hasattr(lib, s), s
