@@ -278,6 +278,7 @@ class JobResult:
     kernel_ms: float = 0.0
     sim_kernel_ms: float = 0.0
     walk_ms: float = 0.0
+    flow_cap_mult: int = 1                           # Ion Torrent: by how much the read capacity had grown at the end of the job (run_job)
 
 
 VCF_HEADER_POST = (
@@ -578,6 +579,7 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
                 rand_ii += b.n_random
                 n_sim += b.n_pairs
             ctx.drop_contig(h0)
+        res.flow_cap_mult = ctx.debug_get("flow_cap_mult")
     res.n_pairs = n_sim
     res.n_random = rand_ii
     res.mutations_txt = bytes(txt)

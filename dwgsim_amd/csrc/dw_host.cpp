@@ -84,6 +84,9 @@ struct Slot {                       // one of the two batches a context can have
     uint64_t n_pairs = 0, out_bytes[3] = {0, 0, 0}, gz_bytes[3] = {0, 0, 0};
     DevBuf gz_out[3], gz_status, segs;        // GPU gzip: the members of each stream, look-back words; the range table of the launch
     SimSeg *h_segs = nullptr; size_t h_segs_cap = 0;      // ... and its page-locked source
+    std::vector<dwgsim_hip_range_t> ranges;      // what the batch in flight covers (it is enqueued again, with larger read buffers, when an Ion Torrent read outgrew them)
+    uint64_t *d_rerun_chain = nullptr;           // [2]: the chain words such a second run starts from
+    int cap_mult = 1;                            // the context's flow_cap_mult this batch was enqueued with
 };
 
 } // namespace
@@ -116,7 +119,7 @@ struct dwgsim_hip_ctx {
     bool seq_justify = false;
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
-    DevBuf flow_scratch;
+    DevBuf flow_scratch, flow_free;
     uint64_t *d_counters = nullptr, *h_counters = nullptr;          // N_COUNTERS x u64 + pinned mirror: calibrate / count_random / debug hooks (compute stream)
     uint64_t *d_wcounters = nullptr;                                // 16 x u64 (mirrored per group: Group::h_wc): the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
     uint64_t *d_pcounters = nullptr, *h_pcounters = nullptr;        // N_COUNTERS x u64 + pinned mirror: count_random (walk stream)
@@ -124,6 +127,9 @@ struct dwgsim_hip_ctx {
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
+    int flow_cap_forced = 0;               // "flow_cap" (tests): the capacity a job starts from, instead of flow_read_capacity()
+    int flow_cap_mult = 1;                 // Ion Torrent: the read capacity is flow_read_capacity() times this; doubled when a read outgrew it (the reference doubles its buffers, dwgsim.c:296-311)
+    int n_cu = 0; int flow_slots = 0;      // compute units of the device; "flow_slots": scratch slots per XCD forced by the tests (0: as many as an XCD can hold blocks)
     int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0; int split = -1;      // dwgsim_hip_debug_option / _debug_get
     hipEvent_t ev_cnt0 = nullptr, ev_cnt1 = nullptr;
     bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
@@ -384,6 +390,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     if (p->data_type == 2) for (const char *q = p->flow_order; *q; ++q) c->flow.push_back(nt4((unsigned char)*q));
     c->prm.read_prefix = nullptr; c->prm.flow_order = nullptr;
     c->device = device;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->n_cu = pr.multiProcessorCount; if (c->n_cu <= 0) c->n_cu = 256; }
     int fail_code = DWGSIM_HIP_ERR_DEVICE;       // (the -B calibration reports reads that outgrow their buffers as DWGSIM_HIP_ERR_FAILED: an option set, not the device)
     auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, fail_code); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
     auto init = [&]() -> int {
@@ -406,6 +413,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         for (Slot &sl : c->slot) {
             HIPC(c, hipMalloc((void **)&sl.d_counters, N_COUNTERS * sizeof(uint64_t)));
             HIPC(c, hipHostMalloc((void **)&sl.h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
+            HIPC(c, hipMalloc((void **)&sl.d_rerun_chain, 2 * sizeof(uint64_t)));
             HIPC(c, hipEventCreate(&sl.ev_k0)); HIPC(c, hipEventCreate(&sl.ev_k1)); HIPC(c, hipEventCreate(&sl.ev_end)); HIPC(c, hipEventCreate(&sl.ev_done)); HIPC(c, hipEventCreate(&sl.ev_fetched));
         }
         { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
@@ -427,14 +435,17 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
                 ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size(); ca.flow_maxk = flow_max_gap(c->flow);
-                ca.cap = flow_read_capacity(len, e, c->flow); ca.lds_words = (ca.cap + 7) / 8;
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-                if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
-                ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
-                HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
-                launch_calibrate(c->stream, ca);
-                HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-                HIPC(c, hipStreamSynchronize(c->stream));
+                for (int mult = 1; mult <= 16; mult *= 2) {       // a read that outgrows its buffers: once more with twice the room (the reference doubles its buffers, dwgsim.c:296-311)
+                    ca.cap = flow_read_capacity(len, e, c->flow) * mult; ca.lds_words = (ca.cap + 7) / 8;
+                    if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
+                    ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
+                    HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
+                    launch_calibrate(c->stream, ca);
+                    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+                    HIPC(c, hipStreamSynchronize(c->stream));
+                    if (!c->h_counters[2]) break;
+                }
                 if (c->h_counters[2]) { c->err = "-B calibration: a read outgrew its flow-space buffer (the flow model's growth at this error rate and flow order: INTEGRATION.md)"; fail_code = DWGSIM_HIP_ERR_FAILED; return -1; }
                 const int32_t n_err = (int32_t)c->h_counters[8], counts = (int32_t)c->h_counters[9];       // int32 accumulators as in the reference
                 sf = e / (n_err / (1.0 * counts));
@@ -535,7 +546,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (auto &g : c->groups) if (g.alive) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->split_state, &c->split_hand, &c->split_agg, &c->split_pre, &c->split_chunk, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
-                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch}) hipFree(b->p);
+                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch, &c->flow_free}) hipFree(b->p);
     for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -548,7 +559,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->ev_cnt0) hipEventDestroy(c->ev_cnt0);
     if (c->ev_cnt1) hipEventDestroy(c->ev_cnt1);
     for (Slot &sl : c->slot) {
-        hipFree(sl.d_counters); hipFree(sl.gz_status.p); hipFree(sl.segs.p);
+        hipFree(sl.d_counters); hipFree(sl.d_rerun_chain); hipFree(sl.gz_status.p); hipFree(sl.segs.p);
         for (int t = 0; t < 3; ++t) hipFree(sl.gz_out[t].p);
         if (sl.h_counters) hipHostFree(sl.h_counters);
         if (sl.h_segs) hipHostFree(sl.h_segs);
@@ -1179,9 +1190,11 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     }
     auto lds_need = [&](int lanes) { return sim_lds_bytes((size_t)((lmax0 + 7) / 8), (size_t)lanes, (size_t)c->qb_words, a.fifo != 0); };     // staged bases + the two base-quality tables + the text FIFOs
     if (p.data_type != 2 && (lds_need(SIM_THREADS) > SIM_LDS_BUDGET || c->force_threads == SIM_THREADS_LONG)) {
+        // reads too long to stage in LDS: one-wave blocks whose reads are staged in scratch slots (global memory, dw_simulate.hip GS); what is left in LDS
+        // is the two base-quality tables (2 bytes per base) and the FIFOs, which bounds a read at ~70 000 bases (the reference has no bound, dwgsim.c:75-153)
         a.sim_threads = SIM_THREADS_LONG; a.fifo = 1;
-        if (lds_need(SIM_THREADS_LONG) > SIM_LDS_BUDGET) {
-            char b[160]; snprintf(b, sizeof b, "dwgsim-hip: reads longer than %d bases are not supported for -c 0 / -c 1\n", (int)((SIM_LDS_BUDGET - SIM_THREADS_LONG * SIM_FIFO_BYTES) / (SIM_THREADS_LONG * 4 + 2) * 8));
+        if (sim_lds_bytes(0, SIM_THREADS_LONG, (size_t)c->qb_words, true) > SIM_LDS_BUDGET) {
+            char b[160]; snprintf(b, sizeof b, "dwgsim-hip: reads longer than %d bases are not supported for -c 0 / -c 1\n", (int)((SIM_LDS_BUDGET - SIM_THREADS_LONG * SIM_FIFO_BYTES) / 2 - 16));
             c->err = b; return DWGSIM_HIP_ERR_UNSUP;
         }
     }
@@ -1189,11 +1202,11 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
         const double emax = p.e_start[0] > p.e_start[1] ? p.e_start[0] : p.e_start[1];
-        a.cap = flow_read_capacity(lmax, emax, c->flow);
+        a.cap = (c->flow_cap_forced > 0 ? c->flow_cap_forced : flow_read_capacity(lmax, emax, c->flow)) * c->flow_cap_mult;
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size(); a.flow_maxk = flow_max_gap(c->flow);
-    a.flow_scratch = nullptr;
+    a.flow_scratch = nullptr; a.flow_free = nullptr; a.flow_slots = 0;
     // Short Illumina reads run as two kernels with the offsets computed in between (dw_simulate.hip SPLIT): no look-backs, and the second half --
     // no staged bases in LDS -- writes the text in 64-byte bursts.  What does not scale with the read length (placement, the look-backs, the name)
     // is most of the work there: 2 x 36 / 2 x 50 / 2 x 75 bp and 100 bp single-end run 16 / 17 / 9 / 15 % faster than in the single kernel, 2 x 100
@@ -1288,7 +1301,15 @@ int dwgsim_hip_set_fail_carry(dwgsim_hip_ctx_t *c, uint64_t carry)
 // Enqueue one batch on the compute stream: [chain set] -> memsets -> k_simulate -> abort-rule epilogue -> [k_gzip] -> counters to the slot's
 // pinned mirror -> event.  Every buffer the batch needs is in place before anything is enqueued or the chain state moves, so a failing call
 // leaves the context as it found it.
+// rerun: the batch of this slot once more with larger Ion Torrent read buffers (dwgsim_hip_wait).  Nothing of the chain moves: the random reads and
+// the failed attempts of a batch do not depend on the flow model, so the first run's epilogue stands; the kernels start from the chain words the
+// first run started from (rand_base = its counters[22]).
+static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t rand_base, int slot, bool rerun);
 int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t rand_base, int slot)
+{
+    return sim_enqueue(c, r, n, rand_base, slot, false);
+}
+static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t rand_base, int slot, bool rerun)
 {
     if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
@@ -1328,10 +1349,18 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
         if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
         const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
         if (ensure(c, c->fail_summ, (nfb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
-        if (p.data_type == 2) {
-            const size_t words = (size_t)flow_words_per_lane(a.lds_words, a.cap) * (size_t)SIM_THREADS * (size_t)nblk;
-            if (ensure(c, c->flow_scratch, words * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
-            a.flow_scratch = (uint32_t *)c->flow_scratch.p;
+        if (p.data_type == 2 || a.sim_threads != SIM_THREADS) {
+            // read buffers (Ion Torrent) / staged reads (one-wave blocks): one slot per block an XCD can hold at a time -- what the LDS admits per CU, at most the eight waves of a SIMD (registers can only
+            // lower it; too few slots would make blocks wait, never fail) --, handed from block to block inside the XCD (dw_simulate.hip scratch_slot_take)
+            const int cu_per_xcd = (c->n_cu >= 64 && c->n_cu % 8 == 0) ? c->n_cu / 8 : c->n_cu;
+            const bool ion = p.data_type == 2;
+            const int per_cu = ion ? sim_blocks_per_cu(sim_lds_bytes((size_t)(FLOW_STACK_RUNS / 2), SIM_THREADS, (size_t)a.qb_words, a.fifo != 0), 8)
+                                   : sim_blocks_per_cu(sim_lds_bytes(0, SIM_THREADS_LONG, (size_t)a.qb_words, true), 32);       // (one-wave blocks: up to eight per SIMD)
+            a.flow_slots = c->flow_slots > 0 ? c->flow_slots : cu_per_xcd * per_cu;
+            if ((uint64_t)a.flow_slots > (uint64_t)nblk) a.flow_slots = (int32_t)nblk;
+            const size_t words = (ion ? (size_t)flow_words_per_lane(a.lds_words, a.cap) * (size_t)SIM_THREADS : (size_t)a.lds_words * (size_t)SIM_THREADS_LONG) * (size_t)a.flow_slots * 8;
+            if (ensure(c, c->flow_scratch, words * sizeof(uint32_t)) || ensure(c, c->flow_free, sizeof(uint64_t) * (256 + 8 * (size_t)nblk))) return DWGSIM_HIP_ERR_DEVICE;
+            a.flow_scratch = (uint32_t *)c->flow_scratch.p; a.flow_free = (uint64_t *)c->flow_free.p;
         }
         if (ensure(c, sl.segs, sizeof(SimSeg) * segs.size())) return DWGSIM_HIP_ERR_DEVICE;
         if (segs.size() > sl.h_segs_cap) {
@@ -1354,6 +1383,7 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
     const dwgsim_hip_range_t *r_first = nullptr, *r_last = nullptr;
     for (int q = 0; q < n; ++q) if (r[q].n_pairs) { if (!r_first) r_first = &r[q]; r_last = &r[q]; }
     if (!r_first) { r_first = &r[0]; r_last = &r[n - 1]; }
+    if (!rerun) {
     const bool continues = c->chain_contig == r_first->contig && c->chain_next_ii == r_first->first_ii && r_first->first_ii != 0;
     const bool set_carry = c->has_carry_override || !continues;
     const uint64_t carry = c->has_carry_override ? c->carry_override : 0;
@@ -1361,6 +1391,11 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
     const bool set_rand = rand_base != DWGSIM_HIP_RAND_CHAIN;
     if (set_rand || set_carry) launch_chain_set(c->stream, c->d_chain, rand_base, set_rand ? 1 : 0, carry, set_carry ? 1 : 0);
     c->chain_contig = r_last->contig; c->chain_next_ii = r_last->first_ii + r_last->n_pairs;
+    if (sl.ranges.data() != r) sl.ranges.assign(r, r + n);
+    } else {
+        launch_chain_set(c->stream, sl.d_rerun_chain, rand_base, 1, 0, 1);
+        a.chain = sl.d_rerun_chain;
+    }
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     uint32_t opens = 0;
     for (const SimSeg &s : segs) opens |= s.contig_start;
@@ -1372,10 +1407,12 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
     sl.group = c->handles[(size_t)g.first_handle].group;
     HIPC(c, hipMemsetAsync(sl.d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
     if (!a.split) HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
+    if (a.flow_free) HIPC(c, hipMemsetAsync(a.flow_free, 0, sizeof(uint64_t) * (256 + 8 * (size_t)nblk), c->stream));
     HIPC(c, hipEventRecord(sl.ev_k0, c->stream));
     launch_simulate(c->stream, a);
     HIPC(c, hipEventRecord(sl.ev_k1, c->stream));
-    launch_failrule(c->stream, a.meta, n_pairs, opens, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
+    sl.cap_mult = c->flow_cap_mult;
+    if (!rerun) launch_failrule(c->stream, a.meta, n_pairs, opens, (uint64_t *)c->fail_summ.p, sl.d_counters, c->d_chain);
     if (c->gzip_on) {      // the .gz form of every stream, enqueued behind the text (lengths are read on the device: counters[4 + t])
         size_t nch[3], off = 0;
         for (int t = 0; t < 3; ++t) { nch[t] = (size_t)gz_chunks(cap[t]); off += nch[t]; }
@@ -1412,7 +1449,21 @@ int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipEventSynchronize(sl.ev_done));
     sl.pending = false;
-    const uint64_t *h = sl.h_counters;
+    uint64_t *h = sl.h_counters;
+    if ((h[2] & 2) && !(h[2] & ~(2ull | 8ull)) && c->prm.data_type == 2) {
+        // a read outgrew its flow-space buffers: the reference doubles them and goes on (dwgsim.c:296-311); here the batch runs again with twice the
+        // capacity (kept for the rest of the job).  Its random reads and failed attempts are settled before the flow model runs, so the chain words
+        // the epilogue of the first run has already moved on stand; the second run starts from the ones the first started from (counters[22]).
+        uint64_t keep[8]; for (int q = 0; q < 6; ++q) keep[q] = h[16 + q];
+        const uint64_t base = h[22];
+        while (h[2] & 2) {
+            if (sl.cap_mult >= c->flow_cap_mult) { if (c->flow_cap_mult >= 16) break; c->flow_cap_mult *= 2; }      // (another batch may have doubled it already)
+            if (const int rc = sim_enqueue(c, sl.ranges.data(), (int)sl.ranges.size(), base, slot, true)) return rc;
+            HIPC(c, hipEventSynchronize(sl.ev_done));
+            sl.pending = false;
+        }
+        for (int q = 0; q < 6; ++q) h[16 + q] = keep[q];
+    }
     if (h[2] & 4) { c->err = "dwgsim-hip: no fragment placement satisfied the target regions (-x) after 2^20 tries (the reference would not terminate)\n"; return DWGSIM_HIP_ERR_FAILED; }
     if (h[2] & 2) { c->err = "dwgsim-hip: a read outgrew its buffer (or degenerated) in the flow-error model\n"; return DWGSIM_HIP_ERR_FAILED; }
     if ((h[2] & ~8ull) || h[20]) {      // one pair used up its 10 001 attempts, or the counter of failed attempts over the pairs of the contig passed the limit (dwgsim.c:635, :833-843)
@@ -1608,6 +1659,8 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "walk_seg_min")) walk_debug_seg_min((uint32_t)value);      // (process-wide)
     else if (!strcmp(key, "place_cap")) c->place_cap = value;
     else if (!strcmp(key, "split")) c->split = (int)value;
+    else if (!strcmp(key, "flow_slots")) c->flow_slots = (int)value;
+    else if (!strcmp(key, "flow_cap")) c->flow_cap_forced = (int)value;
     else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }
@@ -1618,6 +1671,7 @@ int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *c, const char *key, int64_t *value)
 {
     if (!c || !key || !value) return DWGSIM_HIP_ERR_ARG;
     if (!strcmp(key, "place_open")) *value = (int64_t)c->place_open;
+    else if (!strcmp(key, "flow_cap_mult")) *value = (int64_t)c->flow_cap_mult;
     else if (!strcmp(key, "walk_us")) *value = (int64_t)c->walk_us;           // HIP-event time of the walk chains waited for so far (start of the chain to its end, on the walk stream)
     else if (!strcmp(key, "count_us")) *value = (int64_t)c->count_us;         // ... of the random-read counts (k_place .. k_range_counts)
     else { c->err = "unknown debug value"; return DWGSIM_HIP_ERR_ARG; }

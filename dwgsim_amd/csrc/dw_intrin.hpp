@@ -28,6 +28,12 @@ DW_DEV uint32_t lut8(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_
 // two wave-uniform values pinned to scalar registers at this point (an optimisation barrier: the compiler may not hoist what depends on them)
 DW_DEV void keep_scalar(uint32_t &a, uint32_t &b) { asm volatile("" : "+s"(a), "+s"(b)); }
 
+// the XCD (0..7) this wave runs on: s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4).  The eight XCDs have an L2 each and the L2s are not coherent with each
+// other, so memory that is handed from workgroup to workgroup INSIDE a launch (the Ion Torrent scratch slots) stays within one XCD
+DW_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }
+// every store this wave has issued has been acknowledged by the L2 (a workgroup ends without waiting for its stores)
+DW_DEV void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // IEEE-754 binary64 x / y and sqrt(x) for operands far from the ends of the exponent range and without special values:
 // exactly the Newton-Raphson + correction sequences the compiler emits for `/` and sqrt() on gfx950 (LLVM AMDGPU LowerFDIV64 /
 // lowerFSQRTF64) minus their v_div_scale / v_div_fixup / ldexp / class-test range handling, which is the identity on such

@@ -161,7 +161,9 @@ struct SimArgs {
     uint32_t *split_agg;           // per block 16 bytes: random pairs, bytes of stream 1 / 2 (without random reads' hexadecimal digits)
     uint64_t *split_pre;           // per block 4 words: random reads / bytes of stream 1 / bytes of stream 2 in front of it inside its chunk of 1024 blocks (k_split_scan1)
     uint64_t *split_chunk;         // per chunk 4 words: the chunk's sums (k_split_scan1), then the sums in front of the chunk (k_split_scan2)
-    uint32_t *flow_scratch;        // Ion Torrent: per-block read buffers in HBM, (lds_words + ceil(cap/16)) words per lane, word w of lane t at [w * nthr + t]
+    uint32_t *flow_scratch;        // Ion Torrent: read buffers of one block per SLOT, flow_words_per_lane words per lane, word w of lane t at [w * nthr + t]
+    uint64_t *flow_free;           // ... the slots' free lists, one per XCD (dw_simulate.hip scratch_slot_take): 256 header words + 8 x n_blocks queue words, zeroed per launch
+    int32_t flow_slots;            // ... slots per XCD (8 x flow_slots slots in flow_scratch)
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes
 };
 

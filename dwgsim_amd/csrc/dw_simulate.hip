@@ -375,6 +375,35 @@ DW_DEV uint64_t hex_digits_sum(uint64_t b, uint64_t c)
     }
     return sum;
 }
+// ---- scratch slots (Ion Torrent read buffers; the staging of reads too long for LDS) ----
+// A block's read buffers are a global scratch (dw_read.hpp flow_errors).  Indexed by the block's ticket they were fresh memory for every block:
+// written once, read once, every byte of them through the L2 to HBM and back (4.2 x the algorithmic traffic, profiles/r03_ion_*).  Now a
+// block TAKES one of `per_xcd` slots of its XCD and RELEASES it when it ends, so the scratch in use is what the resident blocks need (a few
+// hundred KB per CU) and stays in the L2 / the memory-side cache.  Slots never cross XCDs: the eight L2s are not coherent with each other, and
+// a slot's next owner must find (and overwrite) the previous owner's lines in the SAME L2 -- dirty lines of one address in two L2s would be
+// written back in either order.  free list of XCD x (8-byte words, relaxed agent-scope atomics like the look-back's): header words
+// ff[32 x] = slots taken so far, ff[32 x + 16] = slots released so far; queue ff[256 + x * n_blocks + r] = (slot + 1) of the r-th release.
+// The q-th taker owns slot q outright while q < per_xcd, and otherwise waits for the (q - per_xcd)-th release -- which has happened already
+// when per_xcd >= the blocks an XCD can hold (dw_host.cpp sizes it so).  The slot is taken BEFORE the ticket: every block that owns a ticket
+// owns a slot, so the block with the smallest ticket still running never waits for anything and the look-backs stay deadlock-free whatever
+// per_xcd is ("flow_slots" = 1 in the tests).  Every word of a slot is written by its owner before the owner reads it (nothing of the previous
+// owner's is ever looked at), and the owner's stores are in the L2 before it lets go (wait_stores + the block's last barrier).
+DW_DEV uint32_t scratch_slot_take(uint64_t *ff, uint32_t per_xcd, uint32_t n_blocks)
+{
+    const uint32_t x = xcc_id();
+    const uint64_t q = (uint64_t)atomicAdd((unsigned long long *)&ff[32 * x], 1ull);
+    if (q < per_xcd) return x * per_xcd + (uint32_t)q;
+    uint64_t *e = ff + 256 + (size_t)x * n_blocks + (size_t)(q - per_xcd);
+    uint64_t v;
+    do { v = status_load(e); if (v == 0) __builtin_amdgcn_s_sleep(2); } while (v == 0);
+    return (uint32_t)(v - 1);
+}
+DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
+{
+    const uint32_t x = xcc_id();
+    const uint64_t r = (uint64_t)atomicAdd((unsigned long long *)&ff[32 * x + 16], 1ull);
+    status_store(ff + 256 + (size_t)x * n_blocks + (size_t)r, (uint64_t)slot + 1ull);
+}
 // DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
 // NTHR: lanes per block.  SIM_THREADS_LONG (one wave) is the variant for reads too long to stage at SIM_THREADS lanes.
 // WR = 1: records leave through the per-lane LDS FIFO; 0: straight from registers (dw_read.hpp FifoWriter / Writer)
@@ -390,20 +419,26 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     static_assert(SPLIT == 0 || (DT == 0 && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants with 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
-    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_ticket, s_slot;
     __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][32];          // "@[prefix_]contig" and "@[prefix_]rand", first 128 bytes
     __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
     __shared__ uint8_t s_dist[256];              // ... and the flow-distance table (fill_flow_dist)
     constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
+    // where a lane's packed bases are staged: LDS (Illumina / SOLiD reads up to ~1 180 bases, 256-lane blocks), or a SCRATCH SLOT in global memory --
+    // the Ion Torrent read buffers, and every read too long for that (the one-wave blocks): staged in LDS a 2 000-base read left room for two waves
+    // per CU (half the SIMDs idle, 17 % VALU-active: profiles/r04_variants_pmc.txt) and a 5 000-base read for none.  The slot is read and written
+    // word by word in step by the lanes of a wave (word w of lane t at [w * nthr + t]) and lives in the L2 / memory-side cache
+    constexpr bool GS = DT == 2 || NTHR != SIM_THREADS;
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     DW_PROBE_INIT();
+    if (GS && tid == 0) { s_slot = scratch_slot_take(a.flow_free, (uint32_t)a.flow_slots, a.n_blocks); asm volatile("" ::: "memory"); }      // (before the ticket: see scratch_slot_take)
     if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
-    const size_t stage_words = SPLIT == 2 ? 0 : (size_t)(DT == 2 ? FLOW_STACK_RUNS / 2 : a.lds_words);      // (the second half of the two-kernel form reads its bases from HBM)
+    const size_t stage_words = SPLIT == 2 ? 0 : DT == 2 ? (size_t)(FLOW_STACK_RUNS / 2) : GS ? 0 : (size_t)a.lds_words;      // (the second half of the two-kernel form reads its bases from HBM)
     uint32_t *const s_qb = dyn_lds + stage_words * nthr;
     if (SPLIT != 1) for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     // this lane's text FIFO (record writer), behind the tables
@@ -429,7 +464,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
     // read buffers live in a global scratch so that LDS does not cap residency; only the run stack of pass 2 stays in LDS
     // (second half of the two-kernel form: the tile's staged bases where the first half left them, read once, in batches of eight words)
-    uint32_t *lds = (DT == 2) ? a.flow_scratch + (size_t)t * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid
+    uint32_t *lds = GS ? a.flow_scratch + (size_t)uniform_u32(s_slot) * ((size_t)(DT == 2 ? flow_words_per_lane(a.lds_words, a.cap) : a.lds_words) * nthr) + tid
                   : SPLIT == 2 ? a.split_state + (size_t)t * ((size_t)a.lds_words * nthr) + tid : dyn_lds + tid;
 
     DW_PROBE_MARK(a, 0);     // ticket, fixed strings
@@ -762,6 +797,11 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         if (rec) { o.put('\n'); o.flush(); }
     }
     DW_PROBE_MARK(a, 6);     // quality line
+    if (GS) {                // the scratch slot goes back to this XCD's free list once every wave's accesses to it are done
+        wait_stores();
+        __syncthreads();
+        if (tid == 0) scratch_slot_release(a.flow_free, a.n_blocks, s_slot);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1014,6 +1054,7 @@ __global__ void __launch_bounds__(64) k_failrule_b(const uint64_t *__restrict__ 
         counters[20] = (all.bad || all.P > (uint64_t)MAX_ATTEMPTS || all.S > (uint64_t)MAX_ATTEMPTS) ? 1 : 0;
         counters[21] = all.S;
         chain[1] = all.S;
+        counters[22] = chain[0];      // what this batch's k_simulate started from (a batch is run again when an Ion Torrent read outgrew its buffers: dw_host.cpp)
         chain[0] += counters[3];
     }
 }
@@ -1093,7 +1134,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
         if (pe) launch_sim_split_2(st, a, nb, lds_a, lds_b, out); else launch_sim_split_1(st, a, nb, lds_a, lds_b, out);
         return;
     }
-    const size_t lds = sim_lds_bytes((size_t)(ion ? FLOW_STACK_RUNS / 2 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers are in a.flow_scratch) + the base-quality tables + the text FIFOs
+    const size_t lds = sim_lds_bytes((size_t)(ion ? FLOW_STACK_RUNS / 2 : nthr != (uint32_t)SIM_THREADS ? 0 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers, like the long reads of the one-wave blocks, are in a.flow_scratch) + the base-quality tables + the text FIFOs
     const bool solid = a.p.data_type == 1;
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }

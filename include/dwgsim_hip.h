@@ -322,10 +322,13 @@ void dwgsim_hip_job_destroy(dwgsim_hip_job_t *job);
  * room for n candidates (exercises the exact re-run); "walk_seg_min" = n: segmented form of the walk's serial scans from n candidates on;
  * "writer" = 0 / 1: force the register / LDS-FIFO record writer; "sim_threads" = 64: force the one-wave blocks of the long-read variant;
  * "place_cap" = n: room for n undecided pairs per list in dwgsim_hip_count_random* (exercises its second run); "split" = 0 / 1: the Illumina
- * read kernel as one kernel with look-backs / as two kernels with the offsets computed in between (default: two for reads of up to 100 bases); "phases" = 1: print the phase
+ * read kernel as one kernel with look-backs / as two kernels with the offsets computed in between (default: two for reads of up to 100 bases); "flow_slots" = n:
+ * n scratch slots per XCD for the Ion Torrent read buffers / the long reads of the one-wave blocks (blocks wait for slots); "flow_cap" = n: the Ion Torrent
+ * read capacity a job starts from (a read that outgrows it makes the batch run again with twice the room); "phases" = 1: print the phase
  * split of the -DDW_PHASE_TIMING analysis build. */
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *ctx, const char *key, int64_t value);
-/* "place_open": pairs the last dwgsim_hip_count_random* call could not settle from the coarse haplotype summaries; "walk_us" / "count_us":
+/* "place_open": pairs the last dwgsim_hip_count_random* call could not settle from the coarse haplotype summaries; "flow_cap_mult": how often (as a
+ * power of two) the Ion Torrent read capacity has been doubled so far; "walk_us" / "count_us":
  * HIP-event time (microseconds, accumulated) of the context's walk chains / random-read counts on the walk stream */
 int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *ctx, const char *key, int64_t *value);
 /* the gzip kernel on arbitrary host bytes (the product only ever feeds it FASTQ text) */

@@ -61,6 +61,15 @@ def compare_job_api(lib, oracle_bin, fasta, flags, **kw):
 
 FLOW = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
 
+# reads beyond every LDS staging limit (round 3 returned DWGSIM_HIP_ERR_UNSUP from ~4 600 bases on): the one-wave blocks stage them in scratch slots
+# of global memory (dw_simulate.hip GS); the reference works on realloc'ed buffers and has no limit (dwgsim.c:75-153).  Run on the repeat-rich contigs.
+LONG_READ_CASES = [
+    "-z 5 -N 300 -1 10000 -2 0 -n 200 -r 0.01 -R 0.3 -X 0.5",
+    "-z 5 -N 200 -c 1 -1 6000 -2 0 -n 150 -r 0.005",
+    "-z 6 -N 150 -1 7000 -2 5000 -d 20000 -s 300 -n 300 -y 0.05 -o 0",
+    "-z 7 -N 120 -1 25000 -2 0 -n 1000 -e 0.001-0.01 -Q 4",
+]
+
 # (fasta under tests/golden, flags): the option surface of the accelerated path (Illumina, SOLiD and Ion Torrent)
 CASES = [
     ("ex1.fa", "-z 13 -N 10000"),                                  # the reference's bundled test configuration

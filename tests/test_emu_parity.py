@@ -127,6 +127,28 @@ def test_both_forms_of_the_illumina_read_kernel_on_cpu_emulation(emu_lib, oracle
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=333, debug_options={"split": split})
 
 
+@pytest.mark.parametrize("slots", [1, 2])
+def test_ion_torrent_scratch_slots_change_hands_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, slots):
+    """The Ion Torrent read buffers are scratch SLOTS taken and released by the blocks of an XCD (dw_simulate.hip scratch_slot_take): with one or
+    two slots per XCD and 12 blocks (the emulation puts block b on XCD b % 8) a slot's second owner writes over its first owner's buffers."""
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 3000 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 100 -2 0 -e 0.02 -y 0.05",
+                 debug_options={"flow_slots": slots})
+
+
+@pytest.mark.parametrize("flags,slots", [("-z 5 -N 130 -1 5200 -2 0 -n 100 -r 0.01 -R 0.3", 0), ("-z 5 -N 100 -c 1 -1 2500 -2 2000 -d 5800 -s 20 -n 60 -o 0", 1)])
+def test_reads_beyond_the_lds_staging_limit_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, flags, slots):
+    """The one-wave blocks stage their reads in scratch slots of global memory (no DWGSIM_HIP_ERR_UNSUP for long reads): see tests/test_gpu_parity.py"""
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), flags, debug_options={"flow_slots": slots} if slots else None)
+
+
+def test_ion_torrent_read_outgrows_its_buffers_on_cpu_emulation(emu_lib, oracle_bin, golden_dir):
+    """A read that outgrows its flow-space buffers makes the batch run again with twice the room (the reference doubles its buffers, dwgsim.c:296-311):
+    forced here with a starting capacity of 104 bases for 100-base reads at e = 0.05; small batches, so that several batches meet the limit."""
+    res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 900 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 100 -2 0 -e 0.05 -y 0.1",
+                       batch_pairs=300, debug_options={"flow_cap": 104})
+    assert res.flow_cap_mult >= 2
+
+
 def test_count_random_fast_and_long_path_on_cpu_emulation(emu_lib):
     from parity_common import check_count_random_fast_path
     check_count_random_fast_path(emu_lib, n=1200)

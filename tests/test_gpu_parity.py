@@ -5,7 +5,7 @@ import pytest
 
 from dwgsim_amd import api
 FLOW_ORDER = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
-from parity_common import CASES, compare_case
+from parity_common import CASES, FLOW, compare_case
 
 pytestmark = pytest.mark.gpu
 
@@ -359,6 +359,33 @@ def test_count_random_fast_and_long_path(lib, flags):
     count: 3 Mb contigs with N runs at the ends and inside, paired / single-end / inner-distance / mate-pair geometries, forced list overflow."""
     from parity_common import check_count_random_fast_path
     check_count_random_fast_path(lib, length=3000000, n=150000, flags=flags, ranges=((0, None), (33333, 55555)))
+
+
+@pytest.mark.parametrize("slots", [1, 3, 0])
+def test_ion_torrent_scratch_slots_change_hands(lib, oracle_bin, repeats_fa, slots):
+    """The Ion Torrent read buffers are scratch slots handed from block to block inside an XCD (dw_simulate.hip scratch_slot_take).  One or three
+    slots per XCD make almost every one of the ~ 350 blocks WAIT for a slot that another block of its XCD releases (the path that a normal launch,
+    with a slot per resident block, takes only when a release is still on its way); 0 = the library's own count."""
+    compare_case(lib, oracle_bin, repeats_fa, "-z 41 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 200 -2 0 -C 10 -e 0.02 -y 0.03 -r 0.01",
+                 debug_options={"flow_slots": slots} if slots else None)
+
+
+@pytest.mark.parametrize("flags", __import__("parity_common").LONG_READ_CASES)
+def test_reads_beyond_the_lds_staging_limit(lib, oracle_bin, repeats_fa, flags):
+    """-1 10000, -c 1 -1 6000, 7 000 + 5 000 paired, 25 000: see parity_common.LONG_READ_CASES; also with two scratch slots per XCD (blocks wait for slots)."""
+    compare_case(lib, oracle_bin, repeats_fa, flags)
+    compare_case(lib, oracle_bin, repeats_fa, flags, batch_pairs=77, debug_options={"flow_slots": 2})
+
+
+@pytest.mark.parametrize("cap,flags", [(104, "-1 100 -2 0 -e 0.05 -y 0.1"), (60, "-1 50 -2 50 -d 300 -e 0.1 -E 0.02 -o 0"), (0, "-1 60 -2 0 -e 0.3 -f TCG" + "A" * 30)])
+def test_ion_torrent_read_outgrows_its_buffers(lib, oracle_bin, golden_dir, cap, flags):
+    """A read that outgrows its flow-space buffers makes the batch run again with twice the room (dw_host.cpp dwgsim_hip_wait; the reference doubles its
+    buffers, dwgsim.c:296-311): forced with a small starting capacity, batch by batch and through the job level with two batches in flight per
+    context; cap = 0: an option set whose reads grow far beyond the capacity estimate on their own (e = 0.3, a flow order that keeps T away for 30 flows)."""
+    fl = f"-z 9 -N 2500 -c 2 {'' if ' -f ' in flags else '-f ' + FLOW} {flags}"
+    res = compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), fl, batch_pairs=700, debug_options={"flow_cap": cap} if cap else None)
+    if cap:
+        assert res.flow_cap_mult >= 2
 
 
 def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa):
