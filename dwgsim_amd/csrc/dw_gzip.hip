@@ -4,27 +4,41 @@
 // One workgroup = one 32 KiB chunk of a stream = one complete gzip member (RFC 1952), so the members of a batch are independent and their
 // concatenation is a valid .gz whose decompressed bytes are exactly the text (what the reference's own test compares, testdata/test.sh:23-25):
 //     header with an FNAME field of 0-3 pad characters (so that EVERY member is a multiple of 4 bytes and starts on a word of the output)
-//     | one DEFLATE block with dynamic Huffman codes, literals only (RFC 1951 3.2.7) | an empty stored block (final, byte-aligns)
-//     | CRC-32 and length of the chunk.
-// FASTQ of simulated reads has nothing an LZ77 window could match beyond what entropy coding of its ~45 symbols gives, so the codes are Huffman
-// codes of the chunk's own byte histogram, length-limited to 15 bits.
+//     | one DEFLATE block with dynamic Huffman codes (RFC 1951 3.2.7) | an empty stored block (final, byte-aligns) | CRC-32 and length.
 //
-// A lane owns 128 consecutive bytes and keeps them in registers (8 x dwordx4) for all three passes:
-//   pass 1  histogram (LDS atomics into 8 sub-histograms: the four bases would otherwise collide 64-fold) + CRC-32 of the span (slicing-by-4)
-//   codes   Huffman by repeated merging of the two lightest trees -- the two minima by one block-wide reduction per merge, every lane owning
-//           one symbol -- counts halved until no code is longer than 15 bits; canonical codes; the block header (code lengths) by a scan
+// What is coded.  A FASTQ record is three populations of symbols -- name, bases, qualities -- under ONE Huffman table per block, and a block
+// header costs more than a read's worth of savings, so the table cannot follow them.  Bases and qualities of simulated reads are random: an
+// LZ77 window finds nothing there that a literal does not code as well.  The NAME line is the exception: its symbols are the rare ones of the
+// table (6-7 bits each where digits are not also quality characters) and most of it repeats the name line of the record before -- "@contig_",
+// the strand / random-read flags, ":0:0_" groups, the leading digits of the running index -- or itself (the second position repeats the leading
+// digits of the first).  So name lines, and only they, are searched for matches, at a handful of distances the structure suggests rather than
+// through a hash table: the same column and the same distance from the line's end in the line FOUR LINES UP, and the distances 6 .. 11 inside
+// the line.  Round 3 coded literals only: 0.493 of the text on the bench workload (0.479 on the oracle's sample); with the name-line matches
+// and run-length coded code lengths in the block header: see DESIGN.md section 6b.
+//
+// A lane owns 128 consecutive bytes and keeps them in registers (8 x dwordx4) for all passes:
+//   lines   '\n' masks of the spans -> scan -> the chunk's line starts in LDS
+//   parse   name lines inside the span: greedy matches (>= 3 bytes, never across the span's or the line's end), up to GZ_MAXM per span, kept in LDS
+//   pass 1  histograms of literals / lengths / distances (LDS atomics into 8 sub-histograms) + CRC-32 of the span (slicing-by-4)
+//   codes   two Huffman codes by repeated merging of the two lightest trees -- the two minima by one block-wide reduction per merge, a lane
+//           owning symbols tid and 256 + tid -- counts halved until no code is longer than 15 bits; canonical codes; the code lengths of the
+//           block header run-length coded (symbols 16 / 17 / 18) by one lane
 //   pass 2  bits per span -> block scan -> decoupled look-back over the chunks for the member's byte offset
 //   pass 3  every lane packs its span's codes LSB-first into an IMAGE OF THE MEMBER IN LDS (OR for the words two spans share); CRC-32 of
-//           the spans joined by a tree of x^(8 L) shifts; then the image leaves with plain, coalesced word stores: no global atomics, no
-//           zeroed output buffer.
+//           the spans joined by a tree of x^(8 L) shifts; then the image leaves with plain, coalesced word stores.
+// A chunk whose member would not fit the image (24 KB: text that does not compress to 3/4) leaves as a STORED block instead.
 #include "dw_device.hpp"
 #include "dw_launch.hpp"
 
 namespace dw {
 
 constexpr int GZ_CHUNK = 32768, GZ_THREADS = 256, GZ_SPAN = GZ_CHUNK / GZ_THREADS;      // 128 bytes per lane
-constexpr int GZ_IMG_WORDS = (GZ_CHUNK + 4096) / 4;        // the member image: a prefix code never needs more than ~8 bits per byte + ~200 bytes of tables
+constexpr int GZ_IMG_WORDS = 24576 / 4;                    // the member image; what does not fit is stored
+constexpr int GZ_LINES = 1536;                             // line starts kept per chunk (later lines are coded as literals)
+constexpr int GZ_MAXM = 8;                                 // matches kept per span
+constexpr int GZ_NLIT = 286, GZ_NDIST = 30;
 constexpr int GZ_FIXED_HDR_BITS = 3 + 5 + 5 + 4 + 19 * 3;  // BFINAL, BTYPE, HLIT, HDIST, HCLEN, the 19 code-length code lengths
+constexpr int GZ_MIN_MATCH = 3;
 
 struct GzArgs {
     const uint8_t *text; const uint64_t *n_dev;   // the stream; its length is still on the device when the kernel is enqueued
@@ -46,7 +60,22 @@ DW_DEV uint32_t crc_append_zeros(const uint32_t *tables, uint32_t v, uint32_t nb
     for (uint32_t m = 0; nbytes; ++m, nbytes >>= 1) if (nbytes & 1u) v = crc_apply_shift(tables + m * 1024, v);
     return v;
 }
-DW_DEV uint32_t bit_reverse(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32u - len); }     // len 1..15
+DW_DEV uint32_t bit_reverse(uint32_t code, uint32_t len) { return len ? __builtin_bitreverse32(code) >> (32u - len) : 0u; }     // len 0..15
+
+// DEFLATE length / distance symbols (RFC 1951 3.2.5), computed: sym | extra bits << 8 | extra value << 16
+DW_DEV uint32_t gz_len_sym(uint32_t len)              // 3 .. 258
+{
+    if (len <= 10) return len - 3u;
+    if (len == 258) return 28u;
+    const uint32_t v = len - 3u, e = 29u - (uint32_t)__builtin_clz(v);       // v in [2^(e+2), 2^(e+3)): e extra bits
+    return (4u * e + 4u + ((v >> e) & 3u)) | (e << 8) | ((v & ((1u << e) - 1u)) << 16);
+}
+DW_DEV uint32_t gz_dist_sym(uint32_t dist)            // 1 .. 32768
+{
+    if (dist <= 4) return dist - 1u;
+    const uint32_t v = dist - 1u, e = 30u - (uint32_t)__builtin_clz(v);      // v in [2^(e+1), 2^(e+2)): e extra bits
+    return (2u * e + 2u + ((v >> e) & 1u)) | (e << 8) | ((v & ((1u << e) - 1u)) << 16);
+}
 
 struct LdsBits {            // LSB-first bit packer into the LDS image; the first and the last word of a run may be shared with a neighbour
     uint32_t *img; uint32_t w; uint64_t acc; uint32_t nb; bool first;
@@ -62,22 +91,113 @@ struct LdsBits {            // LSB-first bit packer into the LDS image; the firs
     DW_DEV void finish() { if (nb) atomicOr(&img[w], (uint32_t)acc); }
 };
 
+// bytes of the text at any address (gfx950 takes unaligned dword loads as they are)
+struct __attribute__((packed, aligned(1))) GzUnal4 { uint32_t v; };
+DW_DEV uint32_t gz_load4(const uint8_t *p) { return reinterpret_cast<const GzUnal4 *>(p)->v; }
+// equal bytes of src[p ..] and src[p - d ..], at most lim (p + lim does not pass the line's or the span's end; the buffer is padded for the last dword)
+DW_DEV uint32_t gz_match_len(const uint8_t *src, uint32_t p, uint32_t d, uint32_t lim)
+{
+    uint32_t l = 0;
+    while (l < lim) {
+        const uint32_t x = gz_load4(src + p + l) ^ gz_load4(src + p + l - d);
+        if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+        l += 4;
+    }
+    return l < lim ? l : lim;
+}
+
+// Huffman code lengths of up to 512 symbols (lane tid owns symbols tid and 256 + tid) by repeated merging of the two lightest trees; h0 / h1 =
+// the counts of this lane's symbols.  Lengths land in len[]; counts are flattened ((h >> scale) | 1) until no code is longer than 15 bits.
+// A single used symbol gets length 1 (RFC 1951: one distance code is sent with one bit), none leaves all lengths 0.
+DW_DEV void gz_code_lengths(uint32_t h0, uint32_t h1, uint32_t *wgt, uint32_t *grp, uint32_t *len, uint32_t *s_scan, uint32_t (*s_min)[4][2])
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t scale = 0;; ++scale) {
+        const uint32_t w0 = h0 ? (scale ? ((h0 >> scale) | 1u) : h0) : 0u, w1 = h1 ? (scale ? ((h1 >> scale) | 1u) : h1) : 0u;
+        wgt[tid] = w0; grp[tid] = (uint32_t)tid; len[tid] = 0;
+        wgt[256 + tid] = w1; grp[256 + tid] = 256u + (uint32_t)tid; len[256 + tid] = 0;
+        uint32_t ntrees;
+        { uint32_t tot; (void)block_excl_scan((w0 ? 1u : 0u) + (w1 ? 1u : 0u), s_scan, &tot); ntrees = tot; }      // (its barriers publish the arrays)
+        if (ntrees <= 1) { if (w0) len[tid] = 1; if (w1) len[256 + tid] = 1; __syncthreads(); return; }
+        for (uint32_t merge = 0; ntrees > 1; ++merge, --ntrees) {
+            // keys (weight << 9 | tree id), dead trees = all ones; (a, b) = the two smallest of this lane, then of the wave, then of the block
+            uint32_t ka = wgt[tid] ? ((wgt[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+            if (wgt[256 + tid]) { const uint32_t k2 = (wgt[256 + tid] << 9) | (256u + (uint32_t)tid); if (k2 < ka) { kb = ka; ka = k2; } else kb = k2; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
+                const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
+                ka = lo; kb = hi < ob2 ? hi : ob2;
+            }
+            if (lane == 0) { s_min[merge & 1][wave][0] = ka; s_min[merge & 1][wave][1] = kb; }
+            __syncthreads();
+            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t oa = s_min[merge & 1][w][0], ob = s_min[merge & 1][w][1];
+                const uint32_t lo = m1 < oa ? m1 : oa, hi = m1 < oa ? oa : m1, ob2 = m2 < ob ? m2 : ob;
+                m1 = lo; m2 = hi < ob2 ? hi : ob2;
+            }
+            const uint32_t t1 = m1 & 511u, t2 = m2 & 511u;        // tree t2 joins tree t1: every leaf of both goes one level down
+            if (w0 && (grp[tid] == t1 || grp[tid] == t2)) { ++len[tid]; grp[tid] = t1; }
+            if (w1 && (grp[256 + tid] == t1 || grp[256 + tid] == t2)) { ++len[256 + tid]; grp[256 + tid] = t1; }
+            __syncthreads();                                      // all leaves have read the trees' ids before the weights change
+            if ((uint32_t)tid == (t1 & 255u)) wgt[t1] = (m1 >> 9) + (m2 >> 9);
+            if ((uint32_t)tid == (t2 & 255u)) wgt[t2] = 0;
+            __syncthreads();
+        }
+        uint32_t mx = len[tid] > len[256 + tid] ? len[tid] : len[256 + tid];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, off); mx = o > mx ? o : mx; }
+        if (lane == 0) s_min[0][wave][0] = mx;
+        __syncthreads();
+        mx = s_min[0][0][0]; for (int w = 1; w < 4; ++w) mx = s_min[0][w][0] > mx ? s_min[0][w][0] : mx;
+        __syncthreads();
+        if (mx <= 15) return;                                     // else flatten the histogram and build again (equal weights give depth <= 9)
+    }
+}
+// canonical codes (RFC 1951 3.2.2) of the lengths in len[0 .. 512), stored bit-reversed for LSB-first packing: code[s] = reversed code | length << 16
+// (n_lo / n_hi: how many codes of symbols tid / 256 + tid are kept)
+DW_DEV void gz_canonical(const uint32_t *len, uint32_t *code, int n_lo, int n_hi, uint32_t *s_blc, uint32_t *s_next)
+{
+    const int tid = (int)threadIdx.x;
+    if (tid < 16) s_blc[tid] = 0;
+    __syncthreads();
+    const uint32_t l0 = len[tid], l1 = len[256 + tid];
+    if (l0) atomicAdd(&s_blc[l0], 1u);
+    if (l1) atomicAdd(&s_blc[l1], 1u);
+    __syncthreads();
+    if (tid == 0) { uint32_t c = 0; s_next[0] = 0; for (int bits = 1; bits <= 15; ++bits) { c = (c + (bits > 1 ? s_blc[bits - 1] : 0u)) << 1; s_next[bits] = c; } }
+    __syncthreads();
+    uint32_t r0 = 0, r1 = 0;                                      // symbols below mine with my length
+    if (l0) for (int j = 0; j < tid; ++j) r0 += len[j] == l0 ? 1u : 0u;
+    if (l1) for (int j = 0; j < 256 + tid; ++j) r1 += len[j] == l1 ? 1u : 0u;
+    if (tid < n_lo) code[tid] = l0 ? (bit_reverse(s_next[l0] + r0, l0) | (l0 << 16)) : 0u;
+    if (tid < n_hi) code[256 + tid] = l1 ? (bit_reverse(s_next[l1] + r1, l1) | (l1 << 16)) : 0u;
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
 {
     __shared__ uint32_t s_img[GZ_IMG_WORDS];
-    __shared__ uint32_t s_sub[8][260];        // sub-histograms (lane & 7), then: [0] weights, [1] tree ids, [2] code lengths of the construction
-    __shared__ uint32_t s_code[257];          // bit-reversed canonical code | length << 16
+    __shared__ uint32_t s_sub[8][288];        // sub-histograms of literals / lengths (lane & 7), then the work arrays of the code construction
+    __shared__ uint32_t s_dsub[64];           // distance histogram, then its code lengths
+    __shared__ uint32_t s_code[288];          // bit-reversed canonical code | length << 16 of literals / lengths
+    __shared__ uint32_t s_dcode[32];          // ... of distances
     __shared__ uint32_t s_tab[1024];          // CRC slicing tables, later the span CRCs ([0..255])
+    __shared__ uint32_t s_tok[GZ_MAXM][GZ_THREADS];      // matches of a span: start in the span | length << 8 | distance << 17
+    __shared__ uint16_t s_ls[GZ_LINES + 2];   // line starts of the chunk
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_min[2][4][2];       // the two lightest trees of every wave (double-buffered by merge parity)
     __shared__ uint32_t s_blc[16], s_next[16];
+    __shared__ uint32_t s_hdr[3];             // bits of the run-length coded code lengths, HLIT, HDIST
     __shared__ uint32_t s_ticket; __shared__ uint64_t s_base;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)a.ticket, 1ull);
-    for (int q = tid; q < 8 * 260; q += GZ_THREADS) (&s_sub[0][0])[q] = 0;
+    for (int q = tid; q < 8 * 288; q += GZ_THREADS) (&s_sub[0][0])[q] = 0;
     for (int q = tid; q < GZ_IMG_WORDS; q += GZ_THREADS) s_img[q] = 0;
     for (int q = tid; q < 1024; q += GZ_THREADS) s_tab[q] = a.crc_slice[q];
-    if (tid < 16) s_blc[tid] = 0;
+    if (tid < 64) s_dsub[tid] = 0;
     __syncthreads();
     const uint32_t t = s_ticket;                                  // logical chunk: its predecessors have started
     const uint64_t n_text = *a.n_dev, c0 = (uint64_t)t * GZ_CHUNK;
@@ -103,143 +223,196 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
         }
     }
 
-    // ---- pass 1: histogram + CRC-32 of the span (register started from 0; the chunk's init value enters with lane 0) ----
+    // ---- lines: newline masks of the span (bit i of nl[i >> 5] = byte i is '\n'), the chunk's line starts ----
+    uint32_t nl[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < GZ_SPAN / 4; ++k) {
+        const uint32_t x = d[k] ^ 0x0A0A0A0Au, z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);      // 0x80 in every zero byte of x
+        const uint32_t m = ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+        nl[k >> 3] |= m << (4 * (k & 7));
+    }
+    // (bytes past the text are zero in d[], not '\n')
+    uint32_t nlines_before, nl_total;
+    {
+        const uint32_t cnt = (uint32_t)(__popc(nl[0]) + __popc(nl[1]) + __popc(nl[2]) + __popc(nl[3]));
+        nlines_before = block_excl_scan(cnt, s_scan, &nl_total);
+    }
+    if (tid == 0) s_ls[0] = 0;
+    {
+        uint32_t k = nlines_before + 1;                            // line k starts behind the k-th '\n'
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t m = nl[w];
+            while (m) { const uint32_t b = (uint32_t)__builtin_ctz(m); m &= m - 1; if (k <= (uint32_t)GZ_LINES) s_ls[k] = (uint16_t)(s0 + 32u * (uint32_t)w + b + 1u); ++k; }
+        }
+    }
+    __syncthreads();
+    // lines 0 .. n_lines-1 start inside the chunk; line k ends (exclusive, with its '\n') at ls_end(k)
+    const uint32_t n_lines_all = nl_total + 1u - ((clen > 0 && nl_total > 0 && src[clen - 1] == '\n') ? 1u : 0u);
+    const uint32_t n_lines = n_lines_all < (uint32_t)GZ_LINES ? n_lines_all : (uint32_t)GZ_LINES;
+    auto ls_start = [&](uint32_t k) -> uint32_t { return s_ls[k]; };
+    auto ls_end = [&](uint32_t k) -> uint32_t { return k + 1 < n_lines_all && k + 1 <= (uint32_t)GZ_LINES ? (uint32_t)s_ls[k + 1] : clen; };
+
+    // ---- parse: name lines inside the span ----
+    // A line is taken for a name line when it starts with '@' and the line two above (or, at the top of the chunk, two below) starts with '+':
+    // a wrong guess costs compares, never correctness -- every match is verified byte by byte.
+    uint32_t cov[4] = {0, 0, 0, 0};                               // bytes of the span covered by matches
+    uint32_t mst[4] = {0, 0, 0, 0};                               // ... and where the matches start
+    uint32_t n_tok = 0;
+    if (slen) {
+        uint32_t k = nlines_before;                               // the line that holds the span's first byte
+        uint32_t p = s0;
+        const uint32_t span_end = s0 + slen;
+        while (p < span_end && k < n_lines && n_tok < (uint32_t)GZ_MAXM) {
+            const uint32_t le = ls_end(k), lim_end = le < span_end ? le : span_end;
+            const uint32_t st = ls_start(k);
+            bool name = src[st] == '@';
+            if (name) { if (k >= 2) name = src[ls_start(k - 2)] == '+'; else if (k + 2 < n_lines) name = src[ls_start(k + 2)] == '+'; }
+            if (name) {
+                // candidate distances: the same column of the line four lines up, the same distance from the line's end there, and 6 .. 11 (the line itself)
+                uint32_t dA = 0, dB = 0;
+                if (k >= 4) { dA = st - ls_start(k - 4); dB = le - ls_end(k - 4); if (dB == dA) dB = 0; }
+                uint32_t endA = p, endB = p;                      // the equal run of alignment A / B that has been measured reaches up to here
+                while (p < lim_end && n_tok < (uint32_t)GZ_MAXM) {
+                    const uint32_t lim = lim_end - p < 258u ? lim_end - p : 258u;
+                    uint32_t best = 0, bd = 0;
+                    if (dA && p >= dA) { if (endA <= p) endA = p + gz_match_len(src, p, dA, lim_end - p); const uint32_t l = endA - p < lim ? endA - p : lim; if (l > best) { best = l; bd = dA; } }
+                    if (dB && p >= dB) { if (endB <= p) endB = p + gz_match_len(src, p, dB, lim_end - p); const uint32_t l = endB - p < lim ? endB - p : lim; if (l > best) { best = l; bd = dB; } }
+                    if (best < 8 && p >= 12 && lim >= (uint32_t)GZ_MIN_MATCH) {
+                        const uint32_t cur = gz_load4(src + p);
+#pragma unroll
+                        for (uint32_t ds = 6; ds <= 11; ++ds) {
+                            const uint32_t x = cur ^ gz_load4(src + p - ds);
+                            if ((x & 0xFFFFFFu) == 0) { const uint32_t l = gz_match_len(src, p, ds, lim); if (l > best) { best = l; bd = ds; } }
+                        }
+                    }
+                    if (best >= (uint32_t)GZ_MIN_MATCH) {
+                        const uint32_t o = p - s0;
+                        s_tok[n_tok][tid] = o | (best << 8) | (bd << 17);
+                        ++n_tok;
+                        // bits o .. o + best - 1 of cov, bit o of mst
+                        mst[o >> 5] |= 1u << (o & 31u);           // (dynamic word index: four registers, resolved by selects)
+                        for (uint32_t b = o; b < o + best;) {
+                            const uint32_t w = b >> 5, lo = b & 31u, n = (32u - lo < o + best - b) ? 32u - lo : o + best - b;
+                            const uint32_t m = (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << lo;
+                            cov[w] |= m; b += n;
+                        }
+                        p += best;
+                    } else ++p;
+                }
+            }
+            p = le > p ? (name ? p : le) : p;                      // a line that is not a name line is skipped whole
+            if (p >= le) ++k;
+        }
+    }
+
+    // ---- pass 1: histograms + CRC-32 of the span (register started from 0; the chunk's init value enters with lane 0) ----
     uint32_t crc = tid == 0 ? 0xFFFFFFFFu : 0u;
     {
         uint32_t *hist = s_sub[tid & 7];
 #pragma unroll
         for (int k = 0; k < GZ_SPAN / 4; ++k) {
             const uint32_t w = d[k], base = 4u * (uint32_t)k;
+            const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
             if (base + 4 <= slen) {
-                atomicAdd(&hist[w & 255u], 1u); atomicAdd(&hist[(w >> 8) & 255u], 1u); atomicAdd(&hist[(w >> 16) & 255u], 1u); atomicAdd(&hist[w >> 24], 1u);
+                if (!(cv & 1u)) atomicAdd(&hist[w & 255u], 1u);
+                if (!(cv & 2u)) atomicAdd(&hist[(w >> 8) & 255u], 1u);
+                if (!(cv & 4u)) atomicAdd(&hist[(w >> 16) & 255u], 1u);
+                if (!(cv & 8u)) atomicAdd(&hist[w >> 24], 1u);
                 const uint32_t x = crc ^ w;
                 crc = s_tab[768 + (x & 255u)] ^ s_tab[512 + ((x >> 8) & 255u)] ^ s_tab[256 + ((x >> 16) & 255u)] ^ s_tab[x >> 24];
             } else if (base < slen) {
-                for (uint32_t b = 0; base + b < slen; ++b) { const uint32_t c = (w >> (8 * b)) & 255u; atomicAdd(&hist[c], 1u); crc = s_tab[(crc ^ c) & 255u] ^ (crc >> 8); }
+                for (uint32_t b = 0; base + b < slen; ++b) { const uint32_t c = (w >> (8 * b)) & 255u; if (!((cv >> b) & 1u)) atomicAdd(&hist[c], 1u); crc = s_tab[(crc ^ c) & 255u] ^ (crc >> 8); }
             }
+        }
+        for (uint32_t q = 0; q < n_tok; ++q) {
+            const uint32_t tk = s_tok[q][tid];
+            atomicAdd(&hist[257u + (gz_len_sym((tk >> 8) & 511u) & 255u)], 1u);
+            atomicAdd(&s_dsub[gz_dist_sym(tk >> 17) & 255u], 1u);
         }
     }
     __syncthreads();
 
-    // ---- Huffman code lengths: lane k owns symbol k (lane 0 also the end-of-block symbol 256) ----
-    uint32_t *wgt = s_sub[0], *grp = s_sub[1], *len = s_sub[2];
-    uint32_t h0 = 0, h1 = 0;                                      // the counts of this lane's symbol(s)
-    for (int q = 0; q < 8; ++q) h0 += s_sub[q][tid];
+    // ---- Huffman code lengths: lane k owns symbols k and 256 + k (256 = end of block, 257 .. 285 = lengths) ----
+    uint32_t *wgt = s_sub[0], *grp = s_sub[2], *len = s_sub[4];   // 512 words each (two rows of 288: the second row's first 224 words)
+    uint32_t h0 = 0, h1 = 0;
+    for (int q = 0; q < 8; ++q) { h0 += s_sub[q][tid]; if (tid < GZ_NLIT - 256) h1 += s_sub[q][256 + tid]; }
     if (tid == 0) h1 = 1;                                         // end of block: once
+    const uint32_t hd = tid < GZ_NDIST ? s_dsub[tid] : 0u;
     __syncthreads();                                              // (the sub-histograms become work arrays)
-    for (uint32_t scale = 0;; ++scale) {
-        const uint32_t w0 = h0 ? (scale ? ((h0 >> scale) | 1u) : h0) : 0u, w1 = h1;
-        wgt[tid] = w0; grp[tid] = (uint32_t)tid; len[tid] = 0;
-        if (tid == 0) { wgt[256] = w1; grp[256] = 256; len[256] = 0; }
-        uint32_t ntrees;
-        { uint32_t tot; (void)block_excl_scan((w0 ? 1u : 0u) + (tid == 0 ? 1u : 0u), s_scan, &tot); ntrees = tot; }      // (its barriers publish the arrays)
-        if (ntrees == 1) { if (tid == 0) len[256] = 1; __syncthreads(); break; }     // only the end-of-block symbol: cannot happen (clen >= 1), kept complete
-        for (uint32_t merge = 0; ntrees > 1; ++merge, --ntrees) {
-            // keys (weight << 9 | tree id), dead trees = all ones; (a, b) = the two smallest of this lane, then of the wave, then of the block
-            uint32_t ka = wgt[tid] ? ((wgt[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
-            if (tid == 0 && wgt[256]) { const uint32_t k2 = (wgt[256] << 9) | 256u; if (k2 < ka) { kb = ka; ka = k2; } else kb = k2; }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
-                const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
-                ka = lo; kb = hi < ob2 ? hi : ob2;
-            }
-            if (lane == 0) { s_min[merge & 1][wave][0] = ka; s_min[merge & 1][wave][1] = kb; }
-            __syncthreads();
-            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t oa = s_min[merge & 1][w][0], ob = s_min[merge & 1][w][1];
-                const uint32_t lo = m1 < oa ? m1 : oa, hi = m1 < oa ? oa : m1, ob2 = m2 < ob ? m2 : ob;
-                m1 = lo; m2 = hi < ob2 ? hi : ob2;
-            }
-            const uint32_t t1 = m1 & 511u, t2 = m2 & 511u;        // tree t2 joins tree t1: every leaf of both goes one level down
-            if (grp[tid] == t1 || grp[tid] == t2) { if (h0) { ++len[tid]; grp[tid] = t1; } }
-            if (tid == 0 && (grp[256] == t1 || grp[256] == t2)) { ++len[256]; grp[256] = t1; }
-            __syncthreads();                                      // all leaves have read the weights' owners' ids before the weights change
-            if ((uint32_t)tid == (t1 & 255u) && t1 < 256u) wgt[t1] = (m1 >> 9) + (m2 >> 9);
-            if (tid == 0 && t1 == 256u) wgt[256] = (m1 >> 9) + (m2 >> 9);
-            if ((uint32_t)tid == (t2 & 255u) && t2 < 256u) wgt[t2] = 0;
-            if (tid == 0 && t2 == 256u) wgt[256] = 0;
-            __syncthreads();
-        }
-        uint32_t mx = len[tid]; if (tid == 0 && len[256] > mx) mx = len[256];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, off); mx = o > mx ? o : mx; }
-        if (lane == 0) s_min[0][wave][0] = mx;
-        __syncthreads();
-        mx = s_min[0][0][0]; for (int w = 1; w < 4; ++w) mx = s_min[0][w][0] > mx ? s_min[0][w][0] : mx;
-        __syncthreads();
-        if (mx <= 15) break;                                      // else flatten the histogram and build again (equal weights give depth <= 9)
-    }
+    gz_code_lengths(h0, h1, wgt, grp, len, s_scan, s_min);
+    gz_canonical(len, s_code, 256, 32, s_blc, s_next);
+    const uint32_t my_len = len[tid], my_len1 = len[256 + tid];
+    __syncthreads();
+    gz_code_lengths(hd, 0u, wgt, grp, len, s_scan, s_min);
+    gz_canonical(len, s_dcode, 32, 0, s_blc, s_next);
+    if (tid < 64) s_dsub[tid] = tid < GZ_NDIST ? len[tid] : 0u;   // the distance code lengths, out of the work arrays
+    __syncthreads();
+    // literal / length code lengths back into len[] for the header (the work arrays were reused by the distance code)
+    len[tid] = my_len; len[256 + tid] = my_len1;
+    __syncthreads();
 
-    // ---- canonical codes (RFC 1951 3.2.2), stored bit-reversed for LSB-first packing ----
-    const uint32_t my_len = len[tid], eob_len = len[256];
-    if (my_len) atomicAdd(&s_blc[my_len], 1u);
-    if (tid == 0) atomicAdd(&s_blc[eob_len], 1u);
-    __syncthreads();
-    if (tid == 0) { uint32_t code = 0; s_next[0] = 0; for (int bits = 1; bits <= 15; ++bits) { code = (code + (bits > 1 ? s_blc[bits - 1] : 0u)) << 1; s_next[bits] = code; } }
-    __syncthreads();
-    {
-        uint32_t rank = 0;                                        // symbols below mine with my length (the end-of-block symbol is above every byte)
-        if (my_len) for (int j = 0; j < tid; ++j) rank += len[j] == my_len ? 1u : 0u;
-        s_code[tid] = my_len ? (bit_reverse(s_next[my_len] + rank, my_len) | (my_len << 16)) : 0u;
-        if (tid == 0) { uint32_t r = 0; for (int j = 0; j < 256; ++j) r += len[j] == eob_len ? 1u : 0u; s_code[256] = bit_reverse(s_next[eob_len] + r, eob_len) | (eob_len << 16); }
-    }
-    // the code-length code is fixed and complete: symbols 0..12 take 4 bits (codes 0..12), 13..18 take 5 bits (codes 26..31); every literal
-    // code length is sent as itself, then the single distance code length 0.  Lane k sends symbol k's length (lane 255 also symbol 256's
-    // and the distance code's).
+    // ---- block header: the code lengths, run-length coded (RFC 1951 3.2.7) under a FIXED code-length code: symbols 0 .. 12 take 4 bits (codes
+    // 0 .. 12), 13 .. 18 take 5 bits (codes 26 .. 31).  One lane walks the 257 + HLIT + 1 + HDIST lengths; its tokens go straight into the image ----
     auto cl_code = [](uint32_t sym, uint32_t &nbits) -> uint32_t { nbits = sym <= 12u ? 4u : 5u; return bit_reverse(sym <= 12u ? sym : 26u + (sym - 13u), nbits); };
-    uint32_t hb0, hb1 = 0, hb2 = 0, hc0, hc1 = 0, hc2 = 0;
-    hc0 = cl_code(my_len, hb0);
-    if (tid == 255) { hc1 = cl_code(eob_len, hb1); hc2 = cl_code(0u, hb2); }
-    uint32_t hdr_sym_bits;
-    const uint32_t hdr_before = block_excl_scan(hb0 + hb1 + hb2, s_scan, &hdr_sym_bits);      // (its barriers publish s_code)
+    // (the gzip header's length depends on the member's size through the pad: the code lengths are first counted, then written in pass 3)
+    auto walk_lengths = [&](LdsBits *bs) -> uint32_t {             // bits of the coded lengths; with bs: also written
+        uint32_t hlit = GZ_NLIT; while (hlit > 257u && len[hlit - 1] == 0) --hlit;
+        uint32_t hdist = GZ_NDIST; while (hdist > 1u && s_dsub[hdist - 1] == 0) --hdist;
+        const uint32_t n = hlit + hdist;
+        auto at = [&](uint32_t i) -> uint32_t { return i < hlit ? len[i] : s_dsub[i - hlit]; };
+        uint32_t bits = 0, i = 0;
+        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); bits += nb + ebits; if (bs) { bs->put(c, nb); if (ebits) bs->put(eval, ebits); } };
+        while (i < n) {
+            const uint32_t v = at(i); uint32_t j = i + 1;
+            while (j < n && at(j) == v) ++j;
+            uint32_t run = j - i;
+            if (v == 0) {
+                while (run >= 11) { const uint32_t r = run < 138u ? run : 138u; emit(18, 7, r - 11u); run -= r; }
+                if (run >= 3) { emit(17, 3, run - 3u); run = 0; }
+                while (run) { emit(0, 0, 0); --run; }
+            } else {
+                emit(v, 0, 0); --run;
+                while (run >= 3) { const uint32_t r = run < 6u ? run : 6u; emit(16, 2, r - 3u); run -= r; }
+                while (run) { emit(v, 0, 0); --run; }
+            }
+            i = j;
+        }
+        if (!bs) { s_hdr[1] = hlit - 257u; s_hdr[2] = hdist - 1u; }
+        return bits;
+    };
+    if (tid == 0) s_hdr[0] = walk_lengths(nullptr);
 
     // ---- pass 2: bits of this lane's span; scan; this member's size and its byte offset by look-back over the chunks ----
     uint32_t bits = 0;
 #pragma unroll
     for (int k = 0; k < GZ_SPAN / 4; ++k) {
         const uint32_t w = d[k], base = 4u * (uint32_t)k;
-        if (base + 4 <= slen) bits += (s_code[w & 255u] >> 16) + (s_code[(w >> 8) & 255u] >> 16) + (s_code[(w >> 16) & 255u] >> 16) + (s_code[w >> 24] >> 16);
-        else for (uint32_t b = 0; base + b < slen; ++b) bits += s_code[(w >> (8 * b)) & 255u] >> 16;
+        const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) if (base + b < slen && !((cv >> b) & 1u)) bits += s_code[(w >> (8 * b)) & 255u] >> 16;
+    }
+    for (uint32_t q = 0; q < n_tok; ++q) {
+        const uint32_t tk = s_tok[q][tid], ls = gz_len_sym((tk >> 8) & 511u), ds = gz_dist_sym(tk >> 17);
+        bits += (s_code[257u + (ls & 255u)] >> 16) + ((ls >> 8) & 255u) + (s_dcode[ds & 255u] >> 16) + ((ds >> 8) & 255u);
     }
     uint32_t tot_bits;
-    const uint32_t before = block_excl_scan(bits, s_scan, &tot_bits);
+    const uint32_t before = block_excl_scan(bits, s_scan, &tot_bits);      // (its barriers publish s_hdr)
+    const uint32_t hdr_sym_bits = s_hdr[0];
     const uint32_t eob = s_code[256];
     const uint32_t body_bits = (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + tot_bits + (eob >> 16) + 3u;      // ... + the final stored block's 3 header bits
-    const uint32_t body_bytes = ((body_bits + 7u) >> 3) + 4u;                                                // ... + LEN, NLEN
+    uint32_t body_bytes = ((body_bits + 7u) >> 3) + 4u;                                                      // ... + LEN, NLEN
+    const bool coded = 10u + 4u + body_bytes + 8u <= (uint32_t)GZ_IMG_WORDS * 4u && body_bytes <= 5u + clen;
+    if (!coded) body_bytes = 5u + clen;                                                                      // one stored block: header byte, LEN, NLEN, the text
     const uint32_t pad = (4u - ((10u + 1u + body_bytes + 8u) & 3u)) & 3u;                                    // FNAME = pad characters + NUL
     const uint32_t hdr_bytes = 10u + pad + 1u, member_bytes = hdr_bytes + body_bytes + 8u;
-    const bool fits = member_bytes <= (uint32_t)GZ_IMG_WORDS * 4u;
-    if (wave == 0) { const uint64_t g = lookback_excl(a.status, t, fits ? member_bytes : 0u, 0); if (lane == 0) { s_base = g; if (c0 + clen >= n_text) *a.total = g + (fits ? member_bytes : 0u); } }
+    if (wave == 0) { const uint64_t g = lookback_excl(a.status, t, member_bytes, 0); if (lane == 0) { s_base = g; if (c0 + clen >= n_text) *a.total = g + member_bytes; } }
     __syncthreads();
-    if (!fits || s_base + member_bytes > a.cap) { if (tid == 0) atomicOr((unsigned long long *)a.flags, 8ull); return; }      // (cannot happen for text)
+    if (s_base + member_bytes > a.cap) { if (tid == 0) atomicOr((unsigned long long *)a.flags, 8ull); return; }      // (cannot happen: gz_capacity covers stored members)
 
-    // ---- pass 3: the member image ----
-    const uint32_t data0 = hdr_bytes * 8u;                        // bit position of the DEFLATE data
-    {
-        LdsBits bs; bs.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_before);
-        bs.put(hc0, hb0);
-        if (tid == 255) { bs.put(hc1, hb1); bs.put(hc2, hb2); }
-        bs.finish();
-    }
-    {
-        LdsBits bs; bs.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + before);
-#pragma unroll
-        for (int k = 0; k < GZ_SPAN / 4; ++k) {
-            const uint32_t w = d[k], base = 4u * (uint32_t)k;
-            if (base + 4 <= slen) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { const uint32_t c = s_code[(w >> (8 * b)) & 255u]; bs.put(c & 0xFFFFu, c >> 16); }
-            } else for (uint32_t b = 0; base + b < slen; ++b) { const uint32_t c = s_code[(w >> (8 * b)) & 255u]; bs.put(c & 0xFFFFu, c >> 16); }
-        }
-        bs.finish();
-    }
     // CRC-32 of the chunk: the spans' registers joined by a tree; the right half of a node is shifted in by its true length (the last chunk of
     // a stream is short), so one rule serves every node: left' = left * x^(8 * bytes of the right half) + right
-    __syncthreads();                                              // (the slicing tables are no longer needed: the slots now carry span CRCs)
-    s_tab[tid] = crc;
+    s_tab[tid] = crc;                                             // (the slicing tables are no longer needed: the barrier above)
     __syncthreads();
     for (int k = 0; k < 8; ++k) {
         uint32_t v = 0; const bool act = (tid & ((2 << k) - 1)) == 0;
@@ -252,18 +425,63 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
         if (act) s_tab[tid] = v;
         __syncthreads();
     }
+    const uint32_t chunk_crc = s_tab[0] ^ 0xFFFFFFFFu;
+    const uint8_t hd10[10] = {0x1f, 0x8b, 8, 8, 0, 0, 0, 0, 0, 255};      // gzip header: magic, deflate, FLG = FNAME, mtime 0, xfl 0, OS 255, then the pad name
+
+    if (!coded) {
+        // ---- a stored member (text that does not compress to 3/4): header | 01 LEN NLEN text | CRC, length; written straight from the registers ----
+        uint8_t *dst = reinterpret_cast<uint8_t *>(a.out) + s_base;
+        if (tid == 0) {
+            for (uint32_t q = 0; q < 10; ++q) dst[q] = hd10[q];
+            for (uint32_t q = 0; q < pad; ++q) dst[10 + q] = 'x';
+            dst[10 + pad] = 0;
+            uint8_t *b = dst + hdr_bytes;
+            b[0] = 1; b[1] = (uint8_t)(clen & 255u); b[2] = (uint8_t)(clen >> 8); b[3] = (uint8_t)(~clen & 255u); b[4] = (uint8_t)((~clen >> 8) & 255u);      // BFINAL = 1, BTYPE = 00
+            uint8_t *e = b + 5 + clen;
+            for (uint32_t q = 0; q < 4; ++q) { e[q] = (uint8_t)((chunk_crc >> (8 * q)) & 255u); e[4 + q] = (uint8_t)((clen >> (8 * q)) & 255u); }
+        }
+        uint8_t *body = dst + hdr_bytes + 5u + s0;
+#pragma unroll
+        for (int k = 0; k < GZ_SPAN / 4; ++k) {
+            const uint32_t base = 4u * (uint32_t)k;
+            if (base + 4 <= slen) { GzUnal4 v; v.v = d[k]; *reinterpret_cast<GzUnal4 *>(body + base) = v; }
+            else for (uint32_t b = 0; base + b < slen; ++b) body[base + b] = (uint8_t)((d[k] >> (8 * b)) & 255u);
+        }
+        return;
+    }
+
+    // ---- pass 3: the member image ----
+    const uint32_t data0 = hdr_bytes * 8u;                        // bit position of the DEFLATE data
+    {
+        LdsBits bs; bs.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + before);
+        uint32_t q = 0;
+#pragma unroll
+        for (int k = 0; k < GZ_SPAN / 4; ++k) {
+            const uint32_t w = d[k], base = 4u * (uint32_t)k;
+            const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u, ms = (mst[k >> 3] >> (4 * (k & 7))) & 15u;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                if (base + b >= slen) continue;
+                if ((ms >> b) & 1u) {
+                    const uint32_t tk = s_tok[q][tid], ls = gz_len_sym((tk >> 8) & 511u), ds = gz_dist_sym(tk >> 17); ++q;
+                    const uint32_t lc = s_code[257u + (ls & 255u)], dc = s_dcode[ds & 255u];
+                    bs.put(lc & 0xFFFFu, lc >> 16); if ((ls >> 8) & 255u) bs.put(ls >> 16, (ls >> 8) & 255u);
+                    bs.put(dc & 0xFFFFu, dc >> 16); if ((ds >> 8) & 255u) bs.put(ds >> 16, (ds >> 8) & 255u);
+                } else if (!((cv >> b) & 1u)) { const uint32_t c = s_code[(w >> (8 * b)) & 255u]; bs.put(c & 0xFFFFu, c >> 16); }
+            }
+        }
+        bs.finish();
+    }
     if (tid == 0) {
-        const uint32_t chunk_crc = s_tab[0] ^ 0xFFFFFFFFu;
         auto put_byte = [&](uint32_t pos, uint32_t b) { atomicOr(&s_img[pos >> 2], b << (8 * (pos & 3u))); };
-        // gzip header: magic, deflate, FLG = FNAME, mtime 0, xfl 0, OS 255, the pad name
-        const uint8_t hd[10] = {0x1f, 0x8b, 8, 8, 0, 0, 0, 0, 0, 255};
-        for (uint32_t q = 0; q < 10; ++q) put_byte(q, hd[q]);
+        for (uint32_t q = 0; q < 10; ++q) put_byte(q, hd10[q]);
         for (uint32_t q = 0; q < pad; ++q) put_byte(10u + q, (uint32_t)'x');
-        // block header: BFINAL = 0, BTYPE = 10, HLIT = 0 (257 codes), HDIST = 0 (1 code), HCLEN = 15 (19 code-length code lengths: 4 for 0..12, 5 for 13..18)
+        // block header: BFINAL = 0, BTYPE = 10, HLIT, HDIST, HCLEN = 15 (19 code-length code lengths: 4 for 0..12, 5 for 13..18), then the coded lengths
         LdsBits bh; bh.init(s_img, data0);
-        bh.put(0, 1); bh.put(2, 2); bh.put(0, 5); bh.put(0, 5); bh.put(15, 4);
+        bh.put(0, 1); bh.put(2, 2); bh.put(s_hdr[1], 5); bh.put(s_hdr[2], 5); bh.put(15, 4);
         const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         for (int q = 0; q < 19; ++q) bh.put(order[q] <= 12 ? 4u : 5u, 3);
+        (void)walk_lengths(&bh);
         bh.finish();
         // end of block + the final empty stored block (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
         LdsBits be; be.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + tot_bits);
@@ -280,9 +498,8 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
 }
 
 uint64_t gz_chunks(uint64_t n) { return (n + GZ_CHUNK - 1) / GZ_CHUNK; }
-// An optimal prefix code never needs more than 8 bits per byte on average (the flat 8-bit code is a prefix code); + 1/8 for the rare
-// length-limited case, + the per-member framing and code table
-uint64_t gz_capacity(uint64_t n) { return n + n / 8 + gz_chunks(n) * 256 + 64; }
+// a member is never larger than its stored form: the text + 5 bytes of block header + 22 of framing and pad
+uint64_t gz_capacity(uint64_t n) { return n + gz_chunks(n) * 32 + 64; }
 
 // text_cap: capacity of the text buffer (the grid covers it; chunks past the real length, read from *n_dev on the device, leave at once)
 void launch_gzip(hipStream_t st, const uint8_t *text, const uint64_t *n_dev, uint64_t text_cap, uint8_t *out, uint64_t out_cap, uint64_t *status, uint64_t *ticket, uint64_t *total, uint64_t *flags,
