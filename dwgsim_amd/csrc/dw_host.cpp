@@ -1189,7 +1189,9 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
         if (c->writer >= 0) a.fifo = c->writer ? 1 : 0;
     }
     auto lds_need = [&](int lanes) { return sim_lds_bytes((size_t)((lmax0 + 7) / 8), (size_t)lanes, (size_t)c->qb_words, a.fifo != 0); };     // staged bases + the two base-quality tables + the text FIFOs
-    if (p.data_type != 2 && (lds_need(SIM_THREADS) > SIM_LDS_BUDGET || c->force_threads == SIM_THREADS_LONG)) {
+    // (from where LDS staging leaves room for ONE 256-lane block per CU -- reads of ~650 bases on -- the one-wave blocks are the faster form: 800 / 1 000 /
+    // 2 000 bases 13.1 / 13.0 / 22.7 ms in LDS against 7.8 / 8.0 / 8.6 ms staged in scratch slots, 600 bases 7.4 against 7.9: profiles/r04_long_reads.txt)
+    if (p.data_type != 2 && (lds_need(SIM_THREADS) > SIM_LDS_BUDGET || ((sim_blocks_per_cu(lds_need(SIM_THREADS), 8) < 2 || c->force_threads == SIM_THREADS_LONG) && c->force_threads != SIM_THREADS))) {
         // reads too long to stage in LDS: one-wave blocks whose reads are staged in scratch slots (global memory, dw_simulate.hip GS); what is left in LDS
         // is the two base-quality tables (2 bytes per base) and the FIFOs, which bounds a read at ~70 000 bases (the reference has no bound, dwgsim.c:75-153)
         a.sim_threads = SIM_THREADS_LONG; a.fifo = 1;

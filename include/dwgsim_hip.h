@@ -320,7 +320,7 @@ void dwgsim_hip_job_destroy(dwgsim_hip_job_t *job);
  * ==================================================================================================================================== */
 /* "justify_seq" = 1: left-justification from one thread (cross-check of the cluster-parallel form); "walk_cap" = n: start the mutation walk with
  * room for n candidates (exercises the exact re-run); "walk_seg_min" = n: segmented form of the walk's serial scans from n candidates on;
- * "writer" = 0 / 1: force the register / LDS-FIFO record writer; "sim_threads" = 64: force the one-wave blocks of the long-read variant;
+ * "writer" = 0 / 1: force the register / LDS-FIFO record writer; "sim_threads" = 64 / 256: force the one-wave blocks of the long-read variant / the 256-lane blocks (where their reads fit LDS);
  * "place_cap" = n: room for n undecided pairs per list in dwgsim_hip_count_random* (exercises its second run); "split" = 0 / 1: the Illumina
  * read kernel as one kernel with look-backs / as two kernels with the offsets computed in between (default: two for reads of up to 100 bases); "flow_slots" = n:
  * n scratch slots per XCD for the Ion Torrent read buffers / the long reads of the one-wave blocks (blocks wait for slots); "flow_cap" = n: the Ion Torrent

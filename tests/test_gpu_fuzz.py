@@ -51,7 +51,10 @@ def test_fresh_random_option_sets_bit_exact(oracle_bin, seed, count, mode, mut):
 
 def test_ion_torrent_random_flow_orders_bit_exact(oracle_bin):
     """tests/fuzz_ion_flows.py: the flow model under flow orders of 4 .. 64 flows with long gaps, read lengths 1 .. 400, per-flow error rates up to
-    0.2, -B; reads that outgrow their buffer (the documented limit) are counted, not failed."""
+    0.2, -B; at most one case of the sample may end with a read that outgrew its buffers (they are doubled up to 16 x first)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_ion_flows.py"), "31", "100"], capture_output=True, text=True, timeout=1200)
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-2000:]
+    # a batch whose read outgrew its buffers runs again with twice the room (up to 16 x): what may still fail is a read that degenerates (the run
+    # stack of pass 2, 2^14 errors in one event) -- none in this sample; a regression of the capacity logic would show here
+    assert int(last.split(" outgrew")[0].split()[-1]) <= 1, last
