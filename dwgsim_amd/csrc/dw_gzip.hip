@@ -106,54 +106,87 @@ DW_DEV uint32_t gz_match_len(const uint8_t *src, uint32_t p, uint32_t d, uint32_
     return l < lim ? l : lim;
 }
 
-// Huffman code lengths of up to 512 symbols (lane tid owns symbols tid and 256 + tid) by repeated merging of the two lightest trees; h0 / h1 =
-// the counts of this lane's symbols.  Lengths land in len[]; counts are flattened ((h >> scale) | 1) until no code is longer than 15 bits.
-// A single used symbol gets length 1 (RFC 1951: one distance code is sent with one bit), none leaves all lengths 0.
-DW_DEV void gz_code_lengths(uint32_t h0, uint32_t h1, uint32_t *wgt, uint32_t *grp, uint32_t *len, uint32_t *s_scan, uint32_t (*s_min)[4][2])
+// Huffman code lengths of TWO alphabets at once, by repeated merging of the two lightest trees of each: A = up to 512 symbols (lane tid owns symbols
+// tid and 256 + tid: literals / lengths), B = up to 64 symbols owned by the lanes of wave 0 (distances).  One merge of each per iteration, behind the
+// same three barriers (the barriers, not the arithmetic, are what a merge costs: the distance code rides along).  h0 / h1 / hb = the counts of this
+// lane's symbols.  Lengths land in lenA[0 .. 512) / lenB[0 .. 64); counts are flattened ((h >> scale) | 1) until no code is longer than 15 bits.  An
+// alphabet with a single used symbol gives it length 1 (RFC 1951: one distance code is sent with one bit), none leaves all lengths 0.
+DW_DEV void gz_code_lengths2(uint32_t h0, uint32_t h1, uint32_t hb, uint32_t *wgtA, uint32_t *grpA, uint32_t *lenA, uint32_t *wgtB, uint32_t *grpB, uint32_t *lenB,
+                             uint32_t *s_scan, uint32_t (*s_min)[4][2], uint32_t (*s_minB)[2])
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t scale = 0;; ++scale) {
-        const uint32_t w0 = h0 ? (scale ? ((h0 >> scale) | 1u) : h0) : 0u, w1 = h1 ? (scale ? ((h1 >> scale) | 1u) : h1) : 0u;
-        wgt[tid] = w0; grp[tid] = (uint32_t)tid; len[tid] = 0;
-        wgt[256 + tid] = w1; grp[256 + tid] = 256u + (uint32_t)tid; len[256 + tid] = 0;
-        uint32_t ntrees;
-        { uint32_t tot; (void)block_excl_scan((w0 ? 1u : 0u) + (w1 ? 1u : 0u), s_scan, &tot); ntrees = tot; }      // (its barriers publish the arrays)
-        if (ntrees <= 1) { if (w0) len[tid] = 1; if (w1) len[256 + tid] = 1; __syncthreads(); return; }
-        for (uint32_t merge = 0; ntrees > 1; ++merge, --ntrees) {
+    uint32_t scaleA = 0, scaleB = 0; bool doneA = false, doneB = false;
+    for (;;) {
+        const uint32_t w0 = h0 ? (scaleA ? ((h0 >> scaleA) | 1u) : h0) : 0u, w1 = h1 ? (scaleA ? ((h1 >> scaleA) | 1u) : h1) : 0u;
+        const uint32_t wb = (tid < 64 && hb) ? (scaleB ? ((hb >> scaleB) | 1u) : hb) : 0u;
+        if (!doneA) { wgtA[tid] = w0; grpA[tid] = (uint32_t)tid; lenA[tid] = 0; wgtA[256 + tid] = w1; grpA[256 + tid] = 256u + (uint32_t)tid; lenA[256 + tid] = 0; }
+        if (!doneB && tid < 64) { wgtB[tid] = wb; grpB[tid] = (uint32_t)tid; lenB[tid] = 0; }
+        uint32_t nA, nB;
+        { uint32_t tot; (void)block_excl_scan((w0 ? 1u : 0u) + (w1 ? 1u : 0u) + (wb ? 0x10000u : 0u), s_scan, &tot); nA = tot & 0xFFFFu; nB = tot >> 16; }      // (its barriers publish the arrays)
+        if (!doneA && nA <= 1) { if (w0) lenA[tid] = 1; if (w1) lenA[256 + tid] = 1; doneA = true; }
+        if (!doneB && nB <= 1) { if (wb) lenB[tid] = 1; doneB = true; }
+        for (uint32_t merge = 0; (!doneA && nA > 1) || (!doneB && nB > 1); ++merge) {
+            const bool actA = !doneA && nA > 1, actB = !doneB && nB > 1;
             // keys (weight << 9 | tree id), dead trees = all ones; (a, b) = the two smallest of this lane, then of the wave, then of the block
-            uint32_t ka = wgt[tid] ? ((wgt[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
-            if (wgt[256 + tid]) { const uint32_t k2 = (wgt[256 + tid] << 9) | (256u + (uint32_t)tid); if (k2 < ka) { kb = ka; ka = k2; } else kb = k2; }
+            if (actA) {
+                uint32_t ka = wgtA[tid] ? ((wgtA[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+                if (wgtA[256 + tid]) { const uint32_t k2 = (wgtA[256 + tid] << 9) | (256u + (uint32_t)tid); if (k2 < ka) { kb = ka; ka = k2; } else kb = k2; }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
-                const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
-                ka = lo; kb = hi < ob2 ? hi : ob2;
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
+                    const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
+                    ka = lo; kb = hi < ob2 ? hi : ob2;
+                }
+                if (lane == 0) { s_min[merge & 1][wave][0] = ka; s_min[merge & 1][wave][1] = kb; }
             }
-            if (lane == 0) { s_min[merge & 1][wave][0] = ka; s_min[merge & 1][wave][1] = kb; }
+            if (actB && wave == 0) {
+                uint32_t ka = wgtB[tid] ? ((wgtB[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
+                    const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
+                    ka = lo; kb = hi < ob2 ? hi : ob2;
+                }
+                if (lane == 0) { s_minB[merge & 1][0] = ka; s_minB[merge & 1][1] = kb; }
+            }
             __syncthreads();
-            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, t1 = 0, t2 = 0, b1 = 0, b2 = 0, u1 = 0, u2 = 0;
+            if (actA) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t oa = s_min[merge & 1][w][0], ob = s_min[merge & 1][w][1];
-                const uint32_t lo = m1 < oa ? m1 : oa, hi = m1 < oa ? oa : m1, ob2 = m2 < ob ? m2 : ob;
-                m1 = lo; m2 = hi < ob2 ? hi : ob2;
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t oa = s_min[merge & 1][w][0], ob = s_min[merge & 1][w][1];
+                    const uint32_t lo = m1 < oa ? m1 : oa, hi = m1 < oa ? oa : m1, ob2 = m2 < ob ? m2 : ob;
+                    m1 = lo; m2 = hi < ob2 ? hi : ob2;
+                }
+                t1 = m1 & 511u; t2 = m2 & 511u;                  // tree t2 joins tree t1: every leaf of both goes one level down
+                if (w0 && (grpA[tid] == t1 || grpA[tid] == t2)) { ++lenA[tid]; grpA[tid] = t1; }
+                if (w1 && (grpA[256 + tid] == t1 || grpA[256 + tid] == t2)) { ++lenA[256 + tid]; grpA[256 + tid] = t1; }
             }
-            const uint32_t t1 = m1 & 511u, t2 = m2 & 511u;        // tree t2 joins tree t1: every leaf of both goes one level down
-            if (w0 && (grp[tid] == t1 || grp[tid] == t2)) { ++len[tid]; grp[tid] = t1; }
-            if (w1 && (grp[256 + tid] == t1 || grp[256 + tid] == t2)) { ++len[256 + tid]; grp[256 + tid] = t1; }
+            if (actB) {
+                b1 = s_minB[merge & 1][0]; b2 = s_minB[merge & 1][1]; u1 = b1 & 511u; u2 = b2 & 511u;
+                if (wb && (grpB[tid] == u1 || grpB[tid] == u2)) { ++lenB[tid]; grpB[tid] = u1; }
+            }
             __syncthreads();                                      // all leaves have read the trees' ids before the weights change
-            if ((uint32_t)tid == (t1 & 255u)) wgt[t1] = (m1 >> 9) + (m2 >> 9);
-            if ((uint32_t)tid == (t2 & 255u)) wgt[t2] = 0;
+            if (actA) { if ((uint32_t)tid == (t1 & 255u)) wgtA[t1] = (m1 >> 9) + (m2 >> 9); if ((uint32_t)tid == (t2 & 255u)) wgtA[t2] = 0; --nA; }
+            if (actB) { if ((uint32_t)tid == u1) wgtB[u1] = (b1 >> 9) + (b2 >> 9); if ((uint32_t)tid == u2) wgtB[u2] = 0; --nB; }
             __syncthreads();
         }
-        uint32_t mx = len[tid] > len[256 + tid] ? len[tid] : len[256 + tid];
+        // the longest code of each alphabet
+        uint32_t mx = 0;
+        if (!doneA) mx = lenA[tid] > lenA[256 + tid] ? lenA[tid] : lenA[256 + tid];
+        if (!doneB && tid < 64) mx |= lenB[tid] << 8;
+        uint32_t ma = mx & 255u, mb = mx >> 8;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, off); mx = o > mx ? o : mx; }
-        if (lane == 0) s_min[0][wave][0] = mx;
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t oa = (uint32_t)__shfl_xor((int)ma, off), ob = (uint32_t)__shfl_xor((int)mb, off); ma = oa > ma ? oa : ma; mb = ob > mb ? ob : mb; }
         __syncthreads();
-        mx = s_min[0][0][0]; for (int w = 1; w < 4; ++w) mx = s_min[0][w][0] > mx ? s_min[0][w][0] : mx;
+        if (lane == 0) { s_min[0][wave][0] = ma; s_min[0][wave][1] = mb; }
         __syncthreads();
-        if (mx <= 15) return;                                     // else flatten the histogram and build again (equal weights give depth <= 9)
+        ma = s_min[0][0][0]; mb = s_min[0][0][1];
+        for (int w = 1; w < 4; ++w) { ma = s_min[0][w][0] > ma ? s_min[0][w][0] : ma; mb = s_min[0][w][1] > mb ? s_min[0][w][1] : mb; }
+        __syncthreads();
+        if (!doneA) { if (ma <= 15) doneA = true; else ++scaleA; }      // else flatten the histogram and build again (equal weights give depth <= 9)
+        if (!doneB) { if (mb <= 15) doneB = true; else ++scaleB; }
+        if (doneA && doneB) return;
     }
 }
 // canonical codes (RFC 1951 3.2.2) of the lengths in len[0 .. 512), stored bit-reversed for LSB-first packing: code[s] = reversed code | length << 16
@@ -179,8 +212,14 @@ DW_DEV void gz_canonical(const uint32_t *len, uint32_t *code, int n_lo, int n_hi
 
 __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
 {
-    __shared__ uint32_t s_img[GZ_IMG_WORDS];
-    __shared__ uint32_t s_sub[8][288];        // sub-histograms of literals / lengths (lane & 7), then the work arrays of the code construction
+    // one raw array: during the parse it holds the TEXT of the chunk (name lines are compared with the lines above them at LDS latency: from HBM,
+    // where the text has just been written by k_simulate, every dependent compare cost a microsecond and the kernel ran at 75 instead of 260 GB/s);
+    // afterwards it is the member image (24 KB) followed by the sub-histograms (9 KB)
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[GZ_IMG_WORDS + 8 * 288];
+    static_assert((GZ_IMG_WORDS + 8 * 288) * 4 >= GZ_CHUNK + 16, "the chunk's text fits where the image and the histograms will be");
+    uint32_t *const s_img = s_raw;
+    uint32_t (*const s_sub)[288] = reinterpret_cast<uint32_t (*)[288]>(s_raw + GZ_IMG_WORDS);      // sub-histograms of literals / lengths (lane & 7), then the work arrays of the code construction
+    const uint8_t *const s_text = reinterpret_cast<const uint8_t *>(s_raw);
     __shared__ uint32_t s_dsub[64];           // distance histogram, then its code lengths
     __shared__ uint32_t s_code[288];          // bit-reversed canonical code | length << 16 of literals / lengths
     __shared__ uint32_t s_dcode[32];          // ... of distances
@@ -189,13 +228,14 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     __shared__ uint16_t s_ls[GZ_LINES + 2];   // line starts of the chunk
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_min[2][4][2];       // the two lightest trees of every wave (double-buffered by merge parity)
+    __shared__ uint32_t s_minB[2][2];         // ... of the distance alphabet
+    __shared__ uint32_t s_wb[3][64];          // work arrays of the distance code: weights, tree ids, lengths
     __shared__ uint32_t s_blc[16], s_next[16];
-    __shared__ uint32_t s_hdr[3];             // bits of the run-length coded code lengths, HLIT, HDIST
+    __shared__ uint32_t s_hdr[4];             // bits of the run-length coded code lengths, HLIT, HDIST, their tokens
+    __shared__ uint64_t s_mask[6];            // "code length != 0" of literals / lengths (286 bits) and distances (30 bits)
     __shared__ uint32_t s_ticket; __shared__ uint64_t s_base;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)a.ticket, 1ull);
-    for (int q = tid; q < 8 * 288; q += GZ_THREADS) (&s_sub[0][0])[q] = 0;
-    for (int q = tid; q < GZ_IMG_WORDS; q += GZ_THREADS) s_img[q] = 0;
     for (int q = tid; q < 1024; q += GZ_THREADS) s_tab[q] = a.crc_slice[q];
     if (tid < 64) s_dsub[tid] = 0;
     __syncthreads();
@@ -223,6 +263,11 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
         }
     }
 
+    // the chunk's text into LDS: word i * 256 + tid by lane tid (coalesced from the L2, where the loads above have just brought it; conflict-free in LDS)
+    {
+        const uint32_t nw = (clen + 3u) >> 2;
+        for (uint32_t q = (uint32_t)tid; q < (uint32_t)(GZ_CHUNK / 4 + 4); q += GZ_THREADS) s_raw[q] = q < nw ? reinterpret_cast<const uint32_t *>(src)[q] : 0u;      // (the buffer is padded: whole words)
+    }
     // ---- lines: newline masks of the span (bit i of nl[i >> 5] = byte i is '\n'), the chunk's line starts ----
     uint32_t nl[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -248,7 +293,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     }
     __syncthreads();
     // lines 0 .. n_lines-1 start inside the chunk; line k ends (exclusive, with its '\n') at ls_end(k)
-    const uint32_t n_lines_all = nl_total + 1u - ((clen > 0 && nl_total > 0 && src[clen - 1] == '\n') ? 1u : 0u);
+    const uint32_t n_lines_all = nl_total + 1u - ((clen > 0 && nl_total > 0 && s_text[clen - 1] == '\n') ? 1u : 0u);
     const uint32_t n_lines = n_lines_all < (uint32_t)GZ_LINES ? n_lines_all : (uint32_t)GZ_LINES;
     auto ls_start = [&](uint32_t k) -> uint32_t { return s_ls[k]; };
     auto ls_end = [&](uint32_t k) -> uint32_t { return k + 1 < n_lines_all && k + 1 <= (uint32_t)GZ_LINES ? (uint32_t)s_ls[k + 1] : clen; };
@@ -266,8 +311,8 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
         while (p < span_end && k < n_lines && n_tok < (uint32_t)GZ_MAXM) {
             const uint32_t le = ls_end(k), lim_end = le < span_end ? le : span_end;
             const uint32_t st = ls_start(k);
-            bool name = src[st] == '@';
-            if (name) { if (k >= 2) name = src[ls_start(k - 2)] == '+'; else if (k + 2 < n_lines) name = src[ls_start(k + 2)] == '+'; }
+            bool name = s_text[st] == '@';
+            if (name) { if (k >= 2) name = s_text[ls_start(k - 2)] == '+'; else if (k + 2 < n_lines) name = s_text[ls_start(k + 2)] == '+'; }
             if (name) {
                 // candidate distances: the same column of the line four lines up, the same distance from the line's end there, and 6 .. 11 (the line itself)
                 uint32_t dA = 0, dB = 0;
@@ -276,14 +321,14 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
                 while (p < lim_end && n_tok < (uint32_t)GZ_MAXM) {
                     const uint32_t lim = lim_end - p < 258u ? lim_end - p : 258u;
                     uint32_t best = 0, bd = 0;
-                    if (dA && p >= dA) { if (endA <= p) endA = p + gz_match_len(src, p, dA, lim_end - p); const uint32_t l = endA - p < lim ? endA - p : lim; if (l > best) { best = l; bd = dA; } }
-                    if (dB && p >= dB) { if (endB <= p) endB = p + gz_match_len(src, p, dB, lim_end - p); const uint32_t l = endB - p < lim ? endB - p : lim; if (l > best) { best = l; bd = dB; } }
+                    if (dA && p >= dA) { if (endA <= p) endA = p + gz_match_len(s_text, p, dA, lim_end - p); const uint32_t l = endA - p < lim ? endA - p : lim; if (l > best) { best = l; bd = dA; } }
+                    if (dB && p >= dB) { if (endB <= p) endB = p + gz_match_len(s_text, p, dB, lim_end - p); const uint32_t l = endB - p < lim ? endB - p : lim; if (l > best) { best = l; bd = dB; } }
                     if (best < 8 && p >= 12 && lim >= (uint32_t)GZ_MIN_MATCH) {
-                        const uint32_t cur = gz_load4(src + p);
+                        const uint32_t cur = gz_load4(s_text + p);
 #pragma unroll
                         for (uint32_t ds = 6; ds <= 11; ++ds) {
-                            const uint32_t x = cur ^ gz_load4(src + p - ds);
-                            if ((x & 0xFFFFFFu) == 0) { const uint32_t l = gz_match_len(src, p, ds, lim); if (l > best) { best = l; bd = ds; } }
+                            const uint32_t x = cur ^ gz_load4(s_text + p - ds);
+                            if ((x & 0xFFFFFFu) == 0) { const uint32_t l = gz_match_len(s_text, p, ds, lim); if (l > best) { best = l; bd = ds; } }
                         }
                     }
                     if (best >= (uint32_t)GZ_MIN_MATCH) {
@@ -305,6 +350,10 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
             if (p >= le) ++k;
         }
     }
+
+    __syncthreads();                                              // every lane is done with the text: the array becomes image + histograms
+    for (int q = tid; q < GZ_IMG_WORDS + 8 * 288; q += GZ_THREADS) s_raw[q] = 0;
+    __syncthreads();
 
     // ---- pass 1: histograms + CRC-32 of the span (register started from 0; the chunk's init value enters with lane 0) ----
     uint32_t crc = tid == 0 ? 0xFFFFFFFFu : 0u;
@@ -340,48 +389,66 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     if (tid == 0) h1 = 1;                                         // end of block: once
     const uint32_t hd = tid < GZ_NDIST ? s_dsub[tid] : 0u;
     __syncthreads();                                              // (the sub-histograms become work arrays)
-    gz_code_lengths(h0, h1, wgt, grp, len, s_scan, s_min);
+    gz_code_lengths2(h0, h1, hd, wgt, grp, len, s_wb[0], s_wb[1], s_wb[2], s_scan, s_min, s_minB);
+    __syncthreads();
     gz_canonical(len, s_code, 256, 32, s_blc, s_next);
+    if (tid < 64) s_dsub[tid] = tid < GZ_NDIST ? s_wb[2][tid] : 0u;      // the distance code lengths: s_dsub[0 .. 30), and as a 512-entry array for gz_canonical
     const uint32_t my_len = len[tid], my_len1 = len[256 + tid];
     __syncthreads();
-    gz_code_lengths(hd, 0u, wgt, grp, len, s_scan, s_min);
-    gz_canonical(len, s_dcode, 32, 0, s_blc, s_next);
-    if (tid < 64) s_dsub[tid] = tid < GZ_NDIST ? len[tid] : 0u;   // the distance code lengths, out of the work arrays
+    len[tid] = tid < GZ_NDIST ? s_dsub[tid] : 0u; len[256 + tid] = 0;
     __syncthreads();
-    // literal / length code lengths back into len[] for the header (the work arrays were reused by the distance code)
-    len[tid] = my_len; len[256 + tid] = my_len1;
+    gz_canonical(len, s_dcode, 32, 0, s_blc, s_next);
+    len[tid] = my_len; len[256 + tid] = my_len1;                  // literal / length code lengths back into len[] for the header
     __syncthreads();
 
     // ---- block header: the code lengths, run-length coded (RFC 1951 3.2.7) under a FIXED code-length code: symbols 0 .. 12 take 4 bits (codes
     // 0 .. 12), 13 .. 18 take 5 bits (codes 26 .. 31).  One lane walks the 257 + HLIT + 1 + HDIST lengths; its tokens go straight into the image ----
-    auto cl_code = [](uint32_t sym, uint32_t &nbits) -> uint32_t { nbits = sym <= 12u ? 4u : 5u; return bit_reverse(sym <= 12u ? sym : 26u + (sym - 13u), nbits); };
-    // (the gzip header's length depends on the member's size through the pad: the code lengths are first counted, then written in pass 3)
-    auto walk_lengths = [&](LdsBits *bs) -> uint32_t {             // bits of the coded lengths; with bs: also written
-        uint32_t hlit = GZ_NLIT; while (hlit > 257u && len[hlit - 1] == 0) --hlit;
-        uint32_t hdist = GZ_NDIST; while (hdist > 1u && s_dsub[hdist - 1] == 0) --hdist;
-        const uint32_t n = hlit + hdist;
-        auto at = [&](uint32_t i) -> uint32_t { return i < hlit ? len[i] : s_dsub[i - hlit]; };
-        uint32_t bits = 0, i = 0;
-        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); bits += nb + ebits; if (bs) { bs->put(c, nb); if (ebits) bs->put(eval, ebits); } };
-        while (i < n) {
-            const uint32_t v = at(i); uint32_t j = i + 1;
-            while (j < n && at(j) == v) ++j;
-            uint32_t run = j - i;
-            if (v == 0) {
-                while (run >= 11) { const uint32_t r = run < 138u ? run : 138u; emit(18, 7, r - 11u); run -= r; }
-                if (run >= 3) { emit(17, 3, run - 3u); run = 0; }
-                while (run) { emit(0, 0, 0); --run; }
-            } else {
-                emit(v, 0, 0); --run;
-                while (run >= 3) { const uint32_t r = run < 6u ? run : 6u; emit(16, 2, r - 3u); run -= r; }
-                while (run) { emit(v, 0, 0); --run; }
+    // The lengths are mostly zero, in long runs: the waves ballot "length != 0" into six 64-bit masks, and the one lane that codes the sequence finds
+    // its way through the zero runs with count-trailing-zeros instead of visiting 316 symbols (that serial walk, twice, was a third of the kernel's
+    // time in the first version).  Its tokens (code-length code + extra bits, <= 12 bits each) wait in LDS for pass 3.
+    uint32_t *const s_clt = s_tab + 256;                          // <= 320 tokens: value | bits << 16 (the slicing tables are done with; the span CRCs use s_tab[0 .. 256))
+    {
+        const uint64_t m0 = __ballot(len[tid] != 0);
+        if (lane == 0) s_mask[wave] = m0;
+        if (wave == 0) { const uint64_t m1 = __ballot(lane < GZ_NLIT - 256 && len[256 + lane] != 0); if (lane == 0) s_mask[4] = m1; }
+        if (wave == 1) { const uint64_t m2 = __ballot(lane < GZ_NDIST && s_dsub[lane] != 0); if (lane == 0) s_mask[5] = m2; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        auto cl_code = [](uint32_t sym, uint32_t &nbits) -> uint32_t { nbits = sym <= 12u ? 4u : 5u; return bit_reverse(sym <= 12u ? sym : 26u + (sym - 13u), nbits); };
+        uint32_t bits = 0, ntok = 0;
+        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); s_clt[ntok++] = (c | (eval << nb)) | ((nb + ebits) << 16); bits += nb + ebits; };
+        auto code_seq = [&](const uint64_t *mask, int nwords, uint32_t n, const uint32_t *val) {      // one sequence of n lengths, its "!= 0" bits in mask[0 .. nwords)
+            auto bit = [&](uint32_t i) -> bool { return (mask[i >> 6] >> (i & 63u)) & 1ull; };
+            uint32_t i = 0;
+            while (i < n) {
+                if (bit(i)) {
+                    const uint32_t v = val[i]; uint32_t run = 1;
+                    while (i + run < n && bit(i + run) && val[i + run] == v) ++run;
+                    i += run;
+                    emit(v, 0, 0); --run;
+                    while (run >= 3) { const uint32_t r = run < 6u ? run : 6u; emit(16, 2, r - 3u); run -= r; }
+                    while (run) { emit(v, 0, 0); --run; }
+                } else {
+                    uint32_t nz = n;                              // the next length != 0, or the end
+                    for (uint32_t w = i >> 6; w < (uint32_t)nwords; ++w) {
+                        const uint64_t m = w == (i >> 6) ? (mask[w] >> (i & 63u)) << (i & 63u) : mask[w];
+                        if (m) { const uint32_t q = 64u * w + (uint32_t)__builtin_ctzll(m); nz = q < n ? q : n; break; }
+                    }
+                    uint32_t run = nz - i; i = nz;
+                    while (run >= 11) { const uint32_t r = run < 138u ? run : 138u; emit(18, 7, r - 11u); run -= r; }
+                    if (run >= 3) { emit(17, 3, run - 3u); run = 0; }
+                    while (run) { emit(0, 0, 0); --run; }
+                }
             }
-            i = j;
-        }
-        if (!bs) { s_hdr[1] = hlit - 257u; s_hdr[2] = hdist - 1u; }
-        return bits;
-    };
-    if (tid == 0) s_hdr[0] = walk_lengths(nullptr);
+        };
+        uint32_t hlit = 257;                                      // literal / length codes sent: up to the last used one (the end-of-block symbol is always used)
+        if (s_mask[4] >> 1) hlit = 256u + 64u - (uint32_t)__builtin_clzll(s_mask[4]);
+        uint32_t hdist = s_mask[5] ? 64u - (uint32_t)__builtin_clzll(s_mask[5]) : 1u;
+        code_seq(s_mask, 5, hlit, len);
+        code_seq(s_mask + 5, 1, hdist, s_dsub);
+        s_hdr[0] = bits; s_hdr[1] = hlit - 257u; s_hdr[2] = hdist - 1u; s_hdr[3] = ntok;
+    }
 
     // ---- pass 2: bits of this lane's span; scan; this member's size and its byte offset by look-back over the chunks ----
     uint32_t bits = 0;
@@ -481,7 +548,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
         bh.put(0, 1); bh.put(2, 2); bh.put(s_hdr[1], 5); bh.put(s_hdr[2], 5); bh.put(15, 4);
         const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         for (int q = 0; q < 19; ++q) bh.put(order[q] <= 12 ? 4u : 5u, 3);
-        (void)walk_lengths(&bh);
+        for (uint32_t q = 0; q < s_hdr[3]; ++q) { const uint32_t tk = s_clt[q]; bh.put(tk & 0xFFFFu, tk >> 16); }
         bh.finish();
         // end of block + the final empty stored block (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
         LdsBits be; be.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + tot_bits);

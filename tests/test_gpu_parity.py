@@ -377,15 +377,14 @@ def test_reads_beyond_the_lds_staging_limit(lib, oracle_bin, repeats_fa, flags):
     compare_case(lib, oracle_bin, repeats_fa, flags, batch_pairs=77, debug_options={"flow_slots": 2})
 
 
-@pytest.mark.parametrize("cap,flags", [(104, "-1 100 -2 0 -e 0.05 -y 0.1"), (60, "-1 50 -2 50 -d 300 -e 0.1 -E 0.02 -o 0"), (0, "-1 60 -2 0 -e 0.3 -f TCG" + "A" * 30)])
+@pytest.mark.parametrize("cap,flags", [(104, "-1 100 -2 0 -e 0.05 -y 0.1"), (60, "-1 50 -2 50 -d 300 -e 0.1 -E 0.02 -o 0"), (20, "-1 17 -2 0 -e 0.1 -f TCG" + "A" * 12)])
 def test_ion_torrent_read_outgrows_its_buffers(lib, oracle_bin, golden_dir, cap, flags):
     """A read that outgrows its flow-space buffers makes the batch run again with twice the room (dw_host.cpp dwgsim_hip_wait; the reference doubles its
     buffers, dwgsim.c:296-311): forced with a small starting capacity, batch by batch and through the job level with two batches in flight per
-    context; cap = 0: an option set whose reads grow far beyond the capacity estimate on their own (e = 0.3, a flow order that keeps T away for 30 flows)."""
+    context; the third case: a flow order that keeps T away for twelve flows at e = 0.1 (17-base reads that grow up to 112 bases: three doublings from 20)."""
     fl = f"-z 9 -N 2500 -c 2 {'' if ' -f ' in flags else '-f ' + FLOW} {flags}"
-    res = compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), fl, batch_pairs=700, debug_options={"flow_cap": cap} if cap else None)
-    if cap:
-        assert res.flow_cap_mult >= 2
+    res = compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), fl, batch_pairs=700, debug_options={"flow_cap": cap})
+    assert res.flow_cap_mult >= 2
 
 
 def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa):

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""tools/make_counters_json.py <workload-key> <gpurun_out/tag> [profiles/r03_counters.json] -- analysis only: fold the PMC passes of
+"""tools/make_counters_json.py <workload-key> <gpurun_out/tag> [profiles/r04_counters.json] [round tag, default r04] -- analysis only: fold the PMC passes of
 tools/profile_round.sh into the JSON that bench.py quotes (roofline.traffic, roofline.valu).  Units and corrections as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as
 64 bytes, so it is doubled; separate --pmc passes."""
 import hashlib, json, os, re, subprocess, sys
 
 key, d = sys.argv[1], sys.argv[2]
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_counters.json")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_counters.json")
+rtag = sys.argv[4] if len(sys.argv) > 4 else "r04"
 vals = {}
 for line in open(os.path.join(d, "pmc.txt")):
     m = re.match(r"^.*k_simulate.*?\s([A-Z][A-Z0-9_]+)\s+([0-9.]+)\s+n=", line)
@@ -22,7 +23,7 @@ try:
 except Exception:
     head = None
 pairs = int(pairs / max(bench["config"].get("launches_per_gpu_per_step", 1), 1))
-out = {"source": f"profiles/r03_{os.path.basename(d).replace('final_', '')}_kernel_stats_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
+out = {"source": f"profiles/{rtag}_{os.path.basename(d).replace('final_', '')}_kernel_stats_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
        "kernel": bench["roofline"]["kernel"], "pairs_per_launch": pairs, "lib_sha256": sha, "git_head": head}
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.update({"fetch_size_kib": vals["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kib": vals["WRITE_SIZE"],
