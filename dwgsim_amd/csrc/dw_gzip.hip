@@ -106,105 +106,100 @@ DW_DEV uint32_t gz_match_len(const uint8_t *src, uint32_t p, uint32_t d, uint32_
     return l < lim ? l : lim;
 }
 
-// Huffman code lengths of TWO alphabets at once, by repeated merging of the two lightest trees of each: A = up to 512 symbols (lane tid owns symbols
-// tid and 256 + tid: literals / lengths), B = up to 64 symbols owned by the lanes of wave 0 (distances).  One merge of each per iteration, behind the
-// same three barriers (the barriers, not the arithmetic, are what a merge costs: the distance code rides along).  h0 / h1 / hb = the counts of this
-// lane's symbols.  Lengths land in lenA[0 .. 512) / lenB[0 .. 64); counts are flattened ((h >> scale) | 1) until no code is longer than 15 bits.  An
-// alphabet with a single used symbol gives it length 1 (RFC 1951: one distance code is sent with one bit), none leaves all lengths 0.
-DW_DEV void gz_code_lengths2(uint32_t h0, uint32_t h1, uint32_t hb, uint32_t *wgtA, uint32_t *grpA, uint32_t *lenA, uint32_t *wgtB, uint32_t *grpB, uint32_t *lenB,
-                             uint32_t *s_scan, uint32_t (*s_min)[4][2], uint32_t (*s_minB)[2])
+// Huffman code lengths of TWO alphabets at once: A = up to 512 symbols (lane tid owns symbols tid and 256 + tid: literals / lengths), B = up to 64
+// symbols owned by the lanes of wave 0 (distances).  h0 / h1 / hb = the counts of this lane's symbols.
+// Round 3 merged the two lightest trees once per iteration with a block-wide reduction: three barriers per merge, ~ 60 merges -- half the kernel's
+// time.  Now: the used symbols are gathered and RANK-SORTED by weight in parallel (a used symbol counts the keys below its own), ONE lane per
+// alphabet runs the classic two-queue merge over the sorted leaves (no barrier, one LDS round trip per merge; lane 0 for A and lane 64 for B at
+// the same time), and every leaf then finds its depth by walking its parents -- in parallel again.  Counts are flattened ((h >> scale) | 1) until no
+// code is longer than 15 bits (Fibonacci-like counts only).  An alphabet with a single used symbol gives it length 1 (RFC 1951: one distance code is
+// sent with one bit), none leaves all lengths 0.  Work arrays (LDS): A: key[288] sorted[288] nodew[288] parent[576]; B: key[32] sorted[32] nodew[32] parent[64].
+struct GzTreeMem { uint32_t *keyA, *sortA, *nodeA, *parA, *lenA, *keyB, *sortB, *nodeB, *parB, *lenB; };
+DW_DEV void gz_two_queue(const uint32_t *sorted, uint32_t n, uint32_t *nodew, uint32_t *parent)      // leaves 0 .. n-1 (ascending keys: weight << 9 | symbol), internal node k = n + k
+{
+    uint32_t li = 0, ni = 0, nn = 0;
+    uint32_t lw = sorted[0] >> 9;                                 // weight at the head of the leaf queue
+    uint32_t nw = 0xFFFFFFFFu;                                    // ... of the node queue (empty)
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int pick = 0; pick < 2; ++pick) {                    // a leaf wins a tie: shallower trees
+            if (li < n && lw <= nw) { sum += lw; parent[li] = n + nn; ++li; lw = li < n ? sorted[li] >> 9 : 0xFFFFFFFFu; }
+            else { sum += nw; parent[n + ni] = n + nn; ++ni; nw = ni < nn ? nodew[ni] : 0xFFFFFFFFu; }
+        }
+        nodew[nn] = sum;
+        if (ni == nn) nw = sum;                                   // the node queue was empty: the new node is its head
+        ++nn;
+    }
+}
+DW_DEV void gz_code_lengths2(uint32_t h0, uint32_t h1, uint32_t hb, const GzTreeMem &m, uint32_t *s_scan, uint32_t (*s_min)[4][2])
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t scaleA = 0, scaleB = 0; bool doneA = false, doneB = false;
     for (;;) {
         const uint32_t w0 = h0 ? (scaleA ? ((h0 >> scaleA) | 1u) : h0) : 0u, w1 = h1 ? (scaleA ? ((h1 >> scaleA) | 1u) : h1) : 0u;
         const uint32_t wb = (tid < 64 && hb) ? (scaleB ? ((hb >> scaleB) | 1u) : hb) : 0u;
-        if (!doneA) { wgtA[tid] = w0; grpA[tid] = (uint32_t)tid; lenA[tid] = 0; wgtA[256 + tid] = w1; grpA[256 + tid] = 256u + (uint32_t)tid; lenA[256 + tid] = 0; }
-        if (!doneB && tid < 64) { wgtB[tid] = wb; grpB[tid] = (uint32_t)tid; lenB[tid] = 0; }
+        // the used symbols of each alphabet, gathered (order does not matter: they are sorted next)
         uint32_t nA, nB;
-        { uint32_t tot; (void)block_excl_scan((w0 ? 1u : 0u) + (w1 ? 1u : 0u) + (wb ? 0x10000u : 0u), s_scan, &tot); nA = tot & 0xFFFFu; nB = tot >> 16; }      // (its barriers publish the arrays)
-        if (!doneA && nA <= 1) { if (w0) lenA[tid] = 1; if (w1) lenA[256 + tid] = 1; doneA = true; }
-        if (!doneB && nB <= 1) { if (wb) lenB[tid] = 1; doneB = true; }
-        for (uint32_t merge = 0; (!doneA && nA > 1) || (!doneB && nB > 1); ++merge) {
-            const bool actA = !doneA && nA > 1, actB = !doneB && nB > 1;
-            // keys (weight << 9 | tree id), dead trees = all ones; (a, b) = the two smallest of this lane, then of the wave, then of the block
-            if (actA) {
-                uint32_t ka = wgtA[tid] ? ((wgtA[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
-                if (wgtA[256 + tid]) { const uint32_t k2 = (wgtA[256 + tid] << 9) | (256u + (uint32_t)tid); if (k2 < ka) { kb = ka; ka = k2; } else kb = k2; }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
-                    const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
-                    ka = lo; kb = hi < ob2 ? hi : ob2;
-                }
-                if (lane == 0) { s_min[merge & 1][wave][0] = ka; s_min[merge & 1][wave][1] = kb; }
-            }
-            if (actB && wave == 0) {
-                uint32_t ka = wgtB[tid] ? ((wgtB[tid] << 9) | (uint32_t)tid) : 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const uint32_t oa = (uint32_t)__shfl_xor((int)ka, off), ob = (uint32_t)__shfl_xor((int)kb, off);
-                    const uint32_t lo = ka < oa ? ka : oa, hi = ka < oa ? oa : ka, ob2 = kb < ob ? kb : ob;
-                    ka = lo; kb = hi < ob2 ? hi : ob2;
-                }
-                if (lane == 0) { s_minB[merge & 1][0] = ka; s_minB[merge & 1][1] = kb; }
-            }
-            __syncthreads();
-            uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, t1 = 0, t2 = 0, b1 = 0, b2 = 0, u1 = 0, u2 = 0;
-            if (actA) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t oa = s_min[merge & 1][w][0], ob = s_min[merge & 1][w][1];
-                    const uint32_t lo = m1 < oa ? m1 : oa, hi = m1 < oa ? oa : m1, ob2 = m2 < ob ? m2 : ob;
-                    m1 = lo; m2 = hi < ob2 ? hi : ob2;
-                }
-                t1 = m1 & 511u; t2 = m2 & 511u;                  // tree t2 joins tree t1: every leaf of both goes one level down
-                if (w0 && (grpA[tid] == t1 || grpA[tid] == t2)) { ++lenA[tid]; grpA[tid] = t1; }
-                if (w1 && (grpA[256 + tid] == t1 || grpA[256 + tid] == t2)) { ++lenA[256 + tid]; grpA[256 + tid] = t1; }
-            }
-            if (actB) {
-                b1 = s_minB[merge & 1][0]; b2 = s_minB[merge & 1][1]; u1 = b1 & 511u; u2 = b2 & 511u;
-                if (wb && (grpB[tid] == u1 || grpB[tid] == u2)) { ++lenB[tid]; grpB[tid] = u1; }
-            }
-            __syncthreads();                                      // all leaves have read the trees' ids before the weights change
-            if (actA) { if ((uint32_t)tid == (t1 & 255u)) wgtA[t1] = (m1 >> 9) + (m2 >> 9); if ((uint32_t)tid == (t2 & 255u)) wgtA[t2] = 0; --nA; }
-            if (actB) { if ((uint32_t)tid == u1) wgtB[u1] = (b1 >> 9) + (b2 >> 9); if ((uint32_t)tid == u2) wgtB[u2] = 0; --nB; }
-            __syncthreads();
+        {
+            uint32_t tot; const uint32_t mine = (w0 ? 1u : 0u) + (w1 ? 1u : 0u) + (wb ? 0x10000u : 0u);
+            const uint32_t ex = block_excl_scan(mine, s_scan, &tot);
+            nA = tot & 0xFFFFu; nB = tot >> 16;
+            if (!doneA) { uint32_t q = ex & 0xFFFFu; if (w0) m.keyA[q++] = (w0 << 9) | (uint32_t)tid; if (w1) m.keyA[q] = (w1 << 9) | (256u + (uint32_t)tid); m.lenA[tid] = 0; m.lenA[256 + tid] = 0; }
+            if (!doneB && tid < 64) { if (wb) m.keyB[ex >> 16] = (wb << 9) | (uint32_t)tid; m.lenB[tid] = 0; }
         }
-        // the longest code of each alphabet
-        uint32_t mx = 0;
-        if (!doneA) mx = lenA[tid] > lenA[256 + tid] ? lenA[tid] : lenA[256 + tid];
-        if (!doneB && tid < 64) mx |= lenB[tid] << 8;
-        uint32_t ma = mx & 255u, mb = mx >> 8;
+        __syncthreads();
+        // rank sort: keys are distinct (the symbol is part of them)
+        if (!doneA) for (uint32_t i = (uint32_t)tid; i < nA; i += GZ_THREADS) { const uint32_t key = m.keyA[i]; uint32_t r = 0; for (uint32_t q = 0; q < nA; ++q) r += m.keyA[q] < key ? 1u : 0u; m.sortA[r] = key; }
+        if (!doneB && wave == 1 && (uint32_t)lane < nB) { const uint32_t key = m.keyB[lane]; uint32_t r = 0; for (uint32_t q = 0; q < nB; ++q) r += m.keyB[q] < key ? 1u : 0u; m.sortB[r] = key; }
+        __syncthreads();
+        if (!doneA && tid == 0 && nA > 1) gz_two_queue(m.sortA, nA, m.nodeA, m.parA);
+        if (!doneB && tid == 64 && nB > 1) gz_two_queue(m.sortB, nB, m.nodeB, m.parB);
+        __syncthreads();
+        // depths: leaf i of the sorted order walks up to the root (node 2n - 2)
+        uint32_t mxa = 0, mxb = 0;
+        if (!doneA) {
+            if (nA == 1) { if (tid == 0) m.lenA[m.sortA[0] & 511u] = 1; }
+            else for (uint32_t i = (uint32_t)tid; i < nA; i += GZ_THREADS) { uint32_t d = 1, p = m.parA[i]; while (p != 2 * nA - 2) { p = m.parA[p]; ++d; } m.lenA[m.sortA[i] & 511u] = d; mxa = d > mxa ? d : mxa; }
+        }
+        if (!doneB && wave == 1) {
+            if (nB == 1) { if (lane == 0) m.lenB[m.sortB[0] & 511u] = 1; }
+            else if ((uint32_t)lane < nB) { uint32_t d = 1, p = m.parB[lane]; while (p != 2 * nB - 2) { p = m.parB[p]; ++d; } m.lenB[m.sortB[lane] & 511u] = d; mxb = d; }
+        }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { const uint32_t oa = (uint32_t)__shfl_xor((int)ma, off), ob = (uint32_t)__shfl_xor((int)mb, off); ma = oa > ma ? oa : ma; mb = ob > mb ? ob : mb; }
+        for (int off = 32; off >= 1; off >>= 1) { const uint32_t oa = (uint32_t)__shfl_xor((int)mxa, off), ob = (uint32_t)__shfl_xor((int)mxb, off); mxa = oa > mxa ? oa : mxa; mxb = ob > mxb ? ob : mxb; }
+        if (lane == 0) { s_min[0][wave][0] = mxa; s_min[0][wave][1] = mxb; }
         __syncthreads();
-        if (lane == 0) { s_min[0][wave][0] = ma; s_min[0][wave][1] = mb; }
+        mxa = s_min[0][0][0]; mxb = s_min[0][0][1];
+        for (int w = 1; w < 4; ++w) { mxa = s_min[0][w][0] > mxa ? s_min[0][w][0] : mxa; mxb = s_min[0][w][1] > mxb ? s_min[0][w][1] : mxb; }
         __syncthreads();
-        ma = s_min[0][0][0]; mb = s_min[0][0][1];
-        for (int w = 1; w < 4; ++w) { ma = s_min[0][w][0] > ma ? s_min[0][w][0] : ma; mb = s_min[0][w][1] > mb ? s_min[0][w][1] : mb; }
-        __syncthreads();
-        if (!doneA) { if (ma <= 15) doneA = true; else ++scaleA; }      // else flatten the histogram and build again (equal weights give depth <= 9)
-        if (!doneB) { if (mb <= 15) doneB = true; else ++scaleB; }
+        if (!doneA) { if (mxa <= 15) doneA = true; else ++scaleA; }      // else flatten the histogram and build again (equal weights give depth <= 9)
+        if (!doneB) { if (mxb <= 15) doneB = true; else ++scaleB; }
         if (doneA && doneB) return;
     }
 }
-// canonical codes (RFC 1951 3.2.2) of the lengths in len[0 .. 512), stored bit-reversed for LSB-first packing: code[s] = reversed code | length << 16
-// (n_lo / n_hi: how many codes of symbols tid / 256 + tid are kept)
-DW_DEV void gz_canonical(const uint32_t *len, uint32_t *code, int n_lo, int n_hi, uint32_t *s_blc, uint32_t *s_next)
+// canonical codes (RFC 1951 3.2.2) of the lengths in len[0 .. 512) (lane tid: symbols tid and 256 + tid), stored bit-reversed for LSB-first packing:
+// code[s] = reversed code | length << 16.  A symbol's rank among the symbols of its length: ballots per length inside its group of 64, the groups
+// before it through a small table (round 3 counted them in a loop over all smaller symbols: 256 LDS reads per lane).  n_lo / n_hi: codes kept.
+DW_DEV void gz_canonical(const uint32_t *len, uint32_t *code, int n_lo, int n_hi, uint32_t *s_blc, uint32_t *s_next, uint32_t (*s_cnt)[8])
 {
-    const int tid = (int)threadIdx.x;
-    if (tid < 16) s_blc[tid] = 0;
-    __syncthreads();
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t l0 = len[tid], l1 = len[256 + tid];
-    if (l0) atomicAdd(&s_blc[l0], 1u);
-    if (l1) atomicAdd(&s_blc[l1], 1u);
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;  // the lanes in front of this one
+    uint32_t r0 = 0, r1 = 0;
+    for (uint32_t L = 1; L <= 15; ++L) {                          // group g = wave: symbols 64 g .. 64 g + 63; group 4 + wave: symbols 256 + 64 wave ..
+        const uint64_t b0 = __ballot(l0 == L), b1 = __ballot(l1 == L);
+        if (l0 == L) r0 = (uint32_t)__popcll(b0 & below);
+        if (l1 == L) r1 = (uint32_t)__popcll(b1 & below);
+        if (lane == 0) { s_cnt[L][wave] = (uint32_t)__popcll(b0); s_cnt[L][4 + wave] = (uint32_t)__popcll(b1); }
+    }
+    __syncthreads();
+    if (tid < 16) { uint32_t c = 0; if (tid) for (int g = 0; g < 8; ++g) c += s_cnt[tid][g]; s_blc[tid] = c; }
     __syncthreads();
     if (tid == 0) { uint32_t c = 0; s_next[0] = 0; for (int bits = 1; bits <= 15; ++bits) { c = (c + (bits > 1 ? s_blc[bits - 1] : 0u)) << 1; s_next[bits] = c; } }
     __syncthreads();
-    uint32_t r0 = 0, r1 = 0;                                      // symbols below mine with my length
-    if (l0) for (int j = 0; j < tid; ++j) r0 += len[j] == l0 ? 1u : 0u;
-    if (l1) for (int j = 0; j < 256 + tid; ++j) r1 += len[j] == l1 ? 1u : 0u;
+    if (l0) for (int g = 0; g < wave; ++g) r0 += s_cnt[l0][g];
+    if (l1) for (int g = 0; g < 4 + wave; ++g) r1 += s_cnt[l1][g];
     if (tid < n_lo) code[tid] = l0 ? (bit_reverse(s_next[l0] + r0, l0) | (l0 << 16)) : 0u;
     if (tid < n_hi) code[256 + tid] = l1 ? (bit_reverse(s_next[l1] + r1, l1) | (l1 << 16)) : 0u;
     __syncthreads();
@@ -228,8 +223,8 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     __shared__ uint16_t s_ls[GZ_LINES + 2];   // line starts of the chunk
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_min[2][4][2];       // the two lightest trees of every wave (double-buffered by merge parity)
-    __shared__ uint32_t s_minB[2][2];         // ... of the distance alphabet
-    __shared__ uint32_t s_wb[3][64];          // work arrays of the distance code: weights, tree ids, lengths
+    __shared__ uint32_t s_wb[4][64];          // work arrays of the distance code: keys + sorted keys, node weights, parents, lengths
+    __shared__ uint32_t s_cnt[16][8];         // canonical codes: symbols per code length and group of 64
     __shared__ uint32_t s_blc[16], s_next[16];
     __shared__ uint32_t s_hdr[4];             // bits of the run-length coded code lengths, HLIT, HDIST, their tokens
     __shared__ uint64_t s_mask[6];            // "code length != 0" of literals / lengths (286 bits) and distances (30 bits)
@@ -364,10 +359,13 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
             const uint32_t w = d[k], base = 4u * (uint32_t)k;
             const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
             if (base + 4 <= slen) {
+                if (cv == 0) { atomicAdd(&hist[w & 255u], 1u); atomicAdd(&hist[(w >> 8) & 255u], 1u); atomicAdd(&hist[(w >> 16) & 255u], 1u); atomicAdd(&hist[w >> 24], 1u); }      // (the usual word: no match in it)
+                else {
                 if (!(cv & 1u)) atomicAdd(&hist[w & 255u], 1u);
                 if (!(cv & 2u)) atomicAdd(&hist[(w >> 8) & 255u], 1u);
                 if (!(cv & 4u)) atomicAdd(&hist[(w >> 16) & 255u], 1u);
                 if (!(cv & 8u)) atomicAdd(&hist[w >> 24], 1u);
+                }
                 const uint32_t x = crc ^ w;
                 crc = s_tab[768 + (x & 255u)] ^ s_tab[512 + ((x >> 8) & 255u)] ^ s_tab[256 + ((x >> 16) & 255u)] ^ s_tab[x >> 24];
             } else if (base < slen) {
@@ -383,21 +381,24 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     __syncthreads();
 
     // ---- Huffman code lengths: lane k owns symbols k and 256 + k (256 = end of block, 257 .. 285 = lengths) ----
-    uint32_t *wgt = s_sub[0], *grp = s_sub[2], *len = s_sub[4];   // 512 words each (two rows of 288: the second row's first 224 words)
+    // work arrays of the code construction, where the sub-histograms were: A (literals / lengths) key 288 | sorted 288 | node weights 288 | parents 576 | lengths 512
+    uint32_t *const wk = &s_sub[0][0];
+    const GzTreeMem tm{wk, wk + 288, wk + 576, wk + 864, wk + 1440, s_wb[0], s_wb[0] + 32, s_wb[1], s_wb[2], s_wb[3]};
+    uint32_t *const len = wk + 1440;
     uint32_t h0 = 0, h1 = 0;
     for (int q = 0; q < 8; ++q) { h0 += s_sub[q][tid]; if (tid < GZ_NLIT - 256) h1 += s_sub[q][256 + tid]; }
     if (tid == 0) h1 = 1;                                         // end of block: once
     const uint32_t hd = tid < GZ_NDIST ? s_dsub[tid] : 0u;
     __syncthreads();                                              // (the sub-histograms become work arrays)
-    gz_code_lengths2(h0, h1, hd, wgt, grp, len, s_wb[0], s_wb[1], s_wb[2], s_scan, s_min, s_minB);
+    gz_code_lengths2(h0, h1, hd, tm, s_scan, s_min);
     __syncthreads();
-    gz_canonical(len, s_code, 256, 32, s_blc, s_next);
-    if (tid < 64) s_dsub[tid] = tid < GZ_NDIST ? s_wb[2][tid] : 0u;      // the distance code lengths: s_dsub[0 .. 30), and as a 512-entry array for gz_canonical
+    gz_canonical(len, s_code, 256, 32, s_blc, s_next, s_cnt);
+    if (tid < 64) s_dsub[tid] = tid < GZ_NDIST ? s_wb[3][tid] : 0u;      // the distance code lengths: s_dsub[0 .. 30), and as a 512-entry array for gz_canonical
     const uint32_t my_len = len[tid], my_len1 = len[256 + tid];
     __syncthreads();
     len[tid] = tid < GZ_NDIST ? s_dsub[tid] : 0u; len[256 + tid] = 0;
     __syncthreads();
-    gz_canonical(len, s_dcode, 32, 0, s_blc, s_next);
+    gz_canonical(len, s_dcode, 32, 0, s_blc, s_next, s_cnt);
     len[tid] = my_len; len[256 + tid] = my_len1;                  // literal / length code lengths back into len[] for the header
     __syncthreads();
 
@@ -456,8 +457,11 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     for (int k = 0; k < GZ_SPAN / 4; ++k) {
         const uint32_t w = d[k], base = 4u * (uint32_t)k;
         const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
+        if (base + 4 <= slen && cv == 0) bits += (s_code[w & 255u] >> 16) + (s_code[(w >> 8) & 255u] >> 16) + (s_code[(w >> 16) & 255u] >> 16) + (s_code[w >> 24] >> 16);
+        else {
 #pragma unroll
         for (uint32_t b = 0; b < 4; ++b) if (base + b < slen && !((cv >> b) & 1u)) bits += s_code[(w >> (8 * b)) & 255u] >> 16;
+        }
     }
     for (uint32_t q = 0; q < n_tok; ++q) {
         const uint32_t tk = s_tok[q][tid], ls = gz_len_sym((tk >> 8) & 511u), ds = gz_dist_sym(tk >> 17);
@@ -526,6 +530,11 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
         for (int k = 0; k < GZ_SPAN / 4; ++k) {
             const uint32_t w = d[k], base = 4u * (uint32_t)k;
             const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u, ms = (mst[k >> 3] >> (4 * (k & 7))) & 15u;
+            if (base + 4 <= slen && (cv | ms) == 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const uint32_t c = s_code[(w >> (8 * b)) & 255u]; bs.put(c & 0xFFFFu, c >> 16); }
+                continue;
+            }
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b) {
                 if (base + b >= slen) continue;
