@@ -205,7 +205,7 @@ DW_DEV void gz_canonical(const uint32_t *len, uint32_t *code, int n_lo, int n_hi
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
+__global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
 {
     // one raw array: during the parse it holds the TEXT of the chunk (name lines are compared with the lines above them at LDS latency: from HBM,
     // where the text has just been written by k_simulate, every dependent compare cost a microsecond and the kernel ran at 75 instead of 260 GB/s);
@@ -261,6 +261,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     // the chunk's text into LDS: word i * 256 + tid by lane tid (coalesced from the L2, where the loads above have just brought it; conflict-free in LDS)
     {
         const uint32_t nw = (clen + 3u) >> 2;
+        if (!probe::off(1 << 26))      // (analysis builds: 2^26 = the text is not brought to LDS: only with 2^25)
         for (uint32_t q = (uint32_t)tid; q < (uint32_t)(GZ_CHUNK / 4 + 4); q += GZ_THREADS) s_raw[q] = q < nw ? reinterpret_cast<const uint32_t *>(src)[q] : 0u;      // (the buffer is padded: whole words)
     }
     // ---- lines: newline masks of the span (bit i of nl[i >> 5] = byte i is '\n'), the chunk's line starts ----
@@ -293,56 +294,89 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     auto ls_start = [&](uint32_t k) -> uint32_t { return s_ls[k]; };
     auto ls_end = [&](uint32_t k) -> uint32_t { return k + 1 < n_lines_all && k + 1 <= (uint32_t)GZ_LINES ? (uint32_t)s_ls[k + 1] : clen; };
 
+    if (probe::off(1 << 20)) return;      // (analysis builds, tools/r04_gz_knock.sh: the kernel up to here -- load, text to LDS, line starts)
     // ---- parse: name lines inside the span ----
     // A line is taken for a name line when it starts with '@' and the line two above (or, at the top of the chunk, two below) starts with '+':
     // a wrong guess costs compares, never correctness -- every match is verified byte by byte.
+    // The lanes of a wave parse IN STEP (a first version let every lane walk its own lines and positions, nested loops of different lengths: the wave
+    // paid the sum, 160 of the kernel's 250 us per block): (1) every lane finds the pieces of name lines inside its span -- at most two, a few lines to
+    // look at; (2) for a piece of up to 64 bytes, the bytes that equal the byte `d` back are gathered as a 64-bit mask per candidate distance
+    // (eight candidates, sixteen dword compares each, the same code for every lane); (3) a greedy walk over the masks: the longest run of set bits at
+    // the current position over the eight masks is a match if it has three bytes -- count-trailing-zeros, no memory.
     uint32_t cov[4] = {0, 0, 0, 0};                               // bytes of the span covered by matches
     uint32_t mst[4] = {0, 0, 0, 0};                               // ... and where the matches start
     uint32_t n_tok = 0;
-    if (slen) {
-        uint32_t k = nlines_before;                               // the line that holds the span's first byte
-        uint32_t p = s0;
-        const uint32_t span_end = s0 + slen;
-        while (p < span_end && k < n_lines && n_tok < (uint32_t)GZ_MAXM) {
-            const uint32_t le = ls_end(k), lim_end = le < span_end ? le : span_end;
-            const uint32_t st = ls_start(k);
-            bool name = s_text[st] == '@';
-            if (name) { if (k >= 2) name = s_text[ls_start(k - 2)] == '+'; else if (k + 2 < n_lines) name = s_text[ls_start(k + 2)] == '+'; }
-            if (name) {
-                // candidate distances: the same column of the line four lines up, the same distance from the line's end there, and 6 .. 11 (the line itself)
-                uint32_t dA = 0, dB = 0;
-                if (k >= 4) { dA = st - ls_start(k - 4); dB = le - ls_end(k - 4); if (dB == dA) dB = 0; }
-                uint32_t endA = p, endB = p;                      // the equal run of alignment A / B that has been measured reaches up to here
-                while (p < lim_end && n_tok < (uint32_t)GZ_MAXM) {
-                    const uint32_t lim = lim_end - p < 258u ? lim_end - p : 258u;
-                    uint32_t best = 0, bd = 0;
-                    if (dA && p >= dA) { if (endA <= p) endA = p + gz_match_len(s_text, p, dA, lim_end - p); const uint32_t l = endA - p < lim ? endA - p : lim; if (l > best) { best = l; bd = dA; } }
-                    if (dB && p >= dB) { if (endB <= p) endB = p + gz_match_len(s_text, p, dB, lim_end - p); const uint32_t l = endB - p < lim ? endB - p : lim; if (l > best) { best = l; bd = dB; } }
-                    if (best < 8 && p >= 12 && lim >= (uint32_t)GZ_MIN_MATCH) {
-                        const uint32_t cur = gz_load4(s_text + p);
+    if (!probe::off(1 << 25)) {                                   // (analysis builds: 2^25 = no parse, every byte a literal)
+        // (1) the name-line pieces of this span: start (in the chunk), length (<= 64), distance A and B (0 = none)
+        uint32_t pa[2] = {0, 0}, pn[2] = {0, 0}, pdA[2] = {0, 0}, pdB[2] = {0, 0};
+        {
+            const uint32_t span_end = s0 + slen;
+            uint32_t k = nlines_before, found = 0;
+            for (int it = 0; it < 6; ++it) {                     // (a span of more than six lines holds no FASTQ names worth the search)
+                const bool live = slen && k < n_lines && found < 2u && ls_start(k < n_lines ? k : 0u) < span_end;
+                if (!__ballot(live)) break;
+                if (live) {
+                    const uint32_t st = ls_start(k), le = ls_end(k);
+                    bool name = s_text[st] == '@';
+                    if (name) { if (k >= 2) name = s_text[ls_start(k - 2)] == '+'; else if (k + 2 < n_lines) name = s_text[ls_start(k + 2)] == '+'; }
+                    if (name) {
+                        const uint32_t a0 = st > s0 ? st : s0, b0 = le < span_end ? le : span_end;
+                        uint32_t dA = 0, dB = 0;
+                        if (k >= 4) { dA = st - ls_start(k - 4); dB = le - ls_end(k - 4); if (dB == dA) dB = 0; }
+                        if (b0 > a0) { const uint32_t nn = b0 - a0 < 64u ? b0 - a0 : 64u; if (found == 0) { pa[0] = a0; pn[0] = nn; pdA[0] = dA; pdB[0] = dB; } else { pa[1] = a0; pn[1] = nn; pdA[1] = dA; pdB[1] = dB; } ++found; }
+                    }
+                    ++k;
+                }
+            }
+        }
 #pragma unroll
-                        for (uint32_t ds = 6; ds <= 11; ++ds) {
-                            const uint32_t x = cur ^ gz_load4(s_text + p - ds);
-                            if ((x & 0xFFFFFFu) == 0) { const uint32_t l = gz_match_len(s_text, p, ds, lim); if (l > best) { best = l; bd = ds; } }
-                        }
+        for (int seg = 0; seg < 2; ++seg) {
+            const uint32_t a0 = pa[seg], nn = pn[seg];
+            if (!__ballot(nn != 0)) continue;                     // (2 x 150 bp records: a span never holds two name lines)
+            // (2) equality masks: bit i of E[c] = byte a0 + i equals byte a0 + i - d_c (and that byte lies inside the chunk)
+            const uint32_t dc[8] = {pdA[seg], pdB[seg], 6u, 7u, 8u, 9u, 10u, 11u};
+            uint64_t E[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+            for (int jw = 0; jw < 16; ++jw) {
+                const uint32_t pos = a0 + 4u * (uint32_t)jw;
+                const uint32_t cur = gz_load4(s_text + pos);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t d = dc[c];
+                    uint32_t m = 0;
+                    if (d && pos >= d && 4u * (uint32_t)jw < nn) {
+                        const uint32_t x = cur ^ gz_load4(s_text + pos - d), z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);      // 0x80 in every zero byte of x
+                        m = ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+                    }
+                    E[c] |= (uint64_t)m << (4 * jw);
+                }
+            }
+            // (3) greedy walk
+            uint32_t p = 0;
+            while (__ballot(p < nn && n_tok < (uint32_t)GZ_MAXM)) {
+                if (p < nn && n_tok < (uint32_t)GZ_MAXM) {
+                    uint32_t best = 0, bd = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const uint64_t m = ~(E[c] >> p);                                     // (zeros shifted in from above end every run)
+                        uint32_t r = (uint32_t)__builtin_ctzll(m | (1ull << 63));
+                        if (r > nn - p) r = nn - p;
+                        if (r > best) { best = r; bd = dc[c]; }
                     }
                     if (best >= (uint32_t)GZ_MIN_MATCH) {
-                        const uint32_t o = p - s0;
+                        const uint32_t o = a0 + p - s0;
                         s_tok[n_tok][tid] = o | (best << 8) | (bd << 17);
                         ++n_tok;
-                        // bits o .. o + best - 1 of cov, bit o of mst
                         mst[o >> 5] |= 1u << (o & 31u);           // (dynamic word index: four registers, resolved by selects)
-                        for (uint32_t b = o; b < o + best;) {
+                        for (uint32_t b = o; b < o + best;) {     // bits o .. o + best - 1 of cov
                             const uint32_t w = b >> 5, lo = b & 31u, n = (32u - lo < o + best - b) ? 32u - lo : o + best - b;
-                            const uint32_t m = (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << lo;
-                            cov[w] |= m; b += n;
+                            const uint32_t mm = (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << lo;
+                            cov[w] |= mm; b += n;
                         }
                         p += best;
                     } else ++p;
                 }
             }
-            p = le > p ? (name ? p : le) : p;                      // a line that is not a name line is skipped whole
-            if (p >= le) ++k;
         }
     }
 
@@ -350,6 +384,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     for (int q = tid; q < GZ_IMG_WORDS + 8 * 288; q += GZ_THREADS) s_raw[q] = 0;
     __syncthreads();
 
+    if (probe::off(1 << 21)) return;      // ... + parse
     // ---- pass 1: histograms + CRC-32 of the span (register started from 0; the chunk's init value enters with lane 0) ----
     uint32_t crc = tid == 0 ? 0xFFFFFFFFu : 0u;
     {
@@ -380,6 +415,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     }
     __syncthreads();
 
+    if (probe::off(1 << 22)) return;      // ... + histograms and CRC
     // ---- Huffman code lengths: lane k owns symbols k and 256 + k (256 = end of block, 257 .. 285 = lengths) ----
     // work arrays of the code construction, where the sub-histograms were: A (literals / lengths) key 288 | sorted 288 | node weights 288 | parents 576 | lengths 512
     uint32_t *const wk = &s_sub[0][0];
@@ -402,6 +438,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     len[tid] = my_len; len[256 + tid] = my_len1;                  // literal / length code lengths back into len[] for the header
     __syncthreads();
 
+    if (probe::off(1 << 23)) return;      // ... + the two codes
     // ---- block header: the code lengths, run-length coded (RFC 1951 3.2.7) under a FIXED code-length code: symbols 0 .. 12 take 4 bits (codes
     // 0 .. 12), 13 .. 18 take 5 bits (codes 26 .. 31).  One lane walks the 257 + HLIT + 1 + HDIST lengths; its tokens go straight into the image ----
     // The lengths are mostly zero, in long runs: the waves ballot "length != 0" into six 64-bit masks, and the one lane that codes the sequence finds
@@ -481,6 +518,7 @@ __global__ void __launch_bounds__(GZ_THREADS) k_gzip(GzArgs a)
     __syncthreads();
     if (s_base + member_bytes > a.cap) { if (tid == 0) atomicOr((unsigned long long *)a.flags, 8ull); return; }      // (cannot happen: gz_capacity covers stored members)
 
+    if (probe::off(1 << 24)) return;      // ... + header tokens, bit counts, look-back
     // CRC-32 of the chunk: the spans' registers joined by a tree; the right half of a node is shifted in by its true length (the last chunk of
     // a stream is short), so one rule serves every node: left' = left * x^(8 * bytes of the right half) + right
     s_tab[tid] = crc;                                             // (the slicing tables are no longer needed: the barrier above)
