@@ -219,8 +219,8 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
     __shared__ uint32_t s_code[288];          // bit-reversed canonical code | length << 16 of literals / lengths
     __shared__ uint32_t s_dcode[32];          // ... of distances
     __shared__ uint32_t s_tab[1024];          // CRC slicing tables, later the span CRCs ([0..255])
-    __shared__ uint32_t s_tok[GZ_MAXM][GZ_THREADS];      // matches of a span: start in the span | length << 8 | distance << 17
-    __shared__ uint16_t s_ls[GZ_LINES + 2];   // line starts of the chunk
+    __shared__ uint32_t s_tok[GZ_MAXM][GZ_THREADS];      // matches of a span: start in the span | length << 7 | distance << 14
+    __shared__ uint16_t s_tokp[GZ_MAXM][GZ_THREADS];     // ... their bits (pass 2 -> pass 3a), then where they start in the lane's bit stream (pass 3a -> 3b)
     __shared__ uint32_t s_scan[17];
     __shared__ uint32_t s_min[2][4][2];       // the two lightest trees of every wave (double-buffered by merge parity)
     __shared__ uint32_t s_wb[4][64];          // work arrays of the distance code: keys + sorted keys, node weights, parents, lengths
@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
     __shared__ uint32_t s_ticket; __shared__ uint64_t s_base;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)a.ticket, 1ull);
-    for (int q = tid; q < 1024; q += GZ_THREADS) s_tab[q] = a.crc_slice[q];
+    uint16_t *const s_ls = reinterpret_cast<uint16_t *>(s_tab);  // line starts of the chunk: until the parse is over (then the CRC tables are loaded there)
+    static_assert((GZ_LINES + 2) * 2 <= 1024 * 4, "the line starts fit where the CRC tables will be");
     if (tid < 64) s_dsub[tid] = 0;
     __syncthreads();
     const uint32_t t = s_ticket;                                  // logical chunk: its predecessors have started
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
                     }
                     if (best >= (uint32_t)GZ_MIN_MATCH) {
                         const uint32_t o = a0 + p - s0;
-                        s_tok[n_tok][tid] = o | (best << 8) | (bd << 17);
+                        s_tok[n_tok][tid] = o | (best << 7) | (bd << 14);      // start in the span (7 bits) | length 3 .. 64 (7 bits) | distance
                         ++n_tok;
                         mst[o >> 5] |= 1u << (o & 31u);           // (dynamic word index: four registers, resolved by selects)
                         for (uint32_t b = o; b < o + best;) {     // bits o .. o + best - 1 of cov
@@ -382,6 +383,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
 
     __syncthreads();                                              // every lane is done with the text: the array becomes image + histograms
     for (int q = tid; q < GZ_IMG_WORDS + 8 * 288; q += GZ_THREADS) s_raw[q] = 0;
+    for (int q = tid; q < 1024; q += GZ_THREADS) s_tab[q] = a.crc_slice[q];      // (the line starts are done with)
     __syncthreads();
 
     if (probe::off(1 << 21)) return;      // ... + parse
@@ -394,23 +396,24 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
             const uint32_t w = d[k], base = 4u * (uint32_t)k;
             const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
             if (base + 4 <= slen) {
-                if (cv == 0) { atomicAdd(&hist[w & 255u], 1u); atomicAdd(&hist[(w >> 8) & 255u], 1u); atomicAdd(&hist[(w >> 16) & 255u], 1u); atomicAdd(&hist[w >> 24], 1u); }      // (the usual word: no match in it)
-                else {
+                // (one predicated form for every word: a "no match in this word" fast path beside it made the wave run both, some lane always has a match)
                 if (!(cv & 1u)) atomicAdd(&hist[w & 255u], 1u);
                 if (!(cv & 2u)) atomicAdd(&hist[(w >> 8) & 255u], 1u);
                 if (!(cv & 4u)) atomicAdd(&hist[(w >> 16) & 255u], 1u);
                 if (!(cv & 8u)) atomicAdd(&hist[w >> 24], 1u);
-                }
                 const uint32_t x = crc ^ w;
                 crc = s_tab[768 + (x & 255u)] ^ s_tab[512 + ((x >> 8) & 255u)] ^ s_tab[256 + ((x >> 16) & 255u)] ^ s_tab[x >> 24];
             } else if (base < slen) {
                 for (uint32_t b = 0; base + b < slen; ++b) { const uint32_t c = (w >> (8 * b)) & 255u; if (!((cv >> b) & 1u)) atomicAdd(&hist[c], 1u); crc = s_tab[(crc ^ c) & 255u] ^ (crc >> 8); }
             }
         }
-        for (uint32_t q = 0; q < n_tok; ++q) {
-            const uint32_t tk = s_tok[q][tid];
-            atomicAdd(&hist[257u + (gz_len_sym((tk >> 8) & 511u) & 255u)], 1u);
-            atomicAdd(&s_dsub[gz_dist_sym(tk >> 17) & 255u], 1u);
+        for (uint32_t q = 0; q < (uint32_t)GZ_MAXM; ++q) {
+            if (!__ballot(q < n_tok)) break;
+            if (q < n_tok) {
+                const uint32_t tk = s_tok[q][tid];
+                atomicAdd(&hist[257u + (gz_len_sym((tk >> 7) & 127u) & 255u)], 1u);
+                atomicAdd(&s_dsub[gz_dist_sym(tk >> 14) & 255u], 1u);
+            }
         }
     }
     __syncthreads();
@@ -494,15 +497,18 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
     for (int k = 0; k < GZ_SPAN / 4; ++k) {
         const uint32_t w = d[k], base = 4u * (uint32_t)k;
         const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
-        if (base + 4 <= slen && cv == 0) bits += (s_code[w & 255u] >> 16) + (s_code[(w >> 8) & 255u] >> 16) + (s_code[(w >> 16) & 255u] >> 16) + (s_code[w >> 24] >> 16);
-        else {
 #pragma unroll
-        for (uint32_t b = 0; b < 4; ++b) if (base + b < slen && !((cv >> b) & 1u)) bits += s_code[(w >> (8 * b)) & 255u] >> 16;
-        }
+        for (uint32_t b = 0; b < 4; ++b) { const uint32_t l = s_code[(w >> (8 * b)) & 255u] >> 16; bits += (base + b < slen && !((cv >> b) & 1u)) ? l : 0u; }
+        if ((k & 3) == 3) sched_fence();                          // (sixteen lookups in flight at a time, not all 128: registers)
     }
-    for (uint32_t q = 0; q < n_tok; ++q) {
-        const uint32_t tk = s_tok[q][tid], ls = gz_len_sym((tk >> 8) & 511u), ds = gz_dist_sym(tk >> 17);
-        bits += (s_code[257u + (ls & 255u)] >> 16) + ((ls >> 8) & 255u) + (s_dcode[ds & 255u] >> 16) + ((ds >> 8) & 255u);
+    for (uint32_t q = 0; q < (uint32_t)GZ_MAXM; ++q) {           // a match: length code + extra bits + distance code + extra bits
+        if (!__ballot(q < n_tok)) break;
+        if (q < n_tok) {
+            const uint32_t tk = s_tok[q][tid], ls = gz_len_sym((tk >> 7) & 127u), ds = gz_dist_sym(tk >> 14);
+            const uint32_t L = (s_code[257u + (ls & 255u)] >> 16) + ((ls >> 8) & 255u) + (s_dcode[ds & 255u] >> 16) + ((ds >> 8) & 255u);
+            s_tokp[q][tid] = (uint16_t)L;
+            bits += L;
+        }
     }
     uint32_t tot_bits;
     const uint32_t before = block_excl_scan(bits, s_scan, &tot_bits);      // (its barriers publish s_hdr)
@@ -562,29 +568,51 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
     // ---- pass 3: the member image ----
     const uint32_t data0 = hdr_bytes * 8u;                        // bit position of the DEFLATE data
     {
-        LdsBits bs; bs.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + before);
+        // pass 3a: the literals, in one branch-free form per byte (a covered byte is a code of no bits, the first byte of a match a GAP of the match's
+        // bits whose position in the lane's stream is noted); pass 3b, behind a barrier: the matches are ORed into their gaps.  Emitting a match where
+        // it stands made every wave run the match path at every byte -- some lane always has one there.
+        const uint32_t start_abs = data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + before;
+        LdsBits bs; bs.init(s_img, start_abs);
         uint32_t q = 0;
+        const uint32_t *codes = launder_lds(s_code);              // (the compiler must not keep pass 2's 128 lookups alive for this loop: they are made again)
 #pragma unroll
         for (int k = 0; k < GZ_SPAN / 4; ++k) {
             const uint32_t w = d[k], base = 4u * (uint32_t)k;
             const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u, ms = (mst[k >> 3] >> (4 * (k & 7))) & 15u;
-            if (base + 4 <= slen && (cv | ms) == 0) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { const uint32_t c = s_code[(w >> (8 * b)) & 255u]; bs.put(c & 0xFFFFu, c >> 16); }
-                continue;
-            }
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b) {
-                if (base + b >= slen) continue;
-                if ((ms >> b) & 1u) {
-                    const uint32_t tk = s_tok[q][tid], ls = gz_len_sym((tk >> 8) & 511u), ds = gz_dist_sym(tk >> 17); ++q;
-                    const uint32_t lc = s_code[257u + (ls & 255u)], dc = s_dcode[ds & 255u];
-                    bs.put(lc & 0xFFFFu, lc >> 16); if ((ls >> 8) & 255u) bs.put(ls >> 16, (ls >> 8) & 255u);
-                    bs.put(dc & 0xFFFFu, dc >> 16); if ((ds >> 8) & 255u) bs.put(ds >> 16, (ds >> 8) & 255u);
-                } else if (!((cv >> b) & 1u)) { const uint32_t c = s_code[(w >> (8 * b)) & 255u]; bs.put(c & 0xFFFFu, c >> 16); }
+                const uint32_t c = codes[(w >> (8 * b)) & 255u];
+                const bool live = base + b < slen, isms = live && ((ms >> b) & 1u), iscv = (cv >> b) & 1u;
+                uint32_t len = (live && !iscv) ? c >> 16 : 0u, code = (live && !iscv) ? c & 0xFFFFu : 0u;
+                if (isms) {
+                    len = s_tokp[q][tid];                                                    // the gap
+                    s_tokp[q][tid] = (uint16_t)(((bs.w << 5) + bs.nb) - start_abs);          // ... and where it starts
+                    ++q;
+                }
+                if (__ballot(len > 32u)) { if (len > 32u) { bs.put(0, 16); len -= 16; } }     // (a match of more than 32 bits: next to never)
+                bs.put(code, len);
             }
+            sched_fence();                                        // (keeps the table lookups of later words from being hoisted up here: registers)
         }
         bs.finish();
+        __syncthreads();
+        for (uint32_t t2 = 0; t2 < (uint32_t)GZ_MAXM; ++t2) {
+            if (!__ballot(t2 < n_tok)) break;
+            if (t2 < n_tok) {
+                const uint32_t tk = s_tok[t2][tid], ls = gz_len_sym((tk >> 7) & 127u), ds = gz_dist_sym(tk >> 14);
+                const uint32_t lc = s_code[257u + (ls & 255u)], dc = s_dcode[ds & 255u];
+                uint64_t v = lc & 0xFFFFu; uint32_t nb = lc >> 16;
+                v |= (uint64_t)(ls >> 16) << nb; nb += (ls >> 8) & 255u;
+                v |= (uint64_t)(dc & 0xFFFFu) << nb; nb += dc >> 16;
+                v |= (uint64_t)(ds >> 16) << nb;                                              // <= 15 + 5 + 15 + 13 = 48 bits
+                const uint32_t pos = start_abs + (uint32_t)s_tokp[t2][tid], sh = pos & 31u, w0 = pos >> 5;
+                const uint64_t lo = (v & 0xFFFFFFFFull) << sh, hi = (v >> 32) << sh;          // two halves: each fits 64 bits after the shift
+                if ((uint32_t)lo) atomicOr(&s_img[w0], (uint32_t)lo);
+                const uint32_t mid = (uint32_t)(lo >> 32) | (uint32_t)hi;
+                if (mid) atomicOr(&s_img[w0 + 1], mid);
+                if ((uint32_t)(hi >> 32)) atomicOr(&s_img[w0 + 2], (uint32_t)(hi >> 32));
+            }
+        }
     }
     if (tid == 0) {
         auto put_byte = [&](uint32_t pos, uint32_t b) { atomicOr(&s_img[pos >> 2], b << (8 * (pos & 3u))); };
