@@ -352,10 +352,15 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
                     E[c] |= (uint64_t)m << (4 * jw);
                 }
             }
-            // (3) greedy walk
+            // (3) greedy walk.  `any3`: the positions where some candidate has three equal bytes in a row -- the walk jumps from one to the next
+            uint64_t any3 = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) any3 |= E[c] & (E[c] >> 1) & (E[c] >> 2);
+            if (nn < 64u) any3 &= (1ull << nn) - 1ull;
             uint32_t p = 0;
-            while (__ballot(p < nn && n_tok < (uint32_t)GZ_MAXM)) {
-                if (p < nn && n_tok < (uint32_t)GZ_MAXM) {
+            while (__ballot((any3 >> (p < 63u ? p : 63u)) != 0 && p < nn && n_tok < (uint32_t)GZ_MAXM)) {
+                if ((any3 >> (p < 63u ? p : 63u)) != 0 && p < nn && n_tok < (uint32_t)GZ_MAXM) {
+                    p += (uint32_t)__builtin_ctzll(any3 >> p);                               // the next position with a match of three bytes or more
                     uint32_t best = 0, bd = 0;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -375,7 +380,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
                             cov[w] |= mm; b += n;
                         }
                         p += best;
-                    } else ++p;
+                    } else ++p;                                   // (three equal bytes that run past the piece's end)
                 }
             }
         }
