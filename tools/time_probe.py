@@ -9,6 +9,8 @@ params = api.parse_flags(flags, lib)
 with api.Context(params, 0, lib) as ctx:
     if os.environ.get("SIMT"):
         ctx.debug_option("sim_threads", int(os.environ["SIMT"]))
+    if os.environ.get("FLOW_SLOTS"):
+        ctx.debug_option("flow_slots", int(os.environ["FLOW_SLOTS"]))
     if os.environ.get("SPLIT"):
         ctx.debug_option("split", int(os.environ["SPLIT"]))
     if os.environ.get("WRITER"):
