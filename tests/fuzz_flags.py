@@ -9,13 +9,15 @@ from parity_common import compare_case
 def random_flags(rng):
     f = [f"-z {rng.randrange(1, 10000)}"]
     pe = rng.random() < 0.7
-    l1 = rng.choice([1, 2, 7, 8, 9, 16, 33, 50, 100, 150, 251])
-    l2 = rng.choice([1, 8, 31, 50, 100, 150]) if pe else 0
+    long_reads = bool(os.environ.get("DWGSIM_FUZZ_LONG"))      # reads of 650 bases and more: the one-wave blocks with their reads in scratch slots
+    l1 = rng.choice([640, 700, 1024, 1300, 2500, 3999, 5000]) if long_reads else rng.choice([1, 2, 7, 8, 9, 16, 33, 50, 100, 150, 251])
+    l2 = (rng.choice([1, 150, 650, 1200]) if long_reads else rng.choice([1, 8, 31, 50, 100, 150])) if pe else 0
     f += [f"-1 {l1}", f"-2 {l2}"]
     if pe:
         d = rng.choice([l1 + l2, l1 + l2 + 5, 200, 500, 900]); f += [f"-d {max(d, l1 + l2)}", f"-s {rng.choice([0, 1, 10, 50])}"]
         if rng.random() < 0.2: f.append("-i")
-    f.append(rng.choice([f"-N {rng.choice([1, 2, 63, 64, 65, 257, 1000, 3000])}", f"-C {rng.choice([0.01, 0.5, 2, 7])}"]))
+    if long_reads: f.append(rng.choice([f"-N {rng.choice([1, 63, 65, 300])}", f"-C {rng.choice([0.5, 7])}"]))
+    else: f.append(rng.choice([f"-N {rng.choice([1, 2, 63, 64, 65, 257, 1000, 3000])}", f"-C {rng.choice([0.01, 0.5, 2, 7])}"]))
     if os.environ.get("DWGSIM_FUZZ_MUT"): f.append(f"-r {rng.choice([0.05, 0.1, 0.2, 0.3, 0.5])}")      # (the walk under stress: dense events)
     elif rng.random() < 0.6: f.append(f"-r {rng.choice([0, 0.0001, 0.001, 0.01, 0.05, 0.3])}")
     if rng.random() < 0.5: f.append(f"-R {rng.choice([0, 0.1, 0.5, 1.0])}")

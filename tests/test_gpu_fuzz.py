@@ -49,6 +49,17 @@ def test_fresh_random_option_sets_bit_exact(oracle_bin, seed, count, mode, mut):
     assert r.returncode == 0 and last.endswith(" 0 bad"), f"seed {seed} mode '{mode}' mut {mut}: " + r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("seed,count,mode", [(SRC_SEED + 7, 25, ""), (SRC_SEED + 8, 10, "shards"), (SRC_SEED + 9, 8, "cli")], ids=lambda v: str(v))
+def test_long_reads_random_option_sets_bit_exact(oracle_bin, seed, count, mode):
+    """The same fuzzer with read lengths of 640 .. 5 000 bases (DWGSIM_FUZZ_LONG): the one-wave blocks whose reads are staged in scratch slots, all
+    read models and outputs, sharded and through the executable."""
+    env = dict(os.environ, DWGSIM_FUZZ_LONG="1")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "fuzz_flags.py"), str(seed), str(count)] + mode.split()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0 and last.endswith(" 0 bad"), f"seed {seed} mode '{mode}': " + r.stdout[-2000:]
+
+
 def test_ion_torrent_random_flow_orders_bit_exact(oracle_bin):
     """tests/fuzz_ion_flows.py: the flow model under flow orders of 4 .. 64 flows with long gaps, read lengths 1 .. 400, per-flow error rates up to
     0.2, -B; at most one case of the sample may end with a read that outgrew its buffers (they are doubled up to 16 x first)."""
