@@ -13,7 +13,7 @@ constexpr int PLACE_LISTS = 64;          // k_place hands the pairs it cannot de
 #endif
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
 constexpr int FLOW_STACK_RUNS = 32;           // Ion Torrent pass 2: (base, count) runs that can be pending in front of the examined base (two per LDS word)
-constexpr int SIM_THREADS_LONG = 64;          // ... for reads whose staged bases do not fit LDS at SIM_THREADS lanes (up to ~5 kb)
+constexpr int SIM_THREADS_LONG = 64;          // ... one-wave blocks for reads of ~650 bases and more: their bases are staged in scratch slots, not LDS
 constexpr int SIM_FIFO_BYTES = 40;            // per lane: the text FIFO of the record writer (one 32-byte burst + the overshoot of an 8-byte put)
 constexpr int SIM_FIFO_BYTES_WIDE = 72;       // ... with 64-byte bursts (second half of the two-kernel form: no staged bases compete for LDS)
 // dynamic LDS of a k_simulate block: [words_per_lane][lanes] staged bases | the two base-quality tables | [lanes] text FIFOs (16-byte aligned)

@@ -108,7 +108,7 @@ CASES = [
     # flow orders that keep a base away for 32 and more flows (up to 63 are accepted): the hit bitmap of pass 2 is read in pieces
     ("tiny.fa", "-z 9 -N 1500 -c 2 -f TCG" + "A" * 37 + " -1 120 -2 0 -e 0.03"),
     ("tiny.fa", "-z 9 -N 1200 -c 2 -f " + "TACG" * 4 + "A" * 34 + " -1 90 -2 60 -e 0.02 -E 0.01 -d 300 -o 1"),                       # absurd per-flow error: deep insertion cascades in pass 2
-    # reads too long to stage in LDS at 256 lanes per block: the one-wave-per-block variants (up to ~4.8 kb)
+    # reads too long to stage in LDS at 256 lanes per block: the one-wave-per-block variants
     ("tiny.fa", "-z 3 -N 400 -1 1500 -2 0 -n 40 -r 0.01 -R 0.3"),
     ("tiny.fa", "-z 3 -N 300 -1 1300 -2 1400 -d 3600 -s 40 -n 60 -y 0.1"),
     ("tiny.fa", "-z 3 -N 200 -c 1 -1 1400 -2 0 -n 60 -o 2"),
