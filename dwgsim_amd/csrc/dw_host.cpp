@@ -1330,6 +1330,10 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
     if (const int rc = build_ranges(c, r, n, sim_ppb, &gp, segs, &n_pairs, &nblk, &fixed_max)) return rc;
     Group &g = *gp;
     HIPC(c, hipSetDevice(c->device));
+    // a SMALL launch -- up to ~3 rounds of resident blocks: the product's 2^18-pair batches, an E. coli-sized contig -- also runs as two kernels: the
+    // first round's look-backs resolve one after the other (every block waits for all in front of it, all of them just started), and a launch this
+    // short is mostly first round: 2^17 / 2^18 / 2^19 pairs of 2 x 150 bp -5 / -11.5 / -2 %, 2^20 pairs +1 % (profiles/r04_split.txt)
+    if (!a.split && c->split < 0 && p.data_type == 0 && a.sim_threads == SIM_THREADS && n_pairs && (uint64_t)nblk <= 16ull * (uint64_t)c->n_cu) { a.split = 1; if (c->writer < 0) a.fifo = 1; }
     if (c->rand_fixed_len > fixed_max) fixed_max = c->rand_fixed_len;
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     size_t cap[3] = {0, 0, 0};
