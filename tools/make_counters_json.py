@@ -8,11 +8,15 @@ import hashlib, json, os, re, subprocess, sys
 key, d = sys.argv[1], sys.argv[2]
 dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_counters.json")
 rtag = sys.argv[4] if len(sys.argv) > 4 else "r04"
-vals = {}
+vals, per_kernel = {}, {}
 for line in open(os.path.join(d, "pmc.txt")):
-    m = re.match(r"^.*k_simulate.*?\s([A-Z][A-Z0-9_]+)\s+([0-9.]+)\s+n=", line)
+    m = re.match(r"^(.*k_simulate.*?)\s([A-Z][A-Z0-9_]+)\s+([0-9.]+)\s+n=", line)
     if m:
-        vals[m.group(1)] = float(m.group(2))
+        per_kernel.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(3))
+# a launch that ran as TWO kernels (the two-kernel form of small launches / short reads): bytes, instructions and busy time add up; both halves have the same waves
+for name, kv in per_kernel.items():
+    for k, v in kv.items():
+        vals[k] = v if k == "SQ_WAVES" else vals.get(k, 0.0) + v
 bench = json.load(open(os.path.join(d, "bench_line.json")))
 pairs = bench["config"]["pairs_per_gpu_per_step"]
 waves = vals.get("SQ_WAVES")
@@ -24,7 +28,7 @@ except Exception:
     head = None
 pairs = int(pairs / max(bench["config"].get("launches_per_gpu_per_step", 1), 1))
 out = {"source": f"profiles/{rtag}_{os.path.basename(d).replace('final_', '')}_kernel_stats_pmc.txt (rocprofv3 --kernel-trace --pmc, one counter group per pass, tools/profile_round.sh; MI355X)",
-       "kernel": bench["roofline"]["kernel"], "pairs_per_launch": pairs, "lib_sha256": sha, "git_head": head}
+       "kernel": bench["roofline"]["kernel"] + (" (as two kernels: counters summed over both halves)" if len(per_kernel) > 1 else ""), "pairs_per_launch": pairs, "lib_sha256": sha, "git_head": head}
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     out.update({"fetch_size_kib": vals["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kib": vals["WRITE_SIZE"],
                 "traffic_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)})
