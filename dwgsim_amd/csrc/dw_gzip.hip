@@ -504,7 +504,6 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
         const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u;
 #pragma unroll
         for (uint32_t b = 0; b < 4; ++b) { const uint32_t l = s_code[(w >> (8 * b)) & 255u] >> 16; bits += (base + b < slen && !((cv >> b) & 1u)) ? l : 0u; }
-        if ((k & 3) == 3) sched_fence();                          // (sixteen lookups in flight at a time, not all 128: registers)
     }
     for (uint32_t q = 0; q < (uint32_t)GZ_MAXM; ++q) {           // a match: length code + extra bits + distance code + extra bits
         if (!__ballot(q < n_tok)) break;
@@ -579,14 +578,13 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
         const uint32_t start_abs = data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + before;
         LdsBits bs; bs.init(s_img, start_abs);
         uint32_t q = 0;
-        const uint32_t *codes = launder_lds(s_code);              // (the compiler must not keep pass 2's 128 lookups alive for this loop: they are made again)
 #pragma unroll
         for (int k = 0; k < GZ_SPAN / 4; ++k) {
             const uint32_t w = d[k], base = 4u * (uint32_t)k;
             const uint32_t cv = (cov[k >> 3] >> (4 * (k & 7))) & 15u, ms = (mst[k >> 3] >> (4 * (k & 7))) & 15u;
 #pragma unroll
             for (uint32_t b = 0; b < 4; ++b) {
-                const uint32_t c = codes[(w >> (8 * b)) & 255u];
+                const uint32_t c = s_code[(w >> (8 * b)) & 255u];
                 const bool live = base + b < slen, isms = live && ((ms >> b) & 1u), iscv = (cv >> b) & 1u;
                 uint32_t len = (live && !iscv) ? c >> 16 : 0u, code = (live && !iscv) ? c & 0xFFFFu : 0u;
                 if (isms) {
@@ -597,7 +595,6 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
                 if (__ballot(len > 32u)) { if (len > 32u) { bs.put(0, 16); len -= 16; } }     // (a match of more than 32 bits: next to never)
                 bs.put(code, len);
             }
-            sched_fence();                                        // (keeps the table lookups of later words from being hoisted up here: registers)
         }
         bs.finish();
         __syncthreads();

@@ -34,12 +34,6 @@ DW_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) 
 // every store this wave has issued has been acknowledged by the L2 (a workgroup ends without waiting for its stores)
 DW_DEV void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// nothing is scheduled across this point (long unrolled table-lookup loops: without it the compiler hoists every lookup and its address arithmetic to
-// the top and the kernel's registers double)
-DW_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-// the same LDS address, but the compiler no longer knows what it points at (no common-subexpression elimination with earlier loads through the original)
-DW_DEV const uint32_t *launder_lds(const uint32_t *p) { asm volatile("" : "+v"(p)); return p; }
-
 // IEEE-754 binary64 x / y and sqrt(x) for operands far from the ends of the exponent range and without special values:
 // exactly the Newton-Raphson + correction sequences the compiler emits for `/` and sqrt() on gfx950 (LLVM AMDGPU LowerFDIV64 /
 // lowerFSQRTF64) minus their v_div_scale / v_div_fixup / ldexp / class-test range handling, which is the identity on such
