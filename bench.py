@@ -213,7 +213,7 @@ def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu", fai=False, null_sin
             return {"error": r.stderr.decode(errors="replace")[-300:]}
         gz = sum(os.path.getsize(os.path.join(t, f)) for f in os.listdir(t) if f.endswith(".gz"))
         stages = [ln for ln in r.stderr.decode(errors="replace").splitlines() if ln.startswith("[dwgsim-hip]")]
-    gzinfo = ({"where": "gpu", "members": "32 KiB of text each, dynamic Huffman codes (k_gzip)"} if gzip_mode == "gpu" else
+    gzinfo = ({"where": "gpu", "members": "32 KiB of text each, dynamic Huffman codes + LZ77 matches on the name lines (k_gzip)"} if gzip_mode == "gpu" else
               {"where": "cpu", "threads": effective_cores(), "zlib_level": int(os.environ.get("DWGSIM_HIP_GZIP_LEVEL", "1")), "members": "independent 1 MiB gzip members"})
     return {"seconds": round(dt, 2), "value": round(n_pairs / dt / 1e6, 3), "unit": "M read-pairs/s", "gz_bytes": gz, "gzip": gzinfo,
             "stages": stages[-1][13:] if stages else None,

@@ -9,7 +9,7 @@
 // decompresses to exactly the concatenated text, which is what the reference's own test compares (testdata/test.sh:23-25).
 // Environment (all optional):
 //     DWGSIM_HIP_DEVICES   "0,1,2,3" or a count "4" (default: every HIP device the process sees)
-//     DWGSIM_HIP_GZIP      "gpu" (default): Huffman-coded 32 KiB members made by k_gzip, ~0.49 of the text; "cpu": zlib on the host cores at
+//     DWGSIM_HIP_GZIP      "gpu" (default): 32 KiB members made by k_gzip (Huffman codes + matches on the name lines), ~0.44 of the text; "cpu": zlib on the host cores at
 //                          DWGSIM_HIP_GZIP_LEVEL (default 1; smaller files, deflate-bound) with DWGSIM_HIP_THREADS threads (default: all cores)
 //     DWGSIM_HIP_BATCH     read pairs per GPU launch (default 2^20)
 //     DWGSIM_HIP_GROUP_BP  consecutive contigs are resident together up to this many bases (default 32 Mi)
