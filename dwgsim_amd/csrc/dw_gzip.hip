@@ -495,6 +495,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
         code_seq(s_mask + 5, 1, hdist, s_dsub);
         s_hdr[0] = bits; s_hdr[1] = hlit - 257u; s_hdr[2] = hdist - 1u; s_hdr[3] = ntok;
     }
+    if (probe::off(1 << 27)) { __syncthreads(); return; }         // (analysis builds: ... + the block header's tokens, coded by one lane)
 
     // ---- pass 2: bits of this lane's span; scan; this member's size and its byte offset by look-back over the chunks ----
     uint32_t bits = 0;
