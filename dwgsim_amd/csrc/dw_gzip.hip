@@ -77,16 +77,13 @@ DW_DEV uint32_t gz_dist_sym(uint32_t dist)            // 1 .. 32768
     return (2u * e + 2u + ((v >> e) & 1u)) | (e << 8) | ((v & ((1u << e) - 1u)) << 16);
 }
 
-struct LdsBits {            // LSB-first bit packer into the LDS image; the first and the last word of a run may be shared with a neighbour
-    uint32_t *img; uint32_t w; uint64_t acc; uint32_t nb; bool first;
-    DW_DEV void init(uint32_t *image, uint32_t bitpos) { img = image; w = bitpos >> 5; nb = bitpos & 31u; acc = 0; first = true; }
+struct LdsBits {            // LSB-first bit packer into the (zeroed) LDS image; the first and the last word of a run may be shared with a neighbour, so
+    uint32_t *img; uint32_t w; uint64_t acc; uint32_t nb;      // every word is ORed in (an LDS OR costs what a store costs; no "first word" case to tell apart)
+    DW_DEV void init(uint32_t *image, uint32_t bitpos) { img = image; w = bitpos >> 5; nb = bitpos & 31u; acc = 0; }
     DW_DEV void put(uint32_t code, uint32_t len)
     {
         acc |= (uint64_t)code << nb; nb += len;
-        if (nb >= 32) {
-            if (first) { atomicOr(&img[w], (uint32_t)acc); first = false; } else img[w] = (uint32_t)acc;
-            ++w; acc >>= 32; nb -= 32;
-        }
+        if (nb >= 32) { atomicOr(&img[w], (uint32_t)acc); ++w; acc >>= 32; nb -= 32; }
     }
     DW_DEV void finish() { if (nb) atomicOr(&img[w], (uint32_t)acc); }
 };
@@ -452,7 +449,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
     // The lengths are mostly zero, in long runs: the waves ballot "length != 0" into six 64-bit masks, and the one lane that codes the sequence finds
     // its way through the zero runs with count-trailing-zeros instead of visiting 316 symbols (that serial walk, twice, was a third of the kernel's
     // time in the first version).  Its tokens (code-length code + extra bits, <= 12 bits each) wait in LDS for pass 3.
-    uint32_t *const s_clt = s_tab + 256;                          // <= 320 tokens: value | bits << 16 (the slicing tables are done with; the span CRCs use s_tab[0 .. 256))
+    uint32_t *const s_clt = s_tab + 256;                          // <= 320 tokens: value | bits << 12 | bit offset << 16 (the slicing tables are done with; the span CRCs use s_tab[0 .. 256))
     {
         const uint64_t m0 = __ballot(len[tid] != 0);
         if (lane == 0) s_mask[wave] = m0;
@@ -463,7 +460,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
     if (tid == 0) {
         auto cl_code = [](uint32_t sym, uint32_t &nbits) -> uint32_t { nbits = sym <= 12u ? 4u : 5u; return bit_reverse(sym <= 12u ? sym : 26u + (sym - 13u), nbits); };
         uint32_t bits = 0, ntok = 0;
-        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); s_clt[ntok++] = (c | (eval << nb)) | ((nb + ebits) << 16); bits += nb + ebits; };
+        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); s_clt[ntok++] = (c | (eval << nb)) | ((nb + ebits) << 12) | (bits << 16); bits += nb + ebits; };      // value (<= 12 bits) | bits << 12 | where it starts << 16
         auto code_seq = [&](const uint64_t *mask, int nwords, uint32_t n, const uint32_t *val) {      // one sequence of n lengths, its "!= 0" bits in mask[0 .. nwords)
             auto bit = [&](uint32_t i) -> bool { return (mask[i >> 6] >> (i & 63u)) & 1ull; };
             uint32_t i = 0;
@@ -592,8 +589,8 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
                     len = s_tokp[q][tid];                                                    // the gap
                     s_tokp[q][tid] = (uint16_t)(((bs.w << 5) + bs.nb) - start_abs);          // ... and where it starts
                     ++q;
+                    if (len > 32u) { bs.put(0, 16); len -= 16; }                             // (a match of more than 32 bits: next to never)
                 }
-                if (__ballot(len > 32u)) { if (len > 32u) { bs.put(0, 16); len -= 16; } }     // (a match of more than 32 bits: next to never)
                 bs.put(code, len);
             }
         }
@@ -626,8 +623,7 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
         bh.put(0, 1); bh.put(2, 2); bh.put(s_hdr[1], 5); bh.put(s_hdr[2], 5); bh.put(15, 4);
         const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         for (int q = 0; q < 19; ++q) bh.put(order[q] <= 12 ? 4u : 5u, 3);
-        for (uint32_t q = 0; q < s_hdr[3]; ++q) { const uint32_t tk = s_clt[q]; bh.put(tk & 0xFFFFu, tk >> 16); }
-        bh.finish();
+        bh.finish();                                              // (the coded lengths behind it: every lane ORs in its share of the tokens, below)
         // end of block + the final empty stored block (BFINAL = 1, BTYPE = 00, pad to a byte, LEN = 0, NLEN = 0xFFFF)
         LdsBits be; be.init(s_img, data0 + (uint32_t)GZ_FIXED_HDR_BITS + hdr_sym_bits + tot_bits);
         be.put(eob & 0xFFFFu, eob >> 16); be.put(1, 1); be.put(0, 2);
@@ -635,6 +631,12 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
         const uint32_t tail = hdr_bytes + ((body_bits + 7u) >> 3);
         put_byte(tail + 2, 0xFF); put_byte(tail + 3, 0xFF);
         for (uint32_t q = 0; q < 4; ++q) { put_byte(tail + 4 + q, (chunk_crc >> (8 * q)) & 255u); put_byte(tail + 8 + q, (clen >> (8 * q)) & 255u); }
+    }
+    for (uint32_t q = (uint32_t)tid; q < s_hdr[3]; q += GZ_THREADS) {      // the block header's tokens, each at its own bit offset
+        const uint32_t tk = s_clt[q], pos = data0 + (uint32_t)GZ_FIXED_HDR_BITS + (tk >> 16), sh = pos & 31u;
+        const uint64_t v = (uint64_t)(tk & 0xFFFu) << sh;
+        atomicOr(&s_img[pos >> 5], (uint32_t)v);
+        if ((uint32_t)(v >> 32)) atomicOr(&s_img[(pos >> 5) + 1], (uint32_t)(v >> 32));
     }
     __syncthreads();
     // ---- the image leaves: members are multiples of 4 bytes, so plain coalesced word stores ----
