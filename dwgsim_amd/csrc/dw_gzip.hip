@@ -445,54 +445,86 @@ __global__ void __launch_bounds__(GZ_THREADS, 3) k_gzip(GzArgs a)
 
     if (probe::off(1 << 23)) return;      // ... + the two codes
     // ---- block header: the code lengths, run-length coded (RFC 1951 3.2.7) under a FIXED code-length code: symbols 0 .. 12 take 4 bits (codes
-    // 0 .. 12), 13 .. 18 take 5 bits (codes 26 .. 31).  One lane walks the 257 + HLIT + 1 + HDIST lengths; its tokens go straight into the image ----
-    // The lengths are mostly zero, in long runs: the waves ballot "length != 0" into six 64-bit masks, and the one lane that codes the sequence finds
-    // its way through the zero runs with count-trailing-zeros instead of visiting 316 symbols (that serial walk, twice, was a third of the kernel's
-    // time in the first version).  Its tokens (code-length code + extra bits, <= 12 bits each) wait in LDS for pass 3.
+    // 0 .. 12), 13 .. 18 take 5 bits (codes 26 .. 31) ----
+    // Coded in parallel: a RUN of equal lengths is the unit (RFC 1951's repeat codes never look across one).  Every symbol that starts a run -- ballots
+    // of "differs from the symbol before" -- finds the run's end in the ballot masks, counts its tokens and bits, a scan in symbol order gives it
+    // its place, and it writes its own tokens (code-length code + extra bits, <= 12 bits each, with their bit offsets) to LDS for pass 3.  The literal /
+    // length lengths are one sequence (first symbols by all lanes, then symbols 256 .. by wave 0), the distance lengths another (wave 0 again).
+    // (One lane walking the sequence, even from non-zero to non-zero by count-trailing-zeros, was a tenth of the kernel: profiles/r04_gzip.txt.)
     uint32_t *const s_clt = s_tab + 256;                          // <= 320 tokens: value | bits << 12 | bit offset << 16 (the slicing tables are done with; the span CRCs use s_tab[0 .. 256))
     {
-        const uint64_t m0 = __ballot(len[tid] != 0);
-        if (lane == 0) s_mask[wave] = m0;
-        if (wave == 0) { const uint64_t m1 = __ballot(lane < GZ_NLIT - 256 && len[256 + lane] != 0); if (lane == 0) s_mask[4] = m1; }
-        if (wave == 1) { const uint64_t m2 = __ballot(lane < GZ_NDIST && s_dsub[lane] != 0); if (lane == 0) s_mask[5] = m2; }
+        if (wave == 0) { const uint64_t m1 = __ballot(lane < GZ_NLIT - 256 && len[256 + lane] != 0), m2 = __ballot(lane < GZ_NDIST && s_dsub[lane] != 0); if (lane == 0) { s_mask[4] = m1; s_mask[5] = m2; } }
     }
     __syncthreads();
-    if (tid == 0) {
-        auto cl_code = [](uint32_t sym, uint32_t &nbits) -> uint32_t { nbits = sym <= 12u ? 4u : 5u; return bit_reverse(sym <= 12u ? sym : 26u + (sym - 13u), nbits); };
-        uint32_t bits = 0, ntok = 0;
-        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); s_clt[ntok++] = (c | (eval << nb)) | ((nb + ebits) << 12) | (bits << 16); bits += nb + ebits; };      // value (<= 12 bits) | bits << 12 | where it starts << 16
-        auto code_seq = [&](const uint64_t *mask, int nwords, uint32_t n, const uint32_t *val) {      // one sequence of n lengths, its "!= 0" bits in mask[0 .. nwords)
-            auto bit = [&](uint32_t i) -> bool { return (mask[i >> 6] >> (i & 63u)) & 1ull; };
-            uint32_t i = 0;
-            while (i < n) {
-                if (bit(i)) {
-                    const uint32_t v = val[i]; uint32_t run = 1;
-                    while (i + run < n && bit(i + run) && val[i + run] == v) ++run;
-                    i += run;
-                    emit(v, 0, 0); --run;
-                    while (run >= 3) { const uint32_t r = run < 6u ? run : 6u; emit(16, 2, r - 3u); run -= r; }
-                    while (run) { emit(v, 0, 0); --run; }
-                } else {
-                    uint32_t nz = n;                              // the next length != 0, or the end
-                    for (uint32_t w = i >> 6; w < (uint32_t)nwords; ++w) {
-                        const uint64_t m = w == (i >> 6) ? (mask[w] >> (i & 63u)) << (i & 63u) : mask[w];
-                        if (m) { const uint32_t q = 64u * w + (uint32_t)__builtin_ctzll(m); nz = q < n ? q : n; break; }
-                    }
-                    uint32_t run = nz - i; i = nz;
-                    while (run >= 11) { const uint32_t r = run < 138u ? run : 138u; emit(18, 7, r - 11u); run -= r; }
-                    if (run >= 3) { emit(17, 3, run - 3u); run = 0; }
-                    while (run) { emit(0, 0, 0); --run; }
-                }
-            }
-        };
-        uint32_t hlit = 257;                                      // literal / length codes sent: up to the last used one (the end-of-block symbol is always used)
-        if (s_mask[4] >> 1) hlit = 256u + 64u - (uint32_t)__builtin_clzll(s_mask[4]);
-        uint32_t hdist = s_mask[5] ? 64u - (uint32_t)__builtin_clzll(s_mask[5]) : 1u;
-        code_seq(s_mask, 5, hlit, len);
-        code_seq(s_mask + 5, 1, hdist, s_dsub);
-        s_hdr[0] = bits; s_hdr[1] = hlit - 257u; s_hdr[2] = hdist - 1u; s_hdr[3] = ntok;
+    const uint32_t hlit = (s_mask[4] >> 1) ? 256u + 64u - (uint32_t)__builtin_clzll(s_mask[4]) : 257u;      // literal / length codes sent: up to the last used one (end-of-block always is)
+    const uint32_t hdist = s_mask[5] ? 64u - (uint32_t)__builtin_clzll(s_mask[5]) : 1u;
+    __syncthreads();                                              // (s_mask is reused for the run starts)
+    {
+        const uint32_t v0 = len[tid], p0 = tid ? len[tid - 1] : 0xFFFFu;
+        const uint64_t st0 = __ballot(v0 != p0);
+        if (lane == 0) s_mask[wave] = st0;
+        if (wave == 0) {
+            const uint64_t st1 = __ballot(lane < GZ_NLIT - 256 && len[256 + lane] != len[255 + lane]);
+            const uint64_t st2 = __ballot(lane < GZ_NDIST && (lane == 0 || s_dsub[lane] != s_dsub[lane ? lane - 1 : 0]));
+            if (lane == 0) { s_mask[4] = st1; s_mask[5] = st2; }
+        }
     }
-    if (probe::off(1 << 27)) { __syncthreads(); return; }         // (analysis builds: ... + the block header's tokens, coded by one lane)
+    __syncthreads();
+    auto cl_code = [](uint32_t sym, uint32_t &nbits) -> uint32_t { nbits = sym <= 12u ? 4u : 5u; return bit_reverse(sym <= 12u ? sym : 26u + (sym - 13u), nbits); };
+    // the end (exclusive) of the run that starts at symbol i of a sequence of n symbols whose run starts are the bits of mask[0 .. nwords)
+    auto run_end = [&](const uint64_t *mask, uint32_t nwords, uint32_t i, uint32_t n) -> uint32_t {
+        uint32_t e = n;
+        for (uint32_t w = (i + 1) >> 6; w < nwords; ++w) {
+            const uint64_t m = w == ((i + 1) >> 6) ? (mask[w] >> ((i + 1) & 63u)) << ((i + 1) & 63u) : mask[w];
+            if (m) { const uint32_t q = 64u * w + (uint32_t)__builtin_ctzll(m); e = q < n ? q : n; break; }
+        }
+        return e;
+    };
+    // the tokens of one run of r lengths v: counted (write = false) or written from token `ntok` / bit `bits` on; returns tokens | bits << 16
+    auto code_run = [&](uint32_t v, uint32_t run, bool write, uint32_t ntok, uint32_t bits) -> uint32_t {
+        const uint32_t n0 = ntok, b0 = bits;
+        auto emit = [&](uint32_t sym, uint32_t ebits, uint32_t eval) { uint32_t nb; const uint32_t c = cl_code(sym, nb); if (write) s_clt[ntok] = (c | (eval << nb)) | ((nb + ebits) << 12) | (bits << 16); ++ntok; bits += nb + ebits; };
+        if (v) {
+            emit(v, 0, 0); --run;
+            while (run >= 3) { const uint32_t r = run < 6u ? run : 6u; emit(16, 2, r - 3u); run -= r; }
+            while (run) { emit(v, 0, 0); --run; }
+        } else {
+            while (run >= 11) { const uint32_t r = run < 138u ? run : 138u; emit(18, 7, r - 11u); run -= r; }
+            if (run >= 3) { emit(17, 3, run - 3u); run = 0; }
+            while (run) { emit(0, 0, 0); --run; }
+        }
+        return (ntok - n0) | ((bits - b0) << 16);
+    };
+    {
+        // first symbols: run starts below hlit
+        const bool is0 = (uint32_t)tid < hlit && ((s_mask[wave] >> lane) & 1ull);
+        const uint32_t v0 = len[tid];
+        uint32_t r0 = 0, c0 = 0;
+        if (is0) { r0 = run_end(s_mask, 5, (uint32_t)tid, hlit) - (uint32_t)tid; c0 = code_run(v0, r0, false, 0, 0); }
+        uint32_t tot0;
+        const uint32_t ex0 = block_excl_scan(c0, s_scan, &tot0);      // tokens in the low half, bits in the high half (<= 320 / <= 3 800)
+        if (is0) (void)code_run(v0, r0, true, ex0 & 0xFFFFu, ex0 >> 16);
+        if (wave == 0) {
+            // symbols 256 .. hlit - 1, then the distance lengths: lanes 0 .. 29 of this wave, in order behind the first symbols
+            const uint32_t i1 = 256u + (uint32_t)lane;
+            const bool is1 = lane < GZ_NLIT - 256 && i1 < hlit && ((s_mask[4] >> lane) & 1ull);
+            const uint32_t v1 = len[256 + (lane < GZ_NLIT - 256 ? lane : 0)];
+            uint32_t r1 = 0, c1 = 0;
+            if (is1) { r1 = run_end(s_mask, 5, i1, hlit) - i1; c1 = code_run(v1, r1, false, 0, 0); }
+            const uint32_t in1 = wave_incl_scan(c1), tot1 = (uint32_t)__shfl((int)in1, 63);
+            const uint32_t at1 = tot0 + in1 - c1;
+            if (is1) (void)code_run(v1, r1, true, at1 & 0xFFFFu, at1 >> 16);
+            const bool is2 = (uint32_t)lane < hdist && ((s_mask[5] >> lane) & 1ull);
+            const uint32_t v2 = s_dsub[lane < 64 ? lane : 0];
+            uint32_t r2 = 0, c2 = 0;
+            if (is2) { r2 = run_end(s_mask + 5, 1, (uint32_t)lane, hdist) - (uint32_t)lane; c2 = code_run(v2, r2, false, 0, 0); }
+            const uint32_t in2 = wave_incl_scan(c2), tot2 = (uint32_t)__shfl((int)in2, 63);
+            const uint32_t at2 = tot0 + tot1 + in2 - c2;
+            if (is2) (void)code_run(v2, r2, true, at2 & 0xFFFFu, at2 >> 16);
+            if (lane == 0) { const uint32_t all = tot0 + tot1 + tot2; s_hdr[0] = all >> 16; s_hdr[1] = hlit - 257u; s_hdr[2] = hdist - 1u; s_hdr[3] = all & 0xFFFFu; }
+        }
+    }
+    if (probe::off(1 << 27)) { __syncthreads(); return; }         // (analysis builds: ... + the block header's tokens)
 
     // ---- pass 2: bits of this lane's span; scan; this member's size and its byte offset by look-back over the chunks ----
     uint32_t bits = 0;
