@@ -20,9 +20,9 @@
 //   lines   '\n' masks of the spans -> scan -> the chunk's line starts in LDS
 //   parse   name lines inside the span: greedy matches (>= 3 bytes, never across the span's or the line's end), up to GZ_MAXM per span, kept in LDS
 //   pass 1  histograms of literals / lengths / distances (LDS atomics into 8 sub-histograms) + CRC-32 of the span (slicing-by-4)
-//   codes   two Huffman codes by repeated merging of the two lightest trees -- the two minima by one block-wide reduction per merge, a lane
-//           owning symbols tid and 256 + tid -- counts halved until no code is longer than 15 bits; canonical codes; the code lengths of the
-//           block header run-length coded (symbols 16 / 17 / 18) by one lane
+//   codes   two Huffman codes (literals / lengths, distances): used symbols rank-sorted, one lane's two-queue merge per alphabet, depths by walking
+//           the parents; counts halved until no code is longer than 15 bits; canonical codes with ranks by ballots; the code lengths of the
+//           block header run-length coded (symbols 16 / 17 / 18), every run by the lane that starts it
 //   pass 2  bits per span -> block scan -> decoupled look-back over the chunks for the member's byte offset
 //   pass 3  every lane packs its span's codes LSB-first into an IMAGE OF THE MEMBER IN LDS (OR for the words two spans share); CRC-32 of
 //           the spans joined by a tree of x^(8 L) shifts; then the image leaves with plain, coalesced word stores.
