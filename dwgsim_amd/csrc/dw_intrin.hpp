@@ -34,6 +34,9 @@ DW_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) 
 // every store this wave has issued has been acknowledged by the L2 (a workgroup ends without waiting for its stores)
 DW_DEV void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// issue priority of this wave among the waves of its SIMD (s_setprio 0 .. 3)
+DW_DEV void wave_priority(int p) { if (p) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+
 // IEEE-754 binary64 x / y and sqrt(x) for operands far from the ends of the exponent range and without special values:
 // exactly the Newton-Raphson + correction sequences the compiler emits for `/` and sqrt() on gfx950 (LLVM AMDGPU LowerFDIV64 /
 // lowerFSQRTF64) minus their v_div_scale / v_div_fixup / ldexp / class-test range handling, which is the identity on such

@@ -23,6 +23,7 @@ DW_DEV uint32_t lut8(uint32_t hi, uint32_t lo, uint32_t sel)
 DW_DEV void keep_scalar(uint32_t &, uint32_t &) {}
 DW_DEV uint32_t xcc_id() { return (uint32_t)blockIdx.x & 7u; }      // block b runs on XCD b % 8 (what the hardware is observed to do)
 DW_DEV void wait_stores() {}
+DW_DEV void wave_priority(int) {}
 DW_DEV double div_mid(double x, double y) { return x / y; }
 DW_DEV double sqrt_mid(double x) { return sqrt(x); }
 } // namespace dw
