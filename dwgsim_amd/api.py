@@ -298,6 +298,9 @@ class Context:
         self.h = self.lib.dwgsim_hip_create(C.byref(params), device, C.byref(err))
         if not self.h:
             raise DwgsimError(f"dwgsim_hip_create failed with code {err.value}" + (" (no HIP device? there is no CPU fallback)" if err.value == -2 else " (the library said why on stderr)"))
+        for kv in os.environ.get("DWGSIM_HIP_DEBUG", "").split(","):      # analysis only: "ion_lds=2,flow_slots=3" -> dwgsim_hip_debug_option on every context
+            if "=" in kv:
+                self.lib.dwgsim_hip_debug_option(self.h, kv.split("=")[0].encode(), int(kv.split("=")[1]))
 
     def close(self):
         if self.h:

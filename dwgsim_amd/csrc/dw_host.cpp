@@ -129,6 +129,7 @@ struct dwgsim_hip_ctx {
     bool has_carry_override = false; uint64_t carry_override = 0;
     int flow_cap_forced = 0;               // "flow_cap" (tests): the capacity a job starts from, instead of flow_read_capacity()
     int flow_cap_mult = 1;                 // Ion Torrent: the read capacity is flow_read_capacity() times this; doubled when a read outgrew it (the reference doubles its buffers, dwgsim.c:296-311)
+    int ion_lds = -1;                      // "ion_lds" (tests): where the Ion Torrent read buffers live (fill_sim_args)
     int n_cu = 0; int flow_slots = 0;      // compute units of the device; "flow_slots": scratch slots per XCD forced by the tests (0: as many as an XCD can hold blocks)
     int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0; int split = -1;      // dwgsim_hip_debug_option / _debug_get
     hipEvent_t ev_cnt0 = nullptr, ev_cnt1 = nullptr;
@@ -364,14 +365,6 @@ static int flow_read_capacity(int len, double e, const std::vector<uint8_t> &flo
     return len + 64 + (int)(len * 4.0 * g);
 }
 
-// the largest entry of the kernels' flow-distance table: flows from a flow (inclusive) to the next flow of a base
-static int flow_max_gap(const std::vector<uint8_t> &flow)
-{
-    const int F = (int)flow.size(); int mx = 0;
-    for (int f = 0; f < F; ++f) for (uint8_t b = 0; b < 4; ++b) { int k = 0, g = f; while (flow[(size_t)g] != b && k < F) { ++k; g = g + 1 == F ? 0 : g + 1; } if (k > mx) mx = k; }
-    return mx;
-}
-
 static int set_err(int *err, int v) { if (err) *err = v; return v; }
 
 dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, int *err)
@@ -434,11 +427,12 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 CalibArgs ca;
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
-                ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size(); ca.flow_maxk = flow_max_gap(c->flow);
+                ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
                 const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
                 for (int mult = 1; mult <= 16; mult *= 2) {       // a read that outgrows its buffers: once more with twice the room (the reference doubles its buffers, dwgsim.c:296-311)
-                    ca.cap = flow_read_capacity(len, e, c->flow) * mult; ca.lds_words = (ca.cap + 7) / 8;
-                    if (ensure(c, c->flow_scratch, (size_t)flow_words_per_lane(ca.lds_words, ca.cap) * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
+                    ca.lds_words = (flow_read_capacity(len, e, c->flow) * mult + 15) / 16;       // the flow model's one buffer per lane: 16 bases per word
+                    ca.stack_words = std::min(FLOW_STACK_WORDS * mult, FLOW_STACK_WORDS_MAX);
+                    if (ensure(c, c->flow_scratch, (size_t)ca.lds_words * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
                     ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
                     HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
                     launch_calibrate(c->stream, ca);
@@ -1207,8 +1201,21 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
         a.cap = (c->flow_cap_forced > 0 ? c->flow_cap_forced : flow_read_capacity(lmax, emax, c->flow)) * c->flow_cap_mult;
     }
     a.lds_words = (a.cap + 7) / 8;
-    a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size(); a.flow_maxk = flow_max_gap(c->flow);
+    a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
     a.flow_scratch = nullptr; a.flow_free = nullptr; a.flow_slots = 0;
+    if (p.data_type == 2) {
+        // the flow model's one in-place buffer per lane, 2 bits per base (dw_read.hpp flow_errors), and the run stack of its pass 2.  In LDS while at
+        // least two 256-lane blocks -- or else four one-wave blocks -- fit a CU; beyond that (very long reads, error rates at which reads grow
+        // severalfold) in scratch slots of global memory ("ion_lds": 0 slots, 1 / 2 LDS with 256 / 64 lanes, -1 choose)
+        a.lds_words = (a.cap + 15) / 16; a.cap = 16 * a.lds_words;
+        a.flow_stack_words = std::min(FLOW_STACK_WORDS * c->flow_cap_mult, FLOW_STACK_WORDS_MAX);
+        const size_t per_lane = (size_t)(a.lds_words + a.flow_stack_words);
+        const size_t need256 = sim_lds_bytes(per_lane, SIM_THREADS, (size_t)c->qb_words, true), need64 = sim_lds_bytes(per_lane, SIM_THREADS_LONG, (size_t)c->qb_words, true);
+        int mode = c->ion_lds;
+        if (mode < 0) mode = (need256 <= SIM_LDS_BUDGET && sim_blocks_per_cu(need256, 8) >= 2) ? 1 : (need64 <= SIM_LDS_BUDGET && sim_blocks_per_cu(need64, 32) >= 4) ? 2 : 0;
+        if ((mode == 1 && need256 > SIM_LDS_BUDGET) || (mode == 2 && need64 > SIM_LDS_BUDGET)) mode = 0;
+        a.ion_lds = mode != 0; a.sim_threads = mode == 2 ? SIM_THREADS_LONG : SIM_THREADS;
+    }
     // Short Illumina reads run as two kernels with the offsets computed in between (dw_simulate.hip SPLIT): no look-backs, and the second half --
     // no staged bases in LDS -- writes the text in 64-byte bursts.  What does not scale with the read length (placement, the look-backs, the name)
     // is most of the work there: 2 x 36 / 2 x 50 / 2 x 75 bp and 100 bp single-end run 16 / 17 / 9 / 15 % faster than in the single kernel, 2 x 100
@@ -1355,16 +1362,16 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
         if (ensure(c, c->meta, sizeof(uint32_t) * ((size_t)n_pairs + 8))) return DWGSIM_HIP_ERR_DEVICE;      // (+ padding for 16-byte reads)
         const size_t nfb = (size_t)((n_pairs + 256ull * 64 - 1) / (256ull * 64));
         if (ensure(c, c->fail_summ, (nfb * 4 + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;
-        if (p.data_type == 2 || a.sim_threads != SIM_THREADS) {
+        if (p.data_type == 2 ? !a.ion_lds : a.sim_threads != SIM_THREADS) {
             // read buffers (Ion Torrent) / staged reads (one-wave blocks): one slot per block an XCD can hold at a time -- what the LDS admits per CU, at most the eight waves of a SIMD (registers can only
             // lower it; too few slots would make blocks wait, never fail) --, handed from block to block inside the XCD (dw_simulate.hip scratch_slot_take)
             const int cu_per_xcd = (c->n_cu >= 64 && c->n_cu % 8 == 0) ? c->n_cu / 8 : c->n_cu;
             const bool ion = p.data_type == 2;
-            const int per_cu = ion ? sim_blocks_per_cu(sim_lds_bytes((size_t)(FLOW_STACK_RUNS / 2), SIM_THREADS, (size_t)a.qb_words, a.fifo != 0), 8)
+            const int per_cu = ion ? sim_blocks_per_cu(sim_lds_bytes((size_t)a.flow_stack_words, SIM_THREADS, (size_t)a.qb_words, a.fifo != 0), 8)
                                    : sim_blocks_per_cu(sim_lds_bytes(0, SIM_THREADS_LONG, (size_t)a.qb_words, true), 32);       // (one-wave blocks: up to eight per SIMD)
             a.flow_slots = c->flow_slots > 0 ? c->flow_slots : cu_per_xcd * per_cu;
             if ((uint64_t)a.flow_slots > (uint64_t)nblk) a.flow_slots = (int32_t)nblk;
-            const size_t words = (ion ? (size_t)flow_words_per_lane(a.lds_words, a.cap) * (size_t)SIM_THREADS : (size_t)a.lds_words * (size_t)SIM_THREADS_LONG) * (size_t)a.flow_slots * 8;
+            const size_t words = (ion ? (size_t)flow_words_per_lane(a.lds_words) * (size_t)SIM_THREADS : (size_t)a.lds_words * (size_t)SIM_THREADS_LONG) * (size_t)a.flow_slots * 8;
             if (ensure(c, c->flow_scratch, words * sizeof(uint32_t)) || ensure(c, c->flow_free, sizeof(uint64_t) * (256 + 8 * (size_t)nblk))) return DWGSIM_HIP_ERR_DEVICE;
             a.flow_scratch = (uint32_t *)c->flow_scratch.p; a.flow_free = (uint64_t *)c->flow_free.p;
         }
@@ -1666,6 +1673,7 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "place_cap")) c->place_cap = value;
     else if (!strcmp(key, "split")) c->split = (int)value;
     else if (!strcmp(key, "flow_slots")) c->flow_slots = (int)value;
+    else if (!strcmp(key, "ion_lds")) c->ion_lds = (int)value;
     else if (!strcmp(key, "flow_cap")) c->flow_cap_forced = (int)value;
     else { c->err = "unknown debug option"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;

@@ -381,6 +381,12 @@ int dispatch_pending(dwgsim_hip_job *j)
         j->stage_busy[g->stage_slot] = false; j->cv.notify_all();
         return DWGSIM_HIP_OK;
     }
+    {   // the sequences in the staging as it stands now (begin_contig may have reallocated it after earlier commits, also for a contig that was then skipped)
+        std::vector<int64_t> starts(g->lens.size());
+        (void)dwgsim_hip_group_layout(g->lens.data(), (int)g->lens.size(), starts.data());
+        g->ptrs.clear();
+        for (size_t k = 0; k < g->lens.size(); ++k) g->ptrs.push_back(j->stage[g->stage_slot] + starts[k]);
+    }
     // the group's pairs in file order, cut into batches; batch b belongs to device b mod nd
     g->pairs = 0; for (int64_t n : g->n_pairs) g->pairs += (uint64_t)n;
     g->nd = j->ND;
@@ -554,7 +560,7 @@ uint8_t *dwgsim_hip_job_begin_contig(dwgsim_hip_job_t *j, const char *name, int6
     std::vector<int64_t> starts(lens.size());
     const int64_t total = dwgsim_hip_group_layout(lens.data(), (int)lens.size(), starts.data());
     const int s = g.stage_slot;
-    if ((size_t)total > j->stage_cap[s]) {      // grow, keeping what the group already holds
+    if (!j->stage[s] || (size_t)total > j->stage_cap[s]) {      // grow, keeping what the group already holds (an empty record that opens a group on a fresh slot still needs somewhere to point)
         const size_t want = std::max<size_t>((size_t)total + (size_t)total / 4, std::max<size_t>(j->stage_want, (size_t)std::min<uint64_t>(j->group_bp, 256u << 20) + 8192));
         uint8_t *nb = (uint8_t *)dwgsim_hip_host_alloc(want);
         if (!nb) { job_fail(j, "dwgsim-hip: cannot allocate page-locked host memory for the sequence"); return out(DWGSIM_HIP_ERR_NOMEM); }
@@ -613,11 +619,7 @@ int64_t dwgsim_hip_job_commit_contig(dwgsim_hip_job_t *j)
         j->n_sim += n_pairs;
     }
     j->pending_bytes = (size_t)j->open.total;
-    g.names.push_back(name); g.lens.push_back(l); g.l_eff.push_back(l_eff); g.n_pairs.push_back(n_pairs); g.cindex.push_back(ci);
-    std::vector<int64_t> starts(g.lens.size());
-    (void)dwgsim_hip_group_layout(g.lens.data(), (int)g.lens.size(), starts.data());
-    g.ptrs.clear();
-    for (size_t k = 0; k < g.lens.size(); ++k) g.ptrs.push_back(j->stage[s] + starts[k]);
+    g.names.push_back(name); g.lens.push_back(l); g.l_eff.push_back(l_eff); g.n_pairs.push_back(n_pairs); g.cindex.push_back(ci);      // (where the sequences stand is resolved at dispatch: the staging may still move)
     if (j->pending_bytes >= (size_t)j->group_bp) { if (dispatch_pending(j) < 0) return DWGSIM_HIP_ERR_FAILED; }
     return n_pairs;
 }
@@ -627,7 +629,7 @@ int64_t dwgsim_hip_job_add_contig(dwgsim_hip_job_t *j, const char *name, const u
     if (j && !ascii && l > 0) return arg_error(j, DWGSIM_HIP_ERR_ARG, "job: bad contig arguments");
     int64_t st = 0;
     uint8_t *dst = dwgsim_hip_job_begin_contig(j, name, l, &st);
-    if (!dst) return st;
+    if (st < 0 || !dst) return st < 0 ? st : arg_error(j, DWGSIM_HIP_ERR_STATE, "job: begin_contig returned no place for the sequence");      // (the status decides, not the pointer)
     if (l > 0) memcpy(dst, ascii, (size_t)l);
     return dwgsim_hip_job_commit_contig(j);
 }

@@ -12,7 +12,8 @@ constexpr int PLACE_LISTS = 64;          // k_place hands the pairs it cannot de
 #define DW_SIM_THREADS 256
 #endif
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
-constexpr int FLOW_STACK_RUNS = 32;           // Ion Torrent pass 2: (base, count) runs that can be pending in front of the examined base (two per LDS word)
+constexpr int FLOW_STACK_WORDS = 4;           // Ion Torrent pass 2: LDS words per lane for the (base, count) runs that can be pending in front of the examined base (two per word), times the
+constexpr int FLOW_STACK_WORDS_MAX = 32;      // ... capacity multiplier of the job (a read that outgrows the stack is run again like one that outgrows its buffer), up to this many
 constexpr int SIM_THREADS_LONG = 64;          // ... one-wave blocks for reads of ~650 bases and more: their bases are staged in scratch slots, not LDS
 constexpr int SIM_FIFO_BYTES = 40;            // per lane: the text FIFO of the record writer (one 32-byte burst + the overshoot of an 8-byte put)
 constexpr int SIM_FIFO_BYTES_WIDE = 72;       // ... with 64-byte bursts (second half of the two-kernel form: no staged bases compete for LDS)
@@ -96,20 +97,17 @@ struct SimParams {
 struct CalibArgs {
     uint32_t seed; int32_t end, len; uint64_t n_reads;
     uint64_t thr;                   // ceil(e * 2^32) of the uncalibrated -e
-    const uint8_t *flow; int32_t flow_len, cap, lds_words, flow_maxk;
-    uint32_t *scratch;              // per block [lds_words + (cap + 15) / 16][PAIRS_PER_BLOCK] words
+    const uint8_t *flow; int32_t flow_len, lds_words, stack_words;       // lds_words: words per lane of the read buffer (16 bases each)
+    uint32_t *scratch;              // per block [lds_words][PAIRS_PER_BLOCK] words
     uint64_t *counters;             // [8] += errors, [9] += read lengths after errors, [2] |= 2 on a buffer overflow
 };
 
 constexpr int SUMM_CELLS = 64;          // cells per haplotype-summary word (k_summarize / k_place)
 constexpr int SUMM2_CELLS = 1024;       // ... of the coarse level: bits 0-14 INSERT / DELETE cells, bit 15 a base code >= 4 (16 fine words each)
 
-// Ion Torrent scratch: words per lane of one block's read buffers (4-bit buffer + 2-bit pass-1 buffer), forced odd so that the
-// blocks' areas do not all start on the same HBM channels (a 96 KB stride cost 14 % against 89 KB)
-// Ion Torrent scratch of one lane: the read at 4 bits per base (lds_words), the pass-1 output at 2 bits, and the hit bitmap of the first
-// flow_hit_bits(cap) empty flows of pass 2 (later ones -- long cascades -- are drawn one by one)
-inline constexpr int flow_hit_bits(int cap) { return (2 * cap + 256 + 31) & ~31; }
-inline constexpr int flow_words_per_lane(int lds_words, int cap) { return (lds_words + ((cap + 15) >> 4) + (flow_hit_bits(cap) >> 5)) | 1; }
+// Ion Torrent read buffers in a scratch slot (DT = 2): words per lane, forced odd so that the blocks' areas do not all start on the same HBM
+// channels (a 96 KB stride cost 14 % against 89 KB)
+inline constexpr int flow_words_per_lane(int lds_words) { return lds_words | 1; }
 
 // One read-index range of one contig inside a k_simulate / k_place launch.  A launch covers n_seg of them, in file order; a block never spans two.
 struct SimSeg {
@@ -149,19 +147,20 @@ struct SimArgs {
     uint64_t *counters;            // this batch's slot: [0] ticket, [1] retries, [2] fail flags, [3] total random, [4..6] stream bytes, [16..19] abort-rule segment of the batch, [20] abort, [21] carry out
     uint64_t *status[4];           // look-back words: record bytes of stream BWA1 / BWA2, random-read count, (SOLiD) BFAST bytes
     uint8_t *out[3];               // packed FASTQ text: bwa read1, bwa read2, bfast
-    int32_t lds_words;             // uint32 words of packed bases per lane (per buffer)
-    int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors
+    int32_t lds_words;             // uint32 words of packed bases per lane: 8 bases per word; Ion Torrent: 16 per word, the flow model's one in-place buffer
+    int32_t cap;                   // Ion Torrent: capacity (bases) of a read after flow errors = 16 lds_words
+    int32_t ion_lds;               // Ion Torrent: 1 = the read buffers are in LDS (k_simulate<.., 3>), 0 = in scratch slots (k_simulate<.., 2>)
+    int32_t flow_stack_words;      // Ion Torrent: LDS words per lane of the pass-2 run stack (two runs per word)
     int32_t fifo;                 // 1: the records leave through the per-lane LDS FIFO (32-byte aligned bursts); 0: 16-byte pieces straight from registers (when the FIFO would cost a block per CU)
     int32_t sim_threads;          // lanes per k_simulate block chosen by the host: SIM_THREADS, or SIM_THREADS_LONG for long reads
     int32_t flow_len;              // Ion Torrent: length of the flow order (<= 64)
-    int32_t flow_maxk;             // ... and the largest number of flows between a flow and the next flow of some base (flow_max_gap)
     int32_t split;                 // 1: k_simulate runs as two kernels (dw_simulate.hip SPLIT) handing their state over through the arrays below
     uint32_t *split_state;         // per block [lds_words][lanes]: the staged bases after the error phase
     uint32_t *split_hand;          // per lane 16 bytes: ext_coor | n_err, n_sub | n_indel, n_ins | attempt, flags
     uint32_t *split_agg;           // per block 16 bytes: random pairs, bytes of stream 1 / 2 (without random reads' hexadecimal digits)
     uint64_t *split_pre;           // per block 4 words: random reads / bytes of stream 1 / bytes of stream 2 in front of it inside its chunk of 1024 blocks (k_split_scan1)
     uint64_t *split_chunk;         // per chunk 4 words: the chunk's sums (k_split_scan1), then the sums in front of the chunk (k_split_scan2)
-    uint32_t *flow_scratch;        // Ion Torrent: read buffers of one block per SLOT, flow_words_per_lane words per lane, word w of lane t at [w * nthr + t]
+    uint32_t *flow_scratch;        // scratch slots: the staged reads of one block per SLOT (Ion Torrent DT = 2: flow_words_per_lane words per lane), word w of lane t at [w * nthr + t]
     uint64_t *flow_free;           // ... the slots' free lists, one per XCD (dw_simulate.hip scratch_slot_take): 256 header words + 8 x n_blocks queue words, zeroed per launch
     int32_t flow_slots;            // ... slots per XCD (8 x flow_slots slots in flow_scratch)
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes

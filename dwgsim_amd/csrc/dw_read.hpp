@@ -12,7 +12,7 @@ namespace dw {
 // ------------------------------------------------------------------------------------------------
 struct ReadRes { int32_t ext_coor, n_sub, n_indel, num_n, n_ins; };   // n_ins: INSERT cells crossed (the reference's n_indel_first, dwgsim.c:98)
 
-// dwgsim.c:75-153 __gen_read.  STORE: packed 4-bit bases go to lds[word * stride].
+// dwgsim.c:75-153 __gen_read.  The packed 4-bit bases go to `sink`, eight at a time.
 // The haplotype is read through its 4-bit view (HapDev::view).  A read's window of the view sits at a random place of a contig that no cache
 // of the chip holds for the ~10^5 lanes in flight: what the extraction costs is the memory round trips it takes one after the other, not
 // its arithmetic.  So the window of the next 23 staged words (184 cells) is fetched by up to six 16-byte loads issued TOGETHER -- one round
@@ -34,8 +34,38 @@ DW_DEV uint32_t reverse_nibbles32(uint32_t x)
 }
 struct __attribute__((packed, aligned(4))) ViewQuad { uint32_t a, b, c, d; };      // four consecutive words of the view at a 4-byte aligned address: one dwordx4 load
 constexpr int WIN_CHUNKS = 6, WIN_WORDS = 4 * WIN_CHUNKS - 1;                    // 16-byte blocks per window; staged words it serves
-template <bool STORE>
-DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, uint32_t *lds, int stride)
+// where the extracted bases go: put(kw, codes, n) receives word kw of the read -- bases 8 kw .. 8 kw + n - 1 as 4-bit codes (0-3 ACGT, 4 N), nothing
+// above them -- in rising order of kw, each word once
+struct NoSink { DW_DEV void put(int, uint32_t, int) const {} };                                           // k_place: only the verdict is wanted
+struct WordSink { uint32_t *lds; int stride; DW_DEV void put(int kw, uint32_t codes, int) const { lds[kw * stride] = codes; } };      // word kw of this lane at lds[kw * stride]
+DW_DEV uint32_t nibbles_to_pairs(uint32_t v)      // eight nibbles holding 0 .. 3 -> sixteen bits
+{
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; return (v | (v >> 8)) & 0xFFFFu;
+}
+DW_DEV uint32_t pairs_to_nibbles(uint32_t v)      // sixteen bits -> eight nibbles holding 0 .. 3
+{
+    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; return (v | (v << 2)) & 0x33333333u;
+}
+DW_DEV uint32_t reverse_pairs16(uint32_t v)       // the eight 2-bit fields of v[15:0] in reverse order
+{
+    v = __builtin_bitreverse32(v) >> 16;          // bits reversed: the fields are in place, each with its two bits swapped
+    return ((v & 0x5555u) << 1) | ((v >> 1) & 0x5555u);
+}
+// Ion Torrent: the flow model (flow_errors below) works on 2-bit bases with N read as A (dwgsim.c:253-257), in place, on ONE buffer per lane: base
+// position p of the buffer = pair p & 15 of word p >> 4 (at buf[(p >> 4) * stride]).  A forward read goes to positions h0 * 8 .. in order; a
+// reverse-strand read is stored turned round (dwgsim.c:259-265: reversed, not complemented) with its last extracted base at the buffer's top.
+struct FlowSink {
+    uint32_t *buf; int stride, h0; bool rev;      // h0: the 16-bit piece (eight bases) that word 0 goes to; rev: pieces fall from there, each turned round
+    DW_DEV void put(int kw, uint32_t codes, int) const
+    {
+        uint32_t p = nibbles_to_pairs(codes & 0x33333333u & ~(((codes >> 2) & 0x11111111u) * 3u));
+        if (rev) p = reverse_pairs16(p);
+        const int h = rev ? h0 - kw : h0 + kw;
+        reinterpret_cast<uint16_t *>(buf + (h >> 1) * stride)[h & 1] = (uint16_t)p;
+    }
+};
+template <class Sink>
+DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int s, int strand, const Sink &sink)
 {
     ReadRes r{-10, 0, 0, 0, 0};
     const bool fwd = step > 0;
@@ -47,7 +77,7 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         if (strand) v = v < 4 ? 3 - v : 4;             // dwgsim.c:150-152
         r.num_n += (v == 4);                            // dwgsim.c:824-831
         accw |= v << (4 * na); ++k;
-        if (++na == 8) { if (STORE) lds[((k >> 3) - 1) * stride] = accw; accw = 0; na = 0; }
+        if (++na == 8) { sink.put((k >> 3) - 1, accw, 8); accw = 0; na = 0; }
     };
     const uint32_t *const vw = reinterpret_cast<const uint32_t *>(h.view);
     while (k < s) {
@@ -90,7 +120,7 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
                     if (strand) codes = (codes ^ 0x33333333u) & ~((n8 >> 3) * 3u);          // complement, dwgsim.c:150-152 (N stays N)
                     if (want < 8) codes &= (1u << (4 * want)) - 1u;
                     codes |= n8 >> 1;                                                        // N = code 4
-                    if (STORE) lds[(k >> 3) * stride] = codes;
+                    sink.put(k >> 3, codes, want);
                     k += want; i += fwd ? want : -want;
                 }
             }
@@ -126,7 +156,7 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         if (k < 0) break;
     }
     if (k != s) { r.ext_coor = -10; return r; }
-    if (STORE && na) lds[(k >> 3) * stride] = accw;      // the ragged last word of an episode
+    if (na) sink.put(k >> 3, accw, na);      // the ragged last word of an episode
     return r;
 }
 
@@ -279,18 +309,13 @@ DW_DEV void read_geom(const SimArgs &a, const SegCtx &sc, const PairDraw &pd, in
 }
 
 // ---- Ion Torrent flow-space errors: dwgsim.c:246-417 generate_errors_flows ----
-// The reference edits the read in place; both passes only ever insert/delete at the position being
-// examined, so they are replayed as transducers over packed arrays in the block's global scratch (word w of a
-// lane at base[w * stride]; flow_errors below says how).  Draws: narrow uniforms of domain D_FLOW0 + read end.  The
-// flow mask is per read (the reference's persistent mask is fully rewritten by every read's pass 1).
-// word-cached access to a lane's packed array (BITS = 4: codes 0-5): the event code looks at single bases
-template <int BITS>
-struct PackReader {
-    static constexpr int PER = 32 / BITS, SH = BITS == 4 ? 3 : 4; static constexpr uint32_t M = (1u << BITS) - 1;
-    const uint32_t *base; int stride, cw; uint32_t word;
-    DW_DEV void init(const uint32_t *b, int st) { base = b; stride = st; cw = -1; word = 0; }
-    DW_DEV uint32_t get(int i) { const int w = i >> SH; if (w != cw) { cw = w; word = base[w * stride]; } return (word >> ((i & (PER - 1)) * BITS)) & M; }
-};
+// The reference edits the read in place with memmoves; both passes only ever insert / delete at the position being examined, so they are replayed
+// as transducers over ONE packed buffer per lane, 2 bits per base (the model reads N as A, dwgsim.c:253-257, and never produces anything but
+// ACGT), IN PLACE: the input of a pass stands right-aligned at the buffer's top, its output grows from position 0 and can never catch up with the
+// read pointer while the read fits the buffer (output - input = net growth <= room).  So a lane's whole state is cap / 4 bytes -- in LDS (word w of
+// a lane at buf[w * stride]) -- where rounds 1-4 kept a 4-bit buffer, a 2-bit buffer and two bitmaps of first draws per lane in a global scratch of
+// 150 KB per block (5 x the algorithmic HBM traffic, profiles/r04_ion_*).
+// Draws: dw_common.hpp D_FLOW0.  The flow mask is per read (the reference's persistent mask is fully rewritten by every read's pass 1).
 // First draws of the flow model's events as bits: bit k of the result = (first uniform of event 8 * blk + k) < e, e as thr = e * 2^32
 // (dw_common.hpp D_FLOW0: sixteen-bit halves, the low halves drawn only when a high half ties with thr's).
 DW_DEV uint32_t flow_hits8(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t blk, uint64_t thr)
@@ -327,13 +352,17 @@ struct FlowRng {             // scalar members + value selects only: keeps the g
     // leaves this loop; 2^14 errors in one flow already overflow every buffer, so the caller reports the read as outgrown.
     DW_DEV int more_errors(uint64_t thr) { int n = 1; while ((uint64_t)next() < thr && n < (1 << 14)) ++n; return n; }
 };
-// A lane's packed array with word-wide access (word w at base[w * stride], nw words; indices outside read as zero):
-// get8(p): the eight 4-bit codes at nibble positions p .. p + 7 (p may be negative), get8x2(p): eight 2-bit bases at positions p .. p + 7
-struct WordView {
+// A lane's 2-bit packed buffer (word w at base[w * stride], nw words; a word beyond the end reads as zero)
+struct Buf2 {
     const uint32_t *base; int stride, nw;
-    DW_DEV uint32_t word(int w) const { return (w >= 0 && w < nw) ? base[(size_t)w * stride] : 0u; }
-    DW_DEV uint32_t get8(int p) const { const int w = p >> 3; return __builtin_amdgcn_alignbit(word(w + 1), word(w), ((uint32_t)p & 7u) * 4u); }
-    DW_DEV uint32_t get8x2(int p) const { const int w = p >> 4; return __builtin_amdgcn_alignbit(word(w + 1), word(w), ((uint32_t)p & 15u) * 2u) & 0xFFFFu; }
+    DW_DEV uint32_t word(int w) const { return w < nw ? base[w * stride] : 0u; }
+    DW_DEV uint32_t get8(int p) const      // the eight bases at positions p .. p + 7 (p >= 0) as sixteen bits
+    {
+        const int w = p >> 4; const uint32_t sh = ((uint32_t)p & 15u) * 2u;
+        const uint32_t lo = word(w), hi = sh > 16u ? word(w + 1) : 0u;
+        return __builtin_amdgcn_alignbit(hi, lo, sh) & 0xFFFFu;
+    }
+    DW_DEV uint32_t get1(int p) const { return (word(p >> 4) >> (((uint32_t)p & 15u) * 2u)) & 3u; }
 };
 // Appends BITS-bit elements, one or up to 32 / BITS at a time (v: cnt elements, nothing above them), a word is stored whenever one is full
 template <int BITS>
@@ -343,34 +372,54 @@ struct BitAppender {
     DW_DEV void push_many(uint32_t v, int cnt)
     {
         acc |= (uint64_t)v << fill; fill += (uint32_t)cnt * BITS; n += cnt;
-        if (fill >= 32u) { base[(size_t)wi * stride] = (uint32_t)acc; ++wi; acc >>= 32; fill -= 32u; }
+        if (fill >= 32u) { base[wi * stride] = (uint32_t)acc; ++wi; acc >>= 32; fill -= 32u; }
     }
     DW_DEV void push(uint32_t v) { push_many(v, 1); }
-    DW_DEV void flush() { if (fill) base[(size_t)wi * stride] = (uint32_t)acc; }
+    DW_DEV void flush() { if (fill) base[wi * stride] = (uint32_t)acc; }
 };
-// A lane's bitmap of scoring first draws (word w at base[w * stride], nbits a multiple of 32): the first set bit at or after p, nbits if none
-// (nbits: how far the bitmap has been drawn so far; a search that runs into that frontier returns it, or p when p is already beyond it)
-struct HitMap {
-    const uint32_t *base; int stride; uint32_t nbits;
-    DW_DEV uint32_t next(uint32_t p) const
+// This lane's WINDOW over the first draws of a pass: bit k of `bits` says that the first uniform of event hb + k scores (is below e).  The window
+// lives in registers, slides with the lane (a Philox block = eight events is drawn at its top whenever there is room and some lane of the wave is
+// running short: all lanes draw in step, each its own next block) and is at most 64 events long; a lane that reaches its frontier waits for the
+// next round of draws.  Rounds 3-4 stored whole bitmaps per lane and searched them through memory.
+// oc*: what the FIRST scoring event of the window goes on to draw (dw_common.hpp D_FLOW_EV: further errors, insert-or-delete, the dot-fill flow),
+// drawn ahead of the lane in rounds in which every lane resolves its own next event -- so the event code itself draws nothing, and a lane does
+// not have to wait for others to gather before it can handle one.
+struct FlowWin {
+    uint64_t bits; uint32_t hb, hf;          // events [hb, hb + hf) are drawn; hb is a multiple of 8, hf <= 64
+    uint32_t oc_pos, oc, oc_dot;             // oc: n_err (1 or 2) | 0x100 insert | 0x200 the event draws on (n_err >= 3): taken from FlowRng where it happens
+    DW_DEV void init() { bits = 0; hb = 0; hf = 0; oc_pos = 0xFFFFFFFFu; oc = 0; oc_dot = 0; }
+    DW_DEV uint32_t frontier() const { return hb + hf; }
+    DW_DEV bool room() const { return hf <= 56u; }
+    DW_DEV void advance(uint32_t p)          // the consumer stands at event p >= hb: whole blocks below it leave the window
     {
-        while (p < nbits) {
-            const uint32_t w = base[(size_t)(p >> 5) * stride] >> (p & 31u);
-            if (w) return p + (uint32_t)__ffs((int)w) - 1u;
-            p = (p | 31u) + 1u;
-        }
-        return p > nbits ? p : nbits;
+        const uint32_t k8 = (p - hb) & ~7u;
+        if (k8) { bits = k8 < 64u ? bits >> k8 : 0ull; hf = hf > k8 ? hf - k8 : 0u; hb += k8; }
+    }
+    DW_DEV void draw(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint64_t thr)
+    {
+        const uint32_t b8 = flow_hits8(key, dom, ii, att, (hb + hf) >> 3, thr);
+        bits |= (uint64_t)b8 << hf; hf += 8u;
+    }
+    // the first scoring event at or after p (real), or else how far the lane may go before it needs more draws: the frontier (at least p)
+    DW_DEV uint32_t stop(uint32_t p, bool &real) const
+    {
+        const uint32_t sh = p - hb;
+        const uint64_t m = sh < 64u ? bits >> sh : 0ull;
+        real = m != 0;
+        if (real) return p + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        const uint32_t f = hb + hf;
+        return f > p ? f : p;
+    }
+    DW_DEV void clear(uint32_t pos) { bits &= ~(1ull << (pos - hb)); }       // hb <= pos < hb + 64
+    DW_DEV void resolve(RngKey key, uint32_t dom_ev, uint64_t ii, uint32_t att, uint32_t pos, uint64_t thr)
+    {
+        const U4 b = rng_block(key, dom_ev, ii, att, 0, pos);
+        const bool m0 = (uint64_t)b.x < thr, m1 = (uint64_t)b.y < thr;                // while (drand48() < e) n_err++ (dwgsim.c:296, :373): draws 0, 1, ...
+        const uint32_t insw = m0 ? b.z : b.y;                                         // the draw after the first failing one: insert or delete (dwgsim.c:299)
+        oc_pos = pos; oc_dot = m0 ? b.w : b.z;                                        // ... and the one after that: the dot-fill flow (dwgsim.c:352)
+        oc = (m0 ? 2u : 1u) | (insw < 0x80000000u ? 0x100u : 0u) | ((m0 && m1) ? 0x200u : 0u);
     }
 };
-DW_DEV uint32_t nibbles_reversed(uint32_t v) { v = ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); return __builtin_bswap32(v); }
-DW_DEV uint32_t nibbles_to_pairs(uint32_t v)      // eight nibbles holding 0 .. 3 -> sixteen bits
-{
-    v = (v | (v >> 2)) & 0x0F0F0F0Fu; v = (v | (v >> 4)) & 0x00FF00FFu; return (v | (v >> 8)) & 0xFFFFu;
-}
-DW_DEV uint32_t pairs_to_nibbles(uint32_t v)      // sixteen bits -> eight nibbles holding 0 .. 3
-{
-    v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; return (v | (v << 2)) & 0x33333333u;
-}
 // dist[4 * f + b]: flows from flow f (inclusive) to the first flow of base b, 0 .. F-1 (filled by fill_flow_dist, every base occurs in the order)
 DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, int nthr)
 {
@@ -381,157 +430,155 @@ DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, i
         dist[q] = (uint8_t)k;
     }
 }
-// a batch of parked lanes runs once eight have gathered, or as many as are still running (measured on pass 2: 1 / 2 / 4 / 8 / 16 / 24 / 32 lanes ->
-// 5.66 / 5.36 / 5.17 / 5.06 / 5.15 / 5.37 / 5.55 ms for 848 k reads of 400 bp at e = 0.01; waiting for the last runners alone costs 5 %)
+// lanes waiting for their event's further draws: a round is due once DW_FLOW_BATCH of them wait, or as many as still run (every lane that has an
+// unresolved event in its window takes part in the round, not only the waiting ones)
 #ifndef DW_FLOW_BATCH
 #define DW_FLOW_BATCH 8
 #endif
-DW_DEV bool flow_batch_due(bool parked, bool running)
+DW_DEV bool flow_batch_due(bool waiting, bool running)
 {
-    const uint64_t p = __ballot(parked), r = __ballot(running);
+    const uint64_t p = __ballot(waiting), r = __ballot(running);
     return p && (__popcll(p) >= DW_FLOW_BATCH || __popcll(p) >= __popcll(r));
 }
-// generate_errors_flows (dwgsim.c:246-417).  Every lane of the wave must call this (both passes regroup the lanes of a wave with ballots);
-// lanes without a read pass active = false.  Returns the new length, -1 if a buffer / the pass-2 stack overflowed or the read degenerated.
-// The final read is left in bufA (4-bit) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it is
-// read (dwgsim.c:408-414).  bufB: pass-1 output at 2 bits per base; stk: FLOW_STACK_RUNS (base, count) runs, two per word; bm: this lane's
-// bitmap of scoring first draws (flow_hit_bits(cap) bits), of pass 1 first and then of pass 2.
+// generate_errors_flows (dwgsim.c:246-417).  Every lane of the wave must call this (the loops are wave-uniform); lanes without a read pass
+// active = false.  buf: this lane's buffer of capb bases (a multiple of 16; capb / 16 words).  On entry the read stands where FlowSink put it:
+// forward at positions ((capb - len) & ~7) .. , reverse-strand -- already turned round -- at capb - len .. capb - 1.  On return the read after
+// errors stands at positions 0 .. (result - 1) in the orientation of the flow model; a reverse-strand read is turned back by the caller when it
+// is written (dwgsim.c:408-414).  Returns the new length, or -1 if the read outgrew the buffer / the pass-2 stack (stack_runs (base, count) runs,
+// two per word of stk) or degenerated.
 //
 // Both passes are sequential per read and almost always quiet: the first draw of a position (pass 1) or of an empty flow (pass 2) scores with
-// probability e.  The first draws are made in step, as a bitmap, a word of 32 at a time just ahead of the lane that is furthest along
-// (a read needs about len of pass 1's and 1.6 len of pass 2's; the capacity they are sized for is twice that, and a Philox block per
-// eight draws is the largest single cost of the model); a lane then knows where its next scoring draw is and moves EIGHT
-// bases per iteration up to it -- one word of the packed read, the flow pointer's chain of eight table look-ups, one append -- and only a lane
-// standing on a scoring draw runs the event code.  With 64 lanes some lane scores in almost every iteration, and the event code (a Philox
-// block of its own, homopolymer scans, the run stack) is long: such lanes park, the others run on, and the events are handled for a batch
-// of parked lanes at once.  Each lane still performs exactly its own sequence of operations; only their interleaving changes.
-DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, int maxk, uint64_t thr, uint32_t *bufA, uint32_t *bufB, uint32_t *bm, uint32_t *stk, int stride,
-                       int len, int strand, int cap, int32_t *n_err_out)
+// probability e.  A lane knows from its window (FlowWin) where its next scoring draw is and moves EIGHT bases per iteration up to it -- sixteen
+// bits of the packed read, the flow pointer's chain of eight table look-ups, one append -- and only a lane standing on a scoring draw runs the
+// event code, which is short: what the event draws beyond its first uniform has been drawn ahead, in rounds.  Each lane performs exactly its own
+// sequence of operations; only their interleaving changes.
+DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *buf, uint32_t *stk, int stride, int stack_runs,
+                       int len, int strand, int capb, int32_t *n_err_out)
 {
+    const RngKey key{rg.seed, rg.contig};
     int total = 0, flow_i = 0; bool marked = false; bool failed = !active;
-    const int G0 = flow_hit_bits(cap);
-    auto draw_word = [&](uint32_t dom, uint32_t w) {           // 32 first draws, four Philox blocks, every lane in step
-        if (active) {
-            uint32_t bits = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { if (probe::off(256)) break; bits |= flow_hits8(RngKey{rg.seed, rg.contig}, dom, rg.ii, rg.att, 4u * w + q, thr) << (8 * q); }
-            if (probe::off(4096)) { probe::keep(bits); bits = 0; }
-            bm[(size_t)w * stride] = bits;
-        }
-    };
     auto step_flow = [&](uint32_t k) { flow_i += (int)k; if (flow_i >= F) flow_i -= F; };
+    const int capw = capb >> 4;
+    const Buf2 B{buf, stride, capw};
+    FlowWin W;
 
-    // ---- pass 1 (dwgsim.c:253-364): one error event per homopolymer start whose first draw scores.  Input = bufA (len bases, read
-    // back-to-front when strand == 1, N -> A: dwgsim.c:253-265), output -> bufB.  The output index is the reference's loop index i
-    // (dwgsim.c:281): position i's first draw is bit i of the bitmap. ----
+    // ---- pass 1 (dwgsim.c:253-364): one error event per homopolymer start whose first draw scores.  The output index is the reference's loop
+    // index i (dwgsim.c:281): position i's first draw is event i of the pass. ----
     // The reference's flow mask (dwgsim.c:283-333) never has more than one bit set: a deletion marks the flow the pointer stands on, and the
     // mark is cleared as soon as the pointer moves (the range of skipped flows starts at the pointer) or a new homopolymer starts on that flow --
     // and the pointer stands on the previous base's flow, so both mean "this base differs from the one before".  So the mask is one flag, and
     // what pass 2 sees is that flag together with the final pointer.
-    const uint32_t D1_MAX = (uint32_t)((cap + 31) >> 5) << 5;
-    const WordView inA{bufA, stride, (cap + 7) >> 3};
-    PackReader<4> la; la.init(bufA, stride);
-    auto in1 = [&](int t) -> uint32_t { const uint32_t v = la.get(strand ? len - 1 - t : t); return v >= 4 ? 0u : v; };
-    auto in8 = [&](int t) -> uint32_t {                       // bases t .. t + 7 of the input as nibbles, N -> A
-        uint32_t v = inA.get8(strand ? len - 8 - t : t);
-        v = strand ? nibbles_reversed(v) : v;
-        return v & 0x33333333u & ~(((v >> 2) & 0x11111111u) * 3u);
-    };
-    HitMap hm1{bm, stride, 0u};
-    BitAppender<2> o1; o1.init(bufB, stride);
-    int t = 0; uint32_t prev_c = 4, nh = 0;
+    const int in0 = strand ? capb - len : (capb - len) & ~7;      // where base 0 of the input stands (FlowSink)
+    BitAppender<2> o1; o1.init(buf, stride);
+    int t = 0; uint32_t prev_c = 4;
     if (active) {
-        const uint32_t c0 = in1(0);
+        const uint32_t c0 = B.get1(in0);
         while (flow_i < F && c0 != flow[flow_i]) ++flow_i;
         if (flow_i == F) failed = true;
     }
+    W.init();
     {
         bool done = failed, parked = false;
         for (;;) {
-            // the bitmap stays ahead of every lane: a step looks at up to nine positions (an event that inserts more than that is waited for here)
-            while (__ballot(!done && hm1.nbits < D1_MAX && (uint32_t)o1.n + 16u > hm1.nbits)) {
-                const uint32_t old = hm1.nbits;
-                draw_word(rg.dom, old >> 5);
-                hm1.nbits = old + 32u;
-                if (!done && nh >= old) nh = hm1.next((uint32_t)o1.n > old ? (uint32_t)o1.n : old);
-            }
+            // draws: every lane keeps its window ahead of itself (a step looks at up to eight positions)
+            if (!done) W.advance((uint32_t)o1.n);
+            while (__ballot(!done && W.room() && W.frontier() < (uint32_t)o1.n + 16u)) { if (!done && W.room()) W.draw(key, rg.dom, rg.ii, rg.att, thr); }
             if (!done && !parked) {
                 if (t >= len) done = true;
-                else if (o1.n >= cap) { failed = true; done = true; }
                 else {
-                    const uint32_t v = in8(t);
+                    bool real; const uint32_t st = W.stop((uint32_t)o1.n, real);
+                    const uint32_t v = B.get8(in0 + t);
                     int n = len - t < 8 ? len - t : 8;
-                    if (cap - o1.n < n) n = cap - o1.n;
-                    if ((int)(nh - (uint32_t)o1.n) < n) n = (int)(nh - (uint32_t)o1.n);
+                    if ((int)(st - (uint32_t)o1.n) < n) n = (int)(st - (uint32_t)o1.n);
                     uint32_t pc = prev_c; bool differs = false;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const uint32_t c = (v >> (4 * i)) & 3u;
+                        const uint32_t c = (v >> (2 * i)) & 3u;
                         if (i < n) { step_flow(dist[4 * flow_i + (int)c]); differs = differs || c != pc; pc = c; }
                     }
                     if (differs) marked = false;
-                    o1.push_many(nibbles_to_pairs(v) & ((1u << (2 * n)) - 1u), n);
+                    o1.push_many(v & ((1u << (2 * n)) - 1u), n);
                     t += n; prev_c = pc;
-                    if (n < 8 && (uint32_t)o1.n == nh && t < len && o1.n < cap) {       // standing on a position whose first draw scored
-                        if (((v >> (4 * n)) & 3u) != prev_c) parked = true;            // a homopolymer starts here: the event happens
-                        else nh = hm1.next(nh + 1u);
+                    if (n < 8 && real && (uint32_t)o1.n == st && t < len) {             // standing on a position whose first draw scored
+                        if (((v >> (2 * n)) & 3u) != prev_c) parked = true;           // a homopolymer starts here: the event happens
+                        else W.clear(st);
                     }
                 }
             }
-            if (flow_batch_due(parked, !done && !parked)) {
-                if (parked) {
-                    const uint32_t c = in1(t);
-                    step_flow(dist[4 * flow_i + (int)c]); marked = false;
-                    rg.open((uint32_t)o1.n);
-                    int n_err = rg.more_errors(thr);
-                    if (n_err >= (1 << 14)) failed = true;
-                    else if (rg.next() < 0x80000000u) {              // insert n_err copies in front of the homopolymer (whose own bases follow unexamined: prev_c == c)
-                        if (o1.n + n_err > cap) failed = true;       // (the reference runs out of room at the latest when it reaches the homopolymer itself)
-                        else { for (int q = 0; q < n_err; ++q) o1.push(c); total += n_err; prev_c = c; }
-                    }
-                    else {                                          // delete: bounded by the homopolymer length
-                        int hp_l = 0; uint32_t next_c = c;
-                        while (t + hp_l < len) { next_c = in1(t + hp_l); if (next_c != c) break; ++hp_l; }
-                        if (n_err > hp_l) n_err = hp_l;
-                        t += n_err; marked = true; total += n_err;
-                        if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
-                            if (next_c == c) failed = true;         // the whole read was one deleted homopolymer (the reference asserts)
-                            else {
-                                const int jj = dist[4 * flow_i + (int)next_c];
-                                const int kk = (int)(((uint64_t)rg.next() * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
-                                int f = flow_i + kk; if (f >= F) f -= F;
-                                o1.push(flow[f]);
-                            }
-                        } else if (t < len) { o1.push(in1(t)); ++t; }   // the base now at this position is not examined
-                        prev_c = c;
-                    }
-                    if (failed) done = true; else nh = hm1.next((uint32_t)o1.n);
-                    parked = false;
+            // the further draws of the events ahead, a round for every lane at once
+            {
+                bool real = false; uint32_t st = 0;
+                if (!done) st = W.stop((uint32_t)o1.n, real);
+                const bool unresolved = !done && real && W.oc_pos != st;
+                const bool waiting = parked && unresolved;
+                if (flow_batch_due(waiting, !done && !waiting)) { if (unresolved) W.resolve(key, rg.dom + D_FLOW_EV, rg.ii, rg.att, st, thr); }
+            }
+            if (parked && W.oc_pos == (uint32_t)o1.n) {
+                const uint32_t c = B.get1(in0 + t);
+                step_flow(dist[4 * flow_i + (int)c]); marked = false;
+                int n_err; bool ins = false;
+                const bool slow = (W.oc & 0x200u) != 0;
+                if (slow) { rg.open((uint32_t)o1.n); n_err = rg.more_errors(thr); if (n_err >= (1 << 14)) failed = true; else ins = rg.next() < 0x80000000u; }
+                else { n_err = (int)(W.oc & 0xffu); ins = (W.oc & 0x100u) != 0; }
+                if (failed) {}
+                else if (ins) {                                     // insert n_err copies in front of the homopolymer (whose own bases follow unexamined: prev_c == c)
+                    if (o1.n + n_err > in0 + t) failed = true;      // the output would run into the input: the read has outgrown the buffer
+                    else { for (int q = 0; q < n_err; ++q) o1.push(c); total += n_err; prev_c = c; }
+                } else {                                            // delete: bounded by the homopolymer length
+                    int hp_l = 0; uint32_t next_c = c;
+                    while (t + hp_l < len && hp_l <= n_err) { next_c = B.get1(in0 + t + hp_l); if (next_c != c) break; ++hp_l; }
+                    if (n_err > hp_l) n_err = hp_l;
+                    t += n_err; marked = true; total += n_err;
+                    if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
+                        if (next_c == c) failed = true;             // the whole read was one deleted homopolymer (the reference asserts)
+                        else {
+                            const int jj = dist[4 * flow_i + (int)next_c];
+                            const uint32_t dw = slow ? rg.next() : W.oc_dot;
+                            const int kk = (int)(((uint64_t)dw * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
+                            int f = flow_i + kk; if (f >= F) f -= F;
+                            o1.push(flow[f]);
+                        }
+                    } else if (t < len) { o1.push(B.get1(in0 + t)); ++t; }   // the base now at this position is not examined
+                    prev_c = c;
                 }
+                if (failed) done = true;
+                parked = false;
             }
             if (__ballot(!done) == 0) break;
         }
     }
     o1.flush();
     const int n1 = o1.n;
-    if (probe::off(1024)) { *n_err_out += total; return failed ? -1 : n1; }
     const int marked_flow = marked ? flow_i : -1;      // the one flow of the (persistent) mask that pass 2 finds set
+
+    // ---- the output of pass 1 moves up to the buffer's top (positions capb - n1 ..), from the top word down: one read and one write per word ----
+    if (!failed) {
+        const int D = capb - n1;
+        if (D > 0) {
+            const int dw = D >> 4; const uint32_t sh = ((uint32_t)D & 15u) * 2u;
+            uint32_t hi = buf[(capw - 1 - dw) * stride];
+            for (int j = capw - 1; j >= dw; --j) {
+                const uint32_t lo = j - dw - 1 >= 0 ? buf[(j - dw - 1) * stride] : 0u;
+                buf[j * stride] = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+                hi = lo;
+            }
+        }
+    }
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
-    // g counts the empty flows examined so far: flow g's first draw is bit g of the bitmap (flows beyond the bitmap -- long cascades -- are
-    // drawn one by one), nh is the next scoring flow: a base whose empty flows end at or before nh is quiet.  Lanes with an empty stack
-    // move up to eight quiet bases per iteration, lanes with pending runs one; a base with a scoring flow in front of it parks. ----
+    // g counts the empty flows examined so far: flow g's first draw is event g of the pass.  A base whose empty flows end at or before the next
+    // scoring flow is quiet.  Lanes with an empty stack move up to eight quiet bases per iteration, lanes with pending runs one; a base with a
+    // scoring flow (or the window's end) in front of it goes through the flow-by-flow code below. ----
     const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
-    HitMap hm2{bm, stride, 0u};
-    const uint32_t margin2 = 8u * (uint32_t)maxk + 64u;      // a step moves g by at most eight bases' worth of flows
-    const WordView inB{bufB, stride, (cap + 15) >> 4};
-    BitAppender<4> o2; o2.init(bufA, stride);
+    const int in2 = capb - n1;
+    BitAppender<2> o2; o2.init(buf, stride);
     auto stk_get = [&](int k) -> uint32_t { return (stk[(k >> 1) * stride] >> ((k & 1) * 16)) & 0xffffu; };
     auto stk_set = [&](int k, uint32_t v) { const uint32_t sh = (uint32_t)(k & 1) * 16; uint32_t w = stk[(k >> 1) * stride]; stk[(k >> 1) * stride] = (w & ~(0xffffu << sh)) | (v << sh); };
     int t2 = 0, sp = 0;
     auto settle = [&](uint32_t x) {                        // the position's final base: the examined base, or the first base of the top run
         if (sp == 0) { o2.push(x); ++t2; }
+        else if (o2.n >= in2 + t2) failed = true;          // (the output would run into the input: outgrown)
         else {
             const uint32_t top = stk_get(sp - 1);
             o2.push(top >> 14);
@@ -539,67 +586,60 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
         }
     };
     rg.dom = dom2;
+    W.init();
     {
         bool done = failed, parked = false; uint32_t g = 0, x = 0;
-        nh = 0;
         for (;;) {
-            while (__ballot(!done && hm2.nbits < (uint32_t)G0 && g + margin2 > hm2.nbits)) {
-                const uint32_t old = hm2.nbits;
-                draw_word(dom2, old >> 5);
-                hm2.nbits = old + 32u;
-                if (!done && nh >= old) nh = hm2.next(old);
-            }
+            if (!done) W.advance(g);
+            while (__ballot(!done && W.room() && W.frontier() < g + 32u)) { if (!done && W.room()) W.draw(key, dom2, rg.ii, rg.att, thr); }
             if (!done && !parked) {
                 if (sp == 0 && t2 >= n1) done = true;
-                else if (o2.n >= cap) { failed = true; done = true; }
                 else if (sp > 0) {                                  // runs pending: one base
                     x = stk_get(sp - 1) >> 14;
                     const uint32_t k = dist[4 * flow_i + (int)x];
-                    if (g + k <= nh) { step_flow(k); g += k; settle(x); } else parked = true;
+                    bool real; const uint32_t st = W.stop(g, real);
+                    if (g + k <= st) { step_flow(k); g += k; settle(x); if (failed) done = true; } else parked = true;
                 }
                 else {
-                    const uint32_t v = inB.get8x2(t2);
-                    int n = n1 - t2 < 8 ? n1 - t2 : 8;
-                    if (cap - o2.n < n) n = cap - o2.n;
+                    const uint32_t v = B.get8(in2 + t2);
+                    const int n = n1 - t2 < 8 ? n1 - t2 : 8;
+                    bool real; const uint32_t st = W.stop(g, real);
                     int m = 0; bool quiet = true;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const uint32_t k = dist[4 * flow_i + (int)((v >> (2 * i)) & 3u)];
-                        quiet = quiet && i < n && g + k <= nh;
+                        quiet = quiet && i < n && g + k <= st;
                         if (quiet) { step_flow(k); g += k; ++m; }
                     }
-                    o2.push_many(pairs_to_nibbles(v) & (m == 8 ? 0xFFFFFFFFu : (1u << (4 * m)) - 1u), m);
+                    o2.push_many(v & ((1u << (2 * m)) - 1u), m);
                     t2 += m;
                     if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }
                 }
             }
-            if (flow_batch_due(parked, !done && !parked)) {
-                if (parked) {
-                    uint32_t left = dist[4 * flow_i + (int)x];      // empty flows in front of x still to examine
-                    while (!failed && left > 0) {
-                        uint32_t skip; bool scores;                 // quiet flows before the next scoring one
-                        if (g < (uint32_t)G0) { const uint32_t q = nh - g; skip = q < left ? q : left; scores = q < left && nh < hm2.nbits; }
-                        else {                                      // beyond the bitmap (a long cascade): flow by flow
-                            skip = 0;
-                            while (skip < left && !((flow_hits8(RngKey{rg.seed, rg.contig}, dom2, rg.ii, rg.att, (g + skip) >> 3, thr) >> ((g + skip) & 7u)) & 1u)) ++skip;
-                            scores = skip < left;
-                        }
-                        step_flow(skip);
-                        g += skip; left -= skip;
-                        if (!scores) continue;                      // (all of them looked at, or the bitmap ended: on beyond it)
-                        rg.open(g);                                 // flow g scores: while (drand48() < e) n_err++ goes on in its private stream
-                        const int n_err = rg.more_errors(thr);
-                        if (flow_i != marked_flow) {
-                            if (sp >= FLOW_STACK_RUNS || n_err >= (1 << 14)) failed = true;
-                            else { stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err; }
-                        }
-                        step_flow(1);
-                        ++g; --left;
-                        if (g <= (uint32_t)G0) nh = hm2.next(g);
+            if (parked) {      // flow by flow up to x's own: quiet flows are skipped together, a scoring one inserts (dwgsim.c:373-383)
+                uint32_t left = dist[4 * flow_i + (int)x];
+                for (;;) {
+                    bool real; const uint32_t st = W.stop(g, real);
+                    const uint32_t q = st - g, skip = q < left ? q : left;
+                    step_flow(skip); g += skip; left -= skip;
+                    if (left == 0) { settle(x); parked = false; if (failed) done = true; break; }
+                    if (!real || W.oc_pos != g) break;              // the window's end, or an event whose further draws are not there yet: next round
+                    int n_err;
+                    if (W.oc & 0x200u) { rg.open(g); n_err = rg.more_errors(thr); } else n_err = (int)(W.oc & 0xffu);
+                    if (flow_i != marked_flow) {
+                        if (sp >= stack_runs || n_err >= (1 << 14)) { failed = true; done = true; parked = false; break; }
+                        stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err;
                     }
-                    if (failed) done = true; else settle(x);
-                    parked = false;
+                    step_flow(1);
+                    ++g; --left;
                 }
+            }
+            {
+                bool real = false; uint32_t st = 0;
+                if (!done) st = W.stop(g, real);
+                const bool unresolved = !done && real && W.oc_pos != st;
+                const bool waiting = parked && unresolved && st == g;
+                if (flow_batch_due(waiting, !done && !waiting)) { if (unresolved) W.resolve(key, dom2 + D_FLOW_EV, rg.ii, rg.att, st, thr); }
             }
             if (__ballot(!done) == 0) break;
         }

@@ -16,6 +16,7 @@
 //   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
 //   DW_PART 7, 8: the one-wave-per-block variants for long Illumina / SOLiD reads
 //   DW_PART 9, 10: the two-kernel form (SPLIT) of the paired / single-end Illumina variants
+//   DW_PART 11, 12, 13: the Ion Torrent variants whose read buffers live in LDS (256-lane blocks paired / single-end, one-wave blocks)
 //   DW_PART -1 (default): everything in one translation unit
 #include <algorithm>
 #include "dw_read.hpp"
@@ -34,6 +35,9 @@
 #endif
 #ifndef DW_SIMB_WAVES
 #define DW_SIMB_WAVES 6      // ... requested for the second half of the two-kernel form (text assembly)
+#endif
+#ifndef DW_IONL_WAVES
+#define DW_IONL_WAVES 3      // ... for the Ion Torrent variant whose read buffers live in LDS: LDS, not registers, bounds its residency
 #endif
 #ifndef DW_ION_WAVES
 #define DW_ION_WAVES 5       // minimum waves per SIMD requested for the (latency-bound) Ion Torrent variants: without the hint the window registers of the extraction push them to 104 VGPRs = 4 waves (measured 165 -> 187 M reads/s at 5; 6 brings nothing)
@@ -70,7 +74,7 @@ DW_DEV bool pair_surely_accepted(const SimArgs &a, const SegCtx &sc, RngKey key,
 {
     const int32_t s0 = a.p.len[0], s1 = a.p.len[1], smax = s0 > s1 ? s0 : s1, smin = s1 > 0 && s1 < s0 ? s1 : s0;
     const int64_t l = sc.l;
-    if (l < (int64_t)s0 + s1 + 1) return false;
+    if (l < (int64_t)s0 + s1 + 1 || sc.l_place != sc.l) return false;      // (a placement length of its own -- dwgsim_hip_contig_set_placement_length -- draws other positions: draw_pair decides)
     int64_t dlo = 0, dhi = 0;
     if (s1 > 0) {
         dlo = (int64_t)a.p.dist - a.place_k; dhi = (int64_t)a.p.dist + a.place_k;
@@ -107,7 +111,7 @@ DW_DEV void place_pair_exact(const SimArgs &a, const SegCtx &sc, RngKey key, uin
             int64_t start; int step;
             read_geom(a, sc, pd, j, &start, &step);
             if (!attempt_surely_accepted((pd.hap ? a.summ[1] : a.summ[0]) + sc.start / SUMM_CELLS, sc.l, start, step, sj)) {     // rare: N, dense indels, contig ends
-                const ReadRes r = gen_read<false>(sel_hap(a, sc, pd.hap), sc.l, start, step, sj, j ? pd.strand1 : pd.strand0, nullptr, 0);
+                const ReadRes r = gen_read(sel_hap(a, sc, pd.hap), sc.l, start, step, sj, j ? pd.strand1 : pd.strand0, NoSink{});
                 ok = r.ext_coor >= 0 && r.num_n <= a.p.max_n;
             }
         }
@@ -404,7 +408,9 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
     const uint64_t r = (uint64_t)atomicAdd((unsigned long long *)&ff[32 * x + 16], 1ull);
     status_store(ff + 256 + (size_t)x * n_blocks + (size_t)r, (uint64_t)slot + 1ull);
 }
-// DT = 0: Illumina base-space errors; DT = 2: Ion Torrent flow-space errors (variable read length).
+// DT = 0: Illumina base-space errors; DT = 1: SOLiD colour space; DT = 3: Ion Torrent flow-space errors (variable read length), the read's one
+// in-place 2-bit buffer in LDS (dw_read.hpp flow_errors); DT = 2: the same with the buffer in a scratch slot of global memory -- for reads whose
+// buffers LDS cannot hold (very long reads, per-flow error rates at which reads grow severalfold).
 // NTHR: lanes per block.  SIM_THREADS_LONG (one wave) is the variant for reads too long to stage at SIM_THREADS lanes.
 // WR = 1: records leave through the per-lane LDS FIFO; 0: straight from registers (dw_read.hpp FifoWriter / Writer)
 // SPLIT: 0 = the whole path in one kernel: a block learns where its records go from a decoupled look-back over the blocks in front of it.
@@ -414,7 +420,7 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
 // block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
 // block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
 template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 3 ? DW_IONL_WAVES : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     static_assert(SPLIT == 0 || (DT == 0 && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants with 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
@@ -429,16 +435,17 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // the Ion Torrent read buffers, and every read too long for that (the one-wave blocks): staged in LDS a 2 000-base read left room for two waves
     // per CU (half the SIMDs idle, 17 % VALU-active: profiles/r04_variants_pmc.txt) and a 5 000-base read for none.  The slot is read and written
     // word by word in step by the lanes of a wave (word w of lane t at [w * nthr + t]) and lives in the L2 / memory-side cache
-    constexpr bool GS = DT == 2 || NTHR != SIM_THREADS;
+    constexpr bool ION = DT == 2 || DT == 3;
+    constexpr bool GS = DT == 2 || (DT != 3 && NTHR != SIM_THREADS);
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     DW_PROBE_INIT();
     if (GS && tid == 0) { s_slot = scratch_slot_take(a.flow_free, (uint32_t)a.flow_slots, a.n_blocks); asm volatile("" ::: "memory"); }      // (before the ticket: see scratch_slot_take)
     if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
-    if (DT == 2 && tid < 64) s_flow[tid] = a.flow[tid];
+    if (ION && tid < 64) s_flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
-    const size_t stage_words = SPLIT == 2 ? 0 : DT == 2 ? (size_t)(FLOW_STACK_RUNS / 2) : GS ? 0 : (size_t)a.lds_words;      // (the second half of the two-kernel form reads its bases from HBM)
+    const size_t stage_words = SPLIT == 2 ? 0 : DT == 3 ? (size_t)(a.lds_words + a.flow_stack_words) : DT == 2 ? (size_t)a.flow_stack_words : GS ? 0 : (size_t)a.lds_words;      // (the second half of the two-kernel form reads its bases from HBM)
     uint32_t *const s_qb = dyn_lds + stage_words * nthr;
     if (SPLIT != 1) for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     // this lane's text FIFO (record writer), behind the tables
@@ -453,7 +460,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const SegCtx sc = seg_ctx(a, sg);
     const uint8_t *name_fixed = a.names + sg->name_off;
     if (H != 1) for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
-    if (DT == 2) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
+    if (ION) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
     const int j = (LPP == 2) ? (tid & 1) : 0;
     const uint64_t pair_in = (uint64_t)(t - sg->first_block) * PPB + (uint64_t)(tid / LPP);      // inside the range
     const bool valid = pair_in < sg->n_pairs;
@@ -461,11 +468,14 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     const uint64_t pair = sg->pair_off + pair_in;                 // inside the launch
     const RngKey key{a.p.seed, uniform_u32(sg->contig_index)};
     const int s = sel_len(a, j);
-    // this lane's packed bases: word w at lds[w * nthr].  Illumina: LDS.  Ion Torrent: the (much larger, sequentially accessed)
-    // read buffers live in a global scratch so that LDS does not cap residency; only the run stack of pass 2 stays in LDS
+    // this lane's packed bases: word w at lds[w * nthr].  Illumina / SOLiD: 4 bits per base; Ion Torrent: the one in-place buffer of the flow model,
+    // 2 bits per base, a.lds_words words for a.cap = 16 a.lds_words bases (dw_read.hpp flow_errors), in LDS (DT = 3) or in a scratch slot (DT = 2);
+    // the run stack of its pass 2 (a.flow_stack_words words per lane) is in LDS either way
     // (second half of the two-kernel form: the tile's staged bases where the first half left them, read once, in batches of eight words)
-    uint32_t *lds = GS ? a.flow_scratch + (size_t)uniform_u32(s_slot) * ((size_t)(DT == 2 ? flow_words_per_lane(a.lds_words, a.cap) : a.lds_words) * nthr) + tid
+    uint32_t *lds = GS ? a.flow_scratch + (size_t)uniform_u32(s_slot) * ((size_t)(DT == 2 ? flow_words_per_lane(a.lds_words) : a.lds_words) * nthr) + tid
                   : SPLIT == 2 ? a.split_state + (size_t)t * ((size_t)a.lds_words * nthr) + tid : dyn_lds + tid;
+    uint32_t *const flow_stk = dyn_lds + (DT == 3 ? (size_t)a.lds_words * nthr : 0) + tid;
+    const int capb = 16 * a.lds_words;              // (Ion Torrent) bases the buffer holds
 
     // A block's records can be placed only when every block in front of it has published its sizes: what a wave does BEFORE it publishes its own is on
     // the critical path of all the blocks behind it, what it does after (text assembly) is not.  So a wave runs at raised issue priority up to its
@@ -494,9 +504,13 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
                 int64_t start; int step;
                 read_geom(a, sc, pd, j, &start, &step);
                 DW_PROBE_MARK(a, 7);     // placement draws (phase 1 below is then the base extraction alone)
-                if (probe::off(8)) { rr = ReadRes{(int32_t)start, 0, 0, 0, 0}; for (int w = 0; w * 8 < s; ++w) lds[w * nthr] = 0x32103210u; }
+                if (ION) {        // straight into the flow model's buffer: 2 bits per base, N as A, a reverse-strand read turned round (dw_read.hpp FlowSink)
+                    const bool rev = (j ? pd.strand1 : pd.strand0) != 0;
+                    rr = gen_read(sel_hap(a, sc, pd.hap), sc.l, start, step, s, rev ? 1 : 0, FlowSink{lds, nthr, rev ? (capb >> 3) - 1 : ((capb - s) & ~7) >> 3, rev});
+                }
+                else if (probe::off(8)) { rr = ReadRes{(int32_t)start, 0, 0, 0, 0}; for (int w = 0; w * 8 < s; ++w) lds[w * nthr] = 0x32103210u; }
                 else
-                rr = gen_read<true>(sel_hap(a, sc, pd.hap), sc.l, start, step, s, j ? pd.strand1 : pd.strand0, lds, nthr);
+                rr = gen_read(sel_hap(a, sc, pd.hap), sc.l, start, step, s, j ? pd.strand1 : pd.strand0, WordSink{lds, nthr});
                 ok = rr.ext_coor >= 0 && rr.num_n <= a.p.max_n;
             }
         }
@@ -523,18 +537,26 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
     // ---- sequencing errors (dwgsim.c:233-244) or random bases (dwgsim.c:999-1001) ----
     // 16-bit draws: one Philox block tests eight bases (the low half of a uniform is drawn lazily, see below); an error marks bit 3 of
     // the base's nibble and its substituted base is drawn afterwards, only for the (few) marked bases
-    if (DT == 2) {                              // dwgsim.c:861-864; every lane calls (the second pass regroups the lanes of a wave)
+    if (ION) {                                  // dwgsim.c:861-864; every lane calls (the loops of the model are wave-uniform)
         const bool flows = valid && !is_rand && s > 0;
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(flows, rg, s_flow, s_dist, a.flow_len, a.flow_maxk, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, lds + (size_t)a.lds_words * nthr, lds + (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr, dyn_lds + tid,
-                                   nthr, s, j ? pd.strand1 : pd.strand0, a.cap, &n_err);
+        const int so = flow_errors(flows, rg, s_flow, s_dist, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, flow_stk, nthr, 2 * a.flow_stack_words, s, j ? pd.strand1 : pd.strand0, capb, &n_err);
         if (flows) {
             s_out = so;
             if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
             flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
         }
     }
-    if (valid && (DT != 2 || is_rand) && !(probe::off(4))) {
+    if (ION) {                                  // a random read (dwgsim.c:999-1001): base i = (int)(u * 4.0) & 3 from halfword i of the D_BASE0 stream, at positions 0 .. s - 1 of the buffer
+        if (valid && is_rand) for (int w = 0; w * 8 < s; ++w) {
+            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)w);
+            uint32_t pairs = ((q0.x >> 14) & 3u) | ((q0.x >> 30) << 2) | (((q0.y >> 14) & 3u) << 4) | ((q0.y >> 30) << 6) | (((q0.z >> 14) & 3u) << 8) | ((q0.z >> 30) << 10) | (((q0.w >> 14) & 3u) << 12) | ((q0.w >> 30) << 14);
+            const int rem = s - 8 * w;
+            if (rem < 8) pairs &= (1u << (2 * rem)) - 1u;
+            reinterpret_cast<uint16_t *>(lds + (w >> 1) * nthr)[w & 1] = (uint16_t)pairs;
+        }
+    } else
+    if (valid && !(probe::off(4))) {
         // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
         const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
         uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
@@ -757,14 +779,15 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_
         DW_PROBE_MARK(a, 4); // header line
         // bases (the second writer of -o 0 starts a new section, so that sixteen bases are one store)
         o.rebase();
-        // word w of the record (bases 8w .. 8w + 7).  Ion Torrent, reverse strand: base i of the record = base s_out-1-i of the flow-model
-        // orientation (dwgsim.c:408-414): the eight cells ending at s_out-1-8w, fetched as one window and turned nibble by nibble
+        // word w of the record (bases 8w .. 8w + 7) as nibbles.  Ion Torrent: from the 2-bit buffer, where the read stands at positions 0 .. s_out - 1 in the
+        // orientation of the flow model; reverse strand: base i of the record = base s_out-1-i of it (dwgsim.c:408-414): the eight positions ending at
+        // s_out-1-8w, fetched together and turned round
         auto rec_word = [&](int w) -> uint32_t {
-            if (!(DT == 2 && flow_reversed)) return lds[w * nthr];
-            const int lo = s_out - 8 - 8 * w;                   // first cell of the window (negative in the last, partial word)
-            if (lo < 0) return (uint32_t)(reverse_nibbles((uint64_t)lds[0]) >> 32) >> (4 * (-lo));
-            const uint32_t a0 = lds[(lo >> 3) * nthr], a1 = (lo & 7) ? lds[((lo >> 3) + 1) * nthr] : 0u;
-            return (uint32_t)(reverse_nibbles((uint64_t)__builtin_amdgcn_alignbit(a1, a0, 4u * (uint32_t)(lo & 7))) >> 32);
+            if (!ION) return lds[w * nthr];
+            const Buf2 B{lds, nthr, a.lds_words};
+            if (!flow_reversed) return pairs_to_nibbles(B.get8(8 * w));
+            const int lo = s_out - 8 - 8 * w;                   // first position of the window (negative in the last, partial word)
+            return pairs_to_nibbles(lo < 0 ? reverse_pairs16(B.get8(0)) >> (2 * (-lo)) : reverse_pairs16(B.get8(lo)));
         };
         auto put_last_word = [&](uint32_t word, int rem) __attribute__((always_inline)) {      // fewer than sixteen bases left: this word's share of them
             if (rem >= 8) { o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16)); }
@@ -1122,6 +1145,10 @@ void launch_sim_long_2_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t l
 void launch_sim_long_1_0(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_long_2_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_long_1_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_2_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_1_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_long_2_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
+void launch_sim_long_1_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_split_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
 void launch_sim_split_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
 void launch_split_scan(hipStream_t st, const SimArgs &a, int lpp)
@@ -1140,8 +1167,15 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
         if (pe) launch_sim_split_2(st, a, nb, lds_a, lds_b, out); else launch_sim_split_1(st, a, nb, lds_a, lds_b, out);
         return;
     }
-    const size_t lds = sim_lds_bytes((size_t)(ion ? FLOW_STACK_RUNS / 2 : nthr != (uint32_t)SIM_THREADS ? 0 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);   // staged bases (Ion Torrent: only the pass-2 run stack; its read buffers, like the long reads of the one-wave blocks, are in a.flow_scratch) + the base-quality tables + the text FIFOs
+    // staged bases (Ion Torrent: the read buffers when LDS holds them + the pass-2 run stack; otherwise they are, like the long reads of the one-wave blocks, in a.flow_scratch)
+    // + the base-quality tables + the text FIFOs
+    const size_t lds = sim_lds_bytes((size_t)(ion ? (a.ion_lds ? a.lds_words : 0) + a.flow_stack_words : nthr != (uint32_t)SIM_THREADS ? 0 : a.lds_words), nthr, (size_t)a.qb_words, a.fifo != 0);
     const bool solid = a.p.data_type == 1;
+    if (ion && a.ion_lds) {                                          // Ion Torrent, read buffers in LDS: 256-lane blocks, or one-wave blocks
+        if (nthr != (uint32_t)SIM_THREADS) { if (pe) launch_sim_long_2_3(st, a, nb, lds, out); else launch_sim_long_1_3(st, a, nb, lds, out); }
+        else { if (pe) launch_sim_2_3(st, a, nb, lds, out); else launch_sim_1_3(st, a, nb, lds, out); }
+        return;
+    }
     if (nthr != (uint32_t)SIM_THREADS) {                             // long Illumina / SOLiD reads: one-wave blocks
         if (pe) { if (solid) launch_sim_long_2_1(st, a, nb, lds, out); else launch_sim_long_2_0(st, a, nb, lds, out); }
         else { if (solid) launch_sim_long_1_1(st, a, nb, lds, out); else launch_sim_long_1_0(st, a, nb, lds, out); }
@@ -1219,7 +1253,7 @@ DW_SIM_FAMILY(1, 2)
 
 // -B (dwgsim_opt.c:415-457): lane = one random read of read end a.end pushed through the flow model on the forward strand; the block
 // adds its error and length sums to counters[8], [9].  Draws: bases = narrow words of (D_CALIB + end, read, attempt 0), flow model =
-// the sequential narrow stream of (D_CALIB + end, read, attempt 1).
+// the streams of (D_CALIB + end, read, attempt 1).  The read buffers (dw_read.hpp flow_errors: a.lds_words words per lane) are in a.scratch.
 __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);
@@ -1231,24 +1265,27 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr);
     __syncthreads();
     const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
-    uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)flow_words_per_lane(a.lds_words, a.cap) * nthr) + tid;
+    uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)a.lds_words * nthr) + tid;
+    const int capb = 16 * a.lds_words;
     int32_t n_err = 0; int s_out = 0;
     const bool live = jj < a.n_reads;
     const RngKey key{a.seed, 0u};
     const uint32_t dom = D_CALIB + (uint32_t)a.end;
     if (live) {
+        const int h0 = ((capb - a.len) & ~7) >> 3;             // a forward read: where FlowSink would put it
         for (int w = 0; w * 8 < a.len; ++w) {
             const U4 q0 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w)), q1 = rng_block(key, dom, jj, 0, 0, (uint32_t)(2 * w + 1));
             const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            uint32_t word = 0;
+            uint32_t pairs = 0;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) if (w * 8 + b < a.len) word |= (rw[b] >> 30) << (4 * b);      // (int)(u * 4.0) & 3
-            buf[w * nthr] = word;
+            for (int b = 0; b < 8; ++b) if (w * 8 + b < a.len) pairs |= (rw[b] >> 30) << (2 * b);      // (int)(u * 4.0) & 3
+            const int h = h0 + w;
+            reinterpret_cast<uint16_t *>(buf + (h >> 1) * nthr)[h & 1] = (uint16_t)pairs;
         }
     }
-    {   // every lane calls (the second pass regroups the lanes of a wave)
+    {   // every lane calls (the loops of the model are wave-uniform)
         FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(live, rg, s_flow, s_dist, a.flow_len, a.flow_maxk, a.thr, buf, buf + (size_t)a.lds_words * nthr, buf + (size_t)(a.lds_words + ((a.cap + 15) >> 4)) * nthr, dyn_lds + tid, nthr, a.len, 0, a.cap, &n_err);
+        const int so = flow_errors(live, rg, s_flow, s_dist, a.flow_len, a.thr, buf, dyn_lds + tid, nthr, 2 * a.stack_words, a.len, 0, capb, &n_err);
         if (live) { s_out = so; if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; } }
     }
     const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);
@@ -1256,8 +1293,18 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
 }
 void launch_calibrate(hipStream_t st, const CalibArgs &a)
 {
-    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)(FLOW_STACK_RUNS / 2) * PAIRS_PER_BLOCK * 4, st, a);
+    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)a.stack_words * PAIRS_PER_BLOCK * 4, st, a);
 }
+#endif
+#if DW_HAS(11)
+DW_SIM_FAMILY(2, 3)
+#endif
+#if DW_HAS(12)
+DW_SIM_FAMILY(1, 3)
+#endif
+#if DW_HAS(13)
+DW_SIM_FAMILY_LONG(2, 3)
+DW_SIM_FAMILY_LONG(1, 3)
 #endif
 #if DW_HAS(5)
 DW_SIM_FAMILY(2, 1)

@@ -576,7 +576,7 @@ int main(int argc, char **argv)
     auto feed = [&](const std::string &nm, std::vector<uint8_t> &seq) -> bool {      // a sequence that sits in memory: into the staging with all cores
         int64_t st = 0;
         uint8_t *dst = dwgsim_hip_job_begin_contig(job, nm.c_str(), (int64_t)seq.size(), &st);
-        if (!dst) return taken(st);
+        if (st < 0 || !dst) { if (st >= 0) st = DWGSIM_HIP_ERR_STATE; return taken(st); }      // the status decides; no place without an error is an error too
         parallel_copy(dst, seq.data(), seq.size(), rpool);
         return taken(dwgsim_hip_job_commit_contig(job));
     };
@@ -587,7 +587,7 @@ int main(int argc, char **argv)
                 if (mf.geometry(r, &L, &len)) {
                     int64_t st = 0;
                     uint8_t *dst = dwgsim_hip_job_begin_contig(job, r.name.c_str(), len, &st);
-                    if (!dst) { taken(st); break; }
+                    if (st < 0 || !dst) { if (st >= 0 || !taken(st)) rc = 1; break; }
                     if (mf.fill(r, L, len, dst, rpool)) { done = true; go = taken(dwgsim_hip_job_commit_contig(job)); }
                     else (void)dwgsim_hip_job_cancel_contig(job);
                 }

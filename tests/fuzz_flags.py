@@ -43,6 +43,8 @@ def random_flags(rng):
     return " ".join(f)
 
 
+# DWGSIM_FUZZ_DEBUG="ion_lds=0,flow_cap=40": dwgsim_hip_debug_option settings for every case of --one (e.g. the three homes of the Ion Torrent read buffers)
+DEBUG_OPTIONS = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("DWGSIM_FUZZ_DEBUG", "").split(",") if kv)} or None
 ORACLE_TIMEOUT = float(os.environ.get("DWGSIM_FUZZ_ORACLE_TIMEOUT", "20"))      # option sets on which the oracle (like the reference) never ends: e = 1 in the flow model
 IN = os.path.join(ROOT, "tests", "golden", "inputs")
 def random_flags_tiny_inputs(rng):
@@ -169,7 +171,7 @@ def one_case(flags, fasta):
             print("both reject:", repr(e)[:120], flush=True)
         return 3
     try:
-        compare_case(lib, oracle, fasta, flags)
+        compare_case(lib, oracle, fasta, flags, debug_options=DEBUG_OPTIONS)
     except AssertionError as e:
         print("MISMATCH ::", str(e)[:300], flush=True); return 4
     except Exception as e:
