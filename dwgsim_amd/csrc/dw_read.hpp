@@ -362,6 +362,12 @@ struct Buf2 {
         const uint32_t lo = word(w), hi = sh > 16u ? word(w + 1) : 0u;
         return __builtin_amdgcn_alignbit(hi, lo, sh) & 0xFFFFu;
     }
+    DW_DEV uint32_t get16(int p) const     // the sixteen bases at positions p .. p + 15
+    {
+        const int w = p >> 4; const uint32_t sh = ((uint32_t)p & 15u) * 2u;
+        const uint32_t lo = word(w), hi = sh ? word(w + 1) : 0u;
+        return __builtin_amdgcn_alignbit(hi, lo, sh);
+    }
     DW_DEV uint32_t get1(int p) const { return (word(p >> 4) >> (((uint32_t)p & 15u) * 2u)) & 3u; }
 };
 // Appends BITS-bit elements, one or up to 32 / BITS at a time (v: cnt elements, nothing above them), a word is stored whenever one is full
@@ -420,25 +426,31 @@ struct FlowWin {
         oc = (m0 ? 2u : 1u) | (insw < 0x80000000u ? 0x100u : 0u) | ((m0 && m1) ? 0x200u : 0u);
     }
 };
-// dist[4 * f + b]: flows from flow f (inclusive) to the first flow of base b, 0 .. F-1 (filled by fill_flow_dist, every base occurs in the order)
-DW_DEV void fill_flow_dist(const uint8_t *flow, int F, uint8_t *dist, int tid, int nthr)
+// The flow order as tables (LDS, filled once per block by fill_flow_tables; every base occurs in the order, F <= 64):
+//   dist[4 f + b]   flows from flow f (inclusive) to the first flow of base b, 0 .. F-1;   next1[4 f + b] = that flow
+//   pair[16 f + (b0 | b1 << 2)]   TWO bases at once: the flow after both in bits 0-5, the flows passed over in front of them (k0 + k1) in bits 8-14
+// The flow pointer is a chain of dependent table look-ups, one per base of the read (the only part of the model that is serial base by base); the
+// pair table halves its length.
+struct FlowTables { uint8_t flow[64], dist[256], next1[256]; uint16_t pair[1024]; };
+DW_DEV void fill_flow_tables(FlowTables &T, int F, int tid, int nthr)      // (T.flow is in place; a barrier before and after)
 {
     for (int q = tid; q < 4 * F; q += nthr) {
         const int f = q >> 2; const uint32_t b = (uint32_t)q & 3u;
         int k = 0, g = f;
-        while (flow[g] != b) { ++k; g = g + 1 == F ? 0 : g + 1; }
-        dist[q] = (uint8_t)k;
+        while (T.flow[g] != b) { ++k; g = g + 1 == F ? 0 : g + 1; }
+        T.dist[q] = (uint8_t)k; T.next1[q] = (uint8_t)g;
+    }
+    for (int q = tid; q < 16 * F; q += nthr) {
+        const int f = q >> 4; const uint32_t b0 = (uint32_t)q & 3u, b1 = ((uint32_t)q >> 2) & 3u;
+        int k = 0, g = f;
+        while (T.flow[g] != b0) { ++k; g = g + 1 == F ? 0 : g + 1; }
+        while (T.flow[g] != b1) { ++k; g = g + 1 == F ? 0 : g + 1; }
+        T.pair[q] = (uint16_t)((uint32_t)g | ((uint32_t)k << 8));
     }
 }
-// lanes waiting for their event's further draws: a round is due once DW_FLOW_BATCH of them wait, or as many as still run (every lane that has an
-// unresolved event in its window takes part in the round, not only the waiting ones)
-#ifndef DW_FLOW_BATCH
-#define DW_FLOW_BATCH 8
-#endif
-DW_DEV bool flow_batch_due(bool waiting, bool running)
+DW_DEV uint32_t even_bits16(uint32_t x)      // bits 0, 2, 4, .. 30 of x gathered into sixteen bits
 {
-    const uint64_t p = __ballot(waiting), r = __ballot(running);
-    return p && (__popcll(p) >= DW_FLOW_BATCH || __popcll(p) >= __popcll(r));
+    x &= 0x55555555u; x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0F0F0F0Fu; x = (x | (x >> 4)) & 0x00FF00FFu; return (x | (x >> 8)) & 0xFFFFu;
 }
 // generate_errors_flows (dwgsim.c:246-417).  Every lane of the wave must call this (the loops are wave-uniform); lanes without a read pass
 // active = false.  buf: this lane's buffer of capb bases (a multiple of 16; capb / 16 words).  On entry the read stands where FlowSink put it:
@@ -448,16 +460,15 @@ DW_DEV bool flow_batch_due(bool waiting, bool running)
 // two per word of stk) or degenerated.
 //
 // Both passes are sequential per read and almost always quiet: the first draw of a position (pass 1) or of an empty flow (pass 2) scores with
-// probability e.  A lane knows from its window (FlowWin) where its next scoring draw is and moves EIGHT bases per iteration up to it -- sixteen
-// bits of the packed read, the flow pointer's chain of eight table look-ups, one append -- and only a lane standing on a scoring draw runs the
-// event code, which is short: what the event draws beyond its first uniform has been drawn ahead, in rounds.  Each lane performs exactly its own
-// sequence of operations; only their interleaving changes.
-DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint8_t *dist, int F, uint64_t thr, uint32_t *buf, uint32_t *stk, int stride, int stack_runs,
+// probability e.  A lane knows from its window (FlowWin) where its next scoring draw is and moves SIXTEEN bases per iteration up to it -- one word
+// of the packed read, the flow pointer's chain of eight pair look-ups, one append -- and only a lane standing on an event runs the event code,
+// which is short: what the event draws beyond its first uniform has been drawn ahead, in rounds.  Each lane performs exactly its own sequence
+// of operations; only their interleaving changes.
+DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uint64_t thr, uint32_t *buf, uint32_t *stk, int stride, int stack_runs,
                        int len, int strand, int capb, int32_t *n_err_out)
 {
     const RngKey key{rg.seed, rg.contig};
-    int total = 0, flow_i = 0; bool marked = false; bool failed = !active;
-    auto step_flow = [&](uint32_t k) { flow_i += (int)k; if (flow_i >= F) flow_i -= F; };
+    int total = 0; uint32_t flow_i = 0; bool marked = false; bool failed = !active;
     const int capw = capb >> 4;
     const Buf2 B{buf, stride, capw};
     FlowWin W;
@@ -473,49 +484,55 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     int t = 0; uint32_t prev_c = 4;
     if (active) {
         const uint32_t c0 = B.get1(in0);
-        while (flow_i < F && c0 != flow[flow_i]) ++flow_i;
-        if (flow_i == F) failed = true;
+        while (flow_i < (uint32_t)F && c0 != T.flow[flow_i]) ++flow_i;
+        if (flow_i == (uint32_t)F) failed = true;
     }
     W.init();
     {
         bool done = failed, parked = false;
-        for (;;) {
-            // draws: every lane keeps its window ahead of itself (a step looks at up to eight positions)
+        for (uint32_t it = 0;; ++it) {
+            // draws: every lane keeps its window ahead of itself (a step looks at up to sixteen positions)
             if (!done) W.advance((uint32_t)o1.n);
-            while (__ballot(!done && W.room() && W.frontier() < (uint32_t)o1.n + 16u)) { if (!done && W.room()) W.draw(key, rg.dom, rg.ii, rg.att, thr); }
+            while (__ballot(!done && W.room() && W.frontier() < (uint32_t)o1.n + 24u)) { if (!done && W.room()) W.draw(key, rg.dom, rg.ii, rg.att, thr); }
             if (!done && !parked) {
                 if (t >= len) done = true;
                 else {
-                    bool real; const uint32_t st = W.stop((uint32_t)o1.n, real);
-                    const uint32_t v = B.get8(in0 + t);
-                    int n = len - t < 8 ? len - t : 8;
-                    if ((int)(st - (uint32_t)o1.n) < n) n = (int)(st - (uint32_t)o1.n);
-                    uint32_t pc = prev_c; bool differs = false;
+                    const uint32_t on = (uint32_t)o1.n, sh = on - W.hb;                  // (sh < 8 after advance)
+                    const uint32_t v = B.get16(in0 + t);
+                    int n = len - t < 16 ? len - t : 16;
+                    const int reach = (int)(W.frontier() - on);                          // positions whose first draws are there
+                    if (reach < n) n = reach;
+                    // homopolymer starts among the sixteen: base i differs from the one before it (the first one from prev_c)
+                    const uint32_t x = v ^ ((v << 2) | (prev_c & 3u));
+                    const uint32_t starts = even_bits16(x | (x >> 1)) | (prev_c > 3u ? 1u : 0u);
+                    const uint32_t below = n < 16 ? (1u << n) - 1u : 0xFFFFu;
+                    const uint32_t ev = starts & (uint32_t)(W.bits >> sh) & below;       // ... whose first draw scores: the first of them stops the step
+                    if (ev) n = __ffs((int)ev) - 1;
+                    const uint32_t taken = n < 16 ? (1u << n) - 1u : 0xFFFFu;
+                    // the flow pointer over the n bases: pairs, then the odd one
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const uint32_t c = (v >> (2 * i)) & 3u;
-                        if (i < n) { step_flow(dist[4 * flow_i + (int)c]); differs = differs || c != pc; pc = c; }
+                    for (int p = 0; p < 8; ++p) {
+                        const uint32_t e = T.pair[(flow_i << 4) | ((v >> (4 * p)) & 15u)];
+                        if (2 * p + 2 <= n) flow_i = e & 63u;
                     }
-                    if (differs) marked = false;
-                    o1.push_many(v & ((1u << (2 * n)) - 1u), n);
-                    t += n; prev_c = pc;
-                    if (n < 8 && real && (uint32_t)o1.n == st && t < len) {             // standing on a position whose first draw scored
-                        if (((v >> (2 * n)) & 3u) != prev_c) parked = true;           // a homopolymer starts here: the event happens
-                        else W.clear(st);
-                    }
+                    if (n & 1) flow_i = T.next1[(flow_i << 2) | ((v >> (2 * (n - 1))) & 3u)];
+                    if (starts & taken) marked = false;
+                    o1.push_many(n < 16 ? v & ((1u << (2 * n)) - 1u) : v, n);
+                    if (n) prev_c = (v >> (2 * (n - 1))) & 3u;
+                    t += n;
+                    if (ev) parked = true;                                               // standing on a homopolymer start whose first draw scored: the event happens
                 }
             }
-            // the further draws of the events ahead, a round for every lane at once
+            // the further draws of the events ahead: a round for every lane at once, when a lane stands on an unresolved event, and every fourth iteration
             {
                 bool real = false; uint32_t st = 0;
                 if (!done) st = W.stop((uint32_t)o1.n, real);
                 const bool unresolved = !done && real && W.oc_pos != st;
-                const bool waiting = parked && unresolved;
-                if (flow_batch_due(waiting, !done && !waiting)) { if (unresolved) W.resolve(key, rg.dom + D_FLOW_EV, rg.ii, rg.att, st, thr); }
+                if (__ballot(unresolved && (parked || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, rg.dom + D_FLOW_EV, rg.ii, rg.att, st, thr); }
             }
             if (parked && W.oc_pos == (uint32_t)o1.n) {
                 const uint32_t c = B.get1(in0 + t);
-                step_flow(dist[4 * flow_i + (int)c]); marked = false;
+                flow_i = T.next1[(flow_i << 2) | c]; marked = false;
                 int n_err; bool ins = false;
                 const bool slow = (W.oc & 0x200u) != 0;
                 if (slow) { rg.open((uint32_t)o1.n); n_err = rg.more_errors(thr); if (n_err >= (1 << 14)) failed = true; else ins = rg.next() < 0x80000000u; }
@@ -532,11 +549,11 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
                     if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
                         if (next_c == c) failed = true;             // the whole read was one deleted homopolymer (the reference asserts)
                         else {
-                            const int jj = dist[4 * flow_i + (int)next_c];
+                            const int jj = T.dist[(flow_i << 2) | next_c];
                             const uint32_t dw = slow ? rg.next() : W.oc_dot;
                             const int kk = (int)(((uint64_t)dw * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
-                            int f = flow_i + kk; if (f >= F) f -= F;
-                            o1.push(flow[f]);
+                            int f = (int)flow_i + kk; if (f >= F) f -= F;
+                            o1.push(T.flow[f]);
                         }
                     } else if (t < len) { o1.push(B.get1(in0 + t)); ++t; }   // the base now at this position is not examined
                     prev_c = c;
@@ -549,27 +566,24 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     }
     o1.flush();
     const int n1 = o1.n;
-    const int marked_flow = marked ? flow_i : -1;      // the one flow of the (persistent) mask that pass 2 finds set
+    const int marked_flow = marked ? (int)flow_i : -1;      // the one flow of the (persistent) mask that pass 2 finds set
 
     // ---- the output of pass 1 moves up to the buffer's top (positions capb - n1 ..), from the top word down: one read and one write per word ----
-    if (!failed) {
-        const int D = capb - n1;
-        if (D > 0) {
-            const int dw = D >> 4; const uint32_t sh = ((uint32_t)D & 15u) * 2u;
-            uint32_t hi = buf[(capw - 1 - dw) * stride];
-            for (int j = capw - 1; j >= dw; --j) {
-                const uint32_t lo = j - dw - 1 >= 0 ? buf[(j - dw - 1) * stride] : 0u;
-                buf[j * stride] = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
-                hi = lo;
-            }
+    if (!failed && n1 > 0 && n1 < capb) {
+        const int D = capb - n1, dw = D >> 4; const uint32_t sh = ((uint32_t)D & 15u) * 2u;
+        uint32_t hi = buf[(capw - 1 - dw) * stride];
+        for (int j = capw - 1; j >= dw; --j) {
+            const uint32_t lo = j - dw - 1 >= 0 ? buf[(j - dw - 1) * stride] : 0u;
+            buf[j * stride] = sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;
+            hi = lo;
         }
     }
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
     // g counts the empty flows examined so far: flow g's first draw is event g of the pass.  A base whose empty flows end at or before the next
-    // scoring flow is quiet.  Lanes with an empty stack move up to eight quiet bases per iteration, lanes with pending runs one; a base with a
-    // scoring flow (or the window's end) in front of it goes through the flow-by-flow code below. ----
+    // scoring flow is quiet: lanes with an empty stack move up to sixteen quiet bases per iteration; a base with a scoring flow (or the window's
+    // end) in front of it, and every base examined while runs are pending, goes through the flow-by-flow code below. ----
     const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
     const int in2 = capb - n1;
     BitAppender<2> o2; o2.init(buf, stride);
@@ -589,57 +603,64 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const uint8_t *flow, const uint
     W.init();
     {
         bool done = failed, parked = false; uint32_t g = 0, x = 0;
-        for (;;) {
+        for (uint32_t it = 0;; ++it) {
             if (!done) W.advance(g);
-            while (__ballot(!done && W.room() && W.frontier() < g + 32u)) { if (!done && W.room()) W.draw(key, dom2, rg.ii, rg.att, thr); }
+            while (__ballot(!done && W.room() && W.frontier() < g + 40u)) { if (!done && W.room()) W.draw(key, dom2, rg.ii, rg.att, thr); }
             if (!done && !parked) {
-                if (sp == 0 && t2 >= n1) done = true;
-                else if (sp > 0) {                                  // runs pending: one base
-                    x = stk_get(sp - 1) >> 14;
-                    const uint32_t k = dist[4 * flow_i + (int)x];
-                    bool real; const uint32_t st = W.stop(g, real);
-                    if (g + k <= st) { step_flow(k); g += k; settle(x); if (failed) done = true; } else parked = true;
-                }
+                if (sp > 0) { x = stk_get(sp - 1) >> 14; parked = true; }       // runs pending: base by base, below
+                else if (t2 >= n1) done = true;
                 else {
-                    const uint32_t v = B.get8(in2 + t2);
-                    const int n = n1 - t2 < 8 ? n1 - t2 : 8;
+                    const uint32_t v = B.get16(in2 + t2);
+                    const int n = n1 - t2 < 16 ? n1 - t2 : 16;
                     bool real; const uint32_t st = W.stop(g, real);
-                    int m = 0; bool quiet = true;
+                    uint32_t rem = st - g;                                       // flows that may be passed before the lane has to stop
+                    int m = 0; bool ok = true;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const uint32_t k = dist[4 * flow_i + (int)((v >> (2 * i)) & 3u)];
-                        quiet = quiet && i < n && g + k <= st;
-                        if (quiet) { step_flow(k); g += k; ++m; }
+                    for (int p = 0; p < 8; ++p) {
+                        const uint32_t e = T.pair[(flow_i << 4) | ((v >> (4 * p)) & 15u)], kt = e >> 8;
+                        ok = ok && 2 * p + 2 <= n && kt <= rem;
+                        if (ok) { rem -= kt; flow_i = e & 63u; m += 2; }
                     }
-                    o2.push_many(v & ((1u << (2 * m)) - 1u), m);
+                    if (m < n) {                                                 // the pair that did not fit: its first base alone may
+                        const uint32_t i1 = (flow_i << 2) | ((v >> (2 * m)) & 3u), k = T.dist[i1];
+                        if (k <= rem) { rem -= k; flow_i = T.next1[i1]; ++m; }
+                    }
+                    g = st - rem;
+                    o2.push_many(m < 16 ? v & ((1u << (2 * m)) - 1u) : v, m);
                     t2 += m;
                     if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }
                 }
             }
             if (parked) {      // flow by flow up to x's own: quiet flows are skipped together, a scoring one inserts (dwgsim.c:373-383)
-                uint32_t left = dist[4 * flow_i + (int)x];
                 for (;;) {
+                    uint32_t left = T.dist[(flow_i << 2) | x];
                     bool real; const uint32_t st = W.stop(g, real);
                     const uint32_t q = st - g, skip = q < left ? q : left;
-                    step_flow(skip); g += skip; left -= skip;
-                    if (left == 0) { settle(x); parked = false; if (failed) done = true; break; }
+                    { uint32_t f = flow_i + skip; if (f >= (uint32_t)F) f -= (uint32_t)F; flow_i = f; }
+                    g += skip; left -= skip;
+                    if (left == 0) {
+                        settle(x);
+                        if (failed) { done = true; parked = false; break; }
+                        if (sp == 0) { parked = false; break; }
+                        x = stk_get(sp - 1) >> 14;                  // the next base to examine is the first of the top run
+                        continue;
+                    }
                     if (!real || W.oc_pos != g) break;              // the window's end, or an event whose further draws are not there yet: next round
                     int n_err;
                     if (W.oc & 0x200u) { rg.open(g); n_err = rg.more_errors(thr); } else n_err = (int)(W.oc & 0xffu);
-                    if (flow_i != marked_flow) {
+                    if ((int)flow_i != marked_flow) {
                         if (sp >= stack_runs || n_err >= (1 << 14)) { failed = true; done = true; parked = false; break; }
-                        stk_set(sp, ((uint32_t)flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err;
+                        stk_set(sp, ((uint32_t)T.flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err;
                     }
-                    step_flow(1);
-                    ++g; --left;
+                    flow_i = flow_i + 1u == (uint32_t)F ? 0u : flow_i + 1u;
+                    ++g;
                 }
             }
             {
                 bool real = false; uint32_t st = 0;
                 if (!done) st = W.stop(g, real);
                 const bool unresolved = !done && real && W.oc_pos != st;
-                const bool waiting = parked && unresolved && st == g;
-                if (flow_batch_due(waiting, !done && !waiting)) { if (unresolved) W.resolve(key, dom2 + D_FLOW_EV, rg.ii, rg.att, st, thr); }
+                if (__ballot(unresolved && ((parked && st == g) || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, dom2 + D_FLOW_EV, rg.ii, rg.att, st, thr); }
             }
             if (__ballot(!done) == 0) break;
         }

@@ -420,7 +420,7 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
 // block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
 // block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
 template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 3 ? DW_IONL_WAVES : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     static_assert(SPLIT == 0 || (DT == 0 && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants with 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
@@ -428,8 +428,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 3 ? DW_
     __shared__ uint32_t s_ticket, s_slot;
     __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][32];          // "@[prefix_]contig" and "@[prefix_]rand", first 128 bytes
-    __shared__ uint8_t s_flow[64];               // Ion Torrent flow order
-    __shared__ uint8_t s_dist[256];              // ... and the flow-distance table (fill_flow_dist)
+    __shared__ FlowTables s_ft;                  // Ion Torrent: the flow order and its look-up tables (dw_read.hpp fill_flow_tables)
     constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
     // where a lane's packed bases are staged: LDS (Illumina / SOLiD reads up to ~1 180 bases, 256-lane blocks), or a SCRATCH SLOT in global memory --
     // the Ion Torrent read buffers, and every read too long for that (the one-wave blocks): staged in LDS a 2 000-base read left room for two waves
@@ -443,7 +442,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 3 ? DW_
     if (GS && tid == 0) { s_slot = scratch_slot_take(a.flow_free, (uint32_t)a.flow_slots, a.n_blocks); asm volatile("" ::: "memory"); }      // (before the ticket: see scratch_slot_take)
     if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
-    if (ION && tid < 64) s_flow[tid] = a.flow[tid];
+    if (ION && tid < 64) s_ft.flow[tid] = a.flow[tid];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
     const size_t stage_words = SPLIT == 2 ? 0 : DT == 3 ? (size_t)(a.lds_words + a.flow_stack_words) : DT == 2 ? (size_t)a.flow_stack_words : GS ? 0 : (size_t)a.lds_words;      // (the second half of the two-kernel form reads its bases from HBM)
     uint32_t *const s_qb = dyn_lds + stage_words * nthr;
@@ -460,7 +459,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 3 ? DW_
     const SegCtx sc = seg_ctx(a, sg);
     const uint8_t *name_fixed = a.names + sg->name_off;
     if (H != 1) for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
-    if (ION) { fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr); __syncthreads(); }
+    if (ION) { fill_flow_tables(s_ft, a.flow_len, tid, nthr); __syncthreads(); }
     const int j = (LPP == 2) ? (tid & 1) : 0;
     const uint64_t pair_in = (uint64_t)(t - sg->first_block) * PPB + (uint64_t)(tid / LPP);      // inside the range
     const bool valid = pair_in < sg->n_pairs;
@@ -540,7 +539,7 @@ __global__ void __launch_bounds__(NTHR, (NTHR != SIM_THREADS ? 1 : DT == 3 ? DW_
     if (ION) {                                  // dwgsim.c:861-864; every lane calls (the loops of the model are wave-uniform)
         const bool flows = valid && !is_rand && s > 0;
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(flows, rg, s_flow, s_dist, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, flow_stk, nthr, 2 * a.flow_stack_words, s, j ? pd.strand1 : pd.strand0, capb, &n_err);
+        const int so = flow_errors(flows, rg, s_ft, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, flow_stk, nthr, 2 * a.flow_stack_words, s, j ? pd.strand1 : pd.strand0, capb, &n_err);
         if (flows) {
             s_out = so;
             if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
@@ -1257,12 +1256,11 @@ DW_SIM_FAMILY(1, 2)
 __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
 {
     DW_DYN_SHARED(uint32_t, dyn_lds);
-    __shared__ uint8_t s_flow[64];
-    __shared__ uint8_t s_dist[256];
+    __shared__ FlowTables s_ft;
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK;
-    if (tid < 64) s_flow[tid] = a.flow[tid];
+    if (tid < 64) s_ft.flow[tid] = a.flow[tid];
     __syncthreads();
-    fill_flow_dist(s_flow, a.flow_len, s_dist, tid, nthr);
+    fill_flow_tables(s_ft, a.flow_len, tid, nthr);
     __syncthreads();
     const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
     uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)a.lds_words * nthr) + tid;
@@ -1285,7 +1283,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     }
     {   // every lane calls (the loops of the model are wave-uniform)
         FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(live, rg, s_flow, s_dist, a.flow_len, a.thr, buf, dyn_lds + tid, nthr, 2 * a.stack_words, a.len, 0, capb, &n_err);
+        const int so = flow_errors(live, rg, s_ft, a.flow_len, a.thr, buf, dyn_lds + tid, nthr, 2 * a.stack_words, a.len, 0, capb, &n_err);
         if (live) { s_out = so; if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; } }
     }
     const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);

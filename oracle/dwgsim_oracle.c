@@ -86,7 +86,10 @@ typedef struct {
     int use_libm_log;      /* ran_normal uses libm log() instead of det_log() */
     uint64_t n_draws;      /* number of uniforms consumed (both modes) */
     uint64_t n_log_mismatch; /* mode diagnostics: det_log(x) != log(x) bitwise */
+    FILE *dump;            /* --dump-draws (mode B): every uniform, as a raw double, in the order it is consumed -- what oracle/replay48.c feeds to the
+                              UNMODIFIED reference as its drand48() stream (tests/test_replay_parity.py) */
 } rng_t;
+static inline double rng_out(rng_t *r, double u) { if (r->dump) fwrite(&u, sizeof u, 1, r->dump); return u; }
 
 /* Philox4x32-10, Salmon et al. SC'11 (Random123).  SURVEY.md App. E.2 known answers are
  * checked in tests/test_oracle_units.py. */
@@ -148,7 +151,7 @@ static inline double rng_u(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, u
 {
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    return oracle_philox_uniform(r->k0, r->k1, dom, idx, att, retry, slot);
+    return rng_out(r, oracle_philox_uniform(r->k0, r->k1, dom, idx, att, retry, slot));
 }
 
 /* NARROW uniform of the per-base domains: mode B takes one 32-bit word (word = slot & 3 of block
@@ -169,7 +172,7 @@ static inline double rng_u32(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att,
 {
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    return oracle_philox_uniform32(r->k0, r->k1, dom, idx, att, retry, slot);
+    return rng_out(r, oracle_philox_uniform32(r->k0, r->k1, dom, idx, att, retry, slot));
 }
 
 /* The uniform of base i of read end j (error test dwgsim.c:237, random-read base :1000).  Mode B: 32 bits, u = ((h << 16) | l) * 2^-32 with
@@ -187,14 +190,14 @@ static inline double rng_u16(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att,
 {
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    return (double)philox_halfword(r, dom, idx, att, i) * 0x1p-16;
+    return rng_out(r, (double)philox_halfword(r, dom, idx, att, i) * 0x1p-16);
 }
 static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
 {
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
     const uint32_t h = philox_halfword(r, D_BASE0 + (uint32_t)j, idx, att, i), l = philox_halfword(r, D_BASE_REF0 + (uint32_t)j, idx, att, i);
-    return (double)((h << 16) | l) * 0x1p-32;
+    return rng_out(r, (double)((h << 16) | l) * 0x1p-32);
 }
 
 /* mut.c:618 drand48() < opt->mut_rate, one per non-N position: by far the most frequent draw of the walk, so it is a narrow one, eight per block */
@@ -203,7 +206,7 @@ static inline double walk_site_u(rng_t *r, uint32_t p)
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
     const uint32_t h = philox_halfword(r, D_WALK_SITE, 0, 0, p), l = philox_halfword(r, D_WALK_SITE_REF, 0, 0, p);
-    return (double)((h << 16) | l) * 0x1p-32;
+    return rng_out(r, (double)((h << 16) | l) * 0x1p-32);
 }
 
 /* Deterministic natural log for x > 0 finite: the classic fdlibm/FreeBSD-msun e_log.c
@@ -305,6 +308,7 @@ typedef struct {
     char *fn_regions;               /* -x */
     char *fn_muts; int muts_type;   /* -m (1, txt) / -b (0, bed) / -v (2, vcf): mut_input.h:29-33 */
     int rng_mode, use_libm_log, null_fastq, verbose;
+    const char *dump_path;            /* --dump-draws FILE (mode B only) */
     int64_t emit_first, emit_count;   /* --emit-range first:count (mode B only): emit only these read indices of every contig */
     /* Whole-genome checks without walking the whole genome (mode B only: every decision has its own RNG slot, so nothing else carries over):
      * --as-contig K,TOT,AFTER,NSIM  the FASTA holds ONE contig of a larger genome: it is contig number K (RNG key), the genome's total length is
@@ -908,7 +912,7 @@ static inline double flow_first(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t 
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
     const uint32_t hi = philox_halfword(r, fdom, idx, att, h), lo = philox_halfword(r, fdom + D_FLOW_REF, idx, att, h);
-    return (double)((hi << 16) | lo) * 0x1p-32;
+    return rng_out(r, (double)((hi << 16) | lo) * 0x1p-32);
 }
 static inline double flow_u(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t evt, uint32_t *es)
 {
@@ -1085,6 +1089,11 @@ static int opt_parse(opt_t *o, rng_t *r, int argc, char **argv, int *first_arg)
 
     rng_seed(r, o->rng_mode, (-1 == o->seed) ? (int32_t)time(0) : o->seed);
     r->use_libm_log = o->use_libm_log;
+    if (o->dump_path) {
+        if (r->mode != RNG_PHILOX) { fprintf(stderr, "oracle: --dump-draws needs --rng philox\n"); return 0; }
+        r->dump = fopen(o->dump_path, "wb");
+        if (!r->dump) { fprintf(stderr, "oracle: cannot write %s\n", o->dump_path); return 0; }
+    }
 
     if (IONTORRENT == o->data_type) { /* dwgsim_opt.c:396-413 */
         o->flow_order_len = (int)strlen((char *)o->flow_order);
@@ -1501,6 +1510,7 @@ int oracle_main(int argc, char **argv)
         if (!strcmp(argv[i], "--rng") && i + 1 < argc) { ++i; o.rng_mode = !strcmp(argv[i], "philox") ? RNG_PHILOX : RNG_DRAND48; }
         else if (!strcmp(argv[i], "--log") && i + 1 < argc) { ++i; o.use_libm_log = !strcmp(argv[i], "libm"); }
         else if (!strcmp(argv[i], "--null-fastq")) o.null_fastq = 1;
+        else if (!strcmp(argv[i], "--dump-draws") && i + 1 < argc) { ++i; o.dump_path = argv[i]; }
         else if (!strcmp(argv[i], "--verbose")) o.verbose = 1;
         else if (!strcmp(argv[i], "--emit-range") && i + 1 < argc) { ++i; long long a = 0, b = 0; sscanf(argv[i], "%lld:%lld", &a, &b); o.emit_first = a; o.emit_count = b; }
         else if (!strcmp(argv[i], "--as-contig") && i + 1 < argc) { ++i; long long a = 0, b = 0, c = 0, d = 0; sscanf(argv[i], "%lld,%lld,%lld,%lld", &a, &b, &c, &d); o.as_contig = a; o.as_tot = b; o.as_after = c; o.as_nsim = d; }
@@ -1509,7 +1519,7 @@ int oracle_main(int argc, char **argv)
     }
     av[ac] = NULL;
     int first = 0;
-    if (!opt_parse(&o, &r, ac, av, &first)) { fprintf(stderr, "usage: dwgsim_oracle [--rng drand48|philox] [--log det|libm] [--null-fastq] [dwgsim options] <in.ref.fa> <out.prefix>\n"); free(av); return 1; }
+    if (!opt_parse(&o, &r, ac, av, &first)) { fprintf(stderr, "usage: dwgsim_oracle [--rng drand48|philox] [--log det|libm] [--null-fastq] [--dump-draws FILE] [dwgsim options] <in.ref.fa> <out.prefix>\n"); free(av); return 1; }
     const char *fa = av[first], *prefix = av[first + 1];
     outs_t out; memset(&out, 0, sizeof out);
     out.has_mut = o.output_type != 1;
@@ -1530,6 +1540,7 @@ int oracle_main(int argc, char **argv)
                 o.rng_mode ? "philox" : "drand48", (unsigned long long)st.n_pairs_total, (unsigned long long)st.n_rand_total,
                 (unsigned long long)st.n_attempt_fail, (unsigned long long)r.n_draws, (unsigned long long)r.n_log_mismatch,
                 (unsigned long long)(out.bfast.total + out.bwa1.total + out.bwa2.total));
+    if (r.dump) fclose(r.dump);
     free(o.flow_order); free(o.read_prefix); free(o.fixed_quality); free(av);
     return rc;
 }
