@@ -258,18 +258,21 @@ int dwgsim_hip_params_check(const dwgsim_hip_params_t *p, char *msg, size_t cap)
     else if (0 < p->N) { CHK(p->N, 1, INT32_MAX, "-N"); CHK(p->C, INT32_MIN, -1, "-C"); }
     else { CHK(p->N, INT32_MIN, -1, "-N"); CHK(p->C, 0, INT32_MAX, "-C"); }
     CHK(p->length[0], 1, INT32_MAX, "-1"); CHK(p->length[1], 0, INT32_MAX, "-2");
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {      // dwgsim_opt.c:329-344
         if (p->e_start[i] < 0.0 || 1.0 < p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: the start error is out of range (-e)\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
         if (p->e_end[i] < 0.0 || 1.0 < p->e_end[i]) { if (msg) snprintf(msg, cap, "End %s: the end error is out of range (-e)\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
+        if (p->data_type == 2 && p->e_end[i] != p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: a uniform error rate must be given for Ion Torrent data\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
     }
     CHK(p->mut_rate, 0, 1.0, "-r"); CHK(p->indel_frac, 0, 1.0, "-R"); CHK(p->indel_extend, 0, 1.0, "-X");
     CHK(p->indel_min, 1, INT32_MAX, "-I"); CHK(p->data_type, 0, 2, "-c"); CHK(p->strandedness, 0, 2, "-S");
     CHK(p->read_one_strand, 0, 2, "-A"); CHK(p->max_n, 0, INT32_MAX, "-n"); CHK(p->rand_read, 0, 1.0, "-y");
-    CHK(p->use_base_error, 0, 1, "-B"); CHK(p->is_hap, 0, 1, "-H");
-    CHK(p->quality_std, 0, INT32_MAX, "-Q"); CHK(p->reads_output_type, 0, 2, "-o"); CHK(p->output_type, 0, 2, "-M"); CHK(p->amplicons, 0, 1, "-a");
     if (p->data_type == 2 && !p->flow_order) { if (msg) snprintf(msg, cap, "Error: command line option -f is required\n"); return DWGSIM_HIP_ERR_ARG; }
-    if (p->data_type == 2) {       // dwgsim_opt.c:338-343, :396-413
-        for (int i = 0; i < 2; ++i) if (p->e_end[i] != p->e_start[i]) { if (msg) snprintf(msg, cap, "End %s: a uniform error rate must be given for Ion Torrent data\n", i ? "two" : "one"); return DWGSIM_HIP_ERR_ARG; }
+    CHK(p->use_base_error, 0, 1, "-B"); CHK(p->is_hap, 0, 1, "-H");
+    if (p->fixed_quality < -1 || p->fixed_quality > 255) { if (msg) snprintf(msg, cap, "Error: command line option -q requires one character\n"); return DWGSIM_HIP_ERR_ARG; }      // (-1: none; dwgsim_opt.c:364-367)
+    CHK(p->quality_std, 0, INT32_MAX, "-Q"); CHK(p->reads_output_type, 0, 2, "-o");
+    // (not checked by the reference, which treats every other -M as 0 and every non-zero -a as set; the library wants them clean)
+    CHK(p->output_type, 0, 2, "-M"); CHK(p->amplicons, 0, 1, "-a");
+    if (p->data_type == 2) {       // dwgsim_opt.c:396-413
         const size_t F = strlen(p->flow_order);
         bool has[4] = {false, false, false, false};
         for (size_t i = 0; i < F; ++i) { const uint8_t c = nt4((unsigned char)p->flow_order[i]); if (c < 4) has[c] = true; }
@@ -347,8 +350,10 @@ int64_t dwgsim_hip_group_layout(const int64_t *lens, int n, int64_t *starts)
 // Ion Torrent: room for a read after the flow model.  Every empty flow in front of a base inserts Geometric(e) bases, and inserted bases are
 // examined again.  How many empty flows a base has in front of it is a property of the flow order: m = the mean distance from a flow to the next
 // flow of a given base (about 2.5 for the usual 32-flow orders, 1.5 for TACG, but 15 for an order that keeps three bases away for 37 flows).  The
-// mean growth is g = m e / (1 - e) per base, with the cascade 1 / (1 - g); four times that plus slack keeps overflow (reported as an error, never
-// written out of bounds) out of reach for realistic error rates and far away even for e = 0.3.
+// mean growth is g = m e / (1 - e) per base, with the cascade 1 / (1 - g); two and a half times that (m is taken as at least 3, twice what the
+// usual orders have) plus slack keeps overflow out of reach for realistic error rates -- and what does overflow is run again with twice the room
+// (dwgsim_hip_wait), never written out of bounds.  The room is LDS (dw_read.hpp flow_errors: one in-place buffer of cap / 4 bytes per lane), so it is
+// not handed out as generously as rounds 1-4 did with global scratch (len + 64 + 4 len g).
 static int flow_read_capacity(int len, double e, const std::vector<uint8_t> &flow)
 {
     const double ec = !(e > 0) ? 0 : e > 0.9 ? 0.9 : e;       // (NaN, e.g. -B with -e 0: no flow errors at all)
@@ -362,7 +367,7 @@ static int flow_read_capacity(int len, double e, const std::vector<uint8_t> &flo
     }
     double g = m * ec / (1.0 - ec);
     g = g / (1.0 - (g < 0.75 ? g : 0.75));
-    return len + 64 + (int)(len * 4.0 * g);
+    return len + 32 + (int)(len * 2.5 * g);
 }
 
 static int set_err(int *err, int v) { if (err) *err = v; return v; }

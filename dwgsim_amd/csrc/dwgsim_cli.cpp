@@ -46,34 +46,63 @@
 
 #define PACKAGE_VERSION "0.1.17-hip"
 
-static int usage(const dwgsim_hip_params_t *o)
+// The option summary of the reference (dwgsim_opt.c:93-160), line for line -- it is the interface a drop-in shows -- behind this program's own
+// banner; the bracketed values are the current settings, printed as the reference prints them (an error-rate step that is only computed
+// after parsing, the inverted "not using" of -b / -v, "(null)" for strings that were not given).
+struct UsageExtras { const char *flow, *muts_fn, *regions_fn, *prefix, *fixed_quality; int muts_type; };      // muts_type: 0 bed, 1 txt, 2 vcf (mut_input.h:33-37), -1 none
+static const char *str_or_null(const char *s) { return s ? s : "(null)"; }
+static int usage(const dwgsim_hip_params_t *o, const UsageExtras &x)
 {
-    fprintf(stderr, "\nProgram: dwgsim-hip (short read simulator, MI355X hot path)\nVersion: %s\n\n", PACKAGE_VERSION);
-    fprintf(stderr, "Usage:   dwgsim-hip [options] <in.ref.fa> <out.prefix>\n\nOptions:\n");
-    fprintf(stderr, "         -e FLOAT      per base/color/flow error rate of the first read [from %.3f to %.3f]\n", o->e_start[0], o->e_end[0]);
-    fprintf(stderr, "         -E FLOAT      per base/color/flow error rate of the second read [from %.3f to %.3f]\n", o->e_start[1], o->e_end[1]);
-    fprintf(stderr, "         -i            use the inner distance instead of the outer distance for pairs\n");
-    fprintf(stderr, "         -d INT        outer/inner distance between the two ends for pairs [%d]\n", o->dist);
-    fprintf(stderr, "         -s INT        standard deviation of the distance for pairs [%.3f]\n", o->std_dev);
-    fprintf(stderr, "         -N INT        number of read pairs (-1 to disable) [%lld]\n", (long long)o->N);
-    fprintf(stderr, "         -C FLOAT      mean coverage across available positions (-1 to disable) [%.2lf]\n", o->C);
-    fprintf(stderr, "         -1 INT        length of the first read [%d]\n         -2 INT        length of the second read [%d]\n", o->length[0], o->length[1]);
-    fprintf(stderr, "         -r FLOAT      rate of mutations [%.4f]\n         -F FLOAT      frequency of given mutation [%.4f]\n", o->mut_rate, o->mut_freq);
-    fprintf(stderr, "         -R FLOAT      fraction of mutations that are indels [%.2f]\n         -X FLOAT      probability an indel is extended [%.2f]\n", o->indel_frac, o->indel_extend);
-    fprintf(stderr, "         -I INT        the minimum length indel [%d]\n         -y FLOAT      probability of a random DNA read [%.2f]\n", o->indel_min, o->rand_read);
-    fprintf(stderr, "         -n INT        maximum number of Ns allowed in a given read [%d]\n", o->max_n);
-    fprintf(stderr, "         -c INT        generate reads for 0: Illumina, 1: SOLiD, 2: Ion Torrent [%d]\n", o->data_type);
-    fprintf(stderr, "         -S INT        paired end orientation 0: default, 1: same strand, 2: opposite strand [%d]\n", o->strandedness);
-    fprintf(stderr, "         -A INT        read one strand 0: random, 1: forward, 2: reverse [%d]\n", o->read_one_strand);
-    fprintf(stderr, "         -H            haploid mode\n         -z INT        random seed (-1 uses the current time) [%d]\n", o->seed);
-    fprintf(stderr, "         -M INT        output files 0: reads and mutations, 1: reads only, 2: mutations only [%d]\n", o->output_type);
-    fprintf(stderr, "         -P STRING     a read prefix to prepend to each read name\n         -q STRING     a fixed base quality to apply (single character)\n");
-    fprintf(stderr, "         -Q FLOAT      standard deviation of the base quality scores [%.2lf]\n", o->quality_std);
-    fprintf(stderr, "         -o INT        FASTQ output 0: bfast and bwa, 1: bwa only, 2: bfast only [%d]\n", o->reads_output_type);
-    fprintf(stderr, "         -a            assume each contig is an amplicon\n         -h            print this message\n\n");
-    fprintf(stderr, "         -f STRING     the flow order for Ion Torrent data\n");
-    fprintf(stderr, "         -m FILE       the mutations txt file to re-create\n         -b FILE       the bed-like file set of candidate mutations\n         -v FILE       the vcf file set of candidate mutations (use pl tag for strand)\n");
-    fprintf(stderr, "         -x FILE       the bed of regions to cover\n");
+    auto yes = [](int v) { return v == 1 ? "True" : "False"; };
+    const int mt = x.muts_type;      // (-1 while none was given: dwgsim_opt.c:77)
+    FILE *f = stderr;
+    fprintf(f, "\nProgram: dwgsim-hip (short read simulator, MI355X hot path of dwgsim)\nVersion: %s\n\n", PACKAGE_VERSION);
+    fprintf(f, "Usage:   dwgsim-hip [options] <in.ref.fa> <out.prefix>\n\nOptions:\n");
+    const char *P = "         ";
+    fprintf(f, "%s-e FLOAT      per base/color/flow error rate of the first read [from %.3f to %.3f by %.3f]\n", P, o->e_start[0], o->e_end[0], 0.0);
+    fprintf(f, "%s-E FLOAT      per base/color/flow error rate of the second read [from %.3f to %.3f by %.3f]\n", P, o->e_start[1], o->e_end[1], 0.0);
+    fprintf(f, "%s-i            use the inner distance instead of the outer distance for pairs [%s]\n", P, yes(o->is_inner));
+    fprintf(f, "%s-d INT        %s distance between the two ends for pairs [%d]\n", P, o->is_inner ? "inner" : "outer", o->dist);
+    fprintf(f, "%s-s INT        standard deviation of the distance for pairs [%.3f]\n", P, o->std_dev);
+    fprintf(f, "%s-N INT        number of read pairs (-1 to disable) [%lld]\n", P, (long long)o->N);
+    fprintf(f, "%s-C FLOAT      mean coverage across available positions (-1 to disable) [%.2lf]\n", P, o->C);
+    fprintf(f, "%s-1 INT        length of the first read [%d]\n", P, o->length[0]);
+    fprintf(f, "%s-2 INT        length of the second read [%d]\n", P, o->length[1]);
+    fprintf(f, "%s-r FLOAT      rate of mutations [%.4f]\n", P, o->mut_rate);
+    fprintf(f, "%s-F FLOAT      frequency of given mutation to simulate low fequency somatic mutations [%.4f]\n", P, o->mut_freq);
+    fprintf(f, "%s                  NB: freqeuncy F refers to the first strand of mutation, therefore mutations \n", P);
+    fprintf(f, "%s                  on the second strand occur with a frequency of 1-F \n", P);
+    fprintf(f, "%s-R FLOAT      fraction of mutations that are indels [%.2f]\n", P, o->indel_frac);
+    fprintf(f, "%s-X FLOAT      probability an indel is extended [%.2f]\n", P, o->indel_extend);
+    fprintf(f, "%s-I INT        the minimum length indel [%d]\n", P, o->indel_min);
+    fprintf(f, "%s-y FLOAT      probability of a random DNA read [%.2f]\n", P, o->rand_read);
+    fprintf(f, "%s-n INT        maximum number of Ns allowed in a given read [%d]\n", P, o->max_n);
+    fprintf(f, "%s-c INT        generate reads for [%d]:\n", P, o->data_type);
+    for (const char *l : {"0: Illumina", "1: SOLiD", "2: Ion Torrent"}) fprintf(f, "%s                  %s\n", P, l);
+    fprintf(f, "%s-S INT        generate paired end reads with orientation [%d]:\n", P, o->strandedness);
+    for (const char *l : {"0: default (opposite strand for Illumina, same strand for SOLiD/Ion Torrent)", "1: same strand (mate pair)", "2: opposite strand (paired end)"}) fprintf(f, "%s                  %s\n", P, l);
+    fprintf(f, "%s-A INT        generate paired end reads with read one [%d]:\n", P, o->read_one_strand);
+    for (const char *l : {"0: default (both, random)", "1: forward genomic strand", "2: reverse genomic strand"}) fprintf(f, "%s                  %s\n", P, l);
+    fprintf(f, "%s-f STRING     the flow order for Ion Torrent data [%s]\n", P, str_or_null(x.flow));
+    fprintf(f, "%s-B            use a per-base error rate for Ion Torrent data [%s]\n", P, yes(o->use_base_error));
+    fprintf(f, "%s-H            haploid mode [%s]\n", P, yes(o->is_hap));
+    fprintf(f, "%s-z INT        random seed (-1 uses the current time) [%d]\n", P, o->seed);
+    fprintf(f, "%s-M            output files to generate [%d]:\n", P, o->output_type);
+    for (const char *l : {"0: both reads and mutation files", "1: reads only", "2: mutations only"}) fprintf(f, "%s                  %s\n", P, l);
+    fprintf(f, "%s-m FILE       the mutations txt file to re-create [%s]\n", P, mt != 1 ? "not using" : str_or_null(x.muts_fn));
+    fprintf(f, "%s-b FILE       the bed-like file set of candidate mutations [%s]\n", P, mt == 0 ? "not using" : str_or_null(x.muts_fn));
+    fprintf(f, "%s-v FILE       the vcf file set of candidate mutations (use pl tag for strand) [%s]\n", P, mt == 2 ? "not using" : str_or_null(x.muts_fn));
+    fprintf(f, "%s-x FILE       the bed of regions to cover [%s]\n", P, x.regions_fn ? x.regions_fn : "not using");
+    fprintf(f, "%s-P STRING     a read prefix to prepend to each read name [%s]\n", P, x.prefix ? x.prefix : "not using");
+    fprintf(f, "%s-q STRING     a fixed base quality to apply (single character) [%s]\n", P, x.fixed_quality ? x.fixed_quality : "not using");
+    fprintf(f, "%s-Q FLOAT      standard deviation of the base quality scores [%.2lf]\n", P, x.fixed_quality ? 0.0 : o->quality_std);
+    fprintf(f, "%s-o INT        output type for the FASTQ files [%d]:\n", P, o->reads_output_type);
+    for (const char *l : {"0: interleaved (bfast) and per-read-end (bwa)", "1: per-read-end (bwa) only", "2: interleaved (bfast) only"}) fprintf(f, "%s                  %s\n", P, l);
+    fprintf(f, "%s-a            assume each contig is an amplicon, so read pairs will sequence the full amplicon [%s]\n", P, yes(o->amplicons));
+    fprintf(f, "%s-h            print this message\n\n", P);
+    fprintf(f, "Note: For SOLiD mate pair reads and BFAST, the first read is F3 and the second is R3. For SOLiD mate pair reads\n"
+               "and BWA, the reads in the first file are R3 the reads annotated as the first read etc.\n\n");
+    fprintf(f, "Note: The longest supported insertion is %u.\n\n", UINT32_MAX);
     return 1;
 }
 
@@ -158,7 +187,7 @@ static bool read_fasta(const char *fn, const std::function<bool(const std::strin
     std::vector<char> buf((size_t)1 << 24);
     if (strcmp(fn, "-")) {
         const int fd = open(fn, O_RDONLY);
-        if (fd < 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn); return false; }
+        if (fd < 0) { fprintf(stderr, "[main] fail to open file '%s'. Abort!\n", fn); return false; }      // (xopen in main, dwgsim.c:225, :1139)
         ssize_t n;
         while (ps.go && (n = read(fd, buf.data(), buf.size())) > 0) ps.feed(buf.data(), (size_t)n);
         close(fd);
@@ -422,8 +451,13 @@ int main(int argc, char **argv)
     const double t_start = now_s();
     const bool timing = getenv("DWGSIM_HIP_TIMING") != nullptr;      // stage times on stderr
     dwgsim_hip_params_t o; dwgsim_hip_params_default(&o);
-    std::string prefix_s, fixedq_s, flow_s, regions_fn, muts_fn; int muts_type = -1, muts_flags = 0;
+    std::string prefix_s, fixedq_s, flow_s, regions_fn, muts_fn; int muts_type = -1, muts_flags = 0; bool have_q = false;
     int c;
+    auto usage_now = [&]() {
+        const UsageExtras x{flow_s.empty() ? nullptr : flow_s.c_str(), muts_fn.empty() ? nullptr : muts_fn.c_str(), regions_fn.empty() ? nullptr : regions_fn.c_str(),
+                            o.read_prefix ? prefix_s.c_str() : nullptr, have_q ? fixedq_s.c_str() : nullptr, muts_type};
+        return usage(&o, x);
+    };
     while ((c = getopt(argc, argv, "id:s:N:C:1:2:e:E:r:F:R:X:I:c:S:A:n:y:BHf:z:M:m:b:v:x:P:q:Q:o:ah")) >= 0) {
         switch (c) {
         case 'i': o.is_inner = 1; break;
@@ -446,11 +480,11 @@ int main(int argc, char **argv)
         case 'n': o.max_n = xatoi(optarg, 'n', 0); break;
         case 'y': o.rand_read = atof(optarg); break;
         case 'H': o.is_hap = 1; break;
-        case 'h': return usage(&o);
+        case 'h': return usage_now();
         case 'z': o.seed = xatoi(optarg, 'z', 1); break;
         case 'M': o.output_type = xatoi(optarg, 'M', 0); break;
         case 'P': prefix_s = optarg; o.read_prefix = prefix_s.c_str(); break;
-        case 'q': fixedq_s = optarg; if (fixedq_s.size() != 1) { fprintf(stderr, "Error: command line option -q requires one character\n"); return usage(&o); } o.fixed_quality = (unsigned char)fixedq_s[0]; break;
+        case 'q': fixedq_s = optarg; have_q = true; o.fixed_quality = fixedq_s.size() == 1 ? (unsigned char)fixedq_s[0] : -2; break;      // (checked behind the other options, as the reference does: dwgsim_opt.c:364-367)
         case 'Q': o.quality_std = atof(optarg); break;
         case 'o': o.reads_output_type = atoi(optarg); break;
         case 'a': o.amplicons = 1; break;
@@ -460,16 +494,27 @@ int main(int argc, char **argv)
         case 'v': muts_fn = optarg; muts_type = 2; muts_flags |= 4; break;
         case 'x': regions_fn = optarg; break;
         case 'B': o.use_base_error = 1; break;
-        default: fprintf(stderr, "Unrecognized option: -%c\n", c); return usage(&o);
+        default: fprintf(stderr, "Unrecognized option: -%c\n", c); return usage_now();
         }
     }
-    if (argc - optind < 2) return usage(&o);
-    if (muts_flags != 0 && muts_flags != 1 && muts_flags != 2 && muts_flags != 4) { fprintf(stderr, "Error: -m/-b/-v cannot be used together\n"); return usage(&o); }
-    if (o.read_prefix) fprintf(stderr, "Warning: remember to use the -P option with dwgsim_eval\n");
+    if (argc - optind < 2) return usage_now();
+    const int seed_given = o.seed;      // (the usage text shows what was given)
     if (o.seed == -1) o.seed = (int32_t)(time(0) & 0x7fffffff);
     if (o.seed < 0) o.seed &= 0x7fffffff;
     char msg[512];
-    if (dwgsim_hip_params_check(&o, msg, sizeof msg) != DWGSIM_HIP_OK) { fprintf(stderr, "%s", msg); return usage(&o); }
+    // the checks in the reference's order (dwgsim_opt.c:307-391): ranges up to -Q (dwgsim_hip_params_check follows it), the -P warning, -o, then -m / -b / -v together
+    {
+        auto refuse = [&](const char *m) { fprintf(stderr, "%s", m); o.seed = seed_given; return usage_now(); };
+        dwgsim_hip_params_t chk = o;
+        chk.reads_output_type = 0;
+        if (chk.output_type < 0 || chk.output_type > 2) chk.output_type = 0;      // (the reference does not check -M: anything but 1 and 2 writes everything, dwgsim.c:1143-1159)
+        if (const int rc = dwgsim_hip_params_check(&chk, msg, sizeof msg); rc != DWGSIM_HIP_OK && rc != DWGSIM_HIP_ERR_UNSUP) return refuse(msg);
+        if (o.read_prefix) fprintf(stderr, "Warning: remember to use the -P option with dwgsim_eval\n");
+        if (o.reads_output_type < 0 || o.reads_output_type > 2) return refuse("Error: command line option -o was out of range\n");
+        if (muts_flags != 0 && muts_flags != 1 && muts_flags != 2 && muts_flags != 4) return refuse("Error: -m/-b/-v cannot be used together\n");
+        if (o.output_type < 0 || o.output_type > 2) o.output_type = 0;
+        if (dwgsim_hip_params_check(&o, msg, sizeof msg) != DWGSIM_HIP_OK) return refuse(msg);
+    }
     if (o.output_type == 1) fprintf(stderr, "[dwgsim_core] note: the reference dereferences a NULL VCF handle with -M 1; dwgsim-hip simply writes no mutation files\n");
 
     const bool want_mut = o.output_type != 1, want_reads = o.output_type != 2;
@@ -515,9 +560,11 @@ int main(int argc, char **argv)
     Pool rpool(read_threads);
     MappedFasta mf;
     if (const char *e = getenv("DWGSIM_HIP_READ_CHUNK")) { const long long v = atoll(e); if (v >= 1) mf.chunk_bytes = (size_t)v; }
+    // (the reference opens the FASTA in main, dwgsim.c:1139, and the regions file at the top of dwgsim_core, :460-463, before it reads the contig table)
+    if (strcmp(fn_fa, "-") != 0 && access(fn_fa, R_OK) != 0) { fprintf(stderr, "[main] fail to open file '%s'. Abort!\n", fn_fa); return give_up(1); }
+    if (!regions_fn.empty() && regions_fn != "-" && access(regions_fn.c_str(), R_OK) != 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", regions_fn.c_str()); return give_up(1); }
     const bool mapped = strcmp(fn_fa, "-") != 0 && mf.open_file(fn_fa);
     if (mapped) mf.index(rpool);
-    else if (strcmp(fn_fa, "-") != 0 && access(fn_fa, R_OK) != 0) { fprintf(stderr, "[dwgsim_core] fail to open file '%s'. Abort!\n", fn_fa); return give_up(1); }
     if (FILE *fai = fopen((std::string(fn_fa) + ".fai").c_str(), "r")) {
         char nmbuf[4096]; int ll, d0, d1, d2;
         while (0 < fscanf(fai, "%4095s\t%d\t%d\t%d\t%d", nmbuf, &ll, &d0, &d1, &d2)) { tab_names.push_back(nmbuf); tab_lens.push_back(ll); }
@@ -601,7 +648,7 @@ int main(int argc, char **argv)
     const double t_fed = now_s();
     if (dwgsim_hip_job_finish(job) < 0) job_error();
     const double t_out_done = now_s();
-    fprintf(stderr, "\n[dwgsim_core] Complete!\n");
+    if (rc == 0) fprintf(stderr, "\n[dwgsim_core] Complete!\n");
     if (timing) fprintf(stderr, "[dwgsim-hip] contig table%s %.2f s | contexts, files, inputs %.2f s | %scontigs handed to the GPUs %.2f s | remaining simulate + copy + write %.2f s | "
                                 "total %.2f s; text %.2f GB -> gz %.2f GB, %s\n",
                         streaming ? " (.fai)" : " (FASTA read into memory)", t_fasta - t_start, t_ctx - t_fasta, streaming ? "FASTA read, " : "", t_fed - t_ctx, t_out_done - t_fed, t_out_done - t_start,

@@ -414,3 +414,30 @@ def test_hopeless_target_regions_end_with_an_error(lib, golden_dir, tmp_path):
 def test_mut_debug_aborts_like_the_reference(lib, oracle_bin, golden_dir):
     from parity_common import check_mut_debug_aborts
     check_mut_debug_aborts(lib, oracle_bin, golden_dir)
+
+
+from replay_common import REPLAY_CASES, have_reference
+
+
+@pytest.mark.skipif(not have_reference(), reason="oracle/_ref/dwgsim (the unmodified reference; it travels to the GPU box as a prebuilt binary) is not here")
+@pytest.mark.parametrize("fasta,flags", REPLAY_CASES, ids=[f"{f}:{fl}" for f, fl in REPLAY_CASES])
+def test_hip_path_equals_the_replayed_reference(lib, oracle_bin, golden_dir, tmp_path, fasta, flags):
+    """The HIP path against bytes the UNMODIFIED REFERENCE wrote: oracle/_ref/dwgsim with its drand48() replaying the Philox stream (tests/replay_common.py;
+    single-end configurations without quality normals: Illumina, SOLiD, the whole Ion Torrent flow model, heavy -r / -R, -x, -m / -b / -v) -- no oracle
+    output is compared here, the oracle only dumps the stream.  The last case also goes through the dwgsim-hip executable."""
+    import gzip, subprocess
+    from replay_common import run_replay, SUFFIXES, IN_DIR
+    fa = os.path.join(golden_dir, fasta)
+    orc, rrc, _, ref, served, avail = run_replay(oracle_bin, fa, flags, str(tmp_path))
+    assert orc == 0 and rrc == 0 and served == avail > 0
+    fl = flags.replace("{IN}", IN_DIR)
+    res = api.run_job(api.parse_flags(fl, lib), api.read_fasta(fa), lib=lib)
+    assert res.streams[0] == ref["bwa.read1.fastq"] and res.streams[1] == ref["bwa.read2.fastq"] and res.streams[2] == ref["bfast.fastq"]
+    assert res.mutations_txt == ref["mutations.txt"] and res.mutations_vcf == ref["mutations.vcf"]
+    if (fasta, flags) == REPLAY_CASES[-1]:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.run([os.path.join(root, "dwgsim_amd", "dwgsim-hip")] + fl.split() + [fa, str(tmp_path / "cli")], check=True, stderr=subprocess.DEVNULL)
+        for suf in SUFFIXES:
+            p = str(tmp_path / ("cli." + suf + (".gz" if suf.endswith("fastq") else "")))
+            got = (gzip.open(p, "rb").read() if p.endswith(".gz") else open(p, "rb").read()) if os.path.exists(p) else b""
+            assert got == ref[suf], suf
