@@ -316,27 +316,6 @@ DW_DEV void read_geom(const SimArgs &a, const SegCtx &sc, const PairDraw &pd, in
 // a lane at buf[w * stride]) -- where rounds 1-4 kept a 4-bit buffer, a 2-bit buffer and two bitmaps of first draws per lane in a global scratch of
 // 150 KB per block (5 x the algorithmic HBM traffic, profiles/r04_ion_*).
 // Draws: dw_common.hpp D_FLOW0.  The flow mask is per read (the reference's persistent mask is fully rewritten by every read's pass 1).
-// First draws of the flow model's events as bits: bit k of the result = (first uniform of event 8 * blk + k) < e, e as thr = e * 2^32
-// (dw_common.hpp D_FLOW0: sixteen-bit halves, the low halves drawn only when a high half ties with thr's).
-DW_DEV uint32_t flow_hits8(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t blk, uint64_t thr)
-{
-    const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
-    const U4 b = rng_block(key, dom, ii, att, 0, blk);
-    const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
-    uint32_t lt = 0, closest = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; const uint32_t d = hw[k] ^ t_hi; closest = d < closest ? d : closest; }
-    if (closest == 0 && t_lo) {      // a high half ties with the threshold's (probability 2^-13 per block): the low halves decide
-        uint32_t eq = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) eq |= (hw[k] == t_hi ? 1u : 0u) << k;
-        const U4 r = rng_block(key, dom + D_FLOW_REF, ii, att, 0, blk);
-        const uint32_t lw[8] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16, r.z & 0xFFFFu, r.z >> 16, r.w & 0xFFFFu, r.w >> 16};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lt |= (((eq >> k) & 1u) && lw[k] < t_lo ? 1u : 0u) << k;
-    }
-    return lt;
-}
 struct FlowRng {             // scalar members + value selects only: keeps the generator state in registers
     // The private stream of one event (its draws AFTER the first): draw s = word s & 3 of the block (retry s >> 2, block evt) of dom + D_FLOW_EV.
     uint32_t seed, contig, dom, att, evt, s, w0, w1, w2, w3; uint64_t ii;
@@ -391,20 +370,29 @@ struct BitAppender {
 // drawn ahead of the lane in rounds in which every lane resolves its own next event -- so the event code itself draws nothing, and a lane does
 // not have to wait for others to gather before it can handle one.
 struct FlowWin {
-    uint64_t bits; uint32_t hb, hf;          // events [hb, hb + hf) are drawn; hb is a multiple of 8, hf <= 64
-    uint32_t oc_pos, oc, oc_dot;             // oc: n_err (1 or 2) | 0x100 insert | 0x200 the event draws on (n_err >= 3): taken from FlowRng where it happens
-    DW_DEV void init() { bits = 0; hb = 0; hf = 0; oc_pos = 0xFFFFFFFFu; oc = 0; oc_dot = 0; }
+    uint64_t bits, ties; uint32_t hb, hf;    // events [hb, hb + hf) are drawn; hb is a multiple of 8, hf <= 64.  ties: events whose HIGH half equals the threshold's --
+                                             // counted as scoring in `bits` until the low half has been looked at (resolve): 2^-16 of the draws
+    uint32_t oc_pos, oc, oc_dot;             // oc: n_err (1 or 2) | 0x100 insert | 0x200 the event draws on (n_err >= 3): taken from FlowRng where it happens | 0x400 a tie that does not score after all
+    DW_DEV void init() { bits = ties = 0; hb = 0; hf = 0; oc_pos = 0xFFFFFFFFu; oc = 0; oc_dot = 0; }
     DW_DEV uint32_t frontier() const { return hb + hf; }
     DW_DEV bool room() const { return hf <= 56u; }
     DW_DEV void advance(uint32_t p)          // the consumer stands at event p >= hb: whole blocks below it leave the window
     {
         const uint32_t k8 = (p - hb) & ~7u;
-        if (k8) { bits = k8 < 64u ? bits >> k8 : 0ull; hf = hf > k8 ? hf - k8 : 0u; hb += k8; }
+        if (k8) { bits = k8 < 64u ? bits >> k8 : 0ull; ties = k8 < 64u ? ties >> k8 : 0ull; hf = hf > k8 ? hf - k8 : 0u; hb += k8; }
     }
-    DW_DEV void draw(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint64_t thr)
+    // the next block of eight first draws (dw_common.hpp D_FLOW0: the HIGH halves; a high half equal to the threshold's leaves the event undecided: `ties`),
+    // taken into the window if `go`.  Straight-line code: the callers place it beside the flow pointer's chain of table look-ups, whose latency it fills
+    DW_DEV void draw(bool go, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint64_t thr)
     {
-        const uint32_t b8 = flow_hits8(key, dom, ii, att, (hb + hf) >> 3, thr);
-        bits |= (uint64_t)b8 << hf; hf += 8u;
+        const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
+        const U4 b = rng_block(key, dom, ii, att, 0, (hb + hf) >> 3);
+        const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
+        uint32_t lt = 0, eq = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; eq |= (hw[k] == t_hi ? 1u : 0u) << k; }
+        if (!t_lo) eq = 0;
+        if (go) { bits |= (uint64_t)(lt | eq) << hf; ties |= (uint64_t)eq << hf; hf += 8u; }
     }
     // the first scoring event at or after p (real), or else how far the lane may go before it needs more draws: the frontier (at least p)
     DW_DEV uint32_t stop(uint32_t p, bool &real) const
@@ -417,9 +405,15 @@ struct FlowWin {
         return f > p ? f : p;
     }
     DW_DEV void clear(uint32_t pos) { bits &= ~(1ull << (pos - hb)); }       // hb <= pos < hb + 64
-    DW_DEV void resolve(RngKey key, uint32_t dom_ev, uint64_t ii, uint32_t att, uint32_t pos, uint64_t thr)
+    // dom: the pass's domain of first draws (its low halves: + D_FLOW_REF, the events' further draws: + D_FLOW_EV)
+    DW_DEV void resolve(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t pos, uint64_t thr)
     {
-        const U4 b = rng_block(key, dom_ev, ii, att, 0, pos);
+        if ((ties >> (pos - hb)) & 1ull) {      // the high half tied: the low half decides whether the event scores at all
+            const U4 r = rng_block(key, dom + D_FLOW_REF, ii, att, 0, pos >> 3);
+            const uint32_t wd = (pos & 4u) ? ((pos & 2u) ? r.w : r.z) : ((pos & 2u) ? r.y : r.x), lw = (wd >> ((pos & 1u) * 16u)) & 0xFFFFu;
+            if (!(lw < ((uint32_t)thr & 0xFFFFu))) { oc_pos = pos; oc = 0x400u; oc_dot = 0; return; }
+        }
+        const U4 b = rng_block(key, dom + D_FLOW_EV, ii, att, 0, pos);
         const bool m0 = (uint64_t)b.x < thr, m1 = (uint64_t)b.y < thr;                // while (drand48() < e) n_err++ (dwgsim.c:296, :373): draws 0, 1, ...
         const uint32_t insw = m0 ? b.z : b.y;                                         // the draw after the first failing one: insert or delete (dwgsim.c:299)
         oc_pos = pos; oc_dot = m0 ? b.w : b.z;                                        // ... and the one after that: the dot-fill flow (dwgsim.c:352)
@@ -491,45 +485,49 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
     {
         bool done = failed, parked = false;
         for (uint32_t it = 0;; ++it) {
-            // draws: every lane keeps its window ahead of itself (a step looks at up to sixteen positions)
+            // One block of straight-line code: two rounds of draws for the window (a step consumes up to sixteen positions) beside the step itself, so that
+            // the arithmetic of the one fills the look-up latency of the other.  A lane that does not step (done, parked) goes through it with n = 0.
             if (!done) W.advance((uint32_t)o1.n);
-            while (__ballot(!done && W.room() && W.frontier() < (uint32_t)o1.n + 24u)) { if (!done && W.room()) W.draw(key, rg.dom, rg.ii, rg.att, thr); }
-            if (!done && !parked) {
-                if (t >= len) done = true;
-                else {
-                    const uint32_t on = (uint32_t)o1.n, sh = on - W.hb;                  // (sh < 8 after advance)
-                    const uint32_t v = B.get16(in0 + t);
-                    int n = len - t < 16 ? len - t : 16;
-                    const int reach = (int)(W.frontier() - on);                          // positions whose first draws are there
-                    if (reach < n) n = reach;
-                    // homopolymer starts among the sixteen: base i differs from the one before it (the first one from prev_c)
-                    const uint32_t x = v ^ ((v << 2) | (prev_c & 3u));
-                    const uint32_t starts = even_bits16(x | (x >> 1)) | (prev_c > 3u ? 1u : 0u);
-                    const uint32_t below = n < 16 ? (1u << n) - 1u : 0xFFFFu;
-                    const uint32_t ev = starts & (uint32_t)(W.bits >> sh) & below;       // ... whose first draw scores: the first of them stops the step
-                    if (ev) n = __ffs((int)ev) - 1;
-                    const uint32_t taken = n < 16 ? (1u << n) - 1u : 0xFFFFu;
-                    // the flow pointer over the n bases: pairs, then the odd one
+            const bool act = !done && !parked;
+            if (act && t >= len) done = true;
+            const bool go = act && t < len;
+            const uint32_t on = (uint32_t)o1.n, sh = on - W.hb;                          // (sh < 8 after advance)
+            const uint32_t v = B.get16(in0 + t);
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const uint32_t e = T.pair[(flow_i << 4) | ((v >> (4 * p)) & 15u)];
-                        if (2 * p + 2 <= n) flow_i = e & 63u;
-                    }
-                    if (n & 1) flow_i = T.next1[(flow_i << 2) | ((v >> (2 * (n - 1))) & 3u)];
-                    if (starts & taken) marked = false;
-                    o1.push_many(n < 16 ? v & ((1u << (2 * n)) - 1u) : v, n);
-                    if (n) prev_c = (v >> (2 * (n - 1))) & 3u;
-                    t += n;
-                    if (ev) parked = true;                                               // standing on a homopolymer start whose first draw scored: the event happens
+            for (int r = 0; r < 2; ++r) W.draw(!done && W.room() && W.frontier() < on + 40u, key, rg.dom, rg.ii, rg.att, thr);
+            {
+                int n = len - t < 16 ? len - t : 16;
+                const int reach = (int)(W.frontier() - on);                              // positions whose first draws are there
+                if (reach < n) n = reach;
+                if (!go || n < 0) n = 0;
+                // homopolymer starts among the sixteen: base i differs from the one before it (the first one from prev_c)
+                const uint32_t x = v ^ ((v << 2) | (prev_c & 3u));
+                const uint32_t starts = even_bits16(x | (x >> 1)) | (prev_c > 3u ? 1u : 0u);
+                const uint32_t below = n < 16 ? (1u << n) - 1u : 0xFFFFu;
+                const uint32_t ev = go ? starts & (uint32_t)(W.bits >> sh) & below : 0u;   // ... whose first draw scores: the first of them stops the step
+                if (ev) n = __ffs((int)ev) - 1;
+                const uint32_t taken = n < 16 ? (1u << n) - 1u : 0xFFFFu;
+                // the flow pointer over the n bases: pairs, then the odd one
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const uint32_t e = T.pair[(flow_i << 4) | ((v >> (4 * p)) & 15u)];
+                    if (2 * p + 2 <= n) flow_i = e & 63u;
                 }
+                if (n & 1) flow_i = T.next1[(flow_i << 2) | ((v >> (2 * (n - 1))) & 3u)];
+                if (starts & taken) marked = false;
+                o1.push_many(n < 16 ? v & ((1u << (2 * n)) - 1u) : v, n);
+                if (n) prev_c = (v >> (2 * (n - 1))) & 3u;
+                t += n;
+                if (ev) parked = true;                                                   // standing on a homopolymer start whose first draw scored: the event happens
             }
             // the further draws of the events ahead: a round for every lane at once, when a lane stands on an unresolved event, and every fourth iteration
             {
                 bool real = false; uint32_t st = 0;
                 if (!done) st = W.stop((uint32_t)o1.n, real);
                 const bool unresolved = !done && real && W.oc_pos != st;
-                if (__ballot(unresolved && (parked || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, rg.dom + D_FLOW_EV, rg.ii, rg.att, st, thr); }
+                if (__ballot(unresolved && (parked || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, rg.dom, rg.ii, rg.att, st, thr); }
             }
+            if (parked && W.oc_pos == (uint32_t)o1.n && (W.oc & 0x400u)) { W.clear((uint32_t)o1.n); parked = false; }      // a tie that did not score: no event here
             if (parked && W.oc_pos == (uint32_t)o1.n) {
                 const uint32_t c = B.get1(in0 + t);
                 flow_i = T.next1[(flow_i << 2) | c]; marked = false;
@@ -605,31 +603,32 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
         bool done = failed, parked = false; uint32_t g = 0, x = 0;
         for (uint32_t it = 0;; ++it) {
             if (!done) W.advance(g);
-            while (__ballot(!done && W.room() && W.frontier() < g + 40u)) { if (!done && W.room()) W.draw(key, dom2, rg.ii, rg.att, thr); }
-            if (!done && !parked) {
-                if (sp > 0) { x = stk_get(sp - 1) >> 14; parked = true; }       // runs pending: base by base, below
-                else if (t2 >= n1) done = true;
-                else {
-                    const uint32_t v = B.get16(in2 + t2);
-                    const int n = n1 - t2 < 16 ? n1 - t2 : 16;
-                    bool real; const uint32_t st = W.stop(g, real);
-                    uint32_t rem = st - g;                                       // flows that may be passed before the lane has to stop
-                    int m = 0; bool ok = true;
+            const bool act = !done && !parked;
+            if (act && sp > 0) { x = stk_get(sp - 1) >> 14; parked = true; }      // runs pending: base by base, below
+            if (act && sp == 0 && t2 >= n1) done = true;
+            const bool go = act && sp == 0 && t2 < n1;
+            const uint32_t v = B.get16(in2 + t2);
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const uint32_t e = T.pair[(flow_i << 4) | ((v >> (4 * p)) & 15u)], kt = e >> 8;
-                        ok = ok && 2 * p + 2 <= n && kt <= rem;
-                        if (ok) { rem -= kt; flow_i = e & 63u; m += 2; }
-                    }
-                    if (m < n) {                                                 // the pair that did not fit: its first base alone may
-                        const uint32_t i1 = (flow_i << 2) | ((v >> (2 * m)) & 3u), k = T.dist[i1];
-                        if (k <= rem) { rem -= k; flow_i = T.next1[i1]; ++m; }
-                    }
-                    g = st - rem;
-                    o2.push_many(m < 16 ? v & ((1u << (2 * m)) - 1u) : v, m);
-                    t2 += m;
-                    if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }
+            for (int r = 0; r < 3; ++r) W.draw(!done && W.room() && W.frontier() < g + 56u, key, dom2, rg.ii, rg.att, thr);
+            {
+                const int n = !go ? 0 : n1 - t2 < 16 ? n1 - t2 : 16;
+                bool real; const uint32_t st = W.stop(g, real);
+                uint32_t rem = st - g;                                       // flows that may be passed before the lane has to stop
+                int m = 0; bool ok = true;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const uint32_t e = T.pair[(flow_i << 4) | ((v >> (4 * p)) & 15u)], kt = e >> 8;
+                    ok = ok && 2 * p + 2 <= n && kt <= rem;
+                    if (ok) { rem -= kt; flow_i = e & 63u; m += 2; }
                 }
+                if (m < n) {                                                 // the pair that did not fit: its first base alone may
+                    const uint32_t i1 = (flow_i << 2) | ((v >> (2 * m)) & 3u), k = T.dist[i1];
+                    if (k <= rem) { rem -= k; flow_i = T.next1[i1]; ++m; }
+                }
+                g = st - rem;
+                o2.push_many(m < 16 ? v & ((1u << (2 * m)) - 1u) : v, m);
+                t2 += m;
+                if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }
             }
             if (parked) {      // flow by flow up to x's own: quiet flows are skipped together, a scoring one inserts (dwgsim.c:373-383)
                 for (;;) {
@@ -646,6 +645,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                         continue;
                     }
                     if (!real || W.oc_pos != g) break;              // the window's end, or an event whose further draws are not there yet: next round
+                    if (W.oc & 0x400u) { W.clear(g); continue; }    // a tie that did not score: a quiet flow after all
                     int n_err;
                     if (W.oc & 0x200u) { rg.open(g); n_err = rg.more_errors(thr); } else n_err = (int)(W.oc & 0xffu);
                     if ((int)flow_i != marked_flow) {
@@ -660,7 +660,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                 bool real = false; uint32_t st = 0;
                 if (!done) st = W.stop(g, real);
                 const bool unresolved = !done && real && W.oc_pos != st;
-                if (__ballot(unresolved && ((parked && st == g) || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, dom2 + D_FLOW_EV, rg.ii, rg.att, st, thr); }
+                if (__ballot(unresolved && ((parked && st == g) || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, dom2, rg.ii, rg.att, st, thr); }
             }
             if (__ballot(!done) == 0) break;
         }
