@@ -1215,11 +1215,11 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
         a.lds_words = (a.cap + 15) / 16; a.cap = 16 * a.lds_words;
         a.flow_stack_words = std::min(FLOW_STACK_WORDS * c->flow_cap_mult, FLOW_STACK_WORDS_MAX);
         const size_t per_lane = (size_t)(a.lds_words + a.flow_stack_words);
-        const size_t need256 = sim_lds_bytes(per_lane, SIM_THREADS, (size_t)c->qb_words, true), need64 = sim_lds_bytes(per_lane, SIM_THREADS_LONG, (size_t)c->qb_words, true);
+        const size_t need256 = sim_lds_bytes(per_lane, SIM_THREADS, (size_t)c->qb_words, true), need64 = sim_lds_bytes(per_lane, ION_THREADS_SMALL, (size_t)c->qb_words, true);
         int mode = c->ion_lds;
         if (mode < 0) mode = (need256 <= SIM_LDS_BUDGET && sim_blocks_per_cu(need256, 8) >= 2) ? 1 : (need64 <= SIM_LDS_BUDGET && sim_blocks_per_cu(need64, 32) >= 4) ? 2 : 0;
         if ((mode == 1 && need256 > SIM_LDS_BUDGET) || (mode == 2 && need64 > SIM_LDS_BUDGET)) mode = 0;
-        a.ion_lds = mode != 0; a.sim_threads = mode == 2 ? SIM_THREADS_LONG : SIM_THREADS;
+        a.ion_lds = mode != 0; a.sim_threads = mode == 2 ? ION_THREADS_SMALL : SIM_THREADS;
     }
     // Short Illumina reads run as two kernels with the offsets computed in between (dw_simulate.hip SPLIT): no look-backs, and the second half --
     // no staged bases in LDS -- writes the text in 64-byte bursts.  What does not scale with the read length (placement, the look-backs, the name)

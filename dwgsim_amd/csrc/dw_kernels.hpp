@@ -14,6 +14,10 @@ constexpr int PLACE_LISTS = 64;          // k_place hands the pairs it cannot de
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
 constexpr int FLOW_STACK_WORDS = 4;           // Ion Torrent pass 2: LDS words per lane for the (base, count) runs that can be pending in front of the examined base (two per word), times the
 constexpr int FLOW_STACK_WORDS_MAX = 32;      // ... capacity multiplier of the job (a read that outgrows the stack is run again like one that outgrows its buffer), up to this many
+#ifndef DW_ION_THREADS_SMALL
+#define DW_ION_THREADS_SMALL 128
+#endif
+constexpr int ION_THREADS_SMALL = DW_ION_THREADS_SMALL;      // Ion Torrent with its read buffers in LDS: the smaller block form (fill_sim_args "ion_lds" = 2)
 constexpr int SIM_THREADS_LONG = 64;          // ... one-wave blocks for reads of ~650 bases and more: their bases are staged in scratch slots, not LDS
 constexpr int SIM_FIFO_BYTES = 40;            // per lane: the text FIFO of the record writer (one 32-byte burst + the overshoot of an 8-byte put)
 constexpr int SIM_FIFO_BYTES_WIDE = 72;       // ... with 64-byte bursts (second half of the two-kernel form: no staged bases compete for LDS)

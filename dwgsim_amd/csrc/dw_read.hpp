@@ -366,9 +366,8 @@ struct BitAppender {
 // lives in registers, slides with the lane (a Philox block = eight events is drawn at its top whenever there is room and some lane of the wave is
 // running short: all lanes draw in step, each its own next block) and is at most 64 events long; a lane that reaches its frontier waits for the
 // next round of draws.  Rounds 3-4 stored whole bitmaps per lane and searched them through memory.
-// oc*: what the FIRST scoring event of the window goes on to draw (dw_common.hpp D_FLOW_EV: further errors, insert-or-delete, the dot-fill flow),
-// drawn ahead of the lane in rounds in which every lane resolves its own next event -- so the event code itself draws nothing, and a lane does
-// not have to wait for others to gather before it can handle one.
+// oc*: what a scoring event goes on to draw (dw_common.hpp D_FLOW_EV: further errors, insert-or-delete, the dot-fill flow) -- one Philox block
+// (resolve), drawn by the lanes that stand on an event, together.
 struct FlowWin {
     uint64_t bits, ties; uint32_t hb, hf;    // events [hb, hb + hf) are drawn; hb is a multiple of 8, hf <= 64.  ties: events whose HIGH half equals the threshold's --
                                              // counted as scoring in `bits` until the low half has been looked at (resolve): 2^-16 of the draws
@@ -484,7 +483,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
     W.init();
     {
         bool done = failed, parked = false;
-        for (uint32_t it = 0;; ++it) {
+        for (;;) {
             // One block of straight-line code: two rounds of draws for the window (a step consumes up to sixteen positions) beside the step itself, so that
             // the arithmetic of the one fills the look-up latency of the other.  A lane that does not step (done, parked) goes through it with n = 0.
             if (!done) W.advance((uint32_t)o1.n);
@@ -520,15 +519,10 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                 t += n;
                 if (ev) parked = true;                                                   // standing on a homopolymer start whose first draw scored: the event happens
             }
-            // the further draws of the events ahead: a round for every lane at once, when a lane stands on an unresolved event, and every fourth iteration
-            {
-                bool real = false; uint32_t st = 0;
-                if (!done) st = W.stop((uint32_t)o1.n, real);
-                const bool unresolved = !done && real && W.oc_pos != st;
-                if (__ballot(unresolved && (parked || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, rg.dom, rg.ii, rg.att, st, thr); }
-            }
-            if (parked && W.oc_pos == (uint32_t)o1.n && (W.oc & 0x400u)) { W.clear((uint32_t)o1.n); parked = false; }      // a tie that did not score: no event here
-            if (parked && W.oc_pos == (uint32_t)o1.n) {
+            // a lane standing on an event draws what the event draws beyond its first uniform (one Philox block), then acts on it
+            if (parked) W.resolve(key, rg.dom, rg.ii, rg.att, (uint32_t)o1.n, thr);
+            if (parked && (W.oc & 0x400u)) { W.clear((uint32_t)o1.n); parked = false; }      // a tie that did not score: no event here
+            if (parked) {
                 const uint32_t c = B.get1(in0 + t);
                 flow_i = T.next1[(flow_i << 2) | c]; marked = false;
                 int n_err; bool ins = false;
@@ -601,7 +595,7 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
     W.init();
     {
         bool done = failed, parked = false; uint32_t g = 0, x = 0;
-        for (uint32_t it = 0;; ++it) {
+        for (;;) {
             if (!done) W.advance(g);
             const bool act = !done && !parked;
             if (act && sp > 0) { x = stk_get(sp - 1) >> 14; parked = true; }      // runs pending: base by base, below
@@ -609,7 +603,8 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
             const bool go = act && sp == 0 && t2 < n1;
             const uint32_t v = B.get16(in2 + t2);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) W.draw(!done && W.room() && W.frontier() < g + 56u, key, dom2, rg.ii, rg.att, thr);
+            for (int r = 0; r < 2; ++r) W.draw(!done && W.room() && W.frontier() < g + 56u, key, dom2, rg.ii, rg.att, thr);
+            if (__ballot(!done && W.room() && W.frontier() < g + 32u)) W.draw(!done && W.room() && W.frontier() < g + 56u, key, dom2, rg.ii, rg.att, thr);
             {
                 const int n = !go ? 0 : n1 - t2 < 16 ? n1 - t2 : 16;
                 bool real; const uint32_t st = W.stop(g, real);
@@ -644,7 +639,8 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                         x = stk_get(sp - 1) >> 14;                  // the next base to examine is the first of the top run
                         continue;
                     }
-                    if (!real || W.oc_pos != g) break;              // the window's end, or an event whose further draws are not there yet: next round
+                    if (!real) break;                               // the window's end: more draws first
+                    W.resolve(key, dom2, rg.ii, rg.att, g, thr);    // what the event draws beyond its first uniform
                     if (W.oc & 0x400u) { W.clear(g); continue; }    // a tie that did not score: a quiet flow after all
                     int n_err;
                     if (W.oc & 0x200u) { rg.open(g); n_err = rg.more_errors(thr); } else n_err = (int)(W.oc & 0xffu);
@@ -655,12 +651,6 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                     flow_i = flow_i + 1u == (uint32_t)F ? 0u : flow_i + 1u;
                     ++g;
                 }
-            }
-            {
-                bool real = false; uint32_t st = 0;
-                if (!done) st = W.stop(g, real);
-                const bool unresolved = !done && real && W.oc_pos != st;
-                if (__ballot(unresolved && ((parked && st == g) || (it & 3u) == 3u))) { if (unresolved) W.resolve(key, dom2, rg.ii, rg.att, st, thr); }
             }
             if (__ballot(!done) == 0) break;
         }

@@ -1301,8 +1301,16 @@ DW_SIM_FAMILY(2, 3)
 DW_SIM_FAMILY(1, 3)
 #endif
 #if DW_HAS(13)
-DW_SIM_FAMILY_LONG(2, 3)
-DW_SIM_FAMILY_LONG(1, 3)
+#define DW_SIM_FAMILY_ION_SMALL(LPP)                                                                                               \
+    void launch_sim_long_##LPP##_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out)                              \
+    {                                                                                                                               \
+        const uint32_t nthr = ION_THREADS_SMALL;                                                                                    \
+        if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, 3, ION_THREADS_SMALL>), dim3(nb), dim3(nthr), lds, st, a);             \
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, 3, ION_THREADS_SMALL>), dim3(nb), dim3(nthr), lds, st, a);        \
+        else hipLaunchKernelGGL((k_simulate<LPP, 3, 3, ION_THREADS_SMALL>), dim3(nb), dim3(nthr), lds, st, a);                      \
+    }
+DW_SIM_FAMILY_ION_SMALL(2)
+DW_SIM_FAMILY_ION_SMALL(1)
 #endif
 #if DW_HAS(5)
 DW_SIM_FAMILY(2, 1)
