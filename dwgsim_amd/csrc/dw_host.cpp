@@ -1227,6 +1227,9 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     // the same, 2 x 150 2-3 % slower (the state crosses HBM, 2.5 GB per chr20-sized launch): profiles/r04_split.txt.  "split" = 0 / 1 forces either.
     const bool split_wins = lmax0 <= 100;
     a.split = (p.data_type == 0 && a.sim_threads == SIM_THREADS && (c->split < 0 ? split_wins : c->split != 0)) ? 1 : 0;
+    // Ion Torrent with its buffers in LDS: as two kernels as well (the flow model | qualities + text).  The first half holds no text FIFOs, so a fourth
+    // block fits a CU, and no block waits for the record sizes of the blocks in front of it ("split" = 0 forces the single kernel)
+    if (p.data_type == 2 && a.ion_lds && a.sim_threads == SIM_THREADS && a.cap < 32768 && c->split != 0) a.split = 1;
     if (a.split && c->writer < 0) a.fifo = 1;      // (its LDS holds no bases: the FIFO writer always fits)
     return 0;
 }
@@ -1346,6 +1349,7 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
     // first round's look-backs resolve one after the other (every block waits for all in front of it, all of them just started), and a launch this
     // short is mostly first round: 2^17 / 2^18 / 2^19 pairs of 2 x 150 bp -5 / -11.5 / -2 %, 2^20 pairs +1 % (profiles/r04_split.txt)
     if (!a.split && c->split < 0 && p.data_type == 0 && a.sim_threads == SIM_THREADS && n_pairs && (uint64_t)nblk <= 16ull * (uint64_t)c->n_cu) { a.split = 1; if (c->writer < 0) a.fifo = 1; }
+    if (a.split && p.data_type == 2) a.fifo = 1;
     if (c->rand_fixed_len > fixed_max) fixed_max = c->rand_fixed_len;
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     size_t cap[3] = {0, 0, 0};

@@ -16,7 +16,8 @@
 //   DW_PART 1..6: k_simulate<LPP, *, DT> for (LPP, DT) = (2,0) (1,0) (2,2) (1,2) (2,1) (1,1); part 4 also holds k_calibrate
 //   DW_PART 7, 8: the one-wave-per-block variants for long Illumina / SOLiD reads
 //   DW_PART 9, 10: the two-kernel form (SPLIT) of the paired / single-end Illumina variants
-//   DW_PART 11, 12, 13: the Ion Torrent variants whose read buffers live in LDS (256-lane blocks paired / single-end, one-wave blocks)
+//   DW_PART 11, 12, 13: the Ion Torrent variants whose read buffers live in LDS (256-lane blocks paired / single-end, the smaller blocks)
+//   DW_PART 14, 15: ... their two-kernel form, paired / single-end
 //   DW_PART -1 (default): everything in one translation unit
 #include <algorithm>
 #include "dw_read.hpp"
@@ -35,6 +36,9 @@
 #endif
 #ifndef DW_SIMB_WAVES
 #define DW_SIMB_WAVES 6      // ... requested for the second half of the two-kernel form (text assembly)
+#endif
+#ifndef DW_IONA_WAVES
+#define DW_IONA_WAVES 4      // ... for the first half of its two-kernel form (no text FIFOs in LDS: four blocks per CU)
 #endif
 #ifndef DW_IONL_WAVES
 #define DW_IONL_WAVES 3      // ... for the Ion Torrent variant whose read buffers live in LDS: LDS, not registers, bounds its residency
@@ -420,9 +424,9 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
 // block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
 // block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
 template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
-    static_assert(SPLIT == 0 || (DT == 0 && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants with 256-lane blocks");
+    static_assert(SPLIT == 0 || ((DT == 0 || DT == 3) && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants and for Ion Torrent with its buffers in LDS, 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
     __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
     __shared__ uint32_t s_ticket, s_slot;
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_T
     const SegCtx sc = seg_ctx(a, sg);
     const uint8_t *name_fixed = a.names + sg->name_off;
     if (H != 1) for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
-    if (ION) { fill_flow_tables(s_ft, a.flow_len, tid, nthr); __syncthreads(); }
+    if (ION) { if (SPLIT != 0) __syncthreads(); fill_flow_tables(s_ft, a.flow_len, tid, nthr); __syncthreads(); }      // (the flow order is in LDS: the single kernel's barrier above, or this one)
     const int j = (LPP == 2) ? (tid & 1) : 0;
     const uint64_t pair_in = (uint64_t)(t - sg->first_block) * PPB + (uint64_t)(tid / LPP);      // inside the range
     const bool valid = pair_in < sg->n_pairs;
@@ -641,6 +645,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_T
         const uint4 hm = reinterpret_cast<const uint4 *>(a.split_hand)[(size_t)t * nthr + tid];
         rr.ext_coor = (int32_t)hm.x; n_err = (int32_t)(hm.y & 0xffffu); rr.n_sub = (int32_t)(hm.y >> 16); rr.n_indel = (int32_t)(hm.z & 0xffffu); rr.n_ins = (int32_t)(hm.z >> 16);
         att = hm.w & 0x3fffu; is_rand = (hm.w >> 14) & 1u; pd.strand0 = (int)((hm.w >> 15) & 1u); pd.strand1 = (int)((hm.w >> 16) & 1u);
+        if (ION) { s_out = (int)(hm.w >> 17); flow_reversed = !is_rand && (j ? pd.strand1 : pd.strand0) != 0; }
         __syncthreads();      // the tables of the prologue (names, base qualities)
         { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     }
@@ -682,7 +687,8 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_T
     // ---- record offsets: block scan + decoupled look-back over logical blocks ----
     // The BFAST offsets get their own scan + look-back when a BFAST record is not simply "its BWA record minus the 2-byte suffix" for
     // every lane: SOLiD (different lengths), Ion Torrent (a read the flow model gave up on emits nothing, and must not shift the others)
-    constexpr bool BF_SCAN = DT != 0;
+    // (the two-kernel form of Ion Torrent takes the arithmetic offsets: a batch with a read the model gave up on is run again as a whole, dw_host.cpp)
+    constexpr bool BF_SCAN = DT != 0 && SPLIT == 0;
     uint32_t e1, e2, eb = 0, T1, T2, Tb = 0;
     if (BF_SCAN) {
         const uint32_t Lbf = !emits ? 0u : DT == 1 ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : Lbwa - 2u;
@@ -700,10 +706,10 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_T
         const uint32_t rsum = wave_sum_u32((is_rand && j == 0) ? 1u : 0u), b1 = wave_sum_u32(j == 0 ? Lbwa : 0u), b2 = wave_sum_u32(j == 1 ? Lbwa : 0u);
         if (lane == 0) { sm_rand[0][wave] = rsum; sm_bytes[0][wave] = b1; sm_bytes[1][wave] = b2; }
         const uint4 hm = make_uint4((uint32_t)rr.ext_coor, (uint32_t)n_err | ((uint32_t)rr.n_sub << 16), (uint32_t)rr.n_indel | ((uint32_t)rr.n_ins << 16),
-                                    att | (is_rand ? 1u << 14 : 0u) | ((uint32_t)pd.strand0 << 15) | ((uint32_t)pd.strand1 << 16));
+                                    att | (is_rand ? 1u << 14 : 0u) | ((uint32_t)pd.strand0 << 15) | ((uint32_t)pd.strand1 << 16) | (ION ? (uint32_t)s_out << 17 : 0u));      // (Ion Torrent: the read's length after errors, < 2^15: the host checks the capacity)
         reinterpret_cast<uint4 *>(a.split_hand)[(size_t)t * nthr + tid] = hm;
         uint32_t *gs = a.split_state + (size_t)t * ((size_t)a.lds_words * nthr) + tid;
-        if (valid) for (int w = 0; w < nw; ++w) gs[(size_t)w * nthr] = lds[w * nthr];
+        if (valid) for (int w = 0, n_w = ION ? (s_out + 15) >> 4 : nw; w < n_w; ++w) gs[(size_t)w * nthr] = lds[w * nthr];
         __syncthreads();
         if (tid == 0) { uint32_t r = 0, t1 = 0, t2 = 0; for (int w = 0; w < nwaves; ++w) { r += sm_rand[0][w]; t1 += sm_bytes[0][w]; t2 += sm_bytes[1][w]; } reinterpret_cast<uint4 *>(a.split_agg)[t] = make_uint4(r, t1, t2, 0u); }
         return;
@@ -792,7 +798,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? DW_IONL_WAVES : NTHR != SIM_T
             if (rem >= 8) { o.put4(base_chars4(word)); o.put4(base_chars4(word >> 16)); }
             else { const uint32_t c0 = base_chars4(word), c1 = base_chars4(word >> 16); for (int b = 0; b < rem; ++b) o.put(((b < 4 ? c0 : c1) >> (8 * (b & 3))) & 0xff); }
         };
-        if (SPLIT == 2) {      // the bases come from HBM: eight words (64 bases) fetched together, then written
+        if (SPLIT == 2 && !ION) {      // the bases come from HBM: eight words (64 bases) fetched together, then written
             const int full16 = s_out >> 4;                       // whole groups of sixteen bases
             for (int g0 = 0; g0 < full16; g0 += 4) {
                 uint32_t r[8];
@@ -1150,6 +1156,8 @@ void launch_sim_long_2_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t l
 void launch_sim_long_1_3(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds, int out);
 void launch_sim_split_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
 void launch_sim_split_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
+void launch_sim_split_ion_2(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
+void launch_sim_split_ion_1(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out);
 void launch_split_scan(hipStream_t st, const SimArgs &a, int lpp)
 {
     hipLaunchKernelGGL(k_split_scan1, dim3(cdiv(a.n_blocks, 1024)), dim3(1024), 0, st, a);
@@ -1161,9 +1169,10 @@ void launch_simulate(hipStream_t st, const SimArgs &a)
     const uint32_t nthr = (uint32_t)a.sim_threads;
     const uint32_t nb = a.n_blocks;                                  // a.segs is laid out for nthr / (pe ? 2 : 1) pairs per block
     const int out = (a.p.has_bwa ? 1 : 0) | (a.p.has_bfast ? 2 : 0);
-    if (a.split) {      // Illumina, 256-lane blocks: first half | offsets | second half (k_simulate<.., SPLIT>)
-        const size_t lds_a = sim_lds_bytes((size_t)a.lds_words, nthr, 0, false), lds_b = sim_lds_bytes(0, nthr, (size_t)a.qb_words, a.fifo != 0, SIM_FIFO_BYTES_WIDE);      // (the second half stages no bases)
-        if (pe) launch_sim_split_2(st, a, nb, lds_a, lds_b, out); else launch_sim_split_1(st, a, nb, lds_a, lds_b, out);
+    if (a.split) {      // 256-lane blocks: first half | offsets | second half (k_simulate<.., SPLIT>)
+        const size_t lds_a = sim_lds_bytes((size_t)(a.lds_words + (ion ? a.flow_stack_words : 0)), nthr, 0, false), lds_b = sim_lds_bytes(0, nthr, (size_t)a.qb_words, a.fifo != 0, SIM_FIFO_BYTES_WIDE);      // (the second half stages no bases)
+        if (ion) { if (pe) launch_sim_split_ion_2(st, a, nb, lds_a, lds_b, out); else launch_sim_split_ion_1(st, a, nb, lds_a, lds_b, out); }
+        else if (pe) launch_sim_split_2(st, a, nb, lds_a, lds_b, out); else launch_sim_split_1(st, a, nb, lds_a, lds_b, out);
         return;
     }
     // staged bases (Ion Torrent: the read buffers when LDS holds them + the pass-2 run stack; otherwise they are, like the long reads of the one-wave blocks, in a.flow_scratch)
@@ -1224,6 +1233,23 @@ void launch_split_scan(hipStream_t st, const SimArgs &a, int lpp);
             else hipLaunchKernelGGL((k_simulate<LPP, 3, 0, SIM_THREADS, 0, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);                \
         }                                                                                                                                  \
     }
+// ... of Ion Torrent with its buffers in LDS: the first half is the flow model (no text FIFOs: a block more per CU, and no block waits for the record
+// sizes of the blocks in front of it), the second half qualities and text from the finished reads in HBM
+#define DW_SIM_SPLIT_ION(LPP)                                                                                                              \
+    void launch_sim_split_ion_##LPP(hipStream_t st, const SimArgs &a, uint32_t nb, size_t lds_a, size_t lds_b, int out)                    \
+    {                                                                                                                                      \
+        hipLaunchKernelGGL((k_simulate<LPP, 1, 3, SIM_THREADS, 1, 1>), dim3(nb), dim3(SIM_THREADS), lds_a, st, a);                         \
+        launch_split_scan(st, a, LPP);                                                                                                     \
+        if (out == 1) hipLaunchKernelGGL((k_simulate<LPP, 1, 3, SIM_THREADS, 2, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);           \
+        else if (out == 2) hipLaunchKernelGGL((k_simulate<LPP, 2, 3, SIM_THREADS, 2, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);      \
+        else hipLaunchKernelGGL((k_simulate<LPP, 3, 3, SIM_THREADS, 2, 2>), dim3(nb), dim3(SIM_THREADS), lds_b, st, a);                    \
+    }
+#if DW_HAS(14)
+DW_SIM_SPLIT_ION(2)
+#endif
+#if DW_HAS(15)
+DW_SIM_SPLIT_ION(1)
+#endif
 #if DW_HAS(1)
 DW_SIM_FAMILY(2, 0)
 #endif

@@ -41,6 +41,22 @@ def test_kernel_logic_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, f
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=700)
 
 
+ION_HOMES = [{"ion_lds": 1}, {"ion_lds": 1, "split": 0}, {"ion_lds": 2}, {"ion_lds": 0}]      # as tests/test_gpu_parity.py
+
+
+@pytest.mark.parametrize("home", ION_HOMES, ids=[",".join(f"{k}={v}" for k, v in h.items()) for h in ION_HOMES])
+@pytest.mark.parametrize("fasta,flags,cap", [
+    ("tiny.fa", "-z 9 -N 500 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 400 -2 0 -e 0.01 -y 0.1", 0),
+    ("tiny.fa", "-z 9 -N 400 -c 2 -f TACG -1 100 -2 60 -e 0.2 -E 0.1 -d 300 -o 0", 0),
+    ("odd.fa", "-z 6 -N 500 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2 -A 2", 0),
+    ("tiny.fa", "-z 9 -N 600 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 100 -2 0 -e 0.05 -y 0.1", 104),       # a starting capacity that reads outgrow: the batch runs again with twice the room
+])
+def test_ion_torrent_read_buffer_homes_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags, cap, home):
+    """The Ion Torrent read buffers in LDS (two kernels / one), in LDS with the smaller blocks, in scratch slots: dw_read.hpp flow_errors, dw_host.cpp fill_sim_args."""
+    res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=300, debug_options=dict(home, **({"flow_cap": cap} if cap else {})))
+    if cap: assert res.flow_cap_mult >= 2
+
+
 GROUPED_CASES = [      # the same jobs with all contigs resident together (one walk chain, batches that run across contig boundaries)
     ("ex1.fa", "-z 13 -N 1500"),
     ("tiny.fa", "-z 4 -N 1200 -r 0.02 -R 0.5 -I 30 -X 0.6"),

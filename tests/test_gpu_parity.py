@@ -367,7 +367,25 @@ def test_ion_torrent_scratch_slots_change_hands(lib, oracle_bin, repeats_fa, slo
     slots per XCD make almost every one of the ~ 350 blocks WAIT for a slot that another block of its XCD releases (the path that a normal launch,
     with a slot per resident block, takes only when a release is still on its way); 0 = the library's own count."""
     compare_case(lib, oracle_bin, repeats_fa, "-z 41 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 200 -2 0 -C 10 -e 0.02 -y 0.03 -r 0.01",
-                 debug_options={"flow_slots": slots} if slots else None)
+                 debug_options={"ion_lds": 0, "flow_slots": slots} if slots else {"ion_lds": 0})      # (ion_lds = 0: the buffers in scratch slots -- since round 5 the fallback for reads LDS cannot hold)
+
+
+ION_HOMES = [{"ion_lds": 1}, {"ion_lds": 1, "split": 0}, {"ion_lds": 2}, {"ion_lds": 0}]      # LDS as two kernels (the default) / as one kernel / the smaller blocks / scratch slots
+ION_HOME_CASES = [
+    ("tiny.fa", f"-z 9 -N 3000 -c 2 -f {FLOW} -1 400 -2 0 -e 0.01 -y 0.1"),
+    ("tiny.fa", f"-z 9 -N 2000 -c 2 -f {FLOW} -1 200 -2 100 -e 0.02 -E 0.03 -d 600 -o 0"),
+    ("odd.fa", f"-z 6 -N 3000 -c 2 -f {FLOW} -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2 -A 2"),
+    ("tiny.fa", "-z 9 -N 1200 -c 2 -f " + "TACG" * 4 + "A" * 34 + " -1 90 -2 60 -e 0.02 -E 0.01 -d 300 -o 1"),
+    ("ex1.fa", f"-z 6472 -N 1500 -c 2 -f {FLOW} -1 150 -2 0 -e 0.3 -A 1"),
+]
+
+
+@pytest.mark.parametrize("home", ION_HOMES, ids=[",".join(f"{k}={v}" for k, v in h.items()) for h in ION_HOMES])
+@pytest.mark.parametrize("fasta,flags", ION_HOME_CASES, ids=[f"{f}:{fl}" for f, fl in ION_HOME_CASES])
+def test_ion_torrent_in_every_home_of_its_read_buffers(lib, oracle_bin, golden_dir, fasta, flags, home):
+    """The flow model's one in-place 2-bit buffer per lane (dw_read.hpp flow_errors) in LDS -- as two kernels (flow model | qualities + text: the default) or
+    as one -- in LDS with the smaller blocks, and in scratch slots of global memory (what reads too long for LDS fall back to): the same bytes everywhere."""
+    compare_case(lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=700, debug_options=home)
 
 
 @pytest.mark.parametrize("flags", __import__("parity_common").LONG_READ_CASES)
@@ -383,8 +401,9 @@ def test_ion_torrent_read_outgrows_its_buffers(lib, oracle_bin, golden_dir, cap,
     buffers, dwgsim.c:296-311): forced with a small starting capacity, batch by batch and through the job level with two batches in flight per
     context; the third case: a flow order that keeps T away for twelve flows at e = 0.1 (17-base reads that grow up to 112 bases: three doublings from 20)."""
     fl = f"-z 9 -N 2500 -c 2 {'' if ' -f ' in flags else '-f ' + FLOW} {flags}"
-    res = compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), fl, batch_pairs=700, debug_options={"flow_cap": cap})
-    assert res.flow_cap_mult >= 2
+    for home in ({}, {"ion_lds": 1, "split": 0}, {"ion_lds": 0}):
+        res = compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), fl, batch_pairs=700, debug_options=dict(home, flow_cap=cap))
+        assert res.flow_cap_mult >= 2
 
 
 def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa):
