@@ -41,6 +41,7 @@ ALGO_BYTES_PER_PAIR_2x150 = 863.0  # 713 B FASTQ written + 150 B
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3), "assembly5k": ("5000 scaffolds, N50 ~ 50 kb", 3)}
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "r04_counters.json")
+STRONG_GROUP_BP = (1 << 31) - (1 << 24)      # whole-genome groups for the strong-scaling job: a group's coordinate space holds < 2^31 cells (dw_host.cpp dwgsim_hip_add_contigs): GRCh38 = 2 groups, 2 walk chains
 MAX_LAUNCH_PAIRS = 1 << 23         # pairs per launch at most (a launch's text buffers are sized for it: 6 GB at 2 x 150 bp)
 
 
@@ -259,7 +260,10 @@ def main():
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
     ap.add_argument("--no-pipeline", action="store_true", help="every step prepares itself (walk, random-read count, exchange) before its first launch, on one resident copy of the contigs")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
+    ap.add_argument("--strong-leg", action="store_true", help="also measure the fixed whole-genome job (BASELINE configs[3]) split over the ranks: the `strong` object of the line (default with --gpus > 1)")
+    ap.add_argument("--no-strong-leg", action="store_true")
     args = ap.parse_args()
+    args.strong_leg = (args.strong_leg or args.gpus > 1) and not args.no_strong_leg
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves
@@ -291,146 +295,173 @@ def main():
 
     lib = api.load()
     flags = args.flags or (ION_FLAGS if args.ion else FLAGS)
-    params = api.parse_flags(flags, lib)                  # the workload's own configuration (the legs and baselines run it)
-    job_flags = flags
-    if args.mode == "weak" and world > 1:                 # per-GPU work fixed: world times the coverage
-        toks = flags.split(); i = toks.index("-C"); toks[i + 1] = repr(float(toks[i + 1]) * world); job_flags = " ".join(toks)
-    job_params = api.parse_flags(job_flags, lib)
-    contigs = synth.workload_contigs(args.workload)
-    tot_len = sum(len(a) for _, a in contigs)
-    paired = params.length[1] > 0
 
-    ctx = api.Context(job_params, dev, lib)
-    if args.phases:
-        ctx.debug_option("phases", 1)
-    # the job: pairs per contig exactly as dwgsim_core schedules them (dwgsim.c:582-590); every contig stays resident, in groups
-    job = []
-    n_sim = 0
-    for ci, (name, arr) in enumerate(contigs):
-        n = api.pairs_for_contig(job_params, len(arr), tot_len, ci == len(contigs) - 1, n_sim, lib)
-        if n < 0:
-            continue
-        job.append((name, arr, ci, n))
-        n_sim += n
-    job_pairs = sum(e[3] for e in job)
-    # Every group is resident TWICE (copies A / B, used by alternate steps): the walk rewrites the haplotypes in place, so the walk + random-read
-    # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
-    # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
-    copies = []
-    for _copy in range(1 if args.no_pipeline else 2):
-        gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
-        for grp in make_groups(job, args.group_bp):
-            h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
-            launches = balanced_batches(api, [(h0 + k, 0, n) for k, (_, _, _, n) in enumerate(grp) if n > 0], world, MAX_LAUNCH_PAIRS)
-            gl.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)], "launches": launches, "mine": [b for b in range(len(launches)) if b % world == rank], "pairs": sum(n for l in launches for _, _, n in l)})
-        copies.append(gl)
-    groups = copies[0]
-    my_pairs = sum(n for g in groups for b in g["mine"] for _, _, n in g["launches"][b])
-    n_my_launches = sum(len(g["mine"]) for g in groups)
+    def measure(workload, mode, flags, n_steps, warmup, group_bp):
+        """One measurement: the workload's groups made resident (twice: the pipeline), `warmup` + `n_steps` steps, the barrier-bracketed time of the
+        timed ones (maximum over the ranks).  -> everything the JSON line is made of; the context stays open (the legs use it)."""
+        params = api.parse_flags(flags, lib)                  # the workload's own configuration (the legs and baselines run it)
+        job_flags = flags
+        if mode == "weak" and world > 1:                 # per-GPU work fixed: world times the coverage
+            toks = flags.split(); i = toks.index("-C"); toks[i + 1] = repr(float(toks[i + 1]) * world); job_flags = " ".join(toks)
+        job_params = api.parse_flags(job_flags, lib)
+        contigs = synth.workload_contigs(workload)
+        tot_len = sum(len(a) for _, a in contigs)
+        paired = params.length[1] > 0
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        ctx = api.Context(job_params, dev, lib)
+        if args.phases:
+            ctx.debug_option("phases", 1)
+        # the job: pairs per contig exactly as dwgsim_core schedules them (dwgsim.c:582-590); every contig stays resident, in groups
+        job = []
+        n_sim = 0
+        for ci, (name, arr) in enumerate(contigs):
+            n = api.pairs_for_contig(job_params, len(arr), tot_len, ci == len(contigs) - 1, n_sim, lib)
+            if n < 0:
+                continue
+            job.append((name, arr, ci, n))
+            n_sim += n
+        job_pairs = sum(e[3] for e in job)
+        # Every group is resident TWICE (copies A / B, used by alternate steps): the walk rewrites the haplotypes in place, so the walk + random-read
+        # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
+        # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
+        copies = []
+        for _copy in range(1 if args.no_pipeline else 2):
+            gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
+            for grp in make_groups(job, group_bp):
+                h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
+                launches = balanced_batches(api, [(h0 + k, 0, n) for k, (_, _, _, n) in enumerate(grp) if n > 0], world, MAX_LAUNCH_PAIRS)
+                gl.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)], "launches": launches, "mine": [b for b in range(len(launches)) if b % world == rank], "pairs": sum(n for l in launches for _, _, n in l)})
+            copies.append(gl)
+        groups = copies[0]
+        my_pairs = sum(n for g in groups for b in g["mine"] for _, _, n in g["launches"][b])
+        n_my_launches = sum(len(g["mine"]) for g in groups)
 
-    stats = {"prep_ms": 0.0, "count_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def prepare(gl, record):
-        """What a step needs before its first launch: the walk of every group (every rank walks every group itself: deterministic, no broadcast),
-        this rank's random-read counts (k_place, one launch per group, one count per batch) and ONE all-gather of them; -> the rand_ii base of
-        every launch of this rank.  All of it on the walk stream / the host: it runs beside whatever the compute stream is doing."""
-        t0 = time.perf_counter()
-        for g in gl:
-            ctx.mutate_async(g["h0"])
-        counts = []
-        tc = 0.0
-        for g in gl:
-            ctx.mutate_wait(g["h0"])
+        stats = {"prep_ms": 0.0, "count_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
+
+        def prepare(gl, record):
+            """What a step needs before its first launch: the walk of every group (every rank walks every group itself: deterministic, no broadcast),
+            this rank's random-read counts (k_place, one launch per group, one count per batch) and ONE all-gather of them; -> the rand_ii base of
+            every launch of this rank.  All of it on the walk stream / the host: it runs beside whatever the compute stream is doing."""
+            t0 = time.perf_counter()
+            for g in gl:
+                ctx.mutate_async(g["h0"])
+            counts = []
+            tc = 0.0
+            for g in gl:
+                ctx.mutate_wait(g["h0"])
+                if world > 1:
+                    t1 = time.perf_counter()
+                    flat = [r for b in g["mine"] for r in g["launches"][b]]
+                    per = iter(ctx.count_random_ranges(flat, per_range=True) if flat else [])
+                    counts.append([sum(next(per) for _ in g["launches"][b]) for b in g["mine"]])
+                    tc += time.perf_counter() - t1
+            t2 = time.perf_counter()
+            bases = {}
             if world > 1:
-                t1 = time.perf_counter()
-                flat = [r for b in g["mine"] for r in g["launches"][b]]
-                per = iter(ctx.count_random_ranges(flat, per_range=True) if flat else [])
-                counts.append([sum(next(per) for _ in g["launches"][b]) for b in g["mine"]])
-                tc += time.perf_counter() - t1
-        t2 = time.perf_counter()
-        bases = {}
-        if world > 1:
-            width = max(1, max(-(-len(g["launches"]) // world) for g in gl))
-            mine_vec = torch.zeros(len(gl) * width, dtype=torch.int64)
-            for q in range(len(gl)):
-                for k, cval in enumerate(counts[q]):
-                    mine_vec[q * width + k] = cval
-            allv = torch.empty(world * mine_vec.numel(), dtype=torch.int64)
-            dist.all_gather_into_tensor(allv, mine_vec)          # one integer per launch: the only thing that crosses ranks
-            allv = allv.view(world, len(gl), width)
-            run = 0
-            for q, g in enumerate(gl):      # launch b belongs to rank b mod world; its count sits at that rank's position b // world
-                for b in range(len(g["launches"])):
-                    if b % world == rank:
-                        bases[(q, b)] = run
-                    run += int(allv[b % world, q, b // world])
-        t3 = time.perf_counter()
-        if record:
-            stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
-        return bases
+                width = max(1, max(-(-len(g["launches"]) // world) for g in gl))
+                mine_vec = torch.zeros(len(gl) * width, dtype=torch.int64)
+                for q in range(len(gl)):
+                    for k, cval in enumerate(counts[q]):
+                        mine_vec[q * width + k] = cval
+                allv = torch.empty(world * mine_vec.numel(), dtype=torch.int64)
+                dist.all_gather_into_tensor(allv, mine_vec)          # one integer per launch: the only thing that crosses ranks
+                allv = allv.view(world, len(gl), width)
+                run = 0
+                for q, g in enumerate(gl):      # launch b belongs to rank b mod world; its count sits at that rank's position b // world
+                    for b in range(len(g["launches"])):
+                        if b % world == rank:
+                            bases[(q, b)] = run
+                        run += int(allv[b % world, q, b // world])
+            t3 = time.perf_counter()
+            if record:
+                stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
+            return bases
 
-    def run(gl, bases, record, then=None):
-        """all launches of this rank for one step, two in flight; `then` (the preparation of the next step) runs once the last one is enqueued"""
-        acc = {"bytes": 0, "rand": 0}
-        slot = 0
-        pending = []
+        def run(gl, bases, record, then=None):
+            """all launches of this rank for one step, two in flight; `then` (the preparation of the next step) runs once the last one is enqueued"""
+            acc = {"bytes": 0, "rand": 0}
+            slot = 0
+            pending = []
 
-        def drain(keep):
-            while len(pending) > keep:
-                b = ctx.wait(pending.pop(0))
-                acc["bytes"] += int(b.bytes[0] + b.bytes[1] + b.bytes[2]); acc["rand"] += int(b.n_random)
-                if record:
-                    stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
-        first_launch = True
-        for q, g in enumerate(gl):
-            for b in g["mine"]:
-                drain(1)
-                base = bases[(q, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
-                first_launch = False
-                ctx.simulate_ranges_async(g["launches"][b], base, slot)
-                pending.append(slot); slot ^= 1
-        nxt = then() if then else None
-        drain(0)
-        if record:
-            stats["bytes"] = acc["bytes"]; stats["n_random"] = acc["rand"]
-        return nxt
+            def drain(keep):
+                while len(pending) > keep:
+                    b = ctx.wait(pending.pop(0))
+                    acc["bytes"] += int(b.bytes[0] + b.bytes[1] + b.bytes[2]); acc["rand"] += int(b.n_random)
+                    if record:
+                        stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
+            first_launch = True
+            for q, g in enumerate(gl):
+                for b in g["mine"]:
+                    drain(1)
+                    base = bases[(q, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
+                    first_launch = False
+                    ctx.simulate_ranges_async(g["launches"][b], base, slot)
+                    pending.append(slot); slot ^= 1
+            nxt = then() if then else None
+            drain(0)
+            if record:
+                stats["bytes"] = acc["bytes"]; stats["n_random"] = acc["rand"]
+            return nxt
 
-    def steps(n, record):
-        if args.no_pipeline:
-            for _ in range(n):
-                run(copies[0], prepare(copies[0], record), record)
-            return
-        bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares its successor)
+        def steps(n, record):
+            if args.no_pipeline:
+                for _ in range(n):
+                    run(copies[0], prepare(copies[0], record), record)
+                return
+            bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares its successor)
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(n):
+                nx = copies[(k + 1) & 1]
+                bases = run(copies[k & 1], bases, record, then=lambda: prepare(nx, record))
+            return t0
+
+        steps(warmup, False)
         barrier()
+        gpu_us0 = (ctx.debug_get("walk_us"), ctx.debug_get("count_us"))
         t0 = time.perf_counter()
-        for k in range(n):
-            nx = copies[(k + 1) & 1]
-            bases = run(copies[k & 1], bases, record, then=lambda: prepare(nx, record))
-        return t0
+        t0 = steps(n_steps, True) or t0
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stats["walk_gpu_ms"] = (ctx.debug_get("walk_us") - gpu_us0[0]) / 1e3
+        stats["count_gpu_ms"] = (ctx.debug_get("count_us") - gpu_us0[1]) / 1e3
+        total_pairs = my_pairs
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            tp = torch.tensor([my_pairs], dtype=torch.int64)
+            dist.all_reduce(tp)
+            total_pairs = int(tp.item())
 
-    steps(args.warmup, False)
-    barrier()
-    gpu_us0 = (ctx.debug_get("walk_us"), ctx.debug_get("count_us"))
-    t0 = time.perf_counter()
-    t0 = steps(args.steps, True) or t0
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stats["walk_gpu_ms"] = (ctx.debug_get("walk_us") - gpu_us0[0]) / 1e3
-    stats["count_gpu_ms"] = (ctx.debug_get("count_us") - gpu_us0[1]) / 1e3
-    total_pairs = my_pairs
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tp = torch.tensor([my_pairs], dtype=torch.int64)
-        dist.all_reduce(tp)
-        total_pairs = int(tp.item())
+        return dict(ctx=ctx, params=params, job_flags=job_flags, contigs=contigs, tot_len=tot_len, paired=paired, job=job, job_pairs=job_pairs, groups=groups, my_pairs=my_pairs,
+                    n_my_launches=n_my_launches, stats=stats, elapsed=elapsed, total_pairs=total_pairs)
+
+    m = measure(args.workload, args.mode, flags, args.steps, args.warmup, args.group_bp)
+    ctx, params, job_flags, contigs, tot_len, paired, job, job_pairs, groups, my_pairs, n_my_launches, stats, elapsed, total_pairs = (m[k] for k in (
+        "ctx", "params", "job_flags", "contigs", "tot_len", "paired", "job", "job_pairs", "groups", "my_pairs", "n_my_launches", "stats", "elapsed", "total_pairs"))
+    # the fixed whole-genome job of BASELINE configs[3] split over the ranks, beside the (weak) line: the `strong` object of the line.  Whole-genome
+    # groups (two of them: a group holds < 2^31 cells), three timed steps
+    strong = None
+    if args.strong_leg and not args.ion and args.flags is None and not (args.workload == "grch38" and args.mode == "strong"):
+        ctx.close(); ctx = None; m["ctx"] = None
+        ms = measure("grch38", "strong", FLAGS, 3, 1, STRONG_GROUP_BP)
+        ms["ctx"].close()
+        if rank == 0:
+            Ks = 3
+            strong = {"workload": f"S4 (grch38): {len(ms['job'])} contigs, {ms['tot_len']} bp, {ms['job_pairs']} pairs, dwgsim {ms['job_flags']}: ONE job split over {world} rank(s) (batch b of a group: rank b mod {world}); "
+                                  f"every rank walks every group ({len(ms['groups'])} groups)",
+                      "value": round(ms["total_pairs"] * Ks / ms["elapsed"] / 1e6, 3), "unit": "M read-pairs/s", "n_gpus": world, "steps": Ks, "ms_per_step": round(ms["elapsed"] / Ks * 1e3, 3),
+                      "walk_gpu_ms": round(ms["stats"]["walk_gpu_ms"] / Ks, 3), "count_random_gpu_ms": round(ms["stats"]["count_gpu_ms"] / Ks, 3), "simulate_kernels_ms": round(ms["stats"]["sim_kernel_ms"] / Ks, 3),
+                      "kernel_share": round(ms["stats"]["sim_kernel_ms"] / max(ms["elapsed"] * 1e3, 1e-9), 4),
+                      "note": "efficiency at N GPUs = this value / (N x the value of the N = 1 line); kernel_share = k_simulate time of rank 0 / step time: what the walks, counts and the exchange leave"}
+        ms = None
 
     if rank == 0:
         K = max(args.steps, 1)
@@ -485,6 +516,8 @@ def main():
         }
         if prof_note:
             out["roofline"]["counters_note"] = prof_note
+        if strong:
+            out["strong"] = strong
         if world == 1 and not args.no_legs:
             g0 = max(groups, key=lambda g: g["pairs"])
             cid0, n0 = max(g0["members"], key=lambda m: m[1])          # the contig with the most pairs

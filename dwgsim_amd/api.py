@@ -71,7 +71,7 @@ EXPORTS = [
     "dwgsim_hip_destroy", "dwgsim_hip_last_error", "dwgsim_hip_add_contig", "dwgsim_hip_drop_contig",
     "dwgsim_hip_set_regions", "dwgsim_hip_contig_region_length", "dwgsim_hip_contig_set_placement_length",
     "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
-    "dwgsim_hip_fetch", "dwgsim_hip_device_info",
+    "dwgsim_hip_fetch", "dwgsim_hip_device_info", "dwgsim_hip_device_numa_node",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
     "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_mutate_poll", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
     "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig", "dwgsim_hip_job_begin_contig", "dwgsim_hip_job_commit_contig", "dwgsim_hip_job_cancel_contig", "dwgsim_hip_get_params",

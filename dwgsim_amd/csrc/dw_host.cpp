@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <ctype.h>
 #include <stdarg.h>
 #include <string>
 #include <vector>
@@ -58,7 +59,13 @@ struct Group {
     std::vector<uint8_t> h_names; std::vector<int32_t> h_reg, h_seg;                     // their host sources (alive while asynchronous copies may read them)
     int fixed_max = 0;               // longest "[prefix_]name"
     uint32_t n_cand = 0;
-    uint16_t *d_summ[2] = {nullptr, nullptr}, *d_summ2[2] = {nullptr, nullptr};      // haplotype summaries (per 64 and per 1024 cells) for count_random: written with the read views at the end of the walk
+    uint16_t *d_summ[2] = {nullptr, nullptr}, *d_summ2[2] = {nullptr, nullptr};      // haplotype summaries (per 64 and per 1024 cells) for count_random: kept in step with the read views
+    // the walk as sparse work (dw_walk.hip k_mark_dirty / k_dirty_chunks): the view and the summaries of the UNMUTATED group, made once at upload, and
+    // the bitmap of 64-cell chunks the last walk may have written (dirty_any) -- or "everything" after a walk that kept no bitmap (dirty_all)
+    uint8_t *d_refview = nullptr; uint16_t *d_refsumm = nullptr, *d_refsumm2 = nullptr; uint32_t *d_dirty = nullptr; uint32_t n_dirty_words = 0;
+    bool dirty_any = false, dirty_all = false;
+    // what the allocations above were made for (a dropped group's memory is kept for the next one: dwgsim_hip_ctx::pool)
+    size_t cap_cells = 0, cap_names = 0, cap_reg = 0, cap_seg = 0;
     // a walk that was enqueued and not yet waited for
     int walk_attempt = 0; uint32_t walk_cap = 0; size_t walk_cap_bases = 0; bool walk_reset = false;
     uint32_t n_patch = 0, n_patch_ev = 0;       // file-driven mutations: patched cells / indel events
@@ -107,23 +114,25 @@ struct dwgsim_hip_ctx {
     uint32_t *d_qbase[2] = {nullptr, nullptr}; int32_t qb_words = 1;
     uint8_t *d_rand_fixed = nullptr; int32_t rand_fixed_len = 0;
     std::vector<Group> groups;
+    std::vector<Group> pool;                 // the device memory, events and page-locked mirrors of dropped groups, handed to the next add_contigs whose cells fit: a
+                                             // job of many groups pays its hipMalloc / hipFree (each a device-wide synchronisation) once, not at every group end
     std::vector<HandleRef> handles;          // contig handle -> (group, member); handles are never reused
     // simulate() working set
-    DevBuf meta, fail_summ, block_rand, status_all, out[2][3], split_state, split_hand, split_agg, split_pre, split_chunk;
+    DevBuf meta, fail_summ, block_rand, status_all, out[DWGSIM_HIP_SLOTS][3], split_state, split_hand, split_agg, split_pre, split_chunk;
     // walk-stream working set (grow-only)
-    DevBuf scratch_mask, scratch_cnt, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand, place_list, place_aux;
+    DevBuf scratch_mask, scratch_cnt, scratch_status, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand, place_list, place_aux;
     uint8_t *h_up = nullptr; size_t h_up_cap = 0; hipEvent_t ev_up = nullptr; bool up_in_flight = false;      // page-locked staging of a group's sequence
     SimSeg *h_place_segs = nullptr; size_t h_place_segs_cap = 0;
     uint64_t *h_range_rand = nullptr; size_t h_range_rand_cap = 0;      // page-locked: count_random's result per range
     std::vector<int32_t> h_ppos; std::vector<uint16_t> h_pcells; std::vector<Event> h_pev;      // file-driven mutations of the group being walked
-    bool seq_justify = false;
+    bool seq_justify = false, dense_view = false;      // "justify_seq", "dense_view": the cross-check forms of the walk (one thread justifies a whole group; the views are made from every cell)
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
     DevBuf flow_scratch, flow_free;
     uint64_t *d_counters = nullptr, *h_counters = nullptr;          // N_COUNTERS x u64 + pinned mirror: calibrate / count_random / debug hooks (compute stream)
     uint64_t *d_wcounters = nullptr;                                // 16 x u64 (mirrored per group: Group::h_wc): the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
     uint64_t *d_pcounters = nullptr, *h_pcounters = nullptr;        // N_COUNTERS x u64 + pinned mirror: count_random (walk stream)
-    Slot slot[2];                            // simulate(): two batches in flight (kernels of one overlap the copy-out of the other)
+    Slot slot[DWGSIM_HIP_SLOTS];             // simulate(): up to three batches in flight (kernels | copy-out issued | copy-out landing: dw_job.cpp)
     uint64_t *d_chain = nullptr;             // [0] random reads emitted before the next batch, [1] the abort rule's carry: handed from batch to batch on the device
     int chain_contig = -1; uint64_t chain_next_ii = 0;      // which (contig, read index) the carry continues
     bool has_carry_override = false; uint64_t carry_override = 0;
@@ -212,6 +221,7 @@ void free_group(Group &g)
 {
     hipFree(g.d_ref);
     for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_ins_pos[h]); hipFree(g.d_ins_len[h]); hipFree(g.d_ins_off[h]); hipFree(g.d_ins_bases[h]); hipFree(g.d_summ[h]); hipFree(g.d_summ2[h]); }
+    hipFree(g.d_refview); hipFree(g.d_refsumm); hipFree(g.d_refsumm2); hipFree(g.d_dirty);
     hipFree(g.d_names); hipFree(g.d_reg); hipFree(g.d_seg);
     if (g.ev_walk) hipEventDestroy(g.ev_walk);
     if (g.ev_walk0) hipEventDestroy(g.ev_walk0);
@@ -297,6 +307,20 @@ int64_t dwgsim_hip_pairs_for_contig(const dwgsim_hip_params_t *p, int64_t l, uin
     else if (0 < size1 && l < p->dist + 3 * p->std_dev) return DWGSIM_HIP_SKIP_SHORT_INSERT;                                 // #3 :605-611
     else if (l < size0 || (0 < size1 && l < size1)) return DWGSIM_HIP_SKIP_SHORT_READ;                                     // #4 :612-618
     return n_pairs < 0 ? DWGSIM_HIP_SKIP_NO_PAIRS : n_pairs;
+}
+
+int dwgsim_hip_device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);      // sysfs spells the bus id in lower case
+    char path[160]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
 }
 
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes)
@@ -543,10 +567,11 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->walk_stream) hipStreamSynchronize(c->walk_stream);
     for (auto &g : c->groups) if (g.alive) free_group(g);
+    for (auto &g : c->pool) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
-    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->split_state, &c->split_hand, &c->split_agg, &c->split_pre, &c->split_chunk, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
+    for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->split_state, &c->split_hand, &c->split_agg, &c->split_pre, &c->split_chunk, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->scratch_status, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
                       &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch, &c->flow_free}) hipFree(b->p);
-    for (int s = 0; s < 2; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
+    for (int s = 0; s < DWGSIM_HIP_SLOTS; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->h_pcounters) hipHostFree(c->h_pcounters);
@@ -600,19 +625,40 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
     if (gid < 0) { c->groups.emplace_back(); gid = (int)c->groups.size() - 1; }
     Group &g = c->groups[(size_t)gid];
     g = Group();
+    {   // memory of a dropped group, if one is large enough (the smallest such; none more than four times too large)
+        const size_t want = (size_t)total + CELL_PAD;
+        int best = -1;
+        for (size_t i = 0; i < c->pool.size(); ++i) if (c->pool[i].cap_cells >= want && c->pool[i].cap_cells <= 4 * want + (1u << 20) && (best < 0 || c->pool[i].cap_cells < c->pool[(size_t)best].cap_cells)) best = (int)i;
+        if (best >= 0) { g = c->pool[(size_t)best]; c->pool.erase(c->pool.begin() + best); }
+        // what describes the group that was dropped goes; the allocations and their capacities stay
+        g.mutated = g.walk_pending = false; g.m.clear(); g.h_names.clear(); g.h_reg.clear(); g.h_seg.clear(); g.fixed_max = 0; g.n_cand = 0;
+        g.n_ins[0] = g.n_ins[1] = g.n_ins_bases[0] = g.n_ins_bases[1] = 0; g.walk_attempt = 0; g.walk_cap = 0; g.walk_cap_bases = 0; g.walk_reset = false; g.n_patch = g.n_patch_ev = 0;
+        g.list_valid = false; g.pos.clear(); g.cells.clear(); g.ins[0] = HostIns(); g.ins[1] = HostIns(); g.dirty_any = g.dirty_all = false;
+    }
     g.alive = true; g.total = total; g.first_handle = (int)c->handles.size();
     g.m.resize((size_t)n);
     for (int k = 0; k < n; ++k) { Member &m = g.m[(size_t)k]; m.name = names[k]; m.l = m.l_place = lens[k]; m.contig_index = contig_index[k]; m.start = (int32_t)starts[(size_t)k]; }
     const size_t padded = padded_cells(g);
     bool synced = true;
     auto fill = [&]() -> int {
-        HIPC(c, hipEventCreate(&g.ev_walk)); HIPC(c, hipEventCreate(&g.ev_walk0));
-        HIPC(c, hipHostMalloc((void **)&g.h_wc, 16 * sizeof(uint64_t), hipHostMallocDefault));
-        HIPC(c, hipMalloc((void **)&g.d_ref, padded));
-        for (int h = 0; h < 2; ++h) {
-            HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32));
-            HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, hipMalloc((void **)&g.d_summ2[h], sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
+        if (!g.ev_walk) HIPC(c, hipEventCreate(&g.ev_walk));
+        if (!g.ev_walk0) HIPC(c, hipEventCreate(&g.ev_walk0));
+        if (!g.h_wc) HIPC(c, hipHostMalloc((void **)&g.h_wc, 16 * sizeof(uint64_t), hipHostMallocDefault));
+        if (g.cap_cells < padded) {
+            hipFree(g.d_ref); hipFree(g.d_refview); hipFree(g.d_refsumm); hipFree(g.d_refsumm2); hipFree(g.d_dirty);
+            g.d_ref = g.d_refview = nullptr; g.d_refsumm = g.d_refsumm2 = nullptr; g.d_dirty = nullptr;
+            for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_summ[h]); hipFree(g.d_summ2[h]); g.d_cells[h] = g.d_view[h] = nullptr; g.d_summ[h] = g.d_summ2[h] = nullptr; }
+            g.cap_cells = 0;
+            HIPC(c, hipMalloc((void **)&g.d_ref, padded));
+            for (int h = 0; h < 2; ++h) {
+                HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32));
+                HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, hipMalloc((void **)&g.d_summ2[h], sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
+            }
+            HIPC(c, hipMalloc((void **)&g.d_refview, padded / 2 + 32)); HIPC(c, hipMalloc((void **)&g.d_refsumm, sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, hipMalloc((void **)&g.d_refsumm2, sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
+            HIPC(c, hipMalloc((void **)&g.d_dirty, sizeof(uint32_t) * ((padded + 32 * SUMM_CELLS - 1) / (32 * SUMM_CELLS) + 2)));
+            g.cap_cells = padded;
         }
+        g.n_dirty_words = (uint32_t)((padded + 32 * SUMM_CELLS - 1) / (32 * SUMM_CELLS));
         if (ensure(c, c->up_ascii, padded)) return DWGSIM_HIP_ERR_DEVICE;
         uint8_t *d_ascii = (uint8_t *)c->up_ascii.p;
         // The sequence goes up on the walk stream.  One copy when the caller's buffers already are the group layout inside ONE page-locked
@@ -647,12 +693,19 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
             HIPC(c, hipEventRecord(c->ev_up, c->walk_stream)); c->up_in_flight = true;
         }
         launch_pack(c->walk_stream, d_ascii, g.d_ref, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15);
+        // the read views and summaries of the unmutated group, once: the pristine copies, and what both haplotypes start from (a walk then rewrites
+        // only the chunks it touches)
+        launch_make_view(c->walk_stream, g.d_ref, g.d_ref, (int64_t)padded & ~(int64_t)15, g.total, g.d_refview, g.d_view[0], g.d_refsumm, g.d_summ[0], g.d_refsumm2, g.d_summ2[0]);
+        HIPC(c, hipMemcpyAsync(g.d_view[1], g.d_refview, padded / 2, hipMemcpyDeviceToDevice, c->walk_stream));
+        HIPC(c, hipMemcpyAsync(g.d_summ[1], g.d_refsumm, sizeof(uint16_t) * (padded / SUMM_CELLS), hipMemcpyDeviceToDevice, c->walk_stream));
+        HIPC(c, hipMemcpyAsync(g.d_summ2[1], g.d_refsumm2, sizeof(uint16_t) * (padded / SUMM2_CELLS), hipMemcpyDeviceToDevice, c->walk_stream));
+        HIPC(c, hipMemsetAsync(g.d_dirty, 0, sizeof(uint32_t) * ((size_t)g.n_dirty_words + 2), c->walk_stream));
         HIPC(c, hipGetLastError());
         // segment table, name pool, target regions
         g.h_seg.resize((size_t)(3 * n + 1));
         for (int k = 0; k < n; ++k) { g.h_seg[(size_t)k] = g.m[(size_t)k].start; g.h_seg[(size_t)(n + 1 + k)] = (int32_t)g.m[(size_t)k].l; g.h_seg[(size_t)(2 * n + 1 + k)] = (int32_t)g.m[(size_t)k].contig_index; }
         g.h_seg[(size_t)n] = (int32_t)total;
-        HIPC(c, hipMalloc((void **)&g.d_seg, sizeof(int32_t) * g.h_seg.size()));
+        if (g.cap_seg < g.h_seg.size()) { hipFree(g.d_seg); g.d_seg = nullptr; g.cap_seg = 0; HIPC(c, hipMalloc((void **)&g.d_seg, sizeof(int32_t) * (g.h_seg.size() + 64))); g.cap_seg = g.h_seg.size() + 64; }
         HIPC(c, hipMemcpyAsync(g.d_seg, g.h_seg.data(), sizeof(int32_t) * g.h_seg.size(), hipMemcpyHostToDevice, c->walk_stream));
         for (int k = 0; k < n; ++k) {      // '@' + "[prefix_]name", zero padded to >= 256 + 16 bytes (the kernel stages 128 bytes in LDS), entries 16-byte aligned
             Member &m = g.m[(size_t)k];
@@ -663,7 +716,7 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
             g.h_names.resize(g.h_names.size() + room, 0);
             g.h_names[m.name_off] = '@'; memcpy(&g.h_names[m.name_off + 1], nf.data(), nf.size());
         }
-        HIPC(c, hipMalloc((void **)&g.d_names, g.h_names.size()));
+        if (g.cap_names < g.h_names.size()) { hipFree(g.d_names); g.d_names = nullptr; g.cap_names = 0; HIPC(c, hipMalloc((void **)&g.d_names, g.h_names.size() + 4096)); g.cap_names = g.h_names.size() + 4096; }
         HIPC(c, hipMemcpyAsync(g.d_names, g.h_names.data(), g.h_names.size(), hipMemcpyHostToDevice, c->walk_stream));
         if (c->has_regions) {
             for (int k = 0; k < n; ++k) {
@@ -674,7 +727,7 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
                 g.h_reg.insert(g.h_reg.end(), st.begin(), st.end()); g.h_reg.insert(g.h_reg.end(), en.begin(), en.end());
             }
             g.h_reg.push_back(0);
-            HIPC(c, hipMalloc((void **)&g.d_reg, sizeof(int32_t) * g.h_reg.size()));
+            if (g.cap_reg < g.h_reg.size()) { hipFree(g.d_reg); g.d_reg = nullptr; g.cap_reg = 0; HIPC(c, hipMalloc((void **)&g.d_reg, sizeof(int32_t) * (g.h_reg.size() + 64))); g.cap_reg = g.h_reg.size() + 64; }
             HIPC(c, hipMemcpyAsync(g.d_reg, g.h_reg.data(), sizeof(int32_t) * g.h_reg.size(), hipMemcpyHostToDevice, c->walk_stream));
         }
         // -m / -b / -v: the file's entries for these contigs are resolved now, while the sequence is at hand (mut.c:644-745)
@@ -700,9 +753,18 @@ int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *c, int contig)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->copy_stream);
-    hipStreamSynchronize(c->walk_stream);
+    if (g->walk_pending) hipEventSynchronize(g->ev_walk);      // (not the whole walk stream: it may already carry the upload and the walk of the next group)
     for (size_t k = 0; k < g->m.size(); ++k) { if (c->chain_contig == g->first_handle + (int)k) c->chain_contig = -1; c->handles[(size_t)g->first_handle + k].group = -1; }
-    free_group(*g);
+    // the group's memory waits for the next group (at most three sets are kept: the smallest goes)
+    g->alive = false;
+    c->pool.push_back(*g);
+    *g = Group();
+    if (c->pool.size() > 3) {
+        size_t small = 0;
+        for (size_t i = 1; i < c->pool.size(); ++i) if (c->pool[i].cap_cells < c->pool[small].cap_cells) small = i;
+        hipStreamSynchronize(c->walk_stream);
+        free_group(c->pool[small]); c->pool.erase(c->pool.begin() + (long)small);
+    }
     return DWGSIM_HIP_OK;
 }
 
@@ -809,17 +871,32 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
             launch_mut_debug(st, g.d_ref, g.d_cells[0], g.d_cells[1], total, &c->d_wcounters[13]);      // mut.c:757
         }
         launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.total, g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
+        g.dirty_all = true;
         HIPC(c, hipGetLastError());
         HIPC(c, hipMemcpyAsync(&g.h_wc[12], &c->d_wcounters[12], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIPC(c, hipEventRecord(g.ev_walk, st));
         return DWGSIM_HIP_OK;
     }
     const uint32_t nblk = (uint32_t)((total + SCAN_POS_PER_BLOCK - 1) / SCAN_POS_PER_BLOCK);
-    if (ensure(c, c->scratch_mask, (size_t)nblk * SCAN_THREADS * sizeof(uint16_t))) return DWGSIM_HIP_ERR_DEVICE;
-    if (ensure(c, c->scratch_cnt, (size_t)nblk * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
-    uint16_t *d_mask = (uint16_t *)c->scratch_mask.p; uint32_t *d_cnt = (uint32_t *)c->scratch_cnt.p;
-    if (g.walk_attempt > 0)      // a capacity re-run starts again from the resident packed reference
-        for (int h = 0; h < 2; ++h) HIPC(c, hipMemcpyAsync(g.d_cells[h], g.d_ref, padded, hipMemcpyDeviceToDevice, st));
+    if (ensure(c, c->scratch_status, ((size_t)nblk + 2) * sizeof(uint64_t))) return DWGSIM_HIP_ERR_DEVICE;      // look-back words of k_site_scan_list + its ticket
+    uint64_t *d_status = (uint64_t *)c->scratch_status.p, *d_ticket = d_status + nblk;
+    // where the group stands: fresh from the upload, or with the chunks the previous walk wrote -- those go back to the pristine copies --, or (a
+    // capacity re-run, a walk that kept no bitmap) all of it
+    if (g.walk_attempt > 0 || g.dirty_all) {
+        for (int h = 0; h < 2; ++h) {
+            HIPC(c, hipMemcpyAsync(g.d_cells[h], g.d_ref, padded, hipMemcpyDeviceToDevice, st));
+            HIPC(c, hipMemcpyAsync(g.d_view[h], g.d_refview, padded / 2, hipMemcpyDeviceToDevice, st));
+            HIPC(c, hipMemcpyAsync(g.d_summ[h], g.d_refsumm, sizeof(uint16_t) * (padded / SUMM_CELLS), hipMemcpyDeviceToDevice, st));
+            HIPC(c, hipMemcpyAsync(g.d_summ2[h], g.d_refsumm2, sizeof(uint16_t) * (padded / SUMM2_CELLS), hipMemcpyDeviceToDevice, st));
+        }
+        HIPC(c, hipMemsetAsync(g.d_dirty, 0, sizeof(uint32_t) * ((size_t)g.n_dirty_words + 2), st));
+        g.dirty_all = false; g.dirty_any = false;
+    } else if (g.dirty_any) {
+        launch_dirty_chunks(st, true, g.d_dirty, g.n_dirty_words, g.total, g.d_ref, g.d_refview, g.d_refsumm, g.d_refsumm2, g.d_cells[0], g.d_cells[1], g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
+        HIPC(c, hipMemsetAsync(g.d_dirty, 0, sizeof(uint32_t) * ((size_t)g.n_dirty_words + 2), st));
+        g.dirty_any = false;
+    }
+    HIPC(c, hipMemsetAsync(d_status, 0, ((size_t)nblk + 2) * sizeof(uint64_t), st));
     const uint32_t cap = g.walk_cap; const size_t cap_bases = g.walk_cap_bases;
     const size_t ncap = cap ? cap : 1;
     if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
@@ -845,11 +922,8 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
     uint32_t *d_small = reinterpret_cast<uint32_t *>(&c->d_wcounters[8]);   // [0] max_del, [1..4] tot4: eight words in counters[8..11], so that one copy brings counters[7..11] back
     const Count nc{&c->d_wcounters[7], cap};
     HIPC(c, hipMemsetAsync(&c->d_wcounters[7], 0, 5 * sizeof(uint64_t), st));
-    // K1: candidate sites -> ordered list
-    const bool reset = g.walk_reset && g.walk_attempt == 0;      // (a capacity re-run has just copied the cells back; a first walk finds them fresh from k_pack)
-    launch_site_scan(st, g.d_ref, total, seg, wp, d_mask, d_cnt, reset ? g.d_cells[0] : nullptr, reset ? g.d_cells[1] : nullptr);
-    launch_scan_excl(st, d_cnt, nblk, &c->d_wcounters[7]);
-    launch_compact(st, d_mask, d_cnt, d_cand, total, cap);
+    // K1: candidate sites -> ordered list (one kernel, from the pristine 4-bit view)
+    launch_site_scan_list(st, g.d_refview, total, seg, wp, d_status, d_ticket, d_cand, cap, &c->d_wcounters[7]);
     // K2: events, liveness, insertion-table allocation
     launch_events(st, d_cand, nc, g.d_ref, seg, wp, d_ev, &d_small[0]);
     launch_resolve(st, d_ev, nc, &d_small[0], d_flags, &d_small[1]);
@@ -861,9 +935,17 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
     // ((c + 1..3) & 3, mut.c:621), a homozygous one writes the same cell to both haplotypes and a heterozygous one leaves the other
     // haplotype's cell as it was -- the reference base, also under a deletion or an insertion, before and after left-justification
     // (which only moves an indel over bases equal to its own).  File-driven mutations (-m / -b / -v, above) can violate all three.
-    if (c->seq_justify) launch_justify_seq(st, d_ev, nc, cd);
-    else launch_justify(st, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
-    launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.total, g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
+    if (c->seq_justify || c->dense_view) {      // (the cross-check forms: one thread justifies the whole group / the views are made from every cell as rounds 1-4 did)
+        if (c->seq_justify) launch_justify_seq(st, d_ev, nc, cd); else launch_justify(st, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+        launch_make_view(st, g.d_cells[0], g.d_cells[1], (int64_t)padded & ~(int64_t)15, g.total, g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
+        g.dirty_all = true;
+    } else {
+        launch_justify(st, d_ev, nc, cd, (int32_t *)c->w_lo.p, (int32_t *)c->w_sufmin.p, (uint8_t *)c->w_bound.p);
+        // the chunks the walk may have written (every live event from the lower end of its justification scan to its last cell): their views and summaries
+        launch_mark_dirty(st, d_ev, nc, (const int32_t *)c->w_lo.p, g.d_dirty);
+        launch_dirty_chunks(st, false, g.d_dirty, g.n_dirty_words, g.total, g.d_ref, g.d_refview, g.d_refsumm, g.d_refsumm2, g.d_cells[0], g.d_cells[1], g.d_view[0], g.d_view[1], g.d_summ[0], g.d_summ[1], g.d_summ2[0], g.d_summ2[1]);
+        g.dirty_any = true;
+    }
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpyAsync(&g.h_wc[7], &c->d_wcounters[7], 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));      // [7] candidates, [8..11] the eight words
     HIPC(c, hipEventRecord(g.ev_walk, st));
@@ -1328,7 +1410,7 @@ int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *c, const dwgsim_hip_range
 }
 static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, uint64_t rand_base, int slot, bool rerun)
 {
-    if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS) { if (c) c->err = "bad simulate arguments"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "simulate: the slot still holds a batch that was not waited for"; return DWGSIM_HIP_ERR_STATE; }
     const dwgsim_hip_params_t &p = c->prm;
@@ -1463,7 +1545,7 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii
 
 int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
 {
-    if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad slot"; return DWGSIM_HIP_ERR_ARG; }
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS) { if (c) c->err = "bad slot"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
     if (out) memset(out, 0, sizeof *out);
     if (sl.empty) { sl.pending = false; return DWGSIM_HIP_OK; }
@@ -1530,7 +1612,7 @@ void dwgsim_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 // Copies on the context's second stream: a batch that is being copied out of one slot overlaps with the kernels filling the other.
 int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)
 {
-    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) { if (c) c->err = "bad fetch arguments"; return DWGSIM_HIP_ERR_ARG; }
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS || stream < 0 || stream > 2 || (!host_dst && cap)) { if (c) c->err = "bad fetch arguments"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "fetch: wait for the batch first (its sizes are not known yet)"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
@@ -1560,7 +1642,7 @@ int dwgsim_hip_set_gzip(dwgsim_hip_ctx_t *c, int on)
 
 int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)
 {
-    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) { if (c) c->err = "bad fetch arguments"; return DWGSIM_HIP_ERR_ARG; }
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS || stream < 0 || stream > 2 || (!host_dst && cap)) { if (c) c->err = "bad fetch arguments"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "fetch: wait for the batch first (its sizes are not known yet)"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
@@ -1575,7 +1657,7 @@ int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *h
 
 int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *c, int slot)
 {
-    if (!c || slot < 0 || slot > 1) { if (c) c->err = "bad slot"; return DWGSIM_HIP_ERR_ARG; }
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS) { if (c) c->err = "bad slot"; return DWGSIM_HIP_ERR_ARG; }
     Slot &sl = c->slot[slot];
     if (!sl.fetch_in_flight) return DWGSIM_HIP_OK;
     HIPC(c, hipSetDevice(c->device));
@@ -1586,7 +1668,7 @@ int dwgsim_hip_fetch_wait(dwgsim_hip_ctx_t *c, int slot)
 
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)
 {
-    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || (!host_dst && cap)) return DWGSIM_HIP_ERR_ARG;
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS || stream < 0 || stream > 2 || (!host_dst && cap)) return DWGSIM_HIP_ERR_ARG;
     HIPC(c, hipSetDevice(c->device));
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "fetch: wait for the batch first (its sizes are not known yet)"; return DWGSIM_HIP_ERR_STATE; }
@@ -1619,7 +1701,7 @@ int dwgsim_hip_fetch(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, 
 // Test / analysis hook (not part of the drop-in surface): occurrences of `byte` in one finished stream of a waited-for slot, counted on the device.
 int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *c, int slot, int stream, int byte, uint64_t *count)
 {
-    if (!c || slot < 0 || slot > 1 || stream < 0 || stream > 2 || !count) return DWGSIM_HIP_ERR_ARG;
+    if (!c || slot < 0 || slot >= DWGSIM_HIP_SLOTS || stream < 0 || stream > 2 || !count) return DWGSIM_HIP_ERR_ARG;
     HIPC(c, hipSetDevice(c->device));
     Slot &sl = c->slot[slot];
     if (sl.pending) { c->err = "count_byte: wait for the batch first"; return DWGSIM_HIP_ERR_STATE; }
@@ -1674,6 +1756,7 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
 {
     if (!c || !key) return DWGSIM_HIP_ERR_ARG;
     if (!strcmp(key, "justify_seq")) c->seq_justify = value != 0;
+    else if (!strcmp(key, "dense_view")) c->dense_view = value != 0;
     else if (!strcmp(key, "walk_cap")) c->walk_cap = value;
     else if (!strcmp(key, "phases")) c->phases = value != 0;
     else if (!strcmp(key, "writer")) c->writer = (int)value;

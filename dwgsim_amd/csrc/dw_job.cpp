@@ -28,9 +28,37 @@
 #include <mutex>
 #include <condition_variable>
 #include <atomic>
+#include <sched.h>
 #include "../../include/dwgsim_hip.h"
 
 namespace {
+
+// A device's worker thread -- it allocates the device's page-locked output buffers and waits for its copies -- runs on the cores of the NUMA node the
+// GPU hangs off (dwgsim_hip_device_numa_node: /sys/bus/pci/devices/<bus id>/numa_node), so that on a two-socket node no device copies its members
+// across the socket link.  Quietly does nothing where the node is unknown (-1: single-socket boxes, containers without sysfs), where the node's
+// cores are not among the ones the process may use, or with DWGSIM_HIP_NO_PIN set.
+void pin_thread_to_device_node(int device)
+{
+    if (getenv("DWGSIM_HIP_NO_PIN")) return;
+    const int node = dwgsim_hip_device_numa_node(device);
+    if (node < 0) return;
+    char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char list[4096]; const bool got = fgets(list, sizeof list, f) != nullptr; fclose(f);
+    if (!got) return;
+    cpu_set_t allowed, want; CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    int n_want = 0;
+    for (const char *q = list; *q && *q != '\n';) {      // "0-31,64-95"
+        char *e; long a = strtol(q, &e, 10), b = a;
+        if (e == q) break;
+        if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &want); ++n_want; }
+        q = *e == ',' ? e + 1 : e;
+    }
+    if (n_want > 0) (void)sched_setaffinity(0, sizeof want, &want);
+}
 
 struct PinBuf { char *p[3] = {nullptr, nullptr, nullptr}; size_t cap[3] = {0, 0, 0}; };      // the output of one batch in page-locked memory
 
@@ -89,7 +117,7 @@ struct dwgsim_hip_job {
     uint64_t delivered_pairs = 0; uint64_t total_rand = 0;
     // page-locked output buffers per device
     std::vector<std::vector<std::unique_ptr<PinBuf>>> bufs; std::vector<std::vector<PinBuf *>> free_bufs;
-    int max_bufs = 4;
+    int max_bufs = 6;      // (three batches in flight per device + what the delivery threads hold)
 };
 
 namespace {
@@ -204,6 +232,7 @@ struct Worker {
 
     void run()
     {
+        pin_thread_to_device_node(j->devices[(size_t)d]);
         for (;;) {
             std::shared_ptr<GroupJob> g;
             {
@@ -260,25 +289,34 @@ struct Worker {
         }
         // the next group, if it is already here, is uploaded and walked on the walk stream while this one's batches run
         if (!look_ahead(g)) return false;
-        // batches: two in flight; batch k-1 is copied out while batch k runs
-        struct Pending { bool live = false; int slot = 0, b = 0; } prev;
-        auto finish_batch = [&](Pending &pb) -> bool {
+        // batches: THREE in flight, one per slot of the context -- batch k is enqueued (kernels), then the copy-out of batch k-1 is issued as soon as its
+        // kernels are done (stage A), then the copy-out of batch k-2 is waited for and the batch published (stage B).  The copy of k-1 is queued on the
+        // copy stream while that of k-2 is still landing, so the link never waits for the host; with two slots (rounds 3-4) the copy of a batch was issued
+        // only behind the enqueue of the next one -- 15 host calls during which the copy engine stood still (the whole-genome job moved 33 GB/s over a
+        // link that carries 50).
+        struct Pending { bool live = false; int slot = 0, b = 0; dwgsim_hip_batch_t bt; BatchOut bo; };
+        Pending q1, q2;      // q1: enqueued, stage A to come; q2: stage A done, stage B to come
+        auto stage_a = [&](Pending &pb) -> bool {
+            if (!pb.live) return true;
+            if (dwgsim_hip_wait(x, pb.slot, &pb.bt) < 0) { fail_ctx(); return false; }
+            pb.bo = BatchOut(); pb.bo.lane = d; pb.bo.pairs = pb.bt.n_pairs;
+            if (j->sink.reads) {
+                PinBuf *tb = acquire(j->gzip ? pb.bt.gz_bytes : pb.bt.bytes);
+                if (!tb) return false;
+                pb.bo.buf = tb;
+                for (int s = 0; s < 3; ++s) {
+                    pb.bo.n[s] = j->gzip ? pb.bt.gz_bytes[s] : pb.bt.bytes[s]; pb.bo.text_n[s] = pb.bt.bytes[s];
+                    if (pb.bo.n[s] && (j->gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail_ctx(); return false; }
+                    if (pb.bo.n[s]) ++pb.bo.left;
+                }
+            }
+            return true;
+        };
+        auto stage_b = [&](Pending &pb) -> bool {
             if (!pb.live) return true;
             pb.live = false;
-            dwgsim_hip_batch_t bt;
-            if (dwgsim_hip_wait(x, pb.slot, &bt) < 0) { fail_ctx(); return false; }
-            BatchOut bo; bo.lane = d; bo.pairs = bt.n_pairs;
-            if (j->sink.reads) {
-                PinBuf *tb = acquire(j->gzip ? bt.gz_bytes : bt.bytes);
-                if (!tb) return false;
-                bo.buf = tb;
-                for (int s = 0; s < 3; ++s) {
-                    bo.n[s] = j->gzip ? bt.gz_bytes[s] : bt.bytes[s]; bo.text_n[s] = bt.bytes[s];
-                    if (bo.n[s] && (j->gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail_ctx(); return false; }
-                    if (bo.n[s]) ++bo.left;
-                }
-                if (dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
-            }
+            if (j->sink.reads && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
+            const dwgsim_hip_batch_t &bt = pb.bt; BatchOut &bo = pb.bo;
             uint64_t shown = 0; bool aborted = false;
             {
                 std::lock_guard<std::mutex> lk(j->m);
@@ -300,22 +338,32 @@ struct Worker {
             if (!j->opt.quiet) { char t[64]; snprintf(t, sizeof t, "\r[dwgsim_core] %llu", (unsigned long long)shown); if (j->sink.message) j->sink.message(j->sink.user, t); else fputs(t, stderr); }      // (outside the lock: a sink may call back into the job)
             return true;
         };
-        int kk = 0;
+        int kk = 0; bool fine = true;
         for (int b : mine) {
-            if (!ok()) break;
+            if (!ok()) { fine = false; break; }
             uint64_t rbase;
             if (j->ND > 1) { rbase = g->rand_base; for (int q = 0; q < b; ++q) rbase += g->batch_rand[(size_t)q]; }      // (batch_rand is final: all devices have published)
             else { rbase = first_batch_of_job ? 0 : DWGSIM_HIP_RAND_CHAIN; first_batch_of_job = false; }
             const auto r = ranges_of(b);
-            const int slot = kk & 1;
-            if (dwgsim_hip_simulate_ranges_async(x, r.data(), (int)r.size(), rbase, slot) < 0) { fail_ctx(); break; }
-            if (!finish_batch(prev)) { prev.live = true; prev.slot = slot; prev.b = b; break; }
-            prev.live = true; prev.slot = slot; prev.b = b;
+            const int slot = kk % DWGSIM_HIP_SLOTS;      // (the slot's previous batch, kk - 3, went through stage B in the iteration before)
+            if (dwgsim_hip_simulate_ranges_async(x, r.data(), (int)r.size(), rbase, slot) < 0) { fail_ctx(); fine = false; break; }
+            Pending cur; cur.live = true; cur.slot = slot; cur.b = b;
+            const bool a_ok = stage_a(q1), b_ok = a_ok && stage_b(q2);
+            if (!a_ok || !b_ok) {      // the job has failed: what is in flight is only waited for (below)
+                if (a_ok) { q2 = q1; q1 = cur; } else { Pending lost = cur; dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, lost.slot, &bt); }
+                fine = false; break;
+            }
+            q2 = q1; q1 = cur;
             ++kk;
-            if (!look_ahead(g)) break;
+            if (!look_ahead(g)) { fine = false; break; }
         }
-        if (ok()) { if (!finish_batch(prev)) return false; }
-        else if (prev.live) { dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, prev.slot, &bt); }
+        if (fine && ok()) fine = stage_a(q1) && stage_b(q2) && (q2 = q1, q1.live = false, stage_b(q2));
+        else fine = false;
+        if (!fine) {      // leave the context idle: kernels and copies of whatever was in flight are waited for, nothing more is published
+            if (q1.live) { dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, q1.slot, &bt); (void)dwgsim_hip_fetch_wait(x, q1.slot); }
+            if (q2.live) (void)dwgsim_hip_fetch_wait(x, q2.slot);
+            return false;
+        }
         if (!ok()) return false;
         if (dwgsim_hip_drop_contig(x, h) < 0) { fail_ctx(); return false; }
         return true;

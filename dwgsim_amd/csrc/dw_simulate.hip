@@ -641,6 +641,9 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         const uint64_t hexb = hex_digits_sum(a.chain[0], pre_rand);
         pre_b1 = pi[1] + pc[1] + hexb; pre_b2 = pi[2] + pc[2] + (LPP == 2 ? hexb : 0ull);
     }
+    // (Ion Torrent: a read the flow model gave up on emits nothing, which the arithmetic offsets of the two-kernel form do not allow for -- and the batch
+    // is run again or fails as a whole (dw_host.cpp dwgsim_hip_wait): nothing is written for it)
+    if (ION && H == 2 && (a.counters[2] & 2ull)) return;
     if (H == 2) {
         const uint4 hm = reinterpret_cast<const uint4 *>(a.split_hand)[(size_t)t * nthr + tid];
         rr.ext_coor = (int32_t)hm.x; n_err = (int32_t)(hm.y & 0xffffu); rr.n_sub = (int32_t)(hm.y >> 16); rr.n_indel = (int32_t)(hm.z & 0xffffu); rr.n_ins = (int32_t)(hm.z >> 16);

@@ -95,6 +95,150 @@ __global__ void k_site_scan(const uint8_t *__restrict__ ref, SegTab seg, WalkPar
     if (threadIdx.x == 0) block_count[blockIdx.x] = total;
 }
 
+// K1 as ONE kernel over a group of any size (round 5; k_site_scan + k_scan_excl + k_compact above remain for the callers that still want a mask):
+// the sixteen positions of a thread come from the PRISTINE 4-bit view of the reference (0.5 byte per base instead of 1; a nibble below 4 is A, C, G or T),
+// and the candidates go straight into the ordered list -- the block's place in it from a decoupled look-back over the blocks in front (logical block ids
+// from a ticket, so that every predecessor has started), not from a scan kernel of its own: the single-block scan of the per-block counts was 0.85 ms
+// of a whole-genome walk and grows with the group.  status: one word per block, ticket: one word, both zeroed by the host; total -> *n_out.
+// A block takes SITE_TILES tiles of SCAN_POS_PER_BLOCK positions (each tile inside one contig): 65 536 positions per look-back -- with one tile per block
+// the chain of look-backs (a hop of at most 64 blocks per memory round trip) was slower than the draws: 4.6 ms per 1.5 Gb group, 0.4 ms worth of work.
+constexpr int SITE_TILES = 16;
+__global__ void __launch_bounds__(SCAN_THREADS) k_site_scan_list(const uint8_t *__restrict__ refview, int64_t l_total, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket,
+                                                              int32_t *__restrict__ out, uint32_t cap, uint64_t *n_out, uint32_t n_blocks)
+{
+    __shared__ uint32_t sm[SITE_TILES][16];
+    __shared__ uint32_t s_t; __shared__ uint64_t s_base;
+    if (threadIdx.x == 0) s_t = (uint32_t)atomicAdd((unsigned long long *)ticket, 1ull);
+    __syncthreads();
+    const uint32_t t = uniform_u32(s_t);
+    uint32_t bits[SITE_TILES], cnt[SITE_TILES], off[SITE_TILES], tot[SITE_TILES], block_total = 0;
+#pragma unroll
+    for (int q = 0; q < SITE_TILES; ++q) {
+        const int64_t tile0 = ((int64_t)t * SITE_TILES + q) * SCAN_POS_PER_BLOCK;
+        bits[q] = 0;
+        if (tile0 < l_total) {                                                   // (block-uniform)
+            const uint32_t sk = seg_of(seg, tile0);                              // a tile's positions lie inside one contig: contigs start at multiples of GROUP_ALIGN
+            const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
+            const int64_t g0 = tile0 + (int64_t)threadIdx.x * SCAN_POS_PER_THREAD;
+            const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];              // position inside the contig: what the draws are indexed by
+            if (p0 < l) {
+                const uint64_t v = *reinterpret_cast<const uint64_t *>(refview + (g0 >> 1));      // sixteen nibbles (the view is padded: reading past l is safe)
+                uint32_t acgt = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) { const uint32_t nib = (uint32_t)(v >> (4 * b)) & 15u; if (nib < 4 && p0 + b < l) acgt |= 1u << b; }
+                if (acgt) bits[q] = (site_hits8(key, (uint32_t)(p0 >> 3), wp.mut_thr) | (site_hits8(key, (uint32_t)(p0 >> 3) + 1u, wp.mut_thr) << 8)) & acgt;
+            }
+        }
+        cnt[q] = (uint32_t)__popc(bits[q]);
+    }
+    block_excl_scan_n<SITE_TILES>(cnt, sm, off, tot);      // sixteen block-wide scans behind one barrier
+#pragma unroll
+    for (int q = 0; q < SITE_TILES; ++q) { off[q] += block_total; block_total += tot[q]; }
+    if (threadIdx.x < 64) {
+        const uint64_t g = lookback_excl(status, t, block_total, 0);
+        if (threadIdx.x == 0) { s_base = g; if (t + 1 == n_blocks) *n_out = g + block_total; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SITE_TILES; ++q) {
+        uint64_t at = s_base + off[q]; uint32_t bq = bits[q];
+        const int64_t g0 = ((int64_t)t * SITE_TILES + q) * SCAN_POS_PER_BLOCK + (int64_t)threadIdx.x * SCAN_POS_PER_THREAD;
+        while (bq) { const int b = __ffs((int)bq) - 1; bq &= bq - 1; if (at < cap) out[at] = (int32_t)(g0 + b); ++at; }   // (past the capacity: the host re-runs)
+    }
+}
+
+// ---- the walk as SPARSE work (round 5).  A walk touches about one cell in a thousand; rounds 1-4 nevertheless rewrote dense arrays for every walk (two
+// resets of 1 byte per base, k_make_view over 3 bytes per base: 2.5 of the ~8 ms of kernels per genome).  Now the read views and the haplotype
+// summaries of the UNMUTATED group are made once, at upload (refview / refsumm / refsumm2 stay as pristine copies), and a walk records the
+// 64-cell chunks it may have written in a bitmap (one bit per chunk): the footprint of every live event, from the lower end of its
+// left-justification scan (k_jreach's `lo`, a proven lower bound of every cell the event's scan reads or writes) to its last cell.  Two passes
+// over the bitmap do the rest: AFTER the walk the views and summaries of the dirty chunks are recomputed from the cells; BEFORE the next walk of
+// the group the dirty chunks' cells, views and summaries are set back from the pristine copies. ----
+__global__ void k_mark_dirty(const Event *__restrict__ ev, Count nc, const int32_t *__restrict__ lo, uint32_t *__restrict__ dirty)
+{
+    const uint32_t n = count_of(nc), k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const Event e = ev[k];
+    if (!e.live) return;
+    const int64_t right = (int64_t)e.pos + (e.type == 2 ? (int64_t)e.len - 1 : 0);
+    const int64_t a = (int64_t)(lo[k] < e.pos ? lo[k] : e.pos) >> 6, b = right >> 6;
+    for (int64_t q = a; q <= b; ++q) atomicOr(&dirty[q >> 5], 1u << (q & 31));
+}
+// one thread per word of the bitmap = 32 chunks = 2048 cells = two words of the coarse summaries.  RESTORE = false: views + summaries from the cells;
+// true: cells, views and summaries from the pristine copies.
+template <bool RESTORE>
+__global__ void __launch_bounds__(256) k_dirty_chunks(const uint32_t *__restrict__ dirty, uint32_t n_words, int64_t l_live, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ refview,
+                                                      const uint16_t *__restrict__ refsumm, const uint16_t *__restrict__ refsumm2,
+                                                      uint8_t *__restrict__ cells0, uint8_t *__restrict__ cells1, uint8_t *__restrict__ view0, uint8_t *__restrict__ view1,
+                                                      uint16_t *__restrict__ summ0, uint16_t *__restrict__ summ1, uint16_t *__restrict__ summ2_0, uint16_t *__restrict__ summ2_1)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t bits = dirty[w];
+    if (!bits) return;
+    const uint32_t touched = bits;
+    while (bits) {
+        const int q = __ffs((int)bits) - 1; bits &= bits - 1;
+        const int64_t ch = (int64_t)w * 32 + q, first = ch * SUMM_CELLS;
+        if (RESTORE) {
+#pragma unroll
+            for (int k = 0; k < SUMM_CELLS / 16; ++k) { const uint4 v = *reinterpret_cast<const uint4 *>(ref + first + 16 * k); *reinterpret_cast<uint4 *>(cells0 + first + 16 * k) = v; *reinterpret_cast<uint4 *>(cells1 + first + 16 * k) = v; }
+#pragma unroll
+            for (int k = 0; k < SUMM_CELLS / 32; ++k) { const uint4 v = *reinterpret_cast<const uint4 *>(refview + (first >> 1) + 16 * k); *reinterpret_cast<uint4 *>(view0 + (first >> 1) + 16 * k) = v; *reinterpret_cast<uint4 *>(view1 + (first >> 1) + 16 * k) = v; }
+            const uint16_t sv = refsumm[ch]; summ0[ch] = sv; summ1[ch] = sv;
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint8_t *cells = h ? cells1 : cells0; uint8_t *view = h ? view1 : view0;
+                uint32_t indel = 0, non_acgt = 0;
+#pragma unroll
+                for (int half = 0; half < SUMM_CELLS / 32; ++half) {
+                    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int64_t at = first + 32 * half + 16 * qq;
+                        const uint4 v = *reinterpret_cast<const uint4 *>(cells + at);
+                        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int b = 0; b < 16; ++b) {
+                            const uint32_t c = (wd[b >> 2] >> (8 * (b & 3))) & 0xffu, ty = c & TMASK, base = c & 0xfu;
+                            const uint32_t nib = ty == T_NONE ? (base < 4 ? base : base == 4 ? 8u : 9u) : (ty == T_SUB && base < 4) ? 4u + base : 15u;
+                            const int cell = 16 * qq + b;
+                            out[cell >> 3] |= nib << (4 * (cell & 7));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int64_t rem = l_live - (at + 4 * k);               // cells of this word that belong to the group (the rest is padding)
+                            const uint32_t lm = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ((1u << (8 * (int)rem)) - 1u);
+                            indel += (uint32_t)__popc(wd[k] & lm & 0x10101010u);
+                            non_acgt |= wd[k] & lm & 0x0C0C0C0Cu;
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(view + ((first + 32 * half) >> 1)) = make_uint4(out[0], out[1], out[2], out[3]);
+                }
+                (h ? summ1 : summ0)[ch] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
+            }
+        }
+    }
+    // the coarse summaries (SUMM2_CELLS cells = 16 chunks) that hold a dirty chunk: from their sixteen fine words
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (!((touched >> (16 * half)) & 0xFFFFu)) continue;
+        const int64_t s2 = (int64_t)w * 2 + half;
+        if (s2 * SUMM2_CELLS >= l_live) continue;
+        if (RESTORE) { const uint16_t sv = refsumm2[s2]; summ2_0[s2] = sv; summ2_1[s2] = sv; }
+        else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint16_t *sm1 = h ? summ1 : summ0;
+                uint32_t cnt = 0, fl = 0;
+                for (int k = 0; k < SUMM2_CELLS / SUMM_CELLS; ++k) { const int64_t ch = s2 * (SUMM2_CELLS / SUMM_CELLS) + k; if (ch * SUMM_CELLS < l_live) { const uint32_t v = sm1[ch]; cnt += v & 0x7fffu; fl |= v & 0x8000u; } }
+                (h ? summ2_1 : summ2_0)[s2] = (uint16_t)(cnt | fl);
+            }
+        }
+    }
+}
+
 // single-block exclusive scan (in place) of n uint32; optional 64-bit total.  One barrier per chunk: the LDS scratch alternates
 // between two areas and every thread carries the running total itself.
 __global__ void k_scan_excl(uint32_t *data, uint32_t n, uint64_t *total_out)
@@ -564,6 +708,22 @@ void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0
 void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg, WalkParams wp, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1)
 {
     hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, seg, wp, mask, block_count, reset0, reset1);
+}
+void launch_site_scan_list(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket, int32_t *out, uint32_t cap, uint64_t *n_out)
+{
+    const uint32_t nb = (uint32_t)cdiv((uint64_t)l, (uint64_t)SCAN_POS_PER_BLOCK * SITE_TILES);
+    hipLaunchKernelGGL(k_site_scan_list, dim3(nb), dim3(SCAN_THREADS), 0, st, refview, l, seg, wp, status, ticket, out, cap, n_out, nb);
+}
+void launch_mark_dirty(hipStream_t st, const Event *ev, Count n, const int32_t *lo, uint32_t *dirty)
+{
+    if (n.host) hipLaunchKernelGGL(k_mark_dirty, dim3(cdiv(n.host, 256)), dim3(256), 0, st, ev, n, lo, dirty);
+}
+void launch_dirty_chunks(hipStream_t st, bool restore, const uint32_t *dirty, uint32_t n_words, int64_t l_live, const uint8_t *ref, const uint8_t *refview, const uint16_t *refsumm, const uint16_t *refsumm2,
+                         uint8_t *cells0, uint8_t *cells1, uint8_t *view0, uint8_t *view1, uint16_t *summ0, uint16_t *summ1, uint16_t *summ2_0, uint16_t *summ2_1)
+{
+    if (!n_words) return;
+    if (restore) hipLaunchKernelGGL(k_dirty_chunks<true>, dim3(cdiv(n_words, 256)), dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1);
+    else hipLaunchKernelGGL(k_dirty_chunks<false>, dim3(cdiv(n_words, 256)), dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1);
 }
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out)
 {

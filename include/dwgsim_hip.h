@@ -33,6 +33,7 @@ extern "C" {
 #define DWGSIM_HIP_ERR_NOMEM    -3
 #define DWGSIM_HIP_ERR_UNSUP    -4   /* option outside the accelerated path (see DESIGN.md "out of scope") */
 #define DWGSIM_HIP_ERR_FAILED   -5   /* "failed to generate a read after %d trials" (dwgsim.c:837-840) */
+#define DWGSIM_HIP_SLOTS 3          /* output sets of a context: batches that can be in flight (kernels | copy-out issued | copy-out landing) */
 #define DWGSIM_HIP_ERR_STATE    -6   /* call order violated (e.g. simulate before mutate) */
 
 /* Why dwgsim_core() passes over a contig (dwgsim.c:539-625, the "[dwgsim_core] #k skip sequence" notes): returned in place of a pair count by
@@ -199,13 +200,13 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *ctx, const dwgsim_hip_range
 
 /* Replaces the loop body dwgsim.c:636-1099 for the read-index range [first_ii, first_ii+n_pairs)
  * of one contig.  rand_base = number of random reads emitted before first_ii (over all contigs).
- * slot in {0,1}: which of the context's double-buffered output sets to fill.  Blocking form:
+ * slot in 0 .. DWGSIM_HIP_SLOTS - 1: which of the context's output sets to fill.  Blocking form:
  * returns after the kernels completed; FASTQ text stays in HBM (out->dev_ptr) until a fetch copies it out.
  * Replaces, together with the fetch calls, the gzprintf / gzputc stream of dwgsim.c:919-981. */
 int dwgsim_hip_simulate(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_ii, uint64_t n_pairs,
                         uint64_t rand_base, int slot, dwgsim_hip_batch_t *out);
 
-/* The same in two halves, so that two batches can be in flight (slot 0 / 1): simulate_async only enqueues -- kernels, the abort-rule
+/* The same in two halves, so that several batches can be in flight (one per slot): simulate_async only enqueues -- kernels, the abort-rule
  * epilogue and the read-back of the batch's counters on the context's compute stream -- and returns; wait blocks until that batch has
  * finished, reports its errors and fills *out.  Batch k+1 may be enqueued (other slot, rand_base = DWGSIM_HIP_RAND_CHAIN) before
  * batch k was waited for; a slot is reused only after its wait(), and its kernels wait on the device for any fetch still reading it. */
@@ -249,6 +250,9 @@ int dwgsim_hip_fetch_gz_async(dwgsim_hip_ctx_t *ctx, int slot, int stream, void 
 int dwgsim_hip_fetch(dwgsim_hip_ctx_t *ctx, int slot, int stream, void *host_dst, size_t cap);
 
 /* Library / device info for logs: returns the ABI version; name gets the HIP device name. */
+/* The NUMA node of the host the device hangs off (/sys/bus/pci/devices/<bus id>/numa_node), -1 when unknown.  The job level runs each device's worker
+ * thread -- which allocates and fills that device's page-locked buffers -- on the cores of this node.  (No counterpart in the reference: it has one thread.) */
+int dwgsim_hip_device_numa_node(int device);
 int dwgsim_hip_device_info(int device, char *name, size_t cap, int *n_cu, size_t *hbm_bytes);
 /* HIP devices visible to the process (0 without a GPU). */
 int dwgsim_hip_device_count(void);

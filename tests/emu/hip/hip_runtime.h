@@ -116,6 +116,7 @@ static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+static inline hipError_t hipDeviceGetPCIBusId(char *b, int n, int) { if (n > 0) b[0] = 0; return 1; }      // (no bus on the emulator: the NUMA node is unknown)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "cpu-simt-emulator"); strcpy(p->gcnArchName, "emu"); p->multiProcessorCount = 1; return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void *p) { free(p); return 0; }

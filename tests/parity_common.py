@@ -371,19 +371,22 @@ def check_gzip_kernel_on_hard_inputs(lib, scale=0):
 
 
 def check_walking_a_contig_again(lib, fasta, flags, n=400):
-    """dwgsim_hip_mutate_contig on a contig that was walked before starts again from the resident reference (the cells are reset inside the
-    site scan): same mutation files, same reads -- also when the first walk of the second round has to be re-run for capacity."""
+    """dwgsim_hip_mutate_contig on a contig that was walked before starts again from the pristine copies: the 64-cell chunks the previous walk
+    wrote are set back (dw_walk.hip k_dirty_chunks), the walk runs, the views and summaries of the chunks it wrote are made again.  Same mutation
+    files, same reads, same random-read counts (they come from the summaries) -- also when a walk has to be re-run for capacity (round 2), when the
+    views are made from every cell as rounds 1-4 did ("dense_view", round 3) and on the sparse walk behind that (round 4: everything is set back)."""
     contigs = api.read_fasta(fasta)
     params = api.parse_flags(flags, lib)
     name, arr = contigs[0]
     with api.Context(params, 0, lib) as ctx:
         cid = ctx.add_contig(name, arr, 0)
         got = []
-        for rnd in range(3):
-            if rnd == 2:
-                ctx.debug_option("walk_cap", 5)
+        for rnd in range(5):
+            ctx.debug_option("walk_cap", 5 if rnd == 2 else -1)
+            ctx.debug_option("dense_view", 1 if rnd == 3 else 0)
             ctx.mutate(cid)
+            cnt = ctx.count_random(cid, 7, n - 7)
             b = ctx.simulate(cid, 0, n, 0, rnd & 1)
-            got.append((ctx.mutations_text(cid), [ctx.fetch(rnd & 1, s, b.bytes[s]) for s in range(3)]))
-        assert got[0] == got[1] == got[2]
+            got.append((ctx.mutations_text(cid), [ctx.fetch(rnd & 1, s, b.bytes[s]) for s in range(3)], cnt))
+        assert got[0] == got[1] == got[2] == got[3] == got[4]
         assert len(got[0][0][0]) > 200
