@@ -260,10 +260,10 @@ def main():
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
     ap.add_argument("--no-pipeline", action="store_true", help="every step prepares itself (walk, random-read count, exchange) before its first launch, on one resident copy of the contigs")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
-    ap.add_argument("--strong-leg", action="store_true", help="also measure the fixed whole-genome job (BASELINE configs[3]) split over the ranks: the `strong` object of the line (default with --gpus > 1)")
+    ap.add_argument("--strong-leg", action="store_true", help="also measure the fixed whole-genome job (BASELINE configs[3]) split over the ranks: the `strong` object of the line (default with --gpus > 1, and at N = 1 unless --no-legs)")
     ap.add_argument("--no-strong-leg", action="store_true")
     args = ap.parse_args()
-    args.strong_leg = (args.strong_leg or args.gpus > 1) and not args.no_strong_leg
+    args.strong_leg = (args.strong_leg or args.gpus > 1 or not args.no_legs) and not args.no_strong_leg      # (N = 1 carries it too: the curve's efficiency is taken against that line)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves

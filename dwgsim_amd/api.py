@@ -70,7 +70,7 @@ EXPORTS = [
     "dwgsim_hip_params_default", "dwgsim_hip_params_check", "dwgsim_hip_pairs_for_contig", "dwgsim_hip_create",
     "dwgsim_hip_destroy", "dwgsim_hip_last_error", "dwgsim_hip_add_contig", "dwgsim_hip_drop_contig",
     "dwgsim_hip_set_regions", "dwgsim_hip_contig_region_length", "dwgsim_hip_contig_set_placement_length",
-    "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
+    "dwgsim_hip_set_mutation_input", "dwgsim_hip_mutate_contig", "dwgsim_hip_mutations_text", "dwgsim_hip_mutations_take", "dwgsim_hip_mutlist_text", "dwgsim_hip_mutlist_free", "dwgsim_hip_count_random", "dwgsim_hip_simulate",
     "dwgsim_hip_fetch", "dwgsim_hip_device_info", "dwgsim_hip_device_numa_node",
     "dwgsim_hip_simulate_async", "dwgsim_hip_wait", "dwgsim_hip_fetch_async", "dwgsim_hip_fetch_wait", "dwgsim_hip_host_alloc", "dwgsim_hip_host_free",
     "dwgsim_hip_add_contigs", "dwgsim_hip_group_layout", "dwgsim_hip_mutate_async", "dwgsim_hip_mutate_wait", "dwgsim_hip_mutate_poll", "dwgsim_hip_count_random_ranges", "dwgsim_hip_simulate_ranges_async", "dwgsim_hip_device_count",
@@ -138,6 +138,11 @@ def load(path: str | None = None):
     lib.dwgsim_hip_set_mutation_input.argtypes = [C.c_void_p, C.c_int, C.c_char_p, P(C.c_char_p), P(C.c_int64), C.c_int]
     lib.dwgsim_hip_mutate_contig.argtypes = [C.c_void_p, C.c_int]
     lib.dwgsim_hip_mutations_text.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_size_t), P(C.c_void_p), P(C.c_size_t)]
+    lib.dwgsim_hip_mutations_take.argtypes = [C.c_void_p, C.c_int, P(C.c_int)]
+    lib.dwgsim_hip_mutations_take.restype = C.c_void_p
+    lib.dwgsim_hip_mutlist_text.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_size_t), P(C.c_void_p), P(C.c_size_t)]
+    lib.dwgsim_hip_mutlist_free.argtypes = [C.c_void_p]
+    lib.dwgsim_hip_mutlist_free.restype = None
     lib.dwgsim_hip_count_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, P(C.c_uint64)]
     lib.dwgsim_hip_simulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, P(Batch)]
     lib.dwgsim_hip_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -396,6 +401,23 @@ class Context:
         self._chk(self.lib.dwgsim_hip_mutations_text(self.h, cid, C.byref(t), C.byref(tl), C.byref(v), C.byref(vl)))
         return C.string_at(t, tl.value) if tl.value else b"", C.string_at(v, vl.value) if vl.value else b""
 
+    def mutations_via_list(self, cid: int):
+        """the same text through the two-halves form (mutations_take / mutlist_text): [(txt, vcf)] for every contig of cid's group"""
+        n = C.c_int()
+        L = self.lib.dwgsim_hip_mutations_take(self.h, cid, C.byref(n))
+        if not L:
+            raise RuntimeError(self.lib.dwgsim_hip_last_error(self.h).decode(errors="replace"))
+        try:
+            out = []
+            for k in range(n.value):
+                t, v = C.c_void_p(), C.c_void_p()
+                tl, vl = C.c_size_t(), C.c_size_t()
+                self._chk(self.lib.dwgsim_hip_mutlist_text(L, k, C.byref(t), C.byref(tl), C.byref(v), C.byref(vl)))
+                out.append((C.string_at(t, tl.value) if tl.value else b"", C.string_at(v, vl.value) if vl.value else b""))
+            return out
+        finally:
+            self.lib.dwgsim_hip_mutlist_free(L)
+
     def count_random(self, cid: int, first_ii: int, n_pairs: int) -> int:
         n = C.c_uint64(0)
         self._chk(self.lib.dwgsim_hip_count_random(self.h, cid, first_ii, n_pairs, C.byref(n)))
@@ -527,7 +549,7 @@ def split_ranges(ranges, batch_pairs):
         yield batch
 
 
-def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None, debug_options=None, group_bp: int = 0) -> JobResult:
+def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22, fetch: bool = True, lib=None, debug_options=None, group_bp: int = 0, check_list_form: bool = False) -> JobResult:
     """dwgsim_core (dwgsim.c:419-1121) over the C-ABI: header pass, then schedule -> mutate -> mutations text -> simulate in
     read-index batches.  group_bp = 0: contig after contig, as the reference walks them.  group_bp > 0: consecutive contigs are resident
     together in groups of up to group_bp bases (dwgsim_hip_add_contigs): one walk per group, batches that run across contig boundaries."""
@@ -569,6 +591,11 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
                     t, v = ctx.mutations_text(h0 + k)
                     txt += t
                     vcf += v
+                if check_list_form:      # (tests) the two-halves form the job level uses must give the same text
+                    tv = ctx.mutations_via_list(h0)
+                    if b"".join(a for a, _ in tv) != b"".join(ctx.mutations_text(h0 + k)[0] for k in range(len(grp))) or \
+                       b"".join(b for _, b in tv) != b"".join(ctx.mutations_text(h0 + k)[1] for k in range(len(grp))):
+                        raise DwgsimError("mutations_take / mutlist_text differs from mutations_text")
             ranges = [(h0 + k, 0, ent[3]) for k, ent in enumerate(grp) if want_reads and ent[3] > 0]
             for batch in split_ranges(ranges, batch_pairs):
                 b = ctx.simulate_ranges(batch, rand_ii, 0)

@@ -751,9 +751,12 @@ int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *c, int contig)
     Group *g = get_group(c, contig);
     if (!g) return DWGSIM_HIP_ERR_ARG;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->copy_stream);
-    if (g->walk_pending) hipEventSynchronize(g->ev_walk);      // (not the whole walk stream: it may already carry the upload and the walk of the next group)
+    // what may still read the group's memory: the kernels of batches that were enqueued and not waited for (not the whole compute stream: it may
+    // already carry batches of the NEXT group -- the job level keeps its three batches in flight across a group's end -- and not the copy stream:
+    // copies read the slots' output buffers), and the group's own walk (not the whole walk stream: it may carry the upload and the walk of the next group)
+    const int gid = (int)(g - c->groups.data());
+    for (int s = 0; s < DWGSIM_HIP_SLOTS; ++s) if (c->slot[s].pending && !c->slot[s].empty && c->slot[s].group == gid) hipEventSynchronize(c->slot[s].ev_done);
+    if (g->walk_pending) hipEventSynchronize(g->ev_walk);
     for (size_t k = 0; k < g->m.size(); ++k) { if (c->chain_contig == g->first_handle + (int)k) c->chain_contig = -1; c->handles[(size_t)g->first_handle + k].group = -1; }
     // the group's memory waits for the next group (at most three sets are kept: the smallest goes)
     g->alive = false;
@@ -1070,21 +1073,99 @@ int dwgsim_hip_mutate_contig(dwgsim_hip_ctx_t *c, int contig)
 
 // ---- mutations.txt / mutations.vcf from the sparse list of mutated cells (mut.c:781-893) ----
 namespace {
-const char *ins_text(const HostIns &t, int32_t pos, std::string &tmp)
+// The text is made by plain appends (a vsnprintf per field cost 0.2 us per mutation: 50 ms for a 250 Mb chromosome, during which the worker of
+// round 4's job level enqueued nothing); it is also a pure function of the list, so that it can be made by another thread than the one that
+// drives the device (dwgsim_hip_mutations_take / dwgsim_hip_mutlist_text).
+struct TextOut {
+    std::string &s;
+    void ch(char c) { s.push_back(c); }
+    void str(const char *p, size_t n) { s.append(p, n); }
+    void lit(const char *p) { s.append(p); }
+    void num(long long v)
+    {
+        char b[24]; int n = 0; unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) s.push_back('-');
+        while (n) s.push_back(b[--n]);
+    }
+};
+struct ListView {      // the mutated cells of a group (group coordinates) and its insertion tables
+    const int32_t *pos; const uint32_t *cells; size_t n; const HostIns *ins;
+};
+void ins_text(const HostIns &t, int32_t pos, std::string &tmp)
 {
     tmp.clear();
     auto it = std::lower_bound(t.pos.begin(), t.pos.end(), pos);
-    if (it == t.pos.end() || *it != pos) return tmp.c_str();
+    if (it == t.pos.end() || *it != pos) return;
     const size_t k = (size_t)(it - t.pos.begin());
     for (uint32_t q = 0; q < t.len[k]; ++q) tmp.push_back("ACGTN"[t.bases[t.off[k] + q] & 3]);
-    return tmp.c_str();
 }
-void appendf(std::string &s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-void appendf(std::string &s, const char *fmt, ...)
+// mut_print (mut.c:781-893) for one contig: name, first cell s0 and length l in the group's coordinates
+void format_mutations(const ListView &g, const std::string &name, int64_t s0, int64_t l, std::string &txt_s, std::string &vcf_s)
 {
-    char buf[1024]; va_list ap; va_start(ap, fmt); int n = vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (n < (int)sizeof buf) { s.append(buf, (size_t)n); return; }
-    std::vector<char> big((size_t)n + 1); va_start(ap, fmt); vsnprintf(big.data(), big.size(), fmt, ap); va_end(ap); s.append(big.data(), (size_t)n);
+    txt_s.clear(); vcf_s.clear();
+    // this contig's slice of the list, positions inside the contig
+    const size_t e0 = (size_t)(std::lower_bound(g.pos, g.pos + g.n, (int32_t)s0) - g.pos);
+    const size_t e1 = (size_t)(std::lower_bound(g.pos, g.pos + g.n, (int32_t)(s0 + l)) - g.pos);
+    txt_s.reserve((e1 - e0) * (name.size() + 20)); vcf_s.reserve((e1 - e0) * (name.size() + 56));
+    // sparse restatement of the per-position loop: only listed positions can print; "previous position
+    // mutated" (mut_prev, mut.c:890-891) is "position i-1 is listed with a mutated cell on that haplotype"
+    static const char B5[] = "ACGTN";       // B5[5] is the terminating NUL, as in the reference for code 5 ('-')
+    TextOut txt{txt_s}, vcf{vcf_s};
+    // (a %c of the NUL of B5[5] prints a NUL byte in the reference; r0 < 4 and substituted / inserted bases are 0-3 here, deleted reference bases too)
+    std::string tmp;
+    auto cell = [&](size_t e, int h) -> uint8_t { return (uint8_t)(h ? g.cells[e] >> 8 : g.cells[e]); };
+    auto refc = [&](size_t e) -> uint8_t { return (uint8_t)(g.cells[e] >> 16); };          // nst_nt4_table code of the reference base
+    auto prevc = [&](size_t e) -> uint8_t { return (uint8_t)(g.cells[e] >> 24); };         // ... of the base in front of it
+    auto vcf_head = [&](long long at) { vcf.str(name.data(), name.size()); vcf.ch('\t'); vcf.num(at); vcf.lit("\t.\t"); };
+    for (size_t e = e0; e < e1; ++e) {
+        const int64_t i = g.pos[e] - s0;
+        const uint8_t r0 = refc(e), c1 = cell(e, 0), c2 = cell(e, 1);
+        if (r0 >= 4) continue;
+        const bool adj = e > e0 && g.pos[e - 1] == g.pos[e] - 1;
+        const bool prev0 = adj && (cell(e - 1, 0) & TMASK) != T_NONE, prev1 = adj && (cell(e - 1, 1) & TMASK) != T_NONE;
+        txt.str(name.data(), name.size()); txt.ch('\t'); txt.num((long long)i + 1); txt.ch('\t');
+        const bool hom = (c1 & BTMASK) == (c2 & BTMASK);
+        const uint8_t t1 = c1 & TMASK, t2 = c2 & TMASK;
+        if (hom ? t1 == T_SUB : (t1 == T_SUB || t2 == T_SUB)) {
+            if (hom) {
+                txt.ch(B5[r0]); txt.ch('\t'); txt.ch(B5[c1 & 0xf]); txt.lit("\t3\n");
+                vcf_head((long long)i + 1); vcf.ch(B5[r0]); vcf.ch('\t'); vcf.ch(B5[c1 & 0xf]); vcf.lit("\t100\tPASS\tAF=1.0;pl=3;mt=SUBSTITUTE\n");
+            } else {
+                const int hap = t1 == T_SUB ? 1 : 2;
+                txt.ch(B5[r0]); txt.ch('\t'); txt.ch("XACMGRSVTWYHKDBN"[1 << (c1 & 3) | 1 << (c2 & 3)]); txt.ch('\t'); txt.ch((char)('0' + hap)); txt.ch('\n');
+                vcf_head((long long)i + 1); vcf.ch(B5[r0]); vcf.ch('\t'); vcf.ch(B5[(hap == 1 ? c1 : c2) & 0xf]); vcf.lit("\t100\tPASS\tAF=0.5;pl="); vcf.ch((char)('0' + hap)); vcf.lit(";mt=SUBSTITUTE\n");
+            }
+        } else if (hom ? t1 == T_DEL : (t1 == T_DEL || t2 == T_DEL)) {
+            const int pl = hom ? 3 : (t1 == T_DEL ? 1 : 2);
+            txt.ch(B5[r0]); txt.lit("\t-\t"); txt.ch((char)('0' + pl)); txt.ch('\n');
+            const bool open = hom ? (!prev0 || !prev1) : !(pl == 1 ? prev0 : prev1);
+            if (open) {      // one VCF record for the run, anchored at the previous reference base (mut.c:801-815)
+                vcf_head((long long)i);
+                if (i > 0) vcf.ch(B5[prevc(e)]);
+                size_t ee = e; int64_t j = i;
+                for (;;) {
+                    vcf.ch(B5[refc(ee)]);
+                    if (j + 1 >= l) break;
+                    // cell at j+1: listed -> its cells, else unmutated
+                    if (ee + 1 < e1 && g.pos[ee + 1] - s0 == j + 1) {
+                        ++ee; ++j;
+                        const uint8_t a1 = cell(ee, 0), a2 = cell(ee, 1);
+                        const bool h2 = (a1 & BTMASK) == (a2 & BTMASK);
+                        if (!(h2 == hom && ((pl == 2 ? a2 : a1) & TMASK) == T_DEL)) break;
+                    } else break;
+                }
+                if (i > 0) { vcf.ch('\t'); vcf.ch(B5[prevc(e)]); } else vcf.lit("\t.");
+                vcf.lit("\t100\tPASS\tAF="); vcf.lit(hom ? "1.0" : "0.5"); vcf.lit(";pl="); vcf.ch((char)('0' + pl)); vcf.lit(";mt=DELETE\n");
+            }
+        } else {
+            const int pl = hom ? 3 : (t1 == T_INS ? 1 : 2);
+            ins_text(g.ins[pl == 2 ? 1 : 0], g.pos[e], tmp);
+            txt.lit("-\t"); txt.str(tmp.data(), tmp.size()); txt.ch('\t'); txt.ch((char)('0' + pl)); txt.ch('\n');
+            vcf_head((long long)i + 1); vcf.ch(B5[r0]); vcf.ch('\t'); vcf.ch(B5[r0]); vcf.str(tmp.data(), tmp.size());
+            vcf.lit("\t100\tPASS\tAF="); vcf.lit(hom ? "1.0" : "0.5"); vcf.lit(";pl="); vcf.ch((char)('0' + pl)); vcf.lit(";mt=INSERT\n");
+        }
+    }
 }
 
 // the mutated cells of a walked group (positions in group coordinates, cells + reference codes) and its insertion tables, fetched once
@@ -1134,74 +1215,58 @@ int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *c, int contig, const char **txt,
     Group &g = *gp;
     if (!g.mutated || g.walk_pending) { c->err = "mutate_contig must run first"; return DWGSIM_HIP_ERR_STATE; }
     HIPC(c, hipSetDevice(c->device));
-    c->txt.clear(); c->vcf.clear();
     if (const int rc = fetch_mutated_list(c, g)) return rc;
     const Member &m = g.m[(size_t)km];
-    const int64_t l = m.l, s0 = m.start;
-    // this contig's slice of the list, positions inside the contig
-    const size_t e0 = (size_t)(std::lower_bound(g.pos.begin(), g.pos.end(), (int32_t)s0) - g.pos.begin());
-    const size_t e1 = (size_t)(std::lower_bound(g.pos.begin(), g.pos.end(), (int32_t)(s0 + l)) - g.pos.begin());
-    // sparse restatement of the per-position loop: only listed positions can print; "previous position
-    // mutated" (mut_prev, mut.c:890-891) is "position i-1 is listed with a mutated cell on that haplotype"
-    static const char B5[] = "ACGTN";       // B5[5] is the terminating NUL, as in the reference for code 5 ('-')
-    const char *nm = m.name.c_str();
-    std::string tmp;
-    auto cell = [&](size_t e, int h) -> uint8_t { return (uint8_t)(h ? g.cells[e] >> 8 : g.cells[e]); };
-    auto refc = [&](size_t e) -> uint8_t { return (uint8_t)(g.cells[e] >> 16); };          // nst_nt4_table code of the reference base
-    auto prevc = [&](size_t e) -> uint8_t { return (uint8_t)(g.cells[e] >> 24); };         // ... of the base in front of it
-    for (size_t e = e0; e < e1; ++e) {
-        const int64_t i = g.pos[e] - s0;
-        const uint8_t r0 = refc(e), c1 = cell(e, 0), c2 = cell(e, 1);
-        if (r0 >= 4) continue;
-        const bool adj = e > e0 && g.pos[e - 1] == g.pos[e] - 1;
-        const bool prev0 = adj && (cell(e - 1, 0) & TMASK) != T_NONE, prev1 = adj && (cell(e - 1, 1) & TMASK) != T_NONE;
-        appendf(c->txt, "%s\t%lld\t", nm, (long long)i + 1);
-        const bool hom = (c1 & BTMASK) == (c2 & BTMASK);
-        const uint8_t t1 = c1 & TMASK, t2 = c2 & TMASK;
-        if (hom ? t1 == T_SUB : (t1 == T_SUB || t2 == T_SUB)) {
-            if (hom) {
-                appendf(c->txt, "%c\t%c\t3\n", B5[r0], B5[c1 & 0xf]);
-                appendf(c->vcf, "%s\t%lld\t.\t%c\t%c\t100\tPASS\tAF=1.0;pl=3;mt=SUBSTITUTE\n", nm, (long long)i + 1, B5[r0], B5[c1 & 0xf]);
-            } else {
-                const int hap = t1 == T_SUB ? 1 : 2;
-                appendf(c->txt, "%c\t%c\t%d\n", B5[r0], "XACMGRSVTWYHKDBN"[1 << (c1 & 3) | 1 << (c2 & 3)], hap);
-                appendf(c->vcf, "%s\t%lld\t.\t%c\t%c\t100\tPASS\tAF=0.5;pl=%d;mt=SUBSTITUTE\n", nm, (long long)i + 1, B5[r0], B5[(hap == 1 ? c1 : c2) & 0xf], hap);
-            }
-        } else if (hom ? t1 == T_DEL : (t1 == T_DEL || t2 == T_DEL)) {
-            const int pl = hom ? 3 : (t1 == T_DEL ? 1 : 2);
-            appendf(c->txt, "%c\t-\t%d\n", B5[r0], pl);
-            const bool open = hom ? (!prev0 || !prev1) : !(pl == 1 ? prev0 : prev1);
-            if (open) {      // one VCF record for the run, anchored at the previous reference base (mut.c:801-815)
-                appendf(c->vcf, "%s\t%lld\t.\t", nm, (long long)i);
-                if (i > 0) c->vcf.push_back(B5[prevc(e)]);
-                size_t ee = e; int64_t j = i;
-                for (;;) {
-                    c->vcf.push_back(B5[refc(ee)]);
-                    if (j + 1 >= l) break;
-                    // cell at j+1: listed -> its cells, else unmutated
-                    if (ee + 1 < e1 && g.pos[ee + 1] - s0 == j + 1) {
-                        ++ee; ++j;
-                        const uint8_t a1 = cell(ee, 0), a2 = cell(ee, 1);
-                        const bool h2 = (a1 & BTMASK) == (a2 & BTMASK);
-                        if (!(h2 == hom && ((pl == 2 ? a2 : a1) & TMASK) == T_DEL)) break;
-                    } else break;
-                }
-                if (i > 0) appendf(c->vcf, "\t%c", B5[prevc(e)]); else c->vcf.append("\t.");
-                appendf(c->vcf, "\t100\tPASS\tAF=%s;pl=%d;mt=DELETE\n", hom ? "1.0" : "0.5", pl);
-            }
-        } else {
-            const int pl = hom ? 3 : (t1 == T_INS ? 1 : 2);
-            const char *seq = ins_text(g.ins[pl == 2 ? 1 : 0], g.pos[e], tmp);
-            appendf(c->txt, "-\t%s\t%d\n", seq, pl);
-            appendf(c->vcf, "%s\t%lld\t.\t%c\t%c%s\t100\tPASS\tAF=%s;pl=%d;mt=INSERT\n", nm, (long long)i + 1, B5[r0], B5[r0], seq, hom ? "1.0" : "0.5", pl);
-        }
-    }
+    format_mutations(ListView{g.pos.data(), g.cells.data(), g.pos.size(), g.ins}, m.name, m.start, m.l, c->txt, c->vcf);
     if (txt) *txt = c->txt.data();
     if (txt_len) *txt_len = c->txt.size();
     if (vcf) *vcf = c->vcf.data();
     if (vcf_len) *vcf_len = c->vcf.size();
     return DWGSIM_HIP_OK;
 }
+
+// The same in two halves, for callers that keep the device busy meanwhile (the job level): `take` fetches the group's list of mutated cells (device
+// work, on the calling thread) and hands it over as an object of its own; `mutlist_text` makes the text of one of the group's contigs from it --
+// no context, no device: any thread may call it while the context goes on with the group's reads.
+struct dwgsim_hip_mutlist {
+    std::vector<int32_t> pos; std::vector<uint32_t> cells; HostIns ins[2];
+    struct M { std::string name; int64_t l; int32_t start; };
+    std::vector<M> m;
+    std::string txt, vcf;
+};
+
+dwgsim_hip_mutlist_t *dwgsim_hip_mutations_take(dwgsim_hip_ctx_t *c, int contig, int *n_contigs)
+{
+    if (n_contigs) *n_contigs = 0;
+    if (!c) return nullptr;
+    Group *gp = get_group(c, contig);
+    if (!gp) return nullptr;
+    Group &g = *gp;
+    if (!g.mutated || g.walk_pending) { c->err = "mutate_contig must run first"; return nullptr; }
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "mutations_take: device error"; return nullptr; }
+    if (fetch_mutated_list(c, g)) return nullptr;
+    auto *L = new dwgsim_hip_mutlist();
+    L->pos.swap(g.pos); L->cells.swap(g.cells);
+    for (int h = 0; h < 2; ++h) { L->ins[h] = std::move(g.ins[h]); g.ins[h] = HostIns(); }
+    g.list_valid = false;      // (a later mutations_text for this group fetches it again)
+    for (const Member &m : g.m) L->m.push_back({m.name, m.l, m.start});
+    if (n_contigs) *n_contigs = (int)L->m.size();
+    return L;
+}
+
+int dwgsim_hip_mutlist_text(dwgsim_hip_mutlist_t *L, int k, const char **txt, size_t *txt_len, const char **vcf, size_t *vcf_len)
+{
+    if (!L || k < 0 || k >= (int)L->m.size()) return DWGSIM_HIP_ERR_ARG;
+    const auto &m = L->m[(size_t)k];
+    format_mutations(ListView{L->pos.data(), L->cells.data(), L->pos.size(), L->ins}, m.name, m.start, m.l, L->txt, L->vcf);
+    if (txt) *txt = L->txt.data();
+    if (txt_len) *txt_len = L->txt.size();
+    if (vcf) *vcf = L->vcf.data();
+    if (vcf_len) *vcf_len = L->vcf.size();
+    return DWGSIM_HIP_OK;
+}
+
+void dwgsim_hip_mutlist_free(dwgsim_hip_mutlist_t *L) { delete L; }
 
 // ---- read simulation ----
 // The ranges of one launch: all of one walked group, in file order.  ppb = pairs per block of the kernel that will run.

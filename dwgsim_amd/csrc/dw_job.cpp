@@ -117,7 +117,7 @@ struct dwgsim_hip_job {
     uint64_t delivered_pairs = 0; uint64_t total_rand = 0;
     // page-locked output buffers per device
     std::vector<std::vector<std::unique_ptr<PinBuf>>> bufs; std::vector<std::vector<PinBuf *>> free_bufs;
-    int max_bufs = 6;      // (three batches in flight per device + what the delivery threads hold)
+    int max_bufs = 8;      // (the batches in flight per device, one per output set of the context, + what the delivery threads hold)
 };
 
 namespace {
@@ -154,9 +154,48 @@ struct Worker {
     std::shared_ptr<GroupJob> prepped; int prepped_handle = -1;      // the group whose upload + walk is already enqueued
     bool prepped_waited = false, prepped_counted = false;           // ... whose walk has been waited for / whose random reads this device has counted already
     bool first_batch_of_job = true;
+    // The batches in flight, oldest first -- one per output set of the context, and they stay in flight ACROSS the end of a group: batch k is
+    // enqueued (kernels); then the copy-out of batch k-1 is issued as soon as its kernels are done (stage A); then the copy-out of the oldest batch
+    // is waited for and the batch published (stage B), which frees its slot for batch k+1.  With four slots two batches' copies are queued on the
+    // copy stream while the worker does anything else, so the link does not wait for the host.  Rounds 3-4: two slots, the copy of a batch
+    // issued only behind the enqueue of the next one (33 GB/s over a link that carries 54); round 5's first form: three slots, drained at every
+    // group's end, where the worker then made the next group's mutation text -- 25 to 50 ms per chromosome during which the copy engine stood still
+    // (profiles/r05_genome_trace.txt: busy 0.75).
+    struct Pending { int slot = 0, b = 0, h = -1; bool a_done = false, last_of_group = false; std::shared_ptr<GroupJob> g; dwgsim_hip_batch_t bt; BatchOut bo; };
+    std::deque<Pending> fl;
+    uint64_t kk = 0;      // batches enqueued so far (batch kk takes slot kk mod DWGSIM_HIP_SLOTS)
+    // (device 0) the mutation text: the worker only fetches a group's list of mutated cells; a thread of its own makes the text and hands it to the sink
+    struct MutTask { dwgsim_hip_mutlist_t *list; std::vector<std::string> names; };
+    std::thread mut_thread; std::mutex mm; std::condition_variable mcv; std::deque<MutTask> mq; bool mut_quit = false;
 
     bool ok() const { return !j->failed.load(); }
     void fail_ctx() { job_fail(j, std::string("dwgsim-hip: ") + dwgsim_hip_last_error(x)); }
+
+    void mut_loop()      // mut_print (mut.c:781-893), groups and contigs in order
+    {
+        for (;;) {
+            MutTask t;
+            {
+                std::unique_lock<std::mutex> lk(mm);
+                mcv.wait(lk, [&]() { return mut_quit || !mq.empty(); });
+                if (mq.empty()) return;
+                t = std::move(mq.front()); mq.pop_front();
+            }
+            for (size_t k = 0; k < t.names.size() && ok(); ++k) {
+                const char *tx, *v; size_t tl, vl;
+                if (dwgsim_hip_mutlist_text(t.list, (int)k, &tx, &tl, &v, &vl) < 0) { job_fail(j, "dwgsim-hip: the mutation text could not be made"); break; }
+                if (j->sink.mutations(j->sink.user, t.names[k].c_str(), tx, tl, v, vl) != 0) { job_fail(j, "dwgsim-hip: the sink refused the mutation text"); break; }
+            }
+            dwgsim_hip_mutlist_free(t.list);
+        }
+    }
+    void mut_stop()
+    {
+        if (!mut_thread.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mm); mut_quit = true; }
+        mcv.notify_all();
+        mut_thread.join();
+    }
 
     int prep(const std::shared_ptr<GroupJob> &g)      // upload (asynchronous: the staging is page-locked and in group layout) and enqueue the walk
     {
@@ -230,23 +269,97 @@ struct Worker {
         return b;
     }
 
+    // stage A: the batch's kernels are done -- its sizes are known: the copy-out is issued; the last batch of a group also gives the group's memory back
+    bool stage_a(Pending &pb)
+    {
+        if (pb.a_done) return true;
+        if (dwgsim_hip_wait(x, pb.slot, &pb.bt) < 0) { fail_ctx(); return false; }
+        pb.a_done = true;
+        pb.bo = BatchOut(); pb.bo.lane = d; pb.bo.pairs = pb.bt.n_pairs;
+        if (j->sink.reads) {
+            PinBuf *tb = acquire(j->gzip ? pb.bt.gz_bytes : pb.bt.bytes);
+            if (!tb) return false;
+            pb.bo.buf = tb;
+            for (int s = 0; s < 3; ++s) {
+                pb.bo.n[s] = j->gzip ? pb.bt.gz_bytes[s] : pb.bt.bytes[s]; pb.bo.text_n[s] = pb.bt.bytes[s];
+                if (pb.bo.n[s] && (j->gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail_ctx(); return false; }
+                if (pb.bo.n[s]) ++pb.bo.left;
+            }
+        }
+        if (pb.last_of_group && dwgsim_hip_drop_contig(x, pb.h) < 0) { fail_ctx(); return false; }      // (the kernels of the group's last batch are done: nothing reads it any more)
+        return true;
+    }
+    // stage B: the copy-out has landed: the batch is published (the delivery threads hand it to the sink in file order, behind the abort rule's verdict)
+    bool stage_b(Pending &pb)
+    {
+        if (j->sink.reads && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
+        const dwgsim_hip_batch_t &bt = pb.bt; BatchOut &bo = pb.bo; GroupJob *g = pb.g.get();
+        uint64_t shown = 0; bool aborted = false;
+        {
+            std::lock_guard<std::mutex> lk(j->m);
+            for (int q = 0; q < 4; ++q) g->fail_seg[(size_t)pb.b][(size_t)q] = bt.fail_seg[q];
+            g->got_rand[(size_t)pb.b] = bt.n_random;
+            bo.ready = true;
+            if (bo.left == 0 && bo.buf) { j->free_bufs[(size_t)d].push_back(bo.buf); bo.buf = nullptr; }
+            g->out[(size_t)pb.b] = bo;
+            ++g->batches_done;
+            // the abort rule (dwgsim.c:635, :833-843) over the batches of several devices: the summaries are joined in read-index order as soon
+            // as the batches in front are complete -- a batch goes to the sink only behind its verdict (deliver_loop waits for `joined`)
+            while (!aborted && g->joined < (int)g->out.size() && g->out[(size_t)g->joined].ready) {
+                if (dwgsim_hip_failseg_join(g->fail_acc, g->fail_seg[(size_t)g->joined].data())) aborted = true; else ++g->joined;
+            }
+            shown = (j->delivered_pairs += bt.n_pairs);
+            j->cv.notify_all();
+        }
+        if (aborted) { job_fail(j, "\r[dwgsim_core] failed to generate a read after 10001 trials\n"); return false; }
+        if (!j->opt.quiet) { char t[64]; snprintf(t, sizeof t, "\r[dwgsim_core] %llu", (unsigned long long)shown); if (j->sink.message) j->sink.message(j->sink.user, t); else fputs(t, stderr); }      // (outside the lock: a sink may call back into the job)
+        return true;
+    }
+    // everything in flight goes through both stages (before the worker waits for anything another thread can only provide once these batches are published)
+    bool drain()
+    {
+        while (!fl.empty()) {
+            for (auto &pb : fl) if (!stage_a(pb)) return false;
+            if (!stage_b(fl.front())) return false;
+            fl.pop_front();
+        }
+        return true;
+    }
+    // the job has failed: leave the context idle -- kernels and copies of whatever is in flight are waited for, nothing more is published
+    void abandon()
+    {
+        for (auto &pb : fl) { if (!pb.a_done) { dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, pb.slot, &bt); } (void)dwgsim_hip_fetch_wait(x, pb.slot); }
+        fl.clear();
+    }
+
     void run()
     {
         pin_thread_to_device_node(j->devices[(size_t)d]);
+        if (d == 0 && j->want_mut && j->sink.mutations) mut_thread = std::thread([this]() { mut_loop(); });
+        bool fine = true;
         for (;;) {
             std::shared_ptr<GroupJob> g;
             {
                 std::unique_lock<std::mutex> lk(j->m);
                 const int want = j->next_group[(size_t)d];
-                j->cv.wait(lk, [&]() { return j->failed.load() || group_by_id(j, want) || (j->no_more && want >= j->n_dispatched); });
-                if (j->failed.load()) break;
+                auto there = [&]() { return j->failed.load() || group_by_id(j, want) || (j->no_more && want >= j->n_dispatched); };
+                if (!there() && !fl.empty()) {      // the next group may only be handed over once the one in front has retired -- which takes the batches still in flight here
+                    lk.unlock();
+                    if (!drain()) { fine = false; break; }
+                    lk.lock();
+                }
+                j->cv.wait(lk, there);
+                if (j->failed.load()) { fine = false; break; }
                 g = group_by_id(j, want);
                 if (!g) break;
                 j->next_group[(size_t)d] = want + 1;
             }
-            if (!process(g)) break;
+            if (!process(g)) { fine = false; break; }
         }
+        if (fine && ok()) fine = drain();
+        if (!fine || !ok()) abandon();
         if (prepped) { if (!prepped_waited) (void)dwgsim_hip_mutate_wait(x, prepped_handle); prepped.reset(); }
+        mut_stop();
     }
 
     bool takes_part(const GroupJob &g) const { return d == 0 || (j->want_reads && d < g.nd); }      // device 0 also writes the mutation text
@@ -263,12 +376,12 @@ struct Worker {
         if (prepped && prepped->id == g->id) { h = prepped_handle; waited = prepped_waited; counted = prepped_counted; prepped.reset(); }
         else if ((h = prep(g)) < 0) return false;
         if (!waited && !walked(g, h)) return false;
-        if (d == 0 && j->want_mut && j->sink.mutations) {      // mut_print (mut.c:781-893), contigs in order
-            for (size_t k = 0; k < g->names.size() && ok(); ++k) {
-                const char *t, *v; size_t tl, vl;
-                if (dwgsim_hip_mutations_text(x, h + (int)k, &t, &tl, &v, &vl) < 0) { fail_ctx(); return false; }
-                if (j->sink.mutations(j->sink.user, g->names[k].c_str(), t, tl, v, vl) != 0) { job_fail(j, "dwgsim-hip: the sink refused the mutation text"); return false; }
-            }
+        if (mut_thread.joinable()) {      // the group's list of mutated cells goes to the text thread (a few MB; the device part takes well under a millisecond)
+            int n = 0;
+            dwgsim_hip_mutlist_t *L = dwgsim_hip_mutations_take(x, h, &n);
+            if (!L) { fail_ctx(); return false; }
+            { std::lock_guard<std::mutex> lk(mm); mq.push_back(MutTask{L, g->names}); }
+            mcv.notify_all();
         }
         const int nb = (int)g->batches.size();
         std::vector<int> mine;
@@ -277,7 +390,13 @@ struct Worker {
         if (j->ND > 1 && j->want_reads) {
             if (!counted && !count_mine(g, h)) return false;
             std::unique_lock<std::mutex> lk(j->m);
-            j->cv.wait(lk, [&]() { return j->failed.load() || (g->counted >= g->nd && g->base_known); });
+            auto counts_in = [&]() { return j->failed.load() || (g->counted >= g->nd && g->base_known); };
+            if (!counts_in() && !fl.empty()) {      // another device may be waiting for page-locked buffers that only come back once the batches in flight here are published
+                lk.unlock();
+                if (!drain()) return false;
+                lk.lock();
+            }
+            j->cv.wait(lk, counts_in);
             if (j->failed.load()) return false;
             if (g->counted == g->nd) {      // (every device computes the same thing; the first one publishes it for the next group)
                 uint64_t tot = g->rand_base;
@@ -287,86 +406,29 @@ struct Worker {
                 j->total_rand = tot;
             }
         }
+        if (mine.empty()) {      // nothing to simulate here (device 0 of a small group, or -o 2): the group's memory goes back at once
+            if (dwgsim_hip_drop_contig(x, h) < 0) { fail_ctx(); return false; }
+            return look_ahead(g);
+        }
         // the next group, if it is already here, is uploaded and walked on the walk stream while this one's batches run
         if (!look_ahead(g)) return false;
-        // batches: THREE in flight, one per slot of the context -- batch k is enqueued (kernels), then the copy-out of batch k-1 is issued as soon as its
-        // kernels are done (stage A), then the copy-out of batch k-2 is waited for and the batch published (stage B).  The copy of k-1 is queued on the
-        // copy stream while that of k-2 is still landing, so the link never waits for the host; with two slots (rounds 3-4) the copy of a batch was issued
-        // only behind the enqueue of the next one -- 15 host calls during which the copy engine stood still (the whole-genome job moved 33 GB/s over a
-        // link that carries 50).
-        struct Pending { bool live = false; int slot = 0, b = 0; dwgsim_hip_batch_t bt; BatchOut bo; };
-        Pending q1, q2;      // q1: enqueued, stage A to come; q2: stage A done, stage B to come
-        auto stage_a = [&](Pending &pb) -> bool {
-            if (!pb.live) return true;
-            if (dwgsim_hip_wait(x, pb.slot, &pb.bt) < 0) { fail_ctx(); return false; }
-            pb.bo = BatchOut(); pb.bo.lane = d; pb.bo.pairs = pb.bt.n_pairs;
-            if (j->sink.reads) {
-                PinBuf *tb = acquire(j->gzip ? pb.bt.gz_bytes : pb.bt.bytes);
-                if (!tb) return false;
-                pb.bo.buf = tb;
-                for (int s = 0; s < 3; ++s) {
-                    pb.bo.n[s] = j->gzip ? pb.bt.gz_bytes[s] : pb.bt.bytes[s]; pb.bo.text_n[s] = pb.bt.bytes[s];
-                    if (pb.bo.n[s] && (j->gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail_ctx(); return false; }
-                    if (pb.bo.n[s]) ++pb.bo.left;
-                }
-            }
-            return true;
-        };
-        auto stage_b = [&](Pending &pb) -> bool {
-            if (!pb.live) return true;
-            pb.live = false;
-            if (j->sink.reads && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
-            const dwgsim_hip_batch_t &bt = pb.bt; BatchOut &bo = pb.bo;
-            uint64_t shown = 0; bool aborted = false;
-            {
-                std::lock_guard<std::mutex> lk(j->m);
-                for (int q = 0; q < 4; ++q) g->fail_seg[(size_t)pb.b][(size_t)q] = bt.fail_seg[q];
-                g->got_rand[(size_t)pb.b] = bt.n_random;
-                bo.ready = true;
-                if (bo.left == 0 && bo.buf) { j->free_bufs[(size_t)d].push_back(bo.buf); bo.buf = nullptr; }
-                g->out[(size_t)pb.b] = bo;
-                ++g->batches_done;
-                // the abort rule (dwgsim.c:635, :833-843) over the batches of several devices: the summaries are joined in read-index order as soon
-                // as the batches in front are complete -- a batch goes to the sink only behind its verdict (deliver_loop waits for `joined`)
-                while (!aborted && g->joined < (int)g->out.size() && g->out[(size_t)g->joined].ready) {
-                    if (dwgsim_hip_failseg_join(g->fail_acc, g->fail_seg[(size_t)g->joined].data())) aborted = true; else ++g->joined;
-                }
-                shown = (j->delivered_pairs += bt.n_pairs);
-                j->cv.notify_all();
-            }
-            if (aborted) { job_fail(j, "\r[dwgsim_core] failed to generate a read after 10001 trials\n"); return false; }
-            if (!j->opt.quiet) { char t[64]; snprintf(t, sizeof t, "\r[dwgsim_core] %llu", (unsigned long long)shown); if (j->sink.message) j->sink.message(j->sink.user, t); else fputs(t, stderr); }      // (outside the lock: a sink may call back into the job)
-            return true;
-        };
-        int kk = 0; bool fine = true;
-        for (int b : mine) {
-            if (!ok()) { fine = false; break; }
+        for (size_t q = 0; q < mine.size(); ++q) {
+            const int b = mine[q];
+            if (!ok()) return false;
             uint64_t rbase;
-            if (j->ND > 1) { rbase = g->rand_base; for (int q = 0; q < b; ++q) rbase += g->batch_rand[(size_t)q]; }      // (batch_rand is final: all devices have published)
+            if (j->ND > 1) { rbase = g->rand_base; for (int t = 0; t < b; ++t) rbase += g->batch_rand[(size_t)t]; }      // (batch_rand is final: all devices have published)
             else { rbase = first_batch_of_job ? 0 : DWGSIM_HIP_RAND_CHAIN; first_batch_of_job = false; }
             const auto r = ranges_of(b);
-            const int slot = kk % DWGSIM_HIP_SLOTS;      // (the slot's previous batch, kk - 3, went through stage B in the iteration before)
-            if (dwgsim_hip_simulate_ranges_async(x, r.data(), (int)r.size(), rbase, slot) < 0) { fail_ctx(); fine = false; break; }
-            Pending cur; cur.live = true; cur.slot = slot; cur.b = b;
-            const bool a_ok = stage_a(q1), b_ok = a_ok && stage_b(q2);
-            if (!a_ok || !b_ok) {      // the job has failed: what is in flight is only waited for (below)
-                if (a_ok) { q2 = q1; q1 = cur; } else { Pending lost = cur; dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, lost.slot, &bt); }
-                fine = false; break;
-            }
-            q2 = q1; q1 = cur;
+            const int slot = (int)(kk % DWGSIM_HIP_SLOTS);      // (free: at most DWGSIM_HIP_SLOTS - 1 batches are in flight here)
+            if (dwgsim_hip_simulate_ranges_async(x, r.data(), (int)r.size(), rbase, slot) < 0) { fail_ctx(); return false; }
             ++kk;
-            if (!look_ahead(g)) { fine = false; break; }
+            fl.emplace_back();
+            Pending &cur = fl.back(); cur.slot = slot; cur.b = b; cur.h = h; cur.g = g; cur.last_of_group = q + 1 == mine.size();
+            for (size_t t = 0; t + 1 < fl.size(); ++t) if (!stage_a(fl[t])) return false;
+            while ((int)fl.size() >= DWGSIM_HIP_SLOTS) { if (!stage_b(fl.front())) return false; fl.pop_front(); }
+            if (!look_ahead(g)) return false;
         }
-        if (fine && ok()) fine = stage_a(q1) && stage_b(q2) && (q2 = q1, q1.live = false, stage_b(q2));
-        else fine = false;
-        if (!fine) {      // leave the context idle: kernels and copies of whatever was in flight are waited for, nothing more is published
-            if (q1.live) { dwgsim_hip_batch_t bt; (void)dwgsim_hip_wait(x, q1.slot, &bt); (void)dwgsim_hip_fetch_wait(x, q1.slot); }
-            if (q2.live) (void)dwgsim_hip_fetch_wait(x, q2.slot);
-            return false;
-        }
-        if (!ok()) return false;
-        if (dwgsim_hip_drop_contig(x, h) < 0) { fail_ctx(); return false; }
-        return true;
+        return ok();
     }
 };
 

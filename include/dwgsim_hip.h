@@ -33,7 +33,7 @@ extern "C" {
 #define DWGSIM_HIP_ERR_NOMEM    -3
 #define DWGSIM_HIP_ERR_UNSUP    -4   /* option outside the accelerated path (see DESIGN.md "out of scope") */
 #define DWGSIM_HIP_ERR_FAILED   -5   /* "failed to generate a read after %d trials" (dwgsim.c:837-840) */
-#define DWGSIM_HIP_SLOTS 3          /* output sets of a context: batches that can be in flight (kernels | copy-out issued | copy-out landing) */
+#define DWGSIM_HIP_SLOTS 4          /* output sets of a context: batches that can be in flight (kernels | copy-out issued, twice | copy-out landing) */
 #define DWGSIM_HIP_ERR_STATE    -6   /* call order violated (e.g. simulate before mutate) */
 
 /* Why dwgsim_core() passes over a contig (dwgsim.c:539-625, the "[dwgsim_core] #k skip sequence" notes): returned in place of a pair count by
@@ -186,6 +186,15 @@ int dwgsim_hip_mutate_poll(dwgsim_hip_ctx_t *ctx, int contig);
  * contig.  Buffers are owned by the context and valid until the next call for any contig. */
 int dwgsim_hip_mutations_text(dwgsim_hip_ctx_t *ctx, int contig, const char **txt, size_t *txt_len,
                               const char **vcf, size_t *vcf_len);
+/* mut_print() in two halves, for a caller that keeps the device busy meanwhile (the job level does): `take` fetches the list of mutated cells of
+ * the contig's whole GROUP (device work, on the calling thread) and returns it as an object of its own (NULL: see last_error; *n_contigs =
+ * contigs of the group, in the order they were added); `mutlist_text` makes the mutations.txt / .vcf body lines of the group's k-th contig
+ * from it -- it touches neither the context nor the device, so any thread may call it while the context simulates the group's reads.  The
+ * buffers belong to the list and are valid until the next call on the same list. */
+typedef struct dwgsim_hip_mutlist dwgsim_hip_mutlist_t;
+dwgsim_hip_mutlist_t *dwgsim_hip_mutations_take(dwgsim_hip_ctx_t *ctx, int contig, int *n_contigs);
+int dwgsim_hip_mutlist_text(dwgsim_hip_mutlist_t *list, int k, const char **txt, size_t *txt_len, const char **vcf, size_t *vcf_len);
+void dwgsim_hip_mutlist_free(dwgsim_hip_mutlist_t *list);
 
 /* Number of random reads among pairs [first_ii, first_ii + n_pairs) of the contig (for sharding:
  * rand_ii is a running count over all earlier pairs, dwgsim.c:1042,1096). */

@@ -38,7 +38,7 @@ def compare_case(lib, oracle_bin, fasta, flags, batch_pairs=1 << 22, debug_optio
         want = run_oracle(oracle_bin, fasta, flags, t)
     params = api.parse_flags(flags, lib)
     contigs = api.read_fasta(fasta)
-    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib, debug_options=debug_options, group_bp=group_bp)
+    res = api.run_job(params, contigs, batch_pairs=batch_pairs, lib=lib, debug_options=debug_options, group_bp=group_bp, check_list_form=True)
     assert res.mutations_txt == want["txt"], "mutations.txt: " + first_diff(res.mutations_txt, want["txt"])
     assert res.mutations_vcf == want["vcf"], "mutations.vcf: " + first_diff(res.mutations_vcf, want["vcf"])
     for k in STREAMS:

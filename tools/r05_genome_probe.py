@@ -36,7 +36,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
             run(env, v)
     if os.environ.get("PROBE_TRACE", "1") == "1":
         out = os.path.join(ROOT, "gpurun_out", "genome_trace"); os.makedirs(out, exist_ok=True)
-        env = {}
+        env = {"DWGSIM_HIP_TEARDOWN": "1"}      # (the product leaves through _exit: the profiler writes its database in an exit handler)
         tv = os.environ.get("PROBE_TRACE_VARIANT", "default")
         if tv != "default":
             for kv in tv.split(","):

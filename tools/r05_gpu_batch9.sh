@@ -2,4 +2,4 @@
 # tools/r05_gpu_batch9.sh -- analysis only (gpurun): the whole-genome product run: batch sizes, and a copy / kernel trace of one run
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/b9
-PROBE_VARIANTS="default;DWGSIM_HIP_BATCH=524288;DWGSIM_HIP_BATCH=1048576;DWGSIM_HIP_GROUP_BP=268435456" timeout 1500 python tools/r05_genome_probe.py 2>&1 | tee gpurun_out/b9/probe.txt
+PROBE_VARIANTS="${PROBE_VARIANTS-default}" timeout 1500 python tools/r05_genome_probe.py 2>&1 | tee gpurun_out/b9/probe.txt
