@@ -20,6 +20,10 @@
 #include <limits.h>
 #include <ctype.h>
 #include <stdarg.h>
+#include <stdint.h>
+#include <sys/mman.h>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -604,8 +608,10 @@ int dwgsim_hip_get_params(const dwgsim_hip_ctx_t *c, dwgsim_hip_params_t *out)
     return DWGSIM_HIP_OK;
 }
 
+static bool in_host_registry(const void *p);
 static bool is_page_locked(const void *p)
 {
+    if (in_host_registry(p)) return true;      // (dwgsim_hip_host_alloc)
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return true;
     (void)hipGetLastError();      // pageable memory: the query reports an error that must not stick
@@ -1666,13 +1672,57 @@ int dwgsim_hip_simulate(dwgsim_hip_ctx_t *c, int contig, uint64_t first_ii, uint
     return dwgsim_hip_wait(c, slot, out);
 }
 
+// Page-locked host memory: anonymous memory on TRANSPARENT HUGE PAGES, touched by the calling thread(s) (so it lies on their NUMA node) and then registered
+// with the runtime.  Page-locking is paid per page: hipHostMalloc locks 4 KB pages at 5-6 GB/s -- 60-85 ms for the 300 MB staging of a chromosome, on
+// the critical path of a job's first batch, and the KFD's per-process lock makes every other allocation of the process wait meanwhile -- while 2 MB
+// pages register at 17-55 GB/s (tools/ubench_pin.hip, profiles/r05_genome_trace.txt); copies into either run at the same 49-50 GB/s.  Where the kernel
+// grants no huge pages (transparent_hugepage = never) the same code simply registers 4 KB pages.
+namespace {
+struct HostRegion { uint8_t *base; size_t len; };
+std::mutex g_host_m;
+std::vector<HostRegion> g_host;      // (a handful per process)
+}
+static bool in_host_registry(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_host_m);
+    for (const HostRegion &r : g_host) if ((const uint8_t *)p >= r.base && (const uint8_t *)p < r.base + r.len) return true;
+    return false;
+}
 void *dwgsim_hip_host_alloc(size_t bytes)
 {
-    void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const size_t H = (size_t)2 << 20;
+    const size_t len = ((bytes ? bytes : 1) + H - 1) / H * H;
+    uint8_t *raw = (uint8_t *)mmap(nullptr, len + H, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (raw == MAP_FAILED) return nullptr;
+    uint8_t *p = (uint8_t *)(((uintptr_t)raw + H - 1) & ~(uintptr_t)(H - 1));
+    if (p > raw) munmap(raw, (size_t)(p - raw));
+    if (p + len < raw + len + H) munmap(p + len, (size_t)(raw + len + H - (p + len)));
+    (void)madvise(p, len, MADV_HUGEPAGE);
+    // first touch (a fault per huge page zeroes 2 MB): large buffers by a few threads at once
+    auto touch = [p](size_t from, size_t upto) { for (size_t o = from; o < upto; o += 4096) ((volatile uint8_t *)p)[o] = 0; };
+    const int nt = len >= ((size_t)64 << 20) ? 4 : 1;
+    if (nt == 1) touch(0, len);
+    else {
+        std::vector<std::thread> th; const size_t per = (len / H + (size_t)nt - 1) / (size_t)nt * H;
+        for (int k = 0; k < nt; ++k) { const size_t a = std::min(len, (size_t)k * per), b = std::min(len, a + per); if (b > a) th.emplace_back(touch, a, b); }
+        for (auto &t : th) t.join();
+    }
+    if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); munmap(p, len); return nullptr; }
+    { std::lock_guard<std::mutex> lk(g_host_m); g_host.push_back(HostRegion{p, len}); }
     return p;
 }
-void dwgsim_hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+void dwgsim_hip_host_free(void *p)
+{
+    if (!p) return;
+    HostRegion r{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_host_m);
+        for (size_t i = 0; i < g_host.size(); ++i) if (g_host[i].base == (uint8_t *)p) { r = g_host[i]; g_host.erase(g_host.begin() + (long)i); break; }
+    }
+    if (!r.base) return;      // (not one of ours)
+    (void)hipHostUnregister(r.base);
+    munmap(r.base, r.len);
+}
 
 // Copies on the context's second stream: a batch that is being copied out of one slot overlaps with the kernels filling the other.
 int dwgsim_hip_fetch_async(dwgsim_hip_ctx_t *c, int slot, int stream, void *host_dst, size_t cap)

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <stdarg.h>
+#include <time.h>
 #include <limits.h>
 #include <algorithm>
 #include <string>
@@ -101,8 +102,8 @@ struct dwgsim_hip_job {
     uint64_t tot_len = 0; int n_ref = 0; int64_t n_sim = 0; int prev_skip = 0; uint32_t next_index = 0;
     std::string regions_path, mutin_path; int mutin_type = -1;
     // staging of the sequence: page-locked buffers handed from the adding thread to the device workers
-    static constexpr int N_STAGE = 3;
-    uint8_t *stage[N_STAGE] = {nullptr, nullptr, nullptr}; size_t stage_cap[N_STAGE] = {0, 0, 0}; bool stage_busy[N_STAGE] = {false, false, false};
+    static constexpr int N_STAGE = 2;      // (one being filled while the other's group is uploaded and walked; a third bought nothing and is 0.25 GB of page-locked memory for a genome)
+    uint8_t *stage[N_STAGE] = {nullptr, nullptr}; size_t stage_cap[N_STAGE] = {0, 0}; bool stage_busy[N_STAGE] = {false, false};
     size_t stage_want = 0;        // from the contig table: room for the largest group, so that a staging buffer is page-locked once
     std::shared_ptr<GroupJob> pending; size_t pending_bytes = 0;           // the group being filled
     struct Open { bool open = false; std::string name; int64_t l = 0, st = 0, total = 0; uint32_t ci = 0; } open;      // the contig between begin_contig and commit_contig
@@ -117,10 +118,15 @@ struct dwgsim_hip_job {
     uint64_t delivered_pairs = 0; uint64_t total_rand = 0;
     // page-locked output buffers per device
     std::vector<std::vector<std::unique_ptr<PinBuf>>> bufs; std::vector<std::vector<PinBuf *>> free_bufs;
+    bool tracing = false; double t0 = 0;
     int max_bufs = 8;      // (the batches in flight per device, one per output set of the context, + what the delivery threads hold)
 };
 
 namespace {
+
+// DWGSIM_HIP_TRACE=1 (analysis): when the job's stages happen, in seconds since the job was created, on stderr
+double mono_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+void trace(dwgsim_hip_job *j, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 void job_fail(dwgsim_hip_job *j, const std::string &what)
 {
@@ -140,6 +146,13 @@ void say(dwgsim_hip_job *j, const char *fmt, ...)
 {
     char b[4608]; va_list ap; va_start(ap, fmt); vsnprintf(b, sizeof b, fmt, ap); va_end(ap);
     if (j->sink.message) j->sink.message(j->sink.user, b); else if (!j->opt.quiet) fputs(b, stderr);
+}
+
+void trace(dwgsim_hip_job *j, const char *fmt, ...)
+{
+    if (!j->tracing) return;
+    char b[256]; va_list ap; va_start(ap, fmt); vsnprintf(b, sizeof b, fmt, ap); va_end(ap);
+    fprintf(stderr, "[trace %8.4f] %s\n", mono_s() - j->t0, b);
 }
 
 std::shared_ptr<GroupJob> group_by_id(dwgsim_hip_job *j, int id)      // j->m held
@@ -286,6 +299,7 @@ struct Worker {
                 if (pb.bo.n[s]) ++pb.bo.left;
             }
         }
+        if (pb.b < 2 * j->ND) trace(j, "dev %d group %d: batch %d kernels done, copy issued (%.1f MB)", d, pb.g->id, pb.b, (pb.bo.n[0] + pb.bo.n[1] + pb.bo.n[2]) / 1e6);
         if (pb.last_of_group && dwgsim_hip_drop_contig(x, pb.h) < 0) { fail_ctx(); return false; }      // (the kernels of the group's last batch are done: nothing reads it any more)
         return true;
     }
@@ -293,6 +307,7 @@ struct Worker {
     bool stage_b(Pending &pb)
     {
         if (j->sink.reads && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
+        if (pb.b < 2 * j->ND) trace(j, "dev %d group %d: batch %d landed", d, pb.g->id, pb.b);
         const dwgsim_hip_batch_t &bt = pb.bt; BatchOut &bo = pb.bo; GroupJob *g = pb.g.get();
         uint64_t shown = 0; bool aborted = false;
         {
@@ -374,14 +389,16 @@ struct Worker {
         }
         int h; bool waited = false, counted = false;
         if (prepped && prepped->id == g->id) { h = prepped_handle; waited = prepped_waited; counted = prepped_counted; prepped.reset(); }
-        else if ((h = prep(g)) < 0) return false;
+        else { trace(j, "dev %d group %d: prep", d, g->id); if ((h = prep(g)) < 0) return false; trace(j, "dev %d group %d: upload + walk enqueued", d, g->id); }
         if (!waited && !walked(g, h)) return false;
+        trace(j, "dev %d group %d: walked", d, g->id);
         if (mut_thread.joinable()) {      // the group's list of mutated cells goes to the text thread (a few MB; the device part takes well under a millisecond)
             int n = 0;
             dwgsim_hip_mutlist_t *L = dwgsim_hip_mutations_take(x, h, &n);
             if (!L) { fail_ctx(); return false; }
             { std::lock_guard<std::mutex> lk(mm); mq.push_back(MutTask{L, g->names}); }
             mcv.notify_all();
+            trace(j, "dev %d group %d: mutation list taken", d, g->id);
         }
         const int nb = (int)g->batches.size();
         std::vector<int> mine;
@@ -421,6 +438,7 @@ struct Worker {
             const auto r = ranges_of(b);
             const int slot = (int)(kk % DWGSIM_HIP_SLOTS);      // (free: at most DWGSIM_HIP_SLOTS - 1 batches are in flight here)
             if (dwgsim_hip_simulate_ranges_async(x, r.data(), (int)r.size(), rbase, slot) < 0) { fail_ctx(); return false; }
+            if (q < 3 || q + 1 == mine.size()) trace(j, "dev %d group %d: batch %d enqueued", d, g->id, b);
             ++kk;
             fl.emplace_back();
             Pending &cur = fl.back(); cur.slot = slot; cur.b = b; cur.h = h; cur.g = g; cur.last_of_group = q + 1 == mine.size();
@@ -530,6 +548,7 @@ int dispatch_pending(dwgsim_hip_job *j)
     else { g->rand_base = j->total_rand; g->base_known = true; }      // the group in front has been retired already: its total is final
     j->groups.push_back(g);
     j->cv.notify_all();
+    trace(j, "group %d dispatched (%zu contigs, %llu pairs, %zu batches)", g->id, g->names.size(), (unsigned long long)g->pairs, g->batches.size());
     return DWGSIM_HIP_OK;
 }
 
@@ -569,6 +588,7 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
     else devs.assign(devices, devices + n_devices);
     if (devs.empty()) { fprintf(stderr, "dwgsim-hip: no usable HIP device; the hot path has no CPU fallback\n"); return bad(DWGSIM_HIP_ERR_DEVICE); }
     auto *j = new dwgsim_hip_job();
+    j->tracing = getenv("DWGSIM_HIP_TRACE") != nullptr; j->t0 = mono_s();
     j->prm = *p;
     if (p->read_prefix) { j->prefix = p->read_prefix; j->prm.read_prefix = j->prefix.c_str(); }
     if (p->flow_order) { j->flow = p->flow_order; j->prm.flow_order = j->flow.c_str(); }
@@ -604,6 +624,7 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
     }
     j->next_group.assign((size_t)j->ND, 0);
     j->bufs.resize((size_t)j->ND); j->free_bufs.resize((size_t)j->ND);
+    trace(j, "contexts made");
     if (err) *err = DWGSIM_HIP_OK;
     return j;
 }
@@ -671,8 +692,11 @@ uint8_t *dwgsim_hip_job_begin_contig(dwgsim_hip_job_t *j, const char *name, int6
     const int64_t total = dwgsim_hip_group_layout(lens.data(), (int)lens.size(), starts.data());
     const int s = g.stage_slot;
     if (!j->stage[s] || (size_t)total > j->stage_cap[s]) {      // grow, keeping what the group already holds (an empty record that opens a group on a fresh slot still needs somewhere to point)
-        const size_t want = std::max<size_t>((size_t)total + (size_t)total / 4, std::max<size_t>(j->stage_want, (size_t)std::min<uint64_t>(j->group_bp, 256u << 20) + 8192));
+        // (the contig table says how large a group can get: exactly that much; a table that understated the lengths -- a stale .fai -- grows by a quarter)
+        const size_t want = (size_t)total <= j->stage_want ? j->stage_want : std::max<size_t>((size_t)total + (size_t)total / 4, (size_t)std::min<uint64_t>(j->group_bp, 256u << 20) + 8192);
+        trace(j, "staging %d: page-locking %.0f MB", s, want / 1e6);
         uint8_t *nb = (uint8_t *)dwgsim_hip_host_alloc(want);
+        trace(j, "staging %d: done", s);
         if (!nb) { job_fail(j, "dwgsim-hip: cannot allocate page-locked host memory for the sequence"); return out(DWGSIM_HIP_ERR_NOMEM); }
         if (j->stage[s] && j->pending_bytes) memcpy(nb, j->stage[s], j->pending_bytes);
         dwgsim_hip_host_free(j->stage[s]);

@@ -122,6 +122,9 @@ static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256,
 static inline hipError_t hipFree(void *p) { free(p); return 0; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? 0 : 2; }
 static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
+#define hipHostRegisterDefault 0
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return 0; }
+static inline hipError_t hipHostUnregister(void *) { return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }

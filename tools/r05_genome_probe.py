@@ -26,6 +26,12 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         r = subprocess.run(list(prefix) + [exe] + flags.split() + [fa, os.path.join(t, "out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
         dt = time.time() - t0
         st = [ln for ln in r.stderr.decode(errors="replace").splitlines() if ln.startswith("[dwgsim-hip]")]
+        ck = [ln for ln in r.stderr.decode(errors="replace").splitlines() if ln.startswith("[dwgsim-hip-clock]")]
+        if ck:
+            import re; a, b = (float(v) for v in re.findall(r"at ([0-9.]+)", ck[-1])[:2])
+            print(f"    exec -> main {a - t0:.3f} s | main {b - a:.3f} s | output complete -> process gone {t0 + dt - b:.3f} s")
+        if env.get("DWGSIM_HIP_TRACE"):
+            print("\n".join(ln for ln in r.stderr.decode(errors="replace").splitlines() if ln.startswith("[trace")))
         print(f"{label:40s} wall {dt:.2f} s  rc {r.returncode}  {st[-1][13:] if st else r.stderr.decode(errors='replace')[-300:]}", flush=True)
     for v in variants:
         env = {}
