@@ -449,6 +449,13 @@ def main():
     # the fixed whole-genome job of BASELINE configs[3] split over the ranks, beside the (weak) line: the `strong` object of the line.  Whole-genome
     # groups (two of them: a group holds < 2^31 cells), three timed steps
     strong = None
+    landed = {}
+    if world == 1 and not args.no_legs:      # (the legs that need the resident contig: before the context makes room for the whole-genome job)
+        g0 = max(groups, key=lambda g: g["pairs"])
+        cid0, n0 = max(g0["members"], key=lambda mm: mm[1])          # the contig with the most pairs
+        ctx.mutate(cid0)
+        landed["host_landed"] = host_landed_leg(api, ctx, cid0, n0)
+        landed["host_landed_gz"] = host_landed_leg(api, ctx, cid0, n0, gz=True)
     if args.strong_leg and not args.ion and args.flags is None and not (args.workload == "grch38" and args.mode == "strong"):
         ctx.close(); ctx = None; m["ctx"] = None
         ms = measure("grch38", "strong", FLAGS, 3, 1, STRONG_GROUP_BP)
@@ -518,13 +525,9 @@ def main():
             out["roofline"]["counters_note"] = prof_note
         if strong:
             out["strong"] = strong
-        if world == 1 and not args.no_legs:
-            g0 = max(groups, key=lambda g: g["pairs"])
-            cid0, n0 = max(g0["members"], key=lambda m: m[1])          # the contig with the most pairs
-            ctx.mutate(cid0)
-            out["host_landed"] = host_landed_leg(api, ctx, cid0, n0)
-            out["host_landed_gz"] = host_landed_leg(api, ctx, cid0, n0, gz=True)
-        ctx.close(); ctx = None
+        out.update(landed)
+        if ctx is not None:
+            ctx.close(); ctx = None
         small = [(name, arr) for name, arr, _, _ in job]
         if world == 1 and not args.no_legs and args.workload in ("ecoli", "chr20"):
             out["end_to_end"] = end_to_end_leg(small, flags, job_pairs)

@@ -1356,7 +1356,7 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     a.cap = lmax;
     if (p.data_type == 2) {        // room for flow-space insertions: ~2.4 empty flows per base, each inserting with probability e, plus cascades
         const double emax = p.e_start[0] > p.e_start[1] ? p.e_start[0] : p.e_start[1];
-        a.cap = (c->flow_cap_forced > 0 ? c->flow_cap_forced : flow_read_capacity(lmax, emax, c->flow)) * c->flow_cap_mult;
+        a.cap = (c->flow_cap_forced > 0 ? std::max(c->flow_cap_forced, lmax) : flow_read_capacity(lmax, emax, c->flow)) * c->flow_cap_mult;      // (the read as extracted must fit: a forced capacity is a test's starting point, never below the read length)
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
@@ -1533,6 +1533,11 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
                                    : sim_blocks_per_cu(sim_lds_bytes(0, SIM_THREADS_LONG, (size_t)a.qb_words, true), 32);       // (one-wave blocks: up to eight per SIMD)
             a.flow_slots = c->flow_slots > 0 ? c->flow_slots : cu_per_xcd * per_cu;
             if ((uint64_t)a.flow_slots > (uint64_t)nblk) a.flow_slots = (int32_t)nblk;
+            if (ion) {      // reads that have grown far beyond their estimate (capacity re-runs): fewer slots, at most 4 GB of them (blocks wait for a slot, they never fail for want of one)
+                const size_t slot_bytes = (size_t)flow_words_per_lane(a.lds_words) * (size_t)SIM_THREADS * sizeof(uint32_t);
+                const size_t fit = std::max<size_t>(1, ((size_t)4 << 30) / (slot_bytes * 8));
+                if ((size_t)a.flow_slots > fit) a.flow_slots = (int32_t)fit;
+            }
             const size_t words = (ion ? (size_t)flow_words_per_lane(a.lds_words) * (size_t)SIM_THREADS : (size_t)a.lds_words * (size_t)SIM_THREADS_LONG) * (size_t)a.flow_slots * 8;
             if (ensure(c, c->flow_scratch, words * sizeof(uint32_t)) || ensure(c, c->flow_free, sizeof(uint64_t) * (256 + 8 * (size_t)nblk))) return DWGSIM_HIP_ERR_DEVICE;
             a.flow_scratch = (uint32_t *)c->flow_scratch.p; a.flow_free = (uint64_t *)c->flow_free.p;
@@ -1632,7 +1637,15 @@ int dwgsim_hip_wait(dwgsim_hip_ctx_t *c, int slot, dwgsim_hip_batch_t *out)
         uint64_t keep[8]; for (int q = 0; q < 6; ++q) keep[q] = h[16 + q];
         const uint64_t base = h[22];
         while (h[2] & 2) {
-            if (sl.cap_mult >= c->flow_cap_mult) { if (c->flow_cap_mult >= 16) break; c->flow_cap_mult *= 2; }      // (another batch may have doubled it already)
+            if (sl.cap_mult >= c->flow_cap_mult) {      // (another batch may have doubled it already)
+                // the reference doubles without end (dwgsim.c:296-311); here up to FLOW_CAP_MAX bases per read -- two thousand times a 400-base read, in
+                // scratch slots whose number shrinks as they grow (sim_enqueue).  (Rounds 3-4 stopped at 16 x the estimate: 3 of 300 random flow orders)
+                const int lmx = c->prm.length[0] > c->prm.length[1] ? c->prm.length[0] : c->prm.length[1];
+                const double emx = c->prm.e_start[0] > c->prm.e_start[1] ? c->prm.e_start[0] : c->prm.e_start[1];
+                const int64_t base_cap = c->flow_cap_forced > 0 ? c->flow_cap_forced : flow_read_capacity(lmx, emx, c->flow);
+                if (base_cap * (int64_t)c->flow_cap_mult * 2 > (int64_t)FLOW_CAP_MAX) break;
+                c->flow_cap_mult *= 2;
+            }
             if (const int rc = sim_enqueue(c, sl.ranges.data(), (int)sl.ranges.size(), base, slot, true)) return rc;
             HIPC(c, hipEventSynchronize(sl.ev_done));
             sl.pending = false;

@@ -13,6 +13,7 @@ constexpr int PLACE_LISTS = 64;          // k_place hands the pairs it cannot de
 #endif
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
 constexpr int FLOW_STACK_WORDS = 4;           // Ion Torrent pass 2: LDS words per lane for the (base, count) runs that can be pending in front of the examined base (two per word), times the
+constexpr int FLOW_CAP_MAX = 1 << 20;           // Ion Torrent: bases a read may grow to in the flow model (capacity re-runs double the buffers up to this)
 constexpr int FLOW_STACK_WORDS_MAX = 32;      // ... capacity multiplier of the job (a read that outgrows the stack is run again like one that outgrows its buffer), up to this many
 #ifndef DW_ION_THREADS_SMALL
 #define DW_ION_THREADS_SMALL 128

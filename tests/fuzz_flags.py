@@ -39,6 +39,15 @@ def random_flags(rng):
     if c < 0.15: f.append("-c 1")
     elif c < 0.35 and "-" not in "".join(x for x in f if x.startswith("-e ") or x.startswith("-E "))[3:]:
         f += ["-c 2", f"-f {rng.choice(['TACG', 'TACGTACGTCTGAGCATCGATCGATGTACAGC', 'GATC'])}"]
+        # per-flow error rates of 0.3 and more: reads grow severalfold in the flow model and the reference (like the oracle) spends O(length^2) per read --
+        # a handful of reads, so that these option sets are COMPARED instead of being given up on after the oracle's time limit (they never reached the
+        # kernels in rounds 2-4)
+        # ... and none at all at 0.5 / 1.0: there the UNMODIFIED reference does not finish seven 251-base reads in a minute (oracle/_ref/dwgsim -c 2 -f GATC -E 0.5,
+        # five seeds: the insertions of pass 2 breed faster than they are examined; at 1.0 it never returns, and the HIP path's error for that has a test of
+        # its own) -- such option sets used to be drawn, time out in the oracle and count as "rejected"; the draw now goes to 0.2, which runs
+        f = ["-E 0.2" if x == "-E 0.5" else "-e 0.2" if x == "-e 1.0" else x for x in f]
+        if any(x in ("-e 0.3", "-e 0.2", "-E 0.2") for x in f):
+            f = [x for x in f if not (x.startswith("-N ") or x.startswith("-C "))] + [f"-N {rng.choice([1, 7, 40])}"]
     if rng.random() < 0.1: f.append("-a")
     return " ".join(f)
 
@@ -65,9 +74,10 @@ def one_case_cli(flags, fasta):
         try:
             r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=ORACLE_TIMEOUT)
         except subprocess.TimeoutExpired:
-            print("ORACLE-TIMEOUT", flush=True); return 3
+            print("SKIP oracle-timeout", flush=True); return 3
         c = subprocess.run([cli] + flags.split() + [fasta, os.path.join(t, "c")], capture_output=True, text=True, timeout=100)
         if r.returncode != 0:
+            print("SKIP oracle-rejects", flush=True)
             if c.returncode == 0: print("NOTE oracle rc", r.returncode, "but dwgsim-hip succeeded", flush=True)
             return 3
         if c.returncode != 0:
@@ -139,9 +149,9 @@ def one_case_shards(flags, fasta, seed):
         try:
             r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=ORACLE_TIMEOUT)
         except subprocess.TimeoutExpired:
-            print("ORACLE-TIMEOUT", flush=True); return 3
+            print("SKIP oracle-timeout", flush=True); return 3
         if r.returncode != 0:
-            return 3
+            print("SKIP oracle-rejects", flush=True); return 3
         want = {s: (open(os.path.join(t, "o." + suf), "rb").read() if os.path.exists(os.path.join(t, "o." + suf)) else b"") for s, suf in enumerate(("bwa.read1.fastq", "bwa.read2.fastq", "bfast.fastq"))}
     try:
         got = run_job_in_random_shards(api.parse_flags(flags, lib), api.read_fasta(fasta), lib, random.Random(seed))
@@ -162,8 +172,9 @@ def one_case(flags, fasta):
         try:
             r = subprocess.run([oracle, "--rng", "philox"] + flags.split() + [fasta, os.path.join(t, "o")], capture_output=True, timeout=ORACLE_TIMEOUT)
         except subprocess.TimeoutExpired:
-            print("ORACLE-TIMEOUT", flush=True); return 3
+            print("SKIP oracle-timeout", flush=True); return 3
     if r.returncode != 0:
+        print("SKIP oracle-rejects", flush=True)
         try:
             res = api.run_job(api.parse_flags(flags, lib), api.read_fasta(fasta), lib=lib)
             print("NOTE oracle rc", r.returncode, "but the HIP path produced", res.n_pairs, "pairs", flush=True)
@@ -176,7 +187,7 @@ def one_case(flags, fasta):
         print("MISMATCH ::", str(e)[:300], flush=True); return 4
     except Exception as e:
         if "-B" in flags.split() and "failed with code -5" in repr(e):      # the documented limit of the flow model, met by the calibration
-            print("LIMIT :: -B calibration: a read outgrew its buffer", flush=True); return 3
+            print("SKIP limit :: -B calibration: a read outgrew its buffer", flush=True); return 3
         print("ERROR ::", repr(e)[:300], flush=True); return 4
     return 0
 
@@ -192,6 +203,7 @@ if __name__ == "__main__":
     seed, count = int(sys.argv[1]), int(sys.argv[2])
     rng = random.Random(seed)
     bad = rejected = 0
+    why = {}      # skipped option sets by reason: the oracle (= the reference's own checks) refuses them | the oracle did not finish in time | a documented limit
     for k in range(count):
         if "inputs" in sys.argv[3:]:
             flags, fasta = random_flags_tiny_inputs(rng), os.path.join(ROOT, "tests", "golden", "tiny.fa")
@@ -204,8 +216,12 @@ if __name__ == "__main__":
             rc, out = r.returncode, (r.stdout + r.stderr[-300:]).strip()
         except subprocess.TimeoutExpired:
             rc, out = 5, "TIMEOUT (120 s)"
-        if rc == 3: rejected += 1
+        if rc == 3:
+            rejected += 1
+            reason = next((ln.split()[1] for ln in out.splitlines() if ln.startswith("SKIP ")), "other")
+            why[reason] = why.get(reason, 0) + 1
+            if reason != "oracle-rejects": print(f"[{k}] skipped ({reason}): {os.path.basename(fasta)} {flags}", flush=True)
         if rc not in (0, 3) or "NOTE" in out or "TIMEOUT" in out:
             bad += rc not in (0, 3)
             print(f"[{k}] rc={rc} {os.path.basename(fasta)} {flags}\n      {out[-400:]}", flush=True)
-    print(f"fuzz seed {seed}: {count} cases, {rejected} rejected by the oracle, {bad} bad", flush=True)
+    print(f"fuzz seed {seed}: {count} cases, {rejected} skipped ({', '.join(f'{v} {k}' for k, v in sorted(why.items())) or 'none'}), {bad} bad", flush=True)

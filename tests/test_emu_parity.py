@@ -163,6 +163,10 @@ def test_ion_torrent_read_outgrows_its_buffers_on_cpu_emulation(emu_lib, oracle_
     res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 900 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 100 -2 0 -e 0.05 -y 0.1",
                        batch_pairs=300, debug_options={"flow_cap": 104})
     assert res.flow_cap_mult >= 2
+    # ... and 17-base reads that grow to 2 317 bases (twelve empty flows in front of every T at e = 0.19): 128 x the starting capacity -- rounds 3-4 gave
+    # up at 16 x, the reference keeps doubling (dwgsim.c:296-311)
+    res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 400 -c 2 -f TCG" + "A" * 12 + " -1 17 -2 0 -e 0.19", batch_pairs=300, debug_options={"flow_cap": 20})
+    assert res.flow_cap_mult >= 128
 
 
 def test_count_random_fast_and_long_path_on_cpu_emulation(emu_lib):

@@ -1,6 +1,9 @@
 """-m gpu: random option combinations (tests/fuzz_flags.py) through the HIP path (C-ABI, or the dwgsim-hip executable with "cli") and the
 oracle, byte for byte.
-Every case runs in its own process with a time limit; option sets the oracle itself rejects or gives up on are skipped."""
+Every case runs in its own process with a time limit; option sets that are skipped are counted by reason in the summary line ("oracle-rejects": the
+reference's own option checks refuse them; "oracle-timeout": the oracle did not finish -- the generator no longer draws the Ion Torrent error rates at
+which the unmodified reference does not terminate either, see tests/fuzz_flags.py -- ; "limit": a documented limit).  The source-derived seeds change
+with dwgsim_amd/csrc and include/ only: a round that touches only tests/ or oracle/ re-runs the previous sample."""
 import os, subprocess, sys
 import pytest
 
@@ -62,10 +65,10 @@ def test_long_reads_random_option_sets_bit_exact(oracle_bin, seed, count, mode):
 
 def test_ion_torrent_random_flow_orders_bit_exact(oracle_bin):
     """tests/fuzz_ion_flows.py: the flow model under flow orders of 4 .. 64 flows with long gaps, read lengths 1 .. 400, per-flow error rates up to
-    0.2, -B; at most one case of the sample may end with a read that outgrew its buffers (they are doubled up to 16 x first)."""
+    0.2, -B; the buffers of a read that outgrows them are doubled up to 2^20 bases (rounds 3-4: up to 16 x the estimate, which 1 % of such samples met)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_ion_flows.py"), "31", "60"], capture_output=True, text=True, timeout=1200)
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-2000:]
-    # a batch whose read outgrew its buffers runs again with twice the room (up to 16 x): what may still fail is a read that degenerates (the run
-    # stack of pass 2, 2^14 errors in one event) -- none in this sample; a regression of the capacity logic would show here
-    assert int(last.split(" outgrew")[0].split()[-1]) <= 1, last
+    # a batch whose read outgrew its buffers runs again with twice the room: what may still fail is a read that degenerates (the run stack of pass 2,
+    # 2^14 errors in one event) -- none in this sample; a regression of the capacity logic would show here
+    assert int(last.split(" outgrew")[0].split()[-1]) == 0, last

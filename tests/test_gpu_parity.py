@@ -395,15 +395,16 @@ def test_reads_beyond_the_lds_staging_limit(lib, oracle_bin, repeats_fa, flags):
     compare_case(lib, oracle_bin, repeats_fa, flags, batch_pairs=77, debug_options={"flow_slots": 2})
 
 
-@pytest.mark.parametrize("cap,flags", [(104, "-1 100 -2 0 -e 0.05 -y 0.1"), (60, "-1 50 -2 50 -d 300 -e 0.1 -E 0.02 -o 0"), (20, "-1 17 -2 0 -e 0.1 -f TCG" + "A" * 12)])
+@pytest.mark.parametrize("cap,flags", [(104, "-1 100 -2 0 -e 0.05 -y 0.1"), (60, "-1 50 -2 50 -d 300 -e 0.1 -E 0.02 -o 0"), (20, "-1 17 -2 0 -e 0.1 -f TCG" + "A" * 12),
+                                       (20, "-1 17 -2 0 -e 0.19 -f TCG" + "A" * 12)])      # (the last: 17-base reads that grow to 2 317 bases -- 128 x the starting capacity; rounds 3-4 gave up at 16 x)
 def test_ion_torrent_read_outgrows_its_buffers(lib, oracle_bin, golden_dir, cap, flags):
     """A read that outgrows its flow-space buffers makes the batch run again with twice the room (dw_host.cpp dwgsim_hip_wait; the reference doubles its
     buffers, dwgsim.c:296-311): forced with a small starting capacity, batch by batch and through the job level with two batches in flight per
     context; the third case: a flow order that keeps T away for twelve flows at e = 0.1 (17-base reads that grow up to 112 bases: three doublings from 20)."""
-    fl = f"-z 9 -N 2500 -c 2 {'' if ' -f ' in flags else '-f ' + FLOW} {flags}"
+    fl = f"-z 9 -N {400 if '0.19' in flags else 2500} -c 2 {'' if ' -f ' in flags else '-f ' + FLOW} {flags}"
     for home in ({}, {"ion_lds": 1, "split": 0}, {"ion_lds": 0}):
         res = compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), fl, batch_pairs=700, debug_options=dict(home, flow_cap=cap))
-        assert res.flow_cap_mult >= 2
+        assert res.flow_cap_mult >= (128 if '0.19' in flags else 2)
 
 
 def test_walk_reruns_when_a_capacity_is_exceeded(lib, oracle_bin, repeats_fa):
