@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--no-genome-leg", action="store_true", help="skip the end_to_end_genome leg (dwgsim-hip on the whole S4 genome: about a minute, most of it making the synthetic FASTA)")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
+    ap.add_argument("--no-carry", action="store_true", help="every step waits for its own launches before the next step's first launch is enqueued (the form of rounds 3-4)")
     ap.add_argument("--no-pipeline", action="store_true", help="every step prepares itself (walk, random-read count, exchange) before its first launch, on one resident copy of the contigs")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
     ap.add_argument("--strong-leg", action="store_true", help="also measure the fixed whole-genome job (BASELINE configs[3]) split over the ranks: the `strong` object of the line (default with --gpus > 1, and at N = 1 unless --no-legs)")
@@ -383,30 +384,40 @@ def main():
                 stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
             return bases
 
-        def run(gl, bases, record, then=None):
-            """all launches of this rank for one step, two in flight; `then` (the preparation of the next step) runs once the last one is enqueued"""
-            acc = {"bytes": 0, "rand": 0}
-            slot = 0
-            pending = []
+        # launches in flight (slot, accumulator of their step): kept ACROSS steps -- the first launch of step k+1 is enqueued while the last launch of
+        # step k still runs, as the batches of consecutive groups are in dw_job.cpp; every launch is waited for inside the timed region
+        flight = {"pending": [], "slot": 0}
 
-            def drain(keep):
-                while len(pending) > keep:
-                    b = ctx.wait(pending.pop(0))
-                    acc["bytes"] += int(b.bytes[0] + b.bytes[1] + b.bytes[2]); acc["rand"] += int(b.n_random)
-                    if record:
-                        stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
+        def drain(keep, record):
+            pending = flight["pending"]
+            while len(pending) > keep:
+                sl, acc = pending.pop(0)
+                b = ctx.wait(sl)
+                acc["bytes"] += int(b.bytes[0] + b.bytes[1] + b.bytes[2]); acc["rand"] += int(b.n_random)
+                if record:
+                    stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
+
+        def run(gl, bases, record, then=None, carry=False):
+            """all launches of this rank for one step, two in flight; `then` (the preparation of the next step) runs once the last one is enqueued and
+            every launch of the step BEFORE has finished (the next step's walk rewrites the copy that step read); carry: leave this step's launches
+            in flight for the next step to wait for"""
+            acc = {"bytes": 0, "rand": 0}
+            mine = 0
             first_launch = True
             for q, g in enumerate(gl):
                 for b in g["mine"]:
-                    drain(1)
+                    drain(1, record)
                     base = bases[(q, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
                     first_launch = False
-                    ctx.simulate_ranges_async(g["launches"][b], base, slot)
-                    pending.append(slot); slot ^= 1
+                    ctx.simulate_ranges_async(g["launches"][b], base, flight["slot"])
+                    flight["pending"].append((flight["slot"], acc)); flight["slot"] ^= 1
+                    mine += 1
+            drain(min(mine, 2), record)          # what is left in flight belongs to this step
             nxt = then() if then else None
-            drain(0)
+            if not carry:
+                drain(0, record)
             if record:
-                stats["bytes"] = acc["bytes"]; stats["n_random"] = acc["rand"]
+                stats["acc"] = acc
             return nxt
 
         def steps(n, record):
@@ -419,7 +430,8 @@ def main():
             t0 = time.perf_counter()
             for k in range(n):
                 nx = copies[(k + 1) & 1]
-                bases = run(copies[k & 1], bases, record, then=lambda: prepare(nx, record))
+                bases = run(copies[k & 1], bases, record, then=lambda: prepare(nx, record), carry=not args.no_carry)
+            drain(0, record)
             return t0
 
         steps(warmup, False)
@@ -428,6 +440,7 @@ def main():
         t0 = time.perf_counter()
         t0 = steps(n_steps, True) or t0
         barrier()
+        stats["bytes"] = stats["acc"]["bytes"]; stats["n_random"] = stats["acc"]["rand"]      # (of the last step: every step produces the same)
         elapsed = time.perf_counter() - t0
         stats["walk_gpu_ms"] = (ctx.debug_get("walk_us") - gpu_us0[0]) / 1e3
         stats["count_gpu_ms"] = (ctx.debug_get("count_us") - gpu_us0[1]) / 1e3

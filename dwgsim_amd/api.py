@@ -77,7 +77,7 @@ EXPORTS = [
     "dwgsim_hip_job_create", "dwgsim_hip_job_set_contig_table", "dwgsim_hip_job_set_regions", "dwgsim_hip_job_set_mutation_input", "dwgsim_hip_job_prepare", "dwgsim_hip_job_add_contig", "dwgsim_hip_job_begin_contig", "dwgsim_hip_job_commit_contig", "dwgsim_hip_job_cancel_contig", "dwgsim_hip_get_params",
     "dwgsim_hip_job_finish", "dwgsim_hip_job_last_error", "dwgsim_hip_job_destroy",
     "dwgsim_hip_set_fail_carry", "dwgsim_hip_failseg_join", "dwgsim_hip_shard_range", "dwgsim_hip_debug_option", "dwgsim_hip_debug_get", "dwgsim_hip_debug_count_byte", "dwgsim_hip_set_gzip", "dwgsim_hip_fetch_gz_async", "dwgsim_hip_debug_gzip",
-    "dwgsim_hip_selftest_fp64", "dwgsim_hip_selftest_lazy",
+    "dwgsim_hip_selftest_fp64", "dwgsim_hip_selftest_lazy", "dwgsim_hip_selftest_text",
 ]
 
 _lib = None

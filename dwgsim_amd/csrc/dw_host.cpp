@@ -427,7 +427,10 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         HIPC(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HIPC(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest));
         HIPC(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamDefault, prio_greatest));
-        HIPC(c, hipStreamCreateWithPriority(&c->walk_stream, hipStreamDefault, prio_least));
+        // (DWGSIM_HIP_WALK_PRIO=high|mid: analysis -- the walk stream at the batches' priority or between the two)
+        int prio_walk = prio_least;
+        if (const char *e = getenv("DWGSIM_HIP_WALK_PRIO")) prio_walk = !strcmp(e, "high") ? prio_greatest : !strcmp(e, "mid") ? (prio_least + prio_greatest) / 2 : prio_least;
+        HIPC(c, hipStreamCreateWithPriority(&c->walk_stream, hipStreamDefault, prio_walk));
         HIPC(c, hipEventCreate(&c->ev_up)); HIPC(c, hipEventCreate(&c->ev_cnt0)); HIPC(c, hipEventCreate(&c->ev_cnt1));
         HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
@@ -535,6 +538,20 @@ extern "C" int dwgsim_hip_selftest_fp64(int device, uint32_t seed, uint64_t n, u
     if (hipMalloc((void **)&d, 4 * sizeof(uint64_t)) != hipSuccess) return DWGSIM_HIP_ERR_NOMEM;
     hipMemset(d, 0, 4 * sizeof(uint64_t));
     launch_selftest_fp64(nullptr, seed, n, d);
+    const hipError_t e = hipMemcpy(out, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? DWGSIM_HIP_OK : DWGSIM_HIP_ERR_DEVICE;
+}
+
+// Not part of the drop-in ABI either: the number formatters of the name line (dw_read.hpp put_dec / put_hex) against one division per digit, on the
+// values first + i * stride, i < n (dw_simulate.hip k_selftest_text).  out[0] / out[1] = decimal / hexadecimal texts that differ, out[2] = values compared.
+extern "C" int dwgsim_hip_selftest_text(int device, uint64_t first, uint64_t n, uint64_t stride, uint64_t *out)
+{
+    if (!out || hipSetDevice(device) != hipSuccess) return DWGSIM_HIP_ERR_DEVICE;
+    uint64_t *d = nullptr;
+    if (hipMalloc((void **)&d, 4 * sizeof(uint64_t)) != hipSuccess) return DWGSIM_HIP_ERR_NOMEM;
+    hipMemset(d, 0, 4 * sizeof(uint64_t));
+    launch_selftest_text(nullptr, first, n, stride, d);
     const hipError_t e = hipMemcpy(out, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost);
     hipFree(d);
     return e == hipSuccess ? DWGSIM_HIP_OK : DWGSIM_HIP_ERR_DEVICE;
@@ -1335,9 +1352,13 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     // the FIFO writer unless its LDS costs a resident block per CU (Illumina reads between ~150 and ~240 bases): then 16-byte pieces from registers
     a.fifo = 1;
     if (p.data_type == 0) {
-        const int cap = (p.reads_output_type == 0) ? 4 : 5;      // waves per SIMD the registers allow (k_simulate launch bounds)
+        // waves per SIMD the registers allow (k_simulate launch bounds): five, except with both output families (-o 0) through two register writers;
+        // through the FIFO both families leave from one image (dw_read.hpp FifoWriter DUAL) and the kernel needs no more registers than for one
+        const int cap_fifo = 5, cap_reg = (p.reads_output_type == 0) ? 4 : 5;
         const size_t w0 = (size_t)((lmax0 + 7) / 8);
-        if (sim_blocks_per_cu(sim_lds_bytes(w0, SIM_THREADS, (size_t)c->qb_words, true), cap) < sim_blocks_per_cu(sim_lds_bytes(w0, SIM_THREADS, (size_t)c->qb_words, false), cap)) a.fifo = 0;
+        const int b_fifo = sim_blocks_per_cu(sim_lds_bytes(w0, SIM_THREADS, (size_t)c->qb_words, true), cap_fifo), b_reg = sim_blocks_per_cu(sim_lds_bytes(w0, SIM_THREADS, (size_t)c->qb_words, false), cap_reg);
+        // (-o 0: one assembly for both families outweighs a resident block: 2 x 250 bp 7.72 ms with three blocks per CU against 8.13 ms with four, profiles/r05_o0.txt)
+        if (b_fifo < b_reg && !(p.reads_output_type == 0 && b_fifo >= 3)) a.fifo = 0;
         if (c->writer >= 0) a.fifo = c->writer ? 1 : 0;
     }
     auto lds_need = [&](int lanes) { return sim_lds_bytes((size_t)((lmax0 + 7) / 8), (size_t)lanes, (size_t)c->qb_words, a.fifo != 0); };     // staged bases + the two base-quality tables + the text FIFOs

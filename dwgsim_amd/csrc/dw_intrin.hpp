@@ -7,6 +7,12 @@
 #ifndef DW_DEV
 #define DW_DEV __device__ __forceinline__
 #endif
+// a device function that is called, not inlined (rare paths whose copies at every use would crowd the instruction cache)
+#ifdef DW_INLINE_RARE          // (analysis builds: the rare paths inlined as in rounds 1-4)
+#define DW_DEV_NOINLINE __device__ __forceinline__
+#else
+#define DW_DEV_NOINLINE __device__ __attribute__((noinline))
+#endif
 // dynamic LDS of a kernel
 #define DW_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // A pointer into memory that nothing writes while the kernel runs (tables the host uploaded before the launch), in the constant address space:

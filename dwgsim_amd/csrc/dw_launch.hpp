@@ -36,4 +36,5 @@ void launch_gzip(hipStream_t st, const uint8_t *text, const uint64_t *n_dev, uin
                  const uint32_t *crc_table, const uint32_t *crc_shift);
 void launch_count_byte(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t byte, uint64_t *out);
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism);
+void launch_selftest_text(hipStream_t st, uint64_t first, uint64_t n, uint64_t stride, uint64_t *out);
 }

@@ -704,6 +704,11 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
         } else n = total;
     }
     DW_DEV void put4(uint32_t w) { putn((uint64_t)w, 4); }
+    DW_DEV void put_lead8(uint32_t lead, uint64_t v, uint32_t cnt)          // one character, then cnt (1 .. 8) more
+    {
+        if (cnt < 8) putn((uint64_t)lead | (v << 8), cnt + 1);
+        else { putn((uint64_t)lead | (v << 8), 8); putn(v >> 56, 1); }
+    }
     DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)       // sixteen bytes; one store when the section stands at a multiple of 16
     {
         if (probe::off(1)) return;
@@ -730,33 +735,80 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
 // skip = its address mod 32.  40 bytes, not 48 with 16-byte appends: LDS is what limits the blocks per CU (5 at 2 x 150 bp).
 // BURST = 64 (a 72-byte FIFO): where LDS does not bound residency -- the second half of the two-kernel form, which stages no bases -- the text
 // leaves as aligned 64-byte bursts: whole pairs of sectors, 1.02x the text instead of 1.15x-1.5x.
-template <uint32_t BURST = 32u>
+// DUAL (-o 0, both output families): the BFAST record is the BWA record without the two characters "/1" (or "/2") in front of the name line's
+// end (dwgsim.c:919-981), so the second stream is written FROM THE SAME IMAGE: every burst that leaves for the BWA file leaves for the BFAST file too
+// (the registers are loaded once), at the BFAST record's own byte phase -- unaligned 16-byte stores, two per burst.  Rounds 1-4 assembled the BFAST
+// record a second time in registers and wrote it in 16-byte pieces (2.3-2.4 x the text in HBM writes, two records' worth of assembly per lane:
+// profiles/r04_variants_pmc.txt).  dstb + p is where FIFO position p goes in the BFAST stream; bdone = the first position the BFAST stream has
+// not written yet (it differs from skip only between the suffix and the next drain: the suffix's own two characters are jumped over).
+// bytes [from, upto) of a unit (the ragged first / last unit of a record) from the FIFO at f to dst: rising sizes until the position is aligned (or the
+// next piece would pass upto), then falling sizes.  NOT inlined: it runs once or twice per record, and inlined at every append it made up a third of
+// k_simulate's code (94 KB against a 64 KB instruction cache; 61 KB without)
+template <uint32_t BURST>
+DW_DEV_NOINLINE void fifo_store_range(const uint8_t *f, uint8_t *dst, uint32_t from, uint32_t upto)
+{
+    auto ld8 = [&](uint32_t b) { return *reinterpret_cast<const uint64_t *>(f + b); };
+    auto st16 = [&](uint32_t b) { *reinterpret_cast<uint4 *>(dst + b) = make_uint4((uint32_t)ld8(b), (uint32_t)(ld8(b) >> 32), (uint32_t)ld8(b + 8), (uint32_t)(ld8(b + 8) >> 32)); };
+    uint32_t b = from;
+    if ((b & 1u) && b + 1 <= upto) { dst[b] = f[b]; b += 1; }
+    if ((b & 2u) && b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
+    if ((b & 4u) && b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
+    if ((b & 8u) && b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
+    if (b + 16 <= upto) { st16(b); b += 16; }
+    if (BURST == 64u) { if (b + 16 <= upto) { st16(b); b += 16; } if (b + 16 <= upto) { st16(b); b += 16; } }
+    if (b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
+    if (b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
+    if (b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
+    if (b + 1 <= upto) { dst[b] = f[b]; }
+}
+// the same for a destination of any alignment (the second stream of FifoWriter DUAL): falling sizes by the bits of the count
+template <uint32_t BURST>
+DW_DEV_NOINLINE void fifo_store_range_unaligned(const uint8_t *f, uint8_t *dstb, uint32_t from, uint32_t upto)
+{
+    if (from >= upto) return;
+    auto ld8u = [&](uint32_t b) { return reinterpret_cast<const Unal8 *>(f + b)->v; };
+    uint32_t b = from; const uint32_t n = upto - from;
+    if (BURST == 64u && (n & 64u)) { for (int q = 0; q < 4; ++q) { Unal16 v; v.a = ld8u(b); v.b = ld8u(b + 8); *reinterpret_cast<Unal16 *>(dstb + b) = v; b += 16; } }
+    if (n & 32u) { for (int q = 0; q < 2; ++q) { Unal16 v; v.a = ld8u(b); v.b = ld8u(b + 8); *reinterpret_cast<Unal16 *>(dstb + b) = v; b += 16; } }
+    if (n & 16u) { Unal16 v; v.a = ld8u(b); v.b = ld8u(b + 8); *reinterpret_cast<Unal16 *>(dstb + b) = v; b += 16; }
+    if (n & 8u) { Unal8 v; v.v = ld8u(b); *reinterpret_cast<Unal8 *>(dstb + b) = v; b += 8; }
+    if (n & 4u) { Unal4 v = *reinterpret_cast<const Unal4 *>(f + b); *reinterpret_cast<Unal4 *>(dstb + b) = v; b += 4; }
+    if (n & 2u) { Unal2 v = *reinterpret_cast<const Unal2 *>(f + b); *reinterpret_cast<Unal2 *>(dstb + b) = v; b += 2; }
+    if (n & 1u) { dstb[b] = f[b]; }
+}
+template <uint32_t BURST = 32u, bool DUAL = false>
 struct FifoWriter {
     uint8_t *f, *dst; uint32_t wp, skip;
+    uint8_t *dstb; uint32_t bdone;
     DW_DEV void init(uint8_t *fifo, uint8_t *rec) { const uint32_t h = (uint32_t)((uintptr_t)rec & (BURST - 1u)); f = fifo; dst = rec - h; wp = skip = h; }
+    DW_DEV void init(uint8_t *fifo, uint8_t *rec, uint8_t *rec_b) { init(fifo, rec); dstb = rec_b - skip; bdone = skip; }
     DW_DEV uint64_t ld8(uint32_t b) const { return *reinterpret_cast<const uint64_t *>(f + b); }
+    DW_DEV uint64_t ld8u(uint32_t b) const { return reinterpret_cast<const Unal8 *>(f + b)->v; }
     DW_DEV void st16(uint32_t b) const { *reinterpret_cast<uint4 *>(dst + b) = make_uint4((uint32_t)ld8(b), (uint32_t)(ld8(b) >> 32), (uint32_t)ld8(b + 8), (uint32_t)(ld8(b + 8) >> 32)); }
-    DW_DEV void store_range(uint32_t from, uint32_t upto)        // bytes [from, upto) of the unit (ragged first / last unit of a record), from LDS
+    DW_DEV void st16_both(uint32_t b) const          // sixteen bytes of a whole unit: aligned in the first stream, wherever they fall in the second
     {
-        uint32_t b = from;       // rising sizes until b is aligned (or the next piece would pass upto), then falling sizes
-        if ((b & 1u) && b + 1 <= upto) { dst[b] = f[b]; b += 1; }
-        if ((b & 2u) && b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
-        if ((b & 4u) && b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
-        if ((b & 8u) && b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
-        if (b + 16 <= upto) { st16(b); b += 16; }
-        if (BURST == 64u) { if (b + 16 <= upto) { st16(b); b += 16; } if (b + 16 <= upto) { st16(b); b += 16; } }
-        if (b + 8 <= upto) { *reinterpret_cast<uint64_t *>(dst + b) = ld8(b); b += 8; }
-        if (b + 4 <= upto) { *reinterpret_cast<uint32_t *>(dst + b) = *reinterpret_cast<const uint32_t *>(f + b); b += 4; }
-        if (b + 2 <= upto) { *reinterpret_cast<uint16_t *>(dst + b) = *reinterpret_cast<const uint16_t *>(f + b); b += 2; }
-        if (b + 1 <= upto) { dst[b] = f[b]; }
+        const uint64_t lo = ld8(b), hi = ld8(b + 8);
+        *reinterpret_cast<uint4 *>(dst + b) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        Unal16 v; v.a = lo; v.b = hi; *reinterpret_cast<Unal16 *>(dstb + b) = v;
     }
+    DW_DEV void store_range(uint32_t from, uint32_t upto) const { fifo_store_range<BURST>(f, dst, from, upto); }      // (ragged first / last unit of a record)
+    DW_DEV void store_range_b(uint32_t from, uint32_t upto) const { fifo_store_range_unaligned<BURST>(f, dstb, from, upto); }
     DW_DEV void drain()                          // wp >= BURST: one unit leaves
     {
         if (!(probe::off(2))) {
-            if (skip == 0) { st16(0); st16(16); if (BURST == 64u) { st16(32); st16(48); } }
-            else store_range(skip, BURST);
+            if (!DUAL) {
+                if (skip == 0) { st16(0); st16(16); if (BURST == 64u) { st16(32); st16(48); } }
+                else store_range(skip, BURST);
+            } else {
+                if ((skip | bdone) == 0) { st16_both(0); st16_both(16); if (BURST == 64u) { st16_both(32); st16_both(48); } }
+                else {          // (store_range covers fewer than BURST bytes: a whole unit of the first stream goes as it does above)
+                    if (skip == 0) { st16(0); st16(16); if (BURST == 64u) { st16(32); st16(48); } } else store_range(skip, BURST);
+                    store_range_b(bdone, BURST);
+                }
+            }
         }
         skip = 0;
+        if (DUAL) { bdone = bdone > BURST ? bdone - BURST : 0u; dstb += BURST; }
         *reinterpret_cast<uint64_t *>(f) = ld8(BURST);      // the (< 8) bytes past the unit move to the front
         dst += BURST; wp -= BURST;
     }
@@ -767,67 +819,139 @@ struct FifoWriter {
         Unal8 x; x.v = v; *reinterpret_cast<Unal8 *>(f + wp) = x;
         wp += cnt; if (wp >= BURST) drain();
     }
+    // one character, then cnt (1 .. 8) more: two overlapping stores, one step (the nine bytes end at position wp + 8 <= BURST + 7: inside the FIFO)
+    DW_DEV void put_lead8(uint32_t lead, uint64_t v, uint32_t cnt)
+    {
+        if (probe::off(1)) return;
+        f[wp] = (uint8_t)lead;
+        Unal8 x; x.v = v; *reinterpret_cast<Unal8 *>(f + wp + 1) = x;
+        wp += cnt + 1; if (wp >= BURST) drain();
+    }
+    // DUAL: the next `only_a` characters exist in the first stream only (they are the head of the cnt characters of v).  What the second stream has
+    // not written yet leaves now; from here on its bytes stand only_a places further down
+    DW_DEV void putn_first_only(uint64_t v, uint32_t cnt, uint32_t only_a)
+    {
+        if (probe::off(1)) return;
+        if (!(probe::off(2))) store_range_b(bdone, wp);
+        bdone = wp + only_a; dstb -= only_a;
+        putn(v, cnt);
+    }
     DW_DEV void put4(uint32_t w) { if (probe::off(1)) return; Unal4 x; x.v = w; *reinterpret_cast<Unal4 *>(f + wp) = x; wp += 4; if (wp >= BURST) drain(); }
     DW_DEV void put16(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { putn((uint64_t)a | ((uint64_t)b << 32), 8); putn((uint64_t)c | ((uint64_t)d << 32), 8); }
-    DW_DEV void flush() { if (wp > skip && !(probe::off(2))) store_range(skip, wp); dst += wp; wp = skip = 0; }
+    DW_DEV void flush()
+    {
+        if (!(probe::off(2))) { if (wp > skip) store_range(skip, wp); if (DUAL) store_range_b(bdone, wp); }
+        dst += wp; if (DUAL) dstb += wp;
+        wp = skip = 0; bdone = 0;
+    }
 };
-// OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream.  The (first) output goes through the FIFO writer (WR = 1)
+// OUT bit 0: the bwa stream of this read end, bit 1: the interleaved bfast stream.  The (first) output goes through the FIFO writer (WR = 1, 2)
 // or the register writer (WR = 0: the host found that the FIFO's LDS would cost a resident block per CU); with both outputs (-o 0) the
-// bfast stream always takes the register writer.
-template <int WR> struct PrimaryWriter { typedef FifoWriter<32u> type; };      // WR = 1
-template <> struct PrimaryWriter<0> { typedef Writer type; };
-template <> struct PrimaryWriter<2> { typedef FifoWriter<64u> type; };
+// bfast stream leaves from the same FIFO image (FifoWriter<.., DUAL>), or, beside the register writer, through a register writer of its own.
+template <int WR, bool DUAL> struct PrimaryWriter { typedef FifoWriter<32u, DUAL> type; };      // WR = 1
+template <bool DUAL> struct PrimaryWriter<0, DUAL> { typedef Writer type; };
+template <bool DUAL> struct PrimaryWriter<2, DUAL> { typedef FifoWriter<64u, DUAL> type; };
 template <int OUT, int WR = 1>
 struct Out2 {
-    typename PrimaryWriter<WR>::type a; Writer b;
-    DW_DEV void init(uint8_t *fifo, uint8_t *bwa, uint8_t *bfast) { a.init(fifo, (OUT & 1) ? bwa : bfast); if (OUT == 3) b.init(bfast); }
-    DW_DEV void put(uint32_t c) { a.put(c); if (OUT == 3) b.put(c); }
-    DW_DEV void put4(uint32_t w) { a.put4(w); if (OUT == 3) b.put4(w); }
-    DW_DEV void putn(uint64_t v, uint32_t cnt) { a.putn(v, cnt); if (OUT == 3) b.putn(v, cnt); }
-    DW_DEV void put16(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { a.put16(x, y, z, w); if (OUT == 3) b.put16(x, y, z, w); }
-    // the end of the name line differs between the two families: "/1\n" (bwa) and "\n" (bfast)
+    static constexpr bool DUAL = OUT == 3 && WR != 0;       // both streams from one FIFO image
+    static constexpr bool TWO = OUT == 3 && WR == 0;        // both streams, a register writer each
+    typename PrimaryWriter<WR, DUAL>::type a; Writer b;
+    DW_DEV void init(uint8_t *fifo, uint8_t *bwa, uint8_t *bfast)
+    {
+        if constexpr (DUAL) a.init(fifo, bwa, bfast);
+        else { a.init(fifo, (OUT & 1) ? bwa : bfast); if (TWO) b.init(bfast); }
+    }
+    DW_DEV void put(uint32_t c) { a.put(c); if (TWO) b.put(c); }
+    DW_DEV void put4(uint32_t w) { a.put4(w); if (TWO) b.put4(w); }
+    DW_DEV void putn(uint64_t v, uint32_t cnt) { a.putn(v, cnt); if (TWO) b.putn(v, cnt); }
+    DW_DEV void put_lead8(uint32_t lead, uint64_t v, uint32_t cnt) { a.put_lead8(lead, v, cnt); if (TWO) b.put_lead8(lead, v, cnt); }
+    DW_DEV void put16(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { a.put16(x, y, z, w); if (TWO) b.put16(x, y, z, w); }
+    // the end of the name line differs between the two families: "/1\n" (bwa) and "\n" (bfast): v_bf is the tail of v_bwa
     DW_DEV void put_suffix(uint64_t v_bwa, uint32_t n_bwa, uint64_t v_bf, uint32_t n_bf)
     {
-        if (OUT & 1) a.putn(v_bwa, n_bwa); else a.putn(v_bf, n_bf);
-        if (OUT == 3) b.putn(v_bf, n_bf);
+        if constexpr (DUAL) a.putn_first_only(v_bwa, n_bwa, n_bwa - n_bf);
+        else {
+            if (OUT & 1) a.putn(v_bwa, n_bwa); else a.putn(v_bf, n_bf);
+            if (TWO) b.putn(v_bf, n_bf);
+        }
     }
-    DW_DEV void rebase() { if (WR == 0) a.flush(); if (OUT == 3) b.flush(); }      // a new section of the register writer(s); the FIFO needs none
-    DW_DEV void flush() { a.flush(); if (OUT == 3) b.flush(); }
+    DW_DEV void rebase() { if (WR == 0) a.flush(); if (TWO) b.flush(); }      // a new section of the register writer(s); the FIFO needs none
+    DW_DEV void flush() { a.flush(); if (TWO) b.flush(); }
 };
 DW_DEV uint32_t ndigits10(uint32_t v)
 {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
 }
 DW_DEV uint32_t ndigits16(uint64_t v) { return v ? (uint32_t)(67 - __clzll((long long)v)) >> 2 : 1u; }
-// decimal digits of v as packed ASCII, most significant digit in the lowest byte (stream order);
-// lead = one separator byte to emit in front (0 = none).  Numbers above 10^7 take the two-part path.
+// ---- numbers as text, without a loop per digit (rounds 1-4 divided by ten once per digit: the name line was 0.3 of 5.9 ms) ----
+// the four decimal digits of x < 10 000 as ASCII, most significant digit in the lowest byte (stream order), leading zeros kept: x = 100 a + b by one
+// multiplication, then both two-digit numbers at once in the halves of a word (n / 10 = n * 103 >> 10 for n < 100)
+DW_DEV uint32_t dec4(uint32_t x)
+{
+    const uint32_t a = (x * 5243u) >> 19;                        // x / 100 for x < 43 699
+    const uint32_t p = a | ((x - a * 100u) << 16);
+    const uint32_t t = ((p * 103u) >> 10) & 0x000F000Fu;         // the tens of both (99 * 103 < 2^16: the halves do not mix)
+    return (t | ((p - t * 10u) << 8)) + 0x30303030u;
+}
+// eight digits of v < 10^8, leading zeros kept
+DW_DEV uint64_t dec8(uint32_t v)
+{
+    const uint32_t hi = (uint32_t)(((uint64_t)v * 0xD1B71759ull) >> 45);      // v / 10 000 for every 32-bit v
+    return (uint64_t)dec4(hi) | ((uint64_t)dec4(v - hi * 10000u) << 32);
+}
+// ... with the leading zeros taken off: the digits of v < 10^8 in the low bytes of the result, *nd of them (1 .. 8)
+DW_DEV uint64_t dec8_stripped(uint32_t v, uint32_t *nd)
+{
+    const uint64_t w = dec8(v);
+    const uint32_t z = (uint32_t)__builtin_ctzll((w - 0x3030303030303030ull) | (1ull << 56)) >> 3;      // leading zero digits (at most seven)
+    *nd = 8u - z;
+    return w >> (8u * z);
+}
+// the hexadecimal digits of the low 32 bits of v, most significant first, leading zeros kept: nibbles spread to bytes, 'a' - '0' - 10 added where a digit passes 9
+DW_DEV uint64_t hex8(uint32_t v)
+{
+    auto four = [](uint32_t n) -> uint32_t {                     // digits 3 .. 0 of n (16 bits), digit 3 in the lowest byte
+        uint32_t x = ((n & 0xF000u) >> 12) | ((n & 0x0F00u) << 0) | ((n & 0x00F0u) << 12) | ((n & 0x000Fu) << 24);
+        const uint32_t over = ((x + 0x06060606u) >> 4) & 0x01010101u;      // 1 where the digit is 10 .. 15
+        return x + 0x30303030u + over * 39u;
+    };
+    return (uint64_t)four(v >> 16) | ((uint64_t)four(v & 0xFFFFu) << 32);
+}
+// lead (one separator character) + the decimal digits of v
 template <class O>
 DW_DEV void put_dec(O &o, uint32_t v, uint32_t lead)
 {
-    uint32_t low7 = 0; bool big = false;
-    if (v >= 10000000u) { const uint32_t hi = v / 10000000u; low7 = v - hi * 10000000u; v = hi; big = true; }   // 8..10 digits
-    uint64_t w = 0; uint32_t nd = 0;
-    do { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; ++nd; } while (v);
-    if (lead) { w = (w << 8) | lead; ++nd; }
-    o.putn(w, nd);
-    if (big) {                                 // the low seven digits, zero padded
-        w = 0;
-        for (int d = 0; d < 7; ++d) { const uint32_t q = low7 / 10u; w = (w << 8) | ('0' + (low7 - q * 10u)); low7 = q; }
-        o.putn(w, 7);
+    if (v >= 100000000u) {                     // nine or ten digits: the first one or two with the separator, then eight
+        const uint32_t hi = v / 100000000u;    // 1 .. 42
+        const uint32_t t = (hi * 103u) >> 10;
+        o.putn(t ? (uint64_t)lead | ((uint64_t)('0' + t) << 8) | ((uint64_t)('0' + hi - 10u * t) << 16) : (uint64_t)lead | ((uint64_t)('0' + hi) << 8), t ? 3u : 2u);
+        o.putn(dec8(v - hi * 100000000u), 8);
+        return;
     }
+    uint32_t nd; const uint64_t w = dec8_stripped(v, &nd);
+    o.put_lead8(lead, w, nd);
 }
+// lead + the hexadecimal digits of v
 template <class O>
-DW_DEV void put_hex(O &o, uint64_t v)
+DW_DEV void put_hex(O &o, uint64_t v, uint32_t lead)
 {
     const uint32_t nd = ndigits16(v);
-    for (uint32_t part = 0; part < 2; ++part) {      // up to 16 digits: the high (nd-8) first, then the low 8
-        const uint32_t cnt = part == 0 ? (nd > 8 ? nd - 8 : 0) : (nd > 8 ? 8 : nd);
-        if (!cnt) continue;
-        const uint64_t x = part == 0 ? v >> 32 : (nd > 8 ? (v & 0xFFFFFFFFull) : v);
-        uint64_t w = 0;
-        for (uint32_t d = 0; d < cnt; ++d) { const uint32_t hx = (uint32_t)(x >> (4 * d)) & 15u; w = (w << 8) | (hx < 10 ? '0' + hx : 'a' + (hx - 10)); }
-        o.putn(w, cnt);
-    }
+    if (nd > 8) {
+        o.put_lead8(lead, hex8((uint32_t)(v >> 32)) >> (8u * (16u - nd)), nd - 8u);
+        o.putn(hex8((uint32_t)v), 8);
+    } else o.put_lead8(lead, hex8((uint32_t)v) >> (8u * (8u - nd)), nd);
+}
+// "_e:u:i": the three counts of a read end behind their separators; one piece when all three are single digits (almost always)
+template <class O>
+DW_DEV void put_counts(O &o, uint32_t e, uint32_t u, uint32_t i)
+{
+    if (e < 10u && u < 10u && i < 10u)
+        o.putn((uint64_t)'_' | ((uint64_t)('0' + e) << 8) | ((uint64_t)':' << 16) | ((uint64_t)('0' + u) << 24) | ((uint64_t)':' << 32) | ((uint64_t)('0' + i) << 40), 6);
+    else { put_dec(o, e, '_'); put_dec(o, u, ':'); put_dec(o, i, ':'); }
+}
+DW_DEV uint32_t counts_len(uint32_t e, uint32_t u, uint32_t i)
+{
+    return (e < 10u && u < 10u && i < 10u) ? 6u : 3u + ndigits10(e) + ndigits10(u) + ndigits10(i);
 }
 DW_DEV uint32_t base_chars4(uint32_t nibbles) { return lut8(0x4E4E4E4Eu, 0x54474341u, spread4(nibbles)); }        // four codes (<= 7) -> "ACGTNNNN"[code]
 DW_DEV uint32_t colour_digits4(uint32_t nibbles) { return lut8(0x34343434u, 0x33323130u, spread4(nibbles)); }     // four colours -> "01234444"[colour]

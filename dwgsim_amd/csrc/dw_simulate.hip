@@ -31,8 +31,12 @@
 #define DW_SIM_WAVES 5       // minimum waves per SIMD requested for the Illumina variants (one less when both output families are written):
                              // the kernel sits 1-2 VGPRs above these occupancy steps without the hint; measured +4 % at 5 vs 4 waves, 6 spills (so do the SOLiD variants with any hint)
 #endif
+#ifndef DW_PRIO_DROP
+#define DW_PRIO_DROP 1       // where a wave of the single kernel gives up its raised issue priority: 0 = once its block's look-backs are resolved, 1 = after
+                             // the name line that follows them (profiles/r04_split.txt section 5: 5.84 -> 5.75 ms at 2 x 150 bp, Ion Torrent unchanged)
+#endif
 #ifndef DW_SIM_WAVES_BOTH
-#define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0)
+#define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0) through two register writers (WR = 0; through the FIFO one image serves both)
 #endif
 #ifndef DW_SIMB_WAVES
 #define DW_SIMB_WAVES 6      // ... requested for the second half of the two-kernel form (text assembly)
@@ -230,8 +234,8 @@ DW_DEV void put_rand_tail(O &o, uint64_t rand_ii)
     o.putn(0x305F305F305F305Full, 8);          // "_0_0_0_0"
     o.putn(0x3A305F315F315F00ull >> 8, 7);     // "_1_1_0:"
     o.putn(0x303A305F303A30ull, 7);            // "0:0_0:0"
-    o.putn(0x5F303Aull, 3);                    // ":0_"
-    put_hex(o, rand_ii);
+    o.putn(0x303Aull, 2);                      // ":0"
+    put_hex(o, rand_ii, '_');
 }
 struct NameCounts { int32_t e0, u0, i0, e1, u1, i1; };     // n_err : n_sub : n_indel of read end 1 and 2
 // "_pos1_pos2_strand1_strand2_0_0_e:s:i_e:s:i_<hex>" (dwgsim.c:923-929)
@@ -241,16 +245,14 @@ DW_DEV void put_pair_tail(O &o, int32_t x0, int32_t x1, uint32_t strand0, uint32
     put_dec(o, (uint32_t)(x0 + 1), '_'); put_dec(o, (uint32_t)(x1 + 1), '_');
     o.putn((uint64_t)'_' | ((uint64_t)('0' + strand0) << 8) | ((uint64_t)'_' << 16) | ((uint64_t)('0' + strand1) << 24)
                | ((uint64_t)'_' << 32) | ((uint64_t)'0' << 40) | ((uint64_t)'_' << 48) | ((uint64_t)'0' << 56), 8);     // "_S_S_0_0"
-    put_dec(o, (uint32_t)n.e0, '_'); put_dec(o, (uint32_t)n.u0, ':'); put_dec(o, (uint32_t)n.i0, ':');
-    put_dec(o, (uint32_t)n.e1, '_'); put_dec(o, (uint32_t)n.u1, ':'); put_dec(o, (uint32_t)n.i1, ':');
-    o.put('_');
-    put_hex(o, ii);
+    put_counts(o, (uint32_t)n.e0, (uint32_t)n.u0, (uint32_t)n.i0);
+    put_counts(o, (uint32_t)n.e1, (uint32_t)n.u1, (uint32_t)n.i1);
+    put_hex(o, ii, '_');
 }
 DW_DEV uint32_t pair_tail_len(int32_t x0, int32_t x1, const NameCounts &n, uint64_t ii)
 {
-    return 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 9     // _P0_P1 _S_S_0_0_
-         + ndigits10((uint32_t)n.e0) + 1 + ndigits10((uint32_t)n.u0) + 1 + ndigits10((uint32_t)n.i0) + 1
-         + ndigits10((uint32_t)n.e1) + 1 + ndigits10((uint32_t)n.u1) + 1 + ndigits10((uint32_t)n.i1) + 1 + ndigits16(ii);
+    return 1 + ndigits10((uint32_t)(x0 + 1)) + 1 + ndigits10((uint32_t)(x1 + 1)) + 8     // _P0_P1 _S_S_0_0
+         + counts_len((uint32_t)n.e0, (uint32_t)n.u0, (uint32_t)n.i0) + counts_len((uint32_t)n.e1, (uint32_t)n.u1, (uint32_t)n.i1) + 1 + ndigits16(ii);
 }
 // ---- quality normals (dwgsim.c:156-175 ran_normal, :912): the integer offsets (int)(nrm * sigma + 0.5) that one Philox block delivers.
 // The polar tries of a read's quality string form one sequential stream of 16-BIT uniforms: try t = the two halves of word t & 3 of block
@@ -268,6 +270,13 @@ DW_DEV void quality_try_exact(uint32_t w, double sigma, bool &ok, int32_t &k0, i
     const double fac = sqrt_mid(div_mid(-2.0 * det_log<true>(rsq), rsq));
     k0 = (int32_t)(((v2 * fac) * sigma) + 0.5);
     k1 = (int32_t)(((v1 * fac) * sigma) + 0.5);
+}
+// (the same as a called function for the read kernels: four inlined copies per quality block were 3 KB of code that one block in ten runs; an accepted try)
+DW_DEV_NOINLINE uint64_t quality_try_exact_called(uint32_t w, double sigma)
+{
+    bool ok; int32_t k0 = 0, k1 = 0;
+    quality_try_exact(w, sigma, ok, k0, k1);
+    return (uint64_t)(uint32_t)k0 | ((uint64_t)(uint32_t)k1 << 32);
 }
 // LAZY form -- same results, a fraction of the work.  An estimate y of x = nrm * sigma + 0.5 with a PROVEN bound |y - x| < eps decides the
 // integer whenever y is further than eps from every integer; only the rest (about 2 * eps of all values) takes the exact path.  The estimate is
@@ -315,7 +324,7 @@ DW_DEV uint32_t quality_block(const U4 &b, const QualLazy &ql, double sigma, con
     for (int t = 0; t < 4; ++t) { const uint32_t r = quality_try_lazy(w[t], ql, k[2 * t], k[2 * t + 1]); acc |= (r & 1u) << t; need |= (r >> 1) << t; }
     if (need) {                              // rare (about 2 eps of the values; the branch is skipped when no lane of the wave takes it): the reference's own arithmetic decides
 #pragma unroll
-        for (int t = 0; t < 4; ++t) if ((need >> t) & 1u) { bool ok; quality_try_exact(w[t], sigma, ok, k[2 * t], k[2 * t + 1]); }
+        for (int t = 0; t < 4; ++t) if ((need >> t) & 1u) { const uint64_t kk = quality_try_exact_called(w[t], sigma); k[2 * t] = (int32_t)(uint32_t)kk; k[2 * t + 1] = (int32_t)(uint32_t)(kk >> 32); }
     }
     // the base qualities of the (up to eight) positions this block can fill
     const int pc = pos < nq ? pos : nq;
@@ -424,7 +433,7 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
 // block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
 // block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
 template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : OUT != 3 ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : (OUT != 3 || WR != 0) ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     static_assert(SPLIT == 0 || ((DT == 0 || DT == 3) && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants and for Ion Torrent with its buffers in LDS, 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
@@ -740,7 +749,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         }
     }
 
-    if (SPLIT == 0) wave_priority(0);
+    if (SPLIT == 0 && (DW_PRIO_DROP == 0 || DT == 1)) wave_priority(0);
     DW_PROBE_MARK(a, 3);     // name lengths, block scan, look-back
     // ---- SOLiD records (dwgsim.c:934-976, :1056-1094): the two outputs differ in name counts, suffix, alphabet and length ----
     if (DT == 1) {
@@ -784,6 +793,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         else put_pair_tail(o, x0, x1, pd.strand0, pd.strand1, nc, ii);
         }
         o.put_suffix((uint64_t)'/' | ((uint64_t)('1' + j) << 8) | ((uint64_t)'\n' << 16), 3, (uint64_t)'\n', 1);
+        if (SPLIT == 0 && DW_PRIO_DROP == 1) wave_priority(0);      // (the name line still at the raised priority: see DW_PRIO_DROP)
         DW_PROBE_MARK(a, 4); // header line
         // bases (the second writer of -o 0 starts a new section, so that sixteen bases are one store)
         o.rebase();
@@ -827,6 +837,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         o.put('\n'); o.put('+'); o.put('\n');
         o.rebase();
         }
+        if (SPLIT == 0 && DW_PRIO_DROP == 1) wave_priority(0);      // (a wave none of whose lanes has a record)
         DW_PROBE_MARK(a, 5); // sequence line
         // qualities (dwgsim.c:899-918): up to eight characters per Philox block of the read end's try stream, appended as they come
         if (rec) for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false,
@@ -953,6 +964,43 @@ void launch_selftest_lazy(hipStream_t st, int mode, uint32_t first, uint64_t n, 
 {
     const uint64_t nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_selftest_lazy, dim3((uint32_t)(nb < (1u << 20) ? (nb ? nb : 1) : (1u << 20))), dim3(256), 0, st, mode, first, n, sigma, qk, qeps, qlmin, qnear1, out);
+}
+// Self-test of the number formatters (dw_read.hpp put_dec / put_hex: digits without a loop per digit) against one division per digit: the values
+// first + i * stride, i < n -- their low 32 bits in decimal, all 64 in hexadecimal -- behind a separator, collected byte by byte.
+// out[0] / out[1]: decimal / hexadecimal texts that differ, out[2]: values compared.
+struct TextCollect {
+    uint8_t b[24]; uint32_t n;
+    DW_DEV void putn(uint64_t v, uint32_t cnt) { for (uint32_t k = 0; k < cnt; ++k) b[n++] = (uint8_t)(v >> (8 * k)); }
+    DW_DEV void put_lead8(uint32_t lead, uint64_t v, uint32_t cnt) { b[n++] = (uint8_t)lead; putn(v, cnt); }
+};
+__global__ void __launch_bounds__(256) k_selftest_text(uint64_t first, uint64_t n, uint64_t stride, uint64_t *out)
+{
+    uint32_t bad_dec = 0, bad_hex = 0, done = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t v = first + i * stride;
+        uint8_t want[24]; uint32_t wn;
+        { uint8_t d[10]; uint32_t nd = 0, t = (uint32_t)v; do { d[nd++] = (uint8_t)('0' + t % 10u); t /= 10u; } while (t); wn = 0; want[wn++] = '_'; while (nd) want[wn++] = d[--nd]; }
+        TextCollect c; c.n = 0;
+        put_dec(c, (uint32_t)v, '_');
+        bool same = c.n == wn && wn == 1u + ndigits10((uint32_t)v);
+        for (uint32_t k = 0; k < wn && same; ++k) same = c.b[k] == want[k];
+        bad_dec += same ? 0u : 1u;
+        { uint8_t d[16]; uint32_t nd = 0; uint64_t t = v; do { const uint32_t h = (uint32_t)(t & 15u); d[nd++] = (uint8_t)(h < 10 ? '0' + h : 'a' + (h - 10)); t >>= 4; } while (t); wn = 0; want[wn++] = ':'; while (nd) want[wn++] = d[--nd]; }
+        c.n = 0;
+        put_hex(c, v, ':');
+        same = c.n == wn && wn == 1u + ndigits16(v);
+        for (uint32_t k = 0; k < wn && same; ++k) same = c.b[k] == want[k];
+        bad_hex += same ? 0u : 1u;
+        ++done;
+    }
+    if (bad_dec) atomicAdd((unsigned long long *)&out[0], (unsigned long long)bad_dec);
+    if (bad_hex) atomicAdd((unsigned long long *)&out[1], (unsigned long long)bad_hex);
+    atomicAdd((unsigned long long *)&out[2], (unsigned long long)done);
+}
+void launch_selftest_text(hipStream_t st, uint64_t first, uint64_t n, uint64_t stride, uint64_t *out)
+{
+    const uint64_t nb = cdiv(n, 256);
+    hipLaunchKernelGGL(k_selftest_text, dim3((uint32_t)(nb < (1u << 16) ? (nb ? nb : 1) : (1u << 16))), dim3(256), 0, st, first, n, stride, out);
 }
 void launch_selftest_fp64(hipStream_t st, uint32_t seed, uint64_t n, uint64_t *mism)
 {

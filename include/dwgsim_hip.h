@@ -353,6 +353,9 @@ int dwgsim_hip_debug_count_byte(dwgsim_hip_ctx_t *ctx, int slot, int stream, int
  * try) and, with exhaustive != 0, the hardware log2 / rcp / sqrt on every float of their operand ranges.  out: see dw_host.cpp. */
 int dwgsim_hip_selftest_fp64(int device, uint32_t seed, uint64_t n, uint64_t *out);
 int dwgsim_hip_selftest_lazy(int device, uint32_t first, uint64_t n, double sigma, int exhaustive, uint64_t *out);
+/* the number formatters of the name line (decimal positions and counts, the hexadecimal read index: dw_read.hpp put_dec / put_hex) against one
+ * division per digit on the values first + i * stride, i < n.  out[0] / out[1]: decimal / hexadecimal texts that differ, out[2]: values compared. */
+int dwgsim_hip_selftest_text(int device, uint64_t first, uint64_t n, uint64_t stride, uint64_t *out);
 
 #ifdef __cplusplus
 }

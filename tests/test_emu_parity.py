@@ -36,6 +36,21 @@ def emu_lib():
     return api.load(os.path.join(HERE, "emu", "libdwgsim_emu.so"))
 
 
+def test_number_text_of_the_name_line_on_cpu_emulation(emu_lib):
+    """put_dec / put_hex against one division per digit (tests/test_gpu_parity.py runs every 32-bit value): here the values around every power of ten and
+    of sixteen, and a few million spread over the range."""
+    import ctypes as C
+    out = (C.c_uint64 * 4)()
+    emu_lib.dwgsim_hip_selftest_text.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    emu_lib.dwgsim_hip_selftest_text.restype = C.c_int
+    spans = [(0, 200000, 1), (0, 1 << 21, 2039), (0, 1 << 20, 0xFFF_FFF1_0003)]
+    spans += [(10 ** k - 300, 600, 1) for k in range(3, 10)] + [(m * 10 ** 8 - 300, 600, 1) for m in (2, 9, 10, 11, 42)] + [((1 << 32) - 600, 1200, 1)]
+    spans += [((1 << (4 * k)) - 300, 600, 1) for k in range(3, 16)] + [((1 << 64) - 600, 600, 1)]
+    for first, n, stride in spans:
+        assert emu_lib.dwgsim_hip_selftest_text(0, first, n, stride, out) == 0
+        assert out[2] == n and (out[0], out[1]) == (0, 0), (first, n, stride, list(out))
+
+
 @pytest.mark.parametrize("fasta,flags", EMU_CASES, ids=[f"{f}:{fl}" for f, fl in EMU_CASES])
 def test_kernel_logic_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags):
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=700)

@@ -304,6 +304,18 @@ def test_range_restricted_fp64_forms_equal_the_general_ones(lib):
         assert out[3] > (1 << 29) and (out[0], out[1], out[2]) == (0, 0, 0), list(out)
 
 
+def test_number_text_of_the_name_line_equals_one_division_per_digit(lib):
+    """put_dec / put_hex (dw_read.hpp: four digits per multiplication, hexadecimal digits by nibble spreading) against the plain per-digit loop: EVERY
+    32-bit value in decimal (positions, counts), and in hexadecimal (the read index) every value below 2^32 plus 2^31 values spread over 64 bits."""
+    import ctypes as C
+    out = (C.c_uint64 * 4)()
+    lib.dwgsim_hip_selftest_text.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.dwgsim_hip_selftest_text.restype = C.c_int
+    for first, n, stride in ((0, 1 << 32, 1), (0, 1 << 31, 0x1_0000_0003), (0xFFFF_FFFF_0000_0000, 1 << 24, 257), ((1 << 60) - 5000, 10000, 1)):
+        assert lib.dwgsim_hip_selftest_text(0, first, n, stride, out) == 0
+        assert out[2] == n and (out[0], out[1]) == (0, 0), (first, n, stride, list(out))
+
+
 def test_lazy_quality_normals_decide_exactly_what_the_exact_form_decides(lib):
     """quality_try_lazy (fp32 estimate + proven error bound, exact fp64 path only near a rounding boundary) against quality_try_exact on EVERY
     possible try -- a try of the quality stream is one 32-bit word, so 2^32 of them per quality_std is all there is -- and the hardware
