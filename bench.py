@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--no-genome-leg", action="store_true", help="skip the end_to_end_genome leg (dwgsim-hip on the whole S4 genome: about a minute, most of it making the synthetic FASTA)")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
+    ap.add_argument("--depth", type=int, default=2, help="how many steps ahead the walks run (contigs resident depth + 1 times); 1 = the form of rounds 3-4")
     ap.add_argument("--no-carry", action="store_true", help="every step waits for its own launches before the next step's first launch is enqueued (the form of rounds 3-4)")
     ap.add_argument("--no-pipeline", action="store_true", help="every step prepares itself (walk, random-read count, exchange) before its first launch, on one resident copy of the contigs")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
@@ -322,11 +323,11 @@ def main():
             job.append((name, arr, ci, n))
             n_sim += n
         job_pairs = sum(e[3] for e in job)
-        # Every group is resident TWICE (copies A / B, used by alternate steps): the walk rewrites the haplotypes in place, so the walk + random-read
+        # Every group is resident depth + 1 TIMES (copies used by consecutive steps in turn): the walk rewrites the haplotypes in place, so the walk + random-read
         # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
         # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
         copies = []
-        for _copy in range(1 if args.no_pipeline else 2):
+        for _copy in range(1 if args.no_pipeline else args.depth + 1):
             gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
             for grp in make_groups(job, group_bp):
                 h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
@@ -345,13 +346,18 @@ def main():
 
         stats = {"prep_ms": 0.0, "count_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
 
-        def prepare(gl, record):
-            """What a step needs before its first launch: the walk of every group (every rank walks every group itself: deterministic, no broadcast),
-            this rank's random-read counts (k_place, one launch per group, one count per batch) and ONE all-gather of them; -> the rand_ii base of
-            every launch of this rank.  All of it on the walk stream / the host: it runs beside whatever the compute stream is doing."""
-            t0 = time.perf_counter()
+        def issue(gl):
+            """the walk of every group, enqueued on the walk stream (every rank walks every group itself: deterministic, no broadcast)"""
             for g in gl:
                 ctx.mutate_async(g["h0"])
+
+        def prepare(gl, record, issued=False):
+            """What a step needs before its first launch: the walks (issue), this rank's random-read counts (k_place, one launch per group, one count
+            per batch) and ONE all-gather of them; -> the rand_ii base of every launch of this rank.  All of it on the walk stream / the host: it runs
+            beside whatever the compute stream is doing."""
+            t0 = time.perf_counter()
+            if not issued:
+                issue(gl)
             counts = []
             tc = 0.0
             for g in gl:
@@ -425,13 +431,27 @@ def main():
                 for _ in range(n):
                     run(copies[0], prepare(copies[0], record), record)
                 return
-            bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares its successor)
+            # depth D: while the launches of step k run, the walks of step k + D are on the walk stream and the counts / exchange of step k + 1 are
+            # finished on the host.  D = 1 is the form of rounds 3-4 (profiles/r05_step_timeline.txt: beside a k_simulate that fills the device the
+            # low-priority site scan of the next walk ends when that kernel ends, the fifteen small kernels behind it -- 0.2 ms -- run in the gap, and
+            # the next launch is enqueued after them: 0.31 ms of a 5.95 ms step); with D = 2 the next step's launch is always in the queue
+            D, C = args.depth, len(copies)
+            bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares one successor)
+            for d in range(1, D):
+                issue(copies[d % C])
             barrier()
             t0 = time.perf_counter()
             for k in range(n):
-                nx = copies[(k + 1) & 1]
-                bases = run(copies[k & 1], bases, record, then=lambda: prepare(nx, record), carry=not args.no_carry)
+                far, nx = copies[(k + D) % C], copies[(k + 1) % C]
+                def then():
+                    if D > 1:
+                        issue(far)                                   # the copy step k - 1 read: its launches have been waited for (run)
+                    return prepare(nx, record, issued=D > 1)
+                bases = run(copies[k % C], bases, record, then=then, carry=not args.no_carry)
             drain(0, record)
+            for d in range(1, D):                                    # (walks issued for steps beyond the last: waited for, inside the timed region)
+                for g in copies[(n + d) % C]:
+                    ctx.mutate_wait(g["h0"])
             return t0
 
         steps(warmup, False)
@@ -517,7 +537,7 @@ def main():
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{sname} ({args.workload}): {len(job)} uniform-random contig(s) in {len(groups)} resident group(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {job_flags}, "
                                    f"{job_pairs} pairs per job; step = mutation walk of every contig + all pairs of this rank's read-index ranges, FASTQ text left in HBM; " +
-                                   ("every step prepares itself before its first launch" if args.no_pipeline else "the walk, random-read count and exchange of step k+1 run on the walk stream beside the kernels of step k (contigs resident twice)"),
+                                   ("every step prepares itself before its first launch" if args.no_pipeline else f"the walk of step k+{args.depth} and the random-read count and exchange of step k+1 run on the walk stream / the host beside the kernels of step k (contigs resident {args.depth + 1} times)"),
                        "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
                        "random_pairs": stats["n_random"],
                        "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), one host-side all-gather of integers per step" if world > 1 else "one GPU")},
