@@ -425,11 +425,14 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         // they leave -- the thinning tail of every launch -- instead of taking slots from them
         int prio_least = 0, prio_greatest = 0;
         HIPC(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        HIPC(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest));
+        // (DWGSIM_HIP_WALK_PRIO=high|mid|above: analysis -- the walk stream at the batches' priority, between the two, or the batches below the walk)
+        int prio_walk = prio_least, prio_batch = prio_greatest;
+        if (const char *e = getenv("DWGSIM_HIP_WALK_PRIO")) {
+            prio_walk = !strcmp(e, "high") || !strcmp(e, "above") ? prio_greatest : !strcmp(e, "mid") ? (prio_least + prio_greatest) / 2 : prio_least;
+            if (!strcmp(e, "above")) prio_batch = prio_least;
+        }
+        HIPC(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_batch));
         HIPC(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamDefault, prio_greatest));
-        // (DWGSIM_HIP_WALK_PRIO=high|mid: analysis -- the walk stream at the batches' priority or between the two)
-        int prio_walk = prio_least;
-        if (const char *e = getenv("DWGSIM_HIP_WALK_PRIO")) prio_walk = !strcmp(e, "high") ? prio_greatest : !strcmp(e, "mid") ? (prio_least + prio_greatest) / 2 : prio_least;
         HIPC(c, hipStreamCreateWithPriority(&c->walk_stream, hipStreamDefault, prio_walk));
         HIPC(c, hipEventCreate(&c->ev_up)); HIPC(c, hipEventCreate(&c->ev_cnt0)); HIPC(c, hipEventCreate(&c->ev_cnt1));
         HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));

@@ -7,11 +7,13 @@
 #ifndef DW_DEV
 #define DW_DEV __device__ __forceinline__
 #endif
-// a device function that is called, not inlined (rare paths whose copies at every use would crowd the instruction cache)
-#ifdef DW_INLINE_RARE          // (analysis builds: the rare paths inlined as in rounds 1-4)
-#define DW_DEV_NOINLINE __device__ __forceinline__
-#else
+// The rare paths of k_simulate (the ragged first / last unit of a record, the exact fp64 quality try).  Inlined at every use they make up a third of
+// the kernel's code (94 KB against 57 KB when they are called); measured on one box the called form is 1 % SLOWER at 2 x 150 -o 1 and 0.5 % faster
+// at -o 0 (profiles/r05_bench_lines_final.txt): the instruction cache is not what holds the kernel back.  -DDW_CALL_RARE builds the called form.
+#ifdef DW_CALL_RARE
 #define DW_DEV_NOINLINE __device__ __attribute__((noinline))
+#else
+#define DW_DEV_NOINLINE __device__ __forceinline__
 #endif
 // dynamic LDS of a kernel
 #define DW_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) type name[]

@@ -742,8 +742,7 @@ struct Writer {               // sequential byte stream of one record -> 16-byte
 // profiles/r04_variants_pmc.txt).  dstb + p is where FIFO position p goes in the BFAST stream; bdone = the first position the BFAST stream has
 // not written yet (it differs from skip only between the suffix and the next drain: the suffix's own two characters are jumped over).
 // bytes [from, upto) of a unit (the ragged first / last unit of a record) from the FIFO at f to dst: rising sizes until the position is aligned (or the
-// next piece would pass upto), then falling sizes.  NOT inlined: it runs once or twice per record, and inlined at every append it made up a third of
-// k_simulate's code (94 KB against a 64 KB instruction cache; 61 KB without)
+// next piece would pass upto), then falling sizes.  (DW_DEV_NOINLINE: dw_intrin.hpp)
 template <uint32_t BURST>
 DW_DEV_NOINLINE void fifo_store_range(const uint8_t *f, uint8_t *dst, uint32_t from, uint32_t upto)
 {
@@ -819,6 +818,10 @@ struct FifoWriter {
         Unal8 x; x.v = v; *reinterpret_cast<Unal8 *>(f + wp) = x;
         wp += cnt; if (wp >= BURST) drain();
     }
+    // two characters written `off` (<= 6) places past the write position without moving it, then advance(n): how the quality line lays down the (up to
+    // four) pairs of characters a Philox block delivers -- a rejected try's pair is simply overwritten by the next one's
+    DW_DEV void poke2(uint32_t off, uint32_t v) { if (probe::off(1)) return; Unal2 x; x.v = (uint16_t)v; *reinterpret_cast<Unal2 *>(f + wp + off) = x; }
+    DW_DEV void advance(uint32_t n) { if (probe::off(1)) return; wp += n; if (wp >= BURST) drain(); }
     // one character, then cnt (1 .. 8) more: two overlapping stores, one step (the nine bytes end at position wp + 8 <= BURST + 7: inside the FIFO)
     DW_DEV void put_lead8(uint32_t lead, uint64_t v, uint32_t cnt)
     {

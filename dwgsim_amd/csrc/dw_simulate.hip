@@ -35,6 +35,9 @@
 #define DW_PRIO_DROP 1       // where a wave of the single kernel gives up its raised issue priority: 0 = once its block's look-backs are resolved, 1 = after
                              // the name line that follows them (profiles/r04_split.txt section 5: 5.84 -> 5.75 ms at 2 x 150 bp, Ion Torrent unchanged)
 #endif
+#ifndef DW_QUAL_FIFO
+#define DW_QUAL_FIFO 1       // the quality line's pairs of characters placed by two-byte LDS stores (quality_line_fifo); 0: compacted in registers as in rounds 2-4
+#endif
 #ifndef DW_SIM_WAVES_BOTH
 #define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0) through two register writers (WR = 0; through the FIFO one image serves both)
 #endif
@@ -271,7 +274,7 @@ DW_DEV void quality_try_exact(uint32_t w, double sigma, bool &ok, int32_t &k0, i
     k0 = (int32_t)(((v2 * fac) * sigma) + 0.5);
     k1 = (int32_t)(((v1 * fac) * sigma) + 0.5);
 }
-// (the same as a called function for the read kernels: four inlined copies per quality block were 3 KB of code that one block in ten runs; an accepted try)
+// (the same for the read kernels, an accepted try; DW_DEV_NOINLINE: dw_intrin.hpp)
 DW_DEV_NOINLINE uint64_t quality_try_exact_called(uint32_t w, double sigma)
 {
     bool ok; int32_t k0 = 0, k1 = 0;
@@ -377,6 +380,48 @@ DW_DEV void for_each_quality_block(const SimParams &p, RngKey key, uint32_t dom,
         const uint32_t nb = quality_block(b, ql, p.quality_std, qbw, nq, pos, blk);
         deliver(blk, nb, pos);
         pos += (int)nb;
+    }
+}
+
+// The same line through the FIFO writer (dw_read.hpp FifoWriter): the pair of characters of each of a block's four tries goes straight to its place
+// in the FIFO -- an unaligned two-byte LDS store `accepted tries so far` x 2 places past the write position, a rejected try's pair overwritten by the
+// next one's --, its two base qualities are picked from the eight loaded in front of the draws by one v_perm_b32 at the same offset: no compaction of the
+// accepted pairs in registers (rounds 2-4: seven 64-bit shifts, selects and masks per block -- the LDS does the byte placement here as it does for every
+// append).  (Loading the base qualities pair by pair at their final offsets, after the draws, exposed four LDS round trips per block: the VALU count
+// fell by 5 % and the time did not, profiles/r05_bench_lines_final.txt.)
+template <class W>
+DW_DEV void quality_line_fifo(W &w, const SimParams &p, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, const uint32_t *qbw, int nq, int n_chars)
+{
+    if (p.fixed_quality >= 0 || !(0 < p.quality_std)) { for_each_quality_block(p, key, dom, ii, att, qbw, nq, n_chars, false, [&](uint64_t blk, uint32_t nb) { w.putn(blk, nb); }); return; }
+    const QualLazy ql{p.q_k, p.q_eps, p.q_lmin, p.q_near1};
+    int pos = 0; uint32_t t = 0;
+    while (pos < n_chars) {
+        // the base qualities of the (up to eight) positions this block can fill: loaded before the draws, whose arithmetic hides the LDS round trip
+        // (positions >= nq reuse the last entry: the table holds eight copies of it behind the nq)
+        const int pc = pos < nq ? pos : nq;
+        const uint32_t q0 = qbw[pc >> 2], q1 = qbw[(pc >> 2) + 1], q2w = qbw[(pc >> 2) + 2];
+        const U4 b = rng_block(key, dom, ii, att, 0, t++);
+        const uint32_t wd[4] = {b.x, b.y, b.z, b.w};
+        int32_t k[8]; uint32_t acc = 0, need = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t r = quality_try_lazy(wd[q], ql, k[2 * q], k[2 * q + 1]); acc |= (r & 1u) << q; need |= (r >> 1) << q; }
+        if (need) {                              // rare: the reference's own arithmetic decides (quality_block)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if ((need >> q) & 1u) { const uint64_t kk = quality_try_exact_called(wd[q], p.quality_std); k[2 * q] = (int32_t)(uint32_t)kk; k[2 * q + 1] = (int32_t)(uint32_t)(kk >> 32); }
+        }
+        const uint32_t qlo = __builtin_amdgcn_alignbyte(q1, q0, (uint32_t)pc & 3u), qhi = __builtin_amdgcn_alignbyte(q2w, q1, (uint32_t)pc & 3u);
+        uint32_t off = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t q2 = lut8(qhi, qlo, off * 0x0101u + 0x0100u);       // bytes off, off + 1 of the eight (one v_perm_b32)
+            int32_t qa = (int8_t)((int32_t)(int8_t)(q2 & 0xffu) + k[2 * q]), qc = (int8_t)((int32_t)(int8_t)((q2 >> 8) & 0xffu) + k[2 * q + 1]);
+            qa = qa < 33 ? 33 : qa > 73 ? 73 : qa; qc = qc < 33 ? 33 : qc > 73 ? 73 : qc;
+            w.poke2(off, (uint32_t)qa | ((uint32_t)qc << 8));
+            off += ((acc >> q) & 1u) ? 2u : 0u;
+        }
+        const int left = n_chars - pos;
+        w.advance((int)off < left ? off : (uint32_t)left);
+        pos += (int)off;
     }
 }
 
@@ -840,8 +885,11 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         if (SPLIT == 0 && DW_PRIO_DROP == 1) wave_priority(0);      // (a wave none of whose lanes has a record)
         DW_PROBE_MARK(a, 5); // sequence line
         // qualities (dwgsim.c:899-918): up to eight characters per Philox block of the read end's try stream, appended as they come
-        if (rec) for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false,
+        if (rec) {
+            if constexpr (WR != 0 && DW_QUAL_FIFO) quality_line_fifo(o.a, a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out);
+            else for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false,
                                         [&](uint64_t blk, uint32_t nb) { o.putn(blk, nb); });
+        }
         if (rec) { o.put('\n'); o.flush(); }
     }
     DW_PROBE_MARK(a, 6);     // quality line

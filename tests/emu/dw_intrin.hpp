@@ -7,7 +7,7 @@
 #ifndef DW_DEV
 #define DW_DEV __device__ __forceinline__
 #endif
-#define DW_DEV_NOINLINE __device__ __attribute__((noinline))
+#define DW_DEV_NOINLINE __device__ __forceinline__
 #define DW_DYN_SHARED(type, name) type *name = (type *)hipemu::dyn_shared()
 #define DW_CONST_AS
 
