@@ -36,7 +36,9 @@
                              // the name line that follows them (profiles/r04_split.txt section 5: 5.84 -> 5.75 ms at 2 x 150 bp, Ion Torrent unchanged)
 #endif
 #ifndef DW_QUAL_FIFO
-#define DW_QUAL_FIFO 1       // the quality line's pairs of characters placed by two-byte LDS stores (quality_line_fifo); 0: compacted in registers as in rounds 2-4
+#define DW_QUAL_FIFO 0       // 1: the quality line's pairs of characters placed by two-byte LDS stores (quality_line_fifo); 0: compacted in registers as in rounds
+                             // 2-4.  Measured (profiles/r05_bench_lines_final.txt, one box each): 14.0 k -> 13.2-13.5 k VALU per wave, but four more LDS accesses per
+                             // block (SQ_WAIT_INST_LDS x 4, bank conflicts x 4): 2 x 150 -o 1 1 % SLOWER, E. coli-sized 7 % slower, -o 0 and 2 x 250 equal: not adopted
 #endif
 #ifndef DW_SIM_WAVES_BOTH
 #define DW_SIM_WAVES_BOTH 4  // ... when both output families are written (-o 0) through two register writers (WR = 0; through the FIFO one image serves both)

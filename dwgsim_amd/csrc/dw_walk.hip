@@ -18,6 +18,7 @@
 // Byte/integer work only: no MFMA.  Host-callable launchers (dw_launch.hpp) are at the end.
 #include "dw_device.hpp"
 #include "dw_launch.hpp"
+#include <stdlib.h>
 
 namespace dw {
 
@@ -102,24 +103,27 @@ __global__ void k_site_scan(const uint8_t *__restrict__ ref, SegTab seg, WalkPar
 // of a whole-genome walk and grows with the group.  status: one word per block, ticket: one word, both zeroed by the host; total -> *n_out.
 // A block takes SITE_TILES tiles of SCAN_POS_PER_BLOCK positions (each tile inside one contig): 65 536 positions per look-back -- with one tile per block
 // the chain of look-backs (a hop of at most 64 blocks per memory round trip) was slower than the draws: 4.6 ms per 1.5 Gb group, 0.4 ms worth of work.
-constexpr int SITE_TILES = 16;
-__global__ void __launch_bounds__(SCAN_THREADS) k_site_scan_list(const uint8_t *__restrict__ refview, int64_t l_total, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket,
+// 1024 lanes per block: four tiles at a time, four rounds -- the same 65 536 positions per look-back with a quarter of the serial work per lane (with 256
+// lanes and sixteen tiles in a row a 64 Mb contig was 983 blocks of 50 us each on a device that holds 2 048: 90 us for 17 us' worth of draws).
+constexpr int SITE_TILES = 16, SITE_THREADS = 1024, SITE_ROUNDS = SITE_TILES / (SITE_THREADS / SCAN_THREADS);
+__global__ void __launch_bounds__(SITE_THREADS) k_site_scan_list(const uint8_t *__restrict__ refview, int64_t l_total, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket,
                                                               int32_t *__restrict__ out, uint32_t cap, uint64_t *n_out, uint32_t n_blocks)
 {
-    __shared__ uint32_t sm[SITE_TILES][16];
+    __shared__ uint32_t sm[SITE_ROUNDS][16];
     __shared__ uint32_t s_t; __shared__ uint64_t s_base;
     if (threadIdx.x == 0) s_t = (uint32_t)atomicAdd((unsigned long long *)ticket, 1ull);
     __syncthreads();
     const uint32_t t = uniform_u32(s_t);
-    uint32_t bits[SITE_TILES], cnt[SITE_TILES], off[SITE_TILES], tot[SITE_TILES], block_total = 0;
+    const int sub = (int)(threadIdx.x / SCAN_THREADS), tin = (int)(threadIdx.x % SCAN_THREADS);      // which of the round's tiles, and where in it
+    uint32_t bits[SITE_ROUNDS], cnt[SITE_ROUNDS], off[SITE_ROUNDS], tot[SITE_ROUNDS], block_total = 0;
 #pragma unroll
-    for (int q = 0; q < SITE_TILES; ++q) {
-        const int64_t tile0 = ((int64_t)t * SITE_TILES + q) * SCAN_POS_PER_BLOCK;
+    for (int q = 0; q < SITE_ROUNDS; ++q) {
+        const int64_t tile0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK;
         bits[q] = 0;
-        if (tile0 < l_total) {                                                   // (block-uniform)
+        if (tile0 < l_total) {                                                   // (uniform over the tile's four waves)
             const uint32_t sk = seg_of(seg, tile0);                              // a tile's positions lie inside one contig: contigs start at multiples of GROUP_ALIGN
             const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
-            const int64_t g0 = tile0 + (int64_t)threadIdx.x * SCAN_POS_PER_THREAD;
+            const int64_t g0 = tile0 + (int64_t)tin * SCAN_POS_PER_THREAD;
             const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];              // position inside the contig: what the draws are indexed by
             if (p0 < l) {
                 const uint64_t v = *reinterpret_cast<const uint64_t *>(refview + (g0 >> 1));      // sixteen nibbles (the view is padded: reading past l is safe)
@@ -131,18 +135,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_site_scan_list(const uint8_t *
         }
         cnt[q] = (uint32_t)__popc(bits[q]);
     }
-    block_excl_scan_n<SITE_TILES>(cnt, sm, off, tot);      // sixteen block-wide scans behind one barrier
+    block_excl_scan_n<SITE_ROUNDS>(cnt, sm, off, tot);      // a round's lanes stand in position order (tile by tile): four block-wide scans behind one barrier
 #pragma unroll
-    for (int q = 0; q < SITE_TILES; ++q) { off[q] += block_total; block_total += tot[q]; }
+    for (int q = 0; q < SITE_ROUNDS; ++q) { off[q] += block_total; block_total += tot[q]; }
     if (threadIdx.x < 64) {
         const uint64_t g = lookback_excl(status, t, block_total, 0);
         if (threadIdx.x == 0) { s_base = g; if (t + 1 == n_blocks) *n_out = g + block_total; }
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < SITE_TILES; ++q) {
+    for (int q = 0; q < SITE_ROUNDS; ++q) {
         uint64_t at = s_base + off[q]; uint32_t bq = bits[q];
-        const int64_t g0 = ((int64_t)t * SITE_TILES + q) * SCAN_POS_PER_BLOCK + (int64_t)threadIdx.x * SCAN_POS_PER_THREAD;
+        const int64_t g0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK + (int64_t)tin * SCAN_POS_PER_THREAD;
         while (bq) { const int b = __ffs((int)bq) - 1; bq &= bq - 1; if (at < cap) out[at] = (int32_t)(g0 + b); ++at; }   // (past the capacity: the host re-runs)
     }
 }
@@ -164,19 +168,27 @@ __global__ void k_mark_dirty(const Event *__restrict__ ev, Count nc, const int32
     const int64_t a = (int64_t)(lo[k] < e.pos ? lo[k] : e.pos) >> 6, b = right >> 6;
     for (int64_t q = a; q <= b; ++q) atomicOr(&dirty[q >> 5], 1u << (q & 31));
 }
-// one thread per word of the bitmap = 32 chunks = 2048 cells = two words of the coarse summaries.  RESTORE = false: views + summaries from the cells;
-// true: cells, views and summaries from the pristine copies.
-template <bool RESTORE>
+// one LANE per chunk; a word of the bitmap = 32 chunks = 2048 cells = two words of the coarse summaries is half a wave, and a coarse word's sixteen fine
+// words are summed across its sixteen lanes.  (One thread per bitmap word -- 31 k threads for a 64 Mb contig, each walking its word's chunks in turn --
+// took 97 us of a 0.3 ms walk.)  RESTORE = false: views + summaries from the cells; true: cells, views and summaries from the pristine copies.
+template <bool RESTORE, bool PER_CHUNK>
 __global__ void __launch_bounds__(256) k_dirty_chunks(const uint32_t *__restrict__ dirty, uint32_t n_words, int64_t l_live, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ refview,
                                                       const uint16_t *__restrict__ refsumm, const uint16_t *__restrict__ refsumm2,
                                                       uint8_t *__restrict__ cells0, uint8_t *__restrict__ cells1, uint8_t *__restrict__ view0, uint8_t *__restrict__ view1,
                                                       uint16_t *__restrict__ summ0, uint16_t *__restrict__ summ1, uint16_t *__restrict__ summ2_0, uint16_t *__restrict__ summ2_1)
 {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-    if (w >= n_words) return;
-    uint32_t bits = dirty[w];
-    if (!bits) return;
-    const uint32_t touched = bits;
+    // PER_CHUNK: a lane per chunk (small groups: the kernel is latency, not throughput -- 97 -> 59 us for a 64 Mb contig); otherwise a thread per word of
+    // the bitmap that takes the word's dirty chunks in turn (large groups: a wave's lanes all have work; a lane per chunk there runs the chunk code
+    // for two lanes of a wave at a time: 0.43 -> 1.18 ms per 1.5 Gb group)
+    const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t w = PER_CHUNK ? (uint32_t)(gid >> 5) : (uint32_t)gid;
+    const bool in = w < n_words;
+    const uint32_t touched = in ? dirty[w] : 0u;
+    if (PER_CHUNK) { if (!__ballot(touched != 0u)) return; }    // (wave-uniform: neither of the wave's two words has a dirty chunk)
+    else if (!touched) return;
+    uint32_t bits = PER_CHUNK ? ((touched >> (gid & 31u)) & 1u) << (gid & 31u) : touched;      // the chunks of the word this thread takes
+    uint32_t fine[2] = {0u, 0u};                               // (PER_CHUNK) this lane's chunk's fine summaries as they stand after this kernel
+    const bool mine = bits != 0u;
     while (bits) {
         const int q = __ffs((int)bits) - 1; bits &= bits - 1;
         const int64_t ch = (int64_t)w * 32 + q, first = ch * SUMM_CELLS;
@@ -216,25 +228,47 @@ __global__ void __launch_bounds__(256) k_dirty_chunks(const uint32_t *__restrict
                     }
                     *reinterpret_cast<uint4 *>(view + ((first + 32 * half) >> 1)) = make_uint4(out[0], out[1], out[2], out[3]);
                 }
-                (h ? summ1 : summ0)[ch] = (uint16_t)(indel | (non_acgt ? 0x8000u : 0u));
+                fine[h] = indel | (non_acgt ? 0x8000u : 0u);
+                (h ? summ1 : summ0)[ch] = (uint16_t)fine[h];
             }
         }
     }
     // the coarse summaries (SUMM2_CELLS cells = 16 chunks) that hold a dirty chunk: from their sixteen fine words
+    static_assert(SUMM2_CELLS / SUMM_CELLS == 16, "a coarse summary = the sixteen lanes of half a bitmap word");
+    if (!PER_CHUNK) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (!((touched >> (16 * half)) & 0xFFFFu)) continue;
-        const int64_t s2 = (int64_t)w * 2 + half;
-        if (s2 * SUMM2_CELLS >= l_live) continue;
-        if (RESTORE) { const uint16_t sv = refsumm2[s2]; summ2_0[s2] = sv; summ2_1[s2] = sv; }
-        else {
+        for (int half = 0; half < 2; ++half) {
+            if (!((touched >> (16 * half)) & 0xFFFFu)) continue;
+            const int64_t s2 = (int64_t)w * 2 + half;
+            if (s2 * SUMM2_CELLS >= l_live) continue;
+            if (RESTORE) { const uint16_t sv = refsumm2[s2]; summ2_0[s2] = sv; summ2_1[s2] = sv; }
+            else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint16_t *sm1 = h ? summ1 : summ0;
-                uint32_t cnt = 0, fl = 0;
-                for (int k = 0; k < SUMM2_CELLS / SUMM_CELLS; ++k) { const int64_t ch = s2 * (SUMM2_CELLS / SUMM_CELLS) + k; if (ch * SUMM_CELLS < l_live) { const uint32_t v = sm1[ch]; cnt += v & 0x7fffu; fl |= v & 0x8000u; } }
-                (h ? summ2_1 : summ2_0)[s2] = (uint16_t)(cnt | fl);
+                for (int h = 0; h < 2; ++h) {
+                    const uint16_t *sm1 = h ? summ1 : summ0;
+                    uint32_t cnt = 0, fl = 0;
+                    for (int k = 0; k < SUMM2_CELLS / SUMM_CELLS; ++k) { const int64_t c2 = s2 * (SUMM2_CELLS / SUMM_CELLS) + k; if (c2 * SUMM_CELLS < l_live) { const uint32_t v = sm1[c2]; cnt += v & 0x7fffu; fl |= v & 0x8000u; } }
+                    (h ? summ2_1 : summ2_0)[s2] = (uint16_t)(cnt | fl);
+                }
             }
+        }
+        return;
+    }
+    // ... one fine word per lane of the half-word, summed across the sixteen lanes
+    const int q = (int)(gid & 31u);
+    const int64_t ch = (int64_t)w * 32 + q;
+    const int64_t s2 = (int64_t)w * 2 + (q >> 4);
+    const bool live2 = in && ((touched >> (16 * (q >> 4))) & 0xFFFFu) != 0u && s2 * SUMM2_CELLS < l_live;
+    if (RESTORE) { if (live2 && (q & 15) == 0) { const uint16_t sv = refsumm2[s2]; summ2_0[s2] = sv; summ2_1[s2] = sv; } }
+    else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t v = 0;
+            if (live2 && ch * SUMM_CELLS < l_live) v = mine ? fine[h] : (uint32_t)(h ? summ1 : summ0)[ch];
+            uint32_t cnt = v & 0x7fffu, fl = v & 0x8000u;
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, m); fl |= (uint32_t)__shfl_xor((int)fl, m); }      // (every lane of the wave shuffles)
+            if (live2 && (q & 15) == 0) (h ? summ2_1 : summ2_0)[s2] = (uint16_t)(cnt | fl);
         }
     }
 }
@@ -712,7 +746,7 @@ void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg,
 void launch_site_scan_list(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket, int32_t *out, uint32_t cap, uint64_t *n_out)
 {
     const uint32_t nb = (uint32_t)cdiv((uint64_t)l, (uint64_t)SCAN_POS_PER_BLOCK * SITE_TILES);
-    hipLaunchKernelGGL(k_site_scan_list, dim3(nb), dim3(SCAN_THREADS), 0, st, refview, l, seg, wp, status, ticket, out, cap, n_out, nb);
+    hipLaunchKernelGGL(k_site_scan_list, dim3(nb), dim3(SITE_THREADS), 0, st, refview, l, seg, wp, status, ticket, out, cap, n_out, nb);
 }
 void launch_mark_dirty(hipStream_t st, const Event *ev, Count n, const int32_t *lo, uint32_t *dirty)
 {
@@ -722,8 +756,13 @@ void launch_dirty_chunks(hipStream_t st, bool restore, const uint32_t *dirty, ui
                          uint8_t *cells0, uint8_t *cells1, uint8_t *view0, uint8_t *view1, uint16_t *summ0, uint16_t *summ1, uint16_t *summ2_0, uint16_t *summ2_1)
 {
     if (!n_words) return;
-    if (restore) hipLaunchKernelGGL(k_dirty_chunks<true>, dim3(cdiv(n_words, 256)), dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1);
-    else hipLaunchKernelGGL(k_dirty_chunks<false>, dim3(cdiv(n_words, 256)), dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1);
+    // a lane per chunk while that is at most 2^21 lanes (groups of up to 128 Mb: where the two forms meet, 0.29 us per Mb + 80 us against 0.79 us per Mb);
+    // a thread per bitmap word beyond (k_dirty_chunks).  DWGSIM_HIP_DIRTY_MAP=word|chunk forces either (tests)
+    bool per_chunk = (uint64_t)n_words * 32 <= (1ull << 21);
+    if (const char *e = getenv("DWGSIM_HIP_DIRTY_MAP")) per_chunk = e[0] == 'c';
+    const dim3 grid(cdiv((uint64_t)n_words * (per_chunk ? 32 : 1), 256));
+    if (restore) { if (per_chunk) hipLaunchKernelGGL((k_dirty_chunks<true, true>), grid, dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1); else hipLaunchKernelGGL((k_dirty_chunks<true, false>), grid, dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1); }
+    else { if (per_chunk) hipLaunchKernelGGL((k_dirty_chunks<false, true>), grid, dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1); else hipLaunchKernelGGL((k_dirty_chunks<false, false>), grid, dim3(256), 0, st, dirty, n_words, l_live, ref, refview, refsumm, refsumm2, cells0, cells1, view0, view1, summ0, summ1, summ2_0, summ2_1); }
 }
 void launch_scan_excl(hipStream_t st, uint32_t *data, uint32_t n, uint64_t *total_out)
 {

@@ -160,9 +160,20 @@ def test_both_record_writers(lib, oracle_bin, tmp_path, k):
     check_record_writers(lib, oracle_bin, str(tmp_path), *WRITER_CASES[k])
 
 
-def test_walking_a_contig_again(lib, golden_dir):
+@pytest.mark.parametrize("dirty_map", ["chunk", "word"])
+def test_walking_a_contig_again(lib, golden_dir, monkeypatch, dirty_map):
+    """... with both mappings of k_dirty_chunks (a lane per chunk: small groups; a thread per bitmap word: groups beyond 128 Mb)"""
     from parity_common import check_walking_a_contig_again
+    monkeypatch.setenv("DWGSIM_HIP_DIRTY_MAP", dirty_map)
     check_walking_a_contig_again(lib, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 3 -X 0.6", n=600)
+
+
+def test_both_mappings_of_the_dirty_chunk_kernel(lib, oracle_bin, golden_dir, monkeypatch):
+    """parity of a mutation-rich job and of count_random (the summaries k_place reads) with the thread-per-word form that large groups take"""
+    from parity_common import check_count_random_matches_simulate
+    monkeypatch.setenv("DWGSIM_HIP_DIRTY_MAP", "word")
+    compare_case(lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 8 -N 3000 -1 50 -2 35 -d 300 -r 0.05 -R 0.5 -X 0.6 -y 0.1")
+    check_count_random_matches_simulate(lib, os.path.join(golden_dir, "odd.fa"), "-z 6 -C 3 -1 40 -2 40 -d 150 -s 10 -r 0.08 -R 0.8 -X 0.6 -n 1 -y 0.1")
 
 
 def test_gzip_kernel_on_hard_inputs(lib):
