@@ -327,7 +327,11 @@ def main():
         # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
         # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
         copies = []
-        for _copy in range(1 if args.no_pipeline else args.depth + 1):
+        # (ranks that SHARE one GPU -- the readiness runs of the N-rank paths on one-GPU boxes -- hold the whole-genome job once and prepare every step in
+        # front of its launches: eight ranks x two or three copies of 17 GB + their output slots are more than the one device has)
+        depth = args.depth
+        no_pipeline = args.no_pipeline or (args.share_gpu and world > 2 and workload == "grch38")
+        for _copy in range(1 if no_pipeline else depth + 1):
             gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
             for grp in make_groups(job, group_bp):
                 h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
@@ -427,7 +431,7 @@ def main():
             return nxt
 
         def steps(n, record):
-            if args.no_pipeline:
+            if no_pipeline:
                 for _ in range(n):
                     run(copies[0], prepare(copies[0], record), record)
                 return
@@ -435,7 +439,7 @@ def main():
             # finished on the host.  D = 1 is the form of rounds 3-4 (profiles/r05_step_timeline.txt: beside a k_simulate that fills the device the
             # low-priority site scan of the next walk ends when that kernel ends, the fifteen small kernels behind it -- 0.2 ms -- run in the gap, and
             # the next launch is enqueued after them: 0.31 ms of a 5.95 ms step); with D = 2 the next step's launch is always in the queue
-            D, C = args.depth, len(copies)
+            D, C = depth, len(copies)
             bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares one successor)
             for d in range(1, D):
                 issue(copies[d % C])

@@ -35,6 +35,10 @@
 #define DW_PRIO_DROP 1       // where a wave of the single kernel gives up its raised issue priority: 0 = once its block's look-backs are resolved, 1 = after
                              // the name line that follows them (profiles/r04_split.txt section 5: 5.84 -> 5.75 ms at 2 x 150 bp, Ion Torrent unchanged)
 #endif
+#ifndef DW_SOLID_WAVES
+#define DW_SOLID_WAVES 4     // minimum waves per SIMD requested for the SOLiD variants: without a hint (1) the round-5 kernel takes 152 registers = three waves (126 in
+                             // round 4); capped at 128 it spills 20-46 registers and is 11-33 % FASTER (2 x 50 -o 0 / -o 1 / 75 + 35 -o 2: profiles/r05_bench_lines_final.txt section 7)
+#endif
 #ifndef DW_QUAL_FIFO
 #define DW_QUAL_FIFO 0       // 1: the quality line's pairs of characters placed by two-byte LDS stores (quality_line_fifo); 0: compacted in registers as in rounds
                              // 2-4.  Measured (profiles/r05_bench_lines_final.txt, one box each): 14.0 k -> 13.2-13.5 k VALU per wave, but four more LDS accesses per
@@ -480,7 +484,7 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
 // block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
 // block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
 template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? 1 : SPLIT == 2 ? DW_SIMB_WAVES : (OUT != 3 || WR != 0) ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? DW_SOLID_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : (OUT != 3 || WR != 0) ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     static_assert(SPLIT == 0 || ((DT == 0 || DT == 3) && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants and for Ion Torrent with its buffers in LDS, 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
