@@ -484,7 +484,7 @@ DW_DEV void scratch_slot_release(uint64_t *ff, uint32_t n_blocks, uint32_t slot)
 // block stands still until every block in front of it has published its sizes, and the spread of their arrival times (a few per cent of a
 // block's life, amplified by the maximum over the hundreds of blocks in flight) cost 0.8-0.9 of 5.96 ms (profiles/r04_knockouts.txt).
 template <int LPP, int OUT, int DT, int NTHR = SIM_THREADS, int WR = 1, int SPLIT = 0>
-__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? 1 : DT == 2 ? DW_ION_WAVES : DT == 1 ? DW_SOLID_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : (OUT != 3 || WR != 0) ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
+__global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : DW_IONL_WAVES) : NTHR != SIM_THREADS ? (DT == 1 ? DW_SOLID_WAVES : 1) : DT == 2 ? DW_ION_WAVES : DT == 1 ? DW_SOLID_WAVES : SPLIT == 2 ? DW_SIMB_WAVES : (OUT != 3 || WR != 0) ? DW_SIM_WAVES : DW_SIM_WAVES_BOTH)) k_simulate(SimArgs a)
 {
     static_assert(SPLIT == 0 || ((DT == 0 || DT == 3) && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants and for Ion Torrent with its buffers in LDS, 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
