@@ -258,7 +258,7 @@ def main():
     ap.add_argument("--no-genome-leg", action="store_true", help="skip the end_to_end_genome leg (dwgsim-hip on the whole S4 genome: about a minute, most of it making the synthetic FASTA)")
     ap.add_argument("--flags", default=None, help="analysis only: override the dwgsim flags of the workload (the default is the BASELINE configuration)")
     ap.add_argument("--phases", action="store_true", help="analysis only: print the phase split of the -DDW_PHASE_TIMING build (DWGSIM_HIP_LIB=dwgsim_amd/libdwgsim_hip_phases.so)")
-    ap.add_argument("--depth", type=int, default=2, help="how many steps ahead the walks run (contigs resident depth + 1 times); 1 = the form of rounds 3-4")
+    ap.add_argument("--depth", type=int, default=3, help="how many steps ahead the walks run (contigs resident depth + 2 times)")
     ap.add_argument("--no-carry", action="store_true", help="every step waits for its own launches before the next step's first launch is enqueued (the form of rounds 3-4)")
     ap.add_argument("--no-pipeline", action="store_true", help="every step prepares itself (walk, random-read count, exchange) before its first launch, on one resident copy of the contigs")
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
@@ -323,7 +323,7 @@ def main():
             job.append((name, arr, ci, n))
             n_sim += n
         job_pairs = sum(e[3] for e in job)
-        # Every group is resident depth + 1 TIMES (copies used by consecutive steps in turn): the walk rewrites the haplotypes in place, so the walk + random-read
+        # Every group is resident depth + 2 TIMES (copies used by consecutive steps in turn): the walk rewrites the haplotypes in place, so the walk + random-read
         # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
         # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
         copies = []
@@ -331,7 +331,7 @@ def main():
         # front of its launches: eight ranks x two or three copies of 17 GB + their output slots are more than the one device has)
         depth = args.depth
         no_pipeline = args.no_pipeline or (args.share_gpu and world > 2 and workload == "grch38")
-        for _copy in range(1 if no_pipeline else depth + 1):
+        for _copy in range(1 if no_pipeline else depth + 2):
             gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
             for grp in make_groups(job, group_bp):
                 h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
@@ -408,9 +408,9 @@ def main():
                     stats["sim_kernel_ms"] += b.sim_kernel_ms; stats["launches"] += 1
 
         def run(gl, bases, record, then=None, carry=False):
-            """all launches of this rank for one step, two in flight; `then` (the preparation of the next step) runs once the last one is enqueued and
-            every launch of the step BEFORE has finished (the next step's walk rewrites the copy that step read); carry: leave this step's launches
-            in flight for the next step to wait for"""
+            """all launches of this rank for one step, two in flight; `then` (what is prepared for later steps) runs once the last one is enqueued -- the
+            launches of the step before may still run: the walk issued there rewrites the copy of the step before THAT, whose launches were waited
+            for before this step's first was enqueued; carry: leave this step's launches in flight for the next step to wait for"""
             acc = {"bytes": 0, "rand": 0}
             mine = 0
             first_launch = True
@@ -422,7 +422,6 @@ def main():
                     ctx.simulate_ranges_async(g["launches"][b], base, flight["slot"])
                     flight["pending"].append((flight["slot"], acc)); flight["slot"] ^= 1
                     mine += 1
-            drain(min(mine, 2), record)          # what is left in flight belongs to this step
             nxt = then() if then else None
             if not carry:
                 drain(0, record)
@@ -435,10 +434,12 @@ def main():
                 for _ in range(n):
                     run(copies[0], prepare(copies[0], record), record)
                 return
-            # depth D: while the launches of step k run, the walks of step k + D are on the walk stream and the counts / exchange of step k + 1 are
-            # finished on the host.  D = 1 is the form of rounds 3-4 (profiles/r05_step_timeline.txt: beside a k_simulate that fills the device the
-            # low-priority site scan of the next walk ends when that kernel ends, the fifteen small kernels behind it -- 0.2 ms -- run in the gap, and
-            # the next launch is enqueued after them: 0.31 ms of a 5.95 ms step); with D = 2 the next step's launch is always in the queue
+            # depth D: once the launches of step k are enqueued (those of step k - 1 still run), the walks of step k + D go onto the walk stream and the
+            # counts / exchange of step k + 1 are finished on the host.  Beside a k_simulate that fills the device nothing else runs
+            # (profiles/r05_step_timeline.txt): what is on the walk stream gets the gaps between two launches, a walk needs two of them, the
+            # random-read count of the ranks (N > 1) one more.  D = 1 with a wait for the walk before the next launch was the form of rounds 3-4:
+            # 0.31 ms between two launches of 5.65 ms; with D = 3 the walk of step k + 1 is finished when step k is enqueued, its count runs in the
+            # gap in front of step k, and the launch of step k + 1 is enqueued while step k runs
             D, C = depth, len(copies)
             bases = prepare(copies[0], False)                       # (the first step's preparation; every timed step prepares one successor)
             for d in range(1, D):
@@ -449,7 +450,7 @@ def main():
                 far, nx = copies[(k + D) % C], copies[(k + 1) % C]
                 def then():
                     if D > 1:
-                        issue(far)                                   # the copy step k - 1 read: its launches have been waited for (run)
+                        issue(far)                                   # the copy step k - 2 read (C = D + 2): its launches were waited for before step k's first was enqueued
                     return prepare(nx, record, issued=D > 1)
                 bases = run(copies[k % C], bases, record, then=then, carry=not args.no_carry)
             drain(0, record)
@@ -541,7 +542,7 @@ def main():
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{sname} ({args.workload}): {len(job)} uniform-random contig(s) in {len(groups)} resident group(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {job_flags}, "
                                    f"{job_pairs} pairs per job; step = mutation walk of every contig + all pairs of this rank's read-index ranges, FASTQ text left in HBM; " +
-                                   ("every step prepares itself before its first launch" if args.no_pipeline else f"the walk of step k+{args.depth} and the random-read count and exchange of step k+1 run on the walk stream / the host beside the kernels of step k (contigs resident {args.depth + 1} times)"),
+                                   ("every step prepares itself before its first launch" if args.no_pipeline else f"the walk of step k+{args.depth} and the random-read count and exchange of step k+1 run on the walk stream / the host beside the kernels of step k (contigs resident {args.depth + 2} times)"),
                        "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
                        "random_pairs": stats["n_random"],
                        "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), one host-side all-gather of integers per step" if world > 1 else "one GPU")},

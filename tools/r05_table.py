@@ -6,8 +6,8 @@ import json, re, sys, os
 d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 rows = [("chr20", "2 × 150 `-o 1` (the bench line)"), ("ecoli", "the same, E. coli-sized contig"), ("o0", "2 × 150 `-o 0`, the reference's default output"), ("solid50", "SOLiD 2 × 50 `-o 0`"),
         ("long2000", "2 000-base reads, single-end"), ("ion", "Ion Torrent 400 bp, E. coli-sized"), ("ion_chr20", "Ion Torrent 400 bp")]
-print("| workload (chr20-sized contig unless said) | kernel(s) | launch (rocprofv3 avg) | bench line | algorithmic | fraction | traffic | VALU + SALU per wave | VALU-active |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("| workload (chr20-sized contig unless said) | kernel(s) | launch (rocprofv3 avg) | algorithmic | fraction | traffic | VALU + SALU per wave | VALU-active |")
+print("|---|---|---|---|---|---|---|---|")
 for name, label in rows:
     p = os.path.join(d, f"r05_{name}_kernel_stats_pmc.txt")
     if not os.path.exists(p): continue
@@ -28,4 +28,4 @@ for name, label in rows:
     traffic = (tot("FETCH_SIZE") * 2 + tot("WRITE_SIZE")) * 1024
     va = 100.0 * tot("SQ_ACTIVE_INST_VALU") * 4 / (1024 * tot("GRBM_GUI_ACTIVE") / 8) if tot("GRBM_GUI_ACTIVE") else float("nan")
     ks = " + ".join(k.replace("void dw::", "").replace(", ", ",") for k in kern)
-    print(f"| {label} | `{ks}` | {' + '.join('%.2f' % (v / 1e3) for v in kern.values())} ms | {bench['value']:.0f} {bench['unit'].replace('M ', 'M ')} | {alg / 1e9:.2f} GB | **{alg / (t_us * 1e-6) / 8e12:.3f}** | {traffic / 1e9:.1f} GB ({traffic / alg:.2f} ×) | {tot('SQ_INSTS_VALU') / waves / 1e3:.1f} k + {tot('SQ_INSTS_SALU') / waves / 1e3:.1f} k | {va:.0f} % |")
+    print(f"| {label} | `{ks}` | {' + '.join('%.2f' % (v / 1e3) for v in kern.values())} ms | {alg / 1e9:.2f} GB | **{alg / (t_us * 1e-6) / 8e12:.3f}** | {traffic / 1e9:.1f} GB ({traffic / alg:.2f} ×) | {tot('SQ_INSTS_VALU') / waves / 1e3:.1f} k + {tot('SQ_INSTS_SALU') / waves / 1e3:.1f} k | {va:.0f} % |")
