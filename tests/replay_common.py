@@ -1,9 +1,15 @@
 """Replay parity (test infrastructure): the UNMODIFIED reference binary fed the Philox stream.
 
 `dwgsim_oracle --rng philox --dump-draws F` writes every uniform of mode B in the order it is consumed; oracle/replay48.c, preloaded into
-oracle/_ref/dwgsim, serves them as drand48().  On configurations that draw no normal (single-end, -Q 0 or -q: the reference's Box-Muller cache
+oracle/_ref/dwgsim, serves them as drand48().  On configurations that draw no normal (single-end; -Q 0 or -q, or an even read length: the reference's Box-Muller cache
 leaks a variate from pair to pair, dwgsim.c:158-159, which a counter-based stream deliberately does not reproduce) the reference must then write
-exactly the files mode B writes -- and so must the HIP path -- and consume exactly the draws that were dumped."""
+exactly the files mode B writes -- and so must the HIP path -- and consume exactly the draws that were dumped.
+
+Round 6: quality NOISE is replayed too where it can be.  ran_normal (dwgsim.c:156-175) draws two uniforms per polar try and delivers two normals per
+accepted try; a single-end read of EVEN length with -Q > 0 takes L normals = L / 2 accepted tries, so the static cache is empty at every read boundary
+and nothing leaks from read to read: the unmodified reference (glibc log) then consumes the 16-bit polar tries of the D_QUAL0 stream exactly
+as mode B does.  This puts the headline quality path (16-bit operands, det_log, lazy fp32 estimates on the GPU) under the reference itself.  Odd lengths
+and paired ends (the insert-size normal shares the cache, dwgsim.c:657) stay on the two-link chain."""
 import gzip, os, random, subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +32,12 @@ REPLAY_CASES = [
     ("odd.fa", f"-z 6 -N 2000 -c 2 -f {FLOW} -1 120 -2 0 -e 0.05 -q 9 -n 10 -r 0.05 -R 0.5 -y 0.2"),
     ("ex1.fa", f"-z 6472 -N 1200 -c 2 -f {FLOW} -1 150 -2 0 -e 0.3 -A 1 -Q 0"),
     ("tiny.fa", "-z 9 -N 1000 -c 2 -f TACG -1 100 -2 0 -e 0.2 -o 1 -Q 0 -r 0.05 -R 0.9"),
+    # even-length single-end reads WITH quality noise (module docstring): the normals of the quality line under the unmodified reference
+    ("tiny.fa", "-z 9 -N 3000 -1 100 -2 0 -Q 2"),
+    ("ex1.fa", "-z 13 -N 3000 -1 150 -2 0 -o 1"),                      # -Q 2 is the default (dwgsim_opt.c:80): the headline read length
+    ("odd.fa", "-z 3 -N 3000 -1 50 -2 0 -Q 10 -r 0.05 -R 0.5 -e 0.001-0.05"),
+    ("tiny.fa", "-z 9 -N 2000 -c 1 -1 50 -2 0 -Q 3 -y 0.1"),
+    ("tiny.fa", "-z 77 -N 2000 -1 36 -2 0 -Q 60 -e 0.3"),              # sigma 60: offsets clamp at both ends of the quality range
     ("tiny.fa", "-z 5 -x {IN}/regions_a.bed -N 2000 -1 70 -2 0 -Q 0"),
     ("tiny.fa", "-z 5 -N 2000 -1 70 -2 0 -q I -m {IN}/muts_edge.txt"),
     ("tiny.fa", "-z 5 -N 2000 -1 70 -2 0 -Q 0 -b {IN}/muts_edge.bed"),
@@ -69,10 +81,13 @@ def random_replay_flags(rng: random.Random):
         l1 = rng.choice([40, 100, 150, 251, 400])           # (long enough to visit every flow: the reference's flow mask persists from read to read, mode B's is per read)
         f += ["-c 2", f"-f {rng.choice(['TACG', FLOW, 'GATC', 'TACGTACGTCTGAGCATCGATCGATGTACAGC'])}", f"-e {rng.choice(['0', '0.001', '0.01', '0.05', '0.2'])}"]
     else:
-        l1 = rng.choice([1, 2, 7, 8, 9, 16, 33, 50, 100, 150, 251])
+        l1 = rng.choice([1, 2, 7, 8, 9, 16, 33, 36, 50, 100, 150, 250, 251])
         if model == "solid": f.append("-c 1")
         if rng.random() < 0.6: f.append(f"-e {rng.choice(['0', '0.001', '0.02', '0.0-0.1', '0.3', '0.05-0.001'])}")
-    f += [f"-1 {l1}", "-2 0", rng.choice(["-Q 0", f"-q {rng.choice(['5', 'I', '!'])}"])]
+    if model != "ion" and l1 % 2 == 0 and rng.random() < 0.6:      # even length: quality noise replays exactly (module docstring)
+        f += [f"-1 {l1}", "-2 0"] + ([f"-Q {rng.choice([0.5, 2, 3.7, 10, 60])}"] if rng.random() < 0.8 else [])      # (no -Q: the default, 2)
+    else:
+        f += [f"-1 {l1}", "-2 0", rng.choice(["-Q 0", f"-q {rng.choice(['5', 'I', '!'])}"])]
     f.append(rng.choice([f"-N {rng.choice([1, 2, 63, 64, 65, 257, 1000, 3000])}", f"-C {rng.choice([0.5, 2, 7])}"]))
     if rng.random() < 0.6: f.append(f"-r {rng.choice([0, 0.0001, 0.001, 0.01, 0.05, 0.3])}")
     if rng.random() < 0.5: f.append(f"-R {rng.choice([0, 0.1, 0.5, 1.0])}")

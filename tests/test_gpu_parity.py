@@ -466,7 +466,8 @@ from replay_common import REPLAY_CASES, have_reference
 @pytest.mark.parametrize("fasta,flags", REPLAY_CASES, ids=[f"{f}:{fl}" for f, fl in REPLAY_CASES])
 def test_hip_path_equals_the_replayed_reference(lib, oracle_bin, golden_dir, tmp_path, fasta, flags):
     """The HIP path against bytes the UNMODIFIED REFERENCE wrote: oracle/_ref/dwgsim with its drand48() replaying the Philox stream (tests/replay_common.py;
-    single-end configurations without quality normals: Illumina, SOLiD, the whole Ion Torrent flow model, heavy -r / -R, -x, -m / -b / -v) -- no oracle
+    single-end configurations: Illumina, SOLiD, the whole Ion Torrent flow model, heavy -r / -R, -x, -m / -b / -v, and -- reads of even length -- quality
+    noise -Q 0.5 ... 60, i.e. the 16-bit polar tries and lazy normals of the headline kernel against the reference's own ran_normal with glibc log) -- no oracle
     output is compared here, the oracle only dumps the stream.  The last case also goes through the dwgsim-hip executable."""
     import gzip, subprocess
     from replay_common import run_replay, SUFFIXES, IN_DIR

@@ -80,3 +80,21 @@ def test_single_contig_window_equals_the_slice_of_the_whole_genome_run(oracle_bi
     # the mutation body lines of that contig are those of the whole-genome run
     want_txt = b"".join(l + b"\n" for l in open(full + ".mutations.txt", "rb").read().split(b"\n") if l.startswith(contigs[k][0].encode() + b"\t"))
     assert open(win + ".mutations.txt", "rb").read() == want_txt and len(want_txt) > 0
+
+
+def test_every_possible_quality_try_gives_the_offset_glibc_log_would(oracle_bin):
+    """The link between the two oracle modes on the headline path (paired ends, -Q 2).  A quality normal of mode B is a polar try on two 16-bit
+    operands (D_QUAL0): 2^32 possible tries, 3 373 258 460 of them accepted.  The reference's ran_normal (dwgsim.c:156-175) uses
+    glibc's log, the oracle and the kernels det_log; their last bits differ on ~7 % of the accepted radii -- and for NO try does that change
+    (int)(nrm * sigma + 0.5) (dwgsim.c:912), for any -Q below.  oracle/exhaust_log.c folds the tries into the 2^29 pairs (|s1| <= |s2|) that share
+    rsq and compares the truncations of all four signed variates wherever the logs differ bitwise.  Together with the replay cases of even-length
+    reads (tests/replay_common.py) this retires "same code, other provider" for the quality path."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(oracle_bin), "exhaust_log")
+    sig = ["0.3", "0.5", "1", "2", "3", "3.7", "10", "40", "60", "5000"]
+    out = subprocess.run([exe, str(min(16, os.cpu_count() or 1))] + sig, check=True, capture_output=True, text=True).stdout.split()
+    kv = dict(zip(out[0::2], out[1::2]))
+    assert int(kv["tries_accepted"]) == 3373258460            # |{(s1, s2) in [-32768, 32767]^2 : 0 < s1^2 + s2^2 < 2^30}|
+    assert int(kv["log_bits_differ"]) > 10**7                 # (the check is not vacuous: the two logs do differ, on 30 M of the 422 M distinct radii)
+    for s in sig:
+        assert int(kv[f"offsets_differ[{float(s):g}]"]) == 0, (s, kv)
