@@ -10,7 +10,8 @@ bases (dwgsim_hip_add_contigs): one chain of walk kernels and a few launches per
 Workload at N=1 (default): BASELINE configs[2], the largest single-GPU configuration -- S3, a chr20-sized
 synthetic contig (64 444 167 bp with telomere / centromere N blocks), `-z 13 -1 150 -2 150 -C 30 -o 1`
 (-r 0.001 -R 0.1 are dwgsim's defaults) => 6 783 597 pairs and 4.9 GB of FASTQ text per step.
-`--workload ecoli` is configs[1] (S2, 488 595 pairs), `--workload grch38` the whole-genome S4 job,
+`--workload ecoli` is configs[1] (S2, 488 595 pairs), `--workload chr20_like` / `ecoli_like` the same sizes with a genome's composition instead
+of uniform bases (dwgsim_amd/synth.py genome_like_contig), `--workload grch38` the whole-genome S4 job,
 `--workload assembly5k` a scaffold-level assembly (5000 contigs, N50 ~ 50 kb).
 
 N>1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run) when no launcher did.
@@ -39,7 +40,7 @@ FLAGS = "-z 13 -1 150 -2 150 -C 30 -o 1"
 ION_FLAGS = "-z 13 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 400 -2 0 -C 50 -e 0.01 -o 1"
 ALGO_BYTES_PER_PAIR_2x150 = 863.0  # 713 B FASTQ written + 150 B haplotype bases read at 4 bit/base
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
-WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3), "assembly5k": ("5000 scaffolds, N50 ~ 50 kb", 3)}
+WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "ecoli_like": ("S2 with a bacterial genome's composition", 1), "chr20_like": ("S3 with a human chromosome's composition", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3), "assembly5k": ("5000 scaffolds, N50 ~ 50 kb", 3)}
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "r05_counters.json")
 STRONG_GROUP_BP = (1 << 31) - (1 << 24)      # whole-genome groups for the strong-scaling job: a group's coordinate space holds < 2^31 cells (dw_host.cpp dwgsim_hip_add_contigs): GRCh38 = 2 groups, 2 walk chains
 MAX_LAUNCH_PAIRS = 1 << 23         # pairs per launch at most (a launch's text buffers are sized for it: 6 GB at 2 x 150 bp)
@@ -222,6 +223,67 @@ def end_to_end_leg(contigs, flags, n_pairs, gzip_mode="gpu", fai=False, null_sin
                     ("FASTQ deliveries counted, not written (DWGSIM_HIP_SINK=null)" if null_sink else "outputs on " + ("tmpfs" if _tmpdir() else "the temp dir"))}
 
 
+def bind_to_device_node(lib, device):
+    """This process on the cores of the NUMA node its GPU hangs off (dwgsim_hip_device_numa_node: /sys/bus/pci/devices/<bus id>/numa_node), so that what it
+    page-locks and the copies it waits for do not cross the socket link -- as dw_job.cpp does for the job level's workers.  -> the node, or None where it is
+    unknown (-1: single-socket boxes, containers without sysfs), where none of its cores may be used by this process, or with DWGSIM_HIP_NO_PIN set."""
+    if os.environ.get("DWGSIM_HIP_NO_PIN") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        node = int(lib.dwgsim_hip_device_numa_node(device))
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
+def solo_sweep(args, flags, setup, measure, worlds, lib, dev, numa):
+    """Every rank of every world size in `worlds`, ONE AT A TIME on this one GPU (--solo-sweep): what N GPUs would each do, measured -- not a hardware curve.
+    weak: the default line's job at coverage 30 W (per-GPU work fixed); strong: BASELINE configs[3], the whole-genome job, split over W ranks.
+    T(1) is measured in the same process on the same resident job.  The one thing a real run adds and this cannot show is the host-side all-gather of one
+    integer per launch (0.1-0.2 ms per step, beside the kernels of the step before: DESIGN.md 6)."""
+    out = {"what": "solo-rank, one GPU at a time: rank r of W runs alone on this GPU -- its walks of every group, its random-read counts (k_place), its launches -- "
+                   "with the other ranks' counts taken from a reference pass; efficiency weak = T(1) / max_r T_r(W), strong = T(1) / (W x max_r T_r(W))",
+           "numa_node": numa, "weak": {}, "strong": {}}
+    K, Wm = args.steps, args.warmup
+    for mode in ("weak", "strong"):
+        if mode == "strong" and args.no_strong_leg:
+            continue
+        wl, fl, gbp, k, wm = (args.workload, flags, args.group_bp, K, Wm) if mode == "weak" else ("grch38", FLAGS, STRONG_GROUP_BP, 3, 1)
+        S = None
+        t1 = None
+        for W in [1] + [w for w in worlds if w > 1]:
+            if S is None or mode == "weak":      # (a weak job's coverage depends on W: a context of its own; the strong job is made resident once)
+                if S is not None:
+                    S["ctx"].close()
+                S = setup(wl, mode, fl, gbp, W)
+            per = []
+            for r in range(W):
+                m = measure(S, k, wm, W, r, True)
+                per.append({"rank": r, "ms_per_step": round(m["elapsed"] / k * 1e3, 4), "pairs": m["my_pairs"], "launches": m["n_my_launches"],
+                            "simulate_kernels_ms": round(m["stats"]["sim_kernel_ms"] / k, 4), "walk_gpu_ms": round(m["stats"]["walk_gpu_ms"] / k, 4),
+                            "count_random_gpu_ms": round(m["stats"]["count_gpu_ms"] / k, 4), "host_count_random_ms": round(m["stats"]["count_ms"] / k, 4)})
+            tmax = max(p["ms_per_step"] for p in per)
+            if W == 1:
+                t1 = tmax
+                out[mode]["job"] = f"{wl}: {len(S['job'])} contig(s), {S['tot_len']} bp, dwgsim {S['job_flags'] if mode == 'strong' else fl + ' (coverage x W)'}, {k} timed steps per rank"
+            pairs_all = sum(p["pairs"] for p in per)
+            out[mode][str(W)] = {"ranks": per, "max_ms_per_step": tmax, "min_ms_per_step": min(p["ms_per_step"] for p in per),
+                                 "value_if_ranks_ran_side_by_side": round(pairs_all / tmax / 1e3, 3), "unit": "M read-pairs/s",
+                                 "efficiency": round(t1 / tmax if mode == "weak" else t1 / (W * tmax), 4)}
+        S["ctx"].close()
+    return out
+
+
 def make_groups(job, group_bp):
     """consecutive contigs, up to group_bp bases together (a contig that is longer stands alone)"""
     groups, cur, cur_bp = [], [], 0
@@ -264,7 +326,15 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="analysis only: several ranks on one GPU (1-GPU box)")
     ap.add_argument("--strong-leg", action="store_true", help="also measure the fixed whole-genome job (BASELINE configs[3]) split over the ranks: the `strong` object of the line (default with --gpus > 1, and at N = 1 unless --no-legs)")
     ap.add_argument("--no-strong-leg", action="store_true")
+    ap.add_argument("--world", type=int, default=0, help="with --solo-rank: the world size W of the run this process plays one rank of")
+    ap.add_argument("--solo-rank", type=int, default=None, help="run ALONE, on this one GPU, exactly what rank r of a --world W run does on its GPU: its walks, its random-read counts, its batches; "
+                    "the all-gather is replaced by the counts one reference pass recorded (the path has no data-path collective, so a rank's GPU work does not depend on the others running)")
+    ap.add_argument("--solo-sweep", default=None, help="e.g. 2,4,8: every rank of every world size, one at a time on this GPU, weak line and strong (whole-genome) job; prints one JSON object with "
+                    "T_r(W), T(1) and efficiency = T(1) / max_r T_r(W) (weak), T(1) / (W x max_r T_r(W)) (strong) -- 'solo-rank, one GPU at a time', not a hardware curve")
     args = ap.parse_args()
+    solo = args.solo_rank is not None or args.solo_sweep is not None
+    if args.solo_rank is not None and not (0 <= args.solo_rank < max(args.world, 1)):
+        raise SystemExit("bench.py: --solo-rank r needs --world W with 0 <= r < W")
     args.strong_leg = (args.strong_leg or args.gpus > 1 or not args.no_legs) and not args.no_strong_leg      # (N = 1 carries it too: the curve's efficiency is taken against that line)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -286,30 +356,33 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the hot path)")
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if solo and world != 1:
+        raise SystemExit("bench.py: --solo-rank / --solo-sweep play one rank at a time in ONE process (no launcher, --gpus 1)")
     if world > torch.cuda.device_count() and not args.share_gpu:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible (--share-gpu is the analysis-only way to put several ranks on one)")
     dev = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
     torch.cuda.set_device(dev)
+    lib = api.load()
+    numa = bind_to_device_node(lib, dev)      # this rank's host thread (and what it page-locks) on the cores of its GPU's NUMA node, as the job level's workers are (dw_job.cpp)
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")          # host-side exchange of integers; no RCCL on this path
 
-    lib = api.load()
     flags = args.flags or (ION_FLAGS if args.ion else FLAGS)
+    if args.solo_rank is not None:
+        world, rank = args.world, args.solo_rank
 
-    def measure(workload, mode, flags, n_steps, warmup, group_bp):
-        """One measurement: the workload's groups made resident (twice: the pipeline), `warmup` + `n_steps` steps, the barrier-bracketed time of the
-        timed ones (maximum over the ranks).  -> everything the JSON line is made of; the context stays open (the legs use it)."""
+    def setup(workload, mode, flags, group_bp, W):
+        """The job made resident: the context (the job's flags: a weak job's coverage is W times the workload's) and depth + 2 copies of every group of
+        contigs.  Nothing here depends on which rank this process is; measure() assigns the launches."""
         params = api.parse_flags(flags, lib)                  # the workload's own configuration (the legs and baselines run it)
         job_flags = flags
-        if mode == "weak" and world > 1:                 # per-GPU work fixed: world times the coverage
-            toks = flags.split(); i = toks.index("-C"); toks[i + 1] = repr(float(toks[i + 1]) * world); job_flags = " ".join(toks)
+        if mode == "weak" and W > 1:                     # per-GPU work fixed: W times the coverage
+            toks = flags.split(); i = toks.index("-C"); toks[i + 1] = repr(float(toks[i + 1]) * W); job_flags = " ".join(toks)
         job_params = api.parse_flags(job_flags, lib)
         contigs = synth.workload_contigs(workload)
         tot_len = sum(len(a) for _, a in contigs)
-        paired = params.length[1] > 0
-
         ctx = api.Context(job_params, dev, lib)
         if args.phases:
             ctx.debug_option("phases", 1)
@@ -322,30 +395,56 @@ def main():
                 continue
             job.append((name, arr, ci, n))
             n_sim += n
-        job_pairs = sum(e[3] for e in job)
         # Every group is resident depth + 2 TIMES (copies used by consecutive steps in turn): the walk rewrites the haplotypes in place, so the walk + random-read
         # count + exchange of step k+1 can only run beside the kernels of step k on a copy of its own -- the pipeline a job of many groups has anyway
         # (dw_job.cpp: group g+1 is uploaded, walked and counted while the batches of group g run)
-        copies = []
         # (ranks that SHARE one GPU -- the readiness runs of the N-rank paths on one-GPU boxes -- hold the whole-genome job once and prepare every step in
         # front of its launches: eight ranks x two or three copies of 17 GB + their output slots are more than the one device has)
-        depth = args.depth
-        no_pipeline = args.no_pipeline or (args.share_gpu and world > 2 and workload == "grch38")
-        for _copy in range(1 if no_pipeline else depth + 2):
-            gl = []          # per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
+        no_pipeline = args.no_pipeline or (args.share_gpu and W > 2 and workload == "grch38")
+        raw = []
+        for _copy in range(1 if no_pipeline else args.depth + 2):
+            gl = []
             for grp in make_groups(job, group_bp):
                 h0 = ctx.add_contigs([(name, arr) for name, arr, _, _ in grp], indices=[ci for _, _, ci, _ in grp])
-                launches = balanced_batches(api, [(h0 + k, 0, n) for k, (_, _, _, n) in enumerate(grp) if n > 0], world, MAX_LAUNCH_PAIRS)
-                gl.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)], "launches": launches, "mine": [b for b in range(len(launches)) if b % world == rank], "pairs": sum(n for l in launches for _, _, n in l)})
+                gl.append({"h0": h0, "members": [(h0 + k, n) for k, (_, _, _, n) in enumerate(grp)]})
+            raw.append(gl)
+        return dict(ctx=ctx, params=params, job_flags=job_flags, contigs=contigs, tot_len=tot_len, paired=params.length[1] > 0, job=job, job_pairs=sum(e[3] for e in job),
+                    raw=raw, no_pipeline=no_pipeline, ref_counts={})
+
+    def measure(S, n_steps, warmup, W, R, alone):
+        """One measurement on the resident job S as rank R of W: `warmup` + `n_steps` steps, the barrier-bracketed time of the timed ones (maximum over the
+        ranks).  alone: this process plays rank R of W by itself (--solo-rank): no process group; what the all-gather would bring -- the random-read
+        counts of the other ranks' launches -- comes from one reference pass over ALL launches, made here before anything is timed (the walk is
+        deterministic: every step of every rank sees the same counts); the rank's OWN counts are still taken live, every step, as in the real run, and
+        must equal the recorded ones.  -> everything the JSON line is made of."""
+        ctx, no_pipeline, depth = S["ctx"], S["no_pipeline"], args.depth
+        group_dist = None if alone else dist
+        copies = []          # per copy, per group: handle of its first contig, its launches (each a list of ranges), which of them are this rank's
+        for gl0 in S["raw"]:
+            gl = []
+            for g0 in gl0:
+                launches = balanced_batches(api, [(h, 0, n) for h, n in g0["members"] if n > 0], W, MAX_LAUNCH_PAIRS)
+                gl.append({"h0": g0["h0"], "members": g0["members"], "launches": launches, "mine": [b for b in range(len(launches)) if b % W == R], "pairs": sum(n for l in launches for _, _, n in l)})
             copies.append(gl)
         groups = copies[0]
         my_pairs = sum(n for g in groups for b in g["mine"] for _, _, n in g["launches"][b])
         n_my_launches = sum(len(g["mine"]) for g in groups)
+        ref = None
+        if alone and W > 1:
+            ref = S["ref_counts"].get(W)
+            if ref is None:      # the reference pass: every launch of every rank, counted once on the walked copy 0
+                ref = []
+                for g in groups:
+                    ctx.mutate_async(g["h0"]); ctx.mutate_wait(g["h0"])
+                    flat = [r for l in g["launches"] for r in l]
+                    per = iter(ctx.count_random_ranges(flat, per_range=True) if flat else [])
+                    ref.append([sum(next(per) for _ in l) for l in g["launches"]])
+                S["ref_counts"][W] = ref
 
         def barrier():
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            if group_dist is not None:
+                group_dist.barrier()
             torch.cuda.synchronize()
 
         stats = {"prep_ms": 0.0, "count_ms": 0.0, "exch_ms": 0.0, "sim_kernel_ms": 0.0, "bytes": 0, "n_random": 0, "launches": 0}
@@ -366,7 +465,7 @@ def main():
             tc = 0.0
             for g in gl:
                 ctx.mutate_wait(g["h0"])
-                if world > 1:
+                if W > 1:
                     t1 = time.perf_counter()
                     flat = [r for b in g["mine"] for r in g["launches"][b]]
                     per = iter(ctx.count_random_ranges(flat, per_range=True) if flat else [])
@@ -374,21 +473,30 @@ def main():
                     tc += time.perf_counter() - t1
             t2 = time.perf_counter()
             bases = {}
-            if world > 1:
-                width = max(1, max(-(-len(g["launches"]) // world) for g in gl))
+            if W > 1 and alone:      # the exchange, replaced: the others' counts as the reference pass recorded them, mine as just counted
+                run = 0
+                for q, g in enumerate(gl):
+                    for b in range(len(g["launches"])):
+                        if b % W == R:
+                            bases[(q, b)] = run
+                            if counts[q][b // W] != ref[q][b]:
+                                raise SystemExit(f"bench.py: rank {R} of {W} counted {counts[q][b // W]} random reads in launch {b} of group {q}, the reference pass {ref[q][b]}")
+                        run += ref[q][b]
+            elif W > 1:
+                width = max(1, max(-(-len(g["launches"]) // W) for g in gl))
                 mine_vec = torch.zeros(len(gl) * width, dtype=torch.int64)
                 for q in range(len(gl)):
                     for k, cval in enumerate(counts[q]):
                         mine_vec[q * width + k] = cval
-                allv = torch.empty(world * mine_vec.numel(), dtype=torch.int64)
-                dist.all_gather_into_tensor(allv, mine_vec)          # one integer per launch: the only thing that crosses ranks
-                allv = allv.view(world, len(gl), width)
+                allv = torch.empty(W * mine_vec.numel(), dtype=torch.int64)
+                group_dist.all_gather_into_tensor(allv, mine_vec)          # one integer per launch: the only thing that crosses ranks
+                allv = allv.view(W, len(gl), width)
                 run = 0
-                for q, g in enumerate(gl):      # launch b belongs to rank b mod world; its count sits at that rank's position b // world
+                for q, g in enumerate(gl):      # launch b belongs to rank b mod W; its count sits at that rank's position b // W
                     for b in range(len(g["launches"])):
-                        if b % world == rank:
+                        if b % W == R:
                             bases[(q, b)] = run
-                        run += int(allv[b % world, q, b // world])
+                        run += int(allv[b % W, q, b // W])
             t3 = time.perf_counter()
             if record:
                 stats["prep_ms"] += (t2 - t0 - tc) * 1e3; stats["count_ms"] += tc * 1e3; stats["exch_ms"] += (t3 - t2) * 1e3
@@ -412,16 +520,14 @@ def main():
             launches of the step before may still run: the walk issued there rewrites the copy of the step before THAT, whose launches were waited
             for before this step's first was enqueued; carry: leave this step's launches in flight for the next step to wait for"""
             acc = {"bytes": 0, "rand": 0}
-            mine = 0
             first_launch = True
             for q, g in enumerate(gl):
                 for b in g["mine"]:
                     drain(1, record)
-                    base = bases[(q, b)] if world > 1 else (0 if first_launch else api.RAND_CHAIN)
+                    base = bases[(q, b)] if W > 1 else (0 if first_launch else api.RAND_CHAIN)
                     first_launch = False
                     ctx.simulate_ranges_async(g["launches"][b], base, flight["slot"])
                     flight["pending"].append((flight["slot"], acc)); flight["slot"] ^= 1
-                    mine += 1
             nxt = then() if then else None
             if not carry:
                 drain(0, record)
@@ -470,24 +576,30 @@ def main():
         stats["walk_gpu_ms"] = (ctx.debug_get("walk_us") - gpu_us0[0]) / 1e3
         stats["count_gpu_ms"] = (ctx.debug_get("count_us") - gpu_us0[1]) / 1e3
         total_pairs = my_pairs
-        if dist is not None:
+        if group_dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            group_dist.all_reduce(tt, op=group_dist.ReduceOp.MAX)
             elapsed = float(tt.item())
             tp = torch.tensor([my_pairs], dtype=torch.int64)
-            dist.all_reduce(tp)
+            group_dist.all_reduce(tp)
             total_pairs = int(tp.item())
+        out = dict(S)
+        out.update(groups=groups, my_pairs=my_pairs, n_my_launches=n_my_launches, stats=stats, elapsed=elapsed, total_pairs=total_pairs)
+        return out
 
-        return dict(ctx=ctx, params=params, job_flags=job_flags, contigs=contigs, tot_len=tot_len, paired=paired, job=job, job_pairs=job_pairs, groups=groups, my_pairs=my_pairs,
-                    n_my_launches=n_my_launches, stats=stats, elapsed=elapsed, total_pairs=total_pairs)
+    if args.solo_sweep:
+        print(json.dumps(solo_sweep(args, flags, setup, measure, [int(x) for x in args.solo_sweep.split(",")], lib, dev, numa)), flush=True)
+        return
 
-    m = measure(args.workload, args.mode, flags, args.steps, args.warmup, args.group_bp)
+    m = measure(setup(args.workload, args.mode, flags, args.group_bp, world), args.steps, args.warmup, world, rank, args.solo_rank is not None)
     ctx, params, job_flags, contigs, tot_len, paired, job, job_pairs, groups, my_pairs, n_my_launches, stats, elapsed, total_pairs = (m[k] for k in (
         "ctx", "params", "job_flags", "contigs", "tot_len", "paired", "job", "job_pairs", "groups", "my_pairs", "n_my_launches", "stats", "elapsed", "total_pairs"))
     # the fixed whole-genome job of BASELINE configs[3] split over the ranks, beside the (weak) line: the `strong` object of the line.  Whole-genome
     # groups (two of them: a group holds < 2^31 cells), three timed steps
     strong = None
     landed = {}
+    printer = rank == 0 or args.solo_rank is not None
+    n_gpus = 1 if args.solo_rank is not None else world
     if world == 1 and not args.no_legs:      # (the legs that need the resident contig: before the context makes room for the whole-genome job)
         g0 = max(groups, key=lambda g: g["pairs"])
         cid0, n0 = max(g0["members"], key=lambda mm: mm[1])          # the contig with the most pairs
@@ -496,19 +608,19 @@ def main():
         landed["host_landed_gz"] = host_landed_leg(api, ctx, cid0, n0, gz=True)
     if args.strong_leg and not args.ion and args.flags is None and not (args.workload == "grch38" and args.mode == "strong"):
         ctx.close(); ctx = None; m["ctx"] = None
-        ms = measure("grch38", "strong", FLAGS, 3, 1, STRONG_GROUP_BP)
+        ms = measure(setup("grch38", "strong", FLAGS, STRONG_GROUP_BP, world), 3, 1, world, rank, args.solo_rank is not None)
         ms["ctx"].close()
-        if rank == 0:
+        if printer:
             Ks = 3
             strong = {"workload": f"S4 (grch38): {len(ms['job'])} contigs, {ms['tot_len']} bp, {ms['job_pairs']} pairs, dwgsim {ms['job_flags']}: ONE job split over {world} rank(s) (batch b of a group: rank b mod {world}); "
                                   f"every rank walks every group ({len(ms['groups'])} groups)",
-                      "value": round(ms["total_pairs"] * Ks / ms["elapsed"] / 1e6, 3), "unit": "M read-pairs/s", "n_gpus": world, "steps": Ks, "ms_per_step": round(ms["elapsed"] / Ks * 1e3, 3),
+                      "value": round(ms["total_pairs"] * Ks / ms["elapsed"] / 1e6, 3), "unit": "M read-pairs/s", "n_gpus": n_gpus, "steps": Ks, "ms_per_step": round(ms["elapsed"] / Ks * 1e3, 3),
                       "walk_gpu_ms": round(ms["stats"]["walk_gpu_ms"] / Ks, 3), "count_random_gpu_ms": round(ms["stats"]["count_gpu_ms"] / Ks, 3), "simulate_kernels_ms": round(ms["stats"]["sim_kernel_ms"] / Ks, 3),
                       "kernel_share": round(ms["stats"]["sim_kernel_ms"] / max(ms["elapsed"] * 1e3, 1e-9), 4),
                       "note": "efficiency at N GPUs = this value / (N x the value of the N = 1 line); kernel_share = k_simulate time of rank 0 / step time: what the walks, counts and the exchange leave"}
         ms = None
 
-    if rank == 0:
+    if printer:
         K = max(args.steps, 1)
         ms_per_step = elapsed / K * 1e3
         value = total_pairs * K / elapsed / 1e6
@@ -536,14 +648,15 @@ def main():
         except Exception:
             prof_note = "no counter file for this round"
         sname, cfg_i = WORKLOADS[args.workload]
+        seq_kind = "genome-like (GC content, repeat families, microsatellites, homopolymers, soft-masked)" if args.workload.endswith("_like") else "uniform-random"
         out = {
             "metric": "M read-pairs/sec (2x150 bp PE)" if not args.ion else "M reads/sec (Ion Torrent 400 bp SE)", "value": round(value, 3), "unit": "M read-pairs/s" if paired else "M reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{sname} ({args.workload}): {len(job)} uniform-random contig(s) in {len(groups)} resident group(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {job_flags}, "
+            "config": {"workload": f"{sname} ({args.workload}): {len(job)} {seq_kind} contig(s) in {len(groups)} resident group(s), {tot_len} bp in all (BASELINE configs[{4 if args.ion else cfg_i}] stand-in), dwgsim {job_flags}, "
                                    f"{job_pairs} pairs per job; step = mutation walk of every contig + all pairs of this rank's read-index ranges, FASTQ text left in HBM; " +
                                    ("every step prepares itself before its first launch" if args.no_pipeline else f"the walk of step k+{args.depth} and the random-read count and exchange of step k+1 run on the walk stream / the host beside the kernels of step k (contigs resident {args.depth + 2} times)"),
-                       "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * world * K / elapsed / 1e9, 2),
+                       "pairs_per_gpu_per_step": my_pairs, "launches_per_gpu_per_step": n_my_launches, "fastq_bytes_per_step_per_gpu": stats["bytes"], "fastq_gb_per_s": round(stats["bytes"] * n_gpus * K / elapsed / 1e9, 2),
                        "random_pairs": stats["n_random"],
                        "parallelism": (f"read-index shards x{world} ({args.mode}; batch b of every group's pairs belongs to rank b mod {world}), one host-side all-gather of integers per step" if world > 1 else "one GPU")},
             "breakdown_ms": {"walk_gpu": round(stats["walk_gpu_ms"] / K, 4), "count_random_gpu": round(stats["count_gpu_ms"] / K, 4), "simulate_kernels": round(stats["sim_kernel_ms"] / K, 4),
@@ -561,13 +674,18 @@ def main():
         }
         if prof_note:
             out["roofline"]["counters_note"] = prof_note
+        if args.solo_rank is not None:
+            out["solo_rank"] = {"rank": rank, "world": world, "note": "this process ran ALONE on one GPU what rank r of a W-rank run does on its GPU (walks of every group, its random-read "
+                                "counts, its launches; the other ranks' counts from a reference pass): `value` is THIS RANK's rate, W ranks side by side would give W times the slowest rank's"}
+        if numa is not None:
+            out["config"]["numa_node"] = numa
         if strong:
             out["strong"] = strong
         out.update(landed)
         if ctx is not None:
             ctx.close(); ctx = None
         small = [(name, arr) for name, arr, _, _ in job]
-        if world == 1 and not args.no_legs and args.workload in ("ecoli", "chr20"):
+        if world == 1 and not args.no_legs and args.workload in ("ecoli", "chr20", "ecoli_like", "chr20_like"):
             out["end_to_end"] = end_to_end_leg(small, flags, job_pairs)
             cpu_gz = end_to_end_leg(small, flags, job_pairs, "cpu")
             if cpu_gz and "seconds" in cpu_gz:

@@ -52,7 +52,7 @@ struct Group {
     bool alive = false, mutated = false, walk_pending = false;
     int first_handle = -1;
     std::vector<Member> m;
-    int64_t total = 0;               // cells of the coordinate space (a multiple of 16; allocations add CELL_PAD)
+    int64_t total = 0;               // cells of the coordinate space (a multiple of 16; allocations add CELL_PAD = 64: a whole 64-cell chunk past the last cell stays inside)
     uint8_t *d_ref = nullptr, *d_cells[2] = {nullptr, nullptr}, *d_view[2] = {nullptr, nullptr};      // reference codes, byte cells, 4-bit read views
     int32_t *d_ins_pos[2] = {nullptr, nullptr};
     uint32_t *d_ins_len[2] = {nullptr, nullptr}, *d_ins_off[2] = {nullptr, nullptr};
@@ -155,13 +155,28 @@ namespace {
 
 #define HIPC(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { char b_[512]; snprintf(b_, sizeof b_, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); (ctx)->err = b_; return DWGSIM_HIP_ERR_DEVICE; } } while (0)
 
+void free_group(struct Group &g);
+
+// hipMalloc; when the device is out of memory the sets of dropped groups the context keeps for reuse (dwgsim_hip_ctx::pool) are given back and the
+// allocation is tried once more -- a job that fitted when groups were freed at drop (rounds 1-4) must not fail with gigabytes idle in the pool
+hipError_t dev_malloc(dwgsim_hip_ctx *c, void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess || c->pool.empty()) return e;
+    (void)hipGetLastError();
+    hipStreamSynchronize(c->walk_stream);
+    for (auto &g : c->pool) free_group(g);
+    c->pool.clear();
+    return hipMalloc(p, bytes);
+}
+
 int ensure(dwgsim_hip_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
     if (b.p) HIPC(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     size_t want = bytes + bytes / 8 + 4096;
-    HIPC(c, hipMalloc(&b.p, want));
+    HIPC(c, dev_malloc(c, &b.p, want));
     b.cap = want;
     return 0;
 }
@@ -467,18 +482,28 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
                 ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
-                const size_t nblk = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-                for (int mult = 1; mult <= 16; mult *= 2) {       // a read that outgrows its buffers: once more with twice the room (the reference doubles its buffers, dwgsim.c:296-311)
-                    ca.lds_words = (flow_read_capacity(len, e, c->flow) * mult + 15) / 16;       // the flow model's one buffer per lane: 16 bases per word
+                // a read that outgrows its buffers: once more with twice the room (the reference doubles its buffers, dwgsim.c:296-311) -- by the rule of
+                // dwgsim_hip_wait: up to FLOW_CAP_MAX bases per read.  The scratch holds a CHUNK of the 10^6 reads (at most ~2 GiB), so the room a read
+                // may take does not depend on how many reads there are (round 5 stopped at 16 x: -B then refused flow orders the simulate path handles)
+                const int64_t base_cap = flow_read_capacity(len, e, c->flow);
+                int mult = 1;
+                for (;; mult *= 2) {
+                    ca.lds_words = (int32_t)((base_cap * mult + 15) / 16);       // the flow model's one buffer per lane: 16 bases per word
                     ca.stack_words = std::min(FLOW_STACK_WORDS * mult, FLOW_STACK_WORDS_MAX);
-                    if (ensure(c, c->flow_scratch, (size_t)ca.lds_words * PAIRS_PER_BLOCK * nblk * sizeof(uint32_t))) return -1;
+                    const size_t per_block = (size_t)ca.lds_words * PAIRS_PER_BLOCK * sizeof(uint32_t);
+                    const size_t nblk_all = (size_t)((ca.n_reads + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+                    const size_t nblk = std::max<size_t>(1, std::min(nblk_all, ((size_t)2 << 30) / per_block));
+                    ca.chunk_reads = (uint64_t)nblk * PAIRS_PER_BLOCK;
+                    if (ensure(c, c->flow_scratch, per_block * nblk)) return -1;
                     ca.scratch = (uint32_t *)c->flow_scratch.p; ca.counters = c->d_counters;
                     HIPC(c, hipMemsetAsync(c->d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
-                    launch_calibrate(c->stream, ca);
+                    for (ca.first_read = 0; ca.first_read < ca.n_reads; ca.first_read += ca.chunk_reads) launch_calibrate(c->stream, ca);
                     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
                     HIPC(c, hipStreamSynchronize(c->stream));
-                    if (!c->h_counters[2]) break;
+                    if (!c->h_counters[2] || base_cap * (int64_t)mult * 2 > (int64_t)FLOW_CAP_MAX) break;
                 }
+                // the job's reads will need the room the calibration's needed: start there instead of running the first overflowing batch twice
+                if (mult > c->flow_cap_mult) c->flow_cap_mult = mult;
                 if (c->h_counters[2]) { c->err = "-B calibration: a read outgrew its flow-space buffer (the flow model's growth at this error rate and flow order: INTEGRATION.md)"; fail_code = DWGSIM_HIP_ERR_FAILED; return -1; }
                 const int32_t n_err = (int32_t)c->h_counters[8], counts = (int32_t)c->h_counters[9];       // int32 accumulators as in the reference
                 sf = e / (n_err / (1.0 * counts));
@@ -675,13 +700,13 @@ int dwgsim_hip_add_contigs(dwgsim_hip_ctx_t *c, int n, const char *const *names,
             g.d_ref = g.d_refview = nullptr; g.d_refsumm = g.d_refsumm2 = nullptr; g.d_dirty = nullptr;
             for (int h = 0; h < 2; ++h) { hipFree(g.d_cells[h]); hipFree(g.d_view[h]); hipFree(g.d_summ[h]); hipFree(g.d_summ2[h]); g.d_cells[h] = g.d_view[h] = nullptr; g.d_summ[h] = g.d_summ2[h] = nullptr; }
             g.cap_cells = 0;
-            HIPC(c, hipMalloc((void **)&g.d_ref, padded));
+            HIPC(c, dev_malloc(c, (void **)&g.d_ref, padded));
             for (int h = 0; h < 2; ++h) {
-                HIPC(c, hipMalloc((void **)&g.d_cells[h], padded)); HIPC(c, hipMalloc((void **)&g.d_view[h], padded / 2 + 32));
-                HIPC(c, hipMalloc((void **)&g.d_summ[h], sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, hipMalloc((void **)&g.d_summ2[h], sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
+                HIPC(c, dev_malloc(c, (void **)&g.d_cells[h], padded)); HIPC(c, dev_malloc(c, (void **)&g.d_view[h], padded / 2 + 32));
+                HIPC(c, dev_malloc(c, (void **)&g.d_summ[h], sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, dev_malloc(c, (void **)&g.d_summ2[h], sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
             }
-            HIPC(c, hipMalloc((void **)&g.d_refview, padded / 2 + 32)); HIPC(c, hipMalloc((void **)&g.d_refsumm, sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, hipMalloc((void **)&g.d_refsumm2, sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
-            HIPC(c, hipMalloc((void **)&g.d_dirty, sizeof(uint32_t) * ((padded + 32 * SUMM_CELLS - 1) / (32 * SUMM_CELLS) + 2)));
+            HIPC(c, dev_malloc(c, (void **)&g.d_refview, padded / 2 + 32)); HIPC(c, dev_malloc(c, (void **)&g.d_refsumm, sizeof(uint16_t) * (padded / SUMM_CELLS + 16))); HIPC(c, dev_malloc(c, (void **)&g.d_refsumm2, sizeof(uint16_t) * (padded / SUMM2_CELLS + 16)));
+            HIPC(c, dev_malloc(c, (void **)&g.d_dirty, sizeof(uint32_t) * ((padded + 32 * SUMM_CELLS - 1) / (32 * SUMM_CELLS) + 2)));
             g.cap_cells = padded;
         }
         g.n_dirty_words = (uint32_t)((padded + 32 * SUMM_CELLS - 1) / (32 * SUMM_CELLS));
@@ -781,18 +806,19 @@ int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *c, int contig)
     // already carry batches of the NEXT group -- the job level keeps its three batches in flight across a group's end -- and not the copy stream:
     // copies read the slots' output buffers), and the group's own walk (not the whole walk stream: it may carry the upload and the walk of the next group)
     const int gid = (int)(g - c->groups.data());
-    for (int s = 0; s < DWGSIM_HIP_SLOTS; ++s) if (c->slot[s].pending && !c->slot[s].empty && c->slot[s].group == gid) hipEventSynchronize(c->slot[s].ev_done);
+    // a batch of the group that was enqueued and not yet waited for: its wait may have to run it AGAIN (an Ion Torrent read that outgrew its buffers,
+    // dwgsim_hip_wait), which needs the group -- wait first, then drop (include/dwgsim_hip.h)
+    for (int s = 0; s < DWGSIM_HIP_SLOTS; ++s) if (c->slot[s].pending && !c->slot[s].empty && c->slot[s].group == gid) { c->err = "drop_contig: a batch that reads this group has not been waited for (dwgsim_hip_wait first)"; return DWGSIM_HIP_ERR_STATE; }
     if (g->walk_pending) hipEventSynchronize(g->ev_walk);
     for (size_t k = 0; k < g->m.size(); ++k) { if (c->chain_contig == g->first_handle + (int)k) c->chain_contig = -1; c->handles[(size_t)g->first_handle + k].group = -1; }
-    // the group's memory waits for the next group (at most three sets are kept: the smallest goes)
+    // the group's memory waits for the next group (at most three sets are kept: the one that has waited longest goes -- a set that no later
+    // group can use, e.g. one more than four times too large, does not stay for the life of the context; round 5 dropped the smallest)
     g->alive = false;
     c->pool.push_back(*g);
     *g = Group();
     if (c->pool.size() > 3) {
-        size_t small = 0;
-        for (size_t i = 1; i < c->pool.size(); ++i) if (c->pool[i].cap_cells < c->pool[small].cap_cells) small = i;
         hipStreamSynchronize(c->walk_stream);
-        free_group(c->pool[small]); c->pool.erase(c->pool.begin() + (long)small);
+        free_group(c->pool[0]); c->pool.erase(c->pool.begin());
     }
     return DWGSIM_HIP_OK;
 }

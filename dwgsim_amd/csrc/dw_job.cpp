@@ -120,6 +120,13 @@ struct dwgsim_hip_job {
     std::vector<std::vector<std::unique_ptr<PinBuf>>> bufs; std::vector<std::vector<PinBuf *>> free_bufs;
     bool tracing = false; double t0 = 0;
     int max_bufs = 8;      // (the batches in flight per device, one per output set of the context, + what the delivery threads hold)
+    // DWGSIM_HIP_SOLO=r/W (measurement only): the ONE device of this job does exactly what device r of a W-device job does -- walks every group it
+    // takes part in, counts and simulates batches r, r + W, ... of each, copies them out, delivers them -- and nothing of the other devices' work.  The
+    // path has no device-to-device traffic, so that is what device r's GPU and PCIe link would carry.  The other devices' batches are treated as
+    // delivered and their random-read counts as zero: the OUTPUT of such a run is a share of the job with wrong rand_ii offsets -- for a counting
+    // sink and a clock, not for files.  VD = devices the batches are dealt to (W, or ND), vrank(d) = which of them device d is.
+    int solo_rank = -1, VD = 0;
+    int vrank(int d) const { return solo_rank >= 0 ? solo_rank : d; }
 };
 
 namespace {
@@ -235,14 +242,15 @@ struct Worker {
     // random reads of my batches of the group, counted without producing them (k_place on the walk stream): one launch, one count per batch
     bool count_mine(const std::shared_ptr<GroupJob> &g, int h)
     {
-        if (d < g->nd) {
+        if (j->vrank(d) < g->nd) {
             std::vector<dwgsim_hip_range_t> all; std::vector<int> owner;
-            for (int b = d; b < (int)g->batches.size(); b += g->nd) for (auto q : g->batches[(size_t)b]) { q.contig += h; all.push_back(q); owner.push_back(b); }
+            for (int b = j->vrank(d); b < (int)g->batches.size(); b += g->nd) for (auto q : g->batches[(size_t)b]) { q.contig += h; all.push_back(q); owner.push_back(b); }
             std::vector<uint64_t> per(all.size(), 0); uint64_t tot = 0;
             if (!all.empty() && dwgsim_hip_count_random_ranges(x, all.data(), (int)all.size(), &tot, per.data()) < 0) { fail_ctx(); return false; }
             std::lock_guard<std::mutex> lk(j->m);
             for (size_t q = 0; q < all.size(); ++q) g->batch_rand[(size_t)owner[q]] += per[q];
             ++g->counted;
+            if (j->solo_rank >= 0) g->counted = g->nd;      // (the others' counts are taken as zero)
             j->cv.notify_all();
         }
         return true;
@@ -258,7 +266,7 @@ struct Worker {
             if (nx && takes_part(*nx)) { const int nh = prep(nx); if (nh < 0) return false; prepped = nx; prepped_handle = nh; prepped_waited = prepped_counted = false; }
         }
         if (prepped && !prepped_waited && dwgsim_hip_mutate_poll(x, prepped_handle) == 1) { if (!walked(prepped, prepped_handle)) return false; prepped_waited = true; }
-        if (prepped && prepped_waited && !prepped_counted && j->ND > 1 && j->want_reads) { if (!count_mine(prepped, prepped_handle)) return false; prepped_counted = true; }
+        if (prepped && prepped_waited && !prepped_counted && j->VD > 1 && j->want_reads) { if (!count_mine(prepped, prepped_handle)) return false; prepped_counted = true; }
         return true;
     }
 
@@ -299,7 +307,7 @@ struct Worker {
                 if (pb.bo.n[s]) ++pb.bo.left;
             }
         }
-        if (pb.b < 2 * j->ND) trace(j, "dev %d group %d: batch %d kernels done, copy issued (%.1f MB)", d, pb.g->id, pb.b, (pb.bo.n[0] + pb.bo.n[1] + pb.bo.n[2]) / 1e6);
+        if (pb.b < 2 * j->VD) trace(j, "dev %d group %d: batch %d kernels done, copy issued (%.1f MB)", d, pb.g->id, pb.b, (pb.bo.n[0] + pb.bo.n[1] + pb.bo.n[2]) / 1e6);
         if (pb.last_of_group && dwgsim_hip_drop_contig(x, pb.h) < 0) { fail_ctx(); return false; }      // (the kernels of the group's last batch are done: nothing reads it any more)
         return true;
     }
@@ -307,7 +315,7 @@ struct Worker {
     bool stage_b(Pending &pb)
     {
         if (j->sink.reads && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
-        if (pb.b < 2 * j->ND) trace(j, "dev %d group %d: batch %d landed", d, pb.g->id, pb.b);
+        if (pb.b < 2 * j->VD) trace(j, "dev %d group %d: batch %d landed", d, pb.g->id, pb.b);
         const dwgsim_hip_batch_t &bt = pb.bt; BatchOut &bo = pb.bo; GroupJob *g = pb.g.get();
         uint64_t shown = 0; bool aborted = false;
         {
@@ -350,7 +358,7 @@ struct Worker {
     void run()
     {
         pin_thread_to_device_node(j->devices[(size_t)d]);
-        if (d == 0 && j->want_mut && j->sink.mutations) mut_thread = std::thread([this]() { mut_loop(); });
+        if (j->vrank(d) == 0 && j->want_mut && j->sink.mutations) mut_thread = std::thread([this]() { mut_loop(); });
         bool fine = true;
         for (;;) {
             std::shared_ptr<GroupJob> g;
@@ -377,12 +385,17 @@ struct Worker {
         mut_stop();
     }
 
-    bool takes_part(const GroupJob &g) const { return d == 0 || (j->want_reads && d < g.nd); }      // device 0 also writes the mutation text
+    bool takes_part(const GroupJob &g) const { return j->vrank(d) == 0 || (j->want_reads && j->vrank(d) < g.nd); }      // device 0 also writes the mutation text
 
     bool process(const std::shared_ptr<GroupJob> &g)
     {
         if (!takes_part(*g)) {      // a small group is not worth a copy on every device
             std::lock_guard<std::mutex> lk(j->m);
+            if (j->solo_rank >= 0) {      // (device 0, which is not here, would publish the group's counts: zero, as all the others' are)
+                g->counted = g->nd;
+                auto nx = group_by_id(j, g->id + 1);
+                if (nx && !nx->base_known && g->base_known) { nx->rand_base = g->rand_base; nx->base_known = true; }
+            }
             if (--g->stage_users == 0) { j->stage_busy[g->stage_slot] = false; }
             j->cv.notify_all();
             return true;
@@ -402,9 +415,9 @@ struct Worker {
         }
         const int nb = (int)g->batches.size();
         std::vector<int> mine;
-        if (j->want_reads && d < g->nd) for (int b = d; b < nb; b += g->nd) mine.push_back(b);
+        if (j->want_reads && j->vrank(d) < g->nd) for (int b = j->vrank(d); b < nb; b += g->nd) mine.push_back(b);
         auto ranges_of = [&](int b) { std::vector<dwgsim_hip_range_t> r = g->batches[(size_t)b]; for (auto &q : r) q.contig += h; return r; };
-        if (j->ND > 1 && j->want_reads) {
+        if (j->VD > 1 && j->want_reads) {
             if (!counted && !count_mine(g, h)) return false;
             std::unique_lock<std::mutex> lk(j->m);
             auto counts_in = [&]() { return j->failed.load() || (g->counted >= g->nd && g->base_known); };
@@ -433,7 +446,7 @@ struct Worker {
             const int b = mine[q];
             if (!ok()) return false;
             uint64_t rbase;
-            if (j->ND > 1) { rbase = g->rand_base; for (int t = 0; t < b; ++t) rbase += g->batch_rand[(size_t)t]; }      // (batch_rand is final: all devices have published)
+            if (j->VD > 1) { rbase = g->rand_base; for (int t = 0; t < b; ++t) rbase += g->batch_rand[(size_t)t]; }      // (batch_rand is final: all devices have published)
             else { rbase = first_batch_of_job ? 0 : DWGSIM_HIP_RAND_CHAIN; first_batch_of_job = false; }
             const auto r = ranges_of(b);
             const int slot = (int)(kk % DWGSIM_HIP_SLOTS);      // (free: at most DWGSIM_HIP_SLOTS - 1 batches are in flight here)
@@ -467,6 +480,7 @@ void deliver_loop(dwgsim_hip_job *j, int s)
         const int nb = j->want_reads ? (int)g->batches.size() : 0;
         for (int b = 0; b < nb; ++b) {
             BatchOut bo;
+            if (j->solo_rank >= 0 && b % g->nd != j->solo_rank) continue;      // (another device's batch: not made here)
             {
                 std::unique_lock<std::mutex> lk(j->m);
                 j->cv.wait(lk, [&]() { return j->failed.load() || g->joined > b; });      // simulated, and the abort rule's verdict over everything up to it is in
@@ -495,7 +509,7 @@ void retire_loop_step(dwgsim_hip_job *j)      // j->m held
         bool all_taken = true;
         for (int d = 0; d < j->ND; ++d) if (j->next_group[(size_t)d] <= g->id) all_taken = false;
         if (!delivered || !all_taken || g->stage_users > 0) break;
-        if (j->ND == 1) for (uint64_t r : g->got_rand) j->total_rand += r;
+        if (j->VD == 1) for (uint64_t r : g->got_rand) j->total_rand += r;
         j->groups.pop_front();
     }
 }
@@ -517,7 +531,7 @@ int dispatch_pending(dwgsim_hip_job *j)
     }
     // the group's pairs in file order, cut into batches; batch b belongs to device b mod nd
     g->pairs = 0; for (int64_t n : g->n_pairs) g->pairs += (uint64_t)n;
-    g->nd = j->ND;
+    g->nd = j->VD;
     while (g->nd > 1 && g->pairs / (uint64_t)g->nd < j->min_share) --g->nd;
     if (j->want_reads && g->pairs) {
         // a multiple of nd near-equal batches of at most batch_pairs pairs: every device gets the same number of them, of the same size
@@ -537,6 +551,10 @@ int dispatch_pending(dwgsim_hip_job *j)
     }
     const size_t nb = g->batches.size();
     g->batch_rand.assign(nb, 0); g->fail_seg.assign(nb, std::array<uint64_t, 4>{0, 0, 0, 0}); g->got_rand.assign(nb, 0); g->out.assign(nb, BatchOut());
+    if (j->solo_rank >= 0) {      // (the other devices' batches: as if simulated, joined -- their abort-rule summaries are the identity -- and delivered)
+        for (size_t b = 0; b < nb; ++b) if ((int)(b % (size_t)g->nd) != j->solo_rank) { g->out[b].ready = true; ++g->batches_done; }
+        while (g->joined < (int)nb && g->out[(size_t)g->joined].ready) ++g->joined;
+    }
     g->stage_users = j->ND;
     std::unique_lock<std::mutex> lk(j->m);
     // at most two groups in front of the devices: the staging of a third one is being filled meanwhile
@@ -544,7 +562,7 @@ int dispatch_pending(dwgsim_hip_job *j)
     if (j->failed.load()) return DWGSIM_HIP_ERR_FAILED;
     g->id = j->n_dispatched++;
     if (g->id == 0) { g->base_known = true; g->rand_base = 0; }
-    else if (auto pv = group_by_id(j, g->id - 1)) { if (pv->counted >= pv->nd && pv->base_known && j->ND > 1) { uint64_t t = pv->rand_base; for (uint64_t c : pv->batch_rand) t += c; g->rand_base = t; g->base_known = true; } }
+    else if (auto pv = group_by_id(j, g->id - 1)) { if (pv->counted >= pv->nd && pv->base_known && j->VD > 1) { uint64_t t = pv->rand_base; for (uint64_t c : pv->batch_rand) t += c; g->rand_base = t; g->base_known = true; } }
     else { g->rand_base = j->total_rand; g->base_known = true; }      // the group in front has been retired already: its total is final
     j->groups.push_back(g);
     j->cv.notify_all();
@@ -587,6 +605,11 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
     if (n_devices <= 0 || !devices) { const int n = dwgsim_hip_device_count(); for (int d = 0; d < n; ++d) devs.push_back(d); }      // every device the process sees
     else devs.assign(devices, devices + n_devices);
     if (devs.empty()) { fprintf(stderr, "dwgsim-hip: no usable HIP device; the hot path has no CPU fallback\n"); return bad(DWGSIM_HIP_ERR_DEVICE); }
+    int solo_r = -1, solo_w = 0;
+    if (const char *e = getenv("DWGSIM_HIP_SOLO")) {      // "r/W": measurement only (struct dwgsim_hip_job)
+        if (sscanf(e, "%d/%d", &solo_r, &solo_w) != 2 || solo_w < 1 || solo_r < 0 || solo_r >= solo_w) { fprintf(stderr, "dwgsim-hip: DWGSIM_HIP_SOLO wants r/W with 0 <= r < W\n"); return bad(DWGSIM_HIP_ERR_ARG); }
+        devs.resize(1);
+    }
     auto *j = new dwgsim_hip_job();
     j->tracing = getenv("DWGSIM_HIP_TRACE") != nullptr; j->t0 = mono_s();
     j->prm = *p;
@@ -600,6 +623,7 @@ dwgsim_hip_job_t *dwgsim_hip_job_create(const dwgsim_hip_params_t *p, const int 
     if (j->opt.min_share) j->min_share = j->opt.min_share;
     j->want_mut = p->output_type != 1; j->want_reads = p->output_type != 2;
     j->devices = devs; j->ND = (int)devs.size();
+    j->VD = solo_r >= 0 ? solo_w : j->ND; j->solo_rank = solo_r;
     j->ctx.assign((size_t)j->ND, nullptr);
     {   // one context per device, made side by side (a context costs about 0.1 s of runtime set-up, code objects and buffers)
         std::vector<int> errs((size_t)j->ND, 0);

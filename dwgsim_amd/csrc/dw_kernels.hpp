@@ -30,7 +30,7 @@ constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_POS_PER_BLOCK = SCAN_POS_PER_THREAD * SCAN_THREADS;   // 4096
-constexpr int CELL_PAD = 32;             // cells are allocated with 32 readable pad bytes after the last contig
+constexpr int CELL_PAD = 64;             // cells are allocated with 64 pad bytes after the last contig: vector loads run past a contig end, and k_dirty_chunks handles whole 64-cell chunks (a group total is a multiple of 16 only)
 constexpr int GROUP_ALIGN = SCAN_POS_PER_BLOCK;   // contigs that are resident together share ONE coordinate space ("group"): contig k starts at a multiple of this many cells,
                                          // so that a block of the position-parallel walk kernels, a 32-cell chunk of the read view and a 64-cell summary all lie inside one contig
 constexpr int MAX_ATTEMPTS = 10000;      // dwgsim.c:837
@@ -100,7 +100,7 @@ struct SimParams {
 
 // -B: per-base calibration of the Ion Torrent flow error (dwgsim_opt.c:415-457): n_reads random reads of `len` bases of read end `end`
 struct CalibArgs {
-    uint32_t seed; int32_t end, len; uint64_t n_reads;
+    uint32_t seed; int32_t end, len; uint64_t n_reads, first_read, chunk_reads;      // reads [first_read, min(first_read + chunk_reads, n_reads)) in this launch (the scratch is sized for a chunk)
     uint64_t thr;                   // ceil(e * 2^32) of the uncalibrated -e
     const uint8_t *flow; int32_t flow_len, lds_words, stack_words;       // lds_words: words per lane of the read buffer (16 bases each)
     uint32_t *scratch;              // per block [lds_words][PAIRS_PER_BLOCK] words

@@ -1393,7 +1393,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     __syncthreads();
     fill_flow_tables(s_ft, a.flow_len, tid, nthr);
     __syncthreads();
-    const uint64_t jj = (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
+    const uint64_t jj = a.first_read + (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
     uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)a.lds_words * nthr) + tid;
     const int capb = 16 * a.lds_words;
     int32_t n_err = 0; int s_out = 0;
@@ -1422,7 +1422,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
 }
 void launch_calibrate(hipStream_t st, const CalibArgs &a)
 {
-    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(a.n_reads, PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)a.stack_words * PAIRS_PER_BLOCK * 4, st, a);
+    hipLaunchKernelGGL(k_calibrate, dim3(cdiv(std::min(a.chunk_reads, a.n_reads - a.first_read), (uint64_t)PAIRS_PER_BLOCK)), dim3(PAIRS_PER_BLOCK), (size_t)a.stack_words * PAIRS_PER_BLOCK * 4, st, a);
 }
 #endif
 #if DW_HAS(11)

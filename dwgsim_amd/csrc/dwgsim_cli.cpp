@@ -17,7 +17,10 @@
 //     DWGSIM_HIP_READ_THREADS threads that index, verify and copy the mapped FASTA (default: all cores); DWGSIM_HIP_READ_CHUNK bytes of text per task (4 Mi)
 //     DWGSIM_HIP_TIMING    print the stage times
 //     DWGSIM_HIP_TEARDOWN  free every buffer and context before returning from main (by default the process ends as soon as the files are closed)
-//     DWGSIM_HIP_SINK      "null": measurement aid -- the FASTQ deliveries are counted, not written (the .gz files stay empty)
+//     DWGSIM_HIP_SINK      "null": measurement aid -- the FASTQ deliveries are counted, not written (the .gz files stay empty); "memcpy": every delivery is copied
+//                          once into a scratch buffer by the delivering thread (the least any consumer does with it): with DWGSIM_HIP_TIMING the line reports the time
+//                          the per-stream delivery threads spent inside the sink, i.e. the rate ONE delivery thread can sustain (the job level's ceiling per stream)
+//     DWGSIM_HIP_SOLO      "r/W": measurement aid (dw_job.cpp) -- this process's one device does what device r of a W-device job does, nothing else
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -430,8 +433,9 @@ static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return
 // what the job delivers, written as the reference writes it (dwgsim.c:919-981 -> the three .gz files, mut.c:781-893 -> the two mutation files)
 struct FileSink {
     FILE *fp_txt = nullptr, *fp_vcf = nullptr, *fgz[3] = {nullptr, nullptr, nullptr};
-    DeflatePool *pool = nullptr; bool null_sink = false;
-    std::atomic<uint64_t> bytes_in{0}, bytes_out{0};
+    DeflatePool *pool = nullptr; bool null_sink = false, memcpy_sink = false;
+    std::atomic<uint64_t> bytes_in{0}, bytes_out{0}, sink_ns[3] = {{0}, {0}, {0}}, sink_bytes[3] = {{0}, {0}, {0}};
+    std::vector<char> scratch[3];
     static int mutations(void *u, const char *, const char *txt, size_t tl, const char *vcf, size_t vl)
     {
         FileSink *s = (FileSink *)u;
@@ -446,6 +450,14 @@ struct FileSink {
         if (!f) return 1;
         s->bytes_in += text_len;
         if (s->null_sink) { s->bytes_out += len; return 0; }
+        if (s->memcpy_sink) {      // (one thread per stream calls this: scratch[stream] is that thread's)
+            timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+            if (s->scratch[stream].size() < len) s->scratch[stream].resize(len);
+            memcpy(s->scratch[stream].data(), data, len);
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            s->sink_ns[stream] += (uint64_t)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)); s->sink_bytes[stream] += len;
+            s->bytes_out += len; return 0;
+        }
         if (gz) { s->bytes_out += len; return fwrite(data, 1, len, f) == len ? 0 : 1; }
         const long before = ftell(f);
         if (!s->pool->write(f, (const char *)data, len)) return 1;
@@ -597,7 +609,7 @@ int main(int argc, char **argv)
     fprintf(stderr, "[dwgsim_core] %d sequences, total length: %llu\n", (int)tab_names.size(), (unsigned long long)tot_len);
 
     const bool has_bfast = want_reads && o.reads_output_type != 1, has_bwa = want_reads && o.reads_output_type != 2;
-    if (const char *e = getenv("DWGSIM_HIP_SINK")) fs.null_sink = !strcmp(e, "null");
+    if (const char *e = getenv("DWGSIM_HIP_SINK")) { fs.null_sink = !strcmp(e, "null"); fs.memcpy_sink = !strcmp(e, "memcpy"); }
     std::string p = out_prefix;
     if (want_mut) {
         fs.fp_txt = fopen((p + ".mutations.txt").c_str(), "w"); fs.fp_vcf = fopen((p + ".mutations.vcf").c_str(), "w");
@@ -662,6 +674,9 @@ int main(int argc, char **argv)
                         streaming ? " (.fai)" : " (FASTA read into memory)", t_fasta - t_start, t_ctx - t_fasta, streaming ? "FASTA read, " : "", t_fed - t_ctx, t_out_done - t_fed, t_out_done - t_start,
                         fs.bytes_in.load() / 1e9, fs.bytes_out.load() / 1e9,
                         gpu_gzip ? "gzip members made on the GPU" : (std::string("zlib level ") + std::to_string(gz_level) + " on " + std::to_string(nthreads) + " host threads").c_str());
+    if (timing && fs.memcpy_sink) for (int st = 0; st < 3; ++st) if (fs.sink_bytes[st].load())
+        fprintf(stderr, "[dwgsim-hip-sink] stream %d: %.2f GB copied by its delivery thread in %.3f s inside the sink = %.1f GB/s while delivering (the run took %.2f s)\n", st, fs.sink_bytes[st].load() / 1e9,
+                fs.sink_ns[st].load() / 1e9, fs.sink_bytes[st].load() / (double)std::max<uint64_t>(fs.sink_ns[st].load(), 1), t_out_done - t_start);
     if (timing) { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); const double e = ts.tv_sec + ts.tv_nsec * 1e-9; fprintf(stderr, "[dwgsim-hip-clock] main entered at %.3f, output complete at %.3f (seconds since the epoch)\n", e - (t_out_done - t_start) - (now_s() - t_out_done), e - (now_s() - t_out_done)); }
     if (fs.fp_txt) fclose(fs.fp_txt);
     if (fs.fp_vcf) fclose(fs.fp_vcf);

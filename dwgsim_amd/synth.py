@@ -97,6 +97,95 @@ def repeat_rich_contig(length: int, seed: int) -> np.ndarray:
     return out
 
 
+def genome_like_contig(length: int, seed: int, n_runs=(), gc: float = 0.41, sine_frac: float = 0.11, line_frac: float = 0.17, sat_every: int = 9000,
+                       homopolymer_every: int = 2500, soft_mask: bool = True) -> np.ndarray:
+    """A contig with a genome's COMPOSITION instead of i.i.d. uniform bases (round-5 verdict, item 7): the Ion Torrent flow model does one event test per
+    homopolymer (dwgsim.c:281-364) and left-justification walks through repeats (mut.c:482-589), so uniform bases flatter both.
+      * background: independent bases with the given GC content (41 %: human; 50.8 %: E. coli);
+      * an interspersed SINE-like family: copies of ONE 300-base consensus, each with ~10 % of its bases substituted, a poly-A tail of 12-30 bases, either
+        strand, `sine_frac` of the contig (Alu: 11 % of the human genome); a LINE-like family of 1 kb at ~15 % divergence, 5'-truncated copies, `line_frac` (L1: 17 %);
+      * microsatellites: a tandem repeat of a 1-6 base unit, 8-45 copies, about every `sat_every` bases; homopolymer runs of 6-24 bases about every
+        `homopolymer_every` bases;
+      * repeats are SOFT-MASKED (lower case) as RepeatMasker / UCSC FASTA files have them (nst_nt4_table maps both cases alike: dwgsim.c:56-73);
+      * N blocks as given.
+    Everything is drawn from splitmix64 streams of `seed`: the same bytes on every machine."""
+    with np.errstate(over="ignore"):
+        # background with the GC content: one byte of the stream per base through a 256-entry table
+        n_gc = int(round(gc * 128)) * 2                      # table entries that are C or G
+        tab = np.empty(256, dtype=np.uint8)
+        half_at, half_gc = (256 - n_gc) // 2, n_gc // 2
+        tab[:half_at] = ord("A"); tab[half_at:half_at + half_gc] = ord("C"); tab[half_at + half_gc:half_at + n_gc] = ord("G"); tab[half_at + n_gc:] = ord("T")
+        out = np.empty((length + 7) // 8 * 8, dtype=np.uint8)
+        CH = 1 << 21
+        for a in range(0, len(out) // 8, CH):
+            b = min(len(out) // 8, a + CH)
+            k = np.arange(a + 1, b + 1, dtype=np.uint64)
+            z = np.uint64(seed) + k * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            out[a * 8:b * 8] = tab[z.view(np.uint8)]
+        out = out[:length]
+    lower = np.zeros(length, dtype=bool)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def family(cons_len, frac, div, fam_seed, tail, truncate):
+        if frac <= 0 or length < 4 * cons_len:
+            return
+        cons = acgt[(_splitmix64(cons_len, fam_seed) >> np.uint64(40)).astype(np.int64) & 3]
+        n = int(frac * length / (cons_len * (0.6 if truncate else 1.0)))
+        r = _splitmix64(4 * n, fam_seed ^ 0x5151)
+        pos = np.sort((r[0::4] % np.uint64(max(1, length - cons_len - 64))).astype(np.int64))
+        strand = (r[1::4] & np.uint64(1)).astype(bool)
+        cut = ((r[2::4] % np.uint64(cons_len * 4 // 5)).astype(np.int64) if truncate else np.zeros(n, dtype=np.int64))      # 5' truncation (LINE-like)
+        tails = (r[3::4] % np.uint64(19)).astype(np.int64) + 12 if tail else np.zeros(n, dtype=np.int64)
+        mut = _splitmix64(n * cons_len, fam_seed ^ 0xA11).reshape(n, cons_len)
+        hit = (mut & np.uint64(0xFFFF)).astype(np.float64) < div * 65536.0
+        shift = ((mut >> np.uint64(20)) % np.uint64(3)).astype(np.int64) + 1
+        idx = np.searchsorted(acgt, cons)[None, :].repeat(n, 0)
+        copies = acgt[np.where(hit, (idx + shift) & 3, idx)]
+        last_end = 0
+        for i in range(n):
+            c = copies[i, cut[i]:]
+            if tails[i]:
+                c = np.concatenate([c, np.full(tails[i], ord("A"), dtype=np.uint8)])
+            if strand[i]:
+                c = comp[c[::-1]]
+            p = max(int(pos[i]), last_end)
+            if p + len(c) >= length:
+                break
+            out[p:p + len(c)] = c; lower[p:p + len(c)] = True
+            last_end = p + len(c)
+
+    family(300, sine_frac, 0.10, seed ^ 0x51AE, True, False)
+    family(1000, line_frac, 0.15, seed ^ 0x11AE, False, True)
+    units = [b"A", b"T", b"C", b"G", b"CA", b"GT", b"AT", b"GA", b"AAT", b"CAG", b"AAAT", b"GATA", b"TTAGGG", b"AAAAC"]
+    if sat_every > 0:
+        n = length // sat_every
+        r = _splitmix64(3 * n + 3, seed ^ 0x5A7)
+        for i in range(n):
+            p = i * sat_every + int(r[3 * i] % np.uint64(sat_every))
+            u = np.frombuffer(units[int(r[3 * i + 1] % np.uint64(len(units)))], dtype=np.uint8)
+            reps = int(r[3 * i + 2] % np.uint64(38)) + 8
+            seg = np.tile(u, reps)
+            if p + len(seg) < length:
+                out[p:p + len(seg)] = seg; lower[p:p + len(seg)] = True
+    if homopolymer_every > 0:
+        n = length // homopolymer_every
+        r = _splitmix64(3 * n + 3, seed ^ 0x40B0)
+        for i in range(n):
+            p = i * homopolymer_every + int(r[3 * i] % np.uint64(homopolymer_every))
+            run = int(r[3 * i + 2] % np.uint64(19)) + 6
+            if p + run < length:
+                out[p:p + run] = acgt[int(r[3 * i + 1] % np.uint64(4)) if int(r[3 * i + 1] >> np.uint64(8)) % 10 >= 6 else (0 if int(r[3 * i + 1]) & 4 else 3)]      # mostly poly-A / poly-T
+    if soft_mask:
+        out[lower] |= 0x20
+    for a, b in n_runs:
+        out[a:b] = ord("N")
+    return out
+
+
 # named workloads (SURVEY.md 8d)
 def workload_contigs(name: str):
     if name == "tiny":            # a few kb with an N run, for unit tests
@@ -107,6 +196,10 @@ def workload_contigs(name: str):
         return [("ecoli_synth", random_contig(4_641_652, 1))]
     if name == "chr20":           # S3: chr20-length with telomere / internal N blocks
         return [("chr20_synth", random_contig(64_444_167, 2, [(0, 60_000), (26_400_000, 26_900_000), (64_334_167, 64_444_167)]))]
+    if name == "ecoli_like":      # S2 with a bacterial genome's composition: 50.8 % GC, a few insertion-sequence copies and rRNA operons (1 kb family, 1 %), no soft-masking
+        return [("ecoli_like", genome_like_contig(4_641_652, 101, gc=0.508, sine_frac=0.0, line_frac=0.012, sat_every=60000, homopolymer_every=20000, soft_mask=False))]
+    if name == "chr20_like":      # S3 with a human chromosome's composition: 41 % GC, SINE- / LINE-like families, microsatellites, homopolymers, soft-masked repeats
+        return [("chr20_like", genome_like_contig(64_444_167, 102, [(0, 60_000), (26_400_000, 26_900_000), (64_334_167, 64_444_167)]))]
     if name == "assembly5k":      # a scaffold-level assembly: 5000 contigs, exponential lengths with a mean of 30 kb (N50 ~ 50 kb), 150 Mb in all
         u = (_splitmix64(5000, 77) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
         lens = np.maximum(1000, (-30000.0 * np.log(1.0 - u)).astype(np.int64))

@@ -134,6 +134,7 @@ const char *dwgsim_hip_last_error(const dwgsim_hip_ctx_t *ctx);
  * Returns a handle >= 0 or an error code. */
 int dwgsim_hip_add_contig(dwgsim_hip_ctx_t *ctx, const char *name, const uint8_t *ascii, int64_t len,
                           uint32_t contig_index);
+/* Releases the contig's group.  Every batch that reads the group must have been waited for (dwgsim_hip_wait): DWGSIM_HIP_ERR_STATE otherwise. */
 int dwgsim_hip_drop_contig(dwgsim_hip_ctx_t *ctx, int contig);
 
 /* Several contigs at once -- a GROUP.  The reference's contig loop (dwgsim.c:519-625) costs nothing per contig beyond a calloc; here a contig

@@ -21,6 +21,19 @@ for fasta, flags in [("ex1.fa", "-z 13 -N 160"), ("odd.fa", "-z 3 -N 200 -1 50 -
                      ("tiny.fa", "-z 9 -N 200 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 200 -2 100 -e 0.02 -E 0.03 -d 600"),
                      ("tiny.fa", "-z 3 -N 40 -1 1300 -2 1400 -d 3600 -s 40 -n 60")]:
     compare_case(lib, oracle, os.path.join(g, fasta), flags, batch_pairs=128)
+# a contig whose length is 16 mod 64 with a mutation in its LAST base: the dirty 64-cell chunk of the sparse walk ends 48 cells past the contig
+# (round 5's advisor: with 32 cells of padding k_dirty_chunks read and wrote 16 bytes past the allocations; the emulator's hipMalloc is exact now)
+import numpy as np, tempfile
+from dwgsim_amd import synth
+with tempfile.TemporaryDirectory() as td:
+    for L in (1040, 4112 + 64):
+        fa = os.path.join(td, f"l{L}.fa"); mf = os.path.join(td, f"m{L}.txt")
+        arr = synth.random_contig(L, 5)
+        synth.write_fasta(fa, [("c16", arr)])
+        alt = "A" if chr(arr[L - 1]) != "A" else "C"
+        open(mf, "w").write(f"c16\t{L}\t{chr(arr[L - 1])}\t{alt}\t3\n")
+        compare_case(lib, oracle, fa, f"-z 5 -N 100 -1 50 -2 50 -d 200 -s 10 -m {mf}", batch_pairs=128)
+        compare_case(lib, oracle, fa, "-z 7 -N 100 -1 50 -2 50 -d 200 -s 10 -r 0.2 -R 0.3", batch_pairs=128)
 # contigs resident together (one coordinate space, launches across contig boundaries), and the job level on three contexts
 compare_case(lib, oracle, os.path.join(g, "odd.fa"), "-z 3 -N 300 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50 -y 0.1", batch_pairs=90, group_bp=1 << 30)
 compare_job_api(lib, oracle, os.path.join(g, "tiny.fa"), "-z 9 -N 300 -y 0.2 -r 0.02 -R 0.5", devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=64, min_share=20)

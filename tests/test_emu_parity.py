@@ -320,6 +320,33 @@ def test_command_line_on_several_contexts_on_cpu_emulation(emu_lib, oracle_bin, 
     assert open(str(tmp_path / "cli.mutations.vcf"), "rb").read() == want["vcf"]
 
 
+def test_solo_rank_of_the_job_level_makes_exactly_that_devices_share(emu_lib, oracle_bin, golden_dir, tmp_path):
+    """DWGSIM_HIP_SOLO=r/W (measurement aid, dw_job.cpp): ONE device plays device r of a W-device job.  The records the W solo runs make are, together, the
+    records of the whole job -- every batch made exactly once, none twice -- apart from the running number in the names of random reads (the other devices'
+    random-read counts are taken as zero in a solo run); only device 0 writes the mutation files.  Several contigs, groups the devices share unequally."""
+    import gzip
+    from parity_common import run_oracle
+    flags = "-z 9 -N 3000 -y 0.2 -r 0.02 -R 0.5 -o 1"
+    fa = os.path.join(golden_dir, "tiny.fa")
+    want = run_oracle(oracle_bin, fa, flags, str(tmp_path))
+
+    def recs(b):
+        L = b.split(b"\n")
+        out = [b"\n".join(L[k:k + 4]) for k in range(0, len(L) - 1, 4)]
+        return [r if not r.startswith(b"@rand") else b"@rand" + r.split(b"\n", 1)[1] for r in out]
+    for W in (2, 3):
+        got = {0: [], 1: []}
+        for r in range(W):
+            env = dict(os.environ, DWGSIM_HIP_SOLO=f"{r}/{W}", DWGSIM_HIP_MIN_SHARE="20", DWGSIM_HIP_BATCH="170", DWGSIM_HIP_GZIP="cpu", DWGSIM_HIP_THREADS="2")
+            subprocess.run([os.path.join(HERE, "emu", "dwgsim-emu")] + flags.split() + [fa, str(tmp_path / f"s{W}_{r}")], check=True, stderr=subprocess.DEVNULL, env=env, timeout=300)
+            for k, suf in [(0, "bwa.read1.fastq.gz"), (1, "bwa.read2.fastq.gz")]:
+                got[k] += recs(gzip.open(str(tmp_path / f"s{W}_{r}.{suf}"), "rb").read())
+            txt = open(str(tmp_path / f"s{W}_{r}.mutations.txt"), "rb").read()
+            assert txt == (want["txt"] if r == 0 else b""), (W, r)
+        for k in (0, 1):
+            assert sorted(got[k]) == sorted(recs(want[k])), (W, k)
+
+
 @pytest.mark.parametrize("k", range(6))
 def test_both_record_writers_on_cpu_emulation(emu_lib, oracle_bin, tmp_path, k):
     from parity_common import WRITER_CASES, check_record_writers

@@ -109,6 +109,59 @@ def test_chr20_sized_windows_and_invariants(lib, oracle_bin, tmp_path):
         assert q.min() >= 33 and q.max() <= 73
 
 
+FLOW32 = "TACGTACGTCTGAGCATCGATCGATGTACAGC"
+
+
+@pytest.mark.parametrize("workload,flags,windows", [
+    # sequence with a genome's composition (synth.genome_like_contig: GC content, SINE- / LINE-like repeat families, microsatellites, homopolymers,
+    # soft-masked lower case): the whole E. coli-sized job, and windows + the mutation files of the chr20-sized one, 2 x 150 and Ion Torrent
+    ("ecoli_like", "-z 13 -1 150 -2 150 -C 30 -o 1", None),
+    ("ecoli_like", f"-z 17 -c 2 -f {FLOW32} -1 400 -2 0 -C 6 -e 0.01 -o 1", None),
+    ("chr20_like", "-z 20 -1 150 -2 150 -C 30 -o 1 -r 0.001 -R 0.1", (0, 3_400_000, -4000)),
+    ("chr20_like", "-z 21 -1 150 -2 150 -C 30 -r 0.001 -R 0.1", (2_000_000,)),                      # -o 0, the reference's default: both output families
+    ("chr20_like", f"-z 22 -c 2 -f {FLOW32} -1 400 -2 0 -C 50 -e 0.01 -o 1", (0, 2_100_000, -4000)),
+])
+def test_genome_like_sequence_bit_exact(lib, oracle_bin, tmp_path, workload, flags, windows):
+    """Homopolymers and microsatellites drive the flow model (one event test per homopolymer, the dot-fill rule: dwgsim.c:281-364) and the reach of
+    left-justification (mut.c:482-589); lower-case bases go through nst_nt4_table like upper-case ones (dwgsim.c:56-73)."""
+    fa = str(tmp_path / "ref.fa")
+    contigs = synth.workload_contigs(workload)
+    synth.write_fasta(fa, contigs)
+    params = api.parse_flags(flags, lib)
+    name, arr = contigs[0]
+    assert (arr >= 97).any() or workload == "ecoli_like"
+    sufs = ((0, "bwa.read1.fastq"), (1, "bwa.read2.fastq"), (2, "bfast.fastq"))
+    if windows is None:
+        _oracle(oracle_bin, flags, fa, str(tmp_path / "o"))
+        res = api.run_job(api.parse_flags(flags, lib), contigs, lib=lib)
+        for k, suf in sufs:
+            p = str(tmp_path / ("o." + suf))
+            want = open(p, "rb").read() if os.path.exists(p) else b""
+            assert len(res.streams[k]) == len(want) and hashlib.sha256(res.streams[k]).hexdigest() == hashlib.sha256(want).hexdigest(), suf
+        assert res.mutations_txt == open(str(tmp_path / "o.mutations.txt"), "rb").read()
+        assert res.mutations_vcf == open(str(tmp_path / "o.mutations.vcf"), "rb").read()
+        return
+    n_pairs = api.pairs_for_contig(params, len(arr), len(arr), True, 0, lib)
+    with api.Context(params, 0, lib) as ctx:
+        cid = ctx.add_contig(name, arr, 0)
+        ctx.mutate(cid)
+        txt, vcf = ctx.mutations_text(cid)
+        for k, first in enumerate(windows):
+            cnt = 4000
+            if first < 0:
+                first = n_pairs + first
+            pre = str(tmp_path / f"w{first}")
+            _oracle(oracle_bin, flags, fa, pre, extra=("--emit-range", f"{first}:{cnt}"))
+            rand_base = ctx.count_random(cid, 0, first) if first else 0
+            b = ctx.simulate(cid, first, cnt, rand_base, 0)
+            for s, suf in sufs:
+                want = open(pre + "." + suf, "rb").read() if os.path.exists(pre + "." + suf) else b""
+                got = ctx.fetch(0, s, b.bytes[s]) if b.bytes[s] else b""
+                assert got == want, (first, suf)
+            if k == 0:
+                assert txt == open(pre + ".mutations.txt", "rb").read() and vcf.endswith(open(pre + ".mutations.vcf", "rb").read().split(b"INFO\n", 1)[1])
+
+
 def _assembly_like():
     """A scaffold-level assembly in miniature: 14 contigs from 150 bp to 3 Mb, names with underscores / dots / a 200-character
     name, N-rich and all-N contigs, contigs shorter than a read or a fragment (skip rules #2-#5, dwgsim.c:595-618)."""
