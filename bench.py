@@ -557,6 +557,7 @@ def main():
                 def then():
                     if D > 1:
                         issue(far)                                   # the copy step k - 2 read (C = D + 2): its launches were waited for before step k's first was enqueued
+                    # (the count of step k + 1 below does not queue behind these walks: it runs on the context's count stream, behind the walk of ITS copy only)
                     return prepare(nx, record, issued=D > 1)
                 bases = run(copies[k % C], bases, record, then=then, carry=not args.no_carry)
             drain(0, record)

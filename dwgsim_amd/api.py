@@ -45,11 +45,12 @@ class Range(C.Structure):
 MUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t)
 READS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int)
 MSG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+READS_AT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int)      # (ABI 5) pieces with their offset, from several threads
 
 
 class JobSink(C.Structure):
     """dwgsim_hip_job_sink_t"""
-    _fields_ = [("user", C.c_void_p), ("mutations", MUT_CB), ("reads", READS_CB), ("message", MSG_CB)]
+    _fields_ = [("user", C.c_void_p), ("mutations", MUT_CB), ("reads", READS_CB), ("message", MSG_CB), ("reads_at", READS_AT_CB)]
 
 
 class JobOptions(C.Structure):
@@ -619,7 +620,7 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
 
 
 def run_job_api(params: Params, contigs, devices=None, gzip_on_gpu: bool = True, batch_pairs: int = 0, group_bp: int = 0, min_share: int = 0,
-                lib=None, keep_output: bool = True) -> JobResult:
+                lib=None, keep_output: bool = True, offset_sink: bool = False) -> JobResult:
     """The same job through the JOB level of the C-ABI (dwgsim_hip_job_*): the library schedules, groups, shards over `devices`
     (default: all) and delivers in file order; the sink below only collects.  Streams are returned as text (gzip members are
     decompressed here)."""
@@ -648,7 +649,18 @@ def run_job_api(params: Params, contigs, devices=None, gzip_on_gpu: bool = True,
             raw[stream].append((bool(gz), C.string_at(data, n), text_n))
         return 0
 
-    sink = JobSink(None, MUT_CB(on_mut), READS_CB(on_reads), MSG_CB(lambda u, m: None))
+    import threading
+    at_lock = threading.Lock(); at_pieces = {0: [], 1: [], 2: []}; at_threads = set()
+
+    def on_reads_at(user, stream, offset, data, n, text_n, gz):      # (called from several threads of the job: one per device and stream)
+        blob = C.string_at(data, n) if keep_output else b""
+        with at_lock:
+            at_threads.add(threading.get_ident())
+            order["text_n"][stream] += text_n
+            at_pieces[stream].append((offset, n, bool(gz), blob, text_n))
+        return 0
+
+    sink = JobSink(None, MUT_CB(on_mut), READS_CB(on_reads), MSG_CB(lambda u, m: None), READS_AT_CB(on_reads_at) if offset_sink else READS_AT_CB())
     opt = JobOptions(1 if gzip_on_gpu else 0, 1, batch_pairs, group_bp, min_share)
     err = C.c_int(0)
     devs = (C.c_int * len(devices))(*devices) if devices else None
@@ -678,6 +690,15 @@ def run_job_api(params: Params, contigs, devices=None, gzip_on_gpu: bool = True,
         chk(lib.dwgsim_hip_job_finish(job))
     finally:
         lib.dwgsim_hip_job_destroy(job)
+    if offset_sink:      # the pieces must tile [0, total) of every stream, each exactly once; put in order they are the stream
+        for s_ in range(3):
+            at = 0
+            for off, n, gz, blob, text_n in sorted(at_pieces[s_]):
+                if off != at:
+                    raise DwgsimError(f"reads_at: stream {s_} has a gap or an overlap at offset {at} (next piece at {off})")
+                at += n
+                raw[s_].append((gz, blob, text_n))
+        res.delivery_threads = len(at_threads)
     for s_ in range(3):
         for gz, blob, text_n in raw[s_]:
             piece = _gz.decompress(blob) if gz else blob

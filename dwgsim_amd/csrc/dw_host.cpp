@@ -111,6 +111,8 @@ struct dwgsim_hip_ctx {
     hipStream_t stream = nullptr;            // simulate: kernels of the batches
     hipStream_t copy_stream = nullptr;       // device -> host copies of finished text
     hipStream_t walk_stream = nullptr;       // uploads, the mutation walk, the mutated-cell list: a group can be prepared while another one is being simulated
+    hipStream_t count_stream = nullptr;      // count_random (k_place ..): behind the walk of ITS group only (an event), not behind the walks of groups issued later --
+                                             // on the walk stream the count of step k+1 waited for the walks of steps k+2, k+3 (round 6: profiles/r06_solo_rank_entry.txt)
     std::string err;
     double e_by[2] = {0, 0};
     uint64_t *d_thr[2] = {nullptr, nullptr};
@@ -124,6 +126,8 @@ struct dwgsim_hip_ctx {
     // simulate() working set
     DevBuf meta, fail_summ, block_rand, status_all, out[DWGSIM_HIP_SLOTS][3], split_state, split_hand, split_agg, split_pre, split_chunk;
     // walk-stream working set (grow-only)
+    DevBuf w_slots, w_slot_aux;      // the site scan's per-block slots (dw_walk.hip k_site_scan_slots) and their counts / bases
+    int site_slots = -1; int64_t site_slot_cap = -1;      // "site_slots": -1 choose, 0 the look-back form, 1 the slot form; "site_slot_cap": a slot size to start from (tests: the overflow re-run)
     DevBuf scratch_mask, scratch_cnt, scratch_status, w_cand, w_ev, w_flags, w_lo, w_sufmin, w_bound, w_ppos, w_pcells, up_ascii, l_pos, l_cells, place_segs, place_rand, place_list, place_aux;
     uint8_t *h_up = nullptr; size_t h_up_cap = 0; hipEvent_t ev_up = nullptr; bool up_in_flight = false;      // page-locked staging of a group's sequence
     SimSeg *h_place_segs = nullptr; size_t h_place_segs_cap = 0;
@@ -449,6 +453,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
         HIPC(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_batch));
         HIPC(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamDefault, prio_greatest));
         HIPC(c, hipStreamCreateWithPriority(&c->walk_stream, hipStreamDefault, prio_walk));
+        HIPC(c, hipStreamCreateWithPriority(&c->count_stream, hipStreamDefault, prio_walk));
         HIPC(c, hipEventCreate(&c->ev_up)); HIPC(c, hipEventCreate(&c->ev_cnt0)); HIPC(c, hipEventCreate(&c->ev_cnt1));
         HIPC(c, hipMalloc((void **)&c->d_counters, N_COUNTERS * sizeof(uint64_t)));
         HIPC(c, hipHostMalloc((void **)&c->h_counters, N_COUNTERS * sizeof(uint64_t), hipHostMallocDefault));
@@ -463,8 +468,11 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
             HIPC(c, hipMalloc((void **)&sl.d_rerun_chain, 2 * sizeof(uint64_t)));
             HIPC(c, hipEventCreate(&sl.ev_k0)); HIPC(c, hipEventCreate(&sl.ev_k1)); HIPC(c, hipEventCreate(&sl.ev_end)); HIPC(c, hipEventCreate(&sl.ev_done)); HIPC(c, hipEventCreate(&sl.ev_fetched));
         }
-        { std::vector<uint8_t> fl(64, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
-          HIPC(c, hipMalloc((void **)&c->d_flow, 64)); HIPC(c, hipMemcpy(c->d_flow, fl.data(), 64, hipMemcpyHostToDevice)); }
+        {   // the flow order (64 bytes) and, behind it, the log2 table the flow model's gap draws interpolate in (dw_kernels.hpp flow_log2_table)
+            std::vector<uint8_t> fl(64 + sizeof(uint32_t) * FLOW_LG_ENTRIES, 4); for (size_t i = 0; i < c->flow.size() && i < 64; ++i) fl[i] = c->flow[i];
+            flow_log2_table(reinterpret_cast<uint32_t *>(fl.data() + 64));
+            HIPC(c, hipMalloc((void **)&c->d_flow, fl.size())); HIPC(c, hipMemcpy(c->d_flow, fl.data(), fl.size(), hipMemcpyHostToDevice));
+        }
         // -B (dwgsim_opt.c:415-457): rescale the flow error so that the per-base error rate of 10^6 random reads matches -e
         if (c->prm.data_type == 2 && c->prm.use_base_error) {
             double sf = 0.0;
@@ -481,6 +489,7 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
                 CalibArgs ca;
                 ca.seed = (uint32_t)c->prm.seed; ca.end = i; ca.len = len; ca.n_reads = 1000000;       // ERROR_RATE_NUM_RANDOM_READS, dwgsim_opt.h:5
                 ca.thr = !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0);
+                flow_gap_params(ca.thr, &ca.gap_r, &ca.gap_s);
                 ca.flow = c->d_flow; ca.flow_len = (int32_t)c->flow.size();
                 // a read that outgrows its buffers: once more with twice the room (the reference doubles its buffers, dwgsim.c:296-311) -- by the rule of
                 // dwgsim_hip_wait: up to FLOW_CAP_MAX bases per read.  The scratch holds a CHUNK of the 10^6 reads (at most ~2 GiB), so the room a read
@@ -615,11 +624,12 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->walk_stream) hipStreamSynchronize(c->walk_stream);
+    if (c->count_stream) hipStreamSynchronize(c->count_stream);
     for (auto &g : c->groups) if (g.alive) free_group(g);
     for (auto &g : c->pool) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->split_state, &c->split_hand, &c->split_agg, &c->split_pre, &c->split_chunk, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->scratch_status, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
-                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch, &c->flow_free}) hipFree(b->p);
+                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch, &c->flow_free, &c->w_slots, &c->w_slot_aux}) hipFree(b->p);
     for (int s = 0; s < DWGSIM_HIP_SLOTS; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -640,6 +650,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->walk_stream) hipStreamDestroy(c->walk_stream);
+    if (c->count_stream) hipStreamDestroy(c->count_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -951,7 +962,6 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
         HIPC(c, hipMemsetAsync(g.d_dirty, 0, sizeof(uint32_t) * ((size_t)g.n_dirty_words + 2), st));
         g.dirty_any = false;
     }
-    HIPC(c, hipMemsetAsync(d_status, 0, ((size_t)nblk + 2) * sizeof(uint64_t), st));
     const uint32_t cap = g.walk_cap; const size_t cap_bases = g.walk_cap_bases;
     const size_t ncap = cap ? cap : 1;
     if (ensure(c, c->w_cand, sizeof(int32_t) * ncap) || ensure(c, c->w_ev, sizeof(Event) * ncap) ||
@@ -977,8 +987,24 @@ static int enqueue_walk(dwgsim_hip_ctx_t *c, Group &g)
     uint32_t *d_small = reinterpret_cast<uint32_t *>(&c->d_wcounters[8]);   // [0] max_del, [1..4] tot4: eight words in counters[8..11], so that one copy brings counters[7..11] back
     const Count nc{&c->d_wcounters[7], cap};
     HIPC(c, hipMemsetAsync(&c->d_wcounters[7], 0, 5 * sizeof(uint64_t), st));
-    // K1: candidate sites -> ordered list (one kernel, from the pristine 4-bit view)
-    launch_site_scan_list(st, g.d_refview, total, seg, wp, d_status, d_ticket, d_cand, cap, &c->d_wcounters[7]);
+    // K1: candidate sites -> ordered list, from the pristine 4-bit view.  First attempt: every block into a slot of its own, no block waits for another
+    // (dw_walk.hip k_site_scan_slots: mean + 8 sigma + 32 entries per block of 65 536 positions); a re-run, a mutation rate at which the slots would
+    // be as large as the list itself, or "site_slots" = 0: one kernel with a decoupled look-back
+    {
+        const uint32_t nbs = site_scan_blocks(total);
+        const double m = (double)site_scan_block_positions() * (c->prm.mut_rate > 0 ? c->prm.mut_rate : 0.0);
+        uint32_t slot_cap = (uint32_t)std::min<double>((double)site_scan_block_positions(), m + 8.0 * sqrt(m + 1.0) + 32.0);
+        if (c->site_slot_cap >= 0) slot_cap = (uint32_t)std::max<int64_t>(1, c->site_slot_cap);
+        const size_t slot_bytes = (size_t)nbs * slot_cap * sizeof(int32_t);
+        const bool use_slots = g.walk_attempt == 0 && c->site_slots != 0 && nbs > 0 && (c->site_slots > 0 || slot_bytes <= std::max<size_t>((size_t)64 << 20, (size_t)ncap * 16));
+        if (use_slots) {
+            if (ensure(c, c->w_slots, slot_bytes) || ensure(c, c->w_slot_aux, 2 * (size_t)nbs * sizeof(uint32_t))) return DWGSIM_HIP_ERR_DEVICE;
+            launch_site_scan_slots(st, g.d_refview, total, seg, wp, (int32_t *)c->w_slots.p, slot_cap, (uint32_t *)c->w_slot_aux.p, d_cand, cap, &c->d_wcounters[7], &d_small[6]);
+        } else {
+            HIPC(c, hipMemsetAsync(d_status, 0, ((size_t)nblk + 2) * sizeof(uint64_t), st));
+            launch_site_scan_list(st, g.d_refview, total, seg, wp, d_status, d_ticket, d_cand, cap, &c->d_wcounters[7]);
+        }
+    }
     // K2: events, liveness, insertion-table allocation
     launch_events(st, d_cand, nc, g.d_ref, seg, wp, d_ev, &d_small[0]);
     launch_resolve(st, d_ev, nc, &d_small[0], d_flags, &d_small[1]);
@@ -1088,7 +1114,8 @@ int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *c, int contig)
         }
         const uint64_t n_cand = g.h_wc[7];
         const uint32_t *h_small = reinterpret_cast<const uint32_t *>(&g.h_wc[8]);
-        const bool fits = n_cand <= g.walk_cap && h_small[2] <= g.cap_bases[0] && h_small[4] <= g.cap_bases[1];
+        const bool slot_over = h_small[6] != 0;      // a block of the site scan outgrew its slot (nothing behind it ran: the candidate count was set to 0; h_small[7] = the real one)
+        const bool fits = !slot_over && n_cand <= g.walk_cap && h_small[2] <= g.cap_bases[0] && h_small[4] <= g.cap_bases[1];
         if (fits || g.walk_attempt >= 2) {
             g.walk_pending = false;
             if (!fits) { c->err = "mutation walk: capacities still exceeded after an exact re-run"; return DWGSIM_HIP_ERR_FAILED; }
@@ -1097,7 +1124,7 @@ int dwgsim_hip_mutate_wait(dwgsim_hip_ctx_t *c, int contig)
             return DWGSIM_HIP_OK;
         }
         // exact sizes (the counts read back are those of the complete candidate list unless it was truncated: take generous ones then)
-        g.walk_cap = (uint32_t)std::min<uint64_t>((uint64_t)g.total, n_cand + 16);
+        g.walk_cap = (uint32_t)std::min<uint64_t>((uint64_t)g.total, (slot_over ? (uint64_t)h_small[7] : n_cand) + 16);
         g.walk_cap_bases = std::max<size_t>(g.walk_cap_bases, (size_t)std::max(h_small[2], h_small[4]) * 2 + (size_t)g.walk_cap * 8 + 4096);
         ++g.walk_attempt;
         if (const int rc = enqueue_walk(c, g)) { g.walk_pending = false; return rc; }
@@ -1410,6 +1437,10 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
+    for (int j = 0; j < 2; ++j) {      // Ion Torrent: the gap draws of the flow model, from the read end's (uniform) threshold as dwgsim_hip_create made it (thr[0])
+        const double e0 = c->prm.e_start[j];
+        flow_gap_params(!(e0 > 0) ? 0 : e0 >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e0 * 4294967296.0), &a.flow_gap_r[j], &a.flow_gap_s[j]);
+    }
     a.flow_scratch = nullptr; a.flow_free = nullptr; a.flow_slots = 0;
     if (p.data_type == 2) {
         // the flow model's one in-place buffer per lane, 2 bits per base (dw_read.hpp flow_errors), and the run stack of its pass 2.  In LDS while at
@@ -1447,8 +1478,11 @@ int dwgsim_hip_count_random_ranges(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t
     if (n_pairs == 0) return DWGSIM_HIP_OK;
     Group &g = *gp;
     HIPC(c, hipSetDevice(c->device));
-    hipStream_t st = c->walk_stream;      // (the count of one group can run while batches of another -- or of this one -- are being simulated)
-    // (the haplotype summaries k_place reads -- per 64 and per 1024 cells -- were written with the read views at the end of the walk)
+    hipStream_t st = c->count_stream;     // (the count of one group can run while batches of another -- or of this one -- are being simulated)
+    // (the haplotype summaries k_place reads -- per 64 and per 1024 cells -- were written with the read views at the end of the walk: the count follows
+    // its group's walk by that walk's event, whatever else has been put on the walk stream since)
+    if (g.walk_pending) { if (const int rc = dwgsim_hip_mutate_wait(c, g.first_handle)) return rc; }      // (a walk that exceeded a capacity is run again inside the wait: only then are the summaries final)
+    if (g.ev_walk && g.mutated) HIPC(c, hipStreamWaitEvent(st, g.ev_walk, 0));
     SimArgs a;
     if (const int rc = fill_sim_args(c, g, a)) return rc;
     const size_t ns = segs.size();
@@ -1936,6 +1970,8 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     if (!strcmp(key, "justify_seq")) c->seq_justify = value != 0;
     else if (!strcmp(key, "dense_view")) c->dense_view = value != 0;
     else if (!strcmp(key, "walk_cap")) c->walk_cap = value;
+    else if (!strcmp(key, "site_slots")) c->site_slots = (int)value;
+    else if (!strcmp(key, "site_slot_cap")) c->site_slot_cap = value;
     else if (!strcmp(key, "phases")) c->phases = value != 0;
     else if (!strcmp(key, "writer")) c->writer = (int)value;
     else if (!strcmp(key, "sim_threads")) c->force_threads = (int)value;

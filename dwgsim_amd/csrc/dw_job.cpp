@@ -83,6 +83,9 @@ struct GroupJob {
     bool base_known = false; uint64_t rand_base = 0;              // random reads in front of the group
     std::vector<std::array<uint64_t, 4>> fail_seg; std::vector<uint64_t> got_rand;
     std::vector<BatchOut> out;
+    // reads_at (pieces with their place in the stream, delivered by several threads): a batch's sizes are known when its kernels are done (stage A);
+    // its offsets when the sizes of every batch in front of it are (dwgsim_hip_job::next_off, in file order across groups)
+    std::vector<std::array<uint64_t, 3>> sz, off; std::vector<uint8_t> sized, off_ok;
     int batches_done = 0; bool closed = false;
     int joined = 0; uint64_t fail_acc[4] = {0, 0, 0, 0};          // abort rule: batches 0 .. joined-1 are simulated and their summaries joined, in order
     int mut_done = 0;                                             // (device 0) mutation text delivered
@@ -114,6 +117,9 @@ struct dwgsim_hip_job {
     std::vector<int> next_group;                       // per device: id of the group it takes next
     std::atomic<bool> failed{false}; std::string err;
     std::vector<std::thread> workers; std::thread deliver[3];
+    std::vector<std::thread> deliver_at;               // reads_at: one thread per device and stream
+    uint64_t next_off[3] = {0, 0, 0}; int off_gid = 0, off_b = 0;      // reads_at: the next piece's offsets; the batch (group id, index) they belong to
+    bool has_sink() const { return sink.reads != nullptr || sink.reads_at != nullptr; }
     bool started = false, finished = false;
     uint64_t delivered_pairs = 0; uint64_t total_rand = 0;
     // page-locked output buffers per device
@@ -166,6 +172,24 @@ std::shared_ptr<GroupJob> group_by_id(dwgsim_hip_job *j, int id)      // j->m he
 {
     for (auto &g : j->groups) if (g->id == id) return g;
     return nullptr;
+}
+
+// reads_at: offsets for every batch whose predecessors' sizes are all known (j->m held)
+void assign_offsets(dwgsim_hip_job *j)
+{
+    if (!j->sink.reads_at) return;
+    for (;;) {
+        auto g = group_by_id(j, j->off_gid);
+        if (!g) { if (j->off_gid < j->n_dispatched) { ++j->off_gid; j->off_b = 0; continue; } break; }      // (retired already: it had no batches)
+        const int nb = j->want_reads ? (int)g->batches.size() : 0;
+        while (j->off_b < nb && g->sized[(size_t)j->off_b]) {
+            const size_t b = (size_t)j->off_b;
+            for (int s = 0; s < 3; ++s) { g->off[b][(size_t)s] = j->next_off[s]; j->next_off[s] += g->sz[b][(size_t)s]; }
+            g->off_ok[b] = 1; ++j->off_b;
+        }
+        if (j->off_b < nb) break;
+        ++j->off_gid; j->off_b = 0;
+    }
 }
 
 // ---- one device ----
@@ -297,7 +321,7 @@ struct Worker {
         if (dwgsim_hip_wait(x, pb.slot, &pb.bt) < 0) { fail_ctx(); return false; }
         pb.a_done = true;
         pb.bo = BatchOut(); pb.bo.lane = d; pb.bo.pairs = pb.bt.n_pairs;
-        if (j->sink.reads) {
+        if (j->has_sink()) {
             PinBuf *tb = acquire(j->gzip ? pb.bt.gz_bytes : pb.bt.bytes);
             if (!tb) return false;
             pb.bo.buf = tb;
@@ -305,6 +329,13 @@ struct Worker {
                 pb.bo.n[s] = j->gzip ? pb.bt.gz_bytes[s] : pb.bt.bytes[s]; pb.bo.text_n[s] = pb.bt.bytes[s];
                 if (pb.bo.n[s] && (j->gzip ? dwgsim_hip_fetch_gz_async(x, pb.slot, s, tb->p[s], tb->cap[s]) : dwgsim_hip_fetch_async(x, pb.slot, s, tb->p[s], tb->cap[s])) < 0) { fail_ctx(); return false; }
                 if (pb.bo.n[s]) ++pb.bo.left;
+            }
+            if (j->sink.reads_at) {      // the sizes are known: this batch's offsets, and those of any batch behind it that was only waiting for them
+                std::lock_guard<std::mutex> lk(j->m);
+                for (int s = 0; s < 3; ++s) pb.g->sz[(size_t)pb.b][(size_t)s] = pb.bo.n[s];
+                pb.g->sized[(size_t)pb.b] = 1;
+                assign_offsets(j);
+                j->cv.notify_all();
             }
         }
         if (pb.b < 2 * j->VD) trace(j, "dev %d group %d: batch %d kernels done, copy issued (%.1f MB)", d, pb.g->id, pb.b, (pb.bo.n[0] + pb.bo.n[1] + pb.bo.n[2]) / 1e6);
@@ -314,7 +345,7 @@ struct Worker {
     // stage B: the copy-out has landed: the batch is published (the delivery threads hand it to the sink in file order, behind the abort rule's verdict)
     bool stage_b(Pending &pb)
     {
-        if (j->sink.reads && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
+        if (j->has_sink() && dwgsim_hip_fetch_wait(x, pb.slot) < 0) { fail_ctx(); return false; }
         if (pb.b < 2 * j->VD) trace(j, "dev %d group %d: batch %d landed", d, pb.g->id, pb.b);
         const dwgsim_hip_batch_t &bt = pb.bt; BatchOut &bo = pb.bo; GroupJob *g = pb.g.get();
         uint64_t shown = 0; bool aborted = false;
@@ -498,6 +529,41 @@ void deliver_loop(dwgsim_hip_job *j, int s)
     }
 }
 
+// reads_at: the batches device d made, stream s, each piece with its offset -- one thread per (device, stream): N devices deliver side by side, where the
+// ordered form has ONE thread per stream (21-26 GB/s through a sink that touches the bytes: profiles/r06_solo_rank_entry.txt -- below one device's link)
+void deliver_at_loop(dwgsim_hip_job *j, int d, int s)
+{
+    int gid = 0;
+    for (;;) {
+        std::shared_ptr<GroupJob> g;
+        {
+            std::unique_lock<std::mutex> lk(j->m);
+            j->cv.wait(lk, [&]() { return j->failed.load() || gid < j->n_dispatched || j->no_more; });
+            if (j->failed.load()) return;
+            if (gid >= j->n_dispatched) return;
+            g = group_by_id(j, gid);
+            if (!g) { ++gid; continue; }      // retired already: it had nothing for this thread
+        }
+        const int nb = j->want_reads ? (int)g->batches.size() : 0;
+        for (int b = j->vrank(d); b < nb && j->vrank(d) < g->nd; b += g->nd) {
+            BatchOut bo; uint64_t off = 0;
+            {
+                std::unique_lock<std::mutex> lk(j->m);
+                j->cv.wait(lk, [&]() { return j->failed.load() || (g->joined > b && g->off_ok[(size_t)b]); });      // simulated, landed, behind the abort rule's verdict, and placed
+                if (j->failed.load()) return;
+                bo = g->out[(size_t)b]; off = g->off[(size_t)b][(size_t)s];
+            }
+            if (bo.n[s]) {
+                if (j->sink.reads_at(j->sink.user, s, off, bo.buf->p[s], bo.n[s], bo.text_n[s], j->gzip ? 1 : 0) != 0) { job_fail(j, "dwgsim-hip: writing FASTQ failed"); return; }
+                std::lock_guard<std::mutex> lk(j->m);
+                BatchOut &ref = g->out[(size_t)b];
+                if (--ref.left == 0) { j->free_bufs[(size_t)ref.lane].push_back(ref.buf); ref.buf = nullptr; j->cv.notify_all(); }
+            }
+        }
+        ++gid;
+    }
+}
+
 // the group is complete when every batch was simulated (finish_batch has joined the abort rule's summaries by then) and delivered: retire it
 void retire_loop_step(dwgsim_hip_job *j)      // j->m held
 {
@@ -551,8 +617,9 @@ int dispatch_pending(dwgsim_hip_job *j)
     }
     const size_t nb = g->batches.size();
     g->batch_rand.assign(nb, 0); g->fail_seg.assign(nb, std::array<uint64_t, 4>{0, 0, 0, 0}); g->got_rand.assign(nb, 0); g->out.assign(nb, BatchOut());
+    g->sz.assign(nb, std::array<uint64_t, 3>{0, 0, 0}); g->off.assign(nb, std::array<uint64_t, 3>{0, 0, 0}); g->sized.assign(nb, 0); g->off_ok.assign(nb, 0);
     if (j->solo_rank >= 0) {      // (the other devices' batches: as if simulated, joined -- their abort-rule summaries are the identity -- and delivered)
-        for (size_t b = 0; b < nb; ++b) if ((int)(b % (size_t)g->nd) != j->solo_rank) { g->out[b].ready = true; ++g->batches_done; }
+        for (size_t b = 0; b < nb; ++b) if ((int)(b % (size_t)g->nd) != j->solo_rank) { g->out[b].ready = true; g->sized[b] = 1; ++g->batches_done; }
         while (g->joined < (int)nb && g->out[(size_t)g->joined].ready) ++g->joined;
     }
     g->stage_users = j->ND;
@@ -565,6 +632,7 @@ int dispatch_pending(dwgsim_hip_job *j)
     else if (auto pv = group_by_id(j, g->id - 1)) { if (pv->counted >= pv->nd && pv->base_known && j->VD > 1) { uint64_t t = pv->rand_base; for (uint64_t c : pv->batch_rand) t += c; g->rand_base = t; g->base_known = true; } }
     else { g->rand_base = j->total_rand; g->base_known = true; }      // the group in front has been retired already: its total is final
     j->groups.push_back(g);
+    assign_offsets(j);
     j->cv.notify_all();
     trace(j, "group %d dispatched (%zu contigs, %llu pairs, %zu batches)", g->id, g->names.size(), (unsigned long long)g->pairs, g->batches.size());
     return DWGSIM_HIP_OK;
@@ -585,10 +653,11 @@ int start_threads(dwgsim_hip_job *j)
             std::vector<const char *> nm; for (auto &s : j->tab_names) nm.push_back(s.c_str());
             if (dwgsim_hip_set_mutation_input(j->ctx[(size_t)d], j->mutin_type, j->mutin_path.c_str(), nm.data(), j->tab_lens.data(), (int)nm.size()) < 0) { job_fail(j, dwgsim_hip_last_error(j->ctx[(size_t)d])); return DWGSIM_HIP_ERR_ARG; }
         }
-        if (j->gzip && j->want_reads && j->sink.reads && dwgsim_hip_set_gzip(j->ctx[(size_t)d], 1) < 0) { job_fail(j, dwgsim_hip_last_error(j->ctx[(size_t)d])); return DWGSIM_HIP_ERR_DEVICE; }
+        if (j->gzip && j->want_reads && j->has_sink() && dwgsim_hip_set_gzip(j->ctx[(size_t)d], 1) < 0) { job_fail(j, dwgsim_hip_last_error(j->ctx[(size_t)d])); return DWGSIM_HIP_ERR_DEVICE; }
     }
     for (int d = 0; d < j->ND; ++d) j->workers.emplace_back([j, d]() { Worker w{j, d, j->ctx[(size_t)d]}; w.run(); });
-    if (j->want_reads && j->sink.reads) for (int s = 0; s < 3; ++s) j->deliver[s] = std::thread([j, s]() { deliver_loop(j, s); });
+    if (j->want_reads && j->sink.reads_at) { for (int d = 0; d < j->ND; ++d) for (int s = 0; s < 3; ++s) j->deliver_at.emplace_back([j, d, s]() { deliver_at_loop(j, d, s); }); }
+    else if (j->want_reads && j->sink.reads) for (int s = 0; s < 3; ++s) j->deliver[s] = std::thread([j, s]() { deliver_loop(j, s); });
     return DWGSIM_HIP_OK;
 }
 
@@ -801,6 +870,7 @@ int dwgsim_hip_job_finish(dwgsim_hip_job_t *j)
     { std::lock_guard<std::mutex> lk(j->m); j->no_more = true; j->cv.notify_all(); }
     for (auto &t : j->workers) if (t.joinable()) t.join();
     for (auto &t : j->deliver) if (t.joinable()) t.join();
+    for (auto &t : j->deliver_at) if (t.joinable()) t.join();
     { std::lock_guard<std::mutex> lk(j->m); if (!j->failed.load()) retire_loop_step(j); }
     return j->failed.load() ? DWGSIM_HIP_ERR_FAILED : DWGSIM_HIP_OK;
 }

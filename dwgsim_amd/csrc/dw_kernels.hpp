@@ -13,6 +13,8 @@ constexpr int PLACE_LISTS = 64;          // k_place hands the pairs it cannot de
 #endif
 constexpr int SIM_THREADS = DW_SIM_THREADS;   // k_simulate: threads per block (one lane per read end)
 constexpr int FLOW_STACK_WORDS = 4;           // Ion Torrent pass 2: LDS words per lane for the (base, count) runs that can be pending in front of the examined base (two per word), times the
+constexpr uint32_t FLOW_NEVER = 0xFFFFFFFFu;     // Ion Torrent: "no first draw of this pass scores any more" (dw_read.hpp FlowGap)
+constexpr int FLOW_LG_ENTRIES = 257;              // ... entries of the log2 table the gaps between scoring first draws are computed with (behind the 64 bytes of the flow order)
 constexpr int FLOW_CAP_MAX = 1 << 20;           // Ion Torrent: bases a read may grow to in the flow model (capacity re-runs double the buffers up to this)
 constexpr int FLOW_STACK_WORDS_MAX = 32;      // ... capacity multiplier of the job (a read that outgrows the stack is run again like one that outgrows its buffer), up to this many
 #ifndef DW_ION_THREADS_SMALL
@@ -99,10 +101,41 @@ struct SimParams {
 };
 
 // -B: per-base calibration of the Ion Torrent flow error (dwgsim_opt.c:415-457): n_reads random reads of `len` bases of read end `end`
+// ---- Ion Torrent: the gaps between scoring first draws of the flow model (dw_read.hpp FlowGap; dw_common.hpp D_FLOW0), host side.  Integer arithmetic
+// only, so that the kernels, this file and the CPU restatement the tests check them against agree bit for bit: no libm. ----
+// floor(log2(y) * 2^fb) for y >= 1, fb <= 56: repeated squaring in Q1.63
+inline uint64_t flow_ilog2_fixed(uint64_t y, int fb)
+{
+    const int p = 63 - __builtin_clzll(y);
+    uint64_t m = y << (63 - p), frac = 0;
+    for (int k = 0; k < fb; ++k) {
+        const unsigned __int128 sq = (unsigned __int128)m * m;       // Q2.126
+        if ((uint64_t)(sq >> 127)) { m = (uint64_t)(sq >> 64); frac = (frac << 1) | 1u; }
+        else { m = (uint64_t)(sq >> 63); frac <<= 1; }
+    }
+    return ((uint64_t)p << fb) | frac;
+}
+inline void flow_log2_table(uint32_t *lg)      // FLOW_LG_ENTRIES words: floor(2^32 log2(1 + i / 256)), the last one 2^32 - 1
+{
+    for (int i = 0; i < 256; ++i) lg[i] = (uint32_t)flow_ilog2_fixed(256u + (uint64_t)i, 32);
+    lg[256] = 0xFFFFFFFFu;
+}
+// G = floor(-log2(U) / -log2(1 - thr / 2^32)) as mulhi64(-log2(U) in Q8.56, R) >> s: R = 2^127 / (normalised -log2(1 - e') in Q8.56), s = 63 - its shift
+inline void flow_gap_params(uint64_t thr, uint64_t *R, int32_t *s)
+{
+    *R = 0; *s = 0;
+    if (thr == 0 || thr >= 0x100000000ull) return;      // never / always: no gap is computed
+    const uint64_t Lq = (32ull << 56) - flow_ilog2_fixed(0x100000000ull - thr, 56);
+    const int sh = __builtin_clzll(Lq);
+    const unsigned __int128 q = ((unsigned __int128)1 << 127) / (Lq << sh);
+    *R = (uint64_t)(q >> 64) ? ~0ull : (uint64_t)q; *s = 63 - sh;
+}
+
 struct CalibArgs {
     uint32_t seed; int32_t end, len; uint64_t n_reads, first_read, chunk_reads;      // reads [first_read, min(first_read + chunk_reads, n_reads)) in this launch (the scratch is sized for a chunk)
     uint64_t thr;                   // ceil(e * 2^32) of the uncalibrated -e
-    const uint8_t *flow; int32_t flow_len, lds_words, stack_words;       // lds_words: words per lane of the read buffer (16 bases each)
+    uint64_t gap_r; int32_t gap_s;  // ... and what the gaps between scoring first draws are computed with (flow_gap_params)
+    const uint8_t *flow; int32_t flow_len, lds_words, stack_words;       // flow: 64 bytes of flow order + the log2 table (flow_log2_table)       // lds_words: words per lane of the read buffer (16 bases each)
     uint32_t *scratch;              // per block [lds_words][PAIRS_PER_BLOCK] words
     uint64_t *counters;             // [8] += errors, [9] += read lengths after errors, [2] |= 2 on a buffer overflow
 };
@@ -168,7 +201,8 @@ struct SimArgs {
     uint32_t *flow_scratch;        // scratch slots: the staged reads of one block per SLOT (Ion Torrent DT = 2: flow_words_per_lane words per lane), word w of lane t at [w * nthr + t]
     uint64_t *flow_free;           // ... the slots' free lists, one per XCD (dw_simulate.hip scratch_slot_take): 256 header words + 8 x n_blocks queue words, zeroed per launch
     int32_t flow_slots;            // ... slots per XCD (8 x flow_slots slots in flow_scratch)
-    const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes
+    const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes, followed by the log2 table of the gap draws (FLOW_LG_ENTRIES words)
+    uint64_t flow_gap_r[2]; int32_t flow_gap_s[2];      // Ion Torrent, per read end: flow_gap_params of its threshold e_thr[j][0]
 };
 
 } // namespace dw

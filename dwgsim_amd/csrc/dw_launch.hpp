@@ -7,6 +7,9 @@ namespace dw {
 void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l);
 void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg, WalkParams wp, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1);
 void launch_site_scan_list(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket, int32_t *out, uint32_t cap, uint64_t *n_out);
+uint32_t site_scan_blocks(int64_t l);            // blocks of the site scan over l positions, and the positions a block takes
+uint32_t site_scan_block_positions();
+void launch_site_scan_slots(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, int32_t *slots, uint32_t slot_cap, uint32_t *aux, int32_t *out, uint32_t cap, uint64_t *n_out, uint32_t *over);
 void launch_mark_dirty(hipStream_t st, const Event *ev, Count n, const int32_t *lo, uint32_t *dirty);
 void launch_dirty_chunks(hipStream_t st, bool restore, const uint32_t *dirty, uint32_t n_words, int64_t l_live, const uint8_t *ref, const uint8_t *refview, const uint16_t *refsumm, const uint16_t *refsumm2,
                          uint8_t *cells0, uint8_t *cells1, uint8_t *view0, uint8_t *view1, uint16_t *summ0, uint16_t *summ1, uint16_t *summ2_0, uint16_t *summ2_1);

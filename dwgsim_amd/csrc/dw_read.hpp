@@ -362,71 +362,73 @@ struct BitAppender {
     DW_DEV void push(uint32_t v) { push_many(v, 1); }
     DW_DEV void flush() { if (fill) base[wi * stride] = (uint32_t)acc; }
 };
-// This lane's WINDOW over the first draws of a pass: bit k of `bits` says that the first uniform of event hb + k scores (is below e).  The window
-// lives in registers, slides with the lane (a Philox block = eight events is drawn at its top whenever there is room and some lane of the wave is
-// running short: all lanes draw in step, each its own next block) and is at most 64 events long; a lane that reaches its frontier waits for the
-// next round of draws.  Rounds 3-4 stored whole bitmaps per lane and searched them through memory.
-// oc*: what a scoring event goes on to draw (dw_common.hpp D_FLOW_EV: further errors, insert-or-delete, the dot-fill flow) -- one Philox block
-// (resolve), drawn by the lanes that stand on an event, together.
-struct FlowWin {
-    uint64_t bits, ties; uint32_t hb, hf;    // events [hb, hb + hf) are drawn; hb is a multiple of 8, hf <= 64.  ties: events whose HIGH half equals the threshold's --
-                                             // counted as scoring in `bits` until the low half has been looked at (resolve): 2^-16 of the draws
-    uint32_t oc_pos, oc, oc_dot;             // oc: n_err (1 or 2) | 0x100 insert | 0x200 the event draws on (n_err >= 3): taken from FlowRng where it happens | 0x400 a tie that does not score after all
-    DW_DEV void init() { bits = ties = 0; hb = 0; hf = 0; oc_pos = 0xFFFFFFFFu; oc = 0; oc_dot = 0; }
-    DW_DEV uint32_t frontier() const { return hb + hf; }
-    DW_DEV bool room() const { return hf <= 56u; }
-    DW_DEV void advance(uint32_t p)          // the consumer stands at event p >= hb: whole blocks below it leave the window
+// The FIRST draws of a pass -- `drand48() < e` once per homopolymer start (pass 1, dwgsim.c:296) / per empty flow (pass 2, :373) -- are a Bernoulli(e')
+// sequence, e' = thr / 2^32; 99 % of them say "no".  Rounds 2-5 drew them one by one (a Philox block per eight, a 64-event window of hit bits per lane):
+// 170 blocks per 400-base read, two or three per loop iteration, and most of the flow model's 69.6 k VALU instructions per wave went into drawing and
+// comparing numbers that say "no" (profiles/r05_ion_chr20_kernel_stats_pmc.txt).  In law such a sequence IS its gaps: the quiet draws in front of each
+// scoring one are Geometric(e'), independent.  So the gaps are drawn (dw_common.hpp D_FLOW0: gap m = word m & 3 of block m >> 2 of the pass's domain),
+//     G = floor(-log2(U) / -log2(1 - e')),  U = (2 w + 1) / 2^33,
+// in integer arithmetic only -- a 257-entry table of log2 with linear interpolation, fixed point, one 64 x 64 -> 128 multiplication by the reciprocal
+// the host made (dw_kernels.hpp flow_gap_params; the tests' CPU restatement has the same text) -- and a lane knows the ORDINAL of its next
+// scoring first draw: a dozen gaps per read instead of 1 400 uniforms.  (The unmodified reference replays it all the same: tests/replay_common.py.)
+struct FlowGap {
+    uint32_t next, m, w0, w1, w2, w3;       // ordinal of the next scoring first draw (FLOW_NEVER: none); gaps drawn so far; the words of the current block
+    DW_DEV static uint32_t gap_of(uint32_t w, const uint32_t *lg, uint64_t R, int sR)
     {
-        const uint32_t k8 = (p - hb) & ~7u;
-        if (k8) { bits = k8 < 64u ? bits >> k8 : 0ull; ties = k8 < 64u ? ties >> k8 : 0ull; hf = hf > k8 ? hf - k8 : 0u; hb += k8; }
+        const uint64_t X = ((uint64_t)w << 1) | 1ull;
+        const int p = 63 - __clzll((long long)X);
+        const uint64_t M = X << (63 - p);
+        const uint32_t idx = (uint32_t)(M >> 55) & 0xFFu, r16 = (uint32_t)(M >> 39) & 0xFFFFu;
+        const uint32_t t0 = lg[idx], t1 = lg[idx + 1];
+        const uint32_t f = t0 + (uint32_t)(((uint64_t)(t1 - t0) * r16) >> 16);
+        const uint64_t Lu = ((uint64_t)(33 - p) << 56) - ((uint64_t)f << 24);
+        const uint64_t G = __umul64hi(Lu, R) >> sR;
+        return G > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)G;
     }
-    // the next block of eight first draws (dw_common.hpp D_FLOW0: the HIGH halves; a high half equal to the threshold's leaves the event undecided: `ties`),
-    // taken into the window if `go`.  Straight-line code: the callers place it beside the flow pointer's chain of table look-ups, whose latency it fills
-    DW_DEV void draw(bool go, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint64_t thr)
+    // the next gap: the scoring draw it leads to has ordinal base + G (base = the ordinal after the one that just scored, 0 at the start of a pass)
+    DW_DEV void draw(bool go, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t base, uint64_t thr, const uint32_t *lg, uint64_t R, int sR)
     {
-        const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
-        const U4 b = rng_block(key, dom, ii, att, 0, (hb + hf) >> 3);
-        const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
-        uint32_t lt = 0, eq = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; eq |= (hw[k] == t_hi ? 1u : 0u) << k; }
-        if (!t_lo) eq = 0;
-        if (go) { bits |= (uint64_t)(lt | eq) << hf; ties |= (uint64_t)eq << hf; hf += 8u; }
+        if (!go) return;
+        if (thr == 0) { next = FLOW_NEVER; return; }
+        if ((m & 3u) == 0u) { const U4 b = rng_block(key, dom, ii, att, 0, m >> 2); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
+        const uint32_t k = m & 3u; ++m;
+        const uint32_t w = (k & 2u) ? ((k & 1u) ? w3 : w2) : ((k & 1u) ? w1 : w0);
+        next = base + (thr >= 0x100000000ull ? 0u : gap_of(w, lg, R, sR));
     }
-    // the first scoring event at or after p (real), or else how far the lane may go before it needs more draws: the frontier (at least p)
-    DW_DEV uint32_t stop(uint32_t p, bool &real) const
-    {
-        const uint32_t sh = p - hb;
-        const uint64_t m = sh < 64u ? bits >> sh : 0ull;
-        real = m != 0;
-        if (real) return p + (uint32_t)__ffsll((unsigned long long)m) - 1u;
-        const uint32_t f = hb + hf;
-        return f > p ? f : p;
-    }
-    DW_DEV void clear(uint32_t pos) { bits &= ~(1ull << (pos - hb)); }       // hb <= pos < hb + 64
-    // dom: the pass's domain of first draws (its low halves: + D_FLOW_REF, the events' further draws: + D_FLOW_EV)
+};
+// what a scoring event goes on to draw (dw_common.hpp D_FLOW_EV: further errors, insert-or-delete, the dot-fill flow): one Philox block, block `pos`
+// oc: n_err (1 or 2) | 0x100 insert | 0x200 the event draws on (n_err >= 3): taken from FlowRng where it happens
+struct FlowEvent {
+    uint32_t oc, oc_dot;
     DW_DEV void resolve(RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t pos, uint64_t thr)
     {
-        if ((ties >> (pos - hb)) & 1ull) {      // the high half tied: the low half decides whether the event scores at all
-            const U4 r = rng_block(key, dom + D_FLOW_REF, ii, att, 0, pos >> 3);
-            const uint32_t wd = (pos & 4u) ? ((pos & 2u) ? r.w : r.z) : ((pos & 2u) ? r.y : r.x), lw = (wd >> ((pos & 1u) * 16u)) & 0xFFFFu;
-            if (!(lw < ((uint32_t)thr & 0xFFFFu))) { oc_pos = pos; oc = 0x400u; oc_dot = 0; return; }
-        }
         const U4 b = rng_block(key, dom + D_FLOW_EV, ii, att, 0, pos);
         const bool m0 = (uint64_t)b.x < thr, m1 = (uint64_t)b.y < thr;                // while (drand48() < e) n_err++ (dwgsim.c:296, :373): draws 0, 1, ...
         const uint32_t insw = m0 ? b.z : b.y;                                         // the draw after the first failing one: insert or delete (dwgsim.c:299)
-        oc_pos = pos; oc_dot = m0 ? b.w : b.z;                                        // ... and the one after that: the dot-fill flow (dwgsim.c:352)
+        oc_dot = m0 ? b.w : b.z;                                                      // ... and the one after that: the dot-fill flow (dwgsim.c:352)
         oc = (m0 ? 2u : 1u) | (insw < 0x80000000u ? 0x100u : 0u) | ((m0 && m1) ? 0x200u : 0u);
     }
 };
+// position of the r-th (0-based) set bit of a sixteen-bit mask that has more than r set bits
+DW_DEV int select_bit16(uint32_t m, uint32_t r)
+{
+    int pos = 0;
+    uint32_t c = (uint32_t)__popc(m & 0xFFu); if (r >= c) { r -= c; m >>= 8; pos += 8; }
+    c = (uint32_t)__popc(m & 0xFu); if (r >= c) { r -= c; m >>= 4; pos += 4; }
+    c = (uint32_t)__popc(m & 0x3u); if (r >= c) { r -= c; m >>= 2; pos += 2; }
+    c = m & 1u; if (r >= c) pos += 1;
+    return pos;
+}
 // The flow order as tables (LDS, filled once per block by fill_flow_tables; every base occurs in the order, F <= 64):
 //   dist[4 f + b]   flows from flow f (inclusive) to the first flow of base b, 0 .. F-1;   next1[4 f + b] = that flow
 //   pair[16 f + (b0 | b1 << 2)]   TWO bases at once: the flow after both in bits 0-5, the flows passed over in front of them (k0 + k1) in bits 8-14
 // The flow pointer is a chain of dependent table look-ups, one per base of the read (the only part of the model that is serial base by base); the
 // pair table halves its length.
-struct FlowTables { uint8_t flow[64], dist[256], next1[256]; uint16_t pair[1024]; };
-DW_DEV void fill_flow_tables(FlowTables &T, int F, int tid, int nthr)      // (T.flow is in place; a barrier before and after)
+//   lg[257]         floor(2^32 log2(1 + i / 256)): what FlowGap::gap_of interpolates in (made by the host, behind the flow order in the same device buffer)
+struct FlowTables { uint8_t flow[64], dist[256], next1[256]; uint16_t pair[1024]; uint32_t lg[FLOW_LG_ENTRIES]; };
+DW_DEV void fill_flow_tables(FlowTables &T, int F, int tid, int nthr, const uint8_t *flow_dev)      // (T.flow is in place; a barrier before and after)
 {
+    for (int q = tid; q < FLOW_LG_ENTRIES; q += nthr) T.lg[q] = reinterpret_cast<const uint32_t *>(flow_dev + 64)[q];
     for (int q = tid; q < 4 * F; q += nthr) {
         const int f = q >> 2; const uint32_t b = (uint32_t)q & 3u;
         int k = 0, g = f;
@@ -452,22 +454,24 @@ DW_DEV uint32_t even_bits16(uint32_t x)      // bits 0, 2, 4, .. 30 of x gathere
 // is written (dwgsim.c:408-414).  Returns the new length, or -1 if the read outgrew the buffer / the pass-2 stack (stack_runs (base, count) runs,
 // two per word of stk) or degenerated.
 //
-// Both passes are sequential per read and almost always quiet: the first draw of a position (pass 1) or of an empty flow (pass 2) scores with
-// probability e.  A lane knows from its window (FlowWin) where its next scoring draw is and moves SIXTEEN bases per iteration up to it -- one word
-// of the packed read, the flow pointer's chain of eight pair look-ups, one append -- and only a lane standing on an event runs the event code,
-// which is short: what the event draws beyond its first uniform has been drawn ahead, in rounds.  Each lane performs exactly its own sequence
-// of operations; only their interleaving changes.
-DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uint64_t thr, uint32_t *buf, uint32_t *stk, int stride, int stack_runs,
+// Both passes are sequential per read and almost always quiet.  A lane knows the ordinal of its next scoring first draw (FlowGap) and moves SIXTEEN
+// bases per step up to it -- one word of the packed read, the flow pointer's chain of eight pair look-ups, one append.  A lane that reaches its
+// scoring draw PARKS; the event code (the event's further draws, insert / delete / dot-fill, the run stack of pass 2, the next gap) runs for the
+// parked lanes together, when a quarter of the wave stands parked or no lane can step any more: in rounds 3-5 some lane stood on an event in nearly
+// every iteration and the whole wave went through the event code every time.  Each lane performs exactly its own sequence of operations; only their
+// interleaving changes.
+constexpr int FLOW_EVENT_BATCH = 16;      // parked lanes of a wave that make an event round worth its instructions
+DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uint64_t thr, uint64_t gap_R, int gap_s, uint32_t *buf, uint32_t *stk, int stride, int stack_runs,
                        int len, int strand, int capb, int32_t *n_err_out)
 {
     const RngKey key{rg.seed, rg.contig};
     int total = 0; uint32_t flow_i = 0; bool marked = false; bool failed = !active;
     const int capw = capb >> 4;
     const Buf2 B{buf, stride, capw};
-    FlowWin W;
+    FlowGap G; FlowEvent E;
 
-    // ---- pass 1 (dwgsim.c:253-364): one error event per homopolymer start whose first draw scores.  The output index is the reference's loop
-    // index i (dwgsim.c:281): position i's first draw is event i of the pass. ----
+    // ---- pass 1 (dwgsim.c:253-364): one error event per homopolymer start whose first draw scores.  k1 counts the homopolymer starts examined so far:
+    // the next one's first draw is first draw number k1 of the pass. ----
     // The reference's flow mask (dwgsim.c:283-333) never has more than one bit set: a deletion marks the flow the pointer stands on, and the
     // mark is cleared as soon as the pointer moves (the range of skipped flows starts at the pointer) or a new homopolymer starts on that flow --
     // and the pointer stands on the previous base's flow, so both mean "this base differs from the one before".  So the mask is one flag, and
@@ -480,32 +484,27 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
         while (flow_i < (uint32_t)F && c0 != T.flow[flow_i]) ++flow_i;
         if (flow_i == (uint32_t)F) failed = true;
     }
-    W.init();
+    G.m = 0; G.next = FLOW_NEVER; G.w0 = G.w1 = G.w2 = G.w3 = 0;
+    G.draw(__ballot(!failed) != 0, key, rg.dom, rg.ii, rg.att, 0u, thr, T.lg, gap_R, gap_s);
     {
-        bool done = failed, parked = false;
+        bool done = failed, parked = false; uint32_t k1 = 0;
         for (;;) {
-            // One block of straight-line code: two rounds of draws for the window (a step consumes up to sixteen positions) beside the step itself, so that
-            // the arithmetic of the one fills the look-up latency of the other.  A lane that does not step (done, parked) goes through it with n = 0.
-            if (!done) W.advance((uint32_t)o1.n);
+            // ---- a step: up to sixteen positions, up to the homopolymer start whose first draw scores
             const bool act = !done && !parked;
             if (act && t >= len) done = true;
             const bool go = act && t < len;
-            const uint32_t on = (uint32_t)o1.n, sh = on - W.hb;                          // (sh < 8 after advance)
-            const uint32_t v = B.get16(in0 + t);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) W.draw(!done && W.room() && W.frontier() < on + 40u, key, rg.dom, rg.ii, rg.att, thr);
-            {
-                int n = len - t < 16 ? len - t : 16;
-                const int reach = (int)(W.frontier() - on);                              // positions whose first draws are there
-                if (reach < n) n = reach;
-                if (!go || n < 0) n = 0;
+            if (__ballot(go)) {
+                const uint32_t v = B.get16(in0 + t);
+                int n = !go ? 0 : len - t < 16 ? len - t : 16;
                 // homopolymer starts among the sixteen: base i differs from the one before it (the first one from prev_c)
                 const uint32_t x = v ^ ((v << 2) | (prev_c & 3u));
                 const uint32_t starts = even_bits16(x | (x >> 1)) | (prev_c > 3u ? 1u : 0u);
                 const uint32_t below = n < 16 ? (1u << n) - 1u : 0xFFFFu;
-                const uint32_t ev = go ? starts & (uint32_t)(W.bits >> sh) & below : 0u;   // ... whose first draw scores: the first of them stops the step
-                if (ev) n = __ffs((int)ev) - 1;
+                const uint32_t sb = starts & below, rem = G.next - k1;                     // starts that may be passed before the one that scores
+                const bool ev = go && rem < (uint32_t)__popc(sb);
+                if (ev) n = select_bit16(sb, rem);                                        // ... which stops the step
                 const uint32_t taken = n < 16 ? (1u << n) - 1u : 0xFFFFu;
+                k1 += (uint32_t)__popc(sb & taken);
                 // the flow pointer over the n bases: pairs, then the odd one
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
@@ -519,38 +518,42 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                 t += n;
                 if (ev) parked = true;                                                   // standing on a homopolymer start whose first draw scored: the event happens
             }
-            // a lane standing on an event draws what the event draws beyond its first uniform (one Philox block), then acts on it
-            if (parked) W.resolve(key, rg.dom, rg.ii, rg.att, (uint32_t)o1.n, thr);
-            if (parked && (W.oc & 0x400u)) { W.clear((uint32_t)o1.n); parked = false; }      // a tie that did not score: no event here
-            if (parked) {
-                const uint32_t c = B.get1(in0 + t);
-                flow_i = T.next1[(flow_i << 2) | c]; marked = false;
-                int n_err; bool ins = false;
-                const bool slow = (W.oc & 0x200u) != 0;
-                if (slow) { rg.open((uint32_t)o1.n); n_err = rg.more_errors(thr); if (n_err >= (1 << 14)) failed = true; else ins = rg.next() < 0x80000000u; }
-                else { n_err = (int)(W.oc & 0xffu); ins = (W.oc & 0x100u) != 0; }
-                if (failed) {}
-                else if (ins) {                                     // insert n_err copies in front of the homopolymer (whose own bases follow unexamined: prev_c == c)
-                    if (o1.n + n_err > in0 + t) failed = true;      // the output would run into the input: the read has outgrown the buffer
-                    else { for (int q = 0; q < n_err; ++q) o1.push(c); total += n_err; prev_c = c; }
-                } else {                                            // delete: bounded by the homopolymer length
-                    int hp_l = 0; uint32_t next_c = c;
-                    while (t + hp_l < len && hp_l <= n_err) { next_c = B.get1(in0 + t + hp_l); if (next_c != c) break; ++hp_l; }
-                    if (n_err > hp_l) n_err = hp_l;
-                    t += n_err; marked = true; total += n_err;
-                    if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
-                        if (next_c == c) failed = true;             // the whole read was one deleted homopolymer (the reference asserts)
-                        else {
-                            const int jj = T.dist[(flow_i << 2) | next_c];
-                            const uint32_t dw = slow ? rg.next() : W.oc_dot;
-                            const int kk = (int)(((uint64_t)dw * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
-                            int f = (int)flow_i + kk; if (f >= F) f -= F;
-                            o1.push(T.flow[f]);
-                        }
-                    } else if (t < len) { o1.push(B.get1(in0 + t)); ++t; }   // the base now at this position is not examined
-                    prev_c = c;
+            // ---- an event round: the parked lanes draw what their events draw beyond the first uniform (one Philox block), act on it, and draw their next gap
+            const uint64_t pm = __ballot(parked);
+            if (pm && (__popcll(pm) >= FLOW_EVENT_BATCH || __ballot(!done && !parked) == 0)) {
+                if (parked) E.resolve(key, rg.dom, rg.ii, rg.att, (uint32_t)o1.n, thr);
+                if (parked) {
+                    const uint32_t c = B.get1(in0 + t);
+                    flow_i = T.next1[(flow_i << 2) | c]; marked = false;
+                    int n_err; bool ins = false;
+                    const bool slow = (E.oc & 0x200u) != 0;
+                    if (slow) { rg.open((uint32_t)o1.n); n_err = rg.more_errors(thr); if (n_err >= (1 << 14)) failed = true; else ins = rg.next() < 0x80000000u; }
+                    else { n_err = (int)(E.oc & 0xffu); ins = (E.oc & 0x100u) != 0; }
+                    if (failed) {}
+                    else if (ins) {                                     // insert n_err copies in front of the homopolymer (whose own bases follow unexamined: prev_c == c)
+                        if (o1.n + n_err > in0 + t) failed = true;      // the output would run into the input: the read has outgrown the buffer
+                        else { for (int q = 0; q < n_err; ++q) o1.push(c); total += n_err; prev_c = c; }
+                    } else {                                            // delete: bounded by the homopolymer length
+                        int hp_l = 0; uint32_t next_c = c;
+                        while (t + hp_l < len && hp_l <= n_err) { next_c = B.get1(in0 + t + hp_l); if (next_c != c) break; ++hp_l; }
+                        if (n_err > hp_l) n_err = hp_l;
+                        t += n_err; marked = true; total += n_err;
+                        if (n_err == hp_l && (o1.n == 0 || prev_c == next_c)) {   // dot-fill (dwgsim.c:342-358)
+                            if (next_c == c) failed = true;             // the whole read was one deleted homopolymer (the reference asserts)
+                            else {
+                                const int jj = T.dist[(flow_i << 2) | next_c];
+                                const uint32_t dw = slow ? rg.next() : E.oc_dot;
+                                const int kk = (int)(((uint64_t)dw * (uint64_t)jj) >> 32);   // (int)(drand48() * j)
+                                int f = (int)flow_i + kk; if (f >= F) f -= F;
+                                o1.push(T.flow[f]);
+                            }
+                        } else if (t < len) { o1.push(B.get1(in0 + t)); ++t; }   // the base now at this position is not examined
+                        prev_c = c;
+                    }
+                    ++k1;                                               // the start's own first draw was number k1
+                    if (failed) done = true;
                 }
-                if (failed) done = true;
+                G.draw(parked && !failed, key, rg.dom, rg.ii, rg.att, k1, thr, T.lg, gap_R, gap_s);
                 parked = false;
             }
             if (__ballot(!done) == 0) break;
@@ -573,9 +576,9 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
 
     // ---- pass 2 (dwgsim.c:367-406): insertions in empty flows; inserted bases are examined again later, the examined base
     // itself stays behind them: a stack of (base, count) runs on top of the pass-1 output reproduces the in-place order.
-    // g counts the empty flows examined so far: flow g's first draw is event g of the pass.  A base whose empty flows end at or before the next
-    // scoring flow is quiet: lanes with an empty stack move up to sixteen quiet bases per iteration; a base with a scoring flow (or the window's
-    // end) in front of it, and every base examined while runs are pending, goes through the flow-by-flow code below. ----
+    // g counts the empty flows examined so far: flow g's first draw is first draw number g of the pass.  A base whose empty flows end before the next
+    // scoring flow is quiet: lanes with an empty stack move up to sixteen quiet bases per step; a base with the scoring flow in front of it, and every
+    // base examined while runs are pending, parks and goes through the flow-by-flow code of the event rounds. ----
     const uint32_t dom2 = rg.dom + D_FLOW_PASS2;
     const int in2 = capb - n1;
     BitAppender<2> o2; o2.init(buf, stride);
@@ -592,23 +595,18 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
         }
     };
     rg.dom = dom2;
-    W.init();
+    G.m = 0; G.next = FLOW_NEVER;
+    G.draw(__ballot(!failed) != 0, key, dom2, rg.ii, rg.att, 0u, thr, T.lg, gap_R, gap_s);
     {
         bool done = failed, parked = false; uint32_t g = 0, x = 0;
         for (;;) {
-            if (!done) W.advance(g);
             const bool act = !done && !parked;
-            if (act && sp > 0) { x = stk_get(sp - 1) >> 14; parked = true; }      // runs pending: base by base, below
             if (act && sp == 0 && t2 >= n1) done = true;
-            const bool go = act && sp == 0 && t2 < n1;
-            const uint32_t v = B.get16(in2 + t2);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) W.draw(!done && W.room() && W.frontier() < g + 56u, key, dom2, rg.ii, rg.att, thr);
-            if (__ballot(!done && W.room() && W.frontier() < g + 32u)) W.draw(!done && W.room() && W.frontier() < g + 56u, key, dom2, rg.ii, rg.att, thr);
-            {
+            const bool go = act && !done;
+            if (__ballot(go)) {
+                const uint32_t v = B.get16(in2 + t2);
                 const int n = !go ? 0 : n1 - t2 < 16 ? n1 - t2 : 16;
-                bool real; const uint32_t st = W.stop(g, real);
-                uint32_t rem = st - g;                                       // flows that may be passed before the lane has to stop
+                uint32_t rem = G.next - g;                                   // quiet flows in front of the scoring one: they may be passed
                 int m = 0; bool ok = true;
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
@@ -620,36 +618,40 @@ DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uin
                     const uint32_t i1 = (flow_i << 2) | ((v >> (2 * m)) & 3u), k = T.dist[i1];
                     if (k <= rem) { rem -= k; flow_i = T.next1[i1]; ++m; }
                 }
-                g = st - rem;
+                g = G.next - rem;
                 o2.push_many(m < 16 ? v & ((1u << (2 * m)) - 1u) : v, m);
                 t2 += m;
-                if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }
+                if (m < n) { x = (v >> (2 * m)) & 3u; parked = true; }        // the scoring flow lies in front of this base
             }
-            if (parked) {      // flow by flow up to x's own: quiet flows are skipped together, a scoring one inserts (dwgsim.c:373-383)
-                for (;;) {
-                    uint32_t left = T.dist[(flow_i << 2) | x];
-                    bool real; const uint32_t st = W.stop(g, real);
-                    const uint32_t q = st - g, skip = q < left ? q : left;
-                    { uint32_t f = flow_i + skip; if (f >= (uint32_t)F) f -= (uint32_t)F; flow_i = f; }
-                    g += skip; left -= skip;
-                    if (left == 0) {
-                        settle(x);
-                        if (failed) { done = true; parked = false; break; }
-                        if (sp == 0) { parked = false; break; }
-                        x = stk_get(sp - 1) >> 14;                  // the next base to examine is the first of the top run
-                        continue;
+            // ---- an event round: flow by flow up to the parked base's own flow -- quiet flows are skipped together, the scoring one inserts (dwgsim.c:373-383) --
+            // and on through the runs it leaves pending, until the lane can step again
+            const uint64_t pm = __ballot(parked);
+            if (pm && (__popcll(pm) >= FLOW_EVENT_BATCH || __ballot(!done && !parked) == 0)) {
+                if (parked) {
+                    for (;;) {
+                        uint32_t left = T.dist[(flow_i << 2) | x];
+                        const uint32_t q = G.next - g, skip = q < left ? q : left;
+                        { uint32_t f = flow_i + skip; if (f >= (uint32_t)F) f -= (uint32_t)F; flow_i = f; }
+                        g += skip; left -= skip;
+                        if (left == 0) {
+                            settle(x);
+                            if (failed) { done = true; break; }
+                            if (sp == 0) break;
+                            x = stk_get(sp - 1) >> 14;                  // the next base to examine is the first of the top run
+                            continue;
+                        }
+                        E.resolve(key, dom2, rg.ii, rg.att, g, thr);    // the scoring flow: what the event draws beyond its first uniform
+                        int n_err;
+                        if (E.oc & 0x200u) { rg.open(g); n_err = rg.more_errors(thr); } else n_err = (int)(E.oc & 0xffu);
+                        if ((int)flow_i != marked_flow) {
+                            if (sp >= stack_runs || n_err >= (1 << 14)) { failed = true; done = true; break; }
+                            stk_set(sp, ((uint32_t)T.flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err;
+                        }
+                        flow_i = flow_i + 1u == (uint32_t)F ? 0u : flow_i + 1u;
+                        ++g;
+                        G.draw(true, key, dom2, rg.ii, rg.att, g, thr, T.lg, gap_R, gap_s);
                     }
-                    if (!real) break;                               // the window's end: more draws first
-                    W.resolve(key, dom2, rg.ii, rg.att, g, thr);    // what the event draws beyond its first uniform
-                    if (W.oc & 0x400u) { W.clear(g); continue; }    // a tie that did not score: a quiet flow after all
-                    int n_err;
-                    if (W.oc & 0x200u) { rg.open(g); n_err = rg.more_errors(thr); } else n_err = (int)(W.oc & 0xffu);
-                    if ((int)flow_i != marked_flow) {
-                        if (sp >= stack_runs || n_err >= (1 << 14)) { failed = true; done = true; parked = false; break; }
-                        stk_set(sp, ((uint32_t)T.flow[flow_i] << 14) | (uint32_t)n_err); ++sp; total += n_err;
-                    }
-                    flow_i = flow_i + 1u == (uint32_t)F ? 0u : flow_i + 1u;
-                    ++g;
+                    parked = false;
                 }
             }
             if (__ballot(!done) == 0) break;

@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     const SegCtx sc = seg_ctx(a, sg);
     const uint8_t *name_fixed = a.names + sg->name_off;
     if (H != 1) for (int q = tid; q < 32; q += nthr) s_fixed[0][q] = reinterpret_cast<const uint32_t *>(name_fixed)[q];      // (read after later barriers only)
-    if (ION) { if (SPLIT != 0) __syncthreads(); fill_flow_tables(s_ft, a.flow_len, tid, nthr); __syncthreads(); }      // (the flow order is in LDS: the single kernel's barrier above, or this one)
+    if (ION) { if (SPLIT != 0) __syncthreads(); fill_flow_tables(s_ft, a.flow_len, tid, nthr, a.flow); __syncthreads(); }      // (the flow order is in LDS: the single kernel's barrier above, or this one)
     const int j = (LPP == 2) ? (tid & 1) : 0;
     const uint64_t pair_in = (uint64_t)(t - sg->first_block) * PPB + (uint64_t)(tid / LPP);      // inside the range
     const bool valid = pair_in < sg->n_pairs;
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     if (ION) {                                  // dwgsim.c:861-864; every lane calls (the loops of the model are wave-uniform)
         const bool flows = valid && !is_rand && s > 0;
         FlowRng rg; rg.seed = key.seed; rg.contig = key.contig; rg.dom = D_FLOW0 + (uint32_t)j; rg.att = att; rg.evt = 0; rg.s = 0; rg.ii = ii; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(flows, rg, s_ft, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], lds, flow_stk, nthr, 2 * a.flow_stack_words, s, j ? pd.strand1 : pd.strand0, capb, &n_err);
+        const int so = flow_errors(flows, rg, s_ft, a.flow_len, (j ? a.e_thr[1] : a.e_thr[0])[0], j ? a.flow_gap_r[1] : a.flow_gap_r[0], j ? a.flow_gap_s[1] : a.flow_gap_s[0], lds, flow_stk, nthr, 2 * a.flow_stack_words, s, j ? pd.strand1 : pd.strand0, capb, &n_err);
         if (flows) {
             s_out = so;
             if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; }
@@ -1391,7 +1391,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     const int tid = (int)threadIdx.x, nthr = PAIRS_PER_BLOCK;
     if (tid < 64) s_ft.flow[tid] = a.flow[tid];
     __syncthreads();
-    fill_flow_tables(s_ft, a.flow_len, tid, nthr);
+    fill_flow_tables(s_ft, a.flow_len, tid, nthr, a.flow);
     __syncthreads();
     const uint64_t jj = a.first_read + (uint64_t)blockIdx.x * PAIRS_PER_BLOCK + (uint64_t)tid;
     uint32_t *buf = a.scratch + (size_t)blockIdx.x * ((size_t)a.lds_words * nthr) + tid;
@@ -1414,7 +1414,7 @@ __global__ void __launch_bounds__(PAIRS_PER_BLOCK) k_calibrate(CalibArgs a)
     }
     {   // every lane calls (the loops of the model are wave-uniform)
         FlowRng rg; rg.seed = a.seed; rg.contig = 0; rg.dom = dom; rg.att = 1; rg.evt = 0; rg.s = 0; rg.ii = jj; rg.w0 = rg.w1 = rg.w2 = rg.w3 = 0;
-        const int so = flow_errors(live, rg, s_ft, a.flow_len, a.thr, buf, dyn_lds + tid, nthr, 2 * a.stack_words, a.len, 0, capb, &n_err);
+        const int so = flow_errors(live, rg, s_ft, a.flow_len, a.thr, a.gap_r, a.gap_s, buf, dyn_lds + tid, nthr, 2 * a.stack_words, a.len, 0, capb, &n_err);
         if (live) { s_out = so; if (s_out < 0) { atomicOr((unsigned long long *)&a.counters[2], 2ull); s_out = 0; n_err = 0; } }
     }
     const uint32_t es = wave_sum_u32((uint32_t)n_err), ls = wave_sum_u32((uint32_t)s_out);

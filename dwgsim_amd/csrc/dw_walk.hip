@@ -151,6 +151,76 @@ __global__ void __launch_bounds__(SITE_THREADS) k_site_scan_list(const uint8_t *
     }
 }
 
+// K1 without ANY dependency between blocks (round 6).  The look-back form above spends most of its time in the chain: a block's place in the list
+// is known only when every block in front has published, and the hops of that chain, not the draws, were 2.7 ms of a 5.9 ms whole-genome walk ("three
+// times its instruction count's worth").  Candidates are sparse and their number per block is tightly bounded (Binomial(65 536, r): mean + 8 sigma), so
+// a block writes them into a SLOT of its own (slot_cap entries) with its count beside; one small block then scans the counts (k_slot_scan) and
+// k_slot_gather moves the slots' entries to their places in the ordered list -- 12 bytes per candidate, a thousandth of the positions.  A block that
+// outgrows its slot (never, at mean + 8 sigma; forced in the tests) raises a flag and the host runs the walk again through the look-back form.
+__global__ void __launch_bounds__(SITE_THREADS) k_site_scan_slots(const uint8_t *__restrict__ refview, int64_t l_total, SegTab seg, WalkParams wp, int32_t *__restrict__ slots, uint32_t slot_cap,
+                                                               uint32_t *__restrict__ slot_cnt)
+{
+    __shared__ uint32_t sm[SITE_ROUNDS][16];
+    const uint32_t t = blockIdx.x;
+    const int sub = (int)(threadIdx.x / SCAN_THREADS), tin = (int)(threadIdx.x % SCAN_THREADS);      // which of the round's tiles, and where in it
+    uint32_t bits[SITE_ROUNDS], cnt[SITE_ROUNDS], off[SITE_ROUNDS], tot[SITE_ROUNDS], block_total = 0;
+#pragma unroll
+    for (int q = 0; q < SITE_ROUNDS; ++q) {
+        const int64_t tile0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK;
+        bits[q] = 0;
+        if (tile0 < l_total) {                                                   // (uniform over the tile's four waves)
+            const uint32_t sk = seg_of(seg, tile0);                              // a tile's positions lie inside one contig: contigs start at multiples of GROUP_ALIGN
+            const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
+            const int64_t g0 = tile0 + (int64_t)tin * SCAN_POS_PER_THREAD;
+            const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];              // position inside the contig: what the draws are indexed by
+            if (p0 < l) {
+                const uint64_t v = *reinterpret_cast<const uint64_t *>(refview + (g0 >> 1));      // sixteen nibbles (the view is padded: reading past l is safe)
+                uint32_t acgt = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) { const uint32_t nib = (uint32_t)(v >> (4 * b)) & 15u; if (nib < 4 && p0 + b < l) acgt |= 1u << b; }
+                if (acgt) bits[q] = (site_hits8(key, (uint32_t)(p0 >> 3), wp.mut_thr) | (site_hits8(key, (uint32_t)(p0 >> 3) + 1u, wp.mut_thr) << 8)) & acgt;
+            }
+        }
+        cnt[q] = (uint32_t)__popc(bits[q]);
+    }
+    block_excl_scan_n<SITE_ROUNDS>(cnt, sm, off, tot);      // a round's lanes stand in position order (tile by tile): four block-wide scans behind one barrier
+#pragma unroll
+    for (int q = 0; q < SITE_ROUNDS; ++q) { off[q] += block_total; block_total += tot[q]; }
+    if (threadIdx.x == 0) slot_cnt[t] = block_total;
+    int32_t *const slot = slots + (size_t)t * slot_cap;
+#pragma unroll
+    for (int q = 0; q < SITE_ROUNDS; ++q) {
+        uint32_t at = off[q], bq = bits[q];
+        const int64_t g0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK + (int64_t)tin * SCAN_POS_PER_THREAD;
+        while (bq) { const int b = __ffs((int)bq) - 1; bq &= bq - 1; if (at < slot_cap) slot[at] = (int32_t)(g0 + b); ++at; }   // (past the slot: the host re-runs)
+    }
+}
+// one block: exclusive scan of the nb slot counts -> slot_base[0 .. nb), the candidates in all -> *n_out; over[0] = 1 and over[1] = that total if a slot
+// was outgrown (*n_out = 0 then: the kernels behind find nothing to do)
+__global__ void __launch_bounds__(1024) k_slot_scan(const uint32_t *__restrict__ slot_cnt, uint32_t nb, uint32_t slot_cap, uint32_t *__restrict__ slot_base, uint64_t *n_out, uint32_t *over)
+{
+    __shared__ uint32_t sm[17];
+    __shared__ uint32_t s_over;
+    if (threadIdx.x == 0) s_over = 0;
+    const uint32_t per = (nb + 1023u) / 1024u, a = threadIdx.x * per, b = a + per < nb ? a + per : nb;
+    uint32_t sum = 0; bool big = false;
+    for (uint32_t q = a; q < b; ++q) { const uint32_t c = slot_cnt[q]; sum += c; big |= c > slot_cap; }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, sm, &total);      // (its first barrier also publishes s_over = 0)
+    if (big) atomicOr(&s_over, 1u);
+    for (uint32_t q = a; q < b; ++q) { slot_base[q] = run; run += slot_cnt[q]; }
+    __syncthreads();
+    if (threadIdx.x == 0) { const bool o = s_over != 0; *n_out = o ? 0ull : (uint64_t)total; if (o) { over[0] = 1u; over[1] = total; } }
+}
+// a block per slot: its entries to their places in the ordered list
+__global__ void __launch_bounds__(256) k_slot_gather(const int32_t *__restrict__ slots, uint32_t slot_cap, const uint32_t *__restrict__ slot_cnt, const uint32_t *__restrict__ slot_base,
+                                                     int32_t *__restrict__ out, uint32_t cap)
+{
+    const uint32_t t = blockIdx.x, base = slot_base[t];
+    uint32_t n = slot_cnt[t]; if (n > slot_cap) n = slot_cap;
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) if (base + k < cap) out[base + k] = slots[(size_t)t * slot_cap + k];
+}
+
 // ---- the walk as SPARSE work (round 5).  A walk touches about one cell in a thousand; rounds 1-4 nevertheless rewrote dense arrays for every walk (two
 // resets of 1 byte per base, k_make_view over 3 bytes per base: 2.5 of the ~8 ms of kernels per genome).  Now the read views and the haplotype
 // summaries of the UNMUTATED group are made once, at upload (refview / refsumm / refsumm2 stay as pristine copies), and a walk records the
@@ -747,6 +817,17 @@ void launch_site_scan_list(hipStream_t st, const uint8_t *refview, int64_t l, Se
 {
     const uint32_t nb = (uint32_t)cdiv((uint64_t)l, (uint64_t)SCAN_POS_PER_BLOCK * SITE_TILES);
     hipLaunchKernelGGL(k_site_scan_list, dim3(nb), dim3(SITE_THREADS), 0, st, refview, l, seg, wp, status, ticket, out, cap, n_out, nb);
+}
+uint32_t site_scan_blocks(int64_t l) { return (uint32_t)cdiv((uint64_t)l, (uint64_t)SCAN_POS_PER_BLOCK * SITE_TILES); }
+uint32_t site_scan_block_positions() { return (uint32_t)SCAN_POS_PER_BLOCK * SITE_TILES; }
+// slots: nb x slot_cap entries; aux: 2 nb words (counts, bases); over: two words, zeroed by the caller (k_slot_scan)
+void launch_site_scan_slots(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, int32_t *slots, uint32_t slot_cap, uint32_t *aux, int32_t *out, uint32_t cap, uint64_t *n_out, uint32_t *over)
+{
+    const uint32_t nb = site_scan_blocks(l);
+    if (!nb) return;
+    hipLaunchKernelGGL(k_site_scan_slots, dim3(nb), dim3(SITE_THREADS), 0, st, refview, l, seg, wp, slots, slot_cap, aux);
+    hipLaunchKernelGGL(k_slot_scan, dim3(1), dim3(1024), 0, st, aux, nb, slot_cap, aux + nb, n_out, over);
+    hipLaunchKernelGGL(k_slot_gather, dim3(nb), dim3(256), 0, st, slots, slot_cap, aux, aux + nb, out, cap);
 }
 void launch_mark_dirty(hipStream_t st, const Event *ev, Count n, const int32_t *lo, uint32_t *dirty)
 {

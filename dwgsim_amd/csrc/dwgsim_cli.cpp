@@ -20,6 +20,8 @@
 //     DWGSIM_HIP_SINK      "null": measurement aid -- the FASTQ deliveries are counted, not written (the .gz files stay empty); "memcpy": every delivery is copied
 //                          once into a scratch buffer by the delivering thread (the least any consumer does with it): with DWGSIM_HIP_TIMING the line reports the time
 //                          the per-stream delivery threads spent inside the sink, i.e. the rate ONE delivery thread can sustain (the job level's ceiling per stream)
+//     DWGSIM_HIP_SINK_ORDERED  the FASTQ pieces through the ordered sink (one delivering thread per file, write() in file order) instead of the offset sink (one
+//                          thread per device and file, pwrite() at the piece's place: the default when the members are made on the GPU)
 //     DWGSIM_HIP_SOLO      "r/W": measurement aid (dw_job.cpp) -- this process's one device does what device r of a W-device job does, nothing else
 #include <stdio.h>
 #include <stdlib.h>
@@ -403,10 +405,10 @@ private:
     int level_; std::mutex m_; std::condition_variable cv_, done_; std::deque<Piece *> todo_; std::vector<std::thread> th_; bool stop_ = false;
 };
 
-static void close_gz(FILE *f, int level)
+static void close_gz(FILE *f, int level, uint64_t written_elsewhere = 0)
 {
     if (!f) return;
-    if (ftell(f) == 0) { std::vector<unsigned char> e; deflate_member("", 0, level, e); fwrite(e.data(), 1, e.size(), f); }   // empty stream: still a valid .gz
+    if (ftell(f) == 0 && written_elsewhere == 0) { std::vector<unsigned char> e; deflate_member("", 0, level, e); fwrite(e.data(), 1, e.size(), f); }   // empty stream: still a valid .gz
     fclose(f);
 }
 
@@ -441,6 +443,29 @@ struct FileSink {
         FileSink *s = (FileSink *)u;
         if (s->fp_txt && fwrite(txt, 1, tl, s->fp_txt) != tl) return 1;
         if (s->fp_vcf && fwrite(vcf, 1, vl, s->fp_vcf) != vl) return 1;
+        return 0;
+    }
+    std::atomic<uint64_t> written[3] = {{0}, {0}, {0}};      // bytes that went to file `stream` through reads_at
+    // pieces with their place (dwgsim_hip_job_sink_t::reads_at): several threads per file, pwrite
+    static int reads_at(void *u, int stream, uint64_t offset, const void *data, size_t len, size_t text_len, int)
+    {
+        FileSink *s = (FileSink *)u;
+        FILE *f = s->fgz[stream];
+        if (!f) return 1;
+        s->bytes_in += text_len; s->bytes_out += len;
+        if (s->null_sink) return 0;
+        if (s->memcpy_sink) {
+            static thread_local std::vector<char> mine;
+            timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+            if (mine.size() < len) mine.resize(len);
+            memcpy(mine.data(), data, len);
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            s->sink_ns[stream] += (uint64_t)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)); s->sink_bytes[stream] += len;
+            return 0;
+        }
+        const char *p = (const char *)data; size_t left = len; off_t at = (off_t)offset;
+        while (left) { const ssize_t w = pwrite(fileno(f), p, left, at); if (w <= 0) return 1; p += w; left -= (size_t)w; at += w; }
+        s->written[stream] += len;
         return 0;
     }
     static int reads(void *u, int stream, const void *data, size_t len, size_t text_len, int gz)
@@ -564,6 +589,8 @@ int main(int argc, char **argv)
     FileSink fs;
     dwgsim_hip_job_sink_t sink; memset(&sink, 0, sizeof sink);
     sink.user = &fs; sink.mutations = want_mut ? FileSink::mutations : nullptr; sink.reads = want_reads ? FileSink::reads : nullptr;
+    // members made on the GPU are written where they belong by one thread per device and file (pwrite); text that the host still has to deflate goes through the ordered sink
+    if (want_reads && gpu_gzip && !getenv("DWGSIM_HIP_SINK_ORDERED")) sink.reads_at = FileSink::reads_at;
     int job_err = 0;
     std::future<dwgsim_hip_job_t *> job_made = std::async(std::launch::async, [&]() { return dwgsim_hip_job_create(&o, devs.empty() ? nullptr : devs.data(), (int)devs.size(), &sink, &jo, &job_err); });
     auto give_up = [&](int code) { if (dwgsim_hip_job_t *jb = job_made.get()) dwgsim_hip_job_destroy(jb); return code; };
@@ -675,12 +702,12 @@ int main(int argc, char **argv)
                         fs.bytes_in.load() / 1e9, fs.bytes_out.load() / 1e9,
                         gpu_gzip ? "gzip members made on the GPU" : (std::string("zlib level ") + std::to_string(gz_level) + " on " + std::to_string(nthreads) + " host threads").c_str());
     if (timing && fs.memcpy_sink) for (int st = 0; st < 3; ++st) if (fs.sink_bytes[st].load())
-        fprintf(stderr, "[dwgsim-hip-sink] stream %d: %.2f GB copied by its delivery thread in %.3f s inside the sink = %.1f GB/s while delivering (the run took %.2f s)\n", st, fs.sink_bytes[st].load() / 1e9,
+        fprintf(stderr, "[dwgsim-hip-sink] stream %d: %.2f GB copied by its delivery thread(s) in %.3f thread-seconds inside the sink = %.1f GB/s per thread while delivering (the run took %.2f s)\n", st, fs.sink_bytes[st].load() / 1e9,
                 fs.sink_ns[st].load() / 1e9, fs.sink_bytes[st].load() / (double)std::max<uint64_t>(fs.sink_ns[st].load(), 1), t_out_done - t_start);
     if (timing) { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); const double e = ts.tv_sec + ts.tv_nsec * 1e-9; fprintf(stderr, "[dwgsim-hip-clock] main entered at %.3f, output complete at %.3f (seconds since the epoch)\n", e - (t_out_done - t_start) - (now_s() - t_out_done), e - (now_s() - t_out_done)); }
     if (fs.fp_txt) fclose(fs.fp_txt);
     if (fs.fp_vcf) fclose(fs.fp_vcf);
-    for (int s = 0; s < 3; ++s) close_gz(fs.fgz[s], gz_level);
+    for (int s = 0; s < 3; ++s) close_gz(fs.fgz[s], gz_level, fs.written[s].load());
     if (getenv("DWGSIM_HIP_TEARDOWN")) { dwgsim_hip_job_destroy(job); return rc; }
     // everything has been delivered and the files are closed: the process ends here.  Handing back device memory, page-locked buffers and the
     // runtime piece by piece costs 0.2 s after a chromosome-sized job; the driver reclaims them with the process.

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DWGSIM_HIP_ABI_VERSION 4
+#define DWGSIM_HIP_ABI_VERSION 5
 
 /* error codes (negative) */
 #define DWGSIM_HIP_OK            0
@@ -289,6 +289,12 @@ typedef struct dwgsim_hip_job_sink {
     int (*reads)(void *user, int stream, const void *data, size_t len, size_t text_len, int gz);
     /* dwgsim_core's stderr lines (skip notes, the running pair count); NULL: written to stderr unless options.quiet */
     void (*message)(void *user, const char *text);
+    /* (ABI 5) Instead of reads, for a sink that can take pieces OUT OF ORDER (pwrite): `offset` = where this piece goes in output stream `stream` as it is
+     * delivered (the members back to back, or the text).  Called CONCURRENTLY, by one thread per device and stream -- every device hands over what it made
+     * itself -- each piece exactly once, in any order; together the pieces tile [0, total) of each stream.  The ordered form has one thread per stream, and
+     * a sink that touches the bytes takes 21-26 GB/s from it (measured, memcpy: profiles/r06_solo_rank_entry.txt): less than one device's link delivers, so at
+     * N > 1 devices it would be the job's ceiling.  Used when reads_at != NULL (reads is then ignored).  Non-zero return stops the job. */
+    int (*reads_at)(void *user, int stream, uint64_t offset, const void *data, size_t len, size_t text_len, int gz);
 } dwgsim_hip_job_sink_t;
 
 typedef struct dwgsim_hip_job_options {

@@ -64,15 +64,14 @@ enum {
                           the 32-bit uniform of base i (error test / random-read base); the low half is halfword i of D_BASE_REF0 + j */
     D_QUAL0 = 10,      /* +j; index = ii; 16-BIT: the sequential stream of polar tries of the read's quality normals -- try t = the low (v1) and the high
                           (v2) half of word t & 3 of block t >> 2; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
-    D_FLOW0 = 12,      /* +j; index = ii; generate_errors_flows: 16-bit draws, eight per block -- halfword h is the HIGH half of the FIRST uniform of
-                          the homopolymer event examined at position h of the evolving read (pass 1; + D_FLOW_PASS2: of the h-th empty flow of
-                          pass 2); low halves in + D_FLOW_REF, every further draw of an event in its private stream + D_FLOW_EV (see flow_first) */
+    D_FLOW0 = 12,      /* +j; index = ii; generate_errors_flows: NARROW words, word m = the m-th GAP (quiet first draws in front of the m-th scoring
+                          one) of pass 1 (+ D_FLOW_PASS2: of pass 2); every further draw of an event in its private stream + D_FLOW_EV (see flow_first) */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
     D_FLOW_PASS2 = 8,  /* added to D_FLOW0 / D_CALIB (+j) for the second pass of generate_errors_flows: domains 20-23 */
     D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
     D_MUTIN = 18,      /* mutation-input files (-b): index = entry ordinal; slot 0 hom test, 1 het haplotype (mut.c:662-669) */
     D_MUTIN_BASE = 19, /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
-    D_FLOW_REF = 32,   /* added to a flow-model domain: halfword h = the LOW half of first uniform h (matters with probability 2^-16, drawn lazily) */
+    D_FLOW_REF = 32,   /* (rounds 2-5: the low halves of the per-event first uniforms; unused since the first draws are drawn as gaps) */
     D_FLOW_EV = 64,    /* added to a flow-model domain: the private stream of event h -- draw s = word s & 3 of the block (retry s >> 2, block h) */
     D_BASE_REF0 = 24   /* +j; index = ii; halfword i = the LOW half of the 32-bit uniform of base i (it only matters when the high half alone
                           does not decide u < e, i.e. with probability 2^-16: the kernels draw it lazily) */
@@ -901,18 +900,73 @@ static void flow_alloc(flowbuf_t *b, int len, int F)
     b->mem = (len + 2 > F + 2) ? len + 2 : F + 2;
     b->seq = calloc((size_t)b->mem, 1); b->mask = calloc((size_t)b->mem, 1);
 }
-/* mode B draws of the flow model.  An "event" is a homopolymer start in pass 1 (index h = its position in the evolving read, the loop
- * index i of dwgsim.c:281) or an empty flow in pass 2 (h = the number of empty flows examined before it in this read).  Its FIRST uniform
- * -- 99 % of the events draw nothing else -- is a 16 + 16 bit draw: the high half is halfword h of the domain's stream (eight per Philox
- * block, as D_BASE0), the low half halfword h of domain + D_FLOW_REF.  So the kernels can turn a whole stream into a bitmap of "first
- * draw < e" with one block per eight events, before the serial part starts.  Every further draw of the event (more errors, insert or
- * delete, the dot-fill flow) is word s & 3 of the block (retry s >> 2, block h) of domain + D_FLOW_EV, s = 0, 1, ... */
-static inline double flow_first(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t h)
+/* mode B draws of the flow model (round 6).  An "event" is a homopolymer start in pass 1 or an empty flow in pass 2; the reference gives each a
+ * FIRST uniform, `drand48() < e` (dwgsim.c:296, :373), and 99 % of the events draw nothing else.  Rounds 2-5 gave every event its own 16 + 16 bit
+ * uniform: one Philox block per eight events, 170 blocks per 400-base read, and the kernels spent most of the flow model drawing and comparing
+ * numbers that say "no".  The first draws of a pass are a Bernoulli(e') sequence, e' = thr / 2^32 with thr = ceil(e 2^32) as everywhere (u < e <=>
+ * w < thr); such a sequence is, in law, its GAPS: the number of quiet draws in front of each scoring one is Geometric(e'), independent.  So mode B
+ * draws the gaps, by inversion: gap m of the pass comes from word m & 3 of block m >> 2 of the domain (D_FLOW0 + j, + D_FLOW_PASS2),
+ *     G = floor(-log2(U) / -log2(1 - e')),  U = (2 w + 1) / 2^33,
+ * in INTEGER arithmetic only (flow_gap below: a 257-entry table of log2 made by repeated squaring, fixed point, one 64 x 64 -> 128 multiplication), so
+ * that gcc and the kernels agree bit for bit.  The ordinals of the scoring first draws are S_0 = G_0, S_(m+1) = S_m + 1 + G_(m+1); the k-th first draw
+ * of the pass (k = 0, 1, ...: homopolymer starts examined so far in pass 1, empty flows examined so far in pass 2) scores iff k is one of them.
+ * Every further draw of an event (more errors, insert or delete, the dot-fill flow) is word s & 3 of the block (retry s >> 2, block h) of domain +
+ * D_FLOW_EV, s = 0, 1, ..., with h = the event's position in the evolving read (pass 1) / the number of empty flows examined before it (pass 2), as before.
+ * --dump-draws (replay through the unmodified reference): a first draw is handed over as 0 (scores) or 1 - 2^-48 (quiet) -- the reference only
+ * compares it with e. */
+static uint64_t ilog2_fixed(uint64_t y, int fb)      /* floor(log2(y) * 2^fb) for y >= 1, fb <= 56: repeated squaring in Q1.63 */
+{
+    int p = 63 - __builtin_clzll(y);
+    uint64_t m = y << (63 - p), frac = 0;
+    for (int k = 0; k < fb; ++k) {
+        const unsigned __int128 sq = (unsigned __int128)m * m;       /* Q2.126 */
+        if ((uint64_t)(sq >> 127)) { m = (uint64_t)(sq >> 64); frac = (frac << 1) | 1u; }
+        else { m = (uint64_t)(sq >> 63); frac <<= 1; }
+    }
+    return ((uint64_t)p << fb) | frac;
+}
+static uint32_t flow_lg[257]; static int flow_lg_ready = 0;
+typedef struct { uint64_t thr, R; int s; } gap_par_t;
+static gap_par_t flow_gap_params(uint64_t thr)       /* -log2(1 - e') in Q8.56, normalised, and its reciprocal (dw_kernels.hpp flow_gap_params: the same text) */
+{
+    gap_par_t g; g.thr = thr; g.R = 0; g.s = 0;
+    if (thr == 0 || thr >= 0x100000000ull) return g;
+    if (!flow_lg_ready) { for (int i = 0; i < 256; ++i) flow_lg[i] = (uint32_t)ilog2_fixed(256u + (uint64_t)i, 32); flow_lg[256] = 0xFFFFFFFFu; flow_lg_ready = 1; }
+    const uint64_t Lq = (32ull << 56) - ilog2_fixed(0x100000000ull - thr, 56);
+    const int sh = __builtin_clzll(Lq);
+    const unsigned __int128 q = ((unsigned __int128)1 << 127) / (Lq << sh);
+    g.R = q >> 64 ? ~0ull : (uint64_t)q; g.s = 63 - sh;
+    return g;
+}
+#define FLOW_NEVER 0xFFFFFFFFu
+static uint32_t flow_gap(uint32_t w, const gap_par_t *g)      /* quiet first draws in front of the next scoring one */
+{
+    if (g->thr >= 0x100000000ull) return 0;
+    const uint64_t X = ((uint64_t)w << 1) | 1u;
+    const int p = 63 - __builtin_clzll(X);
+    const uint64_t M = X << (63 - p);
+    const uint32_t idx = (uint32_t)(M >> 55) & 0xFFu, r16 = (uint32_t)(M >> 39) & 0xFFFFu;
+    const uint32_t f = flow_lg[idx] + (uint32_t)(((uint64_t)(flow_lg[idx + 1] - flow_lg[idx]) * r16) >> 16);
+    const uint64_t Lu = ((uint64_t)(33 - p) << 56) - ((uint64_t)f << 24);
+    const uint64_t G = (uint64_t)(((unsigned __int128)Lu * g->R) >> 64) >> g->s;
+    return G > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)G;
+}
+typedef struct { int init; uint32_t m, next; gap_par_t par; } gapstate_t;
+/* does first draw number `ordinal` (0, 1, 2, ... in the order the reference makes them) of the pass score? */
+static inline int flow_first(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t ordinal, double e, gapstate_t *gs)
 {
     r->n_draws++;
-    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    const uint32_t hi = philox_halfword(r, fdom, idx, att, h), lo = philox_halfword(r, fdom + D_FLOW_REF, idx, att, h);
-    return rng_out(r, (double)((hi << 16) | lo) * 0x1p-32);
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x) < e;
+    if (!gs->init) {
+        gs->init = 1; gs->m = 0;
+        gs->par = flow_gap_params(!(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0));
+        gs->next = FLOW_NEVER;
+    }
+    if (gs->par.thr && gs->m == 0) { gs->next = flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, fdom, idx, att, 0, 0) * 4294967296.0), &gs->par); gs->m = 1; }
+    const int hit = ordinal == gs->next;
+    if (hit) { const uint32_t m = gs->m++; gs->next = ordinal + 1u + flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, fdom, idx, att, 0, m) * 4294967296.0), &gs->par); }
+    rng_out(r, hit ? 0.0 : 1.0 - 0x1p-48);
+    return hit;
 }
 static inline double flow_u(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t evt, uint32_t *es)
 {
@@ -925,7 +979,8 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
 {
     int i, j, k, hp_l, flow_i, n_err, F = o->flow_order_len;
     uint8_t prev_c, c;
-    uint32_t fdom = dom, evt = 0, es = 0, g = 0; (void)slot;
+    uint32_t fdom = dom, evt = 0, es = 0, g = 0, k1 = 0; (void)slot;
+    gapstate_t gs1, gs2; memset(&gs1, 0, sizeof gs1); memset(&gs2, 0, sizeof gs2);
     for (i = 0; i < len; ++i) if (b->seq[i] >= 4) b->seq[i] = 0;
     if (strand == 1) for (i = 0; i < len >> 1; ++i) { c = b->seq[i]; b->seq[i] = b->seq[len - i - 1]; b->seq[len - i - 1] = c; }
     for (i = 0; i < F; ++i) {
@@ -942,7 +997,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
             b->mask[flow_i] = 0;
             evt = (uint32_t)i; es = 0;
             n_err = 0;
-            if (flow_first(r, fdom, idx, att, evt) < e) { n_err = 1; while (FLOW_U() < e) n_err++; } /* while(drand48() < e) n_err++ (dwgsim.c:296) */
+            if (flow_first(r, fdom, idx, att, k1++, e, &gs1)) { n_err = 1; while (FLOW_U() < e) n_err++; } /* while(drand48() < e) n_err++ (dwgsim.c:296) */
             if (0 < n_err) {
                 if (FLOW_U() < 0.5) { /* insert */
                     flow_grow(b, len + n_err);
@@ -977,7 +1032,7 @@ static int flow_errors(const opt_t *o, rng_t *r, uint32_t dom, uint64_t idx, uin
         while (c != o->flow_order[flow_i]) {
             evt = g++; es = 0;
             n_err = 0;
-            if (flow_first(r, fdom, idx, att, evt) < e) { n_err = 1; while (FLOW_U() < e) n_err++; } /* dwgsim.c:373 */
+            if (flow_first(r, fdom, idx, att, evt, e, &gs2)) { n_err = 1; while (FLOW_U() < e) n_err++; } /* dwgsim.c:373 */
             if (0 == b->mask[flow_i] && 0 < n_err) {
                 flow_grow(b, len + n_err);
                 for (j = len - 1; i <= j; --j) b->seq[j + n_err] = b->seq[j];

@@ -77,6 +77,7 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

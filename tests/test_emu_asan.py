@@ -40,7 +40,7 @@ compare_job_api(lib, oracle, os.path.join(g, "tiny.fa"), "-z 9 -N 300 -y 0.2 -r 
 # reads the flow model gives up on (absurd per-flow error): the call must fail cleanly, with every write in bounds
 compare_case(lib, oracle, os.path.join(g, "ex1.fa"), "-z 8397 -1 100 -2 0 -N 64 -e 0.3 -o 0 -c 2 -f GATC", batch_pairs=128)      # deep insertion cascades
 # reads that grow to 128 x their starting capacity: the buffers are doubled again and again, from LDS into scratch slots (rounds 3-4 stopped at 16 x)
-compare_case(lib, oracle, os.path.join(g, "tiny.fa"), "-z 9 -N 400 -c 2 -f TCG" + "A" * 12 + " -1 17 -2 0 -e 0.19", batch_pairs=300, debug_options={"flow_cap": 20})
+compare_case(lib, oracle, os.path.join(g, "tiny.fa"), "-z 12 -N 400 -c 2 -f TCG" + "A" * 12 + " -1 17 -2 0 -e 0.19", batch_pairs=300, debug_options={"flow_cap": 20})
 for flags in ["-z 4246 -1 9 -2 0 -N 300 -e 1.0 -y 0.3 -n 20 -c 2 -f TACG", "-z 4246 -1 9 -2 9 -d 40 -N 300 -e 1.0 -o 0 -c 2 -f TACG"]:
     try:
         api.run_job(api.parse_flags(flags, lib), api.read_fasta(os.path.join(g, "ex1.fa")), lib=lib)

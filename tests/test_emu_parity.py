@@ -178,9 +178,9 @@ def test_ion_torrent_read_outgrows_its_buffers_on_cpu_emulation(emu_lib, oracle_
     res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 900 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 100 -2 0 -e 0.05 -y 0.1",
                        batch_pairs=300, debug_options={"flow_cap": 104})
     assert res.flow_cap_mult >= 2
-    # ... and 17-base reads that grow to 2 317 bases (twelve empty flows in front of every T at e = 0.19): 128 x the starting capacity -- rounds 3-4 gave
+    # ... and 17-base reads that grow to 2 059 bases (twelve empty flows in front of every T at e = 0.19): 128 x the starting capacity -- rounds 3-4 gave
     # up at 16 x, the reference keeps doubling (dwgsim.c:296-311)
-    res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 9 -N 400 -c 2 -f TCG" + "A" * 12 + " -1 17 -2 0 -e 0.19", batch_pairs=300, debug_options={"flow_cap": 20})
+    res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 12 -N 400 -c 2 -f TCG" + "A" * 12 + " -1 17 -2 0 -e 0.19", batch_pairs=300, debug_options={"flow_cap": 20})
     assert res.flow_cap_mult >= 128
 
 
@@ -193,6 +193,16 @@ def test_walk_reruns_when_a_capacity_is_exceeded(emu_lib, oracle_bin, golden_dir
     """The walk is enqueued with estimated capacities and checked once at the end; too small a candidate list or inserted-base
     pool must lead to an exact re-run with the same result."""
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 30 -X 0.6", batch_pairs=700, debug_options={"walk_cap": 7})
+
+
+@pytest.mark.parametrize("opts", [{"site_slots": 0}, {"site_slots": 1}, {"site_slots": 1, "site_slot_cap": 3}, {"site_slots": 1, "site_slot_cap": 3, "walk_cap": 7}],
+                         ids=["look-back", "slots", "slot-outgrown", "slot-and-list-outgrown"])
+def test_both_forms_of_the_site_scan(emu_lib, oracle_bin, golden_dir, opts):
+    """Candidate sites into the ordered list: every block into a slot of its own + scan + gather (round 6: no block waits for another), or one kernel with a
+    decoupled look-back (re-runs, high mutation rates).  A block that outgrows its slot -- three entries here -- makes the host run the walk again through the
+    look-back form; mutations and reads as the oracle's either way, also with several contigs in one group (contig boundaries inside a block's tiles)."""
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "tiny.fa"), "-z 4 -N 600 -r 0.02 -R 0.5 -I 3 -X 0.6", batch_pairs=700, debug_options=opts)
+    compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, "odd.fa"), "-z 3 -N 300 -1 50 -2 50 -d 200 -s 20 -r 0.1 -R 1.0 -X 0.7 -n 50 -y 0.1", batch_pairs=90, debug_options=opts, group_bp=1 << 30)
 
 
 def test_walk_scans_in_their_segmented_form(emu_lib, oracle_bin, golden_dir):
@@ -243,6 +253,29 @@ def test_job_level_of_the_abi_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, 
     reads as rand_ii bases, ordered delivery -- every byte as the oracle's single-process run."""
     from parity_common import compare_job_api
     compare_job_api(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, **kw)
+
+
+@pytest.mark.parametrize("fasta,flags,kw", [
+    ("tiny.fa", "-z 9 -N 900 -P pfx -r 0.01 -R 0.3 -y 0.2", dict(devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=100, min_share=40)),
+    ("tiny.fa", "-z 9 -N 300 -y 0.2 -o 1", dict(devices=[0, 0], gzip_on_gpu=True, batch_pairs=100, min_share=40)),
+    ("tiny.fa", "-z 9 -C 3 -y 0.1", dict(devices=[0, 0, 0], gzip_on_gpu=False, batch_pairs=64, min_share=1, group_bp=5000)),
+    ("odd.fa", "-z 6 -N 700 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 120 -2 0 -e 0.05 -n 10 -r 0.05 -R 0.5 -y 0.2", dict(devices=[0, 0, 0, 0], gzip_on_gpu=False, batch_pairs=77, min_share=1)),
+    ("ex1.fa", "-z 13 -N 800 -M 1", dict(devices=[0], gzip_on_gpu=False, batch_pairs=300)),
+])
+def test_job_level_offset_sink_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags, kw):
+    """dwgsim_hip_job_sink_t::reads_at (ABI 5): every device's batches handed over by threads of their own, each piece with its offset in the stream, in any
+    order -- the pieces must tile each stream exactly (api.run_job_api checks: no gap, no overlap) and, put in order, be the oracle's bytes."""
+    from parity_common import compare_job_api
+    res = compare_job_api(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, offset_sink=True, **kw)
+    assert res.delivery_threads >= 1
+
+
+def test_job_level_offset_sink_in_the_shape_of_a_whole_node_on_cpu_emulation(emu_lib, oracle_bin, tmp_path):
+    from parity_common import compare_job_api
+    fa = str(tmp_path / "many.fa")
+    write_many_contigs(fa, 60, seed=8)
+    res = compare_job_api(emu_lib, oracle_bin, fa, "-z 12 -C 5 -1 60 -2 40 -d 220 -s 10 -r 0.02 -R 0.5 -n 10 -y 0.15", devices=[0] * 8, batch_pairs=23, min_share=1, group_bp=3000, offset_sink=True)
+    assert res.delivery_threads > 3      # more deliverers than the ordered sink's one per stream
 
 
 def test_job_level_many_small_contigs_on_cpu_emulation(emu_lib, oracle_bin, tmp_path):
@@ -466,7 +499,7 @@ def test_independent_threads_in_reverse_order_on_cpu_emulation(emu_lib, oracle_b
 
 # every kernel whose blocks do not wait for one another: the whole mutation walk, the random-read count, the scans, the abort rule, the calibration
 # (k_simulate and k_gzip in their single-kernel forms look back at the blocks in front of them: their LANES are reversed, HIPEMU_REVERSE_LANES)
-ORDER_FREE_KERNELS = ("k_pack,k_site_scan,k_scan_excl,k_compact,k_events,k_resolve,k_scan4,k_scan4_fix,k_apply,k_jreach,k_sufmin,k_sufmin_fix,k_jbound,k_jrun,k_apply_patches,"
+ORDER_FREE_KERNELS = ("k_pack,k_site_scan,k_site_scan_slots,k_slot_scan,k_slot_gather,k_mark_dirty,k_dirty_chunks,k_scan_excl,k_compact,k_events,k_resolve,k_scan4,k_scan4_fix,k_apply,k_jreach,k_sufmin,k_sufmin_fix,k_jbound,k_jrun,k_apply_patches,"
                       "k_collect_mask,k_gather,k_mut_debug,k_make_view,k_place,k_place_rest,k_range_counts,k_split_scan1,k_split_scan2,k_failrule_a,k_failrule_b,k_calibrate")
 DENSE_CASES = [      # dense indels, long insertions, homopolymers and tandem repeats, N runs, file-driven mutations, regions: what makes the threads of the walk meet
     ("odd.fa", "-z 8384 -1 7 -2 1 -d 900 -s 1 -C 0.5 -r 0.3 -y 0.3 -n 1000 -S 1 -H -o 1", 0),

@@ -106,3 +106,41 @@ def test_mode_b_draws_from_the_same_distributions_as_mode_a(oracle_bin, tmp_path
     for L in range(1, 8):
         close_counts(int(A["ins_len"][L]), int(B["ins_len"][L]), f"insertions of length {L}")
     assert 0.45 < A["ins_len"][1] / A["n_ins"] < 0.55 and 0.45 < B["ins_len"][1] / B["n_ins"] < 0.55
+
+
+@pytest.mark.parametrize("e,flow", [(0.01, "TACGTACGTCTGAGCATCGATCGATGTACAGC"), (0.06, "TACG")])
+def test_the_gap_drawn_flow_model_has_the_law_of_the_reference(oracle_bin, tmp_path, e, flow):
+    """Ion Torrent (dwgsim.c:246-417).  Mode B does not draw the first uniform of every homopolymer start / empty flow: it draws the GAPS between the scoring
+    ones (Geometric(e'), by inversion in integer arithmetic: oracle flow_first) -- the same Bernoulli process in law, a dozen draws per read
+    instead of 1 400.  Replay parity shows that the unmodified reference, given those decisions, writes mode B's bytes; THIS shows that the decisions have
+    the reference's distribution: 150 000 reads of 200 bases per mode (mode A = the reference's sequential stream, byte-pinned), the per-read error counts
+    (histogram, mean, variance: clustering would show there) and the read lengths after errors (insertions against deletions)."""
+    fa = str(tmp_path / "ref.fa")
+    synth.write_fasta(fa, [("c1", synth.random_contig(400_000, 9))])
+    n = 150_000
+    out = {}
+    for mode, seed in (("drand48", 21), ("philox", 22)):
+        prefix = str(tmp_path / mode)
+        subprocess.run([oracle_bin, "--rng", mode, "-z", str(seed), "-N", str(n), "-c", "2", "-f", flow, "-1", "200", "-2", "0", "-e", str(e), "-r", "0", "-y", "0", "-o", "1", fa, prefix],
+                       check=True, stderr=subprocess.DEVNULL)
+        lines = open(prefix + ".bwa.read1.fastq", "rb").read().split(b"\n")
+        names, seqs = lines[0::4][:n], lines[1::4][:n]
+        errs = np.array([int(nm.rsplit(b"_", 3)[1].split(b":")[0]) for nm in names])
+        lens = np.array([len(s) for s in seqs])
+        out[mode] = (errs, lens)
+        os.remove(prefix + ".bwa.read1.fastq")
+    (ea, la), (eb, lb) = out["drand48"], out["philox"]
+    assert len(ea) == len(eb) == n
+    # error counts per read: mean within 5 standard errors, variance within 3 %, every bin of the histogram within 5 sigma
+    se = np.hypot(ea.std(), eb.std()) / np.sqrt(n)
+    assert abs(ea.mean() - eb.mean()) < 5 * se, (ea.mean(), eb.mean(), se)
+    assert abs(ea.var() / eb.var() - 1) < 0.03, (ea.var(), eb.var())
+    ha, hb = np.bincount(ea, minlength=64)[:64], np.bincount(eb, minlength=64)[:64]
+    for k in range(64):
+        close_counts(int(ha[k]), int(hb[k]), f"reads with {k} flow errors")
+    # read lengths after errors (insertions lengthen, deletions shorten): mean, spread, histogram around 200
+    assert abs(la.mean() - lb.mean()) < 5 * np.hypot(la.std(), lb.std()) / np.sqrt(n), (la.mean(), lb.mean())
+    assert abs(la.std() / lb.std() - 1) < 0.02, (la.std(), lb.std())
+    for L in range(190, 215):
+        close_counts(int((la == L).sum()), int((lb == L).sum()), f"reads of length {L}")
+    assert ea.mean() > 50 * e          # (the test is not vacuous: errors do happen, ~ 200 (1 + 2.4) e of them per read)
