@@ -26,8 +26,9 @@ enum : uint32_t {
                         // 4 hom test (:622,:629, mut.c:301), 5 het haplotype (:625,:633, mut.c:303)
     D_WALK_INSLEN = 2,  // slot k = k-th insertion length-extension test (mut.c:292)
     D_WALK_INSBASE = 3, // slot k = k-th inserted-base draw (mut.c:314 / :351)
-    D_WALK_SITE = 7,    // index = 0.  halfword p (block p >> 3, laid out as D_BASE0) = the HIGH half of the uniform of "mutate position p?" (mut.c:618);
-    D_WALK_SITE_REF = 26, // ... its LOW half, drawn only when the high halves of the uniform and of mut_rate * 2^32 agree
+    D_WALK_SITE = 7,    // index = window q of 256 positions of the contig.  NARROW words: word m = the m-th GAP between candidate sites ("mutate this position?",
+                        // mut.c:618) inside the window: candidates at 256 q + S_m, S_0 = G_0, S_(m+1) = S_m + 1 + G_(m+1) (geom_gap below), while S_m < 256
+    D_WALK_SITE_REF = 26, // (rounds 2-5: the low halves of per-position site draws; unused)
     D_PAIR = 4,         // index = ii.  slot 0 random-read test (dwgsim.c:649), 1 haplotype (:716), 2 strand (:723)
     D_PLACE = 5,        // slot t = position uniform of placement try t (dwgsim.c:671)
     D_PLACE_NORM = 6,   // block t, retry r = polar tries of the insert-size normal of try t (dwgsim.c:657)
@@ -37,10 +38,10 @@ enum : uint32_t {
     D_QUAL0 = 10,       // +read end.  the sequential stream of polar tries of the read's quality normals (dwgsim.c:912, :156-175), 16-BIT uniforms: try t =
                         // the two halves of word t & 3 of block t >> 2 (low half v1, high half v2); every accepted try delivers two normals (v2*fac,
                         // then the cached v1*fac)
-    D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): 16-bit draws, eight per block -- halfword h is the HIGH half of the FIRST
-                        // uniform of event h: the homopolymer start at position h of the evolving read (pass 1), the h-th empty flow of the read
-                        // (pass 2, + D_FLOW_PASS2); low halves: + D_FLOW_REF (lazy); every further draw of an event: its private stream + D_FLOW_EV
-    D_FLOW_REF = 32,    // added to a flow-model domain: halfword h = the LOW half of first uniform h
+    D_FLOW0 = 12,       // +read end.  generate_errors_flows (dwgsim.c:246-417): NARROW words, word m = the m-th GAP between scoring FIRST draws of pass 1 (the
+                        // first draws of the homopolymer starts, in the order they are examined; + D_FLOW_PASS2: of the empty flows of pass 2) -- geom_gap
+                        // below; every further draw of an event: its private stream + D_FLOW_EV
+    D_FLOW_REF = 32,    // (rounds 2-5: the low halves of per-event first uniforms; unused)
     D_FLOW_EV = 64,     // added to a flow-model domain: draw s of event h = word s & 3 of the block (retry s >> 2, block h)
     D_FLOW_PASS2 = 8,   // added to D_FLOW0 / D_CALIB (+read end) for the second pass of the flow model (domains 20-23)
     D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
@@ -144,6 +145,23 @@ DW_DEV double det_log(double x)
         return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
     }
     return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// ---- geometric gaps (round 6).  A sequence of independent "does this one score?" draws with probability e' = thr / 2^32 is, in law, its gaps: the quiet
+// draws in front of each scoring one are Geometric(e').  G = floor(-log2(U) / -log2(1 - e')), U = (2 w + 1) / 2^33, in integer arithmetic only, so that every
+// compiler agrees: lg = the host's 257-entry table floor(2^32 log2(1 + i / 256)) (linear interpolation), -log2(U) in Q8.56, one 64 x 64 -> 128 multiplication by
+// R = 2^127 / (normalised -log2(1 - e')) and a shift (dw_kernels.hpp flow_gap_params).  Used by the flow model's first draws and the walk's site draws. ----
+DW_DEV uint32_t geom_gap(uint32_t w, const uint32_t *lg, uint64_t R, int sR)
+{
+    const uint64_t X = ((uint64_t)w << 1) | 1ull;
+    const int p = 63 - __clzll((long long)X);
+    const uint64_t M = X << (63 - p);
+    const uint32_t idx = (uint32_t)(M >> 55) & 0xFFu, r16 = (uint32_t)(M >> 39) & 0xFFFFu;
+    const uint32_t t0 = lg[idx], t1 = lg[idx + 1];
+    const uint32_t f = t0 + (uint32_t)(((uint64_t)(t1 - t0) * r16) >> 16);
+    const uint64_t Lu = ((uint64_t)(33 - p) << 56) - ((uint64_t)f << 24);
+    const uint64_t G = __umul64hi(Lu, R) >> sR;
+    return G > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)G;
 }
 
 // ---- wave64 helpers (all 64 lanes must call) ----

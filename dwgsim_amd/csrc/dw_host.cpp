@@ -211,6 +211,8 @@ WalkParams walk_params(const dwgsim_hip_ctx *c)
     WalkParams w; w.mut_rate = c->prm.mut_rate; w.indel_frac = c->prm.indel_frac; w.indel_extend = c->prm.indel_extend;
     w.indel_min = c->prm.indel_min; w.is_hap = c->prm.is_hap; w.seed = (uint32_t)c->prm.seed;
     w.mut_thr = !(c->prm.mut_rate > 0) ? 0 : c->prm.mut_rate >= 1.0 ? 0x100000000ull : (uint64_t)ceil(c->prm.mut_rate * 4294967296.0);   // exact scaling by 2^32
+    flow_gap_params(w.mut_thr, &w.gap_r, &w.gap_s);
+    w.lg = reinterpret_cast<const uint32_t *>(c->d_flow + 64);      // (behind the flow order: made in dwgsim_hip_create for every context)
     return w;
 }
 

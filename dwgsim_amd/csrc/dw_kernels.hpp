@@ -86,6 +86,8 @@ struct Count { const uint64_t *dev; uint32_t host; };
 struct WalkParams {
     double mut_rate, indel_frac, indel_extend;
     uint64_t mut_thr;              // ceil(mut_rate * 2^32) (2^32 for a rate of 1): u < mut_rate  <=>  the 32-bit draw < mut_thr
+    uint64_t gap_r; int32_t gap_s; // the gaps between candidate sites (dw_common.hpp geom_gap): flow_gap_params(mut_thr) ...
+    const uint32_t *lg;            // ... and the log2 table they interpolate in (device memory, FLOW_LG_ENTRIES words)
     int32_t indel_min, is_hap;
     uint32_t seed;
 };

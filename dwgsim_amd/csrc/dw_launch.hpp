@@ -5,7 +5,6 @@
 
 namespace dw {
 void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0, uint8_t *h1, int64_t l);
-void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg, WalkParams wp, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1);
 void launch_site_scan_list(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket, int32_t *out, uint32_t cap, uint64_t *n_out);
 uint32_t site_scan_blocks(int64_t l);            // blocks of the site scan over l positions, and the positions a block takes
 uint32_t site_scan_block_positions();

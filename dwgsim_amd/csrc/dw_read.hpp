@@ -373,18 +373,6 @@ struct BitAppender {
 // scoring first draw: a dozen gaps per read instead of 1 400 uniforms.  (The unmodified reference replays it all the same: tests/replay_common.py.)
 struct FlowGap {
     uint32_t next, m, w0, w1, w2, w3;       // ordinal of the next scoring first draw (FLOW_NEVER: none); gaps drawn so far; the words of the current block
-    DW_DEV static uint32_t gap_of(uint32_t w, const uint32_t *lg, uint64_t R, int sR)
-    {
-        const uint64_t X = ((uint64_t)w << 1) | 1ull;
-        const int p = 63 - __clzll((long long)X);
-        const uint64_t M = X << (63 - p);
-        const uint32_t idx = (uint32_t)(M >> 55) & 0xFFu, r16 = (uint32_t)(M >> 39) & 0xFFFFu;
-        const uint32_t t0 = lg[idx], t1 = lg[idx + 1];
-        const uint32_t f = t0 + (uint32_t)(((uint64_t)(t1 - t0) * r16) >> 16);
-        const uint64_t Lu = ((uint64_t)(33 - p) << 56) - ((uint64_t)f << 24);
-        const uint64_t G = __umul64hi(Lu, R) >> sR;
-        return G > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)G;
-    }
     // the next gap: the scoring draw it leads to has ordinal base + G (base = the ordinal after the one that just scored, 0 at the start of a pass)
     DW_DEV void draw(bool go, RngKey key, uint32_t dom, uint64_t ii, uint32_t att, uint32_t base, uint64_t thr, const uint32_t *lg, uint64_t R, int sR)
     {
@@ -393,7 +381,7 @@ struct FlowGap {
         if ((m & 3u) == 0u) { const U4 b = rng_block(key, dom, ii, att, 0, m >> 2); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
         const uint32_t k = m & 3u; ++m;
         const uint32_t w = (k & 2u) ? ((k & 1u) ? w3 : w2) : ((k & 1u) ? w1 : w0);
-        next = base + (thr >= 0x100000000ull ? 0u : gap_of(w, lg, R, sR));
+        next = base + (thr >= 0x100000000ull ? 0u : geom_gap(w, lg, R, sR));
     }
 };
 // what a scoring event goes on to draw (dw_common.hpp D_FLOW_EV: further errors, insert-or-delete, the dot-fill flow): one Philox block, block `pos`
@@ -460,7 +448,10 @@ DW_DEV uint32_t even_bits16(uint32_t x)      // bits 0, 2, 4, .. 30 of x gathere
 // parked lanes together, when a quarter of the wave stands parked or no lane can step any more: in rounds 3-5 some lane stood on an event in nearly
 // every iteration and the whole wave went through the event code every time.  Each lane performs exactly its own sequence of operations; only their
 // interleaving changes.
-constexpr int FLOW_EVENT_BATCH = 16;      // parked lanes of a wave that make an event round worth its instructions
+#ifndef DW_FLOW_EVENT_BATCH
+#define DW_FLOW_EVENT_BATCH 16
+#endif
+constexpr int FLOW_EVENT_BATCH = DW_FLOW_EVENT_BATCH;      // parked lanes of a wave that make an event round worth its instructions
 DW_DEV int flow_errors(bool active, FlowRng &rg, const FlowTables &T, int F, uint64_t thr, uint64_t gap_R, int gap_s, uint32_t *buf, uint32_t *stk, int stride, int stack_runs,
                        int len, int strand, int capb, int32_t *n_err_out)
 {

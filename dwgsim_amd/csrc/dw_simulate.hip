@@ -877,6 +877,31 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
                 put_last_word(wa, rem);
                 if (rem > 8) put_last_word(wb, rem - 8);
             }
+        } else if (ION) {
+            // the 2-bit buffer (LDS, a scratch slot, or -- second half of the two-kernel form -- HBM): the words of SIXTY-FOUR bases fetched together, then
+            // written (round 5 fetched a word, or two, per eight bases and waited for each: in the second half, whose buffer is in HBM, the sequence line was
+            // a chain of a hundred dependent loads per read).  Reverse strand: record group j = buffer positions [s_out - 16 (j + 1), s_out - 16 j) turned round
+            const Buf2 B{lds, nthr, a.lds_words};
+            const int full16 = s_out >> 4;
+            const uint32_t sh2 = ((uint32_t)s_out & 15u) * 2u;
+            for (int g0 = 0; g0 < full16; g0 += 4) {
+                uint32_t r[5];
+                const int base = flow_reversed ? ((s_out - 16 * g0) >> 4) - 4 : g0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) r[q] = (base + q >= 0 && (flow_reversed || q < 4)) ? B.word(base + q) : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (g0 + k < full16) {
+                    uint32_t v;
+                    if (!flow_reversed) v = r[k];
+                    else {
+                        v = sh2 ? __builtin_amdgcn_alignbit(r[4 - k], r[3 - k], sh2) : r[3 - k];
+                        v = __builtin_bitreverse32(v); v = ((v & 0x55555555u) << 1) | ((v >> 1) & 0x55555555u);      // the sixteen pairs in reverse order
+                    }
+                    const uint32_t n0 = pairs_to_nibbles(v & 0xFFFFu), n1 = pairs_to_nibbles(v >> 16);
+                    o.put16(base_chars4(n0), base_chars4(n0 >> 16), base_chars4(n1), base_chars4(n1 >> 16));
+                }
+            }
+            for (int w = 2 * full16; w * 8 < s_out; ++w) put_last_word(rec_word(w), s_out - w * 8);      // the last, shorter group
         } else {
         int w = 0;
         for (; (w + 2) * 8 <= s_out; w += 2) {

@@ -2,7 +2,7 @@
 // (replaces src/mut.c:591-643 mut_diref + :481-589 mut_left_justify + the cell list behind :781-893 mut_print).
 //
 //     k_pack          ASCII -> base codes, initialises both haplotypes            HBM: 1 B in, 3 B out / base
-//     k_site_scan     one 16-bit draw per position (a Philox block per eight): candidate sites (bitmask)     HBM: 1 B in / base
+//     k_site_scan_slots / k_slot_scan / k_slot_gather (or k_site_scan_list)   candidate sites: a gap chain per window of 256 positions -> ordered list     HBM: a byte per candidate
 //     k_scan_excl     single-block exclusive scan of per-block counts
 //     k_compact       ordered compaction of a bitmask into a position list
 //     k_events        one thread per candidate: speculative event (type, ploidy, lengths)
@@ -50,150 +50,91 @@ __global__ void k_pack(const uint8_t *__restrict__ ascii, uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: candidate sites.  mut.c:618 `c < 4 && drand48() < opt->mut_rate`: the draw of position p is halfword p of the D_WALK_SITE stream (16 + 16
-// bits, the low halves drawn only on a tie with the threshold's high half), so one Philox block serves EIGHT positions.  16 positions per
-// thread, 4096 per block; emits a bitmask (uint16 per thread) and the per-block candidate count.
+// K1: candidate sites.  mut.c:618 `c < 4 && drand48() < opt->mut_rate`, once per ACGT position.  Rounds 2-5 drew a 16-bit uniform per position (a Philox
+// block per eight): 386 M blocks per 3.09 Gb genome, ALU-bound at 1 G positions per ms -- 2.1 of the 5.5 ms of a whole-genome walk, on every device that
+// walks it -- to learn "no" 999 times in 1000.  The candidates of a contig are a Bernoulli(r') process over its positions; restricted to a WINDOW of 256
+// positions it is independent of every other window, so every window has a gap chain of its own (dw_common.hpp D_WALK_SITE, geom_gap): S_0 = G_0, S_(m+1) =
+// S_m + 1 + G_(m+1), candidates at 256 q + S_m while S_m < 256 -- one Philox block per four candidates.  A LANE takes a window: it walks its chain once to
+// count the candidates that fall on A, C, G or T inside the contig (the one byte of the pristine 4-bit view each needs is all the sequence that is read),
+// and once more to write them.
 // ------------------------------------------------------------------------------------------------
-DW_DEV uint32_t site_hits8(RngKey key, uint32_t blk, uint64_t thr)      // bit k: the draw of position 8 * blk + k is below mut_rate
-{
-    const uint32_t t_hi = (uint32_t)(thr >> 16), t_lo = (uint32_t)thr & 0xFFFFu;       // t_hi <= 0x10000
-    const U4 b = rng_block(key, D_WALK_SITE, 0, 0, 0, blk);
-    const uint32_t hw[8] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16, b.z & 0xFFFFu, b.z >> 16, b.w & 0xFFFFu, b.w >> 16};
-    uint32_t lt = 0, closest = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { lt |= (hw[k] < t_hi ? 1u : 0u) << k; const uint32_t d = hw[k] ^ t_hi; closest = d < closest ? d : closest; }
-    if (closest == 0 && t_lo) {
-        const U4 r = rng_block(key, D_WALK_SITE_REF, 0, 0, 0, blk);
-        const uint32_t lw[8] = {r.x & 0xFFFFu, r.x >> 16, r.y & 0xFFFFu, r.y >> 16, r.z & 0xFFFFu, r.z >> 16, r.w & 0xFFFFu, r.w >> 16};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lt |= ((hw[k] == t_hi && lw[k] < t_lo) ? 1u : 0u) << k;
+constexpr int SITE_WINDOW = 256, SITE_THREADS = 256, SITE_BLOCK_POS = SITE_WINDOW * SITE_THREADS;      // positions per window (a lane) and per block (65 536)
+static_assert(GROUP_ALIGN % SITE_WINDOW == 0, "a window lies inside one contig: contigs start at multiples of GROUP_ALIGN");
+struct SiteChain {
+    uint32_t m, w0, w1, w2, w3;
+    DW_DEV uint32_t gap(RngKey key, uint32_t q, const WalkParams &wp, const uint32_t *lg)
+    {
+        if ((m & 3u) == 0u) { const U4 b = rng_block<false>(key, D_WALK_SITE, (uint64_t)q, 0, 0, m >> 2); w0 = b.x; w1 = b.y; w2 = b.z; w3 = b.w; }
+        const uint32_t k = m & 3u; ++m;
+        const uint32_t w = (k & 2u) ? ((k & 1u) ? w3 : w2) : ((k & 1u) ? w1 : w0);
+        return wp.mut_thr >= 0x100000000ull ? 0u : geom_gap(w, lg, wp.gap_r, wp.gap_s);
     }
-    return lt;
-}
-// reset0 / reset1 (a contig that is walked AGAIN): the 16 cells of both haplotypes are set back to the reference on the way.
-__global__ void k_site_scan(const uint8_t *__restrict__ ref, SegTab seg, WalkParams wp,
-                            uint16_t *__restrict__ mask, uint32_t *__restrict__ block_count, uint8_t *__restrict__ reset0, uint8_t *__restrict__ reset1)
+};
+// the candidates of the window that starts at group coordinate g0 (a multiple of SITE_WINDOW): f(group coordinate) for each, in rising order; returns how many
+template <class F>
+DW_DEV uint32_t site_window(const uint8_t *__restrict__ refview, int64_t l_total, const SegTab &seg, const WalkParams &wp, const uint32_t *lg, int64_t g0, F &&f)
 {
-    __shared__ uint32_t sm[17];
-    // a block's SCAN_POS_PER_BLOCK positions lie inside one contig of the group (contigs start at multiples of GROUP_ALIGN)
-    const uint32_t sk = seg_of(seg, (int64_t)blockIdx.x * SCAN_POS_PER_BLOCK);
-    const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
-    const int64_t g0 = ((int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_POS_PER_THREAD;
-    const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];               // position inside the contig: what the draws are indexed by
-    uint32_t bits = 0;
-    if (p0 < l) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(ref + g0);      // ref is padded: reading past l is safe
-        if (reset0) { *reinterpret_cast<uint4 *>(reset0 + g0) = v; *reinterpret_cast<uint4 *>(reset1 + g0) = v; }
-        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
-        uint32_t acgt = 0;                                               // positions that hold A, C, G or T (and lie inside the contig)
-#pragma unroll
-        for (int b = 0; b < 16; ++b) { const uint32_t c = (in[b >> 2] >> (8 * (b & 3))) & 0xff; if (c < 4 && p0 + b < l) acgt |= 1u << b; }
-        if (acgt) bits = (site_hits8(key, (uint32_t)(p0 >> 3), wp.mut_thr) | (site_hits8(key, (uint32_t)(p0 >> 3) + 1u, wp.mut_thr) << 8)) & acgt;
+    if (g0 >= l_total || wp.mut_thr == 0) return 0;
+    const uint32_t sk = seg_of(seg, g0);
+    const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];      // position inside the contig: what the draws are indexed by
+    if (p0 >= l) return 0;                                       // (the padding behind a contig)
+    const RngKey key{wp.seed, seg.cindex[sk]};
+    const uint32_t q = (uint32_t)(p0 >> 8);
+    const uint32_t lim = l - p0 < SITE_WINDOW ? (uint32_t)(l - p0) : (uint32_t)SITE_WINDOW;
+    SiteChain ch; ch.m = 0; ch.w0 = ch.w1 = ch.w2 = ch.w3 = 0;
+    uint32_t n = 0;
+    for (uint32_t S = ch.gap(key, q, wp, lg); S < lim; S += 1u + ch.gap(key, q, wp, lg)) {
+        const int64_t g = g0 + S;
+        const uint32_t nib = (refview[g >> 1] >> (4 * (g & 1))) & 15u;      // the pristine view: a nibble below 4 is A, C, G or T
+        if (nib < 4u) { f(g, n); ++n; }
     }
-    mask[(int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x] = (uint16_t)bits;
-    uint32_t total;
-    (void)block_excl_scan((uint32_t)__popc(bits), sm, &total);
-    if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+    return n;
 }
 
-// K1 as ONE kernel over a group of any size (round 5; k_site_scan + k_scan_excl + k_compact above remain for the callers that still want a mask):
-// the sixteen positions of a thread come from the PRISTINE 4-bit view of the reference (0.5 byte per base instead of 1; a nibble below 4 is A, C, G or T),
-// and the candidates go straight into the ordered list -- the block's place in it from a decoupled look-back over the blocks in front (logical block ids
-// from a ticket, so that every predecessor has started), not from a scan kernel of its own: the single-block scan of the per-block counts was 0.85 ms
-// of a whole-genome walk and grows with the group.  status: one word per block, ticket: one word, both zeroed by the host; total -> *n_out.
-// A block takes SITE_TILES tiles of SCAN_POS_PER_BLOCK positions (each tile inside one contig): 65 536 positions per look-back -- with one tile per block
-// the chain of look-backs (a hop of at most 64 blocks per memory round trip) was slower than the draws: 4.6 ms per 1.5 Gb group, 0.4 ms worth of work.
-// 1024 lanes per block: four tiles at a time, four rounds -- the same 65 536 positions per look-back with a quarter of the serial work per lane (with 256
-// lanes and sixteen tiles in a row a 64 Mb contig was 983 blocks of 50 us each on a device that holds 2 048: 90 us for 17 us' worth of draws).
-constexpr int SITE_TILES = 16, SITE_THREADS = 1024, SITE_ROUNDS = SITE_TILES / (SITE_THREADS / SCAN_THREADS);
+// one kernel with a decoupled look-back (re-runs with exact capacities, mutation rates at which slots would be as large as the list): the block's place in
+// the ordered list from the blocks in front (logical block ids from a ticket, so that every predecessor has started).  status: one word per block, ticket:
+// one word, both zeroed by the host; total -> *n_out.
 __global__ void __launch_bounds__(SITE_THREADS) k_site_scan_list(const uint8_t *__restrict__ refview, int64_t l_total, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket,
                                                               int32_t *__restrict__ out, uint32_t cap, uint64_t *n_out, uint32_t n_blocks)
 {
-    __shared__ uint32_t sm[SITE_ROUNDS][16];
+    __shared__ uint32_t sm[1][16], s_lg[FLOW_LG_ENTRIES];
     __shared__ uint32_t s_t; __shared__ uint64_t s_base;
+    for (int q = (int)threadIdx.x; q < FLOW_LG_ENTRIES; q += SITE_THREADS) s_lg[q] = wp.lg[q];
     if (threadIdx.x == 0) s_t = (uint32_t)atomicAdd((unsigned long long *)ticket, 1ull);
     __syncthreads();
     const uint32_t t = uniform_u32(s_t);
-    const int sub = (int)(threadIdx.x / SCAN_THREADS), tin = (int)(threadIdx.x % SCAN_THREADS);      // which of the round's tiles, and where in it
-    uint32_t bits[SITE_ROUNDS], cnt[SITE_ROUNDS], off[SITE_ROUNDS], tot[SITE_ROUNDS], block_total = 0;
-#pragma unroll
-    for (int q = 0; q < SITE_ROUNDS; ++q) {
-        const int64_t tile0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK;
-        bits[q] = 0;
-        if (tile0 < l_total) {                                                   // (uniform over the tile's four waves)
-            const uint32_t sk = seg_of(seg, tile0);                              // a tile's positions lie inside one contig: contigs start at multiples of GROUP_ALIGN
-            const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
-            const int64_t g0 = tile0 + (int64_t)tin * SCAN_POS_PER_THREAD;
-            const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];              // position inside the contig: what the draws are indexed by
-            if (p0 < l) {
-                const uint64_t v = *reinterpret_cast<const uint64_t *>(refview + (g0 >> 1));      // sixteen nibbles (the view is padded: reading past l is safe)
-                uint32_t acgt = 0;
-#pragma unroll
-                for (int b = 0; b < 16; ++b) { const uint32_t nib = (uint32_t)(v >> (4 * b)) & 15u; if (nib < 4 && p0 + b < l) acgt |= 1u << b; }
-                if (acgt) bits[q] = (site_hits8(key, (uint32_t)(p0 >> 3), wp.mut_thr) | (site_hits8(key, (uint32_t)(p0 >> 3) + 1u, wp.mut_thr) << 8)) & acgt;
-            }
-        }
-        cnt[q] = (uint32_t)__popc(bits[q]);
-    }
-    block_excl_scan_n<SITE_ROUNDS>(cnt, sm, off, tot);      // a round's lanes stand in position order (tile by tile): four block-wide scans behind one barrier
-#pragma unroll
-    for (int q = 0; q < SITE_ROUNDS; ++q) { off[q] += block_total; block_total += tot[q]; }
+    const int64_t g0 = ((int64_t)t * SITE_THREADS + threadIdx.x) * SITE_WINDOW;
+    const uint32_t cnt[1] = {site_window(refview, l_total, seg, wp, s_lg, g0, [](int64_t, uint32_t) {})};
+    uint32_t off[1], tot[1];
+    block_excl_scan_n<1>(cnt, sm, off, tot);
     if (threadIdx.x < 64) {
-        const uint64_t g = lookback_excl(status, t, block_total, 0);
-        if (threadIdx.x == 0) { s_base = g; if (t + 1 == n_blocks) *n_out = g + block_total; }
+        const uint64_t g = lookback_excl(status, t, tot[0], 0);
+        if (threadIdx.x == 0) { s_base = g; if (t + 1 == n_blocks) *n_out = g + tot[0]; }
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < SITE_ROUNDS; ++q) {
-        uint64_t at = s_base + off[q]; uint32_t bq = bits[q];
-        const int64_t g0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK + (int64_t)tin * SCAN_POS_PER_THREAD;
-        while (bq) { const int b = __ffs((int)bq) - 1; bq &= bq - 1; if (at < cap) out[at] = (int32_t)(g0 + b); ++at; }   // (past the capacity: the host re-runs)
-    }
+    const uint64_t at0 = s_base + off[0];
+    if (cnt[0]) (void)site_window(refview, l_total, seg, wp, s_lg, g0, [&](int64_t g, uint32_t k) { if (at0 + k < cap) out[at0 + k] = (int32_t)g; });      // (past the capacity: the host re-runs)
 }
 
-// K1 without ANY dependency between blocks (round 6).  The look-back form above spends most of its time in the chain: a block's place in the list
-// is known only when every block in front has published, and the hops of that chain, not the draws, were 2.7 ms of a 5.9 ms whole-genome walk ("three
-// times its instruction count's worth").  Candidates are sparse and their number per block is tightly bounded (Binomial(65 536, r): mean + 8 sigma), so
-// a block writes them into a SLOT of its own (slot_cap entries) with its count beside; one small block then scans the counts (k_slot_scan) and
-// k_slot_gather moves the slots' entries to their places in the ordered list -- 12 bytes per candidate, a thousandth of the positions.  A block that
-// outgrows its slot (never, at mean + 8 sigma; forced in the tests) raises a flag and the host runs the walk again through the look-back form.
+// K1 without ANY dependency between blocks (round 6): a block writes its candidates into a SLOT of its own (slot_cap entries: mean + 8 sigma + 32 of the
+// Binomial(65 536, r)) with its count beside; one small block then scans the counts (k_slot_scan) and k_slot_gather moves the slots' entries to their places
+// in the ordered list -- 12 bytes per candidate, a thousandth of the positions.  A block that outgrows its slot (never, at mean + 8 sigma; forced in the
+// tests) raises a flag and the host runs the walk again through the look-back form.
 __global__ void __launch_bounds__(SITE_THREADS) k_site_scan_slots(const uint8_t *__restrict__ refview, int64_t l_total, SegTab seg, WalkParams wp, int32_t *__restrict__ slots, uint32_t slot_cap,
                                                                uint32_t *__restrict__ slot_cnt)
 {
-    __shared__ uint32_t sm[SITE_ROUNDS][16];
+    __shared__ uint32_t sm[1][16], s_lg[FLOW_LG_ENTRIES];
+    for (int q = (int)threadIdx.x; q < FLOW_LG_ENTRIES; q += SITE_THREADS) s_lg[q] = wp.lg[q];
+    __syncthreads();
     const uint32_t t = blockIdx.x;
-    const int sub = (int)(threadIdx.x / SCAN_THREADS), tin = (int)(threadIdx.x % SCAN_THREADS);      // which of the round's tiles, and where in it
-    uint32_t bits[SITE_ROUNDS], cnt[SITE_ROUNDS], off[SITE_ROUNDS], tot[SITE_ROUNDS], block_total = 0;
-#pragma unroll
-    for (int q = 0; q < SITE_ROUNDS; ++q) {
-        const int64_t tile0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK;
-        bits[q] = 0;
-        if (tile0 < l_total) {                                                   // (uniform over the tile's four waves)
-            const uint32_t sk = seg_of(seg, tile0);                              // a tile's positions lie inside one contig: contigs start at multiples of GROUP_ALIGN
-            const RngKey key{wp.seed, uniform_u32(seg.cindex[sk])};
-            const int64_t g0 = tile0 + (int64_t)tin * SCAN_POS_PER_THREAD;
-            const int64_t p0 = g0 - seg.start[sk], l = seg.len[sk];              // position inside the contig: what the draws are indexed by
-            if (p0 < l) {
-                const uint64_t v = *reinterpret_cast<const uint64_t *>(refview + (g0 >> 1));      // sixteen nibbles (the view is padded: reading past l is safe)
-                uint32_t acgt = 0;
-#pragma unroll
-                for (int b = 0; b < 16; ++b) { const uint32_t nib = (uint32_t)(v >> (4 * b)) & 15u; if (nib < 4 && p0 + b < l) acgt |= 1u << b; }
-                if (acgt) bits[q] = (site_hits8(key, (uint32_t)(p0 >> 3), wp.mut_thr) | (site_hits8(key, (uint32_t)(p0 >> 3) + 1u, wp.mut_thr) << 8)) & acgt;
-            }
-        }
-        cnt[q] = (uint32_t)__popc(bits[q]);
-    }
-    block_excl_scan_n<SITE_ROUNDS>(cnt, sm, off, tot);      // a round's lanes stand in position order (tile by tile): four block-wide scans behind one barrier
-#pragma unroll
-    for (int q = 0; q < SITE_ROUNDS; ++q) { off[q] += block_total; block_total += tot[q]; }
-    if (threadIdx.x == 0) slot_cnt[t] = block_total;
+    const int64_t g0 = ((int64_t)t * SITE_THREADS + threadIdx.x) * SITE_WINDOW;
+    const uint32_t cnt[1] = {site_window(refview, l_total, seg, wp, s_lg, g0, [](int64_t, uint32_t) {})};
+    uint32_t off[1], tot[1];
+    block_excl_scan_n<1>(cnt, sm, off, tot);
+    if (threadIdx.x == 0) slot_cnt[t] = tot[0];
     int32_t *const slot = slots + (size_t)t * slot_cap;
-#pragma unroll
-    for (int q = 0; q < SITE_ROUNDS; ++q) {
-        uint32_t at = off[q], bq = bits[q];
-        const int64_t g0 = ((int64_t)t * SITE_TILES + q * (SITE_THREADS / SCAN_THREADS) + sub) * SCAN_POS_PER_BLOCK + (int64_t)tin * SCAN_POS_PER_THREAD;
-        while (bq) { const int b = __ffs((int)bq) - 1; bq &= bq - 1; if (at < slot_cap) slot[at] = (int32_t)(g0 + b); ++at; }   // (past the slot: the host re-runs)
-    }
+    const uint32_t at0 = off[0];
+    if (cnt[0]) (void)site_window(refview, l_total, seg, wp, s_lg, g0, [&](int64_t g, uint32_t k) { if (at0 + k < slot_cap) slot[at0 + k] = (int32_t)g; });      // (past the slot: the host re-runs)
 }
 // one block: exclusive scan of the nb slot counts -> slot_base[0 .. nb), the candidates in all -> *n_out; over[0] = 1 and over[1] = that total if a slot
 // was outgrown (*n_out = 0 then: the kernels behind find nothing to do)
@@ -809,17 +750,13 @@ void launch_pack(hipStream_t st, const uint8_t *ascii, uint8_t *ref, uint8_t *h0
     uint32_t nb = cdiv(nchunk, 256); if (nb > (1u << 16)) nb = 1u << 16; if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, ascii, ref, h0, h1, l);
 }
-void launch_site_scan(hipStream_t st, const uint8_t *ref, int64_t l, SegTab seg, WalkParams wp, uint16_t *mask, uint32_t *block_count, uint8_t *reset0, uint8_t *reset1)
-{
-    hipLaunchKernelGGL(k_site_scan, dim3(cdiv((uint64_t)l, SCAN_POS_PER_BLOCK)), dim3(SCAN_THREADS), 0, st, ref, seg, wp, mask, block_count, reset0, reset1);
-}
 void launch_site_scan_list(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, uint64_t *status, uint64_t *ticket, int32_t *out, uint32_t cap, uint64_t *n_out)
 {
-    const uint32_t nb = (uint32_t)cdiv((uint64_t)l, (uint64_t)SCAN_POS_PER_BLOCK * SITE_TILES);
+    const uint32_t nb = (uint32_t)cdiv((uint64_t)l, (uint64_t)SITE_BLOCK_POS);
     hipLaunchKernelGGL(k_site_scan_list, dim3(nb), dim3(SITE_THREADS), 0, st, refview, l, seg, wp, status, ticket, out, cap, n_out, nb);
 }
-uint32_t site_scan_blocks(int64_t l) { return (uint32_t)cdiv((uint64_t)l, (uint64_t)SCAN_POS_PER_BLOCK * SITE_TILES); }
-uint32_t site_scan_block_positions() { return (uint32_t)SCAN_POS_PER_BLOCK * SITE_TILES; }
+uint32_t site_scan_blocks(int64_t l) { return (uint32_t)cdiv((uint64_t)l, (uint64_t)SITE_BLOCK_POS); }
+uint32_t site_scan_block_positions() { return (uint32_t)SITE_BLOCK_POS; }
 // slots: nb x slot_cap entries; aux: 2 nb words (counts, bases); over: two words, zeroed by the caller (k_slot_scan)
 void launch_site_scan_slots(hipStream_t st, const uint8_t *refview, int64_t l, SegTab seg, WalkParams wp, int32_t *slots, uint32_t slot_cap, uint32_t *aux, int32_t *out, uint32_t cap, uint64_t *n_out, uint32_t *over)
 {

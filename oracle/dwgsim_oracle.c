@@ -52,8 +52,7 @@ enum { RNG_DRAND48 = 0, RNG_PHILOX = 1 };
 /* mode-B domains (c2 = domain << 24 | attempt) */
 enum {
     D_WALK = 1,        /* index = position; slots 0, 2..5 (see walk_contig); the "mutate this base?" test (mut.c:618) is a 16 + 16 bit draw of its own: */
-    D_WALK_SITE = 7,   /* index = 0; halfword p (block p >> 3, eight per block, laid out as D_BASE0) = the HIGH half of position p's uniform; the LOW
-                          half is halfword p of D_WALK_SITE_REF (matters with probability 2^-16, drawn lazily by the kernel) */
+    D_WALK_SITE = 7,   /* index = window q of 256 positions; NARROW words, word m = the m-th GAP between candidate sites inside the window (walk_site) */
     D_WALK_SITE_REF = 26,
     D_WALK_INSLEN = 2, /* index = position; slot k = k-th length-extension test */
     D_WALK_INSBASE = 3,/* index = position; slot k = k-th inserted-base draw */
@@ -199,13 +198,69 @@ static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uin
     return rng_out(r, (double)((h << 16) | l) * 0x1p-32);
 }
 
-/* mut.c:618 drand48() < opt->mut_rate, one per non-N position: by far the most frequent draw of the walk, so it is a narrow one, eight per block */
-static inline double walk_site_u(rng_t *r, uint32_t p)
+/* ---- geometric gaps in integer arithmetic (round 6): shared by the site draws of the walk (walk_site below) and the first draws of the flow model
+ * (flow_first) -- what a Bernoulli(e') sequence of "does this one score?" draws is in law: the quiet draws in front of each scoring one are Geometric(e'),
+ * G = floor(-log2(U) / -log2(1 - e')), U = (2 w + 1) / 2^33, w one 32-bit word.  No libm: a 257-entry table of log2 made by repeated squaring, fixed
+ * point, one 64 x 64 -> 128 multiplication by a reciprocal -- the kernels and the product's host code hold the same text (dw_kernels.hpp / dw_common.hpp). ---- */
+static uint64_t ilog2_fixed(uint64_t y, int fb)      /* floor(log2(y) * 2^fb) for y >= 1, fb <= 56: repeated squaring in Q1.63 */
 {
+    int p = 63 - __builtin_clzll(y);
+    uint64_t m = y << (63 - p), frac = 0;
+    for (int k = 0; k < fb; ++k) {
+        const unsigned __int128 sq = (unsigned __int128)m * m;       /* Q2.126 */
+        if ((uint64_t)(sq >> 127)) { m = (uint64_t)(sq >> 64); frac = (frac << 1) | 1u; }
+        else { m = (uint64_t)(sq >> 63); frac <<= 1; }
+    }
+    return ((uint64_t)p << fb) | frac;
+}
+static uint32_t flow_lg[257]; static int flow_lg_ready = 0;
+typedef struct { uint64_t thr, R; int s; } gap_par_t;
+static gap_par_t flow_gap_params(uint64_t thr)       /* -log2(1 - e') in Q8.56, normalised, and its reciprocal (dw_kernels.hpp flow_gap_params: the same text) */
+{
+    gap_par_t g; g.thr = thr; g.R = 0; g.s = 0;
+    if (thr == 0 || thr >= 0x100000000ull) return g;
+    if (!flow_lg_ready) { for (int i = 0; i < 256; ++i) flow_lg[i] = (uint32_t)ilog2_fixed(256u + (uint64_t)i, 32); flow_lg[256] = 0xFFFFFFFFu; flow_lg_ready = 1; }
+    const uint64_t Lq = (32ull << 56) - ilog2_fixed(0x100000000ull - thr, 56);
+    const int sh = __builtin_clzll(Lq);
+    const unsigned __int128 q = ((unsigned __int128)1 << 127) / (Lq << sh);
+    g.R = q >> 64 ? ~0ull : (uint64_t)q; g.s = 63 - sh;
+    return g;
+}
+#define FLOW_NEVER 0xFFFFFFFFu
+static uint32_t flow_gap(uint32_t w, const gap_par_t *g)      /* quiet first draws in front of the next scoring one */
+{
+    if (g->thr >= 0x100000000ull) return 0;
+    const uint64_t X = ((uint64_t)w << 1) | 1u;
+    const int p = 63 - __builtin_clzll(X);
+    const uint64_t M = X << (63 - p);
+    const uint32_t idx = (uint32_t)(M >> 55) & 0xFFu, r16 = (uint32_t)(M >> 39) & 0xFFFFu;
+    const uint32_t f = flow_lg[idx] + (uint32_t)(((uint64_t)(flow_lg[idx + 1] - flow_lg[idx]) * r16) >> 16);
+    const uint64_t Lu = ((uint64_t)(33 - p) << 56) - ((uint64_t)f << 24);
+    const uint64_t G = (uint64_t)(((unsigned __int128)Lu * g->R) >> 64) >> g->s;
+    return G > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)G;
+}
+
+/* mut.c:618 `c < 4 && drand48() < opt->mut_rate`, once per ACGT position outside a live deletion run: by far the most frequent draw of the walk -- and one
+ * that says "no" 999 times in 1000.  Mode B (round 6): the candidate sites of a contig are a Bernoulli(r') process over its positions, r' = ceil(r 2^32) / 2^32;
+ * restricted to a window of 256 positions it is independent of every other window, so each window [256 q, 256 q + 256) has a gap chain of its own: S_0 = G_0,
+ * S_(m+1) = S_m + 1 + G_(m+1), gap m = word m & 3 of block m >> 2 of (D_WALK_SITE, index q); position 256 q + S is a candidate for every S < 256.  (Rounds 2-5:
+ * one 16-bit uniform per position, a Philox block per eight positions -- 386 M blocks per 3.09 Gb genome, 2 ms of a 5.5 ms walk on every device that walks it.)
+ * --dump-draws: 0 for a candidate, 1 - 2^-48 otherwise (the reference only compares the draw with the rate). */
+static inline int walk_site(rng_t *r, uint32_t p, double mut_rate)
+{
+    static struct { int valid; uint32_t k0, k1, window, m, next; gap_par_t par; double rate; } st;
     r->n_draws++;
-    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    const uint32_t h = philox_halfword(r, D_WALK_SITE, 0, 0, p), l = philox_halfword(r, D_WALK_SITE_REF, 0, 0, p);
-    return rng_out(r, (double)((h << 16) | l) * 0x1p-32);
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x) < mut_rate;
+    const uint32_t q = p >> 8, in = p & 255u;
+    if (!st.valid || st.k0 != r->k0 || st.k1 != r->k1 || st.window != q || st.rate != mut_rate) {
+        st.valid = 1; st.k0 = r->k0; st.k1 = r->k1; st.window = q; st.rate = mut_rate; st.m = 0;
+        st.par = flow_gap_params(!(mut_rate > 0) ? 0 : mut_rate >= 1.0 ? 0x100000000ull : (uint64_t)ceil(mut_rate * 4294967296.0));
+        st.next = st.par.thr ? flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, D_WALK_SITE, q, 0, 0, st.m++) * 4294967296.0), &st.par) : FLOW_NEVER;
+    }
+    while (st.next < in) st.next += 1u + flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, D_WALK_SITE, q, 0, 0, st.m++) * 4294967296.0), &st.par);
+    const int hit = st.next == in;
+    rng_out(r, hit ? 0.0 : 1.0 - 0x1p-48);
+    return hit;
 }
 
 /* Deterministic natural log for x > 0 finite: the classic fdlibm/FreeBSD-msun e_log.c
@@ -431,7 +486,7 @@ static void walk_contig(const opt_t *o, rng_t *r, const seq_t *seq, hap_t *h0, h
             }
             deleting = 0; dlen = 0;
         }
-        if (c < 4 && walk_site_u(r, (uint32_t)i) < o->mut_rate) {
+        if (c < 4 && walk_site(r, (uint32_t)i, o->mut_rate)) {
             if (rng_u(r, D_WALK, (uint64_t)i, 0, 0, 2) >= o->indel_frac) { /* substitution */
                 double rr = rng_u(r, D_WALK, (uint64_t)i, 0, 0, 3);
                 uint8_t c2 = (uint8_t)((c + (uint64_t)(rr * 3.0 + 1)) & 3);
@@ -914,43 +969,6 @@ static void flow_alloc(flowbuf_t *b, int len, int F)
  * D_FLOW_EV, s = 0, 1, ..., with h = the event's position in the evolving read (pass 1) / the number of empty flows examined before it (pass 2), as before.
  * --dump-draws (replay through the unmodified reference): a first draw is handed over as 0 (scores) or 1 - 2^-48 (quiet) -- the reference only
  * compares it with e. */
-static uint64_t ilog2_fixed(uint64_t y, int fb)      /* floor(log2(y) * 2^fb) for y >= 1, fb <= 56: repeated squaring in Q1.63 */
-{
-    int p = 63 - __builtin_clzll(y);
-    uint64_t m = y << (63 - p), frac = 0;
-    for (int k = 0; k < fb; ++k) {
-        const unsigned __int128 sq = (unsigned __int128)m * m;       /* Q2.126 */
-        if ((uint64_t)(sq >> 127)) { m = (uint64_t)(sq >> 64); frac = (frac << 1) | 1u; }
-        else { m = (uint64_t)(sq >> 63); frac <<= 1; }
-    }
-    return ((uint64_t)p << fb) | frac;
-}
-static uint32_t flow_lg[257]; static int flow_lg_ready = 0;
-typedef struct { uint64_t thr, R; int s; } gap_par_t;
-static gap_par_t flow_gap_params(uint64_t thr)       /* -log2(1 - e') in Q8.56, normalised, and its reciprocal (dw_kernels.hpp flow_gap_params: the same text) */
-{
-    gap_par_t g; g.thr = thr; g.R = 0; g.s = 0;
-    if (thr == 0 || thr >= 0x100000000ull) return g;
-    if (!flow_lg_ready) { for (int i = 0; i < 256; ++i) flow_lg[i] = (uint32_t)ilog2_fixed(256u + (uint64_t)i, 32); flow_lg[256] = 0xFFFFFFFFu; flow_lg_ready = 1; }
-    const uint64_t Lq = (32ull << 56) - ilog2_fixed(0x100000000ull - thr, 56);
-    const int sh = __builtin_clzll(Lq);
-    const unsigned __int128 q = ((unsigned __int128)1 << 127) / (Lq << sh);
-    g.R = q >> 64 ? ~0ull : (uint64_t)q; g.s = 63 - sh;
-    return g;
-}
-#define FLOW_NEVER 0xFFFFFFFFu
-static uint32_t flow_gap(uint32_t w, const gap_par_t *g)      /* quiet first draws in front of the next scoring one */
-{
-    if (g->thr >= 0x100000000ull) return 0;
-    const uint64_t X = ((uint64_t)w << 1) | 1u;
-    const int p = 63 - __builtin_clzll(X);
-    const uint64_t M = X << (63 - p);
-    const uint32_t idx = (uint32_t)(M >> 55) & 0xFFu, r16 = (uint32_t)(M >> 39) & 0xFFFFu;
-    const uint32_t f = flow_lg[idx] + (uint32_t)(((uint64_t)(flow_lg[idx + 1] - flow_lg[idx]) * r16) >> 16);
-    const uint64_t Lu = ((uint64_t)(33 - p) << 56) - ((uint64_t)f << 24);
-    const uint64_t G = (uint64_t)(((unsigned __int128)Lu * g->R) >> 64) >> g->s;
-    return G > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)G;
-}
 typedef struct { int init; uint32_t m, next; gap_par_t par; } gapstate_t;
 /* does first draw number `ordinal` (0, 1, 2, ... in the order the reference makes them) of the pass score? */
 static inline int flow_first(rng_t *r, uint32_t fdom, uint64_t idx, uint32_t att, uint32_t ordinal, double e, gapstate_t *gs)
