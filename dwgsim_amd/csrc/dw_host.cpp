@@ -1439,6 +1439,17 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     }
     a.lds_words = (a.cap + 7) / 8;
     a.flow = c->d_flow; a.flow_len = (int32_t)c->flow.size();
+    for (int j = 0; j < 2; ++j) {      // Illumina / SOLiD: the gap chain of a read end's error sites runs at the largest threshold of its ramp (dw_simulate.hip; thresholds as dwgsim_hip_create made them)
+        const int n = c->prm.length[j];
+        uint64_t tmax = 0, tmin = ~0ull;
+        for (int i = 0; i < n; ++i) {
+            const double ei = c->prm.e_start[j] + c->e_by[j] * i;
+            const uint64_t t = !(ei > 0) ? 0 : ei >= 1.0 ? 0x100000000ull : (uint64_t)ceil(ei * 4294967296.0);
+            tmax = std::max(tmax, t); tmin = std::min(tmin, t);
+        }
+        a.err_thr_max[j] = n > 0 ? tmax : 0; a.err_ramp[j] = (n > 0 && tmin != tmax) ? 1 : 0;
+        flow_gap_params(a.err_thr_max[j], &a.err_gap_r[j], &a.err_gap_s[j]);
+    }
     for (int j = 0; j < 2; ++j) {      // Ion Torrent: the gap draws of the flow model, from the read end's (uniform) threshold as dwgsim_hip_create made it (thr[0])
         const double e0 = c->prm.e_start[j];
         flow_gap_params(!(e0 > 0) ? 0 : e0 >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e0 * 4294967296.0), &a.flow_gap_r[j], &a.flow_gap_s[j]);

@@ -27,7 +27,7 @@ constexpr int SIM_FIFO_BYTES_WIDE = 72;       // ... with 64-byte bursts (second
 // dynamic LDS of a k_simulate block: [words_per_lane][lanes] staged bases | the two base-quality tables | [lanes] text FIFOs (16-byte aligned)
 inline size_t sim_lds_bytes(size_t words_per_lane, size_t lanes, size_t qb_words, bool fifo, size_t fifo_bytes = SIM_FIFO_BYTES) { return ((words_per_lane * lanes + 2 * qb_words + 3) & ~(size_t)3) * 4 + (fifo ? lanes * fifo_bytes : 0); }
 // blocks of SIM_THREADS lanes a CU holds at this much dynamic LDS (160 KB per CU in granules of 1280 bytes, ~0.6 KB static per block), at most `cap` (the register limit)
-inline int sim_blocks_per_cu(size_t dyn_lds, int cap) { const size_t per = (dyn_lds + 640 + 1279) / 1280 * 1280; const int b = (int)(163840 / per); return b < cap ? b : cap; }
+inline int sim_blocks_per_cu(size_t dyn_lds, int cap) { const size_t per = (dyn_lds + 1700 + 1279) / 1280 * 1280;      /* (+ the kernel's static LDS: scan scratch, name lines, the log2 table of the gap draws) */ const int b = (int)(163840 / per); return b < cap ? b : cap; }
 constexpr size_t SIM_LDS_BUDGET = 150 * 1024; // dynamic LDS a block may ask for (160 KB per CU minus the static part)
 constexpr int SCAN_POS_PER_THREAD = 16;  // k_site_scan / k_collect: 16 positions (one 16-B load) per thread
 constexpr int SCAN_THREADS = 256;
@@ -205,6 +205,7 @@ struct SimArgs {
     int32_t flow_slots;            // ... slots per XCD (8 x flow_slots slots in flow_scratch)
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes, followed by the log2 table of the gap draws (FLOW_LG_ENTRIES words)
     uint64_t flow_gap_r[2]; int32_t flow_gap_s[2];      // Ion Torrent, per read end: flow_gap_params of its threshold e_thr[j][0]
+    uint64_t err_thr_max[2], err_gap_r[2]; int32_t err_gap_s[2], err_ramp[2];      // Illumina / SOLiD, per read end: the largest threshold of the error ramp, flow_gap_params of it, and whether any position's threshold is lower (those sites are thinned)
 };
 
 } // namespace dw

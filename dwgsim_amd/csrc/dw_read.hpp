@@ -76,7 +76,7 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
     auto emit = [&](uint32_t v) {                      // one base from the per-cell logic
         if (strand) v = v < 4 ? 3 - v : 4;             // dwgsim.c:150-152
         r.num_n += (v == 4);                            // dwgsim.c:824-831
-        accw |= v << (4 * na); ++k;
+        accw |= (v > 4u ? 4u : v) << (4 * na); ++k;     // (a '-' cell, code 5: not an N for the filter above, clamped as the error loop does: `if (c >= 4) c = 4`, dwgsim.c:235)
         if (++na == 8) { sink.put((k >> 3) - 1, accw, 8); accw = 0; na = 0; }
     };
     const uint32_t *const vw = reinterpret_cast<const uint32_t *>(h.view);

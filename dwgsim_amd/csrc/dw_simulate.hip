@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][32];          // "@[prefix_]contig" and "@[prefix_]rand", first 128 bytes
     __shared__ FlowTables s_ft;                  // Ion Torrent: the flow order and its look-up tables (dw_read.hpp fill_flow_tables)
+    __shared__ uint32_t s_lg[FLOW_LG_ENTRIES];   // Illumina / SOLiD: the log2 table the gaps between error sites interpolate in (dw_common.hpp geom_gap); Ion Torrent has it in s_ft
     constexpr int nthr = NTHR, PPB = NTHR / LPP, nwaves = NTHR / 64;      // PPB pairs per block
     // where a lane's packed bases are staged: LDS (Illumina / SOLiD reads up to ~1 180 bases, 256-lane blocks), or a SCRATCH SLOT in global memory --
     // the Ion Torrent read buffers, and every read too long for that (the one-wave blocks): staged in LDS a 2 000-base read left room for two waves
@@ -507,6 +508,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (ION && tid < 64) s_ft.flow[tid] = a.flow[tid];
+    if (!ION && SPLIT != 2) for (int q = tid; q < FLOW_LG_ENTRIES; q += nthr) s_lg[q] = reinterpret_cast<const uint32_t *>(a.flow + 64)[q];
     // base-quality characters of both read ends (dwgsim.c:906-910), packed, behind the lanes' staging area
     const size_t stage_words = SPLIT == 2 ? 0 : DT == 3 ? (size_t)(a.lds_words + a.flow_stack_words) : DT == 2 ? (size_t)a.flow_stack_words : GS ? 0 : (size_t)a.lds_words;      // (the second half of the two-kernel form reads its bases from HBM)
     uint32_t *const s_qb = dyn_lds + stage_words * nthr;
@@ -557,6 +559,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     const int nw = (s + 7) >> 3;
     int32_t err_first = 0;                      // SOLiD: an error on the first colour (n_err_first, dwgsim.c:240)
     uint32_t rrank = 0, rtot = 0;
+    uint32_t rb[4] = {0, 0, 0, 0};              // the words of the Philox block in use (error sites / random-read bases)
     if (H != 2) {
     while (__ballot(!done)) {
         bool ok = true;
@@ -610,68 +613,75 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
             flow_reversed = (j ? pd.strand1 : pd.strand0) != 0;     // the read is turned back while it is written (dwgsim.c:408-414)
         }
     }
-    if (ION) {                                  // a random read (dwgsim.c:999-1001): base i = (int)(u * 4.0) & 3 from halfword i of the D_BASE0 stream, at positions 0 .. s - 1 of the buffer
-        if (valid && is_rand) for (int w = 0; w * 8 < s; ++w) {
-            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)w);
-            uint32_t pairs = ((q0.x >> 14) & 3u) | ((q0.x >> 30) << 2) | (((q0.y >> 14) & 3u) << 4) | ((q0.y >> 30) << 6) | (((q0.z >> 14) & 3u) << 8) | ((q0.z >> 30) << 10) | (((q0.w >> 14) & 3u) << 12) | ((q0.w >> 30) << 14);
-            const int rem = s - 8 * w;
-            if (rem < 8) pairs &= (1u << (2 * rem)) - 1u;
-            reinterpret_cast<uint16_t *>(lds + (w >> 1) * nthr)[w & 1] = (uint16_t)pairs;
+    if (ION) {                                  // a random read (dwgsim.c:999-1001): base i = the 2-bit field i of the D_BASE0 stream (64 bases per Philox block), at positions 0 .. s - 1 of the buffer
+        if (valid && is_rand) for (int w = 0; w * 16 < s; ++w) {
+            if ((w & 3) == 0) { const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(w >> 2)); rb[0] = q0.x; rb[1] = q0.y; rb[2] = q0.z; rb[3] = q0.w; }
+            uint32_t pairs = (w & 2) ? ((w & 1) ? rb[3] : rb[2]) : ((w & 1) ? rb[1] : rb[0]);
+            const int rem = s - 16 * w;
+            if (rem < 16) pairs &= (1u << (2 * rem)) - 1u;
+            lds[w * nthr] = pairs;
         }
     } else
     if (valid && !(probe::off(4))) {
-        // eight bases (one staged word) at a time: nibble-parallel N clamp / colour conversion, eight 32-bit threshold compares
-        const uint32_t *thr = j ? a.e_thr32[1] : a.e_thr32[0];
-        uint32_t prev_base = 0;                 // SOLiD: previous base in base space; the adaptor counts as 'A' (dwgsim.c:849)
-        for (int w = 0; w < nw; ++w) {
-            uint4 ta = make_uint4(0, 0, 0, 0), tb = ta;
-            if (!is_rand) { ta = *reinterpret_cast<const uint4 *>(thr + 8 * w); tb = *reinterpret_cast<const uint4 *>(thr + 8 * w + 4); }
-            // 16-bit draws, eight per Philox block: halfword b of block w is the HIGH half of base 8w + b's 32-bit uniform, moved to the top of a word
-            const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)w);
-            const uint32_t hw[8] = {q0.x << 16, q0.x & 0xFFFF0000u, q0.y << 16, q0.y & 0xFFFF0000u, q0.z << 16, q0.z & 0xFFFF0000u, q0.w << 16, q0.w & 0xFFFF0000u};
-            const int rem = s - 8 * w;
-            const uint32_t live = rem >= 8 ? 0xFFFFFFFFu : ((1u << (4 * rem)) - 1u);      // nibbles of bases i < s
-            uint32_t word;
-            if (is_rand) {                                                      // random read: base = (int)(u * 4.0) & 3 (dwgsim.c:999-1001)
-                word = 0;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) word |= (hw[b] >> 30) << (4 * b);
-            } else word = lds[w * nthr];
-            if (DT == 1) {                                                      // colour = __gf_add(previous base, base): dwgsim.h:6, dwgsim.c:845-858 / :1022-1032
-                const uint32_t prevw = (word << 4) | prev_base;
-                prev_base = word >> 28;
-                const uint32_t n = (word | prevw) & 0x44444444u;                // either base is not ACGT -> colour 4
-                word = ((word ^ prevw) & 0x33333333u & ~((n >> 1) | (n >> 2))) | n;
-            } else {
-                const uint32_t n4 = word & 0x44444444u;                         // if (c >= 4) c = 4 (dwgsim.c:235)
-                word &= ~((n4 >> 1) | (n4 >> 2));
-            }
-            if (!is_rand) {                                                     // drand48() < e[i]  <=>  u32 < thr[i]; an error marks bit 3 of the nibble
-                const uint32_t t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-                // u32 = high half | low half.  With the low half taken as 0: (high < thr) is the answer unless the high halves of u32 and thr are
-                // equal -- probability 2^-16 per base -- and only then is the low half drawn (halfword b of the D_BASE_REF0 stream's block w)
-                uint32_t hits = 0, closest = 0xFFFFFFFFu;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) { hits |= (hw[b] < t[b]) ? (8u << (4 * b)) : 0u; const uint32_t x = hw[b] ^ t[b]; closest = x < closest ? x : closest; }
-                if (closest < 0x10000u) {
-                    const U4 r0 = rng_block(key, D_BASE_REF0 + (uint32_t)j, ii, att, 0, (uint32_t)w);
-                    const uint32_t lw[8] = {r0.x & 0xFFFFu, r0.x >> 16, r0.y & 0xFFFFu, r0.y >> 16, r0.z & 0xFFFFu, r0.z >> 16, r0.w & 0xFFFFu, r0.w >> 16};
-                    hits = 0;
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) hits |= ((hw[b] | lw[b]) < t[b]) ? (8u << (4 * b)) : 0u;
+        if (is_rand) {                           // random read: base i = the 2-bit field i of the D_BASE0 stream: sixteen bits = the eight bases of a staged word
+            uint32_t prev_base = 0;
+            for (int w = 0; w < nw; ++w) {
+                if ((w & 7) == 0) { const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, (uint32_t)(w >> 3)); rb[0] = q0.x; rb[1] = q0.y; rb[2] = q0.z; rb[3] = q0.w; }
+                const uint32_t wd = ((w >> 1) & 2) ? (((w >> 1) & 1) ? rb[3] : rb[2]) : (((w >> 1) & 1) ? rb[1] : rb[0]);
+                uint32_t word = pairs_to_nibbles((wd >> (16 * (w & 1))) & 0xFFFFu);
+                const int rem = s - 8 * w;
+                const uint32_t live = rem >= 8 ? 0xFFFFFFFFu : ((1u << (4 * rem)) - 1u);
+                if (DT == 1) {                                                      // colour = __gf_add(previous base, base): dwgsim.h:6, dwgsim.c:1022-1032
+                    const uint32_t prevw = (word << 4) | prev_base;
+                    prev_base = word >> 28;
+                    word = (word ^ prevw) & 0x33333333u;
                 }
-                if (a.e_full) {
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) hits |= (t[b] == 0xFFFFFFFFu) ? (8u << (4 * b)) : 0u;
-                }
-                hits &= ~((word & 0x44444444u) << 1) & live;                    // N bases / colours take no error
-                n_err += __popc(hits);
-                if (DT == 1 && w == 0) err_first = (int32_t)((hits >> 3) & 1u);
-                word |= hits;
+                lds[w * nthr] = word & live;
             }
-            lds[w * nthr] = word & live;
-        }
-        if (!is_rand) {
+        } else {
+            if (DT == 1) {                       // SOLiD: bases -> colours (dwgsim.c:845-858): colour = previous base ^ base, 4 if either is not ACGT; the adaptor counts as 'A' (:849)
+                uint32_t prev_base = 0;
+                for (int w = 0; w < nw; ++w) {
+                    uint32_t word = lds[w * nthr];
+                    const uint32_t prevw = (word << 4) | prev_base;
+                    prev_base = word >> 28;
+                    const uint32_t n = (word | prevw) & 0x44444444u;
+                    word = ((word ^ prevw) & 0x33333333u & ~((n >> 1) | (n >> 2))) | n;
+                    const int rem = s - 8 * w;
+                    lds[w * nthr] = rem >= 8 ? word : word & ((1u << (4 * rem)) - 1u);
+                }
+            }
+            // error sites (dwgsim.c:237 `drand48() < e[i]`, once per base that is not N): the gap chain of the read end at the largest rate of its ramp, thinned
+            // where the position's own rate is lower (dw_common.hpp D_BASE0 / D_BASE_REF0): a Philox block per FOUR errors -- rounds 2-5: per eight BASES.
+            // The loop's trip count differs from lane to lane (a read end has ~3 errors); its gap index m does not, so the lanes draw their Philox blocks together
+            const uint64_t tmax = j ? a.err_thr_max[1] : a.err_thr_max[0], gR = j ? a.err_gap_r[1] : a.err_gap_r[0];
+            const int gS = j ? a.err_gap_s[1] : a.err_gap_s[0]; const bool ramp = (j ? a.err_ramp[1] : a.err_ramp[0]) != 0;
+            const uint64_t *thr64 = j ? a.e_thr[1] : a.e_thr[0];
+            if (tmax) {
+                uint32_t m = 0, S = 0, tw[4] = {0, 0, 0, 0};
+                for (;;) {                                                                  // (a per-lane loop: no wave operation inside)
+                    if ((m & 3u) == 0u) {
+                        const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, m >> 2); rb[0] = q0.x; rb[1] = q0.y; rb[2] = q0.z; rb[3] = q0.w;
+                        if (ramp) { const U4 q1 = rng_block(key, D_BASE_REF0 + (uint32_t)j, ii, att, 0, m >> 2); tw[0] = q1.x; tw[1] = q1.y; tw[2] = q1.z; tw[3] = q1.w; }
+                    }
+                    const uint32_t k4 = m & 3u;
+                    const uint32_t gw = (k4 & 2u) ? ((k4 & 1u) ? rb[3] : rb[2]) : ((k4 & 1u) ? rb[1] : rb[0]);
+                    const uint32_t G = tmax >= 0x100000000ull ? 0u : geom_gap(gw, s_lg, gR, gS);
+                    S = m ? S + 1u + G : G;                                                 // site m of the chain
+                    if (S >= (uint32_t)s) break;
+                    const int w = (int)(S >> 3), sh = 4 * (int)(S & 7u);
+                    const uint32_t word = lds[w * nthr];
+                    bool hit = ((word >> sh) & 4u) == 0u;                                    // N bases / colour 4 take no error
+                    if (ramp && hit) {                                                      // thinning: kept with probability thr[S] / thr_max (site m's own word)
+                        const uint64_t ti = thr64[S];
+                        const uint32_t w2 = (k4 & 2u) ? ((k4 & 1u) ? tw[3] : tw[2]) : ((k4 & 1u) ? tw[1] : tw[0]);
+                        hit = ti >= tmax || (uint64_t)w2 * tmax < (ti << 32);
+                    }
+                    if (hit) { lds[w * nthr] = word | (8u << sh); ++n_err; if (DT == 1 && S == 0u) err_first = 1; }
+                    ++m;
+                }
+            }
+            // the substituted base of every marked base (dwgsim.c:238)
             int w = 0; uint32_t pend = 0;
             for (;;) {
                 while (pend == 0 && w < nw) { pend = lds[w * nthr] & 0x88888888u; if (!pend) ++w; }

@@ -59,8 +59,8 @@ enum {
     D_PAIR = 4,        /* index = ii; slot 0 rand-read test, 1 haplotype, 2 strand */
     D_PLACE = 5,       /* index = ii; slot t = position uniform of placement try t */
     D_PLACE_NORM = 6,  /* index = ii; block t = polar tries of placement try t */
-    D_BASE0 = 8,       /* +j; index = ii; 16-bit draws, eight per block: halfword i (block i >> 3, word (i & 7) >> 1, low half first) = the HIGH half of
-                          the 32-bit uniform of base i (error test / random-read base); the low half is halfword i of D_BASE_REF0 + j */
+    D_BASE0 = 8,       /* +j; index = ii; genomic reads: NARROW words, word m = the m-th GAP between error sites of the read end (base_error_sites); random
+                          reads: 2-bit field i = base i (random_base) */
     D_QUAL0 = 10,      /* +j; index = ii; 16-BIT: the sequential stream of polar tries of the read's quality normals -- try t = the low (v1) and the high
                           (v2) half of word t & 3 of block t >> 2; every accepted try delivers two normals (v2*fac, then the cached v1*fac) */
     D_FLOW0 = 12,      /* +j; index = ii; generate_errors_flows: NARROW words, word m = the m-th GAP (quiet first draws in front of the m-th scoring
@@ -173,8 +173,7 @@ static inline double rng_u32(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att,
     return rng_out(r, oracle_philox_uniform32(r->k0, r->k1, dom, idx, att, retry, slot));
 }
 
-/* The uniform of base i of read end j (error test dwgsim.c:237, random-read base :1000).  Mode B: 32 bits, u = ((h << 16) | l) * 2^-32 with
- * h = halfword i of the D_BASE0 + j stream and l = halfword i of the D_BASE_REF0 + j stream (eight 16-bit draws per Philox block). */
+/* (the per-base draws of a read end -- error test dwgsim.c:237, random-read base :1000 -- are defined behind the gap functions: base_error_sites, random_base) */
 static inline uint32_t philox_halfword(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att, uint32_t i)
 {
     uint32_t ctr[4], key[2], w[4];
@@ -189,13 +188,6 @@ static inline double rng_u16(rng_t *r, uint32_t dom, uint64_t idx, uint32_t att,
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
     return rng_out(r, (double)philox_halfword(r, dom, idx, att, i) * 0x1p-16);
-}
-static inline double rng_base_u(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
-{
-    r->n_draws++;
-    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x);
-    const uint32_t h = philox_halfword(r, D_BASE0 + (uint32_t)j, idx, att, i), l = philox_halfword(r, D_BASE_REF0 + (uint32_t)j, idx, att, i);
-    return rng_out(r, (double)((h << 16) | l) * 0x1p-32);
 }
 
 /* ---- geometric gaps in integer arithmetic (round 6): shared by the site draws of the walk (walk_site below) and the first draws of the flow model
@@ -261,6 +253,56 @@ static inline int walk_site(rng_t *r, uint32_t p, double mut_rate)
     const int hit = st.next == in;
     rng_out(r, hit ? 0.0 : 1.0 - 0x1p-48);
     return hit;
+}
+
+/* ---- the per-base draws of read end j (round 6).
+ * Sequencing errors (dwgsim.c:233-244): `drand48() < e.start + e.by * i`, once per base that is not N -- 98 % of them answer no.  Mode B draws the error SITES
+ * of the read end as a gap chain over its positions 0 .. s-1 at the LARGEST rate of the ramp, thr_max = max_i ceil(e_i 2^32): gap m = word m & 3 of block
+ * m >> 2 of (D_BASE0 + j, pair, attempt), sites S_0 = G_0, S_(m+1) = S_m + 1 + G_(m+1) while S_m < s.  Where the position's own threshold thr_i is below
+ * thr_max (a ramp, -e 0.001-0.05) site m is THINNED: kept iff w2 * thr_max < thr_i * 2^32 with w2 = word m & 3 of block m >> 2 of (D_BASE_REF0 + j, ...) --
+ * probability thr_i / thr_max, so that position i errs with probability thr_i / 2^32 as before, independently.  A site on an N base takes no error (the
+ * reference makes no draw there): Bernoulli thinning again.  (Rounds 2-5: a 16 + 16 bit uniform per base, a Philox block per eight bases: 19 blocks per
+ * 150-base read end where one or two do.)  --dump-draws: 0 for an error, 1 - 2^-48 otherwise.
+ * Random reads (dwgsim.c:999-1001): base i = (int)(drand48() * 4) & 3 = the 2-bit field i of the same stream: bits 2 (i & 15) of word (i >> 4) & 3 of block
+ * i >> 6 -- 64 bases per Philox block (rounds 2-5: eight); --dump-draws: (b + 0.5) / 4. ---- */
+static uint64_t err_thr(double e) { return !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0); }
+static void base_error_sites(rng_t *r, int j, uint64_t idx, uint32_t att, int s, double e_start, double e_by, uint8_t *site)      /* site[0 .. s): 1 = this base errs unless it is N */
+{
+    memset(site, 0, (size_t)s);
+    if (r->mode == RNG_DRAND48 || s <= 0) return;
+    uint64_t tmax = 0;
+    for (int i = 0; i < s; ++i) { const uint64_t t = err_thr(e_start + e_by * i); if (t > tmax) tmax = t; }
+    if (tmax == 0) return;
+    const gap_par_t par = flow_gap_params(tmax);
+    uint32_t m = 0;
+    for (uint64_t S = flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, D_BASE0 + (uint32_t)j, idx, att, 0, 0) * 4294967296.0), &par); S < (uint64_t)s; ) {
+        const uint64_t ti = err_thr(e_start + e_by * (double)(int)S);
+        int keep = 1;
+        if (ti < tmax) { const uint64_t w2 = (uint64_t)(oracle_philox_uniform32(r->k0, r->k1, D_BASE_REF0 + (uint32_t)j, idx, att, 0, m) * 4294967296.0); keep = w2 * tmax < (ti << 32); }
+        if (keep) site[S] = 1;
+        ++m;
+        S += 1u + flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, D_BASE0 + (uint32_t)j, idx, att, 0, m) * 4294967296.0), &par);
+    }
+}
+/* the error test of a base that is not N, in the order the reference makes them */
+static inline int base_errs(rng_t *r, const uint8_t *site, int i, double e_i)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x) < e_i;
+    rng_out(r, site[i] ? 0.0 : 1.0 - 0x1p-48);
+    return site[i];
+}
+static inline uint8_t random_base(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
+{
+    r->n_draws++;
+    if (r->mode == RNG_DRAND48) return (uint8_t)((int)(oracle_drand48_next(&r->x) * 4.0) & 3);
+    uint32_t ctr[4], key[2], w[4];
+    ctr[0] = (uint32_t)idx; ctr[1] = (uint32_t)((idx >> 32) & 0xFFFFu); ctr[2] = ((D_BASE0 + (uint32_t)j) << 24) | (att & 0xFFFFFFu); ctr[3] = i >> 6;
+    key[0] = r->k0; key[1] = r->k1;
+    oracle_philox4x32_10(ctr, key, w);
+    const uint8_t b = (uint8_t)((w[(i >> 4) & 3] >> (2 * (i & 15))) & 3u);
+    rng_out(r, ((double)b + 0.5) * 0.25);
+    return b;
 }
 
 /* Deterministic natural log for x > 0 finite: the classic fdlibm/FreeBSD-msun e_log.c
@@ -1334,6 +1376,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
     flowbuf_t tb[2];
     for (int j = 0; j < 2; ++j) flow_alloc(&tb[j], lmax, o->flow_order_len);
     int qcap = lmax; char *qstr = calloc((size_t)qcap + 1, 1);
+    int site_cap = lmax > 0 ? lmax : 1; uint8_t *err_site = calloc((size_t)site_cap, 1);      /* error sites of a read end (base_error_sites) */
     int size[2] = { o->length[0], o->length[1] };
 
     /* pass 1: contig lengths and the VCF header, dwgsim.c:465-492 */
@@ -1513,10 +1556,12 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                         }
                     } else for (int j = 0; j < 2; ++j) if (0 < s[j]) { /* :233-244, :866-881 */
                         int i = strand[j] ? s[j] - 1 : 0, step = strand[j] ? -1 : 1;
+                        if (site_cap < s[j]) { site_cap = s[j]; err_site = realloc(err_site, (size_t)site_cap); }
+                        base_error_sites(r, j, ii, att, s[j], o->e[j].start, o->e[j].by, err_site);
                         for (; 0 <= i && i < s[j]; i += step) {
                             uint8_t c = tb[j].seq[i];
                             if (c >= 4) c = 4;
-                            else if (rng_base_u(r, j, ii, att, (uint32_t)i) < o->e[j].start + o->e[j].by * i) {
+                            else if (base_errs(r, err_site, i, o->e[j].start + o->e[j].by * i)) {
                                 c = (uint8_t)((c + (uint64_t)(rng_u32(r, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 3.0 + 1)) & 3);
                                 ++n_err[j];
                                 if (0 == i) ++n_err_first[j];
@@ -1539,7 +1584,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                     const int in_win = o->emit_count < 0 || ((int64_t)ii >= o->emit_first && (int64_t)ii < o->emit_first + o->emit_count);
                     for (int j = 0; j < 2 && in_win; ++j) {
                         if (s[j] <= 0) continue;
-                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = (uint8_t)((int)(rng_base_u(r, j, ii, att, (uint32_t)i) * 4.0) & 3);
+                        for (int i = 0; i < s[j]; ++i) tb[j].seq[i] = random_base(r, j, ii, att, (uint32_t)i);
                         make_quals(o, r, j, ii, att, s[j], qstr);
                         if (SOLID == o->data_type) to_colors(tb[j].seq, s[j]);
                         emit_read(o, out, j, "rand", 0, 0, 0, 0, 1, 1, zero6, zero6, rand_ii, tb[j].seq, s[j], qstr);
