@@ -41,7 +41,7 @@ ION_FLAGS = "-z 13 -c 2 -f TACGTACGTCTGAGCATCGATCGATGTACAGC -1 400 -2 0 -C 50 -e
 ALGO_BYTES_PER_PAIR_2x150 = 863.0  # 713 B FASTQ written + 150 B haplotype bases read at 4 bit/base
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "ecoli_like": ("S2 with a bacterial genome's composition", 1), "chr20_like": ("S3 with a human chromosome's composition", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3), "assembly5k": ("5000 scaffolds, N50 ~ 50 kb", 3)}
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r05_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r06_counters.json")
 STRONG_GROUP_BP = (1 << 31) - (1 << 24)      # whole-genome groups for the strong-scaling job: a group's coordinate space holds < 2^31 cells (dw_host.cpp dwgsim_hip_add_contigs): GRCh38 = 2 groups, 2 walk chains
 MAX_LAUNCH_PAIRS = 1 << 23         # pairs per launch at most (a launch's text buffers are sized for it: 6 GB at 2 x 150 bp)
 
@@ -635,7 +635,7 @@ def main():
             algo_per_pair = text_per_pair + (params.length[0] + params.length[1]) / 2.0
             algo_note = f"{algo_per_pair:.0f} algorithmic B per pair/read = {text_per_pair:.1f} B of FASTQ written (measured) + {(params.length[0] + params.length[1]) / 2:.0f} B of haplotype bases read at 4 bit/base"
         achieved = algo_per_pair * pairs_per_launch / (sim_ms_launch * 1e-3) / 1e9 if sim_ms_launch > 0 else 0.0
-        # counter evidence (profiles/r05_counters.json, made by tools/make_counters_json.py from rocprofv3 PMC passes) is quoted only when it was
+        # counter evidence (profiles/r06_counters.json, made by tools/make_counters_json.py from rocprofv3 PMC passes) is quoted only when it was
         # taken on exactly the library that is being timed now
         lib_sha = file_sha256(api.LIB_PATH)
         prof, prof_note = {}, None

@@ -33,8 +33,9 @@ enum : uint32_t {
     D_PLACE = 5,        // slot t = position uniform of placement try t (dwgsim.c:671)
     D_PLACE_NORM = 6,   // block t, retry r = polar tries of the insert-size normal of try t (dwgsim.c:657)
     // NARROW domains: a draw is one 32-bit word w of a block, u = w * 2^-32, four draws per Philox block
-    D_BASE0 = 8,        // +read end.  16-bit draws, eight per block: halfword i (block i>>3, word (i&7)>>1, low half first) = the HIGH half of the 32-bit
-                        // uniform of base i: error test (dwgsim.c:237) or random-read base (:1000); the low half is halfword i of D_BASE_REF0
+    D_BASE0 = 8,        // +read end.  Genomic reads: NARROW words, word m = the m-th GAP between error sites of the read end (dwgsim.c:237 `drand48() < e[i]`): sites
+                        // S_0 = G_0, S_(m+1) = S_m + 1 + G_(m+1) < s, the chain at the LARGEST threshold of the ramp (geom_gap below; dw_simulate.hip).
+                        // Random reads (:1000): base i = the 2-bit field i of the stream (bits 2 (i & 15) of word (i >> 4) & 3 of block i >> 6)
     D_QUAL0 = 10,       // +read end.  the sequential stream of polar tries of the read's quality normals (dwgsim.c:912, :156-175), 16-BIT uniforms: try t =
                         // the two halves of word t & 3 of block t >> 2 (low half v1, high half v2); every accepted try delivers two normals (v2*fac,
                         // then the cached v1*fac)
@@ -46,8 +47,8 @@ enum : uint32_t {
     D_FLOW_PASS2 = 8,   // added to D_FLOW0 / D_CALIB (+read end) for the second pass of the flow model (domains 20-23)
     D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
     D_SUB0 = 16,        // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
-    D_BASE_REF0 = 24    // +read end.  halfword i = the LOW half of base i's uniform; it decides u < e only when the high halves of u and e agree
-                        // (probability 2^-16), so it is drawn lazily
+    D_BASE_REF0 = 24    // +read end.  word m = the THINNING draw of error site m where the position's threshold thr_i is below the ramp's largest: the site is kept
+                        // iff w * thr_max < thr_i * 2^32 (probability thr_i / thr_max); not drawn for a constant error rate
 };
 
 struct U4 { uint32_t x, y, z, w; };

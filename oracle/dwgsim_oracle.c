@@ -72,8 +72,7 @@ enum {
     D_MUTIN_BASE = 19, /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
     D_FLOW_REF = 32,   /* (rounds 2-5: the low halves of the per-event first uniforms; unused since the first draws are drawn as gaps) */
     D_FLOW_EV = 64,    /* added to a flow-model domain: the private stream of event h -- draw s = word s & 3 of the block (retry s >> 2, block h) */
-    D_BASE_REF0 = 24   /* +j; index = ii; halfword i = the LOW half of the 32-bit uniform of base i (it only matters when the high half alone
-                          does not decide u < e, i.e. with probability 2^-16: the kernels draw it lazily) */
+    D_BASE_REF0 = 24   /* +j; index = ii; word m = the thinning draw of error site m on a ramp (base_error_sites) */
 };
 
 typedef struct {
