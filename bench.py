@@ -365,7 +365,13 @@ def main():
     lib = api.load()
     numa = bind_to_device_node(lib, dev)      # this rank's host thread (and what it page-locks) on the cores of its GPU's NUMA node, as the job level's workers are (dw_job.cpp)
     dist = None
+    json_out = sys.stdout
     if world > 1:
+        # gloo reports its connections on the C library's stdout ("[Gloo] Rank 0 is connected to 1 peer ranks"): file descriptor 1 goes to stderr for the
+        # run, and the ONE JSON line is written to what was stdout
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("gloo")          # host-side exchange of integers; no RCCL on this path
 
@@ -704,7 +710,7 @@ def main():
             for ci, (name, arr) in enumerate(g38):
                 npairs += max(api.pairs_for_contig(params, len(arr), tl, ci == len(g38) - 1, npairs, lib), 0)
             out["end_to_end_genome"] = end_to_end_leg(g38, flags, npairs, fai=True, null_sink=True)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if ctx is not None:
         ctx.close()
     if dist is not None:

@@ -202,6 +202,14 @@ DW_DEV uint64_t status_load(uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_
 
 // Exclusive prefix of `aggregate` over logical blocks 0..t-1 (+ base).  Called by one whole wave;
 // logical block ids come from an atomic ticket, so every predecessor has already started.
+// A hop looks at LB_W x 64 predecessors.  Round 6 tried wider hops on the theory that the 0.8 ms a 2 x 150 launch spends at its look-backs (a look-back that
+// never waits: 5.34 -> 4.54 ms, also without a single retry in the batch) are the dependent round trips of the hops: 128 / 256 / 512 predecessors per hop
+// make the launch SLOWER (1 238 -> 1 201 / 1 143 / 1 070 M pairs/s, profiles/r06_bench_lines_final.txt): more polling traffic on the same words, no fewer
+// waits -- the time is spent waiting for predecessors to publish, not hopping.  LB_W stays 1.
+#ifndef DW_LB_W
+#define DW_LB_W 1
+#endif
+constexpr int LB_W = DW_LB_W;
 DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, uint64_t base)
 {
     const int lane = lane_id();
@@ -210,14 +218,27 @@ DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, 
     uint64_t excl = 0;
     int64_t k = (int64_t)t - 1;
     for (;;) {
-        const int64_t idx = k - lane;
-        uint64_t v = ST_PREFIX;             // below block 0: an empty prefix
-        if (idx >= 0) { do { v = status_load(&status[idx]); if (probe::off(2048) && (v >> 62) == 0) v = ST_PREFIX; if ((v >> 62) == 0) __builtin_amdgcn_s_sleep(2); } while ((v >> 62) == 0); }      // (probe 2048: a look-back that never waits -- garbage offsets, analysis only)
-        const uint64_t pm = __ballot((v >> 62) == 2);
+        // this lane's LB_W predecessors, nearest first: k - lane * LB_W - w
+        uint64_t v[LB_W];
+#pragma unroll
+        for (int w = 0; w < LB_W; ++w) {
+            const int64_t idx = k - (int64_t)lane * LB_W - w;
+            v[w] = idx >= 0 ? status_load(&status[idx]) : ST_PREFIX;                      // below block 0: an empty prefix
+        }
+#pragma unroll
+        for (int w = 0; w < LB_W; ++w) {
+            const int64_t idx = k - (int64_t)lane * LB_W - w;
+            if (probe::off(2048) && (v[w] >> 62) == 0) v[w] = ST_PREFIX;                  // (probe 2048: a look-back that never waits -- garbage offsets, analysis only)
+            while ((v[w] >> 62) == 0) { __builtin_amdgcn_s_sleep(2); v[w] = status_load(&status[idx]); }
+        }
+        uint64_t mine = 0; bool have = false;                                            // the values up to and including this lane's nearest PREFIX
+#pragma unroll
+        for (int w = 0; w < LB_W; ++w) { if (!have) mine += v[w] & ST_VAL; have = have || (v[w] >> 62) == 2; }
+        const uint64_t pm = __ballot(have);
         const int first = pm ? (__ffsll((unsigned long long)pm) - 1) : 64;
-        excl += wave_sum_u64(lane <= first ? (v & ST_VAL) : 0);
+        excl += wave_sum_u64(lane <= first ? mine : 0);
         if (pm) break;
-        k -= 64;
+        k -= 64 * LB_W;
     }
     if (lane == 0) status_store(&status[t], ST_PREFIX | ((excl + aggregate) & ST_VAL));
     return excl;
