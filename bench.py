@@ -43,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 WORKLOADS = {"ecoli": ("S2", 1), "chr20": ("S3", 2), "ecoli_like": ("S2 with a bacterial genome's composition", 1), "chr20_like": ("S3 with a human chromosome's composition", 2), "grch38": ("S4", 3), "grch38_mini": ("S4/64", 3), "assembly5k": ("5000 scaffolds, N50 ~ 50 kb", 3)}
 COUNTERS_JSON = os.path.join(ROOT, "profiles", "r06_counters.json")
 STRONG_GROUP_BP = (1 << 31) - (1 << 24)      # whole-genome groups for the strong-scaling job: a group's coordinate space holds < 2^31 cells (dw_host.cpp dwgsim_hip_add_contigs): GRCh38 = 2 groups, 2 walk chains
-MAX_LAUNCH_PAIRS = 1 << 23         # pairs per launch at most (a launch's text buffers are sized for it: 6 GB at 2 x 150 bp)
+MAX_LAUNCH_PAIRS = int(os.environ.get("DWGSIM_BENCH_MAX_LAUNCH_PAIRS", 1 << 23))         # pairs per launch at most (a launch's text buffers are sized for it: 6 GB at 2 x 150 bp)
 
 
 def file_sha256(path):
