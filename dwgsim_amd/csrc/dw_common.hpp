@@ -46,7 +46,7 @@ enum : uint32_t {
     D_FLOW_EV = 64,     // added to a flow-model domain: draw s of event h = word s & 3 of the block (retry s >> 2, block h)
     D_FLOW_PASS2 = 8,   // added to D_FLOW0 / D_CALIB (+read end) for the second pass of the flow model (domains 20-23)
     D_CALIB = 14,       // +read end.  -B calibration (dwgsim_opt.c:415-457): index = random read; attempt 0 = its bases, attempt 1 = its flow-model stream
-    D_SUB0 = 16,        // +read end.  word i: substituted-base draw of base i, drawn only when base i is an error (dwgsim.c:238)
+    D_SUB0 = 16,        // +read end.  word m: substituted-base draw of error site m of the read end's chain (dwgsim.c:238): drawn with the chain, a block per four sites
     D_BASE_REF0 = 24    // +read end.  word m = the THINNING draw of error site m where the position's threshold thr_i is below the ramp's largest: the site is kept
                         // iff w * thr_max < thr_i * 2^32 (probability thr_i / thr_max); not drawn for a constant error rate
 };

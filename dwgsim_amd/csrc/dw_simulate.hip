@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
             const int gS = j ? a.err_gap_s[1] : a.err_gap_s[0]; const bool ramp = (j ? a.err_ramp[1] : a.err_ramp[0]) != 0;
             const uint64_t *thr64 = j ? a.e_thr[1] : a.e_thr[0];
             if (tmax) {
-                uint32_t m = 0, S = 0, tw[4] = {0, 0, 0, 0};
+                uint32_t m = 0, S = 0, tw[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0};
                 for (;;) {                                                                  // (a per-lane loop: no wave operation inside)
                     if ((m & 3u) == 0u) {
                         const U4 q0 = rng_block(key, D_BASE0 + (uint32_t)j, ii, att, 0, m >> 2); rb[0] = q0.x; rb[1] = q0.y; rb[2] = q0.z; rb[3] = q0.w;
@@ -669,6 +669,9 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
                     const uint32_t G = tmax >= 0x100000000ull ? 0u : geom_gap(gw, s_lg, gR, gS);
                     S = m ? S + 1u + G : G;                                                 // site m of the chain
                     if (S >= (uint32_t)s) break;
+                    // (the substitution draws of sites 4 q .. 4 q + 3: one block, drawn once a site of the four is inside the read -- rounds 2-5 and the
+                    // first form of round 6 drew a block per ERROR, in a loop of its own whose trip count was the wave's largest error count)
+                    if (k4 == 0u) { const U4 q2 = rng_block(key, D_SUB0 + (uint32_t)j, ii, att, 0, m >> 2); sw[0] = q2.x; sw[1] = q2.y; sw[2] = q2.z; sw[3] = q2.w; }
                     const int w = (int)(S >> 3), sh = 4 * (int)(S & 7u);
                     const uint32_t word = lds[w * nthr];
                     bool hit = ((word >> sh) & 4u) == 0u;                                    // N bases / colour 4 take no error
@@ -677,26 +680,15 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
                         const uint32_t w2 = (k4 & 2u) ? ((k4 & 1u) ? tw[3] : tw[2]) : ((k4 & 1u) ? tw[1] : tw[0]);
                         hit = ti >= tmax || (uint64_t)w2 * tmax < (ti << 32);
                     }
-                    if (hit) { lds[w * nthr] = word | (8u << sh); ++n_err; if (DT == 1 && S == 0u) err_first = 1; }
+                    if (hit) {                                                              // dwgsim.c:238: c = (c + (int)(drand48() * 3.0 + 1)) & 3
+                        const uint32_t rwd = (k4 & 2u) ? ((k4 & 1u) ? sw[3] : sw[2]) : ((k4 & 1u) ? sw[1] : sw[0]);
+                        const uint32_t add = 1u + (uint32_t)(((uint64_t)rwd * 3u) >> 32);      // (int)(u * 3.0 + 1), exact
+                        const uint32_t c = (((word >> sh) & 3u) + add) & 3u;
+                        lds[w * nthr] = (word & ~(0xFu << sh)) | (c << sh);
+                        ++n_err; if (DT == 1 && S == 0u) err_first = 1;
+                    }
                     ++m;
                 }
-            }
-            // the substituted base of every marked base (dwgsim.c:238)
-            int w = 0; uint32_t pend = 0;
-            for (;;) {
-                while (pend == 0 && w < nw) { pend = lds[w * nthr] & 0x88888888u; if (!pend) ++w; }
-                if (!pend) break;
-                const int b = (__ffs((int)pend) - 1) >> 2;
-                pend &= pend - 1;
-                const int i = w * 8 + b;
-                const U4 q = rng_block(key, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)(i >> 2));
-                const uint32_t rwd = (i & 2) ? ((i & 1) ? q.w : q.z) : ((i & 1) ? q.y : q.x);
-                const uint32_t add = 1u + (uint32_t)(((uint64_t)rwd * 3u) >> 32);        // (int)(u * 3.0 + 1), exact
-                uint32_t word = lds[w * nthr];
-                const uint32_t c = (((word >> (4 * b)) & 7u) + add) & 3u;
-                word = (word & ~(0xFu << (4 * b))) | (c << (4 * b));
-                lds[w * nthr] = word;
-                if (!pend) ++w;
             }
         }
     }

@@ -67,7 +67,7 @@ enum {
                           one) of pass 1 (+ D_FLOW_PASS2: of pass 2); every further draw of an event in its private stream + D_FLOW_EV (see flow_first) */
     D_CALIB = 14,      /* -B calibration (dwgsim_opt.c:415-457); index = read number */
     D_FLOW_PASS2 = 8,  /* added to D_FLOW0 / D_CALIB (+j) for the second pass of generate_errors_flows: domains 20-23 */
-    D_SUB0 = 16,       /* +j; index = ii; NARROW: word i = substituted-base draw of base i (only drawn on an error) */
+    D_SUB0 = 16,       /* +j; index = ii; NARROW: word m = substituted-base draw of error site m of the read end's chain (base_error_sites) */
     D_MUTIN = 18,      /* mutation-input files (-b): index = entry ordinal; slot 0 hom test, 1 het haplotype (mut.c:662-669) */
     D_MUTIN_BASE = 19, /* index = entry ordinal; slot j = random base j of the entry (mut.c:676, :314, :319, :354) */
     D_FLOW_REF = 32,   /* (rounds 2-5: the low halves of the per-event first uniforms; unused since the first draws are drawn as gaps) */
@@ -265,9 +265,9 @@ static inline int walk_site(rng_t *r, uint32_t p, double mut_rate)
  * Random reads (dwgsim.c:999-1001): base i = (int)(drand48() * 4) & 3 = the 2-bit field i of the same stream: bits 2 (i & 15) of word (i >> 4) & 3 of block
  * i >> 6 -- 64 bases per Philox block (rounds 2-5: eight); --dump-draws: (b + 0.5) / 4. ---- */
 static uint64_t err_thr(double e) { return !(e > 0) ? 0 : e >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e * 4294967296.0); }
-static void base_error_sites(rng_t *r, int j, uint64_t idx, uint32_t att, int s, double e_start, double e_by, uint8_t *site)      /* site[0 .. s): 1 = this base errs unless it is N */
+static void base_error_sites(rng_t *r, int j, uint64_t idx, uint32_t att, int s, double e_start, double e_by, uint32_t *site)      /* site[0 .. s): m + 1 = this base errs unless it is N, as site m of the chain */
 {
-    memset(site, 0, (size_t)s);
+    memset(site, 0, sizeof(uint32_t) * (size_t)(s > 0 ? s : 0));
     if (r->mode == RNG_DRAND48 || s <= 0) return;
     uint64_t tmax = 0;
     for (int i = 0; i < s; ++i) { const uint64_t t = err_thr(e_start + e_by * i); if (t > tmax) tmax = t; }
@@ -278,18 +278,18 @@ static void base_error_sites(rng_t *r, int j, uint64_t idx, uint32_t att, int s,
         const uint64_t ti = err_thr(e_start + e_by * (double)(int)S);
         int keep = 1;
         if (ti < tmax) { const uint64_t w2 = (uint64_t)(oracle_philox_uniform32(r->k0, r->k1, D_BASE_REF0 + (uint32_t)j, idx, att, 0, m) * 4294967296.0); keep = w2 * tmax < (ti << 32); }
-        if (keep) site[S] = 1;
+        if (keep) site[S] = m + 1u;
         ++m;
         S += 1u + flow_gap((uint32_t)(oracle_philox_uniform32(r->k0, r->k1, D_BASE0 + (uint32_t)j, idx, att, 0, m) * 4294967296.0), &par);
     }
 }
 /* the error test of a base that is not N, in the order the reference makes them */
-static inline int base_errs(rng_t *r, const uint8_t *site, int i, double e_i)
+static inline int base_errs(rng_t *r, const uint32_t *site, int i, double e_i)
 {
     r->n_draws++;
     if (r->mode == RNG_DRAND48) return oracle_drand48_next(&r->x) < e_i;
     rng_out(r, site[i] ? 0.0 : 1.0 - 0x1p-48);
-    return site[i];
+    return site[i] != 0;
 }
 static inline uint8_t random_base(rng_t *r, int j, uint64_t idx, uint32_t att, uint32_t i)
 {
@@ -1375,7 +1375,7 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
     flowbuf_t tb[2];
     for (int j = 0; j < 2; ++j) flow_alloc(&tb[j], lmax, o->flow_order_len);
     int qcap = lmax; char *qstr = calloc((size_t)qcap + 1, 1);
-    int site_cap = lmax > 0 ? lmax : 1; uint8_t *err_site = calloc((size_t)site_cap, 1);      /* error sites of a read end (base_error_sites) */
+    int site_cap = lmax > 0 ? lmax : 1; uint32_t *err_site = calloc((size_t)site_cap, sizeof(uint32_t));      /* error sites of a read end (base_error_sites) */
     int size[2] = { o->length[0], o->length[1] };
 
     /* pass 1: contig lengths and the VCF header, dwgsim.c:465-492 */
@@ -1555,13 +1555,13 @@ static int core(opt_t *o, rng_t *r, const char *fn_fa, outs_t *out, stats_t *st)
                         }
                     } else for (int j = 0; j < 2; ++j) if (0 < s[j]) { /* :233-244, :866-881 */
                         int i = strand[j] ? s[j] - 1 : 0, step = strand[j] ? -1 : 1;
-                        if (site_cap < s[j]) { site_cap = s[j]; err_site = realloc(err_site, (size_t)site_cap); }
+                        if (site_cap < s[j]) { site_cap = s[j]; err_site = realloc(err_site, sizeof(uint32_t) * (size_t)site_cap); }
                         base_error_sites(r, j, ii, att, s[j], o->e[j].start, o->e[j].by, err_site);
                         for (; 0 <= i && i < s[j]; i += step) {
                             uint8_t c = tb[j].seq[i];
                             if (c >= 4) c = 4;
                             else if (base_errs(r, err_site, i, o->e[j].start + o->e[j].by * i)) {
-                                c = (uint8_t)((c + (uint64_t)(rng_u32(r, D_SUB0 + (uint32_t)j, ii, att, 0, (uint32_t)i) * 3.0 + 1)) & 3);
+                                c = (uint8_t)((c + (uint64_t)(rng_u32(r, D_SUB0 + (uint32_t)j, ii, att, 0, r->mode == RNG_PHILOX ? err_site[i] - 1u : (uint32_t)i) * 3.0 + 1)) & 3);      /* mode B: the substitution draw of error SITE m (word m & 3 of block m >> 2): one Philox block per four errors, drawn with the chain */
                                 ++n_err[j];
                                 if (0 == i) ++n_err_first[j];
                             }
