@@ -65,11 +65,14 @@ DW_DEV uint32_t spread4(uint32_t v)
 
 // UNIFORM_KEY: the key is the same in every lane of the wave (scalar registers); the read kernels' keys are, the walk kernels' per-candidate keys
 // (a contig of a group per thread) are not
+#ifndef DW_PHILOX_ROUNDS
+#define DW_PHILOX_ROUNDS 10      // (analysis builds only: the cost of the generator's rounds)
+#endif
 template <bool UNIFORM_KEY = true>
 DW_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < DW_PHILOX_ROUNDS; ++r) {
         if (UNIFORM_KEY) keep_scalar(k0, k1);      // keep the round keys out of 20 hoisted SGPRs: two SALU adds per round instead
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
