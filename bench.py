@@ -392,6 +392,8 @@ def main():
         ctx = api.Context(job_params, dev, lib)
         if args.phases:
             ctx.debug_option("phases", 1)
+        for kv in filter(None, os.environ.get("DWGSIM_BENCH_DEBUG_OPTIONS", "").split(",")):      # analysis only: e.g. split=1,writer=0 (dwgsim_hip_debug_option)
+            k, v = kv.split("="); ctx.debug_option(k, int(v))
         # the job: pairs per contig exactly as dwgsim_core schedules them (dwgsim.c:582-590); every contig stays resident, in groups
         job = []
         n_sim = 0

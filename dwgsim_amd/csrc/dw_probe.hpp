@@ -14,3 +14,4 @@ template <class... T> __device__ __forceinline__ void keep(const T &...) {}
 // phase clocks of k_simulate (shader-clock ticks per phase, added to the batch's counters by the analysis twin)
 #define DW_PROBE_INIT() do { } while (0)
 #define DW_PROBE_MARK(args, k) do { } while (0)
+#define DW_PROBE_MARKF(args, k) do { } while (0)      // (the finer marks of the -DDW_PHASE_FINE analysis build)

@@ -17,8 +17,19 @@ template <class T, class... R> __device__ __forceinline__ void keep(const T &v, 
 } }
 #ifdef DW_PHASE_TIMING
 #define DW_PROBE_INIT() uint64_t ph_t = __builtin_amdgcn_s_memtime()
-#define DW_PROBE_MARK(args, k) do { const uint64_t ph_n = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&(args).counters[8 + (k)], (unsigned long long)(ph_n - ph_t)); ph_t = ph_n; } while (0)
+#define DW_PROBE_MARK_(args, k) do { const uint64_t ph_n = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&(args).counters[8 + (k)], (unsigned long long)(ph_n - ph_t)); ph_t = ph_n; } while (0)
+#ifdef DW_PHASE_FINE
+// the fine split of what happens in front of the text: the coarse marks 3 .. 6 (name lengths + look-backs 2-3, header, sequence, quality) are ONE phase (4), mark 2 becomes 3 = the
+// barrier behind the error phase (the wait for wave 0's look-back of the random-read index), and the fine marks take 5 = the last attempt's extraction + leaving the attempt loop,
+// 6 = the block scan of the random reads (a barrier: the block's slowest wave), 2 = the error phase's own work; 1 is then what wave 0 spends in look-back 1 (nothing in the others)
+#define DW_PROBE_MARK(args, k) DW_PROBE_MARK_(args, ((k) == 2 ? 3 : (k) >= 3 && (k) <= 6 ? 4 : (k)))
+#define DW_PROBE_MARKF(args, k) DW_PROBE_MARK_(args, k)
+#else
+#define DW_PROBE_MARK(args, k) DW_PROBE_MARK_(args, k)
+#define DW_PROBE_MARKF(args, k) do { } while (0)
+#endif
 #else
 #define DW_PROBE_INIT() do { } while (0)
 #define DW_PROBE_MARK(args, k) do { } while (0)
+#define DW_PROBE_MARKF(args, k) do { } while (0)
 #endif

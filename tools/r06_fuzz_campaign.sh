@@ -5,12 +5,12 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 o=gpurun_out/r06_fuzz; mkdir -p $o
 sha256sum dwgsim_amd/libdwgsim_hip.so | tee $o/library_sha256.txt
 {
-for sd in 9511 9512 9513; do DWGSIM_FUZZ_LONG=1 timeout 900 python tests/fuzz_flags.py $sd 60 | tail -3; done
-DWGSIM_FUZZ_LONG=1 timeout 900 python tests/fuzz_flags.py 9514 40 shards | tail -3
-DWGSIM_FUZZ_LONG=1 timeout 900 python tests/fuzz_flags.py 9515 30 cli | tail -3
-for sd in 9611 9612; do timeout 1200 python tests/fuzz_ion_flows.py $sd 150 | tail -3; done
-timeout 900 python tests/fuzz_flags.py 9711 150 | tail -3
-DWGSIM_FUZZ_MUT=1 timeout 900 python tests/fuzz_flags.py 9712 100 | tail -3
-timeout 900 python tests/fuzz_flags.py 9713 60 cli | tail -3
-timeout 900 python tests/fuzz_flags.py 9714 60 inputs shards | tail -3
+for sd in 9521 9522 9523; do DWGSIM_FUZZ_LONG=1 timeout 900 python tests/fuzz_flags.py $sd 60 | tail -3; done
+DWGSIM_FUZZ_LONG=1 timeout 900 python tests/fuzz_flags.py 9524 40 shards | tail -3
+DWGSIM_FUZZ_LONG=1 timeout 900 python tests/fuzz_flags.py 9525 30 cli | tail -3
+for sd in 9621 9622; do timeout 1200 python tests/fuzz_ion_flows.py $sd 150 | tail -3; done
+timeout 900 python tests/fuzz_flags.py 9721 150 | tail -3
+DWGSIM_FUZZ_MUT=1 timeout 900 python tests/fuzz_flags.py 9722 100 | tail -3
+timeout 900 python tests/fuzz_flags.py 9723 60 cli | tail -3
+timeout 900 python tests/fuzz_flags.py 9724 60 inputs shards | tail -3
 } 2>&1 | tee $o/fuzz.txt
