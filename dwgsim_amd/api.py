@@ -285,7 +285,6 @@ class JobResult:
     sim_kernel_ms: float = 0.0
     walk_ms: float = 0.0
     flow_cap_mult: int = 1                           # Ion Torrent: by how much the read capacity had grown at the end of the job (run_job)
-    qual_early_launches: int = 0                     # launches of the single Illumina kernel that drew their quality lines inside the look-back wait (run_job)
 
 
 VCF_HEADER_POST = (
@@ -612,7 +611,6 @@ def run_job(params: Params, contigs, device: int = 0, batch_pairs: int = 1 << 22
                 n_sim += b.n_pairs
             ctx.drop_contig(h0)
         res.flow_cap_mult = ctx.debug_get("flow_cap_mult")
-        res.qual_early_launches = ctx.debug_get("qual_early_launches")
     res.n_pairs = n_sim
     res.n_random = rand_ii
     res.mutations_txt = bytes(txt)

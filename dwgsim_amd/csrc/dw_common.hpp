@@ -213,15 +213,11 @@ DW_DEV uint64_t status_load(uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_
 #define DW_LB_W 1
 #endif
 constexpr int LB_W = DW_LB_W;
-// (in two steps, for a caller that has work to do between publishing its own sum and needing the prefix: lookback_excl = publish + finish)
-DW_DEV void lookback_publish(uint64_t *status, uint32_t t, uint64_t aggregate, uint64_t base)
-{
-    if (lane_id() == 0) status_store(&status[t], t == 0 ? (ST_PREFIX | ((base + aggregate) & ST_VAL)) : (ST_AGG | (aggregate & ST_VAL)));
-}
-DW_DEV uint64_t lookback_finish(uint64_t *status, uint32_t t, uint64_t aggregate, uint64_t base)
+DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, uint64_t base)
 {
     const int lane = lane_id();
-    if (t == 0) return base;
+    if (t == 0) { if (lane == 0) status_store(&status[0], ST_PREFIX | ((base + aggregate) & ST_VAL)); return base; }
+    if (lane == 0) status_store(&status[t], ST_AGG | (aggregate & ST_VAL));
     uint64_t excl = 0;
     int64_t k = (int64_t)t - 1;
     for (;;) {
@@ -249,11 +245,6 @@ DW_DEV uint64_t lookback_finish(uint64_t *status, uint32_t t, uint64_t aggregate
     }
     if (lane == 0) status_store(&status[t], ST_PREFIX | ((excl + aggregate) & ST_VAL));
     return excl;
-}
-DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, uint64_t base)
-{
-    lookback_publish(status, t, aggregate, base);
-    return lookback_finish(status, t, aggregate, base);
 }
 
 } // namespace dw

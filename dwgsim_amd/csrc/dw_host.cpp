@@ -136,7 +136,7 @@ struct dwgsim_hip_ctx {
     bool seq_justify = false, dense_view = false;      // "justify_seq", "dense_view": the cross-check forms of the walk (one thread justifies a whole group; the views are made from every cell)
     MutInput mutin; bool has_mutin = false;                             // -m / -b / -v
     Regions regions; bool has_regions = false;                           // -x
-    DevBuf flow_scratch, flow_free, qual_scratch;
+    DevBuf flow_scratch, flow_free;
     uint64_t *d_counters = nullptr, *h_counters = nullptr;          // N_COUNTERS x u64 + pinned mirror: calibrate / count_random / debug hooks (compute stream)
     uint64_t *d_wcounters = nullptr;                                // 16 x u64 (mirrored per group: Group::h_wc): the walk ([7] candidates, [8..11] eight words, [12], [13] mut_debug, [14] listed cells)
     uint64_t *d_pcounters = nullptr, *h_pcounters = nullptr;        // N_COUNTERS x u64 + pinned mirror: count_random (walk stream)
@@ -148,7 +148,7 @@ struct dwgsim_hip_ctx {
     int flow_cap_mult = 1;                 // Ion Torrent: the read capacity is flow_read_capacity() times this; doubled when a read outgrew it (the reference doubles its buffers, dwgsim.c:296-311)
     int ion_lds = -1;                      // "ion_lds" (tests): where the Ion Torrent read buffers live (fill_sim_args)
     int n_cu = 0; int flow_slots = 0;      // compute units of the device; "flow_slots": scratch slots per XCD forced by the tests (0: as many as an XCD can hold blocks)
-    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0; int split = -1, qual_early = -1; int64_t qual_early_launches = 0;      // dwgsim_hip_debug_option / _debug_get
+    int64_t walk_cap = -1; bool phases = false; int writer = -1, force_threads = 0; int64_t place_cap = -1; uint64_t place_open = 0; double walk_us = 0, count_us = 0; int split = -1;      // dwgsim_hip_debug_option / _debug_get
     hipEvent_t ev_cnt0 = nullptr, ev_cnt1 = nullptr;
     bool gzip_on = false; uint32_t *d_crc_table = nullptr, *d_crc_shift = nullptr;      // dwgsim_hip_set_gzip
     void *h_stage = nullptr; size_t h_stage_cap = 0;   // pinned staging for fetch
@@ -631,7 +631,7 @@ void dwgsim_hip_destroy(dwgsim_hip_ctx_t *c)
     for (auto &g : c->pool) free_group(g);
     for (int j = 0; j < 2; ++j) { hipFree(c->d_thr[j]); hipFree(c->d_thr32[j]); hipFree(c->d_qbase[j]); }
     for (DevBuf *b : {&c->meta, &c->fail_summ, &c->block_rand, &c->status_all, &c->split_state, &c->split_hand, &c->split_agg, &c->split_pre, &c->split_chunk, &c->place_segs, &c->place_rand, &c->place_list, &c->place_aux, &c->scratch_mask, &c->scratch_cnt, &c->scratch_status, &c->w_cand, &c->w_ev, &c->w_flags, &c->w_lo, &c->w_sufmin,
-                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch, &c->flow_free, &c->qual_scratch, &c->w_slots, &c->w_slot_aux}) hipFree(b->p);
+                      &c->w_bound, &c->w_ppos, &c->w_pcells, &c->up_ascii, &c->l_pos, &c->l_cells, &c->flow_scratch, &c->flow_free, &c->w_slots, &c->w_slot_aux}) hipFree(b->p);
     for (int s = 0; s < DWGSIM_HIP_SLOTS; ++s) for (int t = 0; t < 3; ++t) hipFree(c->out[s][t].p);
     hipFree(c->d_rand_fixed); hipFree(c->d_counters); hipFree(c->d_wcounters); hipFree(c->d_pcounters); hipFree(c->d_flow); hipFree(c->d_chain); hipFree(c->d_crc_table); hipFree(c->d_crc_shift);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -1455,7 +1455,6 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
         flow_gap_params(!(e0 > 0) ? 0 : e0 >= 1.0 ? 0x100000000ull : (uint64_t)ceil(e0 * 4294967296.0), &a.flow_gap_r[j], &a.flow_gap_s[j]);
     }
     a.flow_scratch = nullptr; a.flow_free = nullptr; a.flow_slots = 0;
-    a.qual_scratch = nullptr; a.qual_chunks = 0;
     if (p.data_type == 2) {
         // the flow model's one in-place buffer per lane, 2 bits per base (dw_read.hpp flow_errors), and the run stack of its pass 2.  In LDS while at
         // least two 256-lane blocks -- or else four one-wave blocks -- fit a CU; beyond that (very long reads, error rates at which reads grow
@@ -1639,18 +1638,6 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
             const size_t words = (ion ? (size_t)flow_words_per_lane(a.lds_words) * (size_t)SIM_THREADS : (size_t)a.lds_words * (size_t)SIM_THREADS_LONG) * (size_t)a.flow_slots * 8;
             if (ensure(c, c->flow_scratch, words * sizeof(uint32_t)) || ensure(c, c->flow_free, sizeof(uint64_t) * (256 + 8 * (size_t)nblk))) return DWGSIM_HIP_ERR_DEVICE;
             a.flow_scratch = (uint32_t *)c->flow_scratch.p; a.flow_free = (uint64_t *)c->flow_free.p;
-        }
-        // early quality lines (dw_simulate.hip a.qual_scratch): the single Illumina kernel with the FIFO writer, unless "qual_early" = 0; a slot per block an XCD can hold
-        if (!a.split && p.data_type == 0 && a.sim_threads == SIM_THREADS && a.fifo && c->qual_early > 0 && p.fixed_quality < 0 && 0 < p.quality_std) {
-            const int cu_per_xcd = (c->n_cu >= 64 && c->n_cu % 8 == 0) ? c->n_cu / 8 : c->n_cu;
-            const int lmaxq = std::max(p.length[0], p.length[1]);
-            const int per_cu = sim_blocks_per_cu(sim_lds_bytes((size_t)a.lds_words, SIM_THREADS, (size_t)a.qb_words, true), 8);
-            a.flow_slots = c->flow_slots > 0 ? c->flow_slots : cu_per_xcd * per_cu;
-            if ((uint64_t)a.flow_slots > (uint64_t)nblk) a.flow_slots = (int32_t)nblk;
-            a.qual_chunks = (lmaxq + 15) / 16;
-            if (ensure(c, c->qual_scratch, (size_t)a.qual_chunks * SIM_THREADS * 16 * (size_t)a.flow_slots * 8) || ensure(c, c->flow_free, sizeof(uint64_t) * (256 + 8 * (size_t)nblk))) return DWGSIM_HIP_ERR_DEVICE;
-            a.qual_scratch = (uint32_t *)c->qual_scratch.p; a.flow_free = (uint64_t *)c->flow_free.p;
-            ++c->qual_early_launches;
         }
         if (ensure(c, sl.segs, sizeof(SimSeg) * segs.size())) return DWGSIM_HIP_ERR_DEVICE;
         if (segs.size() > sl.h_segs_cap) {
@@ -1988,7 +1975,6 @@ int dwgsim_hip_debug_gzip(dwgsim_hip_ctx_t *c, const void *text, size_t n, void 
 // "sim_threads" = 64 forces the one-wave blocks of the long-read variant (measured: 25 % slower on 2 x 150 bp, small jobs included),
 // "walk_seg_min" = n runs the walk's two serial scans in their segmented form from a capacity of n candidates on (default 16384; 0 restores it),
 // "place_cap" = n gives the lists of pairs that k_place leaves open room for n entries each (exercises the second, full-size run),
-// "qual_early" = 1 switches the early quality lines of the single Illumina kernel on (dw_simulate.hip a.qual_scratch; "flow_slots" sets their scratch slots per XCD too; off by default: measured slower),
 // "split" = 0 / 1 runs the Illumina read kernel as one kernel with look-backs / as two kernels with the offsets computed in between (-1: two for reads of
 // up to 100 bases).
 int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
@@ -2005,7 +1991,6 @@ int dwgsim_hip_debug_option(dwgsim_hip_ctx_t *c, const char *key, int64_t value)
     else if (!strcmp(key, "walk_seg_min")) walk_debug_seg_min((uint32_t)value);      // (process-wide)
     else if (!strcmp(key, "place_cap")) c->place_cap = value;
     else if (!strcmp(key, "split")) c->split = (int)value;
-    else if (!strcmp(key, "qual_early")) c->qual_early = (int)value;
     else if (!strcmp(key, "flow_slots")) c->flow_slots = (int)value;
     else if (!strcmp(key, "ion_lds")) c->ion_lds = (int)value;
     else if (!strcmp(key, "flow_cap")) c->flow_cap_forced = (int)value;
@@ -2022,7 +2007,6 @@ int dwgsim_hip_debug_get(dwgsim_hip_ctx_t *c, const char *key, int64_t *value)
     else if (!strcmp(key, "flow_cap_mult")) *value = (int64_t)c->flow_cap_mult;
     else if (!strcmp(key, "walk_us")) *value = (int64_t)c->walk_us;           // HIP-event time of the walk chains waited for so far (start of the chain to its end, on the walk stream)
     else if (!strcmp(key, "count_us")) *value = (int64_t)c->count_us;         // ... of the random-read counts (k_place .. k_range_counts)
-    else if (!strcmp(key, "qual_early_launches")) *value = c->qual_early_launches;      // launches of the single Illumina kernel that drew their quality lines inside the look-back wait
     else { c->err = "unknown debug value"; return DWGSIM_HIP_ERR_ARG; }
     return DWGSIM_HIP_OK;
 }

@@ -504,13 +504,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     DW_PROBE_INIT();
-    // EARLY QUALITY LINES (a.qual_scratch): a block stands still from the moment it has published its count of random reads until every block in front of it
-    // has published its own (look-back 1) -- 40 % of a wave's lifetime at 2 x 150 bp (phase clocks, profiles/r06_bench_lines_final.txt 10): the spread of the
-    // predecessors' arrival, inherent in ordered output.  The quality lines are half of the kernel's instructions and need nothing from another block: they are
-    // drawn INSIDE that wait, into a scratch slot (16-byte pieces, a wave's stores contiguous), and copied into the records once the offsets are known.
-    constexpr bool QE_OK = SPLIT == 0 && DT == 0 && NTHR == SIM_THREADS && WR != 0;
-    const bool qe = QE_OK && a.qual_scratch != nullptr;
-    if ((GS || qe) && tid == 0) { s_slot = scratch_slot_take(a.flow_free, (uint32_t)a.flow_slots, a.n_blocks); asm volatile("" ::: "memory"); }      // (before the ticket: see scratch_slot_take)
+    if (GS && tid == 0) { s_slot = scratch_slot_take(a.flow_free, (uint32_t)a.flow_slots, a.n_blocks); asm volatile("" ::: "memory"); }      // (before the ticket: see scratch_slot_take)
     if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
     if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (ION && tid < 64) s_ft.flow[tid] = a.flow[tid];
@@ -601,11 +595,8 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     DW_PROBE_MARKF(a, 6);    // (fine) the block scan of the random reads
     if (wave == 0) {
-        if (qe) lookback_publish(a.status[2], t, rtot, 0);      // (the prefix is asked for behind the quality lines)
-        else {
         const uint64_t g = probe::off(128) ? (uint64_t)t * 6 : lookback_excl(a.status[2], t, rtot, 0);
         if (lane == 0) { s_rbase = g; if (t + 1 == a.n_blocks) a.counters[3] = g + rtot; }
-        }
     }
     }
     // (the barrier that publishes s_rbase comes after the error phase, which does not need the index: the look-back's latency
@@ -724,25 +715,6 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         if (ION) { s_out = (int)(hm.w >> 17); flow_reversed = !is_rand && (j ? pd.strand1 : pd.strand0) != 0; }
         __syncthreads();      // the tables of the prologue (names, base qualities)
         { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
-    }
-    uint4 *qs = nullptr;
-    if (QE_OK) if (qe) {
-        qs = reinterpret_cast<uint4 *>(a.qual_scratch) + (size_t)uniform_u32(s_slot) * ((size_t)a.qual_chunks * nthr) + tid;      // piece c of this lane at qs[c * nthr]
-        if (valid && s_out > 0) {
-            uint64_t qlo = 0, qhi = 0; uint32_t qn = 0; int qc = 0;      // the piece being filled: qn (< 16) characters in {qhi, qlo}
-            for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false, [&](uint64_t blk, uint32_t nb) {
-                const uint64_t carry = qn > 8u ? blk >> (8u * (16u - qn)) : 0ull;      // what does not fit the piece (qn + nb > 16 needs qn > 8)
-                if (qn < 8u) { qlo |= blk << (8u * qn); if (qn) qhi |= blk >> (8u * (8u - qn)); }
-                else qhi |= blk << (8u * (qn - 8u));
-                qn += nb;
-                if (qn >= 16u) { qs[(size_t)qc * nthr] = make_uint4((uint32_t)qlo, (uint32_t)(qlo >> 32), (uint32_t)qhi, (uint32_t)(qhi >> 32)); ++qc; qn -= 16u; qlo = carry; qhi = 0; }
-            });
-            if (qn) qs[(size_t)qc * nthr] = make_uint4((uint32_t)qlo, (uint32_t)(qlo >> 32), (uint32_t)qhi, (uint32_t)(qhi >> 32));
-        }
-        if (wave == 0) {
-            const uint64_t g = lookback_finish(a.status[2], t, rtot, 0);
-            if (lane == 0) { s_rbase = g; if (t + 1 == a.n_blocks) a.counters[3] = g + rtot; }
-        }
     }
     DW_PROBE_MARKF(a, 2);    // (fine) the error phase's own work
     if (H == 0) __syncthreads();
@@ -949,19 +921,6 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         if (SPLIT == 0 && DW_PRIO_DROP == 1) wave_priority(0);      // (a wave none of whose lanes has a record)
         DW_PROBE_MARK(a, 5); // sequence line
         // qualities (dwgsim.c:899-918): up to eight characters per Philox block of the read end's try stream, appended as they come
-        if (QE_OK && qe) {
-            if (rec) {                                   // the pieces drawn early: the next one is on its way while this one is appended
-                const int nch = (s_out + 15) >> 4;
-                uint4 cur = qs[0];
-                for (int c = 0; c < nch; ++c) {
-                    const uint4 nxt = c + 1 < nch ? qs[(size_t)(c + 1) * nthr] : cur;
-                    const int left = s_out - 16 * c;
-                    o.putn((uint64_t)cur.x | ((uint64_t)cur.y << 32), left >= 8 ? 8u : (uint32_t)left);
-                    if (left > 8) o.putn((uint64_t)cur.z | ((uint64_t)cur.w << 32), left >= 16 ? 8u : (uint32_t)(left - 8));
-                    cur = nxt;
-                }
-            }
-        } else
         if (rec) {
             if constexpr (WR != 0 && DW_QUAL_FIFO) quality_line_fifo(o.a, a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out);
             else for_each_quality_block(a.p, key, D_QUAL0 + (uint32_t)j, ii, att, s_qb + (j ? a.qb_words : 0), s, s_out, false,
@@ -970,7 +929,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         if (rec) { o.put('\n'); o.flush(); }
     }
     DW_PROBE_MARK(a, 6);     // quality line
-    if (GS || qe) {          // the scratch slot goes back to this XCD's free list once every wave's accesses to it are done
+    if (GS) {                // the scratch slot goes back to this XCD's free list once every wave's accesses to it are done
         wait_stores();
         __syncthreads();
         if (tid == 0) scratch_slot_release(a.flow_free, a.n_blocks, s_slot);

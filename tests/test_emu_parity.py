@@ -158,23 +158,6 @@ def test_both_forms_of_the_illumina_read_kernel_on_cpu_emulation(emu_lib, oracle
     compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=333, debug_options={"split": split})
 
 
-@pytest.mark.parametrize("early,slots", [(1, 0), (1, 1), (1, 2), (0, 0)])
-@pytest.mark.parametrize("fasta,flags", [
-    ("tiny.fa", "-z 9 -N 2500 -y 0.15 -n 0"),                                  # 2 x 70, the default ramp, random reads
-    ("odd.fa", "-z 6 -N 1500 -1 33 -2 81 -d 200 -s 10 -r 0.05 -R 0.5 -Q 7.5 -o 0"),     # two lengths (3 and 6 pieces, the last of either ragged), both output families
-    ("tiny.fa", "-z 4 -N 1200 -1 48 -2 0 -Q 0.5 -e 0.03 -o 1"),                # single end, whole pieces only
-])
-def test_early_quality_lines_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, fasta, flags, early, slots):
-    """The single Illumina kernel draws its quality lines between publishing its random-read count and asking for the counts in front of it, into a
-    scratch slot, and copies them into the records later (dw_simulate.hip a.qual_scratch).  On and off; with one or two slots per XCD a slot's
-    second owner writes over its first owner's lines (12+ blocks; the emulation puts block b on XCD b % 8)."""
-    opts = {"split": 0, "writer": 1, "qual_early": early}
-    if slots:
-        opts["flow_slots"] = slots
-    res = compare_case(emu_lib, oracle_bin, os.path.join(golden_dir, fasta), flags, batch_pairs=1 << 20, debug_options=opts)
-    assert (res.qual_early_launches > 0) == bool(early)
-
-
 @pytest.mark.parametrize("slots", [1, 2])
 def test_ion_torrent_scratch_slots_change_hands_on_cpu_emulation(emu_lib, oracle_bin, golden_dir, slots):
     """The Ion Torrent read buffers are scratch SLOTS taken and released by the blocks of an XCD (dw_simulate.hip scratch_slot_take): with one or
