@@ -1604,6 +1604,14 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)
     size_t cap[3] = {0, 0, 0};
     for (int j = 0; j < 2; ++j) if (p.length[j] > 0) cap[j] = (size_t)n_pairs * (size_t)(1 + fixed_max + 120 + 3 + 2 * (p.data_type == 2 ? a.cap : p.length[j]) + 4);
+    {   // the one look-back word of the single Illumina kernel: 62 bits for the random reads and the bytes of stream 1 in front of a block
+        const uint64_t bytes0 = (uint64_t)cap[0] | 1ull;
+        int bw_bytes = 0, bw_pairs = 0;
+        while (bw_bytes < 63 && (bytes0 >> bw_bytes)) ++bw_bytes;
+        while (bw_pairs < 63 && ((uint64_t)n_pairs >> bw_pairs)) ++bw_pairs;
+        a.lb_shift = bw_bytes;
+        if (p.data_type == 0 && bw_bytes + bw_pairs > 62) { c->err = "too many pairs in one call"; return DWGSIM_HIP_ERR_ARG; }
+    }
     cap[2] = cap[0] + cap[1];
     if (!a.p.has_bwa) cap[0] = cap[1] = 0;
     if (!a.p.has_bfast) cap[2] = 0;

@@ -203,6 +203,7 @@ struct SimArgs {
     uint32_t *flow_scratch;        // scratch slots: the staged reads of one block per SLOT (Ion Torrent DT = 2: flow_words_per_lane words per lane), word w of lane t at [w * nthr + t]
     uint64_t *flow_free;           // ... the slots' free lists, one per XCD (dw_simulate.hip scratch_slot_take): 256 header words + 8 x n_blocks queue words, zeroed per launch
     int32_t flow_slots;            // ... slots per XCD (8 x flow_slots slots in flow_scratch)
+    int32_t lb_shift;              // the single Illumina kernel's one look-back word: random reads << lb_shift | bytes of stream 1 (dw_simulate.hip ONE_LB)
     const uint8_t *flow;           // Ion Torrent: flow order as base codes (dwgsim_opt.c:404-407), device memory, 64 bytes, followed by the log2 table of the gap draws (FLOW_LG_ENTRIES words)
     uint64_t flow_gap_r[2]; int32_t flow_gap_s[2];      // Ion Torrent, per read end: flow_gap_params of its threshold e_thr[j][0]
     uint64_t err_thr_max[2], err_gap_r[2]; int32_t err_gap_s[2], err_ramp[2];      // Illumina / SOLiD, per read end: the largest threshold of the error ramp, flow_gap_params of it, and whether any position's threshold is lower (those sites are thinned)

@@ -40,6 +40,9 @@
                              // round 4); capped at 128 it spills 20-46 registers and is 11-33 % FASTER (2 x 50 -o 0 / -o 1 / 75 + 35 -o 2: profiles/r05_bench_lines_final.txt section 7)
 #endif
 #ifndef DW_QUAL_FIFO
+#ifndef DW_ONE_LB
+#define DW_ONE_LB 1          // 1: the single Illumina kernel places its records with ONE look-back (k_simulate, "ONE_LB"); 0: the three of rounds 2-5 (analysis builds)
+#endif
 #define DW_QUAL_FIFO 0       // 1: the quality line's pairs of characters placed by two-byte LDS stores (quality_line_fifo); 0: compacted in registers as in rounds
                              // 2-4.  Measured (profiles/r05_bench_lines_final.txt, one box each): 14.0 k -> 13.2-13.5 k VALU per wave, but four more LDS accesses per
                              // block (SQ_WAIT_INST_LDS x 4, bank conflicts x 4): 2 x 150 -o 1 1 % SLOWER, E. coli-sized 7 % slower, -o 0 and 2 x 250 equal: not adopted
@@ -501,6 +504,14 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     // word by word in step by the lanes of a wave (word w of lane t at [w * nthr + t]) and lives in the L2 / memory-side cache
     constexpr bool ION = DT == 2 || DT == 3;
     constexpr bool GS = DT == 2 || (DT != 3 && NTHR != SIM_THREADS);
+    // ONE LOOK-BACK (Illumina, one kernel).  Rounds 2-5 walked three chains: the random-read counts first (a random read's name ends in its running index: its
+    // hexadecimal digits are part of the record lengths), then -- from every block only once it had its index -- the byte totals of the two streams.  Two fronts
+    // one behind the other: a block stood still until the second one had passed it.  But the digits are arithmetic (the random reads in front of a block have
+    // consecutive indices: hex_digits_sum), and the second stream's total follows from the first's (a pair's two records differ by twice the difference of the read
+    // lengths).  So a block publishes ONE word -- its random reads (upper bits) and the bytes of its stream-1 records WITHOUT those digits (lower a.lb_shift bits) --, one chain
+    // carries both sums, and everything else is added by the block itself.  One front, two barriers and two block scans fewer.
+    constexpr bool ONE_LB = DW_ONE_LB != 0 && DT == 0 && SPLIT == 0;
+    const int LB_SHIFT = a.lb_shift;      // (bits of the byte sum; the host sizes it to the launch and refuses one whose two sums would not fit 62 bits: dw_host.cpp)
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     DW_PROBE_INIT();
@@ -591,7 +602,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     if (valid && j == 0) a.meta[pair] = att | (is_rand ? 0x80000000u : 0u) | ((sg->contig_start && pair_in == 0) ? 0x40000000u : 0u);
     { const uint32_t retries = wave_sum_u32((valid && j == 0) ? att : 0u); if (lane == 0 && retries) atomicAdd((unsigned long long *)&a.counters[1], (unsigned long long)retries); }
     // running random-read index (dwgsim.c:1042,1096): look-back over the blocks' random counts + rank inside the block
-    if (H == 0) {
+    if (H == 0 && !ONE_LB) {
     { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     DW_PROBE_MARKF(a, 6);    // (fine) the block scan of the random reads
     if (wave == 0) {
@@ -717,9 +728,9 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         { const uint32_t v[1] = {(is_rand && j == 0) ? 1u : 0u}; uint32_t ex[1], tot[1]; block_excl_scan_n<1>(v, sm_rand, ex, tot); rrank = ex[0]; rtot = tot[0]; }
     }
     DW_PROBE_MARKF(a, 2);    // (fine) the error phase's own work
-    if (H == 0) __syncthreads();
+    if (H == 0 && !ONE_LB) __syncthreads();
     // (the first half does not know the running index yet: its lengths leave the hexadecimal digits of random reads' names out, k_split_scan adds them)
-    const uint64_t rand_ii = H == 1 ? 0 : a.chain[0] + (SPLIT == 2 ? pre_rand : s_rbase) + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
+    uint64_t rand_ii = (H == 1 || ONE_LB) ? 0 : a.chain[0] + (SPLIT == 2 ? pre_rand : s_rbase) + rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);   // odd lane: its even partner was counted
     DW_PROBE_MARK(a, 2);     // error tests + substitutions
     // ---- name fields of the pair (dwgsim.c:923-929): both ends print both ends' numbers ----
     int32_t e0 = n_err, u0 = rr.n_sub, i0 = rr.n_indel, x0 = rr.ext_coor;     // read end 1
@@ -741,7 +752,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     }
     const NameCounts nc{e0, u0, i0, e1c, u1, i1}, ncw{e0w, u0, i0w, e1w, u1, i1w};
     uint32_t tail_len, tail_len_w, fixed_len;
-    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + (H == 1 ? 0u : ndigits16(rand_ii)); }   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
+    if (is_rand) { fixed_len = (uint32_t)a.rand_fixed_len; tail_len = tail_len_w = 25u + ((H == 1 || ONE_LB) ? 0u : ndigits16(rand_ii)); }      // (ONE_LB: the digits are added below)   // "_0_0_0_0_1_1_0:0:0_0:0:0_" (25 chars) + hex
     else {
         fixed_len = (uint32_t)sg->name_fixed_len;
         tail_len = pair_tail_len(x0, x1, nc, ii);
@@ -758,6 +769,37 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     // (the two-kernel form of Ion Torrent takes the arithmetic offsets: a batch with a read the model gave up on is run again as a whole, dw_host.cpp)
     constexpr bool BF_SCAN = DT != 0 && SPLIT == 0;
     uint32_t e1, e2, eb = 0, T1, T2, Tb = 0;
+    uint64_t G1_one = 0, G2_one = 0;
+    if (ONE_LB) {
+        // one scan (random reads, bytes of stream 1 / 2 without the digits), one word published, one look-back
+        const uint32_t v[3] = {(is_rand && j == 0) ? 1u : 0u, j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u};
+        uint32_t ex[3], tot[3]; block_excl_scan_n<3>(v, sm_bytes, ex, tot);
+        rrank = ex[0]; e1 = ex[1]; e2 = ex[2]; rtot = tot[0];
+        DW_PROBE_MARKF(a, 6);
+        if (wave == 0) {
+            const uint64_t g = lookback_excl(a.status[0], t, ((uint64_t)tot[0] << LB_SHIFT) | (uint64_t)tot[1], 0);
+            if (lane == 0) s_base[0] = g;
+        }
+        __syncthreads();
+        const uint64_t pk = s_base[0];
+        const uint64_t base_r = pk >> LB_SHIFT, pre1 = pk & ((1ull << LB_SHIFT) - 1ull);
+        const uint64_t rb0 = a.chain[0] + base_r;                                  // the index of the block's first random read
+        const uint64_t hex_before = hex_digits_sum(a.chain[0], base_r);           // the digits of all the random reads in front of the block (block-uniform)
+        const uint64_t pairs_before = sg->pair_off + (uint64_t)(t - sg->first_block) * PPB;      // every one of them has its record(s): Illumina reads keep their length
+        G1_one = pre1 + hex_before;
+        G2_one = LPP == 2 ? pre1 + (uint64_t)((int64_t)2 * (a.p.len[1] - a.p.len[0]) * (int64_t)pairs_before) + hex_before : 0ull;
+        // this lane: its index, its name's length with the digits, and the digits of the block's random reads in front of its record in either stream
+        const uint32_t cnt2 = rrank - ((LPP == 2 && j == 1 && is_rand) ? 1u : 0u);      // random pairs in front of this lane's pair
+        rand_ii = rb0 + cnt2;
+        if (is_rand) tail_len = tail_len_w = 25u + ndigits16(rand_ii);
+        const uint32_t dlo = ndigits16(rb0);
+        const bool one_width = dlo == ndigits16(rb0 + rtot);                       // (block-uniform; all but a handful of blocks of a launch)
+        const uint32_t h1 = one_width ? dlo * rrank : (uint32_t)hex_digits_sum(rb0, rrank), h2 = one_width ? dlo * cnt2 : (uint32_t)hex_digits_sum(rb0, cnt2);
+        const uint32_t htot = one_width ? dlo * rtot : (uint32_t)hex_digits_sum(rb0, rtot);
+        e1 += h1; if (LPP == 2) e2 += h2;      // (single end: no second stream)
+        T1 = tot[1] + htot; T2 = tot[2] + (LPP == 2 ? htot : 0u);
+        if (tid == nthr - 1 && t + 1 == a.n_blocks) a.counters[3] = base_r + rtot;
+    } else
     if (BF_SCAN) {
         const uint32_t Lbf = !emits ? 0u : DT == 1 ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : Lbwa - 2u;
         const uint32_t v[3] = {j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u, Lbf};
@@ -782,7 +824,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         if (tid == 0) { uint32_t r = 0, t1 = 0, t2 = 0; for (int w = 0; w < nwaves; ++w) { r += sm_rand[0][w]; t1 += sm_bytes[0][w]; t2 += sm_bytes[1][w]; } reinterpret_cast<uint4 *>(a.split_agg)[t] = make_uint4(r, t1, t2, 0u); }
         return;
     }
-    if (H == 0) {
+    if (H == 0 && !ONE_LB) {
     if (wave == 0) {
         const uint64_t g = probe::off(128) ? (uint64_t)t * PPB * (uint64_t)(60 + 2 * s + a.rand_fixed_len + sg->name_fixed_len) : lookback_excl(a.status[0], t, T1, 0); if (lane == 0) s_base[0] = g;
         if (BF_SCAN) { const uint64_t gb = lookback_excl(a.status[3], t, Tb, 0); if (lane == 0) s_base[2] = gb; }
@@ -790,7 +832,7 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     if (wave == (nwaves > 1 ? 1 : 0)) { const uint64_t g = probe::off(128) ? (uint64_t)t * PPB * (uint64_t)(60 + 2 * s + a.rand_fixed_len + sg->name_fixed_len) : lookback_excl(a.status[1], t, T2, 0); if (lane == 0) s_base[1] = g; }
     __syncthreads();
     }
-    const uint64_t G1 = SPLIT == 2 ? pre_b1 : s_base[0], G2 = SPLIT == 2 ? pre_b2 : s_base[1];
+    const uint64_t G1 = ONE_LB ? G1_one : SPLIT == 2 ? pre_b1 : s_base[0], G2 = ONE_LB ? G2_one : SPLIT == 2 ? pre_b2 : s_base[1];
     const uint64_t reads_before_block = (sg->pair_off + (uint64_t)(t - sg->first_block) * PPB) * (uint64_t)LPP;      // (every block in front of a range's last is full)
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
