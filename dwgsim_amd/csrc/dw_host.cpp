@@ -1472,7 +1472,9 @@ static int fill_sim_args(dwgsim_hip_ctx_t *c, Group &g, SimArgs &a)
     // no staged bases in LDS -- writes the text in 64-byte bursts.  What does not scale with the read length (placement, the look-backs, the name)
     // is most of the work there: 2 x 36 / 2 x 50 / 2 x 75 bp and 100 bp single-end run 16 / 17 / 9 / 15 % faster than in the single kernel, 2 x 100
     // the same, 2 x 150 2-3 % slower (the state crosses HBM, 2.5 GB per chr20-sized launch): profiles/r04_split.txt.  "split" = 0 / 1 forces either.
-    const bool split_wins = lmax0 <= 100;
+    // Round 6, the single kernel with ONE look-back (dw_simulate.hip ONE_LB), re-measured (profiles/r06_bench_lines_final.txt 14): 2 x 36 bp +5.5 % as two kernels, 2 x 50 +0.8 %, 2 x 75
+    // -3 %, 2 x 100 -10 %, 100 bp single-end -9 %, 2 x 150 -12 %: the cut moves from 100 bases to 50.
+    const bool split_wins = lmax0 <= 50;
     a.split = (p.data_type == 0 && a.sim_threads == SIM_THREADS && (c->split < 0 ? split_wins : c->split != 0)) ? 1 : 0;
     // Ion Torrent with its buffers in LDS: as two kernels as well (the flow model | qualities + text).  The first half holds no text FIFOs, so a fourth
     // block fits a CU, and no block waits for the record sizes of the blocks in front of it ("split" = 0 forces the single kernel)
@@ -1595,10 +1597,10 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
     if (const int rc = build_ranges(c, r, n, sim_ppb, &gp, segs, &n_pairs, &nblk, &fixed_max)) return rc;
     Group &g = *gp;
     HIPC(c, hipSetDevice(c->device));
-    // a SMALL launch -- up to ~3 rounds of resident blocks: the product's 2^18-pair batches, an E. coli-sized contig -- also runs as two kernels: the
-    // first round's look-backs resolve one after the other (every block waits for all in front of it, all of them just started), and a launch this
-    // short is mostly first round: 2^17 / 2^18 / 2^19 pairs of 2 x 150 bp -5 / -11.5 / -2 %, 2^20 pairs +1 % (profiles/r04_split.txt)
-    if (!a.split && c->split < 0 && p.data_type == 0 && a.sim_threads == SIM_THREADS && n_pairs && (uint64_t)nblk <= 16ull * (uint64_t)c->n_cu) { a.split = 1; if (c->writer < 0) a.fifo = 1; }
+    // (rounds 4-5: a SMALL launch -- up to ~3 rounds of resident blocks: the product's 2^18-pair batches, an E. coli-sized contig -- also ran as two kernels: the
+    // first round's three look-backs resolved one after the other, 2^17 / 2^18 / 2^19 pairs of 2 x 150 bp -5 / -11.5 / -2 %: profiles/r04_split.txt)
+    // (round 6: with one look-back the single kernel is level with the two-kernel form on launches this small too -- 2^17 / 2^18 / 2^19 pairs of 2 x 150 bp +4 / -3 / +9 %, an E. coli-sized
+    // contig +2.5 % -- and the rule is gone: profiles/r06_bench_lines_final.txt 14)
     if (a.split && p.data_type == 2) a.fifo = 1;
     if (c->rand_fixed_len > fixed_max) fixed_max = c->rand_fixed_len;
     // upper bound of one FASTQ record (name tail: 2 positions <= 10 digits, 6 counters, 16 hex digits)

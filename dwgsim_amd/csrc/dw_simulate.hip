@@ -491,7 +491,8 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
 {
     static_assert(SPLIT == 0 || ((DT == 0 || DT == 3) && NTHR == SIM_THREADS), "the two-kernel form exists for the Illumina variants and for Ion Torrent with its buffers in LDS, 256-lane blocks");
     DW_DYN_SHARED(uint32_t, dyn_lds);                                    // [lds_words][blockDim] packed bases
-    __shared__ uint32_t sm_rand[1][16], sm_bytes[3][16];     // one scratch area per scan: each is written once
+    __shared__ uint32_t sm_all[4][16];     // one scratch row per scanned quantity: each is written once
+    uint32_t (*const sm_bytes)[16] = sm_all, (*const sm_rand)[16] = sm_all + 3, (*const sm_one)[16] = sm_all;      // (the three-look-back forms: bytes in rows 0-2, random reads in row 3)
     __shared__ uint32_t s_ticket, s_slot;
     __shared__ uint64_t s_rbase, s_base[3];
     __shared__ uint32_t s_fixed[2][32];          // "@[prefix_]contig" and "@[prefix_]rand", first 128 bytes
@@ -510,7 +511,9 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     // consecutive indices: hex_digits_sum), and the second stream's total follows from the first's (a pair's two records differ by twice the difference of the read
     // lengths).  So a block publishes ONE word -- its random reads (upper bits) and the bytes of its stream-1 records WITHOUT those digits (lower a.lb_shift bits) --, one chain
     // carries both sums, and everything else is added by the block itself.  One front, two barriers and two block scans fewer.
-    constexpr bool ONE_LB = DW_ONE_LB != 0 && DT == 0 && SPLIT == 0;
+    // (SOLiD: the BFAST records' lengths are not a function of the BWA records' -- the name counts differ --: their bytes are a second word, on a chain of its own walked
+    // by wave 1 at the same time: still one front)
+    constexpr bool ONE_LB = DW_ONE_LB != 0 && (DT == 0 || DT == 1) && SPLIT == 0;
     const int LB_SHIFT = a.lb_shift;      // (bits of the byte sum; the host sizes it to the launch and refuses one whose two sums would not fit 62 bits: dw_host.cpp)
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -769,17 +772,22 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     // (the two-kernel form of Ion Torrent takes the arithmetic offsets: a batch with a read the model gave up on is run again as a whole, dw_host.cpp)
     constexpr bool BF_SCAN = DT != 0 && SPLIT == 0;
     uint32_t e1, e2, eb = 0, T1, T2, Tb = 0;
-    uint64_t G1_one = 0, G2_one = 0;
+    uint64_t G1_one = 0, G2_one = 0, Gb_one = 0;
     if (ONE_LB) {
         // one scan (random reads, bytes of stream 1 / 2 without the digits), one word published, one look-back
-        const uint32_t v[3] = {(is_rand && j == 0) ? 1u : 0u, j == 0 ? Lbwa : 0u, j == 1 ? Lbwa : 0u};
-        uint32_t ex[3], tot[3]; block_excl_scan_n<3>(v, sm_bytes, ex, tot);
-        rrank = ex[0]; e1 = ex[1]; e2 = ex[2]; rtot = tot[0];
+        constexpr bool BF_ONE = DT == 1;      // (SOLiD: the BFAST stream's own sum)
+        constexpr int NS = BF_ONE ? 4 : 3;
+        const uint32_t Lbf1 = (BF_ONE && emits) ? (1u + fixed_len + tail_len + 1u + 1u + 2u * (uint32_t)s_out + 3u + 1u) : 0u;
+        uint32_t v[NS], ex[NS], tot[NS];
+        v[0] = (is_rand && j == 0) ? 1u : 0u; v[1] = j == 0 ? Lbwa : 0u; v[2] = j == 1 ? Lbwa : 0u; if (BF_ONE) v[NS - 1] = Lbf1;
+        block_excl_scan_n<NS>(v, sm_one, ex, tot);
+        rrank = ex[0]; e1 = ex[1]; e2 = ex[2]; rtot = tot[0]; if (BF_ONE) eb = ex[NS - 1];
         DW_PROBE_MARKF(a, 6);
         if (wave == 0) {
             const uint64_t g = lookback_excl(a.status[0], t, ((uint64_t)tot[0] << LB_SHIFT) | (uint64_t)tot[1], 0);
             if (lane == 0) s_base[0] = g;
         }
+        if (BF_ONE && wave == (nwaves > 1 ? 1 : 0)) { const uint64_t gb = lookback_excl(a.status[3], t, (uint64_t)tot[NS - 1], 0); if (lane == 0) s_base[2] = gb; }
         __syncthreads();
         const uint64_t pk = s_base[0];
         const uint64_t base_r = pk >> LB_SHIFT, pre1 = pk & ((1ull << LB_SHIFT) - 1ull);
@@ -798,6 +806,10 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
         const uint32_t htot = one_width ? dlo * rtot : (uint32_t)hex_digits_sum(rb0, rtot);
         e1 += h1; if (LPP == 2) e2 += h2;      // (single end: no second stream)
         T1 = tot[1] + htot; T2 = tot[2] + (LPP == 2 ? htot : 0u);
+        if (BF_ONE) {      // both ends' records of a random pair carry the index
+            eb += LPP == 2 ? h1 + h2 : h1; Tb = tot[NS - 1] + (LPP == 2 ? 2u : 1u) * htot;
+            Gb_one = s_base[2] + (LPP == 2 ? 2ull : 1ull) * hex_before;
+        }
         if (tid == nthr - 1 && t + 1 == a.n_blocks) a.counters[3] = base_r + rtot;
     } else
     if (BF_SCAN) {
@@ -837,13 +849,13 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     const uint64_t nvalid_before = (uint64_t)tid;                  // valid lanes form a prefix of the block
     const uint64_t off_bwa = (j == 0) ? G1 + e1 : G2 + e2;
     // Illumina: a BFAST record is its BWA record minus the 2-byte "/1" suffix, so its offset follows from the two BWA scans
-    const uint64_t off_bf = BF_SCAN ? s_base[2] + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
+    const uint64_t off_bf = BF_SCAN ? (ONE_LB ? Gb_one : s_base[2]) + eb : G1 + G2 - 2 * reads_before_block + e1 + e2 - 2 * nvalid_before;
     if (H == 0 && tid == nthr - 1) {
         if (t + 1 == a.n_blocks) {
             const uint64_t nreads = a.n_pairs * (uint64_t)((a.p.len[1] > 0) ? 2 : 1);
             a.counters[4] = a.p.has_bwa ? G1 + T1 : 0;
             a.counters[5] = a.p.has_bwa ? G2 + T2 : 0;
-            a.counters[6] = !a.p.has_bfast ? 0 : BF_SCAN ? s_base[2] + Tb : G1 + T1 + G2 + T2 - 2 * nreads;
+            a.counters[6] = !a.p.has_bfast ? 0 : BF_SCAN ? (ONE_LB ? Gb_one : s_base[2]) + Tb : G1 + T1 + G2 + T2 - 2 * nreads;
         }
     }
 
