@@ -209,6 +209,9 @@ DW_DEV uint64_t status_load(uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_
 // never waits: 5.34 -> 4.54 ms, also without a single retry in the batch) are the dependent round trips of the hops: 128 / 256 / 512 predecessors per hop
 // make the launch SLOWER (1 238 -> 1 201 / 1 143 / 1 070 M pairs/s, profiles/r06_bench_lines_final.txt): more polling traffic on the same words, no fewer
 // waits -- the time is spent waiting for predecessors to publish, not hopping.  LB_W stays 1.
+#ifndef DW_LB_SLEEP
+#define DW_LB_SLEEP 2      // (s_sleep units of 64 cycles between two polls of a predecessor that has not published)
+#endif
 #ifndef DW_LB_W
 #define DW_LB_W 1
 #endif
@@ -232,7 +235,7 @@ DW_DEV uint64_t lookback_excl(uint64_t *status, uint32_t t, uint64_t aggregate, 
         for (int w = 0; w < LB_W; ++w) {
             const int64_t idx = k - (int64_t)lane * LB_W - w;
             if (probe::off(2048) && (v[w] >> 62) == 0) v[w] = ST_PREFIX;                  // (probe 2048: a look-back that never waits -- garbage offsets, analysis only)
-            while ((v[w] >> 62) == 0) { __builtin_amdgcn_s_sleep(2); v[w] = status_load(&status[idx]); }
+            while ((v[w] >> 62) == 0) { __builtin_amdgcn_s_sleep(DW_LB_SLEEP); v[w] = status_load(&status[idx]); }
         }
         uint64_t mine = 0; bool have = false;                                            // the values up to and including this lane's nearest PREFIX
 #pragma unroll

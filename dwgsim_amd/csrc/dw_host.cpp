@@ -442,12 +442,14 @@ dwgsim_hip_ctx_t *dwgsim_hip_create(const dwgsim_hip_params_t *p, int device, in
     auto fail = [&](const char *what) { fprintf(stderr, "dwgsim-hip: %s: %s\n", what, c->err.c_str()); set_err(err, fail_code); dwgsim_hip_destroy(c); return (dwgsim_hip_ctx *)nullptr; };
     auto init = [&]() -> int {
         HIPC(c, hipSetDevice(device));
-        // the batches' kernels get the compute units first; what prepares the NEXT group (upload, walk, random-read count: walk stream) fills what
-        // they leave -- the thinning tail of every launch -- instead of taking slots from them
+        // What prepares the NEXT group (upload, walk, random-read count: walk stream) runs at the batches' own priority.  Rounds 3-5 put it below them ("fills the
+        // thinning tail of every launch instead of taking slots"): its fifteen small kernels then ran one after the other in the gap between two k_simulate launches --
+        // 0.07 of the 0.46 ms of an E. coli-sized step.  At equal priority they slip in as slots fall free while the big kernel runs and are done when it ends: E. coli-sized
+        // 1 146-1 159 against 980-1 060 M pairs/s, chr20-sized / whole genome / N-rank weak lines unchanged (profiles/r06_bench_lines_final.txt 15).
         int prio_least = 0, prio_greatest = 0;
         HIPC(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        // (DWGSIM_HIP_WALK_PRIO=high|mid|above: analysis -- the walk stream at the batches' priority, between the two, or the batches below the walk)
-        int prio_walk = prio_least, prio_batch = prio_greatest;
+        // (DWGSIM_HIP_WALK_PRIO=low|mid|above: analysis -- the walk stream below the batches (rounds 3-5), between the two, or the batches below the walk)
+        int prio_walk = prio_greatest, prio_batch = prio_greatest;
         if (const char *e = getenv("DWGSIM_HIP_WALK_PRIO")) {
             prio_walk = !strcmp(e, "high") || !strcmp(e, "above") ? prio_greatest : !strcmp(e, "mid") ? (prio_least + prio_greatest) / 2 : prio_least;
             if (!strcmp(e, "above")) prio_batch = prio_least;
@@ -1670,20 +1672,21 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
     const dwgsim_hip_range_t *r_first = nullptr, *r_last = nullptr;
     for (int q = 0; q < n; ++q) if (r[q].n_pairs) { if (!r_first) r_first = &r[q]; r_last = &r[q]; }
     if (!r_first) { r_first = &r[0]; r_last = &r[n - 1]; }
+    uint64_t *ch_ptr = c->d_chain; int ch_rand = 0, ch_carry = 0; uint64_t ch_carry_v = 0;      // the running values the launch starts from: set by launch_init with the rest
     if (!rerun) {
     const bool continues = c->chain_contig == r_first->contig && c->chain_next_ii == r_first->first_ii && r_first->first_ii != 0;
     const bool set_carry = c->has_carry_override || !continues;
     const uint64_t carry = c->has_carry_override ? c->carry_override : 0;
     c->has_carry_override = false;
     const bool set_rand = rand_base != DWGSIM_HIP_RAND_CHAIN;
-    if (set_rand || set_carry) launch_chain_set(c->stream, c->d_chain, rand_base, set_rand ? 1 : 0, carry, set_carry ? 1 : 0);
+    ch_ptr = c->d_chain; ch_rand = set_rand ? 1 : 0; ch_carry_v = carry; ch_carry = set_carry ? 1 : 0;
     c->chain_contig = r_last->contig; c->chain_next_ii = r_last->first_ii + r_last->n_pairs;
     if (sl.ranges.data() != r) sl.ranges.assign(r, r + n);
     } else {
-        launch_chain_set(c->stream, sl.d_rerun_chain, rand_base, 1, 0, 1);
+        ch_ptr = sl.d_rerun_chain; ch_rand = 1; ch_carry_v = 0; ch_carry = 1;
         a.chain = sl.d_rerun_chain;
     }
-    if (n_pairs == 0) return DWGSIM_HIP_OK;
+    if (n_pairs == 0) { if (ch_rand || ch_carry) launch_chain_set(c->stream, ch_ptr, rand_base, ch_rand, ch_carry_v, ch_carry); return DWGSIM_HIP_OK; }
     uint32_t opens = 0;
     for (const SimSeg &s : segs) opens |= s.contig_start;
     memcpy(sl.h_segs, segs.data(), sizeof(SimSeg) * segs.size());
@@ -1692,9 +1695,9 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
     a.meta = (uint32_t *)c->meta.p; a.block_rand = (uint32_t *)c->block_rand.p; a.counters = sl.d_counters;
     for (int j = 0; j < 4; ++j) a.status[j] = a.split ? nullptr : (uint64_t *)c->status_all.p + (size_t)j * (size_t)nblk;
     sl.group = c->handles[(size_t)g.first_handle].group;
-    HIPC(c, hipMemsetAsync(sl.d_counters, 0, N_COUNTERS * sizeof(uint64_t), c->stream));
-    if (!a.split) HIPC(c, hipMemsetAsync(a.status[0], 0, 4 * sizeof(uint64_t) * (size_t)nblk, c->stream));
-    if (a.flow_free) HIPC(c, hipMemsetAsync(a.flow_free, 0, sizeof(uint64_t) * (256 + 8 * (size_t)nblk), c->stream));
+    // one operation in front of the kernel: counters, look-back words (the four arrays are contiguous), the scratch slots' free lists, the running values
+    launch_init(c->stream, sl.d_counters, (uint32_t)N_COUNTERS, a.split ? nullptr : a.status[0], a.split ? 0 : 4 * (uint64_t)nblk, a.flow_free, a.flow_free ? 256 + 8 * (uint64_t)nblk : 0,
+                ch_ptr, rand_base, ch_rand, ch_carry_v, ch_carry);
     HIPC(c, hipEventRecord(sl.ev_k0, c->stream));
     launch_simulate(c->stream, a);
     HIPC(c, hipEventRecord(sl.ev_k1, c->stream));

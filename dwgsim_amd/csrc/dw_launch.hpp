@@ -30,6 +30,7 @@ void launch_simulate(hipStream_t st, const SimArgs &a);
 void launch_calibrate(hipStream_t st, const CalibArgs &a);
 void launch_failrule(hipStream_t st, const uint32_t *meta, uint64_t n_pairs, uint32_t opens_contig, uint64_t *summ, uint64_t *counters, uint64_t *chain);
 void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry);
+void launch_init(hipStream_t st, uint64_t *counters, uint32_t n_counters, uint64_t *z0, uint64_t n0, uint64_t *z1, uint64_t n1, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry);
 void launch_selftest_lazy(hipStream_t st, int mode, uint32_t first, uint64_t n, double sigma, float qk, float qeps, float qlmin, int qnear1, uint64_t *out);
 uint64_t gz_chunks(uint64_t n);
 uint64_t gz_capacity(uint64_t n);

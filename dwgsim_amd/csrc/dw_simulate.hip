@@ -1298,6 +1298,21 @@ void launch_chain_set(hipStream_t st, uint64_t *chain, uint64_t rand_base, int s
 {
     hipLaunchKernelGGL(k_chain_set, dim3(1), dim3(64), 0, st, chain, rand_base, set_rand, carry, set_carry);
 }
+// Everything a launch needs reset in front of it, in ONE stream operation: its counters, the look-back words of its blocks (and the scratch slots' free lists), the running
+// values it starts from.  (Rounds 2-5: two or three memsets and k_chain_set -- four operations of ~10 us each in front of a kernel that takes 400 us for an E. coli-sized contig.)
+__global__ void __launch_bounds__(256) k_launch_init(uint64_t *counters, uint32_t n_counters, uint64_t *z0, uint64_t n0, uint64_t *z1, uint64_t n1, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    if (i < n_counters) counters[i] = 0;
+    for (uint64_t k = i; k < n0; k += stride) z0[k] = 0;
+    for (uint64_t k = i; k < n1; k += stride) z1[k] = 0;
+    if (i == 0) { if (set_rand) chain[0] = rand_base; if (set_carry) chain[1] = carry; }
+}
+void launch_init(hipStream_t st, uint64_t *counters, uint32_t n_counters, uint64_t *z0, uint64_t n0, uint64_t *z1, uint64_t n1, uint64_t *chain, uint64_t rand_base, int set_rand, uint64_t carry, int set_carry)
+{
+    const uint64_t most = n0 > n1 ? n0 : n1, want = (most + 255) / 256;
+    hipLaunchKernelGGL(k_launch_init, dim3((uint32_t)(want < 1 ? 1 : want > 2048 ? 2048 : want)), dim3(256), 0, st, counters, n_counters, z0, n0, z1, n1, chain, rand_base, set_rand, carry, set_carry);
+}
 // test / analysis hook: how many bytes of text[0 .. n) equal `byte` (size-independent checks of whole outputs without copying them out)
 __global__ void __launch_bounds__(256) k_count_byte(const uint8_t *__restrict__ text, uint64_t n, uint32_t byte, uint64_t *out)
 {

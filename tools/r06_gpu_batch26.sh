@@ -1,0 +1,38 @@
+#!/bin/bash
+# tools/r06_gpu_batch26.sh -- (gpurun) the round's FINAL library: the -m gpu suite, the final profiles + counters + bench line, every line the documents quote, the solo-rank sweep
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+o=gpurun_out/r06b26; mkdir -p $o
+sha256sum dwgsim_amd/libdwgsim_hip.so > $o/library_sha256.txt
+timeout 2400 python -m pytest tests -x -q -m gpu > $o/gputest.txt 2>&1; tail -3 $o/gputest.txt
+bash tools/r06_final_profiles.sh > $o/final.log 2>&1
+cp gpurun_out/final/r06_counters.json profiles/r06_counters.json
+python bench.py > gpurun_out/final/bench_line_n1.json 2> gpurun_out/final/bench_line_n1.err; python -c "import json; d=json.loads(open('gpurun_out/final/bench_line_n1.json').read().strip().splitlines()[-1]); print('bench line', d['value'], d['roofline']['frac'], d['roofline']['traffic'], d['strong']['value'])"
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['breakdown_ms']['simulate_kernels'], d['breakdown_ms']['walk_gpu'], d['roofline']['frac'])"; }
+{
+python bench.py --workload chr20 --steps 100 --no-legs --no-cpu-baseline 2>/dev/null | line "chr20,2x150"
+python bench.py --workload chr20 --steps 100 --no-legs --no-cpu-baseline 2>/dev/null | line "chr20,2x150"
+python bench.py --workload chr20_like --steps 100 --no-legs --no-cpu-baseline 2>/dev/null | line "chr20_like,2x150"
+python bench.py --workload ecoli --steps 200 --no-legs --no-cpu-baseline 2>/dev/null | line "ecoli,2x150"
+DWGSIM_BENCH_DEBUG_OPTIONS=split=1 python bench.py --workload ecoli --steps 200 --no-legs --no-cpu-baseline 2>/dev/null | line "ecoli,2x150,two-kernels"
+python bench.py --workload ecoli_like --steps 200 --no-legs --no-cpu-baseline 2>/dev/null | line "ecoli_like,2x150"
+python bench.py --workload assembly5k --steps 20 --no-legs --no-cpu-baseline 2>/dev/null | line "assembly5k,2x150"
+python bench.py --workload chr20 --steps 60 --no-legs --no-cpu-baseline "--flags=-z 13 -1 50 -2 50 -C 30 -o 1" 2>/dev/null | line "chr20,2x50"
+python bench.py --workload chr20 --steps 60 --no-legs --no-cpu-baseline "--flags=-z 13 -1 100 -2 100 -C 30 -o 1" 2>/dev/null | line "chr20,2x100"
+python bench.py --workload chr20 --steps 60 --no-legs --no-cpu-baseline "--flags=-z 13 -1 250 -2 250 -C 30 -o 1" 2>/dev/null | line "chr20,2x250"
+python bench.py --workload chr20 --steps 60 --no-legs --no-cpu-baseline "--flags=-z 13 -1 150 -2 150 -C 30 -o 0" 2>/dev/null | line "chr20,2x150,-o0"
+python bench.py --workload chr20 --steps 60 --no-legs --no-cpu-baseline "--flags=-z 13 -1 150 -2 150 -C 30 -o 0" 2>/dev/null | line "chr20,2x150,-o0"
+python bench.py --workload chr20 --steps 40 --no-legs --no-cpu-baseline "--flags=-z 13 -c 1 -1 50 -2 50 -C 30 -o 0" 2>/dev/null | line "chr20,solid2x50,-o0"
+python bench.py --workload chr20 --steps 40 --no-legs --no-cpu-baseline "--flags=-z 13 -c 1 -1 50 -2 50 -C 30 -o 1" 2>/dev/null | line "chr20,solid2x50,-o1"
+python bench.py --workload chr20 --steps 40 --no-legs --no-cpu-baseline --ion 2>/dev/null | line "chr20,ion400"
+python bench.py --workload ecoli --steps 50 --no-legs --no-cpu-baseline --ion 2>/dev/null | line "ecoli,ion400"
+python bench.py --workload grch38 --mode strong --steps 3 --warmup 1 --no-legs --no-cpu-baseline 2>/dev/null | line "genome,strong,N=1"
+python bench.py --workload grch38 --mode strong --steps 3 --warmup 1 --no-pipeline --group-bp 2130706432 --no-legs --no-cpu-baseline 2>/dev/null | line "genome-two-groups,no-pipeline(walk alone)"
+} | tee $o/lines.txt
+timeout 900 python bench.py --solo-sweep 2,4,8 --no-cpu-baseline --no-legs > $o/solo_sweep.json 2> $o/solo_sweep.err; python - <<PY | tee $o/solo_sweep.txt
+import json; d=json.load(open("$o/solo_sweep.json"))
+for mode in ("weak","strong"):
+    print("##", mode, d[mode].get("job"))
+    for W,v in d[mode].items():
+        if W=="job": continue
+        print(mode, "W", W, "max", v["max_ms_per_step"], "min", v["min_ms_per_step"], "eff", v["efficiency"])
+PY
