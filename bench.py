@@ -678,8 +678,9 @@ def main():
                          "traffic": prof.get("traffic_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": int(algo_per_pair * pairs_per_launch), "launch_ms": round(sim_ms_launch, 4), "library_sha256": lib_sha,
                          "valu": {k: prof[k] for k in ("valu_instr_per_pair", "valu_instr_per_wave", "salu_instr_per_wave", "valu_issue_active_pct", "source", "git_head") if k in prof},
-                         "note": algo_note + " x pairs per launch / HIP-event time of the launch (events on the library's own stream); the kernel is bound by VALU issue "
-                                 "(Philox rounds, fp32 / fp64 quality normals, text formatting), not by HBM: the fraction of the HBM roof says how far the ALU work has been squeezed"},
+                         "note": algo_note + " x pairs per launch / HIP-event time of the launch (events on the library's own stream); the kernel is bound by instruction issue "
+                                 "(12 k VALU per wave: quality normals, text formatting, Philox) and by what five waves per SIMD leave uncovered of the ordered output's one look-back front, not by HBM: "
+                                 "the fraction of the HBM roof says how far that has been squeezed (valu_issue_active_pct = SQ_ACTIVE_INST_VALU, which ticks once per instruction in quad-cycles: DESIGN.md 7b)"},
         }
         if prof_note:
             out["roofline"]["counters_note"] = prof_note

@@ -1614,7 +1614,7 @@ static int sim_enqueue(dwgsim_hip_ctx_t *c, const dwgsim_hip_range_t *r, int n, 
         while (bw_bytes < 63 && (bytes0 >> bw_bytes)) ++bw_bytes;
         while (bw_pairs < 63 && ((uint64_t)n_pairs >> bw_pairs)) ++bw_pairs;
         a.lb_shift = bw_bytes;
-        if (p.data_type == 0 && bw_bytes + bw_pairs > 62) { c->err = "too many pairs in one call"; return DWGSIM_HIP_ERR_ARG; }
+        if (p.data_type != 2 && bw_bytes + bw_pairs > 62) { c->err = "too many pairs in one call"; return DWGSIM_HIP_ERR_ARG; }      // (Illumina and SOLiD; at 2 x 150 bp: more than 2^26 pairs)
     }
     cap[2] = cap[0] + cap[1];
     if (!a.p.has_bwa) cap[0] = cap[1] = 0;

@@ -225,7 +225,10 @@ int dwgsim_hip_simulate_async(dwgsim_hip_ctx_t *ctx, int contig, uint64_t first_
 int dwgsim_hip_wait(dwgsim_hip_ctx_t *ctx, int slot, dwgsim_hip_batch_t *out);
 /* ... for several ranges at once: one launch, one contiguous piece of every output stream (the loop dwgsim.c:519-1099 over several
  * contigs).  The abort rule's counter starts from zero wherever a range begins its contig (first_ii == 0), as `int num_failed = 0` does at
- * dwgsim.c:635; rand_base counts the random reads in front of the first range. */
+ * dwgsim.c:635; rand_base counts the random reads in front of the first range.
+ * ONE call takes at most 2^31 blocks of pairs; Illumina / SOLiD: and only as many pairs as leave the sum of their random reads and the bytes of their first output
+ * stream in 62 bits together (the kernels' one look-back word: at 2 x 150 bp 2^26 pairs, 50 GB of text per stream) -- beyond either: DWGSIM_HIP_ERR_ARG
+ * "too many pairs in one call"; a job is cut into calls long before (dwgsim_hip_job_*: 2^18 pairs each). */
 int dwgsim_hip_simulate_ranges_async(dwgsim_hip_ctx_t *ctx, const dwgsim_hip_range_t *ranges, int n_ranges, uint64_t rand_base, int slot);
 
 /* The failure counter carried into the next simulate call (default: the previous batch's counter when the call continues the

@@ -555,3 +555,19 @@ def test_ion_torrent_random_flow_orders_on_cpu_emulation(emu_lib, oracle_bin):
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0 and last.endswith(" 0 bad"), r.stdout[-3000:]
     assert int(last.split(" outgrew")[0].split()[-1]) <= 1, last      # (buffers are doubled up to 16 x before a case may count as that)
+
+
+@pytest.mark.parametrize("flags", ["-z 3 -1 150 -2 150", "-z 3 -c 1 -1 50 -2 50"])
+def test_a_call_whose_look_back_word_would_overflow_is_refused_on_cpu_emulation(emu_lib, golden_dir, flags):
+    """The single Illumina / SOLiD kernel carries the random reads and the bytes of the first stream in front of a block in ONE 62-bit word (dw_simulate.hip ONE_LB);
+    a call with so many pairs that the two sums could not share it (2^27 pairs of 2 x 150 bp: 90 GB of text per stream) is refused before anything is allocated
+    (include/dwgsim_hip.h dwgsim_hip_simulate_ranges_async).  A read-index range is not bound by the contig's length: the tiny contig will do."""
+    params = api.parse_flags(flags, emu_lib)
+    contigs = api.read_fasta(os.path.join(golden_dir, "tiny.fa"))
+    with api.Context(params, 0, emu_lib) as ctx:
+        h0 = ctx.add_contigs(contigs[:1], indices=[0])
+        ctx.mutate(h0)
+        with pytest.raises(api.DwgsimError, match="too many pairs in one call"):
+            ctx.simulate_ranges([(h0, 0, 1 << 34)], 0, 0)
+        b = ctx.simulate_ranges([(h0, 0, 100)], 0, 0)      # (and the context is still good)
+        assert b.n_pairs == 100
