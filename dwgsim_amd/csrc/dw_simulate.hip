@@ -519,7 +519,9 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     const int wave = tid >> 6, lane = tid & 63;
     DW_PROBE_INIT();
     if (GS && tid == 0) { s_slot = scratch_slot_take(a.flow_free, (uint32_t)a.flow_slots, a.n_blocks); asm volatile("" ::: "memory"); }      // (before the ticket: see scratch_slot_take)
+#ifndef DW_TICKET_LATE
     if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
+#endif
     if (SPLIT != 1) for (int q = tid; q < 32; q += nthr) s_fixed[1][q] = reinterpret_cast<const uint32_t *>(a.rand_fixed)[q];      // buffers are padded to 256 + 16 bytes
     if (ION && tid < 64) s_ft.flow[tid] = a.flow[tid];
     if (!ION && SPLIT != 2) for (int q = tid; q < FLOW_LG_ENTRIES; q += nthr) s_lg[q] = reinterpret_cast<const uint32_t *>(a.flow + 64)[q];
@@ -529,6 +531,9 @@ __global__ void __launch_bounds__(NTHR, (DT == 3 ? (SPLIT == 1 ? DW_IONA_WAVES :
     if (SPLIT != 1) for (int q = tid; q < 2 * a.qb_words; q += nthr) s_qb[q] = (q < a.qb_words ? a.qbase[0] : a.qbase[1])[q < a.qb_words ? q : q - a.qb_words];
     // this lane's text FIFO (record writer), behind the tables
     uint8_t *const s_fifo = reinterpret_cast<uint8_t *>(dyn_lds + (((stage_words * nthr + 2 * (size_t)a.qb_words) + 3) & ~(size_t)3)) + (size_t)tid * (WR == 2 ? SIM_FIFO_BYTES_WIDE : SIM_FIFO_BYTES);
+#ifdef DW_TICKET_LATE      // (analysis: the ticket taken behind the staging of the tables instead of in front of it: what stands between a block's ticket and its look-back is on every later block's path)
+    if (SPLIT == 0 && tid == 0) s_ticket = (uint32_t)atomicAdd((unsigned long long *)&a.counters[0], 1ull);
+#endif
     if (SPLIT == 0) __syncthreads();
     constexpr int H = SPLIT;      // which half of the path this kernel is: 0 both (the single kernel), 1 first, 2 second
     // logical block.  One kernel: from an atomic ticket, so that a block's predecessors have started when it looks back at them.  Two kernels:
