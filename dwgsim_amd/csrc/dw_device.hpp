@@ -50,12 +50,32 @@ DW_DEV void block_excl_scan_n(const uint32_t (&v)[N], uint32_t (*sm)[16], uint32
     }
 }
 
+// the first entry of the (sorted) insertion table at or behind pos.  A read that crosses an INSERT cell looks its bases up here while every block behind its own waits for
+// that block's sizes (dw_simulate.hip, "one look-back"): a bisection over a few thousand entries is a dozen DEPENDENT loads.  Insertions lie about evenly over a
+// contig, so the search interpolates (every other step bisects: the bound of a bisection, twice over, whatever the table looks like): four or five loads, the
+// table's two ends fetched together first.  Which entries it looks at changes nothing about what it finds.
 DW_DEV uint32_t ins_find(const HapDev &h, int64_t pos)
 {
     pos += h.pos_off;                      // the table holds group coordinates
-    uint32_t lo = 0, hi = h.n_ins;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)h.ins_pos[mid] < pos) lo = mid + 1; else hi = mid; }
-    return lo;
+    const uint32_t n = h.n_ins;
+    if (n == 0) return 0;
+    int64_t vlo = (int64_t)h.ins_pos[0], vhi = (int64_t)h.ins_pos[n - 1];
+    if (pos <= vlo) return 0;
+    if (pos > vhi) return n;
+    uint32_t lo = 0, hi = n - 1;           // invariant: ins_pos[lo] < pos <= ins_pos[hi]
+    bool bisect = false;
+    while (hi - lo > 1) {
+        uint32_t g = lo + ((hi - lo) >> 1);
+        if (!bisect) {
+            const float f = (float)(pos - vlo) / (float)(vhi - vlo);
+            g = lo + (uint32_t)((float)(hi - lo) * f);
+            g = g <= lo ? lo + 1 : g >= hi ? hi - 1 : g;
+        }
+        const int64_t v = (int64_t)h.ins_pos[g];
+        if (v < pos) { lo = g; vlo = v; } else { hi = g; vhi = v; }
+        bisect = !bisect;
+    }
+    return hi;
 }
 
 // which contig of the group holds group coordinate g (the last k with start[k] <= g; a position in the padding behind a contig belongs to it)

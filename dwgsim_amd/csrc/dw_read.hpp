@@ -127,9 +127,23 @@ DW_DEV ReadRes gen_read(const HapDev &h, int64_t l, int64_t start, int step, int
         }
         if (!esc) continue;
         // ---- an episode of the reference's per-cell logic, until the output stands at a word boundary again
+        // (episodes) the sixteen byte cells around the one in hand, fetched together: the per-cell logic below walks a handful of neighbouring cells, and a load per cell
+        // was a memory round trip per cell -- on the path of every block behind this one (dw_simulate.hip, "one look-back").  h.cells is 16-byte aligned (a contig starts at
+        // a multiple of GROUP_ALIGN cells), its buffer padded behind the last contig (CELL_PAD)
+        // (fetched ONCE, where the episode starts: sixteen cells in travel order from cell i -- an episode rarely leaves them, and then falls back to a load per cell)
+        const int32_t ck_base = (i < 0 || i >= li) ? 0 : fwd ? (i & ~3) : ((i | 3) - 15 < 0 ? 0 : (i | 3) - 15);      // 4-byte aligned, inside the buffer (padded behind, CELL_PAD)
+        const ViewQuad ckq = *reinterpret_cast<const ViewQuad *>(h.cells + ck_base);
+        const uint32_t ck0 = ckq.a, ck1 = ckq.b, ck2 = ckq.c, ck3 = ckq.d;
+        const uint8_t *const cellp = h.cells;
+        auto cell_at = [=](int32_t q) -> uint32_t {      // (captures by VALUE: a choice between references is a choice between addresses, and the four words would live in memory)
+            const uint32_t o = (uint32_t)(q - ck_base);
+            if (o >= 16u) return cellp[q];
+            const uint32_t w01 = (o & 4u) ? ck1 : ck0, w23 = (o & 4u) ? ck3 : ck2;
+            return (((o & 8u) ? w23 : w01) >> (8u * (o & 3u))) & 0xffu;
+        };
         for (;;) {
             if (i < 0 || i >= li) { k = -1; break; }                 // walked off the contig before the read was complete
-            const uint32_t c = h.cells[i], mt = c & TMASK;
+            const uint32_t c = cell_at(i), mt = c & TMASK;
             if (r.ext_coor < 0) {
                 if (mt != T_NONE && mt != T_SUB) { i += step; continue; }
                 r.ext_coor = i;
